@@ -1,0 +1,255 @@
+"""Pin the NumPy oracle against the reference's own known answers.
+
+The reference holds no stored numeric fixtures; these are the identities and
+analytic demos it ships.  CPU only.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle.ls_oracle import (EPS, LSOracle, hooke, isotropic_laminate_ceff,
+                              laminate_split, material_from_pair, pk1_laminate, pk1_voigt)
+
+SQRT_EPS = math.sqrt(EPS)  # check_tol default, F:23502-23520
+
+
+def sphere_phi(n, R=0.3, c=(0.5, 0.5, 0.5), sub=4):
+    """Sub-sampled volume fraction of a sphere in the unit cell (test geometry)."""
+    nx, ny, nz = n
+    s = (np.arange(sub) + 0.5) / sub
+    x = ((np.arange(nx)[:, None] + s[None, :]) / nx).reshape(-1)
+    y = ((np.arange(ny)[:, None] + s[None, :]) / ny).reshape(-1)
+    z = ((np.arange(nz)[:, None] + s[None, :]) / nz).reshape(-1)
+    d2 = ((x[:, None, None] - c[0]) ** 2 + (y[None, :, None] - c[1]) ** 2 + (z[None, None, :] - c[2]) ** 2)
+    inside = (d2 <= R * R).astype(np.float64)
+    return inside.reshape(nx, sub, ny, sub, nz, sub).mean(axis=(1, 3, 5))
+
+
+def sphere_normals(n, c=(0.5, 0.5, 0.5)):
+    nx, ny, nz = n
+    x = (np.arange(nx) + 0.5) / nx - c[0]
+    y = (np.arange(ny) + 0.5) / ny - c[1]
+    z = (np.arange(nz) + 0.5) / nz - c[2]
+    v = np.stack(np.broadcast_arrays(x[:, None, None], y[None, :, None], z[None, None, :])).astype(np.float64)
+    r = np.sqrt((v * v).sum(axis=0))
+    r[r == 0] = 1.0
+    return v / r
+
+
+@pytest.mark.parametrize("grid,dims", [
+    ((2, 1, 1), (1, 1, 1)),                # F:27261
+    ((41, 33, 11), (1, 1, 1)),             # F:27266
+    ((41, 33, 11), (41, 33, 11)),          # F:27271
+    ((42, 33, 11), (1.1, 10.4, 2.23)),     # F:27277
+    ((8, 6, 4), (1, 2, 3)),
+])
+def test_staggered_epsG0div_identity(grid, dims):
+    """'staggered epsG0div identity'  F:24129-24151 with C0 = (324.2, 1324.3) F:24007-24008."""
+    nx, ny, nz = grid
+    o = LSOracle(nx, ny, nz, *dims)
+    lam0, mu0 = 324.2, 1324.3
+    rng = np.random.default_rng(1)
+    tau = rng.standard_normal((6, nx, ny, nz))
+    Z = np.zeros(6)
+    e_org = o.eps_staggered(Z, tau[:3])
+    t = o.calc_stress_const(mu0, lam0, e_org)
+    f = o.div_staggered(t)
+    u = o.g0_staggered(mu0, lam0, f, 1.0)
+    e = o.eps_staggered(Z, u)
+    diff = np.abs(e - e_org).reshape(6, -1).max(axis=1)
+    # the reference checks norm_2(max) <= sqrt(eps) on N(0,1) fields
+    scale = max(1.0, np.abs(e_org).max())
+    assert np.linalg.norm(diff) <= SQRT_EPS * scale
+
+
+def test_isotropic_material_derivative():
+    """'isotropic material derivative'  F:24058-24083: dPK1 == PK1 by linearity."""
+    rng = np.random.default_rng(2)
+    e = rng.standard_normal((6, 5))
+    d = rng.standard_normal((6, 5))
+    lam, mu = 1234.3, 134.4
+    h = SQRT_EPS
+    fd = (hooke(e + h * d, mu, lam) - hooke(e - h * d, mu, lam)) / (2 * h)
+    assert np.abs(fd - hooke(d, mu, lam)).max() < 12 * math.sqrt(SQRT_EPS)
+
+
+def test_material_pairs_roundtrip():
+    """Material::calc_from_*  F:7376-7454: all ten pairs describe the same solid."""
+    ref = material_from_pair(E=100.0, nu=0.4)
+    pairs = [("K", "E"), ("K", "lambda"), ("K", "mu"), ("K", "nu"), ("E", "mu"), ("E", "nu"),
+             ("lambda", "mu"), ("lambda", "nu"), ("mu", "nu"), ("mu", "M")]
+    for a, b in pairs:
+        m = material_from_pair(**{a: ref[a], b: ref[b]})
+        for k in ref:
+            assert m[k] == pytest.approx(ref[k], rel=1e-12), (a, b, k)
+    with pytest.raises(RuntimeError):
+        material_from_pair(E=1.0)
+    with pytest.raises(RuntimeError):
+        material_from_pair(E=1.0, nu=0.3, mu=2.0)
+
+
+def test_homogeneous_medium_one_iteration():
+    """Known answer (iv): homogeneous medium => eps == E after the first pass, Ceff = C."""
+    m = material_from_pair(E=3.0, nu=0.25)
+    n = (6, 4, 8)
+    o = LSOracle(*n, mats=[(m["mu"], m["lambda"])], phis=[np.ones(n)], tol=1e-10)
+    E = np.array([1.0, 0.5, -0.2, 0.1, 0.3, -0.4])
+    assert o.run(E) is False
+    assert np.abs(o.eps - E[:, None, None, None]).max() < 1e-14
+    C = o.calc_effective_properties()
+    Cex = np.zeros((6, 6))
+    Cex[:3, :3] = m["lambda"]
+    Cex[np.arange(3), np.arange(3)] += 2 * m["mu"]
+    Cex[np.arange(3, 6), np.arange(3, 6)] = m["mu"]
+    assert np.abs(C - Cex).max() < 1e-13
+
+
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_three_layer_laminate_demo(mixing):
+    """demo/elasticity/laminate/project.xml:17-43 vs calc_isotropic_laminate F:26405-26446.
+
+    10x1x1 voxels, layers 0.2/0.3/0.5 along x with (E,nu) = (100,.4), (25,.25), (50,.3);
+    voxel-aligned interfaces => the FFT solution is exact for any tolerance.
+    """
+    mats = [material_from_pair(E=100, nu=0.4), material_from_pair(E=25, nu=0.25), material_from_pair(E=50, nu=0.3)]
+    n = (10, 1, 1)
+    phis = [np.zeros(n) for _ in mats]
+    phis[0][0:2] = 1
+    phis[1][2:5] = 1
+    phis[2][5:10] = 1
+    normals = np.zeros((3,) + n)
+    normals[0] = 1
+    o = LSOracle(*n, mats=[(m["mu"], m["lambda"]) for m in mats], phis=phis, normals=normals,
+                 mixing_rule=mixing, tol=1e-13, maxiter=2000)
+    C = o.calc_effective_properties()
+    Cex = isotropic_laminate_ceff([(0.2, mats[0]["mu"], mats[0]["lambda"]),
+                                   (0.3, mats[1]["mu"], mats[1]["lambda"]),
+                                   (0.5, mats[2]["mu"], mats[2]["lambda"])])
+    assert np.abs(C - Cex).max() / np.abs(Cex).max() < 1e-9
+
+
+def test_laminate_mixing_exact_for_subvoxel_interface():
+    """The laminate rule is exact when the interface cuts a voxel parallel to a face:
+    layers 0.25/0.75 on 10 voxels (voxel 2 is half/half) must reproduce the closed form,
+    the Voigt rule must not.  (Property behind LaminateMixedMaterialLaw F:13085.)"""
+    m1 = material_from_pair(E=100, nu=0.4)
+    m2 = material_from_pair(E=25, nu=0.25)
+    n = (10, 1, 1)
+    phi1 = np.zeros(n)
+    phi1[0:2] = 1
+    phi1[2] = 0.5
+    phis = [phi1, 1 - phi1]
+    normals = np.zeros((3,) + n)
+    normals[0] = 1
+    Cex = isotropic_laminate_ceff([(0.25, m1["mu"], m1["lambda"]), (0.75, m2["mu"], m2["lambda"])])
+    res = {}
+    for mixing in ("laminate", "voigt"):
+        o = LSOracle(*n, mats=[(m1["mu"], m1["lambda"]), (m2["mu"], m2["lambda"])], phis=phis,
+                     normals=normals, mixing_rule=mixing, tol=1e-13, maxiter=3000)
+        res[mixing] = o.calc_effective_properties()
+    assert np.abs(res["laminate"] - Cex).max() / np.abs(Cex).max() < 1e-8
+    assert np.abs(res["voigt"] - Cex).max() / np.abs(Cex).max() > 1e-3
+
+
+def test_ref_material_closed_form_matches_eigensolver():
+    """mu0 from the closed-form tangent spectrum == the per-voxel 6x6 eigensolve
+    the reference performs with LAPACK syev (F:12518-12527)."""
+    n = (6, 5, 4)
+    phi = sphere_phi(n, R=0.35)
+    mats = [(1.0 / 2.6, 0.5769230769), (10.0 / 2.4, 2.777777)]
+    o = LSOracle(*n, mats=mats, phis=[1 - phi, phi])
+    lo, hi = o.tangent_eig_minmax()
+    lo2, hi2 = math.inf, -math.inf
+    for w in np.unique(phi):
+        mu = (1 - w) * mats[0][0] + w * mats[1][0]
+        lam = (1 - w) * mats[0][1] + w * mats[1][1]
+        C = np.zeros((6, 6))
+        C[:3, :3] = lam
+        C[np.arange(6), np.arange(6)] += 2 * mu
+        e = np.linalg.eigvalsh(C)
+        lo2, hi2 = min(lo2, e.min()), max(hi2, e.max())
+    assert lo == pytest.approx(lo2, rel=1e-13)
+    assert hi == pytest.approx(hi2, rel=1e-13)
+
+
+def test_laminate_split_scalar_vs_vector_and_stationarity():
+    """laminate_split: (i) vectorised == per-voxel evaluation, (ii) the one Newton step
+    is exact for quadratic energies: traction continuity [sigma].n = 0 afterwards."""
+    rng = np.random.default_rng(5)
+    m = 64
+    F = rng.standard_normal((6, m))
+    nrm = rng.standard_normal((3, m))
+    nrm /= np.sqrt((nrm * nrm).sum(axis=0))
+    c1 = rng.uniform(0.05, 0.95, m)
+    c2 = 1 - c1
+    mat1, mat2 = (1.3, 0.7), (11.0, 4.0)
+    F1, F2 = laminate_split(F, nrm, c1, c2, mat1, mat2)
+    for v in range(0, m, 7):
+        a1, a2 = laminate_split([F[i][v] for i in range(6)], [nrm[i][v] for i in range(3)], c1[v], c2[v], mat1, mat2)
+        for i in range(6):
+            assert float(a1[i]) == F1[i][v] and float(a2[i]) == F2[i][v]
+    F1 = np.array(F1)
+    F2 = np.array(F2)
+    assert np.abs(c1 * F1 + c2 * F2 - F).max() < 1e-13          # mean strain preserved
+    ds = hooke(F1, *mat1) - hooke(F2, *mat2)
+    full = lambda s: np.array([[s[0], s[5], s[4]], [s[5], s[1], s[3]], [s[4], s[3], s[2]]])
+    t = np.einsum("ijv,jv->iv", full(ds), nrm)
+    assert np.abs(t).max() < 1e-11
+
+
+def test_pk1_laminate_pure_and_mixed_dispatch():
+    rng = np.random.default_rng(6)
+    n = (3, 2, 2)
+    e = rng.standard_normal((6,) + n)
+    phi = np.zeros(n)
+    phi[0] = 1.0
+    phi[1] = 0.3
+    mats = [(1.0, 2.0), (5.0, 3.0)]
+    nrm = np.zeros((3,) + n)
+    nrm[1] = 1
+    P = pk1_laminate(e, [phi, 1 - phi], mats, nrm)
+    assert np.array_equal(P[:, 0], hooke(e[:, 0], 1.0, 2.0, 1.0))
+    assert np.array_equal(P[:, 2], hooke(e[:, 2], 5.0, 3.0, 1.0))
+    # mixed voxels differ from the Voigt average unless the strain is laminate-compatible
+    Pv = pk1_voigt(e, [phi, 1 - phi], mats)
+    assert np.abs(P[:, 1] - Pv[:, 1]).max() > 1e-3
+    with pytest.raises(RuntimeError):
+        pk1_laminate(e, [phi * 0 + 0.2, phi * 0 + 0.3, phi * 0 + 0.5], mats + [(1.0, 1.0)], nrm)
+
+
+def test_error_estimator_and_stop_rule_two_phase():
+    """Iteration history properties of runBasic (F:21716-21805): first residual is 1
+    (zero start field, F:21379 + F:14612-14631), residuals recorded every iteration,
+    stop at rel <= tol."""
+    n = (8, 8, 8)
+    phi = sphere_phi(n)
+    m0 = material_from_pair(E=1.0, nu=0.3)
+    m1 = material_from_pair(E=10.0, nu=0.2)
+    o = LSOracle(*n, mats=[(m0["mu"], m0["lambda"]), (m1["mu"], m1["lambda"])], phis=[1 - phi, phi], tol=1e-8)
+    assert o.run([1, 0, 0, 0, 0, 0]) is False
+    assert o.residuals[0] == pytest.approx(1.0, abs=1e-15)
+    assert len(o.residuals) == o.iterations
+    assert o.residuals[-1] <= 1e-8 < o.residuals[-2]
+    assert np.abs(o.mean_strain() - np.array([1, 0, 0, 0, 0, 0.0])).max() < 1e-12
+    # Voigt/Reuss bounds on C11 (F:7463-7484 as inequalities)
+    s = o.mean_stress()
+    f = phi.mean()
+    M0, M1 = m0["lambda"] + 2 * m0["mu"], m1["lambda"] + 2 * m1["mu"]
+    assert 1 / ((1 - f) / M0 + f / M1) - 1e-9 <= s[0] <= (1 - f) * M0 + f * M1 + 1e-9
+
+
+def test_mixed_bc_projector_uniaxial_stress():
+    """setBCProjector / calcBCMean / applyBCProjector F:20599-20665, F:20242-20270:
+    prescribe eps11 and zero stress elsewhere on a homogeneous solid => uniaxial stress."""
+    m = material_from_pair(E=2.0, nu=0.3)
+    n = (4, 4, 4)
+    o = LSOracle(*n, mats=[(m["mu"], m["lambda"])], phis=[np.ones(n)], tol=1e-12, bc_tol=1e-10, maxiter=500)
+    P = np.zeros((6, 6))
+    P[0, 0] = 1.0
+    assert o.run([0.01, 0, 0, 0, 0, 0], S0=np.zeros(6), P=P) is False
+    s = o.mean_stress()
+    e = o.mean_strain()
+    assert s[0] == pytest.approx(2.0 * 0.01, rel=1e-8)
+    assert np.abs(s[1:]).max() < 1e-10
+    assert e[1] == pytest.approx(-0.3 * 0.01, rel=1e-8)
