@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the Lippmann-Schwinger basic-scheme pass on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--n 256] [--mixing voigt|laminate]
+
+A "step" is one LS iteration (one basicScheme pass, F:20558-20578) on a synthetic fibre
+RVE resident in HBM.  With N > 1 (torchrun, one rank per GPU) every rank solves its own
+load case of the same RVE -- the six load cases of calc_effective_properties
+(F:26030-26114) are independent, so this shards without any data-path collective
+("scaling": "weak"); the value is the aggregate over ranks.
+Rank 0 prints one JSON line (metric of BASELINE.json: LS iterations/s, plus the HBM
+roofline of the dominant kernel and the CPU baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(n, nphases, mixing):
+    """Algorithmic HBM bytes per launch of each kernel (DESIGN.md / SURVEY 8d): inputs read
+    once, outputs written once, float64."""
+    nx, ny, nz = n
+    N = nx * ny * nz
+    nzc = nz // 2 + 1
+    F = nx * ny * nzc  # complex frequencies (= padded pairs)
+    stress = (6 + 1 + 6) * 8 * N  # 6 eps + phi (second phase = 1 - phi) in, 6 tau out
+    if nphases != 2:
+        stress = (12 + nphases) * 8 * N
+    fft_pass = 3 * 2 * 16 * F     # 3 components, read + write, complex128
+    return {
+        "stress": stress,
+        "div": 9 * 8 * N,
+        "r2c_z": fft_pass, "c2c_y_fwd": fft_pass, "c2c_x_fwd": fft_pass,
+        "g0": 96 * F,
+        "c2c_x_inv": fft_pass, "c2c_y_inv": fft_pass, "c2r_z": fft_pass,
+        "eps_norm": 9 * 8 * N,
+    }
+
+
+A_MIN_BYTES_PER_VOXEL = 392   # maximum legal fusion
+A_STAGE_BYTES_PER_VOXEL = 632
+
+
+def cpu_baseline(n, mixing, budget_s=20.0):
+    """Oracle (NumPy restatement of the reference pass structure) timed on the host cores,
+    on a bounded sample: passes of the same grid until ~budget_s is used (at least one)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.ls_oracle import LSOracle
+    from fibergen_amd.rve import synthetic_fiber_rve
+    from helpers import INCLUSION, MATRIX, lame
+    phi, normals = synthetic_fiber_rve(n, K=max(1, 40 * (n[0] // 128) ** 3) if n[0] >= 128 else 5,
+                                       R=0.05 * 128 / max(n[0], 128), L=0.4 * 128 / max(n[0], 128), seed=0)
+    o = LSOracle(*n, mats=[lame(**MATRIX), lame(**INCLUSION)], phis=[1 - phi, phi], normals=normals,
+                 mixing_rule=mixing)
+    o.calc_ref_material()
+    E = np.array([1.0, 0, 0, 0, 0, 0])
+    eps = np.zeros((6,) + tuple(n))
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        eps = o.basic_scheme(E, eps)
+        o.component_norm(eps)
+        it += 1
+        if time.perf_counter() - t0 > budget_s or it >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": it / dt, "unit": "it/s", "cores": 1, "kind": "port",
+            "sample": "%d passes of the same %dx%dx%d RVE, NumPy oracle (pocketfft rfftn), 1 thread" % (it, *n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=256, help="grid size per axis (128, 256, 512)")
+    ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # torch is plumbing for the multi-rank barrier / max-reduction only.  It must be imported
+    # BEFORE libfibergen_amd.so is loaded so that both share one HIP runtime (same soname).
+    torch = None
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from fibergen_amd import LSSolver
+    from fibergen_amd.rve import synthetic_fiber_rve
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import INCLUSION, MATRIX, lame
+
+    n = (args.n, args.n, args.n)
+    scale = max(args.n, 128) / 128.0
+    K = int(round(40 * scale ** 3)) if args.n >= 128 else 5
+    phi, normals = synthetic_fiber_rve(n, K=K, R=0.05 / scale, L=0.4 / scale, seed=0,
+                                       with_normals=(args.mixing == "laminate"))
+    s = LSSolver(*n, device=local_rank)
+    s.set_num_phases(2)
+    mats = [lame(**MATRIX), lame(**INCLUSION)]
+    s.set_phase(0, mats[0][0], mats[0][1], 1.0 - phi)
+    s.set_phase(1, mats[1][0], mats[1][1], phi)
+    if normals is not None:
+        s.set_normals(normals)
+    s.set_options(mixing_rule=args.mixing)
+    vf = float(phi.mean())
+    del phi, normals
+    s.calc_ref_material()
+    # each rank its own load case (calc_effective_properties' unit strains)
+    E = np.zeros(6)
+    E[rank % 6] = 1.0
+
+    def sync():
+        s.synchronize()  # the solver's own HIP stream carries all the work
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    s.iterate(E, args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    s.iterate(E, args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # per-kernel durations, measured live with HIP events on the solver's stream
+        s.enable_stage_timing(True)
+        s.iterate(E, min(args.steps, 20))
+        times, cnt = s.stage_times()
+        s.enable_stage_timing(False)
+        ab = algorithmic_bytes(n, 2, args.mixing)
+        kern = {}
+        for k, ms in times.items():
+            avg = ms / max(cnt, 1)
+            kern[k] = {"avg_ms": avg, "alg_GB": ab[k] / 1e9, "GBps": (ab[k] / 1e9) / (avg / 1e3) if avg > 0 else 0.0}
+        dom = max(kern, key=lambda k: kern[k]["avg_ms"])
+        N = n[0] * n[1] * n[2]
+        roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                "alg_bytes_per_launch": ab[dom], "avg_launch_ms": kern[dom]["avg_ms"]}
+        out = {
+            "metric": "LS iterations/sec (basic scheme, staggered grid, linear elastic)",
+            "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d^3 two-phase fibre RVE (K=%d capsules, vf=%.3f), contrast 10, mixing=%s, "
+                                   "one load case per GPU" % (args.n, K, vf, args.mixing),
+                       "grid": list(n), "mixing_rule": args.mixing, "parallelism": "loadcase x%d" % world},
+            "roofline": roof,
+            "loop_GBps_Amin": A_MIN_BYTES_PER_VOXEL * N * (args.steps / dt) / 1e9,
+            "loop_GBps_Astage": A_STAGE_BYTES_PER_VOXEL * N * (args.steps / dt) / 1e9,
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            s.close()
+            out["cpu_baseline"] = cpu_baseline(n, args.mixing, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

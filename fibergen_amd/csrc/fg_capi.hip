@@ -1,0 +1,236 @@
+// extern "C" boundary of libfibergen_amd.so: converts exceptions to return codes.
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "../../include/fibergen_amd.h"
+#include "fg_hip_util.h"
+#include "fg_solver.h"
+
+struct fg_solver {
+  fg::Solver* impl;
+  std::string error;
+};
+
+namespace {
+thread_local std::string g_create_error;
+
+template <class F>
+int guarded(fg_solver* s, F&& f) {
+  if (!s || !s->impl) return FG_ERROR;
+  try {
+    f(*s->impl);
+    return FG_OK;
+  } catch (const std::exception& e) {
+    s->error = e.what();
+  } catch (...) {
+    s->error = "unknown error";
+  }
+  return FG_ERROR;
+}
+}  // namespace
+
+extern "C" {
+
+int fg_abi_version(void) { return FG_ABI_VERSION; }
+
+const char* fg_last_error(const fg_solver* s) { return s ? s->error.c_str() : g_create_error.c_str(); }
+
+fg_solver* fg_create(int nx, int ny, int nz, double dx, double dy, double dz, int device) {
+  try {
+    fg_solver* s = new fg_solver();
+    try {
+      s->impl = new fg::Solver(nx, ny, nz, dx, dy, dz, device);
+    } catch (...) {
+      delete s;
+      throw;
+    }
+    return s;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+  } catch (...) {
+    g_create_error = "unknown error";
+  }
+  return nullptr;
+}
+
+void fg_destroy(fg_solver* s) {
+  if (!s) return;
+  try {
+    delete s->impl;
+  } catch (...) {
+  }
+  delete s;
+}
+
+int fg_set_num_phases(fg_solver* s, int n) {
+  return guarded(s, [&](fg::Solver& v) { v.set_num_phases(n); });
+}
+
+int fg_set_phase(fg_solver* s, int p, double mu, double lambda, const double* phi) {
+  return guarded(s, [&](fg::Solver& v) {
+    v.set_phase_material(p, mu, lambda);
+    if (phi) v.set_phase_field(p, phi);
+  });
+}
+
+int fg_set_normals(fg_solver* s, const double* normals) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!normals) throw std::runtime_error("normals pointer is NULL");
+    v.set_normals(normals);
+  });
+}
+
+int fg_set_option_d(fg_solver* s, const char* key, double value) {
+  return guarded(s, [&](fg::Solver& v) {
+    const std::string k = key ? key : "";
+    fg::SolverOptions& o = v.options();
+    if (k == "tol") o.tol = value;
+    else if (k == "abs_tol") o.abs_tol = value;
+    else if (k == "bc_tol") o.bc_tol = value;
+    else if (k == "ref_scale") o.ref_scale = value;
+    else if (k == "bc_relax") o.bc_relax = value;
+    else if (k == "mu_0") o.mu_0 = value;
+    else if (k == "lambda_0") o.lambda_0 = value;
+    else if (k == "eps_g") o.eps_g = value;
+    else if (k == "eps_a") o.eps_a = value;
+    else throw std::runtime_error("unknown option '" + k + "'");
+  });
+}
+
+int fg_set_option_i(fg_solver* s, const char* key, long value) {
+  return guarded(s, [&](fg::Solver& v) {
+    const std::string k = key ? key : "";
+    fg::SolverOptions& o = v.options();
+    if (k == "maxiter") o.maxiter = value;
+    else if (k == "mixing_rule") {
+      if (value != FG_MIXING_VOIGT && value != FG_MIXING_LAMINATE) throw std::runtime_error("Unknown mixing rule");
+      o.mixing = (int)value;
+    } else if (k == "update_ref") o.update_ref = value != 0;
+    else throw std::runtime_error("unknown option '" + k + "'");
+  });
+}
+
+int fg_set_bc_projector(fg_solver* s, const double* P36) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!P36) throw std::runtime_error("projector pointer is NULL");
+    v.set_bc_projector(P36);
+  });
+}
+
+int fg_set_convergence_callback(fg_solver* s, fg_callback cb, void* user) {
+  return guarded(s, [&](fg::Solver& v) { v.set_callback(cb, user); });
+}
+
+int fg_cancel(fg_solver* s) {
+  return guarded(s, [&](fg::Solver& v) { v.cancel(); });
+}
+
+int fg_run_load_case(fg_solver* s, const double* E6, const double* S6, int* failed) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!E6) throw std::runtime_error("strain pointer is NULL");
+    const bool f = v.run(E6, S6);
+    if (failed) *failed = f ? 1 : 0;
+  });
+}
+
+int fg_iterate(fg_solver* s, const double* E6, int n) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!E6) throw std::runtime_error("strain pointer is NULL");
+    v.iterate(E6, n);
+  });
+}
+
+int fg_time_iterations(fg_solver* s, const double* E6, int n, double* elapsed_ms) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!E6) throw std::runtime_error("strain pointer is NULL");
+    hipEvent_t a, b;
+    FG_HIP_CHECK(hipEventCreate(&a));
+    FG_HIP_CHECK(hipEventCreate(&b));
+    FG_HIP_CHECK(hipEventRecord(a, v.stream()));
+    v.iterate(E6, n);
+    FG_HIP_CHECK(hipEventRecord(b, v.stream()));
+    FG_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    FG_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (elapsed_ms) *elapsed_ms = ms;
+  });
+}
+
+long fg_get_iterations(const fg_solver* s) { return (s && s->impl) ? s->impl->iterations() : 0; }
+
+int fg_get_residuals(const fg_solver* s, double* out, int capacity) {
+  if (!s || !s->impl) return 0;
+  const std::vector<double>& r = s->impl->residuals();
+  const int n = (int)r.size();
+  if (out)
+    for (int i = 0; i < n && i < capacity; ++i) out[i] = r[i];
+  return n;
+}
+
+double fg_get_solve_time(const fg_solver* s) { return (s && s->impl) ? s->impl->solve_time() : 0.0; }
+
+int fg_mean_stress(fg_solver* s, double* out6) {
+  return guarded(s, [&](fg::Solver& v) { v.mean_stress(out6); });
+}
+int fg_mean_strain(fg_solver* s, double* out6) {
+  return guarded(s, [&](fg::Solver& v) { v.mean_strain(out6); });
+}
+int fg_volume_fraction(fg_solver* s, int p, double* out) {
+  return guarded(s, [&](fg::Solver& v) { *out = v.volume_fraction(p); });
+}
+
+int fg_calc_ref_material(fg_solver* s) {
+  return guarded(s, [&](fg::Solver& v) { v.calc_ref_material(); });
+}
+int fg_get_ref_material(const fg_solver* s, double* mu_0, double* lambda_0) {
+  if (!s || !s->impl) return FG_ERROR;
+  if (mu_0) *mu_0 = s->impl->mu_0();
+  if (lambda_0) *lambda_0 = s->impl->lambda_0();
+  return FG_OK;
+}
+
+int fg_field_components(const fg_solver* s, const char* name) {
+  if (!s || !s->impl || !name) return 0;
+  return s->impl->field_components(name);
+}
+int fg_get_field(fg_solver* s, const char* name, double* out) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!name || !out) throw std::runtime_error("NULL argument");
+    v.get_field(name, out);
+  });
+}
+int fg_set_field(fg_solver* s, const char* name, const double* in) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!name || !in) throw std::runtime_error("NULL argument");
+    v.set_field(name, in);
+  });
+}
+
+void* fg_device_pointer(fg_solver* s, const char* name, int comp) {
+  if (!s || !s->impl || !name) return nullptr;
+  return s->impl->device_component(name, comp);
+}
+void* fg_get_stream(fg_solver* s) { return (s && s->impl) ? (void*)s->impl->stream() : nullptr; }
+int fg_synchronize(fg_solver* s) {
+  return guarded(s, [&](fg::Solver& v) { FG_HIP_CHECK(hipStreamSynchronize(v.stream())); });
+}
+
+int fg_run_stage(fg_solver* s, int stage, const double* E6) {
+  return guarded(s, [&](fg::Solver& v) { v.run_stage(stage, E6); });
+}
+int fg_enable_stage_timing(fg_solver* s, int enable) {
+  return guarded(s, [&](fg::Solver& v) { v.enable_stage_timing(enable != 0); });
+}
+int fg_get_stage_times(const fg_solver* s, double* ms, long* count) {
+  if (!s || !s->impl) return FG_ERROR;
+  const fg::StageTimes t = s->impl->stage_times();
+  if (ms)
+    for (int i = 0; i < fg::kNumTimedKernels; ++i) ms[i] = t.ms[i];
+  if (count) *count = t.count;
+  return FG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// Shared host/device helpers for the fibergen_amd kernels.
+//
+// Everything in this header is plain arithmetic that must behave identically
+// on the device (hipcc, gfx950) and in the host-side emulation used by the
+// CPU test-suite (g++, -DFG_HOST_EMULATION).  All floating point is IEEE
+// float64 and the library is compiled with -ffp-contract=off so that the
+// element-wise stages reproduce the reference's operation order bit for bit.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#if defined(__HIPCC__) && !defined(FG_HOST_EMULATION)
+#include <hip/hip_runtime.h>
+#define FG_HD __host__ __device__ __forceinline__
+#define FG_D __device__ __forceinline__
+#else
+#define FG_HD inline
+#define FG_D inline
+#endif
+
+namespace fg {
+
+struct alignas(16) cplx {
+  double re, im;
+};
+
+FG_HD cplx cmake(double re, double im) { cplx c; c.re = re; c.im = im; return c; }
+FG_HD cplx cadd(cplx a, cplx b) { return cmake(a.re + b.re, a.im + b.im); }
+FG_HD cplx csub(cplx a, cplx b) { return cmake(a.re - b.re, a.im - b.im); }
+// (a+ib)(c+id) = (ac - bd) + i(ad + bc): the finite-operand result of
+// std::complex<double>::operator* (libstdc++ __muldc3) used by the reference.
+FG_HD cplx cmul(cplx a, cplx b) { return cmake(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+FG_HD cplx cscale(double s, cplx a) { return cmake(s * a.re, s * a.im); }
+FG_HD cplx cconj(cplx a) { return cmake(a.re, -a.im); }
+// multiply by -i (forward) : (re,im) -> (im,-re) ; by +i : (re,im) -> (-im, re)
+FG_HD cplx cmul_mi(cplx a) { return cmake(a.im, -a.re); }
+FG_HD cplx cmul_pi(cplx a) { return cmake(-a.im, a.re); }
+
+// Geometry of one padded field component (reference layout):
+// real  [nx][ny][nzp], nzp = 2*(nz/2+1), z fastest; complex view [nx][ny][nzc].
+struct Grid {
+  int nx, ny, nz;
+  int nzc;      // nz/2+1
+  int nzp;      // 2*nzc
+  long nyzp;    // ny*nzp
+  long n;       // nx*ny*nzp padded reals per component
+  long nxyz;    // nx*ny*nz
+  double dx, dy, dz;
+};
+
+FG_HD Grid make_grid(int nx, int ny, int nz, double dx, double dy, double dz) {
+  Grid g;
+  g.nx = nx; g.ny = ny; g.nz = nz;
+  g.nzc = nz / 2 + 1;
+  g.nzp = 2 * g.nzc;
+  g.nyzp = (long)ny * g.nzp;
+  g.n = (long)nx * g.nyzp;
+  g.nxyz = (long)nx * ny * nz;
+  g.dx = dx; g.dy = dy; g.dz = dz;
+  return g;
+}
+
+}  // namespace fg

@@ -1,0 +1,49 @@
+// 3-D real-to-complex / complex-to-real FFT plan on one MI355X (host interface).
+//
+// Same contract as the reference's FFT3<double> (F:7203-7245, FFTW r2c/c2r):
+// in place on a padded component [nx][ny][nzp] <-> [nx][ny][nzc] complex,
+// unnormalised, forward e^{-i}; a scale factor can be folded into the last
+// forward pass (the reference multiplies by 1/N in a separate sweep, F:18501-18506).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "fg_common.h"
+
+namespace fg {
+
+class Fft3 {
+ public:
+  Fft3(const Grid& g, hipStream_t stream);
+  ~Fft3();
+  Fft3(const Fft3&) = delete;
+  Fft3& operator=(const Fft3&) = delete;
+
+  // data: ncomp components, comp_stride doubles apart, each g.n doubles.
+  void forward(double* data, int ncomp, long comp_stride, double scale);
+  void inverse(double* data, int ncomp, long comp_stride);
+
+  // single-axis entry points (used by the slab-decomposed driver and the stage tests)
+  void r2c_z(double* data, int ncomp, long comp_stride);
+  void c2c_y(double* data, int ncomp, long comp_stride, int dir, double scale);
+  void c2c_x(double* data, int ncomp, long comp_stride, int dir, double scale);
+  void c2r_z(double* data, int ncomp, long comp_stride);
+  void scale(double* data, int ncomp, long comp_stride, double scale);
+
+  bool fast_x() const { return fast_[0]; }
+  bool fast_y() const { return fast_[1]; }
+  bool fast_z() const { return fast_[2]; }
+  const cplx* x_twiddles() const { return tw_[0]; }
+
+ private:
+  void strided(double* data, int ncomp, long comp_stride, int axis, int dir, double scale);
+  Grid g_;
+  hipStream_t stream_;
+  bool fast_[3];
+  cplx* tw_[3];      // per-axis pass twiddles (fast path) ; z: for M = nz/2
+  cplx* wz_;         // w^k = e^{-2 pi i k/nz}, k = 0..nz/2   (fast z path)
+  cplx* wgen_[3];    // e^{-2 pi i k/n}, k = 0..n-1           (generic path)
+  double* scratch_;  // one padded component (generic path)
+};
+
+}  // namespace fg

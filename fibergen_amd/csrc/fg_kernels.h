@@ -1,0 +1,46 @@
+// Host-callable launchers of the streaming kernels (fg_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "fg_stage_math.h"
+
+namespace fg {
+
+template <int N>
+struct FieldPtrs {
+  double* p[N];
+};
+
+struct Vec6 {
+  double v[6];
+};
+
+// Separable factors of the staggered Green operator (F:19856-19876), device arrays:
+// kpm[a][m] = sin(xi)/h, kp[a][m] = kpm e^{i xi}; the z tables hold nzc entries.
+struct G0Tables {
+  const double* kpm[3];
+  const cplx* kp[3];
+};
+
+constexpr int kMaxReduceBlocks = 4096;  // partial-sum rows of the two-stage reductions
+
+int reduce_blocks(const Grid& g);
+
+void launch_stress(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps, const FieldPtrs<kMaxPhases>& phi,
+                   const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, int* error_flag, hipStream_t s);
+void launch_stress_mean(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
+                        const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& normals, double* partial, double* out6,
+                        int* error_flag, hipStream_t s);
+void launch_stress_const(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<6>& eps, const FieldPtrs<6>& tau,
+                         hipStream_t s);
+void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, hipStream_t s);
+void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, hipStream_t s);
+void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps, const Vec6& E, const Vec6& R,
+                     bool add_R, double* partial, double* sumsq6, hipStream_t s);
+void launch_sum6(const Grid& g, const FieldPtrs<6>& x, bool square, double* partial, double* out6, hipStream_t s);
+void launch_sum1(const Grid& g, const double* x, double* partial, double* out1, hipStream_t s);
+void launch_tangent_minmax(const Grid& g, const PhaseTable& pt, int mixing, const FieldPtrs<kMaxPhases>& phi,
+                           double* partial, double* out2, int* error_flag, hipStream_t s);
+
+}  // namespace fg

@@ -1,0 +1,455 @@
+// Streaming kernels of the Lippmann-Schwinger iteration for gfx950.
+//
+// All of them are HBM-bound float64 sweeps over SoA components laid out like the
+// reference's TensorField (F:9584-10282): [nx][ny][nzp], z fastest, nzp = 2*(nz/2+1).
+// Threads own one double2 (two z-neighbouring voxels) => 16-byte coalesced accesses;
+// the z padding pair is skipped.  Reductions are two-stage with a fixed tree, so
+// results are bitwise reproducible from run to run.
+#include "fg_kernels.h"
+
+#include "fg_hip_util.h"
+
+namespace fg {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double2 ld2(const double* p, long i) { return *reinterpret_cast<const double2*>(p + i); }
+__device__ __forceinline__ void st2(double* p, long i, double2 v) { *reinterpret_cast<double2*>(p + i) = v; }
+
+// Decompose a pair index into (row, k): rows are (i,j) lines of nzc pairs.
+struct PairPos {
+  long row;   // i*ny + j
+  int i, j, k;
+  long off;   // element offset of (i,j,k)
+};
+
+__device__ __forceinline__ PairPos pair_pos(long pidx, const Grid& g) {
+  PairPos p;
+  p.row = pidx / g.nzc;
+  p.k = 2 * (int)(pidx - p.row * g.nzc);
+  p.i = (int)(p.row / g.ny);
+  p.j = (int)(p.row - (long)p.i * g.ny);
+  p.off = p.row * g.nzp + p.k;
+  return p;
+}
+
+// Deterministic block reduction of NV values per thread: wave shuffle tree, then
+// LDS across the 4 waves, lane 0 of wave 0 holds the result.
+template <int NV, class Op>
+__device__ __forceinline__ void block_reduce(double* v, double* smem, Op op) {
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v[q] = op(v[q], __shfl_down(v[q], s, 64));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) smem[wave * NV + q] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      double a = smem[q];
+      for (int w = 1; w < nw; ++w) a = op(a, smem[w * NV + q]);
+      v[q] = a;
+    }
+  }
+}
+
+struct OpSum { __device__ double operator()(double a, double b) const { return a + b; } };
+struct OpMin { __device__ double operator()(double a, double b) const { return a < b ? a : b; } };
+struct OpMax { __device__ double operator()(double a, double b) const { return a > b ? a : b; } };
+
+// ----------------------------------------------------------------------------- stress
+// calcStress  F:18134-18184.  REDUCE = false: tau <- P(eps) - C0:eps written out.
+// REDUCE = true: per-block partial sums of P (meanPK1  F:12312-12351, alpha already /N).
+// MIX / NPH are compile-time so the Voigt two-phase sweep keeps a small register footprint.
+template <bool REDUCE, int MIX, int NPH>
+__global__ __launch_bounds__(kBlock) void k_stress(Grid g, StressParams sp, FieldPtrs<6> eps, FieldPtrs<kMaxPhases> phi,
+                                                   FieldPtrs<3> normals, FieldPtrs<6> tau, double* partial,
+                                                   int* error_flag) {
+  __shared__ double smem[4 * 6];
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
+    const PairPos p = pair_pos(pidx, g);
+    if (p.k >= g.nz) continue;  // padding pair
+    const bool second = p.k + 1 < g.nz;
+    double2 e[6], f[NPH], nn[3];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) e[c] = ld2(eps.p[c], p.off);
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) f[q] = q < sp.pt.n ? ld2(phi.p[q], p.off) : make_double2(0.0, 0.0);
+    if (MIX == kMixLaminate) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nn[c] = ld2(normals.p[c], p.off);
+    } else {
+      nn[0] = nn[1] = nn[2] = make_double2(0.0, 0.0);
+    }
+    double F[6], ph[NPH], nv[3], P0[6], P1[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) F[c] = e[c].x;
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) ph[q] = f[q].x;
+    nv[0] = nn[0].x; nv[1] = nn[1].x; nv[2] = nn[2].x;
+    int err = stress_voxel<NPH>(F, ph, nv, sp, P0);
+    if (second) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) F[c] = e[c].y;
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) ph[q] = f[q].y;
+      nv[0] = nn[0].y; nv[1] = nn[1].y; nv[2] = nn[2].y;
+      err |= stress_voxel<NPH>(F, ph, nv, sp, P1);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) P1[c] = 0.0;
+    }
+    if (err) atomicOr(error_flag, 1);
+    if (REDUCE) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] += P0[c] + P1[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) st2(tau.p[c], p.off, make_double2(P0[c], P1[c]));
+    }
+  }
+  if (REDUCE) {
+    block_reduce<6>(acc, smem, OpSum());
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- divergence
+// divOperatorStaggered  F:18853-18908:
+//  f0 = D-x t0 + D+y t5 + D+z t4 ; f1 = D+x t5 + D-y t1 + D+z t3 ; f2 = D+x t4 + D+y t3 + D-z t2
+__global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtrs<3> f) {
+  const double hx = g.nx / g.dx, hy = g.ny / g.dy, hz = g.nz / g.dz;
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
+    const PairPos p = pair_pos(pidx, g);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    // periodic neighbour offsets (F:14867-14891)
+    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+    const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+    const long rowoff = p.off - p.k;
+    const int kb = p.k == 0 ? g.nz - 1 : p.k - 1;               // z-1 of the first voxel
+    const int kf2 = (p.k + 2 >= g.nz) ? p.k + 2 - g.nz : p.k + 2;  // z+1 of the second voxel
+
+    const double2 t0 = ld2(t.p[0], p.off), t1 = ld2(t.p[1], p.off), t2 = ld2(t.p[2], p.off);
+    const double2 t3 = ld2(t.p[3], p.off), t4 = ld2(t.p[4], p.off), t5 = ld2(t.p[5], p.off);
+    const double2 t0xb = ld2(t.p[0], p.off + xb);
+    const double2 t5yf = ld2(t.p[5], p.off + yf);
+    const double2 t5xf = ld2(t.p[5], p.off + xf);
+    const double2 t1yb = ld2(t.p[1], p.off + yb);
+    const double2 t4xf = ld2(t.p[4], p.off + xf);
+    const double2 t3yf = ld2(t.p[3], p.off + yf);
+    const double t4zf2 = t.p[4][rowoff + kf2];
+    const double t3zf2 = t.p[3][rowoff + kf2];
+    const double t2zb = t.p[2][rowoff + kb];
+    // z+1 of the first voxel is the second voxel, or (odd nz, last pair) wraps to k = 0
+    const double t4zf1 = second ? t4.y : t.p[4][rowoff];
+    const double t3zf1 = second ? t3.y : t.p[3][rowoff];
+
+    double2 f0, f1, f2;
+    f0.x = (t0.x - t0xb.x) * hx + (t5yf.x - t5.x) * hy + (t4zf1 - t4.x) * hz;
+    f1.x = (t5xf.x - t5.x) * hx + (t1.x - t1yb.x) * hy + (t3zf1 - t3.x) * hz;
+    f2.x = (t4xf.x - t4.x) * hx + (t3yf.x - t3.x) * hy + (t2.x - t2zb) * hz;
+    f0.y = (t0.y - t0xb.y) * hx + (t5yf.y - t5.y) * hy + (t4zf2 - t4.y) * hz;
+    f1.y = (t5xf.y - t5.y) * hx + (t1.y - t1yb.y) * hy + (t3zf2 - t3.y) * hz;
+    f2.y = (t4xf.y - t4.y) * hx + (t3yf.y - t3.y) * hy + (t2.y - t2.x) * hz;
+    st2(f.p[0], p.off, f0);
+    st2(f.p[1], p.off, f1);
+    st2(f.p[2], p.off, f2);
+  }
+}
+
+// ----------------------------------------------------------------------------- Green operator
+// G0OperatorFourierStaggeredGeneral  F:19834-19927, in place on 3 complex components.
+__global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables tb, double c10, double c20) {
+  const long nfreq = (long)g.nx * g.ny * g.nzc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < nfreq; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / g.nzc;
+    const int kk = (int)(idx - row * g.nzc);
+    const int ii = (int)(row / g.ny);
+    const int jj = (int)(row - (long)ii * g.ny);
+    cplx* c0 = reinterpret_cast<cplx*>(fh.p[0]);
+    cplx* c1 = reinterpret_cast<cplx*>(fh.p[1]);
+    cplx* c2 = reinterpret_cast<cplx*>(fh.p[2]);
+    cplx e0, e1, e2;
+    if (idx == 0) {
+      e0 = e1 = e2 = cmake(0.0, 0.0);  // zero frequency  F:19924-19926
+    } else {
+      g0_point(c0[idx], c1[idx], c2[idx], tb.kpm[0][ii], tb.kpm[1][jj], tb.kpm[2][kk], tb.kp[0][ii], tb.kp[1][jj],
+               tb.kp[2][kk], c10, c20, &e0, &e1, &e2);
+    }
+    c0[idx] = e0;
+    c1[idx] = e1;
+    c2[idx] = e2;
+  }
+}
+
+// ----------------------------------------------------------------------------- strain + norm
+// epsOperatorStaggered  F:18614-18692, followed by eps += R (applyBCProjector  F:20263-20270)
+// and the per-component sums of squares of component_norm (F:10088-10138) fused in.
+__global__ __launch_bounds__(kBlock) void k_eps_norm(Grid g, FieldPtrs<3> u, FieldPtrs<6> eps, Vec6 E, Vec6 R, int add_R,
+                                                     double* partial) {
+  __shared__ double smem[4 * 6];
+  const double hx = g.nx / g.dx, hy = g.ny / g.dy, hz = g.nz / g.dz;
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
+    const PairPos p = pair_pos(pidx, g);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+    const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+    const long rowoff = p.off - p.k;
+    const int kb = p.k == 0 ? g.nz - 1 : p.k - 1;
+    const int kf2 = (p.k + 2 >= g.nz) ? p.k + 2 - g.nz : p.k + 2;
+
+    const double2 u0 = ld2(u.p[0], p.off), u1 = ld2(u.p[1], p.off), u2 = ld2(u.p[2], p.off);
+    const double2 u0xf = ld2(u.p[0], p.off + xf), u1xb = ld2(u.p[1], p.off + xb), u2xb = ld2(u.p[2], p.off + xb);
+    const double2 u0yb = ld2(u.p[0], p.off + yb), u1yf = ld2(u.p[1], p.off + yf), u2yb = ld2(u.p[2], p.off + yb);
+    const double u0zb = u.p[0][rowoff + kb], u1zb = u.p[1][rowoff + kb];
+    const double u2zf2 = u.p[2][rowoff + kf2];
+    const double u2zf1 = second ? u2.y : u.p[2][rowoff];
+
+    double2 e[6];
+    e[3].x = E.v[3] + 0.5 * ((u2.x - u2yb.x) * hy + (u1.x - u1zb) * hz);
+    e[4].x = E.v[4] + 0.5 * ((u2.x - u2xb.x) * hx + (u0.x - u0zb) * hz);
+    e[5].x = E.v[5] + 0.5 * ((u1.x - u1xb.x) * hx + (u0.x - u0yb.x) * hy);
+    e[0].x = E.v[0] + (u0xf.x - u0.x) * hx;
+    e[1].x = E.v[1] + (u1yf.x - u1.x) * hy;
+    e[2].x = E.v[2] + (u2zf1 - u2.x) * hz;
+    e[3].y = E.v[3] + 0.5 * ((u2.y - u2yb.y) * hy + (u1.y - u1.x) * hz);
+    e[4].y = E.v[4] + 0.5 * ((u2.y - u2xb.y) * hx + (u0.y - u0.x) * hz);
+    e[5].y = E.v[5] + 0.5 * ((u1.y - u1xb.y) * hx + (u0.y - u0yb.y) * hy);
+    e[0].y = E.v[0] + (u0xf.y - u0.y) * hx;
+    e[1].y = E.v[1] + (u1yf.y - u1.y) * hy;
+    e[2].y = E.v[2] + (u2zf2 - u2.y) * hz;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      if (add_R) {
+        e[c].x += R.v[c];
+        e[c].y += R.v[c];
+      }
+      if (!second) e[c].y = 0.0;
+      acc[c] += e[c].x * e[c].x + e[c].y * e[c].y;
+      st2(eps.p[c], p.off, e[c]);
+    }
+  }
+  block_reduce<6>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+  }
+}
+
+// ----------------------------------------------------------------------------- plain reductions
+// Per-component sums (TensorField::average F:10171-10210) or sums of squares over the
+// valid voxels of NC components.
+template <int NC, bool SQUARE>
+__global__ __launch_bounds__(kBlock) void k_sum(Grid g, FieldPtrs<NC> x, double* partial) {
+  __shared__ double smem[4 * NC];
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
+    const PairPos p = pair_pos(pidx, g);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      double2 v = ld2(x.p[c], p.off);
+      if (!second) v.y = 0.0;
+      acc[c] += SQUARE ? (v.x * v.x + v.y * v.y) : (v.x + v.y);
+    }
+  }
+  block_reduce<NC>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) partial[(long)blockIdx.x * NC + c] = acc[c];
+  }
+}
+
+// min / max of the tangent spectrum over all voxels (reference-material scan)
+__global__ __launch_bounds__(kBlock) void k_tangent_minmax(Grid g, PhaseTable pt, int mixing, FieldPtrs<kMaxPhases> phi,
+                                                           double* partial, int* error_flag) {
+  __shared__ double smem[4 * 2];
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[2] = {1.0 / 0.0, 1.0 / 0.0};  // (min, -max) so one OpMin tree serves both
+  for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
+    const PairPos p = pair_pos(pidx, g);
+    for (int s = 0; s < 2; ++s) {
+      if (p.k + s >= g.nz) continue;
+      double ph[kMaxPhases];
+#pragma unroll
+      for (int q = 0; q < kMaxPhases; ++q) ph[q] = q < pt.n ? phi.p[q][p.off + s] : 0.0;
+      double lo, hi;
+      if (tangent_eigs<kMaxPhases>(ph, pt, mixing, &lo, &hi) != 0) {
+        atomicOr(error_flag, 1);
+        continue;
+      }
+      acc[0] = acc[0] < lo ? acc[0] : lo;
+      acc[1] = acc[1] < -hi ? acc[1] : -hi;
+    }
+  }
+  block_reduce<2>(acc, smem, OpMin());
+  if (threadIdx.x == 0) {
+    partial[(long)blockIdx.x * 2 + 0] = acc[0];
+    partial[(long)blockIdx.x * 2 + 1] = acc[1];
+  }
+}
+
+// calcStressConst  F:17973-18020 : tau = 2 mu0 eps + lambda0 tr(eps) I  (whole padded arrays)
+__global__ __launch_bounds__(kBlock) void k_stress_const(long n2, double two_mu, double lambda, FieldPtrs<6> eps,
+                                                         FieldPtrs<6> tau) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+    double2 e[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) e[c] = ld2(eps.p[c], 2 * i);
+    const double lx = lambda * (e[0].x + e[1].x + e[2].x);
+    const double ly = lambda * (e[0].y + e[1].y + e[2].y);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st2(tau.p[c], 2 * i, make_double2(e[c].x * two_mu + lx, e[c].y * two_mu + ly));
+#pragma unroll
+    for (int c = 3; c < 6; ++c) st2(tau.p[c], 2 * i, make_double2(e[c].x * two_mu, e[c].y * two_mu));
+  }
+}
+
+// second stage: one block folds nblocks x NV partials in a fixed order
+template <class Op>
+__global__ __launch_bounds__(kBlock) void k_fold(const double* partial, int nblocks, int nv, double init, double* out) {
+  __shared__ double smem[kBlock];
+  Op op;
+  for (int q = 0; q < nv; ++q) {
+    double a = init;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) a = op(a, partial[(long)b * nv + q]);
+    smem[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = kBlock / 2; s >= 1; s >>= 1) {
+      if ((int)threadIdx.x < s) smem[threadIdx.x] = op(smem[threadIdx.x], smem[threadIdx.x + s]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[q] = smem[0];
+    __syncthreads();
+  }
+}
+
+int grid_for(long nwork, int max_blocks) {
+  long b = (nwork + kBlock - 1) / kBlock;
+  if (b > max_blocks) b = max_blocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+namespace {
+template <bool REDUCE>
+void stress_dispatch(dim3 grid, const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
+                     const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& normals, const FieldPtrs<6>& tau,
+                     double* partial, int* error_flag, hipStream_t s) {
+  const bool lam = sp.mixing == kMixLaminate;
+  const bool small = sp.pt.n <= 2;
+#define FG_LAUNCH(MIX, NPH)                                                                                        \
+  hipLaunchKernelGGL((k_stress<REDUCE, MIX, NPH>), grid, dim3(kBlock), 0, s, g, sp, eps, phi, normals, tau, partial, \
+                     error_flag)
+  if (lam && small) FG_LAUNCH(kMixLaminate, 2);
+  else if (lam) FG_LAUNCH(kMixLaminate, kMaxPhases);
+  else if (small) FG_LAUNCH(kMixVoigt, 2);
+  else FG_LAUNCH(kMixVoigt, kMaxPhases);
+#undef FG_LAUNCH
+  FG_HIP_CHECK(hipGetLastError());
+}
+}  // namespace
+
+int reduce_blocks(const Grid& g) { return grid_for((long)g.nx * g.ny * g.nzc, kMaxReduceBlocks); }
+
+void launch_stress(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps, const FieldPtrs<kMaxPhases>& phi,
+                   const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, int* error_flag, hipStream_t s) {
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  stress_dispatch<false>(dim3(grid_for(npairs, 1 << 20)), g, sp, eps, phi, normals, tau, nullptr, error_flag, s);
+}
+
+void launch_stress_mean(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
+                        const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& normals, double* partial, double* out6,
+                        int* error_flag, hipStream_t s) {
+  const int nb = reduce_blocks(g);
+  FieldPtrs<6> none = {};
+  stress_dispatch<true>(dim3(nb), g, sp, eps, phi, normals, none, partial, error_flag, s);
+  hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, out6);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_stress_const(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<6>& eps, const FieldPtrs<6>& tau,
+                         hipStream_t s) {
+  const long n2 = g.n / 2;
+  hipLaunchKernelGGL(k_stress_const, dim3(grid_for(n2, 1 << 20)), dim3(kBlock), 0, s, n2, 2 * mu_0, lambda_0, eps, tau);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, hipStream_t s) {
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  hipLaunchKernelGGL(k_div, dim3(grid_for(npairs, 1 << 20)), dim3(kBlock), 0, s, g, tau, f);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, hipStream_t s) {
+  const long nfreq = (long)g.nx * g.ny * g.nzc;
+  hipLaunchKernelGGL(k_g0, dim3(grid_for(nfreq, 1 << 20)), dim3(kBlock), 0, s, g, fh, tb, c10, c20);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps, const Vec6& E, const Vec6& R,
+                     bool add_R, double* partial, double* sumsq6, hipStream_t s) {
+  const int nb = reduce_blocks(g);
+  hipLaunchKernelGGL(k_eps_norm, dim3(nb), dim3(kBlock), 0, s, g, u, eps, E, R, add_R ? 1 : 0, partial);
+  FG_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, sumsq6);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_sum6(const Grid& g, const FieldPtrs<6>& x, bool square, double* partial, double* out6, hipStream_t s) {
+  const int nb = reduce_blocks(g);
+  if (square) hipLaunchKernelGGL((k_sum<6, true>), dim3(nb), dim3(kBlock), 0, s, g, x, partial);
+  else hipLaunchKernelGGL((k_sum<6, false>), dim3(nb), dim3(kBlock), 0, s, g, x, partial);
+  FG_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, out6);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_sum1(const Grid& g, const double* x, double* partial, double* out1, hipStream_t s) {
+  const int nb = reduce_blocks(g);
+  FieldPtrs<1> f;
+  f.p[0] = const_cast<double*>(x);
+  hipLaunchKernelGGL((k_sum<1, false>), dim3(nb), dim3(kBlock), 0, s, g, f, partial);
+  FG_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 1, 0.0, out1);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_tangent_minmax(const Grid& g, const PhaseTable& pt, int mixing, const FieldPtrs<kMaxPhases>& phi,
+                           double* partial, double* out2, int* error_flag, hipStream_t s) {
+  const int nb = reduce_blocks(g);
+  hipLaunchKernelGGL(k_tangent_minmax, dim3(nb), dim3(kBlock), 0, s, g, pt, mixing, phi, partial, error_flag);
+  FG_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_fold<OpMin>, dim3(1), dim3(kBlock), 0, s, partial, nb, 2, 1.0 / 0.0, out2);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace fg

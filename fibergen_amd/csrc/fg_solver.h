@@ -1,0 +1,157 @@
+// Single-GPU Lippmann-Schwinger solver (basic scheme, staggered grid, linear
+// elasticity): the device-resident restatement of LSSolver<double,double,3>
+// (F:14641-24740) for the path  run -> runLoadsteppingSolver -> runBasic ->
+// basicScheme -> calcStress + GammaOperatorStaggered.
+//
+// All fields stay in HBM for the whole load case; per iteration only the six
+// sums of squares of the error estimator cross back to the host.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "fg_fft.h"
+#include "fg_hostmath.h"
+#include "fg_kernels.h"
+
+namespace fg {
+
+typedef int (*ConvergenceCallback)(void* user);
+
+struct SolverOptions {
+  // defaults of the LSSolver constructor  F:14800-14862
+  double tol = 1e-4;
+  double abs_tol = 2.220446049250313e-16;
+  double bc_tol = 1e-3;
+  long maxiter = 10000;
+  double ref_scale = 1.0;
+  double bc_relax = 1.0;
+  int mixing = kMixVoigt;
+  int update_ref = 1;           // update_ref != "never"
+  double mu_0 = 0.0 / 1.0;      // set to NaN in the constructor unless <ref> given (F:15340)
+  double lambda_0 = 0.0;
+  double eps_g = 2.220446049250313e-16;          // laminate tolerances F:13110-13111
+  double eps_a = 3.666852862501036e-11;          // eps^(2/3)
+};
+
+enum Stage {
+  kStageStress = 0,     // eps -> tau            calcStressDiff (mu_0, lambda_0)
+  kStageDiv = 1,        // tau -> f
+  kStageFftForward = 2, // f -> f_hat (scaled 1/N)
+  kStageG0 = 3,         // f_hat -> u_hat (alpha = -1)
+  kStageFftInverse = 4, // u_hat -> u
+  kStageEps = 5,        // u -> eps (+E, +R), sums of squares
+  kStageIteration = 6,  // all of the above = one basicScheme call
+  kStageStressConst = 7 // eps -> tau = C0 : eps
+};
+
+// kernels of one pass, in launch order (HIP-event timing slots)
+constexpr int kNumTimedKernels = 10;
+//  0 stress  1 div  2 r2c_z  3 c2c_y_fwd  4 c2c_x_fwd  5 g0  6 c2c_x_inv  7 c2c_y_inv  8 c2r_z  9 eps_norm
+struct StageTimes {
+  double ms[kNumTimedKernels];
+  long count;
+};
+
+class Solver {
+ public:
+  Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device);
+  ~Solver();
+  Solver(const Solver&) = delete;
+  Solver& operator=(const Solver&) = delete;
+
+  const Grid& grid() const { return g_; }
+  SolverOptions& options() { return opt_; }
+  hipStream_t stream() const { return stream_; }
+
+  void set_num_phases(int n);
+  int num_phases() const { return pt_.n; }
+  void set_phase_material(int p, double mu, double lambda);
+  void set_phase_field(int p, const double* phi_host);  // [nx][ny][nz], copied
+  void set_normals(const double* n_host);                // [3][nx][ny][nz]
+  void set_bc_projector(const double* P36);              // row-major 6x6
+  void set_callback(ConvergenceCallback cb, void* user) { cb_ = cb; cb_user_ = user; }
+  void cancel() { cancel_ = true; }
+
+  // LSSolver::run  F:21247-21398.  Returns false on success, true on error like the reference.
+  bool run(const double* E6, const double* S6);
+  // timed iterations without convergence logic (bench / profiling): n passes of basicScheme
+  void iterate(const double* E6, int n);
+
+  void mean_stress(double* out6);   // calcMeanStress  F:17793-17811
+  void mean_strain(double* out6);   // TensorField::average  F:10171
+  double volume_fraction(int p);
+
+  const std::vector<double>& residuals() const { return residuals_; }
+  long iterations() const { return iterations_; }
+  double solve_time() const { return solve_time_; }
+  double mu_0() const { return opt_.mu_0; }
+  double lambda_0() const { return opt_.lambda_0; }
+  void calc_ref_material();         // calcRefMaterial  F:22283-22313
+
+  // field access (host copies, z padding stripped / added)
+  int field_components(const std::string& name) const;
+  void get_field(const std::string& name, double* out_host);
+  void set_field(const std::string& name, const double* in_host);
+  // device pointer of a padded component (for zero-copy wrapping by the caller)
+  double* device_component(const std::string& name, int c);
+
+  // single stages on the solver's own buffers (parity tests, profiling)
+  void run_stage(int stage, const double* E6);
+  void enable_stage_timing(bool on);
+  StageTimes stage_times() const { return times_; }
+  void reset_stage_times();
+
+ private:
+  void basic_scheme(const double* E6);
+  void recompute_bc();
+  double bc_error(const double* E_cur, const double* S_cur);
+  StressParams stress_params(double mu_0, double lambda_0, double alpha) const;
+  FieldPtrs<6> ptrs6(double* base) const;
+  FieldPtrs<3> ptrs3(double* base) const;
+  void check_device_error(const char* where);
+  void upload_padded(double* dst, const double* src_unpadded);
+  void download_unpadded(const double* src, double* dst_unpadded);
+  void time_begin(int stage);
+  void time_end(int stage);
+
+  Grid g_;
+  SolverOptions opt_;
+  PhaseTable pt_;
+  int device_;
+  hipStream_t stream_;
+  std::unique_ptr<Fft3> fft_;
+
+  double* eps_ = nullptr;      // 6 padded components
+  double* tau_ = nullptr;      // 6
+  double* fu_ = nullptr;       // 3 (real f / u, complex f_hat / u_hat)
+  double* phi_ = nullptr;      // nphase
+  double* normals_ = nullptr;  // 3 (allocated on demand)
+  double* partial_ = nullptr;  // reduction partials
+  double* dscal_ = nullptr;    // device scalars
+  double* hscal_ = nullptr;    // pinned host mirror
+  int* derr_ = nullptr;        // device error flag
+  int* herr_ = nullptr;
+  double* g0_kpm_[3] = {nullptr, nullptr, nullptr};
+  cplx* g0_kp_[3] = {nullptr, nullptr, nullptr};
+
+  hostmath::Mat6 BC_P_, BC_Q_, BC_M_, BC_MQ_, BC_QC0_;
+  double F00_[6];
+  ConvergenceCallback cb_ = nullptr;
+  void* cb_user_ = nullptr;
+  bool cancel_ = false;
+
+  std::vector<double> residuals_;
+  long iterations_ = 0;
+  double solve_time_ = 0.0;
+  double sumsq_[6];
+
+  bool timing_ = false;
+  StageTimes times_;
+  hipEvent_t ev_[2];
+};
+
+}  // namespace fg

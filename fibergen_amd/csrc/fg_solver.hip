@@ -1,0 +1,657 @@
+#include "fg_solver.h"
+
+#include <chrono>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+#include "fg_hip_util.h"
+
+namespace fg {
+
+using namespace hostmath;
+
+namespace {
+constexpr double kEps = 2.220446049250313e-16;
+// device scalar slots
+constexpr int kSlotSumSq = 0;    // 6
+constexpr int kSlotMean = 6;     // 6
+constexpr int kSlotMinMax = 12;  // 2
+constexpr int kSlotMisc = 14;    // 2
+constexpr int kNumSlots = 16;
+
+double now_seconds() {
+  using clk = std::chrono::steady_clock;
+  return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
+}
+}  // namespace
+
+Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device) : device_(device) {
+  if (nx < 1 || ny < 1 || nz < 1) throw std::runtime_error("grid dimensions must be >= 1");
+  if (!(dx > 0) || !(dy > 0) || !(dz > 0)) throw std::runtime_error("RVE dimensions must be > 0");
+  g_ = make_grid(nx, ny, nz, dx, dy, dz);
+  if (g_.n >= (1L << 31)) throw std::runtime_error("grid too large: padded component exceeds 2^31 reals");
+  int ndev = 0;
+  FG_HIP_CHECK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) throw std::runtime_error("no HIP device available: fibergen_amd needs an AMD GPU (gfx950)");
+  if (device < 0 || device >= ndev) throw std::runtime_error("invalid device index");
+  FG_HIP_CHECK(hipSetDevice(device));
+  FG_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  FG_HIP_CHECK(hipEventCreate(&ev_[0]));
+  FG_HIP_CHECK(hipEventCreate(&ev_[1]));
+  pt_.n = 0;
+  for (int i = 0; i < kMaxPhases; ++i) pt_.mu[i] = pt_.lambda[i] = 0.0;
+  opt_.mu_0 = std::numeric_limits<double>::quiet_NaN();  // F:15340
+  opt_.eps_a = std::pow(kEps, 2.0 / 3.0);
+
+  const size_t comp = g_.n * sizeof(double);
+  FG_HIP_CHECK(hipMalloc(&eps_, 6 * comp));
+  FG_HIP_CHECK(hipMalloc(&tau_, 6 * comp));
+  FG_HIP_CHECK(hipMalloc(&fu_, 3 * comp));
+  FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * comp, stream_));
+  FG_HIP_CHECK(hipMemsetAsync(tau_, 0, 6 * comp, stream_));
+  FG_HIP_CHECK(hipMemsetAsync(fu_, 0, 3 * comp, stream_));
+  FG_HIP_CHECK(hipMalloc(&partial_, (size_t)kMaxReduceBlocks * 8 * sizeof(double)));
+  FG_HIP_CHECK(hipMalloc(&dscal_, kNumSlots * sizeof(double)));
+  FG_HIP_CHECK(hipHostMalloc(&hscal_, kNumSlots * sizeof(double)));
+  FG_HIP_CHECK(hipMalloc(&derr_, sizeof(int)));
+  FG_HIP_CHECK(hipHostMalloc(&herr_, sizeof(int)));
+  FG_HIP_CHECK(hipMemsetAsync(derr_, 0, sizeof(int), stream_));
+
+  fft_.reset(new Fft3(g_, stream_));
+
+  // Separable factors of G0OperatorFourierStaggeredGeneral  F:19838-19876, evaluated on the
+  // host with the same libm calls the reference makes per frequency.
+  const int len[3] = {nx, ny, nz};
+  const double d[3] = {dx, dy, dz};
+  for (int a = 0; a < 3; ++a) {
+    const int n = len[a];
+    const int cnt = (a == 2) ? g_.nzc : n;
+    std::vector<double> kpm(cnt);
+    std::vector<cplx> kp(cnt);
+    const double h = d[a] / (2 * n);
+    const double xi_0 = 2 * M_PI * h / d[a];
+    const bool even = (n & 1) == 0;
+    const size_t half = even ? (size_t)(n / 2 - 1) : (size_t)(n / 2);
+    for (size_t i = 0; i < (size_t)cnt; ++i) {
+      const double xi = xi_0 * ((i <= half) ? (double)i : ((double)i - (double)n));
+      const double s = std::sin(xi) / h;
+      const std::complex<double> z = s * std::exp(std::complex<double>(0, xi));
+      kpm[i] = s;
+      kp[i] = cmake(z.real(), z.imag());
+    }
+    FG_HIP_CHECK(hipMalloc(&g0_kpm_[a], cnt * sizeof(double)));
+    FG_HIP_CHECK(hipMalloc(&g0_kp_[a], cnt * sizeof(cplx)));
+    FG_HIP_CHECK(hipMemcpy(g0_kpm_[a], kpm.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(g0_kp_[a], kp.data(), cnt * sizeof(cplx), hipMemcpyHostToDevice));
+  }
+
+  BC_P_ = voigt_id4();
+  for (int i = 0; i < 6; ++i) F00_[i] = 0.0, sumsq_[i] = 0.0;
+  recompute_bc();
+  reset_stage_times();
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+Solver::~Solver() {
+  (void)hipSetDevice(device_);
+  (void)hipStreamSynchronize(stream_);
+  fft_.reset();
+  double* bufs[] = {eps_, tau_, fu_, phi_, normals_, partial_, dscal_};
+  for (double* b : bufs)
+    if (b) (void)hipFree(b);
+  if (hscal_) (void)hipHostFree(hscal_);
+  if (derr_) (void)hipFree(derr_);
+  if (herr_) (void)hipHostFree(herr_);
+  for (int a = 0; a < 3; ++a) {
+    if (g0_kpm_[a]) (void)hipFree(g0_kpm_[a]);
+    if (g0_kp_[a]) (void)hipFree(g0_kp_[a]);
+  }
+  (void)hipEventDestroy(ev_[0]);
+  (void)hipEventDestroy(ev_[1]);
+  (void)hipStreamDestroy(stream_);
+}
+
+// ------------------------------------------------------------------ configuration
+void Solver::set_num_phases(int n) {
+  if (n < 1 || n > kMaxPhases) throw std::runtime_error("number of phases must be in [1, 8]");
+  FG_HIP_CHECK(hipSetDevice(device_));
+  if (phi_) FG_HIP_CHECK(hipFree(phi_));
+  phi_ = nullptr;
+  FG_HIP_CHECK(hipMalloc(&phi_, (size_t)n * g_.n * sizeof(double)));
+  FG_HIP_CHECK(hipMemset(phi_, 0, (size_t)n * g_.n * sizeof(double)));
+  pt_.n = n;
+}
+
+void Solver::set_phase_material(int p, double mu, double lambda) {
+  if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
+  pt_.mu[p] = mu;
+  pt_.lambda[p] = lambda;
+}
+
+void Solver::set_phase_field(int p, const double* phi_host) {
+  if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
+  upload_padded(phi_ + (long)p * g_.n, phi_host);
+}
+
+void Solver::set_normals(const double* n_host) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  if (!normals_) {
+    FG_HIP_CHECK(hipMalloc(&normals_, 3 * g_.n * sizeof(double)));
+    FG_HIP_CHECK(hipMemset(normals_, 0, 3 * g_.n * sizeof(double)));
+  }
+  for (int c = 0; c < 3; ++c) upload_padded(normals_ + (long)c * g_.n, n_host + (long)c * g_.nxyz);
+}
+
+void Solver::set_bc_projector(const double* P36) {
+  // setBCProjector checks  F:20601-20615
+  Mat6 P;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) P.a[i][j] = P36[i * 6 + j];
+  const double se = std::sqrt(kEps);
+  Mat6 D = P;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) D.a[i][j] = P.a[i][j] - P.a[j][i];
+  if (frobenius(D) > se) throw std::runtime_error("Projector is not symmetric");
+  Mat6 PP = voigt_mm(P, P);
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) D.a[i][j] = P.a[i][j] - PP.a[i][j];
+  if (frobenius(D) > se) throw std::runtime_error("Specified Projector is not a projector");
+  BC_P_ = P;
+  recompute_bc();
+}
+
+// setBCProjector body  F:20617-20664 (depends on the current reference material)
+void Solver::recompute_bc() {
+  const Mat6 Id = voigt_id4(), II = voigt_ii4();
+  bool q_zero = true;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      BC_Q_.a[i][j] = Id.a[i][j] - BC_P_.a[i][j];
+      if (BC_Q_.a[i][j] != 0.0) q_zero = false;
+    }
+  if (q_zero) {  // pure strain BC: Q:C0, M, MQ vanish whatever C0 is (also while mu_0 is NaN)
+    BC_QC0_ = BC_M_ = BC_MQ_ = mat6_zero();
+    return;
+  }
+  Mat6 C0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) C0.a[i][j] = 2 * opt_.mu_0 * Id.a[i][j] + opt_.lambda_0 * II.a[i][j];
+  BC_QC0_ = voigt_mm(BC_Q_, C0);
+  if (std::isnan(opt_.mu_0)) {
+    // run() calls setBCProjector before calcRefMaterial replaced the NaN (F:21354 vs F:21742);
+    // the values are recomputed before their first use.
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) BC_M_.a[i][j] = BC_MQ_.a[i][j] = std::numeric_limits<double>::quiet_NaN();
+    return;
+  }
+  BC_M_ = bc_pseudo_inverse(voigt_mm(BC_QC0_, BC_Q_));
+  BC_MQ_ = voigt_mm(BC_M_, BC_Q_);
+}
+
+// ------------------------------------------------------------------ helpers
+FieldPtrs<6> Solver::ptrs6(double* base) const {
+  FieldPtrs<6> f;
+  for (int c = 0; c < 6; ++c) f.p[c] = base + (long)c * g_.n;
+  return f;
+}
+FieldPtrs<3> Solver::ptrs3(double* base) const {
+  FieldPtrs<3> f;
+  for (int c = 0; c < 3; ++c) f.p[c] = base + (long)c * g_.n;
+  return f;
+}
+
+StressParams Solver::stress_params(double mu_0, double lambda_0, double alpha) const {
+  StressParams sp;
+  sp.pt = pt_;
+  sp.mixing = opt_.mixing;
+  sp.mu_0 = mu_0;
+  sp.lambda_0 = lambda_0;
+  sp.alpha = alpha;
+  sp.eps_g = opt_.eps_g;
+  sp.eps_a = opt_.eps_a;
+  return sp;
+}
+
+void Solver::upload_padded(double* dst, const double* src) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  FG_HIP_CHECK(hipMemcpy2D(dst, g_.nzp * sizeof(double), src, g_.nz * sizeof(double), g_.nz * sizeof(double),
+                           (size_t)g_.nx * g_.ny, hipMemcpyHostToDevice));
+}
+
+void Solver::download_unpadded(const double* src, double* dst) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  FG_HIP_CHECK(hipMemcpy2D(dst, g_.nz * sizeof(double), src, g_.nzp * sizeof(double), g_.nz * sizeof(double),
+                           (size_t)g_.nx * g_.ny, hipMemcpyDeviceToHost));
+}
+
+void Solver::check_device_error(const char* where) {
+  FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (*herr_ != 0) {
+    FG_HIP_CHECK(hipMemsetAsync(derr_, 0, sizeof(int), stream_));
+    if (opt_.mixing == kMixLaminate)
+      throw std::runtime_error(std::string("The laminate mixing rule supports only two phase mixtures (") + where + ")");
+    throw std::runtime_error(std::string("device kernel reported an error (") + where + ")");
+  }
+}
+
+void Solver::enable_stage_timing(bool on) { timing_ = on; }
+void Solver::reset_stage_times() {
+  for (int i = 0; i < kNumTimedKernels; ++i) times_.ms[i] = 0.0;
+  times_.count = 0;
+}
+void Solver::time_begin(int) {
+  if (timing_) FG_HIP_CHECK(hipEventRecord(ev_[0], stream_));
+}
+void Solver::time_end(int stage) {
+  if (!timing_) return;
+  FG_HIP_CHECK(hipEventRecord(ev_[1], stream_));
+  FG_HIP_CHECK(hipEventSynchronize(ev_[1]));
+  float ms = 0.f;
+  FG_HIP_CHECK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+  times_.ms[stage] += ms;
+}
+
+// ------------------------------------------------------------------ one pass of the basic scheme
+// basicScheme  F:20558-20578 + GammaOperatorStaggered  F:20288-20300:
+//   tau = (C - C0):eps ; f = div tau ; u = G0 f ; eps = E + sym grad u (+ R)
+void Solver::basic_scheme(const double* E6) {
+  if (pt_.n < 1) throw std::runtime_error("No materials specified");
+  if (opt_.mixing == kMixLaminate && !normals_) throw std::runtime_error("laminate mixing needs interface normals");
+  FieldPtrs<kMaxPhases> phi;
+  for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+  FieldPtrs<3> nrm;
+  for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+  const double alpha = -1.0;  // GammaOperator(..., -1)  F:20575
+
+  if (opt_.bc_relax != 1.0) mean_strain(F00_);  // F:20563-20565
+
+  time_begin(0);
+  launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
+  time_end(0);
+
+  // initBCProjector  F:20228-20239
+  double F0[6] = {0, 0, 0, 0, 0, 0};
+  const bool mq_zero = frobenius(BC_MQ_) < kEps;
+  if (!mq_zero) {
+    launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)g_.nxyz;
+  }
+
+  time_begin(1);
+  launch_div(g_, ptrs6(tau_), ptrs3(fu_), stream_);
+  time_end(1);
+  {
+    // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
+    const double scale = 1 / (double)g_.nxyz;
+    const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
+    time_begin(2);
+    fft_->r2c_z(fu_, 3, g_.n);
+    time_end(2);
+    time_begin(3);
+    fft_->c2c_y(fu_, 3, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
+    time_end(3);
+    time_begin(4);
+    fft_->c2c_x(fu_, 3, g_.n, -1, has_x ? scale : 1.0);
+    time_end(4);
+    if (!has_x && !has_y) fft_->scale(fu_, 3, g_.n, scale);
+  }
+  time_begin(5);
+  {
+    // G0OperatorFourierStaggered  F:19749-19755
+    const double c10 = -alpha / (opt_.mu_0);
+    const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    G0Tables tb;
+    for (int a = 0; a < 3; ++a) {
+      tb.kpm[a] = g0_kpm_[a];
+      tb.kp[a] = g0_kp_[a];
+    }
+    launch_g0(g_, ptrs3(fu_), tb, c10, c20, stream_);
+  }
+  time_end(5);
+  time_begin(6);
+  fft_->c2c_x(fu_, 3, g_.n, +1, 1.0);
+  time_end(6);
+  time_begin(7);
+  fft_->c2c_y(fu_, 3, g_.n, +1, 1.0);
+  time_end(7);
+  time_begin(8);
+  fft_->c2r_z(fu_, 3, g_.n);
+  time_end(8);
+
+  // applyBCProjector  F:20247-20270: R = alpha*(bc_relax*MQ:F0 - (1-bc_relax)*M:(QC0:F00))
+  Vec6 E, R;
+  double t1[6], t2[6], t3[6];
+  voigt_mv(BC_MQ_, F0, t1);
+  voigt_mv(BC_QC0_, F00_, t2);
+  voigt_mv(BC_M_, t2, t3);
+  bool add_R = false;
+  for (int c = 0; c < 6; ++c) {
+    E.v[c] = E6[c];
+    R.v[c] = mq_zero && opt_.bc_relax == 1.0 ? 0.0 : alpha * (opt_.bc_relax * t1[c] - (1 - opt_.bc_relax) * t3[c]);
+    if (R.v[c] != 0.0) add_R = true;
+  }
+  time_begin(9);
+  launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), E, R, add_R, partial_, dscal_ + kSlotSumSq, stream_);
+  time_end(9);
+  if (timing_) times_.count++;
+}
+
+void Solver::iterate(const double* E6, int n) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  for (int i = 0; i < n; ++i) basic_scheme(E6);
+}
+
+// ------------------------------------------------------------------ means
+void Solver::mean_stress(double* out6) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  if (pt_.n < 1) throw std::runtime_error("No materials specified");
+  FieldPtrs<kMaxPhases> phi;
+  for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+  FieldPtrs<3> nrm;
+  for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+  // meanPK1: alpha /= nxyz, accumulate  F:12318-12340
+  launch_stress_mean(g_, stress_params(0.0, 0.0, 1.0 / (double)g_.nxyz), ptrs6(eps_), phi, nrm, partial_,
+                     dscal_ + kSlotMean, derr_, stream_);
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  for (int c = 0; c < 6; ++c) out6[c] = hscal_[kSlotMean + c];
+}
+
+void Solver::mean_strain(double* out6) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  launch_sum6(g_, ptrs6(eps_), false, partial_, dscal_ + kSlotMean, stream_);
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  for (int c = 0; c < 6; ++c) out6[c] = hscal_[kSlotMean + c] / (double)g_.nxyz;
+}
+
+double Solver::volume_fraction(int p) {
+  if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
+  FG_HIP_CHECK(hipSetDevice(device_));
+  launch_sum1(g_, phi_ + (long)p * g_.n, partial_, dscal_ + kSlotMisc, stream_);
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMisc, dscal_ + kSlotMisc, sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  return hscal_[kSlotMisc] / (double)g_.nxyz;
+}
+
+// calcRefMaterial  F:22283-22313 -> getRefMaterial  F:12153-12236
+void Solver::calc_ref_material() {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  if (pt_.n < 1) throw std::runtime_error("No materials specified");
+  FieldPtrs<kMaxPhases> phi;
+  for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+  launch_tangent_minmax(g_, pt_, opt_.mixing, phi, partial_, dscal_ + kSlotMinMax, derr_, stream_);
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMinMax, dscal_ + kSlotMinMax, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  check_device_error("reference material");
+  double lambda_min = hscal_[kSlotMinMax], lambda_max = -hscal_[kSlotMinMax + 1];
+  if (lambda_min < 0) lambda_min = 0;  // F:12183-12223
+  double mu_0 = 0.5 * (lambda_min + lambda_max);
+  mu_0 *= 0.5 * opt_.ref_scale;
+  opt_.mu_0 = mu_0;
+  recompute_bc();  // F:22312
+}
+
+// bc_error  F:21129-21161
+double Solver::bc_error(const double* E_cur, const double* S_cur) {
+  double Emean[6], Smean[6], PE[6], QS[6], PEc[6], d[6];
+  mean_strain(Emean);
+  mean_stress(Smean);
+  voigt_mv(BC_P_, Emean, PE);
+  voigt_mv(BC_Q_, Smean, QS);
+  voigt_mv(BC_P_, E_cur, PEc);
+  const double norm_E = voigt_norm2(PEc);
+  for (int i = 0; i < 6; ++i) d[i] = PE[i] - E_cur[i];
+  const double err_F = voigt_norm2(d) / ((norm_E < opt_.bc_tol) ? 1 : norm_E);
+  const double norm_S = voigt_norm2(S_cur);
+  for (int i = 0; i < 6; ++i) d[i] = QS[i] - S_cur[i];
+  const double err_S = voigt_norm2(d) / ((norm_S < opt_.bc_tol) ? 1 : norm_S);
+  return err_F > err_S ? err_F : err_S;
+}
+
+// ------------------------------------------------------------------ the solver loop
+// run F:21247-21398 -> runLoadsteppingSolver (single load step, t = 1) F:21584-21685
+// -> runSolver -> runBasic F:21716-21805 with the stop rule of _converged F:21177-21244.
+bool Solver::run(const double* E6, const double* S6) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  if (pt_.n < 1) throw std::runtime_error("No materials specified");
+  solve_time_ = 0.0;
+  residuals_.clear();
+  iterations_ = 0;
+  cancel_ = false;
+  double E0[6], S0[6];
+  for (int i = 0; i < 6; ++i) {
+    E0[i] = E6[i];
+    S0[i] = S6 ? S6[i] : 0.0;
+  }
+  recompute_bc();  // F:21354
+  {
+    const double se = std::sqrt(kEps);
+    double t[6];
+    voigt_mv(BC_P_, S0, t);
+    if (norm2(t, 6) > se * norm2(S0, 6)) throw std::runtime_error("Incompatible stress boundary condition specified");
+    voigt_mv(BC_Q_, E0, t);
+    if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
+  }
+  const double t_start = now_seconds();
+  FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * g_.n * sizeof(double), stream_));  // F:21379
+  for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
+
+  // EpsilonErrorEstimator  F:14591-14637: norms of the zero field at construction
+  double prev = 0.0;
+  long iter = 1;
+  bool update_ref = opt_.update_ref != 0;
+  double E[6];
+  for (int i = 0; i < 6; ++i) E[i] = E0[i];
+  bool failed = false;
+  const double small = std::numeric_limits<double>::min();
+
+  for (;;) {
+    if (update_ref) {
+      calc_ref_material();
+      // calcBCMean  F:20242-20245
+      double t1[6], t2[6], t3[6];
+      voigt_mv(BC_QC0_, E0, t1);
+      for (int i = 0; i < 6; ++i) t2[i] = S0[i] - t1[i];
+      voigt_mv(BC_M_, t2, t3);
+      for (int i = 0; i < 6; ++i) E[i] = E0[i] + opt_.bc_relax * t3[i];
+      update_ref = false;
+    }
+    basic_scheme(E);
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    check_device_error("stress");
+
+    // component_norm + fix_dim + norm_2 over 9 mirrored entries  F:10127-10138, F:14600-14609, F:14627
+    double m[6], s9 = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      sumsq_[c] = hscal_[kSlotSumSq + c];
+      m[c] = std::sqrt(sumsq_[c] / (double)g_.nxyz);
+    }
+    for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
+    for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
+    const double cur = std::sqrt(s9);
+    const double abs_err = std::fabs(prev - cur);
+    const double rel_err = abs_err / (small + cur);
+    prev = cur;
+
+    // _converged  F:21177-21244
+    if (std::isnan(rel_err)) {
+      failed = true;  // "NaN detected in solution. Aborting."
+      break;
+    }
+    if (cancel_) {
+      failed = true;
+      break;
+    }
+    residuals_.push_back(rel_err);
+    if (cb_ && cb_(cb_user_)) break;
+    if (cancel_) {
+      failed = true;
+      break;
+    }
+    if (iter >= opt_.maxiter) break;
+    if (rel_err <= opt_.tol || abs_err <= opt_.abs_tol) {
+      const double bc_err = bc_error(E0, S0);
+      if (bc_err <= opt_.bc_tol) break;
+    }
+    iter++;
+  }
+  iterations_ = iter;
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  solve_time_ += now_seconds() - t_start;
+  return failed;
+}
+
+// ------------------------------------------------------------------ stages and fields
+void Solver::run_stage(int stage, const double* E6) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  FieldPtrs<kMaxPhases> phi;
+  for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+  FieldPtrs<3> nrm;
+  for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+  const double zero6[6] = {0, 0, 0, 0, 0, 0};
+  const double* E = E6 ? E6 : zero6;
+  switch (stage) {
+    case kStageStress:
+      if (pt_.n < 1) throw std::runtime_error("No materials specified");
+      launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
+      check_device_error("stress");
+      break;
+    case kStageStressConst:
+      launch_stress_const(g_, opt_.mu_0, opt_.lambda_0, ptrs6(eps_), ptrs6(tau_), stream_);
+      break;
+    case kStageDiv:
+      launch_div(g_, ptrs6(tau_), ptrs3(fu_), stream_);
+      break;
+    case kStageFftForward:
+      fft_->forward(fu_, 3, g_.n, 1 / (double)g_.nxyz);
+      break;
+    case kStageG0: {
+      const double alpha = E6 ? E6[0] : -1.0;  // stage tests pass alpha in E6[0]
+      const double c10 = -alpha / (opt_.mu_0);
+      const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+      G0Tables tb;
+      for (int a = 0; a < 3; ++a) {
+        tb.kpm[a] = g0_kpm_[a];
+        tb.kp[a] = g0_kp_[a];
+      }
+      launch_g0(g_, ptrs3(fu_), tb, c10, c20, stream_);
+      break;
+    }
+    case kStageFftInverse:
+      fft_->inverse(fu_, 3, g_.n);
+      break;
+    case kStageEps: {
+      Vec6 Ev, R;
+      for (int c = 0; c < 6; ++c) Ev.v[c] = E[c], R.v[c] = 0.0;
+      launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), Ev, R, false, partial_, dscal_ + kSlotSumSq, stream_);
+      FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      FG_HIP_CHECK(hipStreamSynchronize(stream_));
+      for (int c = 0; c < 6; ++c) sumsq_[c] = hscal_[kSlotSumSq + c];
+      break;
+    }
+    case kStageIteration:
+      basic_scheme(E);
+      check_device_error("stress");
+      break;
+    default:
+      throw std::runtime_error("unknown stage");
+  }
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+int Solver::field_components(const std::string& name) const {
+  if (name == "epsilon" || name == "sigma" || name == "tau") return 6;
+  if (name == "u" || name == "f" || name == "normals") return 3;
+  if (name == "f_hat") return 3;
+  if (name == "phi") return pt_.n;
+  if (name == "sumsq") return 6;
+  return 0;
+}
+
+double* Solver::device_component(const std::string& name, int c) {
+  if (name == "epsilon" && c >= 0 && c < 6) return eps_ + (long)c * g_.n;
+  if (name == "tau" && c >= 0 && c < 6) return tau_ + (long)c * g_.n;
+  if ((name == "f" || name == "u" || name == "f_hat") && c >= 0 && c < 3) return fu_ + (long)c * g_.n;
+  if (name == "phi" && c >= 0 && c < pt_.n) return phi_ + (long)c * g_.n;
+  if (name == "normals" && normals_ && c >= 0 && c < 3) return normals_ + (long)c * g_.n;
+  return nullptr;
+}
+
+// get_raw_field  F:15396-15684 (epsilon, sigma, u, phi, normals) + raw stage buffers for the tests
+void Solver::get_field(const std::string& name, double* out) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  if (name == "sumsq") {
+    for (int c = 0; c < 6; ++c) out[c] = sumsq_[c];
+    return;
+  }
+  if (name == "f_hat") {  // complex [3][nx][ny][nzc] interleaved = the padded buffer as is
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    FG_HIP_CHECK(hipMemcpy(out, fu_, 3 * g_.n * sizeof(double), hipMemcpyDeviceToHost));
+    return;
+  }
+  if (name == "sigma") {  // calcStress with C0 = 0  F:15496-15508
+    if (pt_.n < 1) throw std::runtime_error("No materials specified");
+    FieldPtrs<kMaxPhases> phi;
+    for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+    FieldPtrs<3> nrm;
+    for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+    launch_stress(g_, stress_params(0.0, 0.0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
+    check_device_error("sigma");
+    for (int c = 0; c < 6; ++c) download_unpadded(tau_ + (long)c * g_.n, out + (long)c * g_.nxyz);
+    return;
+  }
+  if (name == "u") {  // u = G0 div (C0 : eps), alpha = 1  F:15509-15521
+    launch_stress_const(g_, opt_.mu_0, opt_.lambda_0, ptrs6(eps_), ptrs6(tau_), stream_);
+    launch_div(g_, ptrs6(tau_), ptrs3(fu_), stream_);
+    fft_->forward(fu_, 3, g_.n, 1 / (double)g_.nxyz);
+    const double alpha = 1.0;
+    const double c10 = -alpha / (opt_.mu_0);
+    const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    G0Tables tb;
+    for (int a = 0; a < 3; ++a) {
+      tb.kpm[a] = g0_kpm_[a];
+      tb.kp[a] = g0_kp_[a];
+    }
+    launch_g0(g_, ptrs3(fu_), tb, c10, c20, stream_);
+    fft_->inverse(fu_, 3, g_.n);
+    for (int c = 0; c < 3; ++c) download_unpadded(fu_ + (long)c * g_.n, out + (long)c * g_.nxyz);
+    return;
+  }
+  const int nc = field_components(name);
+  if (nc == 0) throw std::runtime_error("Unknown field '" + name + "'");
+  for (int c = 0; c < nc; ++c) {
+    double* d = device_component(name, c);
+    if (!d) throw std::runtime_error("field '" + name + "' is not available");
+    download_unpadded(d, out + (long)c * g_.nxyz);
+  }
+}
+
+void Solver::set_field(const std::string& name, const double* in) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  if (name == "f_hat") {
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    FG_HIP_CHECK(hipMemcpy(fu_, in, 3 * g_.n * sizeof(double), hipMemcpyHostToDevice));
+    return;
+  }
+  if (name == "normals") {
+    set_normals(in);
+    return;
+  }
+  const int nc = field_components(name);
+  if (nc == 0 || name == "sigma" || name == "sumsq") throw std::runtime_error("field '" + name + "' cannot be set");
+  for (int c = 0; c < nc; ++c) {
+    double* d = device_component(name, c);
+    if (!d) throw std::runtime_error("field '" + name + "' is not available");
+    upload_padded(d, in + (long)c * g_.nxyz);
+  }
+}
+
+}  // namespace fg

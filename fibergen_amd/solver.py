@@ -1,0 +1,227 @@
+"""Thin object wrapper over the C ABI: one `LSSolver` = one `fg_solver*`.
+
+Mirrors the reference's LSSolver<double,double,3> surface that the project
+layer uses (F:14641-24740): materials, phases, normals, options, run(),
+means, fields, residuals.  All compute happens in libfibergen_amd.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+MIXING = {"voigt": 0, "laminate": 1}
+
+STAGES = {"stress": 0, "div": 1, "fft_forward": 2, "g0": 3, "fft_inverse": 4, "eps": 5, "iteration": 6,
+          "stress_const": 7}
+
+
+# kernels of one pass in launch order (FG_NUM_TIMED_KERNELS slots of fg_get_stage_times)
+KERNELS = ["stress", "div", "r2c_z", "c2c_y_fwd", "c2c_x_fwd", "g0", "c2c_x_inv", "c2c_y_inv", "c2r_z", "eps_norm"]
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+class LSSolver:
+    def __init__(self, nx, ny, nz, dx=1.0, dy=1.0, dz=1.0, device=0):
+        self._lib = _lib.load()
+        self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        self.dx, self.dy, self.dz = float(dx), float(dy), float(dz)
+        self._h = self._lib.fg_create(self.nx, self.ny, self.nz, self.dx, self.dy, self.dz, int(device))
+        if not self._h:
+            raise RuntimeError(self._lib.fg_last_error(None).decode())
+        self._cb_keepalive = None
+        self.nphases = 0
+
+    # -- plumbing ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self._lib.fg_last_error(self._h).decode())
+
+    @property
+    def shape(self):
+        return (self.nx, self.ny, self.nz)
+
+    # -- configuration ----------------------------------------------------
+    def set_num_phases(self, n):
+        self._check(self._lib.fg_set_num_phases(self._h, int(n)))
+        self.nphases = int(n)
+
+    def set_phase(self, p, mu, lam, phi=None):
+        ptr = None
+        if phi is not None:
+            phi = np.ascontiguousarray(phi, dtype=np.float64)
+            if phi.shape != self.shape:
+                raise ValueError("phi must have shape %r" % (self.shape,))
+            ptr = _dp(phi)
+        self._check(self._lib.fg_set_phase(self._h, int(p), float(mu), float(lam), ptr))
+
+    def set_normals(self, normals):
+        normals = np.ascontiguousarray(normals, dtype=np.float64)
+        if normals.shape != (3,) + self.shape:
+            raise ValueError("normals must have shape %r" % ((3,) + self.shape,))
+        self._check(self._lib.fg_set_normals(self._h, _dp(normals)))
+
+    def set_options(self, **kw):
+        for k, v in kw.items():
+            if k == "mixing_rule":
+                if v not in MIXING:
+                    raise RuntimeError("Unknown mixing rule '%s'" % v)
+                self._check(self._lib.fg_set_option_i(self._h, b"mixing_rule", MIXING[v]))
+            elif k in ("maxiter",):
+                self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
+            elif k == "update_ref":
+                flag = 0 if v in ("never", 0, False) else 1
+                self._check(self._lib.fg_set_option_i(self._h, b"update_ref", flag))
+            else:
+                self._check(self._lib.fg_set_option_d(self._h, k.encode(), float(v)))
+
+    def set_bc_projector(self, P):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        if P.shape != (6, 6):
+            raise ValueError("projector must be 6x6")
+        self._check(self._lib.fg_set_bc_projector(self._h, _dp(P)))
+
+    def set_convergence_callback(self, fn):
+        if fn is None:
+            self._cb_keepalive = _lib.CALLBACK()
+        else:
+            def tramp(_user):
+                return 1 if fn() else 0
+            self._cb_keepalive = _lib.CALLBACK(tramp)
+        self._check(self._lib.fg_set_convergence_callback(self._h, self._cb_keepalive, None))
+
+    def cancel(self):
+        self._check(self._lib.fg_cancel(self._h))
+
+    # -- running ------------------------------------------------------------
+    def run(self, E, S=None):
+        """LSSolver::run; returns True on error like the reference."""
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        Sp = None
+        if S is not None:
+            S = np.ascontiguousarray(S, dtype=np.float64)
+            Sp = _dp(S)
+        failed = ctypes.c_int(0)
+        self._check(self._lib.fg_run_load_case(self._h, _dp(E), Sp, ctypes.byref(failed)))
+        return bool(failed.value)
+
+    def iterate(self, E, n):
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        self._check(self._lib.fg_iterate(self._h, _dp(E), int(n)))
+
+    def time_iterations(self, E, n):
+        """n basic-scheme passes bracketed by HIP events on the solver stream -> milliseconds."""
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        ms = ctypes.c_double(0.0)
+        self._check(self._lib.fg_time_iterations(self._h, _dp(E), int(n), ctypes.byref(ms)))
+        return ms.value
+
+    def run_stage(self, stage, E=None):
+        sid = STAGES[stage] if isinstance(stage, str) else int(stage)
+        Ep = None
+        if E is not None:
+            E = np.ascontiguousarray(E, dtype=np.float64)
+            Ep = _dp(E)
+        self._check(self._lib.fg_run_stage(self._h, sid, Ep))
+
+    def synchronize(self):
+        self._check(self._lib.fg_synchronize(self._h))
+
+    # -- results --------------------------------------------------------------
+    @property
+    def iterations(self):
+        return int(self._lib.fg_get_iterations(self._h))
+
+    @property
+    def residuals(self):
+        n = self._lib.fg_get_residuals(self._h, None, 0)
+        out = np.zeros(max(n, 1))
+        self._lib.fg_get_residuals(self._h, _dp(out), n)
+        return out[:n].tolist()
+
+    @property
+    def solve_time(self):
+        return float(self._lib.fg_get_solve_time(self._h))
+
+    def mean_stress(self):
+        out = np.zeros(6)
+        self._check(self._lib.fg_mean_stress(self._h, _dp(out)))
+        return out
+
+    def mean_strain(self):
+        out = np.zeros(6)
+        self._check(self._lib.fg_mean_strain(self._h, _dp(out)))
+        return out
+
+    def volume_fraction(self, p):
+        out = ctypes.c_double(0.0)
+        self._check(self._lib.fg_volume_fraction(self._h, int(p), ctypes.byref(out)))
+        return out.value
+
+    def calc_ref_material(self):
+        self._check(self._lib.fg_calc_ref_material(self._h))
+        return self.ref_material
+
+    @property
+    def ref_material(self):
+        mu, lam = ctypes.c_double(0), ctypes.c_double(0)
+        self._lib.fg_get_ref_material(self._h, ctypes.byref(mu), ctypes.byref(lam))
+        return mu.value, lam.value
+
+    def get_field(self, name):
+        nc = self._lib.fg_field_components(self._h, name.encode())
+        if nc <= 0:
+            raise RuntimeError("Unknown field '%s'" % name)
+        if name == "sumsq":
+            out = np.zeros(6)
+        elif name == "f_hat":
+            nzc = self.nz // 2 + 1
+            out = np.zeros((3, self.nx, self.ny, nzc, 2))
+        else:
+            out = np.zeros((nc,) + self.shape)
+        self._check(self._lib.fg_get_field(self._h, name.encode(), _dp(out)))
+        if name == "f_hat":
+            return out.view(np.complex128)[..., 0]
+        return out
+
+    def set_field(self, name, value):
+        if name == "f_hat":
+            v = np.ascontiguousarray(value, dtype=np.complex128)
+            nzc = self.nz // 2 + 1
+            if v.shape != (3, self.nx, self.ny, nzc):
+                raise ValueError("bad f_hat shape")
+            value = v.view(np.float64)
+        else:
+            value = np.ascontiguousarray(value, dtype=np.float64)
+            nc = self._lib.fg_field_components(self._h, name.encode())
+            if value.shape != (nc,) + self.shape:
+                raise ValueError("field '%s' must have shape %r" % (name, (nc,) + self.shape))
+        self._check(self._lib.fg_set_field(self._h, name.encode(), _dp(value)))
+
+    def enable_stage_timing(self, on=True):
+        self._check(self._lib.fg_enable_stage_timing(self._h, 1 if on else 0))
+
+    def stage_times(self):
+        ms = np.zeros(len(KERNELS))
+        cnt = ctypes.c_long(0)
+        self._lib.fg_get_stage_times(self._h, _dp(ms), ctypes.byref(cnt))
+        return dict(zip(KERNELS, ms.tolist())), cnt.value
+
+    def device_pointer(self, name, comp):
+        return self._lib.fg_device_pointer(self._h, name.encode(), int(comp))

@@ -1,0 +1,133 @@
+/* fibergen_amd -- C ABI of the MI355X-native Lippmann-Schwinger solver.
+ *
+ * This is the drop-in boundary for fibergen's hot path.
+ * The reference has no C ABI of its own: the path is reached through the
+ * boost.python class FG (src/fibergen.cpp:27142-27187) and the C++ class
+ * LSSolver<double,double,3> behind it.  Each entry point below names the
+ * reference member it stands in for (F: = /root/reference/src/fibergen.cpp).
+ * A reference-side binding would call these from FG<T,R,DIM>::run_actions
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *  - plain C: pointers and sizes only, no exceptions cross the boundary;
+ *  - every function returning int returns FG_OK (0) or FG_ERROR (1); the
+ *    message is available from fg_last_error();
+ *  - host arrays are float64, C order [ncomp][nx][ny][nz] without z padding,
+ *    component order 11,22,33,23,13,12 with plain tensor shear components;
+ *  - all work is enqueued on the solver's own HIP stream; calls that return
+ *    data synchronise that stream, nothing else.
+ *  - not re-entrant per solver object (like the reference, F:380-406); distinct
+ *    solver objects may be driven from distinct threads.
+ */
+#ifndef FIBERGEN_AMD_H
+#define FIBERGEN_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FG_OK 0
+#define FG_ERROR 1
+#define FG_ABI_VERSION 1
+
+/* mixing_rule option values (F:15129, create_mixing_rule) */
+#define FG_MIXING_VOIGT 0
+#define FG_MIXING_LAMINATE 1
+
+/* stages of one basic-scheme pass, for fg_run_stage (each is one reference routine) */
+#define FG_STAGE_STRESS 0        /* calcStressDiff            F:18030-18033, F:18134-18184 : epsilon -> tau   */
+#define FG_STAGE_DIV 1           /* divOperatorStaggered      F:18853-18908                : tau -> f         */
+#define FG_STAGE_FFT_FORWARD 2   /* fftVector                 F:18481-18510                : f -> f_hat       */
+#define FG_STAGE_G0 3            /* G0OperatorFourierStaggered F:19749-19755, F:19834-19927 : f_hat -> u_hat  */
+#define FG_STAGE_FFT_INVERSE 4   /* fftInvVector              F:18513-18528                : u_hat -> u       */
+#define FG_STAGE_EPS 5           /* epsOperatorStaggered      F:18614-18692 (+ component_norm F:10127) : u -> epsilon */
+#define FG_STAGE_ITERATION 6     /* basicScheme               F:20558-20578                                    */
+#define FG_STAGE_STRESS_CONST 7  /* calcStressConst           F:17973-18020                : epsilon -> tau   */
+
+typedef struct fg_solver fg_solver;
+
+/* convergence callback, consulted once per iteration before the tolerance test
+ * (F:21215); return non-zero to stop.  Called on the caller's thread. */
+typedef int (*fg_callback)(void* user);
+
+int fg_abi_version(void);
+
+/* Last error message of `s`, or (s == NULL) of the last failed fg_create on this thread. */
+const char* fg_last_error(const fg_solver* s);
+
+/* LSSolver::LSSolver(nx,ny,nz,dx,dy,dz)  F:14780-14892.  Allocates the strain field,
+ * the polarisation/displacement work fields and the FFT plan on HIP device `device`.
+ * Returns NULL on failure (no GPU, out of memory, bad sizes). */
+fg_solver* fg_create(int nx, int ny, int nz, double dx, double dy, double dz, int device);
+void fg_destroy(fg_solver* s);
+
+/* Materials: the <materials> block of readSettings  F:15177-15299 after parameter conversion
+ * (F:7333-7454).  Phase order = materials order.  phi may be NULL to keep the current field. */
+int fg_set_num_phases(fg_solver* s, int nphases);
+int fg_set_phase(fg_solver* s, int p, double mu, double lambda, const double* phi /* [nx][ny][nz] */);
+/* interface normals for laminate mixing (LSSolver::_normals, F:14717) */
+int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
+
+/* Solver settings of readSettings  F:15046-15094.  Keys (double): tol, abs_tol, bc_tol,
+ * ref_scale, bc_relax, mu_0, lambda_0 (the <ref> material), eps_g, eps_a (<laminate_mixing>).
+ * Keys (integer): maxiter, mixing_rule (FG_MIXING_*), update_ref (0 = "never"). */
+int fg_set_option_d(fg_solver* s, const char* key, double value);
+int fg_set_option_i(fg_solver* s, const char* key, long value);
+
+/* setBCProjector  F:20599-20665: symmetric 6x6 Voigt projector, row-major. */
+int fg_set_bc_projector(fg_solver* s, const double* P36);
+int fg_set_convergence_callback(fg_solver* s, fg_callback cb, void* user);
+/* FG::cancel  F:25190-25193: makes a running fg_run_load_case fail at the next iteration. */
+int fg_cancel(fg_solver* s);
+
+/* setStrain + setStress + LSSolver::run  F:21247-21398 (one load step, method=basic,
+ * gamma_scheme=staggered).  S may be NULL (= 0).  *failed receives the reference's
+ * return value (1 = stopped on an error such as a NaN residual, F:21202-21208). */
+int fg_run_load_case(fg_solver* s, const double* E6, const double* S6, int* failed);
+
+/* n passes of basicScheme without convergence logic, and the same bracketed by HIP
+ * events on the solver stream (benchmarks). */
+int fg_iterate(fg_solver* s, const double* E6, int n);
+int fg_time_iterations(fg_solver* s, const double* E6, int n, double* elapsed_ms);
+
+/* results: getResiduals F:14766, iteration count, getSolveTime F:14767, calcMeanStress
+ * F:17793-17811, calcMeanStrain (average F:10171), getVolumeFraction */
+long fg_get_iterations(const fg_solver* s);
+int fg_get_residuals(const fg_solver* s, double* out, int capacity); /* returns the count */
+double fg_get_solve_time(const fg_solver* s);
+int fg_mean_stress(fg_solver* s, double* out6);
+int fg_mean_strain(fg_solver* s, double* out6);
+int fg_volume_fraction(fg_solver* s, int p, double* out);
+
+/* calcRefMaterial  F:22283-22313 and the resulting (mu_0, lambda_0) */
+int fg_calc_ref_material(fg_solver* s);
+int fg_get_ref_material(const fg_solver* s, double* mu_0, double* lambda_0);
+
+/* get_raw_field  F:15396-15684.  Names: "epsilon" (6), "sigma" (6, evaluated with C0 = 0),
+ * "u" (3), "phi" (nphases), "normals" (3); work buffers for stage tests: "tau" (6), "f" (3),
+ * "f_hat" (3 complex components in the padded layout [nx][ny][nz/2+1][2]), "sumsq" (6 scalars). */
+int fg_field_components(const fg_solver* s, const char* name);
+int fg_get_field(fg_solver* s, const char* name, double* out);
+int fg_set_field(fg_solver* s, const char* name, const double* in);
+
+/* Device-side access for zero-copy callers (slab-decomposed driver): pointer to padded
+ * component `comp` ([nx][ny][2*(nz/2+1)] doubles) and the solver's hipStream_t. */
+void* fg_device_pointer(fg_solver* s, const char* name, int comp);
+void* fg_get_stream(fg_solver* s);
+int fg_synchronize(fg_solver* s);
+
+/* Single stages on the solver's buffers (parity tests and profiling).  For FG_STAGE_G0,
+ * E6[0] carries alpha (default -1).  With timing enabled every kernel of a pass is bracketed
+ * by HIP events on the solver stream; fg_get_stage_times reports the accumulated milliseconds
+ * of the FG_NUM_TIMED_KERNELS kernels in launch order: stress, div, r2c_z, c2c_y_fwd,
+ * c2c_x_fwd, g0, c2c_x_inv, c2c_y_inv, c2r_z, eps_norm, and the number of passes timed. */
+#define FG_NUM_TIMED_KERNELS 10
+int fg_run_stage(fg_solver* s, int stage, const double* E6);
+int fg_enable_stage_timing(fg_solver* s, int enable);
+int fg_get_stage_times(const fg_solver* s, double* ms /* [FG_NUM_TIMED_KERNELS] */, long* count);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FIBERGEN_AMD_H */

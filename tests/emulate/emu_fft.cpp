@@ -1,0 +1,114 @@
+// Host emulation of the FFT kernels' thread bodies (test infrastructure).
+// Runs every phase for all threads of a block in turn, which is what the
+// device does between __syncthreads(); build with g++ -DFG_HOST_EMULATION.
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "../../fibergen_amd/csrc/fg_fft_kernels.h"
+#include "../../fibergen_amd/csrc/fg_fft_tables.h"
+
+using namespace fg;
+using namespace fg::fft;
+
+template <class K, class Args, int PH>
+struct PhaseLoop {
+  static void run(std::vector<typename K::Regs>& regs, int block, double* lds, const Args& a) {
+    for (int tid = 0; tid < K::THREADS; ++tid) K::template phase<PH>(regs[tid], block, tid, lds, a);
+    if constexpr (PH + 1 < K::NPHASE) PhaseLoop<K, Args, PH + 1>::run(regs, block, lds, a);
+  }
+};
+
+template <class K, class Args>
+static void run_blocks(long nblocks, const Args& a) {
+  std::vector<typename K::Regs> regs(K::THREADS);
+  std::vector<double> lds(K::LDS_DOUBLES);
+  for (long b = 0; b < nblocks; ++b) {
+    for (auto& x : lds) x = NAN;  // catch reads of never-written LDS
+    PhaseLoop<K, Args, 0>::run(regs, (int)b, lds.data(), a);
+  }
+}
+
+template <int N, int C>
+static void strided_dir(StridedArgs a, long nblocks, int dir) {
+  if (dir < 0) run_blocks<StridedKernel<N, C, -1>, StridedArgs>(nblocks, a);
+  else run_blocks<StridedKernel<N, C, +1>, StridedArgs>(nblocks, a);
+}
+
+extern "C" {
+
+// c2c along a strided axis of data[nouter][N][ncols] (ls = ncols, os = N*ncols), device tile geometry
+int emu_strided(int N, int dir, double* data, int ncols, int nouter, double scale) {
+  std::vector<cplx> tw = make_pass_twiddles(N);
+  StridedArgs a;
+  a.data = reinterpret_cast<cplx*>(data);
+  a.ls = ncols;
+  a.os = (long)N * ncols;
+  a.ncols = ncols;
+  a.scale = scale;
+  a.tw = tw.data();
+#define CASE(n)                                                  \
+  if (N == n) {                                                  \
+    constexpr int C = TileCols<n>::value;                        \
+    a.tiles_per_outer = (ncols + C - 1) / C;                     \
+    strided_dir<n, C>(a, (long)a.tiles_per_outer * nouter, dir); \
+    return 0;                                                    \
+  }
+  CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) CASE(512) CASE(1024)
+#undef CASE
+  return 1;
+}
+
+int emu_r2c(int nz, double* data, long nrows) {
+  int M = nz / 2;
+  std::vector<cplx> tw = make_pass_twiddles(M);
+  std::vector<cplx> wz = make_unit_roots(nz, M + 1);
+  ZArgs a = {data, nrows, 2 * (nz / 2 + 1), tw.data(), wz.data()};
+#define CASE(m)                                                              \
+  if (M == m) {                                                              \
+    constexpr int l = ZLines<m>::value;                                      \
+    run_blocks<R2CKernel<m, l>, ZArgs>((nrows + l - 1) / l, a);              \
+    return 0;                                                                \
+  }
+  CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) CASE(512) CASE(1024)
+#undef CASE
+  return 1;
+}
+
+int emu_c2r(int nz, double* data, long nrows) {
+  int M = nz / 2;
+  std::vector<cplx> tw = make_pass_twiddles(M);
+  std::vector<cplx> wz = make_unit_roots(nz, M + 1);
+  ZArgs a = {data, nrows, 2 * (nz / 2 + 1), tw.data(), wz.data()};
+#define CASE(m)                                                              \
+  if (M == m) {                                                              \
+    constexpr int l = ZLines<m>::value;                                      \
+    run_blocks<C2RKernel<m, l>, ZArgs>((nrows + l - 1) / l, a);              \
+    return 0;                                                                \
+  }
+  CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) CASE(512) CASE(1024)
+#undef CASE
+  return 1;
+}
+// generic fall-backs
+void emu_dft_strided(const double* src, double* dst, int n, int ncols, int nouter, int dir, double scale) {
+  std::vector<cplx> w = make_unit_roots(n, n);
+  for (int o = 0; o < nouter; ++o)
+    for (int c = 0; c < ncols; ++c)
+      for (int k = 0; k < n; ++k)
+        dft_strided_point(reinterpret_cast<const cplx*>(src), reinterpret_cast<cplx*>(dst),
+                          (long)o * n * ncols + c, ncols, n, k, dir, scale, w.data());
+}
+void emu_r2c_generic(const double* src, double* dst, int nz, long nrows) {
+  std::vector<cplx> w = make_unit_roots(nz, nz);
+  int nzc = nz / 2 + 1, nzp = 2 * nzc;
+  for (long r = 0; r < nrows; ++r)
+    for (int k = 0; k < nzc; ++k) r2c_point(src + r * nzp, reinterpret_cast<cplx*>(dst + r * nzp), nz, k, w.data());
+}
+void emu_c2r_generic(const double* src, double* dst, int nz, long nrows) {
+  std::vector<cplx> w = make_unit_roots(nz, nz);
+  int nzc = nz / 2 + 1, nzp = 2 * nzc;
+  for (long r = 0; r < nrows; ++r)
+    for (int m = 0; m < nz; ++m) c2r_point(reinterpret_cast<const cplx*>(src + r * nzp), dst + r * nzp, nz, m, w.data());
+}
+}

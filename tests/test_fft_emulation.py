@@ -1,0 +1,81 @@
+"""Host emulation of the FFT kernels' per-thread phase code (the very functions the HIP
+kernels call between __syncthreads) against numpy.fft.  CPU only; validates index math,
+twiddles, LDS padding map and the FFTW r2c/c2r conventions without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dp = ctypes.POINTER(ctypes.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("emu") / "emu_fft.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFG_HOST_EMULATION", "-ffp-contract=off", "-shared", "-fPIC",
+                           "-o", out, os.path.join(ROOT, "tests", "emulate", "emu_fft.cpp")])
+    return ctypes.CDLL(out)
+
+
+@pytest.mark.parametrize("N", [8, 16, 32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("d", [-1, 1])
+def test_strided_c2c(emu, N, d):
+    rng = np.random.default_rng(N)
+    ncols, nouter = 11, 2  # ragged last tile
+    x = rng.standard_normal((nouter, N, ncols)) + 1j * rng.standard_normal((nouter, N, ncols))
+    y = x.copy()
+    assert emu.emu_strided(N, d, P(y.view(np.float64)), ncols, nouter, ctypes.c_double(0.5)) == 0
+    ref = (np.fft.fft(x, axis=1) if d < 0 else np.fft.ifft(x, axis=1) * N) * 0.5
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-14
+
+
+@pytest.mark.parametrize("nz", [16, 32, 64, 128, 256, 512, 1024, 2048])
+def test_r2c_c2r(emu, nz):
+    rng = np.random.default_rng(nz)
+    nrows = 5
+    nzc = nz // 2 + 1
+    x = rng.standard_normal((nrows, nz))
+    buf = np.full((nrows, 2 * nzc), np.nan)
+    buf[:, :nz] = x
+    assert emu.emu_r2c(nz, P(buf), ctypes.c_long(nrows)) == 0
+    ref = np.fft.rfft(x, axis=1)
+    assert np.abs(buf.view(np.complex128) - ref).max() / np.abs(ref).max() < 1e-14
+    # non-Hermitian input: imaginary parts of DC / Nyquist must be ignored like FFTW's c2r
+    X = rng.standard_normal((nrows, nzc)) + 1j * rng.standard_normal((nrows, nzc))
+    buf = X.copy().view(np.float64).copy()
+    assert emu.emu_c2r(nz, P(buf), ctypes.c_long(nrows)) == 0
+    ref = np.fft.irfft(X, n=nz, axis=1) * nz
+    assert np.abs(buf[:, :nz] - ref).max() / np.abs(ref).max() < 1e-14
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 10, 11, 33, 41])
+def test_generic_dft(emu, n):
+    rng = np.random.default_rng(n)
+    ncols, nouter = 3, 2
+    x = rng.standard_normal((nouter, n, ncols)) + 1j * rng.standard_normal((nouter, n, ncols))
+    for d in (-1, 1):
+        y = np.zeros_like(x)
+        emu.emu_dft_strided(P(x.view(np.float64)), P(y.view(np.float64)), n, ncols, nouter, d, ctypes.c_double(1.0))
+        ref = np.fft.fft(x, axis=1) if d < 0 else np.fft.ifft(x, axis=1) * n
+        assert np.abs(y - ref).max() < 1e-12 * max(1, np.abs(ref).max())
+    nrows = 4
+    nzc = n // 2 + 1
+    xr = rng.standard_normal((nrows, n))
+    src = np.zeros((nrows, 2 * nzc))
+    src[:, :n] = xr
+    dst = np.zeros((nrows, 2 * nzc))
+    emu.emu_r2c_generic(P(src), P(dst), n, ctypes.c_long(nrows))
+    assert np.abs(dst.view(np.complex128) - np.fft.rfft(xr, axis=1)).max() < 1e-12
+    X = rng.standard_normal((nrows, nzc)) + 1j * rng.standard_normal((nrows, nzc))
+    src = X.copy().view(np.float64).copy()
+    dst = np.zeros((nrows, 2 * nzc))
+    emu.emu_c2r_generic(P(src), P(dst), n, ctypes.c_long(nrows))
+    ref = np.fft.irfft(X, n=n, axis=1) * n
+    assert np.abs(dst[:, :n] - ref).max() < 1e-12 * max(1, np.abs(ref).max())

@@ -1,0 +1,251 @@
+"""GPU parity: every stage kernel and the full basic-scheme loop, called through the
+C ABI (libfibergen_amd.so), against the NumPy oracle on the same seeded inputs.
+
+Tolerances (float64): element-wise stages are expected bit-exact (the library is built
+without FMA contraction and follows the reference's operation order); they are asserted
+to 1e-14 relative so that a libm difference of an ulp in the host-side k-tables cannot
+flip the test.  FFT-containing quantities: 1e-12 relative max-norm per stage, 1e-9 on
+fields after a converged run, 1e-10 on mean stresses / effective moduli (north_star asks
+1e-6 on effective moduli).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_gpu_solver, make_oracle, rel_err, two_phase_setup
+
+pytestmark = pytest.mark.gpu
+
+GRIDS = [
+    ((16, 16, 16), (1.0, 1.0, 1.0)),      # all axes on the LDS radix path
+    ((32, 16, 64), (1.0, 2.0, 0.5)),      # mixed lengths, anisotropic cell
+    ((12, 10, 6), (1.0, 1.0, 1.0)),       # generic DFT path on every axis
+    ((41, 33, 11), (41.0, 33.0, 11.0)),   # the reference's self-test grid F:27271 (odd, prime)
+    ((10, 1, 1), (1.0, 1.0, 1.0)),        # laminate demo grid (demo/elasticity/laminate)
+    ((8, 16, 5), (1.0, 1.0, 1.0)),        # odd nz
+]
+EXACT = {}
+
+
+def note(key, a, b):
+    EXACT[key] = bool(np.array_equal(a, b))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def dump_exactness():
+    yield
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/stage_bit_exactness.json", "w") as f:
+        json.dump(EXACT, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("grid,dims", GRIDS)
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_stress_stage(grid, dims, mixing):
+    rng = np.random.default_rng(10)
+    o = make_oracle(grid, dims, mixing)
+    s = make_gpu_solver(grid, dims, mixing, mu_0=0.77, lambda_0=0.31)
+    eps = rng.standard_normal((6,) + grid)
+    s.set_field("epsilon", eps)
+    s.run_stage("stress")
+    got = s.get_field("tau")
+    ref = o.calc_stress(0.77, 0.31, eps)
+    note("stress/%s/%s" % (mixing, "x".join(map(str, grid))), got, ref)
+    assert rel_err(got, ref) < 1e-14
+    # sigma = C:eps (C0 = 0), get_raw_field('sigma') F:15496-15508
+    assert rel_err(s.get_field("sigma"), o.calc_stress(0.0, 0.0, eps)) < 1e-14
+    # mean stress (tree-reduced on the GPU): summation order differs => 1e-13
+    o.eps = eps
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-12
+    assert rel_err(s.mean_strain(), o.mean_strain()) < 1e-12 + 1e-13
+
+
+@pytest.mark.parametrize("grid,dims", GRIDS)
+def test_div_and_eps_stages(grid, dims):
+    rng = np.random.default_rng(11)
+    o = make_oracle(grid, dims)
+    s = make_gpu_solver(grid, dims)
+    tau = rng.standard_normal((6,) + grid)
+    s.set_field("tau", tau)
+    s.run_stage("div")
+    got = s.get_field("f")
+    ref = o.div_staggered(tau)
+    note("div/" + "x".join(map(str, grid)), got, ref)
+    assert rel_err(got, ref) < 1e-14
+    u = rng.standard_normal((3,) + grid)
+    E = np.array([0.3, -0.2, 0.1, 0.05, -0.07, 0.02])
+    s.set_field("u", u)
+    s.run_stage("eps", E)
+    got = s.get_field("epsilon")
+    ref = o.eps_staggered(E, u)
+    note("eps/" + "x".join(map(str, grid)), got, ref)
+    assert rel_err(got, ref) < 1e-14
+    # fused sums of squares feeding component_norm F:10127
+    assert rel_err(s.get_field("sumsq"), (ref.reshape(6, -1) ** 2).sum(axis=1)) < 1e-12
+
+
+@pytest.mark.parametrize("grid,dims", GRIDS + [((64, 64, 64), (1.0, 1.0, 1.0)), ((128, 8, 256), (1.0, 1.0, 1.0))])
+def test_fft_forward_inverse(grid, dims):
+    rng = np.random.default_rng(12)
+    o = make_oracle(grid, dims) if max(grid) <= 64 else None
+    s = make_gpu_solver(grid, dims)
+    f = rng.standard_normal((3,) + grid)
+    s.set_field("f", f)
+    s.run_stage("fft_forward")
+    got = s.get_field("f_hat")
+    ref = np.fft.rfftn(f, axes=(1, 2, 3)) / float(np.prod(grid))
+    assert rel_err(got, ref) < 1e-13
+    # inverse of an arbitrary (non-Hermitian) spectrum: FFTW c2r semantics
+    nzc = grid[2] // 2 + 1
+    spec = rng.standard_normal((3,) + grid[:2] + (nzc,)) + 1j * rng.standard_normal((3,) + grid[:2] + (nzc,))
+    s.set_field("f_hat", spec)
+    s.run_stage("fft_inverse")
+    got = s.get_field("u")
+    ref = np.fft.irfftn(spec, s=grid, axes=(1, 2, 3)) * float(np.prod(grid))
+    assert rel_err(got, ref) < 1e-13
+
+
+@pytest.mark.parametrize("grid,dims", GRIDS)
+def test_green_operator_stage(grid, dims):
+    rng = np.random.default_rng(13)
+    o = make_oracle(grid, dims)
+    s = make_gpu_solver(grid, dims, mu_0=1324.3, lambda_0=324.2)  # F:24007-24008
+    nzc = grid[2] // 2 + 1
+    spec = rng.standard_normal((3,) + grid[:2] + (nzc,)) + 1j * rng.standard_normal((3,) + grid[:2] + (nzc,))
+    for alpha in (-1.0, 1.0):
+        s.set_field("f_hat", spec)
+        s.run_stage("g0", np.array([alpha, 0, 0, 0, 0, 0.0]))
+        got = s.get_field("f_hat")
+        ref = o.g0_apply(1324.3, 324.2, spec, alpha)
+        mask = np.isfinite(ref)  # ny = nz = 1 grids: only the (0,0,0) bin is 0/0 before being zeroed
+        assert mask.all()
+        note("g0/%g/%s" % (alpha, "x".join(map(str, grid))), got, ref)
+        assert rel_err(got, ref) < 1e-14
+
+
+@pytest.mark.parametrize("grid,dims", GRIDS)
+def test_staggered_epsG0div_identity_on_gpu(grid, dims):
+    """The reference's own self test F:24129-24151 run through the HIP stages."""
+    rng = np.random.default_rng(14)
+    s = make_gpu_solver(grid, dims, mu_0=1324.3, lambda_0=324.2)
+    u0 = rng.standard_normal((3,) + grid)
+    s.set_field("u", u0)
+    s.run_stage("eps", np.zeros(6))
+    e_org = s.get_field("epsilon")
+    s.run_stage("stress_const")
+    s.run_stage("div")
+    s.run_stage("fft_forward")
+    s.run_stage("g0", np.array([1.0, 0, 0, 0, 0, 0]))
+    s.run_stage("fft_inverse")
+    s.run_stage("eps", np.zeros(6))
+    e = s.get_field("epsilon")
+    diff = np.abs(e - e_org).reshape(6, -1).max(axis=1)
+    assert np.linalg.norm(diff) <= np.sqrt(np.finfo(float).eps) * max(1.0, np.abs(e_org).max())
+
+
+@pytest.mark.parametrize("grid,dims", GRIDS)
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_one_iteration(grid, dims, mixing):
+    rng = np.random.default_rng(15)
+    o = make_oracle(grid, dims, mixing)
+    s = make_gpu_solver(grid, dims, mixing)
+    o.calc_ref_material()
+    mu0, lam0 = s.calc_ref_material()
+    assert mu0 == pytest.approx(o.mu_0, rel=1e-15)
+    assert lam0 == 0.0
+    eps = 0.1 * rng.standard_normal((6,) + grid)
+    E = np.array([1.0, 0.2, -0.3, 0.1, 0.0, 0.4])
+    s.set_field("epsilon", eps)
+    s.run_stage("iteration", E)
+    got = s.get_field("epsilon")
+    ref = o.basic_scheme(E, eps)
+    assert rel_err(got, ref) < 1e-12
+
+
+@pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (32, 32, 32)])
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_full_run_matches_oracle(grid, mixing):
+    tol = 1e-8
+    o = make_oracle(grid, mixing=mixing, tol=tol)
+    s = make_gpu_solver(grid, mixing=mixing, tol=tol)
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    assert o.run(E) is False
+    assert s.run(E) is False
+    assert s.iterations == o.iterations
+    r_gpu, r_ref = np.array(s.residuals), np.array(o.residuals)
+    assert len(r_gpu) == len(r_ref)
+    # residuals are differences of norms: compare with an absolute floor
+    assert np.abs(r_gpu - r_ref).max() < 1e-11
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(s.get_field("sigma"), o.get_field("sigma")) < 1e-9
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-10
+    assert rel_err(s.get_field("u"), o.get_field("u")) < 1e-8
+    assert s.solve_time > 0
+
+
+def test_homogeneous_and_callbacks():
+    grid = (16, 8, 32)
+    from fibergen_amd import LSSolver
+    s = LSSolver(*grid)
+    s.set_num_phases(1)
+    s.set_phase(0, 1.3, 0.9, np.ones(grid))
+    s.set_options(tol=1e-10)
+    E = np.array([1.0, 0.5, -0.2, 0.1, 0.3, -0.4])
+    assert s.run(E) is False
+    assert np.abs(s.get_field("epsilon") - E[:, None, None, None]).max() < 1e-13
+    assert s.residuals[0] == pytest.approx(1.0, abs=1e-14)
+    # convergence callback stops the loop after the first iteration (F:21215)
+    s2 = make_gpu_solver((16, 16, 16), tol=1e-12)
+    calls = []
+    s2.set_convergence_callback(lambda: calls.append(1) or True)
+    assert s2.run(E) is False
+    assert len(calls) == 1 and s2.iterations == 1 and len(s2.residuals) == 1
+    # maxiter
+    s2.set_convergence_callback(None)
+    s2.set_options(maxiter=3)
+    assert s2.run(E) is False
+    assert s2.iterations == 3 and len(s2.residuals) == 3
+
+
+def test_mixed_bc_uniaxial_stress():
+    """setBCProjector / calcBCMean / applyBCProjector F:20599-20665 on the GPU path."""
+    grid = (16, 16, 16)
+    o = make_oracle(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    s = make_gpu_solver(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    P = np.zeros((6, 6))
+    P[0, 0] = 1.0
+    E = np.array([0.01, 0, 0, 0, 0, 0])
+    assert o.run(E, S0=np.zeros(6), P=P) is False
+    s.set_bc_projector(P)
+    assert s.run(E, np.zeros(6)) is False
+    assert s.iterations == o.iterations
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-9
+    assert np.abs(s.mean_stress()[1:]).max() < 1e-7
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8
+
+
+def test_error_paths():
+    from fibergen_amd import LSSolver
+    s = LSSolver(8, 8, 8)
+    with pytest.raises(RuntimeError, match="No materials"):
+        s.run(np.zeros(6))
+    with pytest.raises(RuntimeError):
+        s.set_num_phases(9)
+    s.set_num_phases(3)
+    third = np.full((8, 8, 8), 1.0 / 3.0)
+    for p in range(3):
+        s.set_phase(p, 1.0 + p, 1.0, third)
+    s.set_normals(np.zeros((3, 8, 8, 8)))
+    s.set_options(mixing_rule="laminate")
+    with pytest.raises(RuntimeError, match="two phase"):
+        s.run(np.array([1.0, 0, 0, 0, 0, 0]))
+    with pytest.raises(RuntimeError, match="projector"):
+        s.set_bc_projector(np.full((6, 6), 0.3))
+    with pytest.raises(RuntimeError, match="Unknown field"):
+        s.get_field("nonsense")
+    # NaN in the solution => run() reports failure (F:21202-21208)
+    s2 = make_gpu_solver((8, 8, 8))
+    s2.set_phase(1, float("nan"), 1.0)
+    assert s2.run(np.array([1.0, 0, 0, 0, 0, 0])) is True
