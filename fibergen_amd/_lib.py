@@ -14,6 +14,14 @@ LIB_PATH = os.path.join(_HERE, "libfibergen_amd.so")
 c_double_p = ctypes.POINTER(ctypes.c_double)
 CALLBACK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
 
+
+
+class FgFiber(ctypes.Structure):
+    """struct fg_fiber of include/fibergen_amd.h"""
+    _fields_ = [("kind", ctypes.c_int), ("material", ctypes.c_int), ("c", ctypes.c_double * 3),
+                ("a", ctypes.c_double * 3), ("L", ctypes.c_double), ("R", ctypes.c_double)]
+
+
 # name -> (restype, argtypes); mirrors include/fibergen_amd.h one to one
 SIGNATURES = {
     "fg_abi_version": (ctypes.c_int, []),
@@ -49,6 +57,10 @@ SIGNATURES = {
     "fg_run_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p]),
     "fg_enable_stage_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "fg_get_stage_times": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long)]),
+    "fg_voxelize": (ctypes.c_int, [ctypes.POINTER(FgFiber), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_double, ctypes.c_double, ctypes.c_double, c_double_p, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p, c_double_p,
+                                   ctypes.c_char_p, ctypes.c_int]),
 }
 
 _lib = None

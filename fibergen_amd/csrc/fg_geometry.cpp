@@ -1,0 +1,349 @@
+// Host-side voxeliser: analytic shapes -> phase volume fractions and interface normals.
+//
+// Pre-processing that runs once per project (not part of the per-iteration hot path),
+// kept native like the reference's.  Restates, for the shapes the elasticity demos use
+// (capsule / sphere and half space placed with <place_fiber>):
+//   LSSolver::initPhi               F:17489-17581   one closest-shape query per voxel centre
+//   LSSolver::integratePhiVoxel     F:16622-16752   adaptive octree refinement + plane cuts
+//   halfspace_box_cut_volume        F:1385-1577     volume of a box cut by a plane (divergence theorem)
+//   CapsuleFiber / HalfSpaceFiber   F:5237-5524, F:5529-5640   signed distance, gradient, curvature
+//   FiberCluster::closestFibers     F:3336-3361     shapes within r of a point
+//   sampleSlice(NORMALS)            F:6905-6925     normal = distance gradient of the closest shape
+// normalizePhi (F:17588-17646) is applied by the caller.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/fibergen_amd.h"
+
+namespace {
+
+struct V3 {
+  double v[3];
+  double& operator[](int i) { return v[i]; }
+  double operator[](int i) const { return v[i]; }
+};
+inline V3 mk(double a, double b, double c) { V3 r; r.v[0] = a; r.v[1] = b; r.v[2] = c; return r; }
+inline V3 operator+(V3 a, V3 b) { return mk(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+inline V3 operator-(V3 a, V3 b) { return mk(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+inline V3 operator*(double s, V3 a) { return mk(s * a[0], s * a[1], s * a[2]); }
+inline double dot(V3 a, V3 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
+
+const double kEps = std::numeric_limits<double>::epsilon();
+
+// orthonormal_vector  F:605-621
+V3 orthonormal(V3 v) {
+  int i_max = 0, i_min = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (std::fabs(v[i]) < std::fabs(v[i_min])) i_min = i;
+    if (std::fabs(v[i]) > std::fabs(v[i_max])) i_max = i;
+  }
+  if (i_min == i_max) i_min = (i_max + 1) % 3;
+  V3 x = v;
+  x[i_min] = -v[i_max];
+  x[i_max] = v[i_min];
+  x = x - dot(x, v) * x;
+  const double nx = norm(x);
+  return (1.0 / nx) * x;
+}
+
+struct Shape {
+  int kind;      // 0 capsule, 1 half space
+  int material;
+  // capsule
+  V3 a, r, c1, c, c2;
+  double R, L0, L, B;
+  // half space
+  V3 p, n;
+
+  // distanceTo(p, x): signed distance, x = closest surface point
+  double distance(V3 q, V3& x) const {
+    if (kind == 1) {
+      const double d = dot(q - p, n);
+      x = q - d * n;
+      return d;
+    }
+    double t = dot(q - c1, a);
+    t = std::min(std::max(0.0, t), L);
+    x = c1 + t * a;
+    double d = norm(q - x);
+    if (d < kEps * R) x = x + r;
+    else x = x + (R / d) * (q - x);
+    return d - R;
+  }
+  // distanceGrad
+  V3 grad(V3 q) const {
+    if (kind == 1) return n;
+    double t = dot(q - c1, a);
+    t = std::min(std::max(0.0, t), L);
+    V3 g = q - c1 - t * a;
+    const double ng = norm(g);
+    if (ng < std::sqrt(kEps)) return ((t < 0.5 * L) ? -1.0 : 1.0) * a;
+    return (1.0 / ng) * g;
+  }
+  double curvature() const { return kind == 1 ? 0.0 : 1.0 / R; }
+  double bb_distance_min(V3 q) const {  // F:3046
+    if (kind == 1) return -std::numeric_limits<double>::infinity();
+    return norm(q - c) - B;
+  }
+  double volume() const {
+    if (kind == 1) return std::numeric_limits<double>::infinity();
+    return M_PI * R * R * (L + 4.0 / 3.0 * R);
+  }
+};
+
+struct Info {
+  V3 x;
+  const Shape* shape;
+  double d;
+};
+
+// halfspace_box_cut_volume: volume of the part of the box [x0, x0+(dx,dy,dz)] with (y - x).n < 0
+double box_cut_volume(V3 x, V3 n, V3 x0, double dx, double dy, double dz) {
+  const double ext[3] = {dx, dy, dz};
+  V3 vert[8];
+  vert[0] = x0;
+  vert[1] = x0 + mk(dx, 0, 0);
+  vert[2] = x0 + mk(0, dy, 0);
+  vert[3] = x0 + mk(0, 0, dz);
+  vert[4] = vert[1] + mk(0, dy, 0);
+  vert[5] = vert[2] + mk(0, 0, dz);
+  vert[6] = vert[3] + mk(dx, 0, 0);
+  vert[7] = vert[6] + mk(0, dy, 0);
+  (void)ext;
+  static const int edges[12][2] = {{0, 1}, {2, 4}, {3, 6}, {5, 7}, {0, 2}, {1, 4},
+                                   {3, 5}, {6, 7}, {0, 3}, {1, 6}, {2, 5}, {4, 7}};
+  static const int faces[6][4] = {{8, 6, -10, -4}, {9, 7, -11, -5}, {0, 9, -2, -8},
+                                  {1, 11, -3, -10}, {0, 5, -1, -4}, {2, 7, -3, -6}};
+  static const int face_sign[6] = {-1, 1, -1, 1, -1, 1};
+  bool inside[8];
+  int num_inside = 0;
+  for (int i = 0; i < 8; ++i) {
+    inside[i] = dot(vert[i] - x, n) < 0;
+    num_inside += inside[i] ? 1 : 0;
+  }
+  double cut_t[6];
+  int cut_of_edge[12];
+  int ncut = 0, any_edge = -1;
+  for (int e = 0; e < 12; ++e) {
+    if ((inside[edges[e][0]] ? 1 : 0) + (inside[edges[e][1]] ? 1 : 0) == 1) {
+      cut_t[ncut] = dot(x - vert[edges[e][0]], n) / n[e / 4];
+      cut_of_edge[e] = ncut;
+      any_edge = e;
+      ++ncut;
+    } else {
+      cut_of_edge[e] = -1;
+    }
+  }
+  if (ncut == 0) return inside[0] ? dx * dy * dz : 0.0;
+  auto unit = [](int k, double s) { V3 u = mk(0, 0, 0); u[k] = s; return u; };
+  const V3 xi = vert[edges[any_edge][0]] + unit(any_edge / 4, cut_t[cut_of_edge[any_edge]]);
+  const bool flip = num_inside > 4;
+  static const int cross_idx[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+  V3 pts[5];
+  double V = 0.0;
+  for (int f = 0; f < 6; ++f) {
+    const int ni = f >> 1;
+    int np = 0;
+    for (int i = 0; i < 4; ++i) {
+      int e = faces[f][i];
+      int i1 = 0, i2 = 1;
+      if (e < 0) { e = -e; i1 = 1; i2 = 0; }
+      if (np == 0 && (inside[edges[e][i1]] != flip)) {
+        pts[np] = vert[edges[e][i1]];
+        if (pts[0][ni] == xi[ni]) break;
+        ++np;
+      }
+      if (cut_of_edge[e] >= 0) {
+        pts[np] = vert[edges[e][0]] + unit(e / 4, cut_t[cut_of_edge[e]]);
+        if (np == 0 && pts[0][ni] == xi[ni]) break;
+        ++np;
+      }
+      if (i < 3 && (inside[edges[e][i2]] != flip)) {
+        pts[np] = vert[edges[e][i2]];
+        if (np == 0 && pts[0][ni] == xi[ni]) break;
+        ++np;
+      }
+    }
+    if (np < 3) continue;
+    const int a1 = cross_idx[ni][0], a2 = cross_idx[ni][1];
+    double area = 0.0;
+    for (int i = 2; i < np; ++i)
+      area += std::fabs((pts[i - 1][a1] - pts[0][a1]) * (pts[i][a2] - pts[0][a2]) -
+                        (pts[i - 1][a2] - pts[0][a2]) * (pts[i][a1] - pts[0][a1]));
+    V += face_sign[f] * (pts[0][ni] - xi[ni]) * area;
+  }
+  V *= (1.0 / 6.0);
+  if (flip) V = dx * dy * dz - V;
+  return V;
+}
+
+// integratePhiVoxel  F:16622-16752
+double integrate_voxel(int levels, double tol, double r_voxel0, V3 p, double dx, double dy, double dz,
+                       std::vector<Info>& list) {
+  if (list.empty()) return 0.0;
+  double r_voxel = 0.5 * std::sqrt(dx * dx + dy * dy + dz * dz);
+  size_t i_min = 0;
+  for (size_t i = 1; i < list.size(); ++i)
+    if (list[i].d < list[i_min].d) i_min = i;
+  if (std::fabs(list[i_min].d) >= r_voxel) return (list[i_min].d < 0) ? dx * dy * dz : 0.0;
+  const V3 x0 = mk(p[0] - 0.5 * dx, p[1] - 0.5 * dy, p[2] - 0.5 * dz);
+  double V = 0.0;
+  const double V_max = dx * dy * dz;
+  if (levels < 0) {  // adaptive error estimate
+    const double K = list[i_min].shape->curvature();
+    const double Kd = r_voxel * K;
+    const double err = (Kd > 1) ? 1.0 : Kd * Kd * std::pow(r_voxel / r_voxel0, 2.0 / 3.0);
+    if (err < tol) levels = 0;
+  }
+  if (levels == 0) {
+    for (size_t i = 0; i < list.size(); ++i) {
+      const V3 n = list[i].shape->grad(list[i].x);
+      V += box_cut_volume(list[i].x, n, x0, dx, dy, dz);
+    }
+    return std::min(V, V_max);
+  }
+  levels--;
+  dx *= 0.5;
+  dy *= 0.5;
+  dz *= 0.5;
+  r_voxel *= 0.5;
+  std::vector<Info> sub;
+  sub.reserve(list.size());
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < 2; ++k) {
+        const V3 ps = mk(x0[0] + (i + 0.5) * dx, x0[1] + (j + 0.5) * dy, x0[2] + (k + 0.5) * dz);
+        sub.clear();
+        for (size_t q = 0; q < list.size(); ++q) {
+          list[q].d = list[q].shape->distance(ps, list[q].x);
+          if (std::fabs(list[q].d) >= r_voxel) {
+            if (list[q].d < 0) {  // sub-voxel completely inside this shape
+              V += dx * dy * dz;
+              sub.clear();
+              break;
+            }
+            continue;
+          }
+          sub.push_back(list[q]);
+        }
+        if (!sub.empty()) V += integrate_voxel(levels, tol, r_voxel0, ps, dx, dy, dz, sub);
+      }
+  return std::min(V, V_max);
+}
+
+}  // namespace
+
+extern "C" int fg_voxelize(const fg_fiber* fibers, int nfibers, int nx, int ny, int nz, double dx, double dy, double dz,
+                           const double* x0, int nphases, int matrix_mat, int smooth_levels, double smooth_tol,
+                           double* phi, double* normals, double* real_volume, char* err, int errlen) {
+  auto fail = [&](const std::string& m) {
+    if (err && errlen > 0) std::snprintf(err, errlen, "%s", m.c_str());
+    return FG_ERROR;
+  };
+  if (nx < 1 || ny < 1 || nz < 1 || nphases < 1 || !phi || !x0) return fail("fg_voxelize: bad arguments");
+  if (nfibers > 0 && !fibers) return fail("fg_voxelize: fibers is NULL");
+  std::vector<Shape> shapes(nfibers);
+  for (int i = 0; i < nfibers; ++i) {
+    const fg_fiber& f = fibers[i];
+    Shape& s = shapes[i];
+    s.kind = f.kind;
+    s.material = f.material;
+    if (f.material < 0 || f.material >= nphases) return fail("fg_voxelize: fiber material out of range");
+    const V3 c = mk(f.c[0], f.c[1], f.c[2]);
+    const V3 a = mk(f.a[0], f.a[1], f.a[2]);
+    const double na = norm(a);
+    if (f.kind == 0) {  // CapsuleFiber  F:5254-5275
+      s.L0 = std::fabs(f.L);
+      s.R = std::fabs(f.R);
+      s.L = std::max(0.0, s.L0 - (4.0 / 3.0) * s.R);
+      if (na != 0) s.a = (1.0 / na) * a;
+      else if (s.L != 0) return fail("CapsuleFiber: given nonzero fiber length without orientation vector!");
+      else s.a = mk(0, 0, 0);
+      s.c = c;
+      s.c1 = c - (s.L / 2) * s.a;
+      s.c2 = c + (s.L / 2) * s.a;
+      s.B = s.L / 2 + s.R;
+      s.r = (na != 0) ? s.R * orthonormal(s.a) : mk(0, 0, 0);
+    } else if (f.kind == 1) {  // HalfSpaceFiber  F:5537-5549
+      if (na == 0) return fail("HalfSpaceFiber: given zero normal vector!");
+      s.n = (1.0 / na) * a;
+      s.p = c;
+    } else {
+      return fail("Unknown fiber type");
+    }
+  }
+  const double dxv = dx / nx, dyv = dy / ny, dzv = dz / nz;
+  const double V_voxel = dxv * dyv * dzv;
+  const double r_voxel = 0.5 * std::sqrt(dxv * dxv + dyv * dyv + dzv * dzv);
+  const long N = (long)nx * ny * nz;
+  if (real_volume) {
+    for (int m = 0; m < nphases; ++m) real_volume[m] = 0.0;
+    for (const Shape& s : shapes) real_volume[s.material] += s.volume();
+  }
+  for (int m = 0; m < nphases; ++m) {
+    double* ph = phi + (long)m * N;
+    if (m == matrix_mat) {
+      for (long i = 0; i < N; ++i) ph[i] = 1.0;
+      continue;
+    }
+    std::vector<const Shape*> mine;
+    for (const Shape& s : shapes)
+      if (s.material == m) mine.push_back(&s);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nx; ++i) {
+      std::vector<Info> list;
+      for (int j = 0; j < ny; ++j)
+        for (int k = 0; k < nz; ++k) {
+          const V3 p = mk(dxv * (i + 0.5) + x0[0], dyv * (j + 0.5) + x0[1], dzv * (k + 0.5) + x0[2]);
+          list.clear();
+          for (const Shape* s : mine) {  // closestFibers  F:3336-3361
+            if (s->bb_distance_min(p) <= r_voxel) {
+              Info in;
+              in.d = s->distance(p, in.x);
+              if (in.d <= r_voxel) {
+                in.shape = s;
+                list.push_back(in);
+              }
+            }
+          }
+          double v = 0.0;
+          if (!list.empty()) v = integrate_voxel(smooth_levels, smooth_tol, r_voxel, p, dxv, dyv, dzv, list) / V_voxel;
+          ph[((long)i * ny + j) * nz + k] = v;
+        }
+    }
+  }
+  if (normals) {
+    if (shapes.empty()) {
+      for (long i = 0; i < 3 * N; ++i) normals[i] = 0.0;
+    } else {
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < ny; ++j)
+          for (int k = 0; k < nz; ++k) {
+            const V3 p = mk(dxv * (i + 0.5) + x0[0], dyv * (j + 0.5) + x0[1], dzv * (k + 0.5) + x0[2]);
+            const Shape* best = nullptr;
+            double dbest = std::numeric_limits<double>::infinity();
+            V3 x;
+            for (const Shape& s : shapes) {
+              const double d = s.distance(p, x);
+              if (!best || d < dbest) {
+                best = &s;
+                dbest = d;
+              }
+            }
+            const V3 g = best->grad(p);
+            const long o = ((long)i * ny + j) * nz + k;
+            normals[o] = g[0];
+            normals[N + o] = g[1];
+            normals[2 * N + o] = g[2];
+          }
+    }
+  }
+  return FG_OK;
+}

@@ -1,0 +1,738 @@
+"""`FG` -- the project / action layer of fibergen on top of the MI355X solver.
+
+Mirrors the reference's Python class fibergen.FG (boost.python, F:27142-27187) and the
+pieces of FGProject (F:26516-26781), FG<T,R,DIM> (F:24836-26490) and run_actions
+(F:25297-26489) that drive the Lippmann-Schwinger hot path:
+
+    fg = FG(); fg.load_xml("project.xml"); fg.set("solver..n", 64); fg.run()
+    fg.get_effective_property(); fg.get_field("sigma"); fg.get_mean_stress(); ...
+
+XML subset: <settings> dx,dy,dz,x0,y0,z0, <variables>, <python>, <solver n nx ny nz mult>
+with tol, abs_tol, bc_tol, maxiter, method, gamma_scheme, mode, mixing_rule,
+error_estimator, ref_scale, update_ref, bc_relax, <laminate_mixing>, <materials>;
+actions select_material, place_fiber, read_raw_data, init_phase, run_load_case,
+calc_effective_properties, calc_isotropic_laminate, python, print_timings, exit,
+group-*, skip.  Everything numeric is evaluated as a Python expression over the project
+variables, like the reference's embedded interpreter (F:744-756).
+
+All field arithmetic runs in libfibergen_amd.so on the GPU; this module is host glue.
+"""
+from __future__ import annotations
+
+import builtins
+import gzip
+import logging
+import math
+import os
+import warnings
+
+import numpy as np
+
+from . import materials as _materials
+from .solver import LSSolver
+from .xmlproject import XMLProject
+
+log = logging.getLogger("fibergen_amd")
+
+EXIT_SUCCESS, EXIT_FAILURE = 0, 1
+_VOIGT = (11, 22, 33, 23, 13, 12)
+_SOLVER_DOUBLE_KEYS = ("tol", "abs_tol", "bc_tol", "ref_scale", "bc_relax")
+
+
+class _Fiber:
+    def __init__(self, kind, c, a, L, R, material):
+        self.kind, self.c, self.a, self.L, self.R, self.material = kind, np.array(c, float), np.array(a, float), L, R, material
+
+
+class FG:
+    """The fibergen solver class (reference: PyFG, F:26785-26851)."""
+
+    def __init__(self, device=0):
+        self._device = device
+        self._project = XMLProject()
+        self._variables = {}
+        self._py_enabled = True
+        self._xml_precision = -1
+        self._convergence_callback = None
+        self._loadstep_callback = None
+        self._log_file = None
+        self._Ceff_voigt = None
+        self._timings = {}
+        self._injected_phi = {}      # extension: phase arrays handed in by the caller, survive run()
+        self._injected_normals = None
+        self._reset_state()
+
+    # ------------------------------------------------------------------ state
+    def _reset_state(self):
+        """FG::reset  F:24932-24942"""
+        lss = getattr(self, "_lss", None)
+        if lss is not None:
+            lss.close()
+        self._lss = None
+        self._error = None
+        self._fibers = []
+        self._selected_material = 0
+        self._phase_valid = False
+        self._solver_valid = False
+        self._raw_phase = False
+        self._phase_names = []
+        self._phase_materials = []
+        self._matrix_mat = 0
+        self._phi = None        # host copy of the phase fields [nphase][nx][ny][nz]
+        self._normals = None
+        self._want_normals = False
+        self._method = "cg"
+        self._real_vf = {}
+
+    def reset(self):
+        """Resets the solver to its initial state and unloads any loaded XML (F:26536-26541)."""
+        self._project.reset()
+        self._injected_phi = {}
+        self._injected_normals = None
+        self._reset_state()
+
+    # ------------------------------------------------------------------ XML access
+    def load_xml(self, filename):
+        self._project.load_xml(filename)
+
+    def set_xml(self, xml):
+        self._project.set_xml(xml)
+
+    def get_xml(self):
+        return self._project.get_xml()
+
+    def set_xml_precision(self, digits):
+        self._xml_precision = int(digits)
+
+    def get_xml_precision(self):
+        return self._xml_precision
+
+    def _format_value(self, value):
+        if isinstance(value, bool):
+            return "1" if value else "0"
+        if isinstance(value, int):
+            return str(value)
+        if isinstance(value, float):
+            if self._xml_precision >= 0:
+                return "%.*g" % (self._xml_precision, value)
+            return repr(value)
+        if isinstance(value, str):
+            return value
+        raise RuntimeError("invalid argument for attribute specified")
+
+    def set(self, path, *args, **kwargs):
+        """set(path), set(path, value), set(path, a=1, b=2)  (SetParameters, F:26854-26901)"""
+        if not args and not kwargs:
+            self._project.set(path, "")
+        for v in args:
+            self._project.set(path, self._format_value(v))
+        for k, v in kwargs.items():
+            try:
+                self._project.set(path + "." + k, self._format_value(v))
+            except RuntimeError:
+                raise RuntimeError("invalid argument for attribute '%s' specified" % (path + "." + k))
+
+    def get(self, path):
+        return self._project.get(path)
+
+    def erase(self, path):
+        self._project.erase(path)
+
+    # ------------------------------------------------------------------ python evaluation
+    def set_py_enabled(self, enabled):
+        self._py_enabled = bool(enabled)
+
+    def set_variable(self, name, value):
+        self._variables[name] = value
+
+    def get_variable(self, name):
+        return self._variables[name]
+
+    def _eval(self, text, typ=float):
+        """PY::eval<T>  F:744-756: Python expression over the project variables when enabled."""
+        if isinstance(text, (int, float)):
+            return typ(text)
+        s = str(text).strip()
+        if self._py_enabled:
+            try:
+                v = eval(s, {"__builtins__": builtins, "math": math, "np": np}, self._variables)
+            except Exception as e:
+                raise RuntimeError("error evaluating expression '%s': %s" % (s, e))
+            return typ(v)
+        if typ is bool:
+            return s not in ("0", "false", "False", "")
+        if typ is int:
+            return int(float(s))
+        return typ(s)
+
+    def _attr(self, el, name, default=None, typ=float):
+        if el is None or name not in el.attrib:
+            if default is None and typ is not str:
+                raise RuntimeError("Undefined property: %s!" % name)
+            return default
+        if typ is str:
+            return el.attrib[name]
+        return self._eval(el.attrib[name], typ)
+
+    def _child_value(self, el, name, default, typ=float):
+        c = el.find(name) if el is not None else None
+        if c is None or c.text is None or c.text.strip() == "":
+            return default
+        if typ is str:
+            return c.text.strip()
+        return self._eval(c.text, typ)
+
+    # ------------------------------------------------------------------ callbacks / misc API
+    def set_convergence_callback(self, func):
+        self._convergence_callback = func
+
+    def set_loadstep_callback(self, func):
+        self._loadstep_callback = func
+
+    def set_log_file(self, filename):
+        self._log_file = filename
+        handler = logging.FileHandler(filename)
+        log.addHandler(handler)
+        log.setLevel(logging.INFO)
+
+    def cancel(self):
+        """FG::cancel  F:25190-25193"""
+        self._error = "fibergen canceled"
+        if self._lss is not None:
+            self._lss.cancel()
+
+    def get_error(self):
+        return self._error is not None
+
+    # ------------------------------------------------------------------ initialisation
+    def _settings(self):
+        return self._project.root
+
+    def _grid(self):
+        st = self._settings()
+        solver = st.find("solver")
+        na = self._attr(solver, "n", 0, int)
+        mult = self._attr(solver, "mult", 1.0, float)
+        dims = []
+        for key in ("nx", "ny", "nz"):
+            v = self._attr(solver, key, na, int)
+            dims.append(max(1, int(v * mult)))
+        d = [self._child_value(st, k, 1.0) for k in ("dx", "dy", "dz")]
+        x0 = [self._child_value(st, k, 0.0) for k in ("x0", "y0", "z0")]
+        return tuple(dims), d, x0
+
+    def init_lss(self):
+        """FG::init_lss + LSSolver::readSettings  F:24990-25017, F:15044-15363"""
+        if self._solver_valid:
+            return
+        st = self._settings()
+        solver = st.find("solver")
+        (nx, ny, nz), (dx, dy, dz), x0 = self._grid()
+        self._dims = (dx, dy, dz)
+        self._x0 = x0
+        mode = self._child_value(solver, "mode", "elasticity", str)
+        if mode != "elasticity":
+            raise RuntimeError("mode '%s' is not available on the MI355X path (elasticity only)" % mode)
+        method = self._child_value(solver, "method", "cg", str)
+        if method not in ("basic", "cg"):
+            raise RuntimeError("Unknown solver method '%s'" % method)
+        if method == "cg":
+            warnings.warn("method=cg is not available on the MI355X path yet; the basic scheme is used "
+                          "(same fixed point, different iteration history)")
+        self._method = method
+        scheme = self._child_value(solver, "gamma_scheme", "auto", str)
+        if scheme == "auto":
+            scheme = "staggered"
+        if scheme != "staggered":
+            raise RuntimeError("Unknown gamma scheme '%s' (MI355X path: staggered)" % scheme)
+        est = self._child_value(solver, "error_estimator", "epsilon", str)
+        if est != "epsilon":
+            raise RuntimeError("error estimator '%s' is not available (epsilon only)" % est)
+        mixing = self._child_value(solver, "mixing_rule", "voigt", str)
+        if mixing not in ("voigt", "laminate"):
+            raise RuntimeError("Unknown mixing rule '%s'" % mixing)
+
+        lss = LSSolver(nx, ny, nz, dx, dy, dz, device=self._device)
+        opts = {"mixing_rule": mixing}
+        for k in _SOLVER_DOUBLE_KEYS:
+            v = self._child_value(solver, k, None)
+            if v is not None:
+                opts[k] = v
+        v = self._child_value(solver, "maxiter", None, int)
+        if v is not None:
+            opts["maxiter"] = v
+        upd = self._child_value(solver, "update_ref", None, str)
+        if upd is not None:
+            opts["update_ref"] = upd
+        lam = solver.find("laminate_mixing") if solver is not None else None
+        if lam is not None:
+            for k in ("eps_g", "eps_a"):
+                v = self._child_value(lam, k, None)
+                if v is not None:
+                    opts[k] = v
+        # <materials>  F:15177-15299
+        mats = solver.find("materials") if solver is not None else None
+        names, consts = [], []
+        matrix_mat, matrix_set = 0, False
+        if mats is not None:
+            for m in mats:
+                if not isinstance(m.tag, str):
+                    continue
+                attrs = dict(m.attrib)
+                if m.tag == "ref":
+                    c = _materials.material_constants(attrs, self._eval)
+                    opts["mu_0"], opts["lambda_0"] = c["mu"], c["lambda"]
+                    continue
+                if m.tag == "matrix" or self._eval(attrs.get("matrix", "0"), int) != 0:
+                    if matrix_set:
+                        raise RuntimeError("Matrix material already specified")
+                    matrix_set = True
+                    matrix_mat = len(names)
+                law = attrs.get("law", "iso")
+                if law != "iso":
+                    raise RuntimeError("Unknown material law '%s'" % law)
+                names.append(m.tag)
+                consts.append(_materials.material_constants(attrs, self._eval))
+        if not names:
+            raise RuntimeError("No materials specified")
+        lss.set_num_phases(len(names))
+        for p, c in enumerate(consts):
+            lss.set_phase(p, c["mu"], c["lambda"])
+        lss.set_options(**opts)
+        lss.set_convergence_callback(self._on_iteration)
+        self._lss = lss
+        self._phase_names = names
+        self._phase_materials = consts
+        self._matrix_mat = matrix_mat
+        self._mixing = mixing
+        self._solver_valid = True
+
+    def init_fibers(self):
+        """Random fibre generation is out of scope; placed fibres need no generation."""
+        return
+
+    def _material_id(self, name):
+        try:
+            return self._phase_names.index(name)
+        except ValueError:
+            raise RuntimeError("Material '%s' not found" % name)
+
+    def init_phase(self):
+        """FG::init_phase  F:25026-25038: discretise the geometry into phase fractions (+ normals)."""
+        if self._phase_valid:
+            return
+        self.init_lss()
+        lss = self._lss
+        shape = lss.shape
+        nph = len(self._phase_names)
+        for name, arr in self._injected_phi.items():
+            m = self._material_id(name)
+            if arr.shape != shape:
+                raise RuntimeError("Phase dimensions are incompatible")
+            if not self._raw_phase:
+                self._phi = np.ones((nph,) + shape)  # setPhasesOne  F:17128
+                self._raw_phase = True
+            self._phi[m] = arr
+        if self._injected_normals is not None:
+            if self._injected_normals.shape != (3,) + shape:
+                raise RuntimeError("normals must have shape (3, nx, ny, nz)")
+            self._normals = self._injected_normals
+        if self._raw_phase:
+            phi = self._phi
+        else:
+            from . import geometry
+            phi, normals, real_vf = geometry.voxelize(self._fibers, shape, self._dims, self._x0, nph, self._matrix_mat,
+                                                      want_normals=(self._want_normals or self._mixing == "laminate"),
+                                                      smooth_levels=self._solver_int("smooth_levels", -1),
+                                                      smooth_tol=self._solver_float("smooth_tol", 0.001))
+            if normals is not None:
+                self._normals = normals
+            self._real_vf = real_vf
+        phi = _normalize_phi(phi)  # normalizePhi  F:17588-17646 (last material wins)
+        self._phi = phi
+        for p in range(nph):
+            lss.set_phase(p, self._phase_materials[p]["mu"], self._phase_materials[p]["lambda"], phi[p])
+        if self._normals is not None:
+            lss.set_normals(self._normals)
+        elif self._mixing == "laminate":
+            raise RuntimeError("laminate mixing needs interface normals (init_phase normals=\"1\" or set_normals)")
+        self._phase_valid = True
+
+    def _solver_float(self, key, default):
+        return self._child_value(self._settings().find("solver"), key, default)
+
+    def _solver_int(self, key, default):
+        return self._child_value(self._settings().find("solver"), key, default, int)
+
+    # extension of the reference API: inject phase fractions / normals as arrays
+    def set_phase_field(self, name, phi):
+        """Provide the volume-fraction field of material `name` as an array [nx,ny,nz]
+        (equivalent to read_raw_data with dtype=double, order=row).  Unlike the XML tree this
+        is not part of the project file; it stays in effect for later run() calls until
+        reset()."""
+        self._injected_phi[name] = np.clip(np.asarray(phi, dtype=np.float64), 0.0, 1.0)
+        self._phase_valid = False
+
+    def set_normals(self, normals):
+        """Provide the interface normals [3,nx,ny,nz] (see set_phase_field)."""
+        self._injected_normals = np.asarray(normals, dtype=np.float64)
+        self._phase_valid = False
+
+    # ------------------------------------------------------------------ results
+    def get_phase_names(self):
+        self.init_lss()
+        return list(self._phase_names)
+
+    def get_volume_fraction(self, name):
+        self.init_lss()
+        return self._lss.volume_fraction(self._material_id(name))
+
+    def get_real_volume_fraction(self, name):
+        self.init_lss()
+        return float(self._real_vf.get(self._material_id(name), float("nan")))
+
+    def get_residuals(self):
+        self.init_lss()
+        return self._lss.residuals
+
+    def get_solve_time(self):
+        self.init_lss()
+        return self._lss.solve_time
+
+    def get_mean_stress(self):
+        self.init_lss()
+        return self._lss.mean_stress().tolist()
+
+    def get_mean_strain(self):
+        self.init_lss()
+        return self._lss.mean_strain().tolist()
+
+    def get_mean_energy(self):
+        """calcMeanEnergy (F:17784): <W> = 1/2 <sigma : epsilon> for linear phases."""
+        self.init_lss()
+        s = self._lss.get_field("sigma")
+        e = self._lss.get_field("epsilon")
+        w = (s[:3] * e[:3]).sum(axis=0) + 2 * (s[3:] * e[3:]).sum(axis=0)
+        return float(0.5 * w.mean())
+
+    def get_effective_property(self):
+        if self._Ceff_voigt is None:
+            return []
+        return [list(map(float, row)) for row in self._Ceff_voigt]
+
+    def get_rve_dims(self):
+        (_, _, _), (dx, dy, dz), x0 = self._grid()
+        return [x0[0], x0[1], x0[2], dx, dy, dz]
+
+    def get_distance_evals(self):
+        return 0
+
+    def get_A2(self):
+        raise RuntimeError("fibre orientation statistics are outside the MI355X hot path")
+
+    get_A4 = get_A2
+
+    def get_B_from_A(self, a0, a1, a2):
+        raise RuntimeError("fibre orientation statistics are outside the MI355X hot path")
+
+    def get_field(self, name, range_x=(), range_y=(), range_z=(), components=()):
+        """GetField  F:26931-27010: ndarray[ncomp, nx, ny, nz] (float64), optionally sub-sampled."""
+        self.init_lss()
+        lss = self._lss
+        if name in ("epsilon", "sigma", "u"):
+            data = lss.get_field(name)
+        elif name == "phi":
+            self.init_phase()
+            data = lss.get_field("phi")
+        elif name == "normals":
+            self.init_phase()
+            data = lss.get_field("normals")
+        elif name in self._phase_names:
+            self.init_phase()
+            data = lss.get_field("phi")[self._material_id(name)][None]
+        else:
+            raise RuntimeError("Unknown field '%s'" % name)
+
+        def rng(r, n):
+            if len(r) == 0:
+                return np.arange(n)
+            r = np.unique(np.asarray(r, dtype=np.int64))
+            if r.min() < 0 or r.max() >= n:
+                raise IndexError("index out of range")
+            return r
+        ic = rng(components, data.shape[0])
+        ix, iy, iz = rng(range_x, data.shape[1]), rng(range_y, data.shape[2]), rng(range_z, data.shape[3])
+        return np.ascontiguousarray(data[np.ix_(ic, ix, iy, iz)])
+
+    # ------------------------------------------------------------------ running
+    def _on_iteration(self):
+        if self._error is not None:
+            return True
+        res = self._lss.residuals
+        log.info("# Iteration %d: epsilon error rel. = %g", len(res), res[-1] if res else float("nan"))
+        if self._convergence_callback is not None:
+            r = self._convergence_callback()
+            if isinstance(r, (bool, np.bool_)) and r:
+                log.info("Custom convergence test returned true.")
+                return True
+        return False
+
+    def _init_python(self):
+        """FG::init_python  F:24873-24930: <variables> then <python> blocks."""
+        self._variables["fg"] = self
+        st = self._settings()
+        variables = st.find("variables")
+        if variables is not None:
+            for v in variables:
+                if not isinstance(v.tag, str):
+                    continue
+                typ = v.attrib.get("type", "object")
+                val = v.attrib.get("value", "")
+                if typ == "str":
+                    pv = val
+                elif typ == "int":
+                    pv = self._eval(val, int)
+                elif typ == "float":
+                    pv = self._eval(val, float)
+                elif typ == "object":
+                    pv = eval(val.strip(), {"__builtins__": builtins, "math": math, "np": np}, self._variables)
+                else:
+                    raise RuntimeError("Unknown variable type '%s' for %s" % (typ, v.tag))
+                self._variables[v.tag] = pv
+        for p in st.findall("python"):
+            self._exec_python(p.text or "")
+
+    def _exec_python(self, code):
+        import textwrap
+        g = {"__builtins__": builtins}
+        g.update(self._variables)
+        exec(textwrap.dedent(code), g)
+        for k, v in g.items():
+            if k != "__builtins__":
+                self._variables[k] = v
+
+    def run(self, path="actions"):
+        """FG::run  F:25195-25295: reset, evaluate variables, perform the actions below `path`."""
+        self._reset_state()
+        self._init_python()
+        try:
+            return self._run_actions(path)
+        finally:
+            self._variables.pop("fg", None)
+
+    def _run_actions(self, path):
+        st = self._settings()
+        node = st
+        for part in path.split("."):
+            node = node.find(part) if node is not None else None
+        if node is None:
+            return EXIT_SUCCESS
+        if self._eval(node.attrib.get("skip", "0"), int) != 0:
+            return EXIT_SUCCESS
+        for act in node:
+            if self._error is not None:
+                return EXIT_FAILURE
+            if not isinstance(act.tag, str):
+                continue  # comment
+            if act.tag == "skip" or self._eval(act.attrib.get("skip", "0"), int) != 0:
+                continue
+            if act.tag.startswith("group-"):
+                ret = self._run_actions(path + "." + act.tag)
+                if ret != 0:
+                    return ret
+                continue
+            ret = self._run_action(act)
+            if ret == "exit":
+                return EXIT_SUCCESS
+            if ret not in (None, 0):
+                return ret
+        return EXIT_FAILURE if self._error is not None else EXIT_SUCCESS
+
+    def _voigt_vector(self, act, prefix):
+        """read_voigt_vector  F:1126-1138: e1..e3 shorthand, then e11,e22,e33,e23,e13,e12"""
+        v = np.zeros(6)
+        for i in range(3):
+            v[i] = self._attr(act, "%s%d" % (prefix, i + 1), v[i])
+        for i, idx in enumerate(_VOIGT):
+            v[i] = self._attr(act, "%s%d" % (prefix, idx), v[i])
+        return v
+
+    def _run_action(self, act):
+        name = act.tag
+        if name == "select_material":
+            self.init_lss()
+            self._selected_material = self._material_id(self._attr(act, "name", None, str) or "")
+            return None
+        if name == "place_fiber":
+            (_, _, _), (dx, dy, dz), x0 = self._grid()
+            L = self._attr(act, "L", 0.0)
+            R = self._attr(act, "R", 0.25 * dx)
+            V = self._attr(act, "V", -1.0)
+            kind = self._attr(act, "type", "capsule", str)
+            if V >= 0:
+                R = (V / (4 * math.pi / 3.0)) ** (1 / 3.0)
+            c = [self._attr(act, "cx", x0[0] + 0.5 * dx), self._attr(act, "cy", x0[1] + 0.5 * dy),
+                 self._attr(act, "cz", x0[2] + 0.5 * dz)]
+            a = [self._attr(act, "ax", 1.0), self._attr(act, "ay", 0.0), self._attr(act, "az", 0.0)]
+            if kind not in ("capsule", "halfspace"):
+                raise RuntimeError("Unknown fiber type '%s'" % kind)
+            self._fibers.append(_Fiber(kind, c, a, L, R, self._selected_material))
+            self._phase_valid = False
+            return None
+        if name == "read_raw_data":
+            return self._read_raw_data(act)
+        if name == "init_phase":
+            self.init_lss()
+            if self._attr(act, "normals", False, bool):
+                self._want_normals = True
+            self.init_phase()
+            return None
+        if name == "run_load_case":
+            E = self._voigt_vector(act, "e")
+            S = self._voigt_vector(act, "s")
+            P = np.diag([1.0, 1.0, 1.0, 0.5, 0.5, 0.5])
+            for i in range(6):
+                for j in range(6):
+                    key = "p%d%d" % (i + 1, j + 1)
+                    if key in act.attrib:
+                        P[i, j] = P[j, i] = self._eval(act.attrib[key])
+            self.init_lss()
+            self.init_phase()
+            self._lss.set_bc_projector(P)
+            failed = self._lss.run(E, S)
+            if failed:
+                self._error = self._error or "NaN detected in solution. Aborting."
+                return EXIT_FAILURE
+            if self._loadstep_callback is not None and self._loadstep_callback():
+                pass  # the reference ignores run()'s return value here (F:25938)
+            if self._error is not None:
+                return EXIT_FAILURE
+            outfile = self._attr(act, "outfile", "", str)
+            if outfile:
+                warnings.warn("VTK output is not available yet (outfile='%s' ignored)" % outfile)
+            return None
+        if name == "calc_effective_properties":
+            self.init_lss()
+            self.init_phase()
+            S = np.zeros((6, 6))
+            for i in range(6):
+                Ep = np.zeros(6)
+                Ep[i] = 1.0
+                failed = self._lss.run(Ep)
+                stop = self._loadstep_callback is not None and self._loadstep_callback()
+                if failed or stop or self._error is not None:
+                    self._error = self._error or "NaN detected in solution. Aborting."
+                    return EXIT_FAILURE
+                S[:, i] = self._lss.mean_stress()
+            Ceff = S @ np.linalg.inv(np.eye(6))  # Ceff = S E^-1 with unit experiments  F:26072-26075
+            Cv = Ceff.copy()
+            Cv[:, 3:6] *= 0.5                     # F:26083-26088
+            self._Ceff_voigt = Cv
+            log.info("Effective stiffness matrix (Voigt notation):\n%s", Cv)
+            return None
+        if name == "calc_isotropic_laminate":
+            c = np.zeros(6)
+            for m in act:
+                if not isinstance(m.tag, str):
+                    continue
+                k = _materials.material_constants(dict(m.attrib), self._eval)
+                phi = self._eval(m.attrib.get("phi", "0"))
+                lam, mu = k["lambda"], k["mu"]
+                c += phi * np.array([1 / (lam + 2 * mu), 1 / mu, mu, lam / (lam + 2 * mu),
+                                     4 * mu * (lam + mu) / (lam + 2 * mu), 2 * mu * lam / (lam + 2 * mu)])
+            C = np.zeros((6, 6))
+            C[0, 0] = 1 / c[0]
+            C[1, 1] = C[2, 2] = c[4] + c[3] * c[3] / c[0]
+            C[3, 3] = c[2]
+            C[4, 4] = C[5, 5] = 1 / c[1]
+            C[0, 1] = C[1, 0] = C[0, 2] = C[2, 0] = c[3] / c[0]
+            C[1, 2] = C[2, 1] = c[5] + c[3] * c[3] / c[0]
+            self._laminate_Ceff = C
+            log.info("Effective stiffness matrix (Voigt notation):\n%s", C)
+            return None
+        if name == "python":
+            self._exec_python(act.text or "")
+            return None
+        if name == "print_timings":
+            log.info("solve time: %g s", self._lss.solve_time if self._lss else 0.0)
+            return None
+        if name == "exit":
+            return "exit"
+        raise RuntimeError("Unknown action: '%s'" % name)
+
+    def _read_raw_data(self, act):
+        """read_raw_data  F:25494-25573 + readRawPhase F:16925-17001 + initMultiphase F:16761-16922"""
+        self.init_lss()
+        shape = self._lss.shape
+        n = self._attr(act, "n", 0, int)
+        dims = [self._attr(act, k, n if n > 0 else shape[i], int) for i, k in enumerate(("nx", "ny", "nz"))]
+        filename = self._attr(act, "filename", None, str)
+        if filename is None:
+            raise RuntimeError("Undefined property: filename!")
+        dtype = self._attr(act, "dtype", "uint8", str)
+        treshold = self._attr(act, "treshold", -1.0)
+        col_order = self._attr(act, "order", "col", str) == "col"
+        header = self._attr(act, "header_bytes", 0, int)
+        np_types = {"uint8": (np.uint8, 1 / 255.0), "uint16": (np.uint16, 1 / 65535.0),
+                    "uint32": (np.uint32, 1 / 4294967295.0), "float": (np.float32, 1.0), "double": (np.float64, 1.0)}
+        if dtype not in np_types:
+            raise RuntimeError("Unknown data type '%s'" % dtype)
+        nt, default_scale = np_types[dtype]
+        scale = self._attr(act, "scale", default_scale)
+        opener = gzip.open if filename.endswith(".gz") else open
+        try:
+            with opener(filename, "rb") as f:
+                f.read(header)
+                count = dims[0] * dims[1] * dims[2]
+                raw = np.frombuffer(f.read(count * np.dtype(nt).itemsize), dtype=nt)
+        except OSError as e:
+            raise RuntimeError("Error reading file '%s': %s" % (filename, e))
+        if raw.size != dims[0] * dims[1] * dims[2]:
+            raise RuntimeError("Error reading raw data: file too short")
+        if col_order:   # x fastest in the file  F:16946-16966
+            t = raw.reshape(dims[2], dims[1], dims[0]).transpose(2, 1, 0)
+        else:
+            t = raw.reshape(dims[0], dims[1], dims[2])
+        t = np.minimum(np.maximum(scale * t.astype(np.float64), 0.0), 1.0)
+        if treshold >= 0:
+            t = (t > treshold).astype(np.float64)
+        if not self._raw_phase:
+            self._phi = np.ones((len(self._phase_names),) + shape)  # setPhasesOne
+            self._raw_phase = True
+        mapping = {}
+        single = None
+        for k, v in act.attrib.items():
+            if k.startswith("material_"):
+                mapping[int(k[len("material_"):])] = self._material_id(v)
+            elif k == "material":
+                single = self._material_id(v)
+        if any(dims[i] % shape[i] for i in range(3)):
+            raise RuntimeError("Phase dimensions are incompatible %d %d %d %d %d %d"
+                               % (dims[0], shape[0], dims[1], shape[1], dims[2], shape[2]))
+        s = [max(1, dims[i] // shape[i]) for i in range(3)]
+        blocks = t.reshape(shape[0], s[0], shape[1], s[1], shape[2], s[2])
+        if single is not None:
+            self._phi[single] = blocks.mean(axis=(1, 3, 5))   # psum/ns  F:16838-16843
+        elif mapping:
+            cls = np.floor(blocks / scale + 0.5).astype(np.int64)
+            known = np.isin(cls, list(mapping))
+            if not known.all():
+                raise RuntimeError("Material value %d not mapped!" % int(cls[~known].flat[0]))
+            ns = s[0] * s[1] * s[2]
+            for m in range(len(self._phase_names)):
+                vals = [v for v, mm in mapping.items() if mm == m]
+                self._phi[m] = np.isin(cls, vals).sum(axis=(1, 3, 5)) / float(ns) if vals else 0.0
+        self._phase_valid = False
+        return None
+
+
+def _normalize_phi(phi):
+    """normalizePhi  F:17588-17646: walking materials from last to first, each takes
+    min(remaining, phi); the volume fractions of a voxel then sum to at most 1."""
+    out = np.empty_like(phi)
+    rem = np.ones(phi.shape[1:])
+    for m in range(phi.shape[0] - 1, -1, -1):
+        vol = np.minimum(rem, phi[m])
+        out[m] = vol
+        rem = rem - vol
+    return out

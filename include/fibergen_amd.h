@@ -126,6 +126,27 @@ int fg_run_stage(fg_solver* s, int stage, const double* E6);
 int fg_enable_stage_timing(fg_solver* s, int enable);
 int fg_get_stage_times(const fg_solver* s, double* ms /* [FG_NUM_TIMED_KERNELS] */, long* count);
 
+/* ---- geometry pre-processing (host side, no GPU needed) ------------------------------
+ * Analytic shapes placed with <place_fiber> (F:25788-25822) -> phase volume fractions and
+ * interface normals: LSSolver::initPhi F:17489-17581 (adaptive sub-voxel integration,
+ * integratePhiVoxel F:16622-16752, plane cuts F:1385-1577) and the NORMALS sampling
+ * F:6905-6925.  kind 0 = capsule (centre c, axis a, total length L, radius R; L = 0 is a
+ * sphere), kind 1 = half space (point c, outward normal a).  phi is [nphases][nx][ny][nz]
+ * BEFORE normalizePhi (the matrix phase is all ones); normals (may be NULL) is
+ * [3][nx][ny][nz]; real_volume (may be NULL) receives the analytic volume per phase. */
+typedef struct fg_fiber {
+  int kind;
+  int material;
+  double c[3];
+  double a[3];
+  double L;
+  double R;
+} fg_fiber;
+
+int fg_voxelize(const fg_fiber* fibers, int nfibers, int nx, int ny, int nz, double dx, double dy, double dz,
+                const double* x0, int nphases, int matrix_mat, int smooth_levels, double smooth_tol,
+                double* phi, double* normals, double* real_volume, char* err, int errlen);
+
 #ifdef __cplusplus
 }
 #endif

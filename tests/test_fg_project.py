@@ -1,0 +1,174 @@
+"""CPU tests of the project layer (host logic of the drop-in boundary): XML path syntax,
+expression evaluation, material constants, phase normalisation and the native voxeliser.
+No GPU compute is called."""
+import math
+
+import numpy as np
+import pytest
+
+from fibergen_amd import geometry, materials
+from fibergen_amd.fg import FG, _Fiber, _normalize_phi
+from fibergen_amd.xmlproject import XMLProject
+from oracle.ls_oracle import material_from_pair
+
+XML = """
+<settings>
+  <title>Title</title>
+  <variables><dx type="float" value="2" /><n type="int" value="8" /></variables>
+  <dx>dx</dx>
+  <solver n="16">
+    <tol>1e-6</tol>
+    <materials>
+      <matrix E="1" nu="0.3" />
+      <fiber  E="2" nu="0.3" />
+    </materials>
+  </solver>
+  <actions>
+    <select_material name="fiber" />
+    <place_fiber R="0.5" />
+    <run_load_case e11="1" />
+    <run_load_case e22="1" />
+  </actions>
+</settings>
+"""
+
+
+def test_xml_path_syntax_like_reference():
+    """get_path / set / get / erase  F:26632-26736 and SetParameters F:26854-26901
+    (the calls of demo/python/pure_python/project.py:34-40)."""
+    fg = FG()
+    fg.set_xml(XML)
+    fg.set("solver..n", 32)
+    fg.set("solver.tol", 1e-8)
+    fg.set("title", "New Title")
+    fg.set("solver.materials.fiber.", E=10, nu=0.35)
+    fg.set("actions.run_load_case[0].", e11=2)
+    fg.set("actions.run_load_case[1].", e22=0, e33=1)
+    assert fg.get("solver..n") == "32"
+    assert float(fg.get("solver.tol")) == 1e-8
+    assert fg.get("title") == "New Title"
+    assert fg.get("solver.materials.fiber..E") == "10"
+    assert fg.get("actions.run_load_case[1]..e33") == "1"
+    assert fg.get("actions.run_load_case[0]..e11") == "2"
+    with pytest.raises(RuntimeError, match="not found"):
+        fg.get("solver.nonexistent")
+    fg.set("solver.maxiter", 5)                # creates the element
+    assert fg.get("solver.maxiter") == "5"
+    fg.set("actions.run_load_case[3]..e12", 0.5)   # creates cases [2] and [3]
+    assert len(fg._project.root.find("actions").findall("run_load_case")) == 4
+    fg.erase("actions.run_load_case[3]")
+    fg.erase("actions.run_load_case[2]")
+    assert len(fg._project.root.find("actions").findall("run_load_case")) == 2
+    fg.erase("solver..n")
+    with pytest.raises(RuntimeError):
+        fg.get("solver..n")
+    xml = fg.get_xml()
+    assert xml.startswith("<?xml") and "New Title" in xml
+    fg2 = FG()
+    fg2.set_xml(xml)
+    assert fg2.get("solver.materials.fiber..nu") == "0.35"
+    fg.set_xml_precision(3)
+    fg.set("solver.tol", 1.23456789e-5)
+    assert fg.get("solver.tol") == "1.23e-05"
+    assert fg.get_xml_precision() == 3
+
+
+def test_expression_evaluation_and_grid():
+    fg = FG()
+    fg.set_xml(XML)
+    fg._init_python()
+    assert fg._eval("0.2*dx") == pytest.approx(0.4)
+    assert fg._eval("n*2", int) == 16
+    (nx, ny, nz), (dx, dy, dz), x0 = fg._grid()
+    assert (nx, ny, nz) == (16, 16, 16) and dx == 2.0 and dy == 1.0
+    fg.set("solver..mult", 0.5)
+    fg.set("solver..nz", 4)
+    assert fg._grid()[0] == (8, 8, 2)
+    fg.set_variable("variable", [1, 2, 3])
+    assert fg.get_variable("variable") == [1, 2, 3]
+    assert fg.get_rve_dims() == [0.0, 0.0, 0.0, 2.0, 1.0, 1.0]
+    fg.set_py_enabled(False)
+    with pytest.raises(Exception):
+        fg._eval("0.2*dx")
+    assert fg._eval("0.25") == 0.25
+
+
+def test_material_constants_match_oracle_and_errors():
+    ref = material_from_pair(E=100.0, nu=0.4)
+    for a, b in materials.PAIRS:
+        got = materials.material_constants({a: repr(ref[a]), b: repr(ref[b]), "law": "iso"})
+        chk = material_from_pair(**{a: ref[a], b: ref[b]})
+        for k in chk:
+            assert got[k] == chk[k], (a, b, k)   # same formulas, same operation order
+    with pytest.raises(RuntimeError, match="Incomplete"):
+        materials.material_constants({"E": "1"})
+    with pytest.raises(RuntimeError, match="Ambiguous"):
+        materials.material_constants({"E": "1", "nu": "0.3", "mu": "2"})
+
+
+def test_normalize_phi_last_material_wins():
+    """normalizePhi  F:17613-17626"""
+    phi = np.array([[1.0, 1.0, 1.0, 1.0], [0.0, 0.6, 1.0, 0.3], [0.0, 0.0, 0.5, 0.9]])[:, :, None, None]
+    out = _normalize_phi(phi)[:, :, 0, 0]
+    assert np.allclose(out[2], [0, 0, 0.5, 0.9])
+    assert np.allclose(out[1], [0, 0.6, 0.5, 0.1])
+    assert np.allclose(out[0], [1, 0.4, 0, 0])
+    assert np.allclose(out.sum(axis=0), 1)
+
+
+def test_voxeliser_sphere_capsule_halfspace():
+    sph = [_Fiber("capsule", [.5, .5, .5], [1, 0, 0], 0.0, 0.3, 1)]
+    phi, nrm, real = geometry.voxelize(sph, (32, 32, 32), (1, 1, 1), (0, 0, 0), 2, 0, want_normals=True)
+    exact = 4 / 3 * math.pi * 0.3 ** 3
+    assert phi[0].min() == 1.0                      # matrix: all ones before normalisation
+    assert abs(phi[1].mean() - exact) / exact < 5e-4
+    assert real[1] == pytest.approx(exact, rel=1e-14)
+    assert ((phi[1] >= 0) & (phi[1] <= 1)).all()
+    # normals: unit, pointing out of the inclusion (F:5286-5294)
+    assert np.allclose((nrm * nrm).sum(axis=0), 1.0)
+    assert nrm[0, 31, 16, 16] > 0.99 and nrm[0, 0, 16, 16] < -0.99
+    # symmetric under the cube group
+    assert np.allclose(phi[1], phi[1][::-1]) and np.allclose(phi[1], phi[1].transpose(1, 0, 2))
+    # capsule: total length L, cylinder part L - 4/3 R (F:5256-5258): volume = pi R^2 L
+    cap = [_Fiber("capsule", [.5, .5, .5], [0, 0, 1], 0.6, 0.2, 1)]
+    phi, _, real = geometry.voxelize(cap, (32, 32, 32), (1, 1, 1), (0, 0, 0), 2, 0)
+    assert real[1] == pytest.approx(math.pi * 0.2 ** 2 * 0.6, rel=1e-13)
+    assert abs(phi[1].mean() - real[1]) / real[1] < 2e-3
+    # the three half spaces of demo/elasticity/laminate/project.xml:31-36
+    fib = [_Fiber("halfspace", [0.0, .5, .5], [1, 0, 0], 0, 0.25, 0),
+           _Fiber("halfspace", [0.2, .5, .5], [-1, 0, 0], 0, 0.25, 1),
+           _Fiber("halfspace", [0.5, .5, .5], [-1, 0, 0], 0, 0.25, 2)]
+    phi, _, _ = geometry.voxelize(fib, (10, 1, 1), (1, 1, 1), (0, 0, 0), 3, 0)
+    out = _normalize_phi(phi)[:, :, 0, 0]
+    assert np.allclose(out[0], [1, 1, 0, 0, 0, 0, 0, 0, 0, 0], atol=1e-15)
+    assert np.allclose(out[1], [0, 0, 1, 1, 1, 0, 0, 0, 0, 0], atol=1e-15)
+    assert np.allclose(out[2], [0, 0, 0, 0, 0, 1, 1, 1, 1, 1], atol=1e-15)
+    # a plane cutting voxels obliquely: exact volume fraction of the half space x+y < 1 is 1/2
+    obl = [_Fiber("halfspace", [.5, .5, .5], [1, 1, 0], 0, 0.25, 1)]
+    phi, _, _ = geometry.voxelize(obl, (8, 8, 2), (1, 1, 1), (0, 0, 0), 2, 0)
+    assert phi[1].mean() == pytest.approx(0.5, abs=1e-14)
+    with pytest.raises(RuntimeError, match="zero normal"):
+        geometry.voxelize([_Fiber("halfspace", [0, 0, 0], [0, 0, 0], 0, 0.1, 1)], (4, 4, 4), (1, 1, 1), (0, 0, 0), 2, 0)
+
+
+def test_unknown_settings_raise_like_reference(monkeypatch):
+    fg = FG()
+    fg.set_xml(XML)
+    fg._init_python()
+    fg.set("solver.mode", "heat")
+
+    class Dummy:
+        def __init__(self, *a, **k):
+            raise AssertionError("solver must not be created")
+    import fibergen_amd.fg as fgmod
+    monkeypatch.setattr(fgmod, "LSSolver", Dummy)
+    with pytest.raises(RuntimeError, match="mode"):
+        fg.init_lss()
+    fg.set("solver.mode", "elasticity")
+    fg.set("solver.gamma_scheme", "willot")
+    with pytest.raises(RuntimeError, match="gamma scheme"):
+        fg.init_lss()
+    fg.set("solver.gamma_scheme", "auto")
+    fg.set("solver.method", "nesterov2")
+    with pytest.raises(RuntimeError, match="solver method"):
+        fg.init_lss()

@@ -1,0 +1,277 @@
+"""GPU tests of the drop-in boundary: fibergen XML projects run through `FG` (project
+layer -> C ABI -> HIP kernels) against the reference's own known answers and the oracle."""
+import gzip
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+from oracle.ls_oracle import LSOracle, isotropic_laminate_ceff, material_from_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def FG():
+    from fibergen_amd import FG as cls
+    return cls()
+
+
+LAMINATE_XML = """
+<settings>
+  <variables><dx type="float" value="1" /></variables>
+  <dx>dx</dx>
+  <solver nx="10" ny="1" nz="1" mult="1">
+    <method>basic</method>
+    <tol>1e-12</tol>
+    <materials>
+      <layer1 E="100" nu="0.4" law="iso" />
+      <layer2 E="25" nu="0.25" law="iso" />
+      <layer3 E="50" nu="0.3" law="iso" />
+    </materials>
+    <mode>elasticity</mode>
+  </solver>
+  <actions>
+    <select_material name="layer1" />
+    <place_fiber type="halfspace" cx="0.0" />
+    <select_material name="layer2" />
+    <place_fiber type="halfspace" cx="0.2*dx" ax="-1" />
+    <select_material name="layer3" />
+    <place_fiber type="halfspace" cx="0.5*dx" ax="-1" />
+    <calc_effective_properties />
+    <calc_isotropic_laminate>
+      <layer1 phi="0.2" E="100" nu="0.4" />
+      <layer2 phi="0.3" E="25" nu="0.25" />
+      <layer2 phi="0.5" E="50" nu="0.3" />
+    </calc_isotropic_laminate>
+  </actions>
+</settings>
+"""
+
+
+def test_laminate_demo_matches_closed_form():
+    """demo/elasticity/laminate/project.xml: FFT solution == calc_isotropic_laminate (F:26405-26446)."""
+    fg = FG()
+    fg.set_xml(LAMINATE_XML)
+    assert fg.run() == 0
+    C = np.array(fg.get_effective_property())
+    assert C.shape == (6, 6)
+    assert rel_err(C, fg._laminate_Ceff) < 1e-9
+    m = [material_from_pair(E=100, nu=0.4), material_from_pair(E=25, nu=0.25), material_from_pair(E=50, nu=0.3)]
+    Cex = isotropic_laminate_ceff([(0.2, m[0]["mu"], m[0]["lambda"]), (0.3, m[1]["mu"], m[1]["lambda"]),
+                                   (0.5, m[2]["mu"], m[2]["lambda"])])
+    assert rel_err(C, Cex) < 1e-9
+    assert fg.get_phase_names() == ["layer1", "layer2", "layer3"]
+    assert fg.get_volume_fraction("layer2") == pytest.approx(0.3, abs=1e-12)
+
+
+HASHIN_XML = """
+<settings>
+  <solver n="64">
+    <method>basic</method>
+    <tol>1e-10</tol>
+    <materials>
+      <matrix mu="1" lambda="3.63867684478" />
+      <mat2 mu="3" lambda="2" />
+      <mat1 mu="5" lambda="4" />
+    </materials>
+  </solver>
+  <actions>
+    <run_load_case e11="1" e22="1" e33="1" outfile="" />
+  </actions>
+</settings>
+"""
+
+
+def test_hashin_coated_sphere_known_answer():
+    """demo/elasticity/hashin/project.xml:30-32: <sigma> = 12.9152 * I, the reference's own
+    recorded result for this project (n=64, tol 1e-10, Voigt).  The recorded digits are
+    reproduced with voxel-centre (binary) phase indicators -- 12.915237 -- whereas interface-
+    smoothed fractions give 12.9203 (both on the CPU oracle and here), so the demo comment
+    predates the smoothing default; the phases are therefore injected as arrays.  Pins
+    polarisation, stencils, FFT, Green operator and the stop rule end to end."""
+    n = 64
+    x = (np.arange(n) + 0.5) / n - 0.5
+    r = np.sqrt(x[:, None, None] ** 2 + x[None, :, None] ** 2 + x[None, None, :] ** 2)
+    fg = FG()
+    fg.set_xml(HASHIN_XML)
+    fg.set_phase_field("mat2", (r < 0.4).astype(float))
+    fg.set_phase_field("mat1", (r < 0.2).astype(float))
+    assert fg.run() == 0
+    s = np.array(fg.get_mean_stress())
+    assert np.abs(s[:3] - 12.9152).max() < 5e-5      # all printed digits
+    assert np.abs(s[3:]).max() < 1e-3               # staggered shear points break the mirror symmetry
+    e = np.array(fg.get_mean_strain())
+    assert np.abs(e - np.array([1, 1, 1, 0, 0, 0])).max() < 1e-12
+    assert fg.get_residuals()[-1] <= 1e-10
+    # neutral inclusion: k_eff close to the matrix bulk modulus k* = 4.3053435 (theory)
+    assert abs(s[0] / 3 - 4.305343511446667) < 5e-4
+
+
+def test_hashin_project_with_place_fiber_runs():
+    """The demo XML itself (place_fiber + native voxeliser with interface smoothing)."""
+    fg = FG()
+    fg.set_xml(HASHIN_XML.replace("<actions>", """<actions>
+    <select_material name="mat1" /><place_fiber R="0.2" />
+    <select_material name="mat2" /><place_fiber R="0.4" />"""))
+    assert fg.run() == 0
+    s = np.array(fg.get_mean_stress())
+    assert np.abs(s[:3] - 12.9203).max() < 2e-4 and np.abs(s[3:]).max() < 1e-3
+    assert fg.get_volume_fraction("mat1") == pytest.approx(4 / 3 * np.pi * 0.2 ** 3, rel=1e-3)
+    assert fg.get_real_volume_fraction("mat1") == pytest.approx(4 / 3 * np.pi * 0.2 ** 3, rel=1e-12)
+
+
+PP_XML = """
+<settings>
+  <title>Title</title>
+  <solver n="16">
+    <method>basic</method>
+    <materials>
+      <matrix E="1" nu="0.3" />
+      <fiber  E="2" nu="0.3" />
+    </materials>
+  </solver>
+  <actions>
+    <select_material name="fiber" />
+    <place_fiber R="0.5" />
+    <run_load_case e11="1" />
+    <run_load_case e22="1" />
+    <python>
+      fg.set_variable("seen", variable)
+    </python>
+  </actions>
+</settings>
+"""
+
+
+def test_pure_python_demo_flow():
+    """demo/python/pure_python/project.py:1-76 walk-through of the FG API."""
+    fg = FG()
+    fg.set_xml(PP_XML)
+    fg.set("solver..n", 32)
+    fg.set("solver.tol", 1e-8)
+    fg.set("solver.materials.fiber.", E=10, nu=0.35)
+    fg.set("actions.run_load_case[0].", e11=2)
+    fg.set("actions.run_load_case[1].", e22=0, e33=1)
+    calls = []
+
+    def cb():
+        res = fg.get_residuals()[-1]
+        calls.append(res)
+        return res < 1e-4
+    fg.set_convergence_callback(cb)
+    fg.set_variable("variable", [1, 2, 3])
+    assert fg.run() == 0
+    assert fg.get_variable("seen") == [1, 2, 3]
+    assert calls and calls[-1] < 1e-4 and all(c >= 1e-4 for c in calls[-len(fg.get_residuals()):-1])
+    phases = fg.get_phase_names()
+    assert phases == ["matrix", "fiber"]
+    vf = [fg.get_volume_fraction(p) for p in phases]
+    assert sum(vf) == pytest.approx(1.0, abs=1e-12)
+    assert vf[1] == pytest.approx(4 / 3 * np.pi * 0.125, rel=2e-3)
+    u = fg.get_field("u")
+    assert u.shape == (3, 32, 32, 32)
+    sig = fg.get_field("sigma", range_x=[0, 5], components=[0, 3])
+    assert sig.shape == (2, 2, 32, 32)
+    full = fg.get_field("sigma")
+    assert np.array_equal(sig, full[np.ix_([0, 3], [0, 5])])
+    assert fg.get_field("fiber").shape == (1, 32, 32, 32)
+    ms = fg.get_mean_stress()
+    assert len(ms) == 6 and ms[2] > 0             # last load case: e33 = 1
+    assert fg.get_mean_strain()[2] == pytest.approx(1.0, abs=1e-10)
+    assert fg.get_solve_time() > 0 and not fg.get_error()
+    assert fg.get_mean_energy() > 0
+    with pytest.raises(RuntimeError, match="Unknown field"):
+        fg.get_field("nope")
+
+
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_fg_sphere_project_matches_oracle(mixing):
+    """Same XML project, same phi / normals: FG (GPU) vs the oracle loop: Ceff within 1e-9
+    (north_star asks 1e-6), identical iteration counts."""
+    fg = FG()
+    fg.set_xml("""
+    <settings><solver n="24"><method>basic</method><gamma_scheme>staggered</gamma_scheme><tol>1e-8</tol>
+      <mixing_rule>%s</mixing_rule>
+      <materials><matrix E="1" nu="0.3" /><incl E="10" nu="0.2" /></materials></solver>
+      <actions><select_material name="incl" /><place_fiber R="0.3" /><init_phase normals="1" />
+      <calc_effective_properties /></actions></settings>""" % mixing)
+    assert fg.run() == 0
+    C = np.array(fg.get_effective_property())
+    phi = fg.get_field("phi")
+    nrm = fg.get_field("normals")
+    m0, m1 = material_from_pair(E=1, nu=0.3), material_from_pair(E=10, nu=0.2)
+    o = LSOracle(24, 24, 24, mats=[(m0["mu"], m0["lambda"]), (m1["mu"], m1["lambda"])], phis=[phi[0], phi[1]],
+                 normals=nrm, mixing_rule=mixing, tol=1e-8)
+    Co = o.calc_effective_properties()
+    assert rel_err(C, Co) < 1e-9
+    assert fg._lss.iterations == o.ceff_iterations[-1]
+    # cubic symmetry of the sphere RVE
+    assert C[0, 0] == pytest.approx(C[1, 1], rel=1e-9) and C[3, 3] == pytest.approx(C[5, 5], rel=1e-9)
+
+
+def test_read_raw_data_orders_and_multiphase(tmp_path):
+    """read_raw_data  F:25494-25573: column order (x fastest, default) vs row order, gz,
+    uint8 scaling, down-sampling by block averaging, material_<v> class maps."""
+    rng = np.random.default_rng(3)
+    n = 16
+    vol = (rng.random((n, n, n)) > 0.7).astype(np.uint8) * 255
+    col = tmp_path / "col.raw.gz"
+    with gzip.open(col, "wb") as f:
+        f.write(vol.transpose(2, 1, 0).tobytes())      # x fastest in the file
+    row = tmp_path / "row.raw"
+    row.write_bytes(b"HEAD" + vol.tobytes())
+    xml = """
+    <settings><solver n="%d"><method>basic</method><tol>1e-6</tol>
+      <materials><matrix K="0.037" mu="0.044" /><quartz K="37.0" mu="44.0" /></materials></solver>
+      <actions><read_raw_data material="quartz" filename="%s" %s /><run_load_case e11="1" /></actions></settings>"""
+    results = []
+    for nn, fn, extra in ((n, col, ""), (n, row, 'order="row" header_bytes="4"'), (n // 2, col, 'n="%d"' % n)):
+        fg = FG()
+        fg.set_xml(xml % (nn, fn, extra))
+        assert fg.run() == 0
+        results.append((fg.get_field("quartz")[0], np.array(fg.get_mean_stress())))
+    assert np.array_equal(results[0][0], vol / 255.0)
+    assert np.array_equal(results[1][0], results[0][0])
+    assert rel_err(results[1][1], results[0][1]) < 1e-12
+    down = (vol / 255.0).reshape(8, 2, 8, 2, 8, 2).mean(axis=(1, 3, 5))
+    assert np.allclose(results[2][0], down, atol=1e-15)
+    # class map: value 0 -> matrix, 1 -> quartz (scale = 1)
+    cls = tmp_path / "cls.raw"
+    cls.write_bytes((vol // 255).astype(np.uint8).transpose(2, 1, 0).tobytes())
+    fg = FG()
+    fg.set_xml("""
+    <settings><solver n="%d"><method>basic</method><tol>1e-6</tol>
+      <materials><matrix K="0.037" mu="0.044" /><quartz K="37.0" mu="44.0" /></materials></solver>
+      <actions><read_raw_data filename="%s" scale="1" material_0="matrix" material_1="quartz" />
+      <run_load_case e11="1" /></actions></settings>""" % (n, cls))
+    assert fg.run() == 0
+    assert np.array_equal(fg.get_field("quartz")[0], vol / 255.0)
+    assert rel_err(np.array(fg.get_mean_stress()), results[0][1]) < 1e-12
+
+
+def test_error_conventions():
+    """C++ exceptions -> RuntimeError; failures inside the iteration -> run() returns 1 and
+    get_error() is True (F:396-406, F:21202-21208, F:26484)."""
+    fg = FG()
+    fg.set_xml(PP_XML.replace("<run_load_case e22=\"1\" />", "<frobnicate />"))
+    with pytest.raises(RuntimeError, match="Unknown action"):
+        fg.run()
+    fg = FG()
+    fg.set_xml(PP_XML.replace('E="2" nu="0.3"', 'E="float(\'nan\')" nu="0.3"'))
+    assert fg.run() == 1
+    assert fg.get_error()
+    fg = FG()
+    fg.set_xml(PP_XML.replace("<method>basic</method>", ""))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        fg.set_variable("variable", 0)
+        assert fg.run() == 0
+        assert any("method=cg" in str(x.message) for x in w)
+    # cancel() from a callback makes run() fail (F:25190-25193)
+    fg = FG()
+    fg.set_xml(PP_XML)
+    fg.set_variable("variable", 0)
+    fg.set_convergence_callback(lambda: fg.cancel())
+    assert fg.run() == 1 and fg.get_error()

@@ -129,6 +129,23 @@ def test_three_layer_laminate_demo(mixing):
     assert np.abs(C - Cex).max() / np.abs(Cex).max() < 1e-9
 
 
+def test_hashin_coated_sphere_demo_value():
+    """demo/elasticity/hashin/project.xml:30-32 records <sigma> = 12.9152 I for the coated
+    sphere (n=64, tol 1e-10, Voigt).  With voxel-centre phase indicators the oracle returns
+    12.915237 -- every printed digit of the reference's own result."""
+    n = 64
+    x = (np.arange(n) + 0.5) / n - 0.5
+    r = np.sqrt(x[:, None, None] ** 2 + x[None, :, None] ** 2 + x[None, None, :] ** 2)
+    p2 = (r < 0.4).astype(float)
+    p1 = (r < 0.2).astype(float)
+    phis = [1 - p2, p2 - p1, p1]   # normalizePhi: last material wins (F:17613-17626)
+    o = LSOracle(n, n, n, mats=[(1.0, 3.63867684478), (3.0, 2.0), (5.0, 4.0)], phis=phis, tol=1e-10)
+    assert o.run([1, 1, 1, 0, 0, 0]) is False
+    s = o.mean_stress()
+    assert np.abs(s[:3] - 12.9152).max() < 5e-5
+    assert np.abs(s[3:]).max() < 1e-3   # staggered shear points break the mirror symmetry slightly
+
+
 def test_laminate_mixing_exact_for_subvoxel_interface():
     """The laminate rule is exact when the interface cuts a voxel parallel to a face:
     layers 0.25/0.75 on 10 voxels (voxel 2 is half/half) must reproduce the closed form,
