@@ -51,30 +51,36 @@ A_STAGE_BYTES_PER_VOXEL = 632
 
 
 def cpu_baseline(n, mixing, budget_s=20.0):
-    """Oracle (NumPy restatement of the reference pass structure) timed on the host cores,
-    on a bounded sample: passes of the same grid until ~budget_s is used (at least one)."""
+    """The reference's per-iteration loop nests restated in C/OpenMP (oracle/c, pass structure of
+    BASELINE.md section 3) + pocketfft (scipy.fft, workers = cores) in place of threaded FFTW,
+    timed on all host cores on a bounded sample: passes of the same RVE until ~budget_s is used."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle.ls_oracle import LSOracle
+    from oracle.c_oracle import CRef
     from fibergen_amd.rve import synthetic_fiber_rve
     from helpers import INCLUSION, MATRIX, lame
-    phi, normals = synthetic_fiber_rve(n, K=max(1, 40 * (n[0] // 128) ** 3) if n[0] >= 128 else 5,
-                                       R=0.05 * 128 / max(n[0], 128), L=0.4 * 128 / max(n[0], 128), seed=0)
-    o = LSOracle(*n, mats=[lame(**MATRIX), lame(**INCLUSION)], phis=[1 - phi, phi], normals=normals,
-                 mixing_rule=mixing)
-    o.calc_ref_material()
+    scale = max(n[0], 128) / 128.0
+    K = int(round(40 * scale ** 3)) if n[0] >= 128 else 5
+    phi, normals = synthetic_fiber_rve(n, K=K, R=0.05 / scale, L=0.4 / scale, seed=0,
+                                       with_normals=(mixing == "laminate"))
+    c = CRef(n, (1.0, 1.0, 1.0), [lame(**MATRIX), lame(**INCLUSION)], [1 - phi, phi], normals, mixing)
     E = np.array([1.0, 0, 0, 0, 0, 0])
     eps = np.zeros((6,) + tuple(n))
+    mu_0 = 0.5 * (lame(**MATRIX)[0] + lame(**INCLUSION)[0])  # any positive reference medium: cost is identical
+    eps = c.basic_scheme(E, eps, mu_0, 0.0)   # warm-up (page faults, pocketfft plan cache)
+    c.fft_seconds = 0.0
     t0 = time.perf_counter()
     it = 0
     while True:
-        eps = o.basic_scheme(E, eps)
-        o.component_norm(eps)
+        eps = c.basic_scheme(E, eps, mu_0, 0.0)
+        c.component_norm(eps)
         it += 1
-        if time.perf_counter() - t0 > budget_s or it >= 20:
+        if time.perf_counter() - t0 > budget_s or it >= 50:
             break
     dt = time.perf_counter() - t0
-    return {"value": it / dt, "unit": "it/s", "cores": 1, "kind": "port",
-            "sample": "%d passes of the same %dx%dx%d RVE, NumPy oracle (pocketfft rfftn), 1 thread" % (it, *n)}
+    return {"value": it / dt, "unit": "it/s", "cores": int(c.threads), "kind": "port",
+            "fft_share": c.fft_seconds / dt,
+            "sample": "%d passes of the same %dx%dx%d RVE; reference loop nests in C/OpenMP (oracle/c) + "
+                      "pocketfft rfftn/irfftn with %d workers standing in for threaded FFTW" % (it, *n, c.threads)}
 
 
 def main():

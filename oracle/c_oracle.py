@@ -1,0 +1,107 @@
+"""ctypes wrapper of oracle/c/libfg_ref.so: the reference's per-iteration loop nests in
+C/OpenMP with the FFT supplied by scipy.fft (pocketfft, `workers` threads) in place of
+threaded FFTW.  TEST INFRASTRUCTURE ONLY (checker + bench.py cpu_baseline)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import scipy.fft
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _P(a):
+    return a.ctypes.data_as(_dp)
+
+
+def load(build=True):
+    so = os.path.join(_HERE, "c", "libfg_ref.so")
+    if not os.path.exists(so) and build:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "c")], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    lib.ref_max_threads.restype = ctypes.c_int
+    return lib
+
+
+class CRef:
+    """One pass of basicScheme (F:20558-20578) with the reference's pass structure."""
+
+    def __init__(self, n, dims, mats, phis, normals=None, mixing="voigt", threads=None):
+        self.lib = load()
+        self.nx, self.ny, self.nz = n
+        self.dims = tuple(float(d) for d in dims)
+        self.N = self.nx * self.ny * self.nz
+        self.mu = np.array([m[0] for m in mats], dtype=np.float64)
+        self.lam = np.array([m[1] for m in mats], dtype=np.float64)
+        self.phi = np.ascontiguousarray(np.stack(phis), dtype=np.float64)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+        self.mixing = {"voigt": 0, "laminate": 1}[mixing]
+        self.threads = threads or self.lib.ref_max_threads()
+        self.lib.ref_set_threads(int(self.threads))
+        self.eps_g = np.finfo(float).eps
+        self.eps_a = np.finfo(float).eps ** (2.0 / 3.0)
+        self.fft_seconds = 0.0
+
+    def _d(self, v):
+        return ctypes.c_double(float(v))
+
+    def calc_stress(self, mu_0, lambda_0, eps, alpha=1.0):
+        tau = np.empty_like(eps)
+        err = self.lib.ref_calc_stress(self.nx, self.ny, self.nz, _P(eps), _P(self.phi),
+                                       _P(self.normals) if self.normals is not None else None, len(self.mu),
+                                       _P(self.mu), _P(self.lam), self.mixing, self._d(mu_0), self._d(lambda_0),
+                                       self._d(alpha), self._d(self.eps_g), self._d(self.eps_a), _P(tau))
+        if err:
+            raise RuntimeError("The laminate mixing rule supports only two phase mixtures")
+        return tau
+
+    def mean_stress(self, eps):
+        out = np.zeros(6)
+        self.lib.ref_mean_stress(self.nx, self.ny, self.nz, _P(eps), _P(self.phi),
+                                 _P(self.normals) if self.normals is not None else None, len(self.mu), _P(self.mu),
+                                 _P(self.lam), self.mixing, self._d(self.eps_g), self._d(self.eps_a), _P(out))
+        return out
+
+    def div(self, tau):
+        f = np.empty((3,) + tau.shape[1:])
+        self.lib.ref_div(self.nx, self.ny, self.nz, *map(self._d, self.dims), _P(tau), _P(f))
+        return f
+
+    def g0(self, mu_0, lambda_0, fh, alpha):
+        fh = np.ascontiguousarray(fh, dtype=np.complex128)
+        self.lib.ref_g0(self.nx, self.ny, self.nz, *map(self._d, self.dims), self._d(mu_0), self._d(lambda_0),
+                        self._d(alpha), fh.ctypes.data_as(ctypes.c_void_p))
+        return fh
+
+    def eps_op(self, E, u):
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        y = np.empty((6,) + u.shape[1:])
+        self.lib.ref_eps(self.nx, self.ny, self.nz, *map(self._d, self.dims), _P(E), _P(u), _P(y))
+        return y
+
+    def component_norm(self, eps):
+        m = np.zeros(6)
+        self.lib.ref_component_norm(ctypes.c_size_t(self.N), _P(eps), _P(m))
+        return m
+
+    def basic_scheme(self, E, eps, mu_0, lambda_0):
+        import time
+        tau = self.calc_stress(mu_0, lambda_0, eps)
+        f = self.div(tau)
+        t = time.perf_counter()
+        fh = scipy.fft.rfftn(f, axes=(1, 2, 3), workers=self.threads)     # 3 x FFTW r2c  F:18496-18499
+        self.fft_seconds += time.perf_counter() - t
+        v = fh.view(np.float64)
+        self.lib.ref_scale(ctypes.c_size_t(v.size), self._d(1 / float(self.N)), _P(v))  # F:18501-18506
+        fh = self.g0(mu_0, lambda_0, fh, -1.0)
+        t = time.perf_counter()
+        u = scipy.fft.irfftn(fh, s=(self.nx, self.ny, self.nz), axes=(1, 2, 3), workers=self.threads, norm="forward")
+        self.fft_seconds += time.perf_counter() - t
+        u = np.ascontiguousarray(u)
+        e = self.eps_op(E, u)
+        self.lib.ref_add(ctypes.c_size_t(self.N), _P(np.zeros(6)), _P(e))  # applyBCProjector's eps.add(R)  F:20269
+        return e
