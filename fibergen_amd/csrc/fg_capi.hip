@@ -54,6 +54,46 @@ fg_solver* fg_create(int nx, int ny, int nz, double dx, double dy, double dz, in
   return nullptr;
 }
 
+fg_solver* fg_create_slab(int nx, int ny, int nz, double dx, double dy, double dz, int device, int rank, int nranks) {
+  try {
+    fg_solver* s = new fg_solver();
+    try {
+      s->impl = new fg::Solver(nx, ny, nz, dx, dy, dz, device, rank, nranks);
+    } catch (...) {
+      delete s;
+      throw;
+    }
+    return s;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+  } catch (...) {
+    g_create_error = "unknown error";
+  }
+  return nullptr;
+}
+
+int fg_slab_phase(fg_solver* s, int phase, const double* E6, const double* R6) {
+  return guarded(s, [&](fg::Solver& v) { v.slab_phase(phase, E6, R6); });
+}
+
+void* fg_exchange_buffer(fg_solver* s, const char* name, unsigned long* bytes) {
+  void* p = nullptr;
+  guarded(s, [&](fg::Solver& v) {
+    if (!name) throw std::runtime_error("NULL argument");
+    size_t b = 0;
+    p = v.exchange_buffer(name, &b);
+    if (bytes) *bytes = (unsigned long)b;
+  });
+  return p;
+}
+
+int fg_local_sums(fg_solver* s, const char* what, double* out) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!what || !out) throw std::runtime_error("NULL argument");
+    v.local_sums(what, out);
+  });
+}
+
 void fg_destroy(fg_solver* s) {
   if (!s) return;
   try {

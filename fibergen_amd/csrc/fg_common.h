@@ -47,6 +47,7 @@ struct Grid {
   long n;       // nx*ny*nzp padded reals per component
   long nxyz;    // nx*ny*nz
   double dx, dy, dz;
+  double hx, hy, hz;  // voxels per unit length of the GLOBAL grid: n_a / d_a  (F:18618-18620)
 };
 
 FG_HD Grid make_grid(int nx, int ny, int nz, double dx, double dy, double dz) {
@@ -58,6 +59,7 @@ FG_HD Grid make_grid(int nx, int ny, int nz, double dx, double dy, double dz) {
   g.n = (long)nx * g.nyzp;
   g.nxyz = (long)nx * ny * nz;
   g.dx = dx; g.dy = dy; g.dz = dz;
+  g.hx = nx / dx; g.hy = ny / dy; g.hz = nz / dz;
   return g;
 }
 

@@ -23,6 +23,20 @@ struct G0Tables {
   const cplx* kp[3];
 };
 
+// x-halo planes ([ny][nzp] doubles each) of an x-slab: lo = plane just below the slab, hi = just above.
+// Null pointers mean "periodic wrap inside this field" (single-GPU case).
+//   div : lo[0] = tau0 ;            hi[0] = tau5, hi[1] = tau4
+//   eps : lo[0] = u1, lo[1] = u2 ;  hi[0] = u0
+struct XHalo {
+  const double* lo[2];
+  const double* hi[2];
+};
+
+struct G0Layout {
+  int transposed;  // 0: [nx][ny][nzc]   1: y-slab [nyl][nx][nzc]
+  int nyl, jj0;
+};
+
 constexpr int kMaxReduceBlocks = 4096;  // partial-sum rows of the two-stage reductions
 
 int reduce_blocks(const Grid& g);
@@ -34,10 +48,14 @@ void launch_stress_mean(const Grid& g, const StressParams& sp, const FieldPtrs<6
                         int* error_flag, hipStream_t s);
 void launch_stress_const(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<6>& eps, const FieldPtrs<6>& tau,
                          hipStream_t s);
-void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, hipStream_t s);
-void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, hipStream_t s);
+void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);
+void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
+               hipStream_t s);
 void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps, const Vec6& E, const Vec6& R,
-                     bool add_R, double* partial, double* sumsq6, hipStream_t s);
+                     bool add_R, double* partial, double* sumsq6, const XHalo& h, hipStream_t s);
+void launch_transpose_A(const double* src, double* dst, int nxl, int ny, int nyl, int nzc, bool to_blocks, hipStream_t s);
+void launch_transpose_B(const double* src, double* dst, int nx, int nxl, int nyl, int nzc, bool to_blocks, hipStream_t s);
+void launch_copy(const double* src, double* dst, long ndoubles, hipStream_t s);
 void launch_sum6(const Grid& g, const FieldPtrs<6>& x, bool square, double* partial, double* out6, hipStream_t s);
 void launch_sum1(const Grid& g, const double* x, double* partial, double* out1, hipStream_t s);
 void launch_tangent_minmax(const Grid& g, const PhaseTable& pt, int mixing, const FieldPtrs<kMaxPhases>& phi,

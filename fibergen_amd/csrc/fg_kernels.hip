@@ -130,8 +130,8 @@ __global__ __launch_bounds__(kBlock) void k_stress(Grid g, StressParams sp, Fiel
 // ----------------------------------------------------------------------------- divergence
 // divOperatorStaggered  F:18853-18908:
 //  f0 = D-x t0 + D+y t5 + D+z t4 ; f1 = D+x t5 + D-y t1 + D+z t3 ; f2 = D+x t4 + D+y t3 + D-z t2
-__global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtrs<3> f) {
-  const double hx = g.nx / g.dx, hy = g.ny / g.dy, hz = g.nz / g.dz;
+__global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtrs<3> f, XHalo h) {
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
   for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
     const PairPos p = pair_pos(pidx, g);
@@ -148,11 +148,14 @@ __global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtr
 
     const double2 t0 = ld2(t.p[0], p.off), t1 = ld2(t.p[1], p.off), t2 = ld2(t.p[2], p.off);
     const double2 t3 = ld2(t.p[3], p.off), t4 = ld2(t.p[4], p.off), t5 = ld2(t.p[5], p.off);
-    const double2 t0xb = ld2(t.p[0], p.off + xb);
+    // x neighbours of the first / last local plane come from the halo planes when the grid is an x-slab
+    const long inplane = p.off - (long)p.i * g.nyzp;
+    const bool lo = p.i == 0 && h.lo[0] != nullptr, hi = p.i + 1 == g.nx && h.hi[0] != nullptr;
+    const double2 t0xb = lo ? ld2(h.lo[0], inplane) : ld2(t.p[0], p.off + xb);
     const double2 t5yf = ld2(t.p[5], p.off + yf);
-    const double2 t5xf = ld2(t.p[5], p.off + xf);
+    const double2 t5xf = hi ? ld2(h.hi[0], inplane) : ld2(t.p[5], p.off + xf);
     const double2 t1yb = ld2(t.p[1], p.off + yb);
-    const double2 t4xf = ld2(t.p[4], p.off + xf);
+    const double2 t4xf = hi ? ld2(h.hi[1], inplane) : ld2(t.p[4], p.off + xf);
     const double2 t3yf = ld2(t.p[3], p.off + yf);
     const double t4zf2 = t.p[4][rowoff + kf2];
     const double t3zf2 = t.p[3][rowoff + kf2];
@@ -176,18 +179,28 @@ __global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtr
 
 // ----------------------------------------------------------------------------- Green operator
 // G0OperatorFourierStaggeredGeneral  F:19834-19927, in place on 3 complex components.
-__global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables tb, double c10, double c20) {
-  const long nfreq = (long)g.nx * g.ny * g.nzc;
+// layout.transposed == 0: [nx][ny][nzc] (g = full grid).  transposed == 1 (y-slab of the slab-decomposed
+// transform): [nyl][nx][nzc] with global ky = jj0 + jl; the zero mode lives on the slab with jj0 == 0.
+__global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables tb, double c10, double c20,
+                                               G0Layout lay) {
+  const long nfreq = lay.transposed ? (long)lay.nyl * g.nx * g.nzc : (long)g.nx * g.ny * g.nzc;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < nfreq; idx += (long)gridDim.x * blockDim.x) {
     const long row = idx / g.nzc;
     const int kk = (int)(idx - row * g.nzc);
-    const int ii = (int)(row / g.ny);
-    const int jj = (int)(row - (long)ii * g.ny);
+    int ii, jj;
+    if (lay.transposed) {
+      const int jl = (int)(row / g.nx);
+      ii = (int)(row - (long)jl * g.nx);
+      jj = lay.jj0 + jl;
+    } else {
+      ii = (int)(row / g.ny);
+      jj = (int)(row - (long)ii * g.ny);
+    }
     cplx* c0 = reinterpret_cast<cplx*>(fh.p[0]);
     cplx* c1 = reinterpret_cast<cplx*>(fh.p[1]);
     cplx* c2 = reinterpret_cast<cplx*>(fh.p[2]);
     cplx e0, e1, e2;
-    if (idx == 0) {
+    if (ii == 0 && jj == 0 && kk == 0) {
       e0 = e1 = e2 = cmake(0.0, 0.0);  // zero frequency  F:19924-19926
     } else {
       g0_point(c0[idx], c1[idx], c2[idx], tb.kpm[0][ii], tb.kpm[1][jj], tb.kpm[2][kk], tb.kp[0][ii], tb.kp[1][jj],
@@ -203,9 +216,9 @@ __global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables
 // epsOperatorStaggered  F:18614-18692, followed by eps += R (applyBCProjector  F:20263-20270)
 // and the per-component sums of squares of component_norm (F:10088-10138) fused in.
 __global__ __launch_bounds__(kBlock) void k_eps_norm(Grid g, FieldPtrs<3> u, FieldPtrs<6> eps, Vec6 E, Vec6 R, int add_R,
-                                                     double* partial) {
+                                                     double* partial, XHalo h) {
   __shared__ double smem[4 * 6];
-  const double hx = g.nx / g.dx, hy = g.ny / g.dy, hz = g.nz / g.dz;
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
@@ -221,7 +234,11 @@ __global__ __launch_bounds__(kBlock) void k_eps_norm(Grid g, FieldPtrs<3> u, Fie
     const int kf2 = (p.k + 2 >= g.nz) ? p.k + 2 - g.nz : p.k + 2;
 
     const double2 u0 = ld2(u.p[0], p.off), u1 = ld2(u.p[1], p.off), u2 = ld2(u.p[2], p.off);
-    const double2 u0xf = ld2(u.p[0], p.off + xf), u1xb = ld2(u.p[1], p.off + xb), u2xb = ld2(u.p[2], p.off + xb);
+    const long inplane = p.off - (long)p.i * g.nyzp;
+    const bool lo = p.i == 0 && h.lo[0] != nullptr, hi = p.i + 1 == g.nx && h.hi[0] != nullptr;
+    const double2 u0xf = hi ? ld2(h.hi[0], inplane) : ld2(u.p[0], p.off + xf);
+    const double2 u1xb = lo ? ld2(h.lo[0], inplane) : ld2(u.p[1], p.off + xb);
+    const double2 u2xb = lo ? ld2(h.lo[1], inplane) : ld2(u.p[2], p.off + xb);
     const double2 u0yb = ld2(u.p[0], p.off + yb), u1yf = ld2(u.p[1], p.off + yf), u2yb = ld2(u.p[2], p.off + yb);
     const double u0zb = u.p[0][rowoff + kb], u1zb = u.p[1][rowoff + kb];
     const double u2zf2 = u.p[2][rowoff + kf2];
@@ -315,6 +332,49 @@ __global__ __launch_bounds__(kBlock) void k_tangent_minmax(Grid g, PhaseTable pt
   }
 }
 
+// Slab <-> pencil transposes of the 3 complex components, one complex per thread.
+// A: x-slab field [c][nxl][ny][nzc]  <->  blocks [q][c][nxl][nyl][nzc]   (q = owner of the y range)
+// B: blocks [p][c][nxl][nyl][nzc]    <->  y-slab field [c][nyl][nx][nzc]  (p = owner of the x range)
+__global__ __launch_bounds__(kBlock) void k_transpose_A(const cplx* src, cplx* dst, int nxl, int ny, int nyl, int nzc,
+                                                        int to_blocks) {
+  const long total = 3L * nxl * ny * nzc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int kz = (int)(idx % nzc);
+    long r = idx / nzc;
+    const int y = (int)(r % ny);
+    r /= ny;
+    const int xl = (int)(r % nxl);
+    const int c = (int)(r / nxl);
+    const int q = y / nyl, yl = y - q * nyl;
+    const long blk = ((((long)q * 3 + c) * nxl + xl) * nyl + yl) * nzc + kz;
+    if (to_blocks) dst[blk] = src[idx];
+    else dst[idx] = src[blk];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_transpose_B(const cplx* src, cplx* dst, int nx, int nxl, int nyl, int nzc,
+                                                        int to_blocks) {
+  const long total = 3L * nyl * nx * nzc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int kz = (int)(idx % nzc);
+    long r = idx / nzc;
+    const int x = (int)(r % nx);
+    r /= nx;
+    const int yl = (int)(r % nyl);
+    const int c = (int)(r / nyl);
+    const int p = x / nxl, xl = x - p * nxl;
+    const long blk = ((((long)p * 3 + c) * nxl + xl) * nyl + yl) * nzc + kz;
+    if (to_blocks) dst[blk] = src[idx];
+    else dst[idx] = src[blk];
+  }
+}
+
+// copy one x-plane of a padded component (halo packing)
+__global__ __launch_bounds__(kBlock) void k_copy(const double* src, double* dst, long n2) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x)
+    st2(dst, 2 * i, ld2(src, 2 * i));
+}
+
 // calcStressConst  F:17973-18020 : tau = 2 mu0 eps + lambda0 tr(eps) I  (whole padded arrays)
 __global__ __launch_bounds__(kBlock) void k_stress_const(long n2, double two_mu, double lambda, FieldPtrs<6> eps,
                                                          FieldPtrs<6> tau) {
@@ -403,24 +463,45 @@ void launch_stress_const(const Grid& g, double mu_0, double lambda_0, const Fiel
   FG_HIP_CHECK(hipGetLastError());
 }
 
-void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, hipStream_t s) {
+void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s) {
   const long npairs = (long)g.nx * g.ny * g.nzc;
-  hipLaunchKernelGGL(k_div, dim3(grid_for(npairs, 1 << 20)), dim3(kBlock), 0, s, g, tau, f);
+  hipLaunchKernelGGL(k_div, dim3(grid_for(npairs, 1 << 20)), dim3(kBlock), 0, s, g, tau, f, h);
   FG_HIP_CHECK(hipGetLastError());
 }
 
-void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, hipStream_t s) {
-  const long nfreq = (long)g.nx * g.ny * g.nzc;
-  hipLaunchKernelGGL(k_g0, dim3(grid_for(nfreq, 1 << 20)), dim3(kBlock), 0, s, g, fh, tb, c10, c20);
+void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
+               hipStream_t s) {
+  const long nfreq = lay.transposed ? (long)lay.nyl * g.nx * g.nzc : (long)g.nx * g.ny * g.nzc;
+  hipLaunchKernelGGL(k_g0, dim3(grid_for(nfreq, 1 << 20)), dim3(kBlock), 0, s, g, fh, tb, c10, c20, lay);
   FG_HIP_CHECK(hipGetLastError());
 }
 
 void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps, const Vec6& E, const Vec6& R,
-                     bool add_R, double* partial, double* sumsq6, hipStream_t s) {
+                     bool add_R, double* partial, double* sumsq6, const XHalo& h, hipStream_t s) {
   const int nb = reduce_blocks(g);
-  hipLaunchKernelGGL(k_eps_norm, dim3(nb), dim3(kBlock), 0, s, g, u, eps, E, R, add_R ? 1 : 0, partial);
+  hipLaunchKernelGGL(k_eps_norm, dim3(nb), dim3(kBlock), 0, s, g, u, eps, E, R, add_R ? 1 : 0, partial, h);
   FG_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, sumsq6);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_transpose_A(const double* src, double* dst, int nxl, int ny, int nyl, int nzc, bool to_blocks, hipStream_t s) {
+  const long total = 3L * nxl * ny * nzc;
+  hipLaunchKernelGGL(k_transpose_A, dim3(grid_for(total, 1 << 20)), dim3(kBlock), 0, s, reinterpret_cast<const cplx*>(src),
+                     reinterpret_cast<cplx*>(dst), nxl, ny, nyl, nzc, to_blocks ? 1 : 0);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_transpose_B(const double* src, double* dst, int nx, int nxl, int nyl, int nzc, bool to_blocks, hipStream_t s) {
+  const long total = 3L * nyl * nx * nzc;
+  hipLaunchKernelGGL(k_transpose_B, dim3(grid_for(total, 1 << 20)), dim3(kBlock), 0, s, reinterpret_cast<const cplx*>(src),
+                     reinterpret_cast<cplx*>(dst), nx, nxl, nyl, nzc, to_blocks ? 1 : 0);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_copy(const double* src, double* dst, long ndoubles, hipStream_t s) {
+  const long n2 = ndoubles / 2;
+  hipLaunchKernelGGL(k_copy, dim3(grid_for(n2, 1 << 16)), dim3(kBlock), 0, s, src, dst, n2);
   FG_HIP_CHECK(hipGetLastError());
 }
 

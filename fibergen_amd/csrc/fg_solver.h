@@ -58,7 +58,8 @@ struct StageTimes {
 
 class Solver {
  public:
-  Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device);
+  // (nx, ny, nz) is the GLOBAL grid; with nranks > 1 this object holds x-slab `rank` of it.
+  Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device, int rank = 0, int nranks = 1);
   ~Solver();
   Solver(const Solver&) = delete;
   Solver& operator=(const Solver&) = delete;
@@ -99,6 +100,14 @@ class Solver {
   // device pointer of a padded component (for zero-copy wrapping by the caller)
   double* device_component(const std::string& name, int c);
 
+  // slab-decomposed pass: phases 0..4 with exchanges in between (see fg_solver.hip)
+  void slab_phase(int phase, const double* E6, const double* R6);
+  double* exchange_buffer(const std::string& name, size_t* bytes);
+  void local_sums(const std::string& what, double* out);
+  int rank() const { return rank_; }
+  int nranks() const { return nranks_; }
+  int nx_global() const { return nxg_; }
+
   // single stages on the solver's own buffers (parity tests, profiling)
   void run_stage(int stage, const double* E6);
   void enable_stage_timing(bool on);
@@ -123,7 +132,13 @@ class Solver {
   PhaseTable pt_;
   int device_;
   hipStream_t stream_;
+  int rank_ = 0, nranks_ = 1;
+  int nxg_ = 0;        // global nx (g_.nx is the local slab thickness)
+  int nyl_ = 0;        // ny / nranks: thickness of the y-slab after the transpose
+  long nglobal_ = 0;   // global voxel count
   std::unique_ptr<Fft3> fft_;
+  std::unique_ptr<Fft3> fft_t_;  // x transform in the y-slab layout
+  double* halo_[4] = {nullptr, nullptr, nullptr, nullptr};  // send_lo, send_hi, recv_lo, recv_hi (2 planes each)
 
   double* eps_ = nullptr;      // 6 padded components
   double* tau_ = nullptr;      // 6

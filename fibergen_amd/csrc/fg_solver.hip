@@ -28,10 +28,19 @@ double now_seconds() {
 }
 }  // namespace
 
-Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device) : device_(device) {
+Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device, int rank, int nranks)
+    : device_(device), rank_(rank), nranks_(nranks), nxg_(nx) {
   if (nx < 1 || ny < 1 || nz < 1) throw std::runtime_error("grid dimensions must be >= 1");
   if (!(dx > 0) || !(dy > 0) || !(dz > 0)) throw std::runtime_error("RVE dimensions must be > 0");
-  g_ = make_grid(nx, ny, nz, dx, dy, dz);
+  if (nranks < 1 || rank < 0 || rank >= nranks) throw std::runtime_error("invalid rank / number of ranks");
+  if (nranks > 1 && (nx % nranks != 0 || ny % nranks != 0))
+    throw std::runtime_error("slab decomposition needs nx and ny divisible by the number of ranks");
+  // x-slab: this rank owns planes [rank*nxl, (rank+1)*nxl) of every component; cell sizes stay global
+  const int nxl = nx / nranks;
+  nyl_ = ny / nranks;
+  g_ = make_grid(nxl, ny, nz, dx, dy, dz);
+  g_.hx = nx / dx;
+  nglobal_ = (long)nx * ny * nz;
   if (g_.n >= (1L << 31)) throw std::runtime_error("grid too large: padded component exceeds 2^31 reals");
   int ndev = 0;
   FG_HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -61,10 +70,19 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   FG_HIP_CHECK(hipMemsetAsync(derr_, 0, sizeof(int), stream_));
 
   fft_.reset(new Fft3(g_, stream_));
+  if (nranks_ > 1 || true) {
+    // x-lines in the y-slab layout [nyl][nx][nzc] are "y lines" of a (nyl, nx, nz) grid
+    fft_t_.reset(new Fft3(make_grid(nyl_, nxg_, nz, 1.0, 1.0, 1.0), stream_));
+    const size_t plane = (size_t)g_.nyzp * sizeof(double);
+    for (int k = 0; k < 4; ++k) {
+      FG_HIP_CHECK(hipMalloc(&halo_[k], 2 * plane));
+      FG_HIP_CHECK(hipMemsetAsync(halo_[k], 0, 2 * plane, stream_));
+    }
+  }
 
   // Separable factors of G0OperatorFourierStaggeredGeneral  F:19838-19876, evaluated on the
   // host with the same libm calls the reference makes per frequency.
-  const int len[3] = {nx, ny, nz};
+  const int len[3] = {nxg_, ny, nz};
   const double d[3] = {dx, dy, dz};
   for (int a = 0; a < 3; ++a) {
     const int n = len[a];
@@ -99,6 +117,9 @@ Solver::~Solver() {
   (void)hipSetDevice(device_);
   (void)hipStreamSynchronize(stream_);
   fft_.reset();
+  fft_t_.reset();
+  for (int k = 0; k < 4; ++k)
+    if (halo_[k]) (void)hipFree(halo_[k]);
   double* bufs[] = {eps_, tau_, fu_, phi_, normals_, partial_, dscal_};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
@@ -261,6 +282,7 @@ void Solver::time_end(int stage) {
 // basicScheme  F:20558-20578 + GammaOperatorStaggered  F:20288-20300:
 //   tau = (C - C0):eps ; f = div tau ; u = G0 f ; eps = E + sym grad u (+ R)
 void Solver::basic_scheme(const double* E6) {
+  if (nranks_ != 1) throw std::runtime_error("basic_scheme: slab solvers are driven phase by phase (fg_slab_phase)");
   if (pt_.n < 1) throw std::runtime_error("No materials specified");
   if (opt_.mixing == kMixLaminate && !normals_) throw std::runtime_error("laminate mixing needs interface normals");
   FieldPtrs<kMaxPhases> phi;
@@ -282,15 +304,15 @@ void Solver::basic_scheme(const double* E6) {
     launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);
     FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
     FG_HIP_CHECK(hipStreamSynchronize(stream_));
-    for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)g_.nxyz;
+    for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)nglobal_;
   }
 
   time_begin(1);
-  launch_div(g_, ptrs6(tau_), ptrs3(fu_), stream_);
+  launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
   time_end(1);
   {
     // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
-    const double scale = 1 / (double)g_.nxyz;
+    const double scale = 1 / (double)nglobal_;
     const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
     time_begin(2);
     fft_->r2c_z(fu_, 3, g_.n);
@@ -313,7 +335,7 @@ void Solver::basic_scheme(const double* E6) {
       tb.kpm[a] = g0_kpm_[a];
       tb.kp[a] = g0_kp_[a];
     }
-    launch_g0(g_, ptrs3(fu_), tb, c10, c20, stream_);
+    launch_g0(g_, ptrs3(fu_), tb, c10, c20, G0Layout{0, 0, 0}, stream_);
   }
   time_end(5);
   time_begin(6);
@@ -339,7 +361,8 @@ void Solver::basic_scheme(const double* E6) {
     if (R.v[c] != 0.0) add_R = true;
   }
   time_begin(9);
-  launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), E, R, add_R, partial_, dscal_ + kSlotSumSq, stream_);
+  launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), E, R, add_R, partial_, dscal_ + kSlotSumSq,
+                  XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
   time_end(9);
   if (timing_) times_.count++;
 }
@@ -358,7 +381,7 @@ void Solver::mean_stress(double* out6) {
   FieldPtrs<3> nrm;
   for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
   // meanPK1: alpha /= nxyz, accumulate  F:12318-12340
-  launch_stress_mean(g_, stress_params(0.0, 0.0, 1.0 / (double)g_.nxyz), ptrs6(eps_), phi, nrm, partial_,
+  launch_stress_mean(g_, stress_params(0.0, 0.0, 1.0 / (double)nglobal_), ptrs6(eps_), phi, nrm, partial_,
                      dscal_ + kSlotMean, derr_, stream_);
   FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -370,7 +393,7 @@ void Solver::mean_strain(double* out6) {
   launch_sum6(g_, ptrs6(eps_), false, partial_, dscal_ + kSlotMean, stream_);
   FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
-  for (int c = 0; c < 6; ++c) out6[c] = hscal_[kSlotMean + c] / (double)g_.nxyz;
+  for (int c = 0; c < 6; ++c) out6[c] = hscal_[kSlotMean + c] / (double)nglobal_;
 }
 
 double Solver::volume_fraction(int p) {
@@ -379,7 +402,7 @@ double Solver::volume_fraction(int p) {
   launch_sum1(g_, phi_ + (long)p * g_.n, partial_, dscal_ + kSlotMisc, stream_);
   FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMisc, dscal_ + kSlotMisc, sizeof(double), hipMemcpyDeviceToHost, stream_));
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
-  return hscal_[kSlotMisc] / (double)g_.nxyz;
+  return hscal_[kSlotMisc] / (double)nglobal_;
 }
 
 // calcRefMaterial  F:22283-22313 -> getRefMaterial  F:12153-12236
@@ -472,7 +495,7 @@ bool Solver::run(const double* E6, const double* S6) {
     double m[6], s9 = 0.0;
     for (int c = 0; c < 6; ++c) {
       sumsq_[c] = hscal_[kSlotSumSq + c];
-      m[c] = std::sqrt(sumsq_[c] / (double)g_.nxyz);
+      m[c] = std::sqrt(sumsq_[c] / (double)nglobal_);
     }
     for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
     for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
@@ -509,6 +532,146 @@ bool Solver::run(const double* E6, const double* S6) {
   return failed;
 }
 
+// ------------------------------------------------------------------ slab-decomposed pass
+// One basicScheme pass of an x-slab, cut at the four exchange points.  Between the phases the
+// caller (fibergen_amd/distributed.py) moves the named buffers between ranks:
+//   after phase 0 and 3: halo planes   halo_send_hi -> right neighbour's halo_recv_lo,
+//                                       halo_send_lo -> left  neighbour's halo_recv_hi
+//   after phase 1 and 2: all-to-all    block q of a2a_send -> rank q's block <my rank> of a2a_recv
+// a2a_send / a2a_recv alias tau components 0-2 / 3-5 (tau is dead once the divergence is taken).
+void Solver::slab_phase(int phase, const double* E6, const double* R6) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  if (pt_.n < 1) throw std::runtime_error("No materials specified");
+  if (opt_.mixing == kMixLaminate && !normals_) throw std::runtime_error("laminate mixing needs interface normals");
+  const long plane = g_.nyzp;
+  const long last = (long)(g_.nx - 1) * g_.nyzp;
+  double* a2a_send = tau_;
+  double* a2a_recv = tau_ + 3 * g_.n;
+  double *send_lo = halo_[0], *send_hi = halo_[1], *recv_lo = halo_[2], *recv_hi = halo_[3];
+  const double alpha = -1.0;
+  switch (phase) {
+    case 0: {  // polarisation; halo of tau for the divergence
+      FieldPtrs<kMaxPhases> phi;
+      for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+      FieldPtrs<3> nrm;
+      for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+      launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
+      launch_copy(tau_ + 0 * g_.n + last, send_hi, plane, stream_);          // tau0, my last plane  -> right (x-1 there)
+      launch_copy(tau_ + 5 * g_.n, send_lo, plane, stream_);                 // tau5, my first plane -> left  (x+1 there)
+      launch_copy(tau_ + 4 * g_.n, send_lo + plane, plane, stream_);         // tau4
+      break;
+    }
+    case 1: {  // divergence, z and y transforms, pack for the slab -> pencil transpose
+      XHalo h = {{recv_lo, nullptr}, {recv_hi, recv_hi + plane}};
+      launch_div(g_, ptrs6(tau_), ptrs3(fu_), h, stream_);
+      fft_->r2c_z(fu_, 3, g_.n);
+      fft_->c2c_y(fu_, 3, g_.n, -1, 1.0);
+      launch_transpose_A(fu_, a2a_send, g_.nx, g_.ny, nyl_, g_.nzc, true, stream_);
+      break;
+    }
+    case 2: {  // x transform, Green operator and inverse x transform on the y-slab
+      launch_transpose_B(a2a_recv, fu_, nxg_, g_.nx, nyl_, g_.nzc, false, stream_);
+      const long cs = (long)nyl_ * nxg_ * g_.nzp;
+      const double scale = 1 / (double)nglobal_;
+      if (nxg_ > 1) fft_t_->c2c_y(fu_, 3, cs, -1, scale);
+      else fft_t_->scale(fu_, 3, cs, scale);
+      const double c10 = -alpha / (opt_.mu_0);
+      const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+      G0Tables tb;
+      for (int a = 0; a < 3; ++a) {
+        tb.kpm[a] = g0_kpm_[a];
+        tb.kp[a] = g0_kp_[a];
+      }
+      Grid gg = g_;
+      gg.nx = nxg_;
+      FieldPtrs<3> f3;
+      for (int c = 0; c < 3; ++c) f3.p[c] = fu_ + c * cs;
+      launch_g0(gg, f3, tb, c10, c20, G0Layout{1, nyl_, rank_ * nyl_}, stream_);
+      if (nxg_ > 1) fft_t_->c2c_y(fu_, 3, cs, +1, 1.0);
+      launch_transpose_B(fu_, a2a_send, nxg_, g_.nx, nyl_, g_.nzc, true, stream_);
+      break;
+    }
+    case 3: {  // back on the x-slab: inverse y and z transforms; halo of u for the strain operator
+      launch_transpose_A(a2a_recv, fu_, g_.nx, g_.ny, nyl_, g_.nzc, false, stream_);
+      fft_->c2c_y(fu_, 3, g_.n, +1, 1.0);
+      fft_->c2r_z(fu_, 3, g_.n);
+      launch_copy(fu_ + 1 * g_.n + last, send_hi, plane, stream_);           // u1, my last plane  -> right
+      launch_copy(fu_ + 2 * g_.n + last, send_hi + plane, plane, stream_);   // u2
+      launch_copy(fu_ + 0 * g_.n, send_lo, plane, stream_);                  // u0, my first plane -> left
+      break;
+    }
+    case 4: {  // strain + local sums of squares
+      XHalo h = {{recv_lo, recv_lo + plane}, {recv_hi, nullptr}};
+      Vec6 E, R;
+      bool add_R = false;
+      for (int c = 0; c < 6; ++c) {
+        E.v[c] = E6 ? E6[c] : 0.0;
+        R.v[c] = R6 ? R6[c] : 0.0;
+        if (R.v[c] != 0.0) add_R = true;
+      }
+      launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), E, R, add_R, partial_, dscal_ + kSlotSumSq, h, stream_);
+      FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      check_device_error("stress");
+      for (int c = 0; c < 6; ++c) sumsq_[c] = hscal_[kSlotSumSq + c];
+      break;
+    }
+    default:
+      throw std::runtime_error("unknown slab phase");
+  }
+}
+
+double* Solver::exchange_buffer(const std::string& name, size_t* bytes) {
+  const size_t plane2 = 2 * (size_t)g_.nyzp * sizeof(double);
+  const size_t a2a = 3 * (size_t)g_.n * sizeof(double);
+  if (name == "halo_send_lo") { *bytes = plane2; return halo_[0]; }
+  if (name == "halo_send_hi") { *bytes = plane2; return halo_[1]; }
+  if (name == "halo_recv_lo") { *bytes = plane2; return halo_[2]; }
+  if (name == "halo_recv_hi") { *bytes = plane2; return halo_[3]; }
+  if (name == "a2a_send") { *bytes = a2a; return tau_; }
+  if (name == "a2a_recv") { *bytes = a2a; return tau_ + 3 * g_.n; }
+  throw std::runtime_error("unknown exchange buffer '" + name + "'");
+}
+
+// Local (this slab's) contributions to the global reductions of the loop; the caller adds / min-maxes
+// them over ranks in rank order.
+void Solver::local_sums(const std::string& what, double* out) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  FieldPtrs<kMaxPhases> phi;
+  for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+  FieldPtrs<3> nrm;
+  for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+  int n = 6, slot = kSlotMean;
+  if (what == "sumsq") {
+    for (int c = 0; c < 6; ++c) out[c] = sumsq_[c];
+    return;
+  } else if (what == "epsilon") {
+    launch_sum6(g_, ptrs6(eps_), false, partial_, dscal_ + kSlotMean, stream_);
+  } else if (what == "tau") {
+    launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);
+  } else if (what == "stress") {  // sum of PK1(eps)/N_global over the slab  (meanPK1  F:12312-12351)
+    if (pt_.n < 1) throw std::runtime_error("No materials specified");
+    launch_stress_mean(g_, stress_params(0.0, 0.0, 1.0 / (double)nglobal_), ptrs6(eps_), phi, nrm, partial_,
+                       dscal_ + kSlotMean, derr_, stream_);
+  } else if (what == "tangent_minmax") {
+    if (pt_.n < 1) throw std::runtime_error("No materials specified");
+    launch_tangent_minmax(g_, pt_, opt_.mixing, phi, partial_, dscal_ + kSlotMinMax, derr_, stream_);
+    n = 2;
+    slot = kSlotMinMax;
+  } else if (what.rfind("phi:", 0) == 0) {
+    const int p = std::stoi(what.substr(4));
+    if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
+    launch_sum1(g_, phi_ + (long)p * g_.n, partial_, dscal_ + kSlotMisc, stream_);
+    n = 1;
+    slot = kSlotMisc;
+  } else {
+    throw std::runtime_error("unknown local sum '" + what + "'");
+  }
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + slot, dscal_ + slot, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  check_device_error(what.c_str());
+  for (int c = 0; c < n; ++c) out[c] = hscal_[slot + c];
+  if (what == "tangent_minmax") out[1] = -out[1];  // stored as (min, -max)
+}
+
 // ------------------------------------------------------------------ stages and fields
 void Solver::run_stage(int stage, const double* E6) {
   FG_HIP_CHECK(hipSetDevice(device_));
@@ -528,10 +691,10 @@ void Solver::run_stage(int stage, const double* E6) {
       launch_stress_const(g_, opt_.mu_0, opt_.lambda_0, ptrs6(eps_), ptrs6(tau_), stream_);
       break;
     case kStageDiv:
-      launch_div(g_, ptrs6(tau_), ptrs3(fu_), stream_);
+      launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
       break;
     case kStageFftForward:
-      fft_->forward(fu_, 3, g_.n, 1 / (double)g_.nxyz);
+      fft_->forward(fu_, 3, g_.n, 1 / (double)nglobal_);
       break;
     case kStageG0: {
       const double alpha = E6 ? E6[0] : -1.0;  // stage tests pass alpha in E6[0]
@@ -542,7 +705,7 @@ void Solver::run_stage(int stage, const double* E6) {
         tb.kpm[a] = g0_kpm_[a];
         tb.kp[a] = g0_kp_[a];
       }
-      launch_g0(g_, ptrs3(fu_), tb, c10, c20, stream_);
+      launch_g0(g_, ptrs3(fu_), tb, c10, c20, G0Layout{0, 0, 0}, stream_);
       break;
     }
     case kStageFftInverse:
@@ -551,7 +714,8 @@ void Solver::run_stage(int stage, const double* E6) {
     case kStageEps: {
       Vec6 Ev, R;
       for (int c = 0; c < 6; ++c) Ev.v[c] = E[c], R.v[c] = 0.0;
-      launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), Ev, R, false, partial_, dscal_ + kSlotSumSq, stream_);
+      launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), Ev, R, false, partial_, dscal_ + kSlotSumSq,
+                      XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
       FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
       FG_HIP_CHECK(hipStreamSynchronize(stream_));
       for (int c = 0; c < 6; ++c) sumsq_[c] = hscal_[kSlotSumSq + c];
@@ -610,8 +774,8 @@ void Solver::get_field(const std::string& name, double* out) {
   }
   if (name == "u") {  // u = G0 div (C0 : eps), alpha = 1  F:15509-15521
     launch_stress_const(g_, opt_.mu_0, opt_.lambda_0, ptrs6(eps_), ptrs6(tau_), stream_);
-    launch_div(g_, ptrs6(tau_), ptrs3(fu_), stream_);
-    fft_->forward(fu_, 3, g_.n, 1 / (double)g_.nxyz);
+    launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
+    fft_->forward(fu_, 3, g_.n, 1 / (double)nglobal_);
     const double alpha = 1.0;
     const double c10 = -alpha / (opt_.mu_0);
     const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
@@ -620,7 +784,7 @@ void Solver::get_field(const std::string& name, double* out) {
       tb.kpm[a] = g0_kpm_[a];
       tb.kp[a] = g0_kp_[a];
     }
-    launch_g0(g_, ptrs3(fu_), tb, c10, c20, stream_);
+    launch_g0(g_, ptrs3(fu_), tb, c10, c20, G0Layout{0, 0, 0}, stream_);
     fft_->inverse(fu_, 3, g_.n);
     for (int c = 0; c < 3; ++c) download_unpadded(fu_ + (long)c * g_.n, out + (long)c * g_.nxyz);
     return;

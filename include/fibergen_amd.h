@@ -126,6 +126,31 @@ int fg_run_stage(fg_solver* s, int stage, const double* E6);
 int fg_enable_stage_timing(fg_solver* s, int enable);
 int fg_get_stage_times(const fg_solver* s, double* ms /* [FG_NUM_TIMED_KERNELS] */, long* count);
 
+/* ---- slab decomposition over the GPUs of a node ----------------------------
+ * The reference is single-process; this is the multi-GPU counterpart of one LSSolver.  Rank r
+ * of nranks owns the x-planes [r*nx/nranks, (r+1)*nx/nranks) of every field (nx and ny must be
+ * divisible by nranks); all arrays passed to / returned by the calls above then have the LOCAL
+ * shape [ncomp][nx/nranks][ny][nz].  One pass of basicScheme is cut at its four exchange points:
+ *
+ *   fg_slab_phase(s,0)  polarisation                         -> halo exchange (tau)
+ *   fg_slab_phase(s,1)  divergence, z- and y-FFT, pack       -> all-to-all
+ *   fg_slab_phase(s,2)  x-FFT, Green operator, x-FFT^-1      -> all-to-all
+ *   fg_slab_phase(s,3)  y- and z-FFT^-1                      -> halo exchange (u)
+ *   fg_slab_phase(s,4)  strain operator (+E, +R), local sums of squares
+ *
+ * Halo exchange: "halo_send_hi" -> right neighbour's "halo_recv_lo", "halo_send_lo" -> left
+ * neighbour's "halo_recv_hi" (periodic; 2 planes of [ny][2*(nz/2+1)] doubles each).
+ * All-to-all: "a2a_send" holds nranks blocks [3][nx/P][ny/P][nz/2+1] complex, block q goes to
+ * rank q; "a2a_recv" holds the blocks received, ordered by source rank.  The caller moves the
+ * bytes (RCCL, driven by fibergen_amd/distributed.py); fg_exchange_buffer
+ * returns device pointers.  fg_local_sums returns this slab's contribution to a global
+ * reduction: "sumsq" (6, after phase 4), "epsilon" (6), "tau" (6), "stress" (6, already / N),
+ * "tangent_minmax" (min, max), "phi:<p>" (1). */
+fg_solver* fg_create_slab(int nx, int ny, int nz, double dx, double dy, double dz, int device, int rank, int nranks);
+int fg_slab_phase(fg_solver* s, int phase, const double* E6, const double* R6);
+void* fg_exchange_buffer(fg_solver* s, const char* name, unsigned long* bytes);
+int fg_local_sums(fg_solver* s, const char* what, double* out);
+
 /* ---- geometry pre-processing (host side, no GPU needed) ------------------------------
  * Analytic shapes placed with <place_fiber> (F:25788-25822) -> phase volume fractions and
  * interface normals: LSSolver::initPhi F:17489-17581 (adaptive sub-voxel integration,
