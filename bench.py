@@ -83,6 +83,63 @@ def cpu_baseline(n, mixing, budget_s=20.0):
                       "pocketfft rfftn/irfftn with %d workers standing in for threaded FFTW" % (it, *n, c.threads)}
 
 
+def slab_section(args, n, K, rank, world, local_rank, dist, torch):
+    """The same RVE as ONE problem, x-slab decomposed over the ranks."""
+    from fibergen_amd.distributed import DistributedLSSolver
+    from fibergen_amd.rve import synthetic_fiber_rve
+    from helpers import INCLUSION, MATRIX, lame
+    if n[0] % world or n[1] % world:
+        return {"error": "grid not divisible by the number of ranks"}
+    scale = max(args.n, 128) / 128.0
+    phi, normals = synthetic_fiber_rve(n, K=K, R=0.05 / scale, L=0.4 / scale, seed=0,
+                                       with_normals=(args.mixing == "laminate"))
+    s = DistributedLSSolver(*n, device=local_rank)
+    s.set_num_phases(2)
+    mats = [lame(**MATRIX), lame(**INCLUSION)]
+    s.set_phase(0, mats[0][0], mats[0][1], s.slab(1.0 - phi))
+    s.set_phase(1, mats[1][0], mats[1][1], s.slab(phi))
+    if normals is not None:
+        s.set_normals(s.slab(normals))
+    s.set_options(mixing_rule=args.mixing)
+    del phi, normals
+    s.calc_ref_material()
+    E = np.array([1.0, 0, 0, 0, 0, 0])
+    s.iterate(E, max(2, args.warmup))
+    torch.cuda.synchronize()
+    dist.barrier()
+    s.comm_time = 0.0
+    t0 = time.perf_counter()
+    s.iterate(E, args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, s.comm_time], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt, comm = float(t[0].item()), float(t[1].item())
+    return {"value": args.steps / dt, "unit": "it/s", "ms_per_step": 1e3 * dt / args.steps, "scaling": "strong",
+            "exchange_ms_per_step": 1e3 * comm / args.steps,
+            "parallelism": "x-slabs x%d, 2 all-to-all + 2 halo exchanges per pass (RCCL p2p)" % world}
+
+
+def guarded_slab_section(args, n, K, rank, world, local_rank, dist, torch, out):
+    import threading
+
+    def give_up():
+        if rank == 0 and out is not None:
+            out["slab"] = {"error": "slab section exceeded %d s" % args.slab_timeout}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    timer = threading.Timer(args.slab_timeout, give_up)
+    timer.daemon = True
+    timer.start()
+    try:
+        return slab_section(args, n, K, rank, world, local_rank, dist, torch)
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        timer.cancel()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +149,8 @@ def main():
     ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-slab", action="store_true", help="N > 1: skip the slab-decomposed measurement")
+    ap.add_argument("--slab-timeout", type=int, default=240)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,10 +243,21 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             s.close()
             out["cpu_baseline"] = cpu_baseline(n, args.mixing, args.cpu_budget)
+    if world > 1 and not args.no_slab:
+        # Second measurement: ONE problem slab-decomposed over all ranks (x-slabs, two RCCL
+        # all-to-alls per pass).  Guarded: a failure or a stall here must not cost the line above.
+        s.close()
+        slab = guarded_slab_section(args, n, K, rank, world, local_rank, dist, torch, out)
+        if out is not None:
+            out["slab"] = slab
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":
