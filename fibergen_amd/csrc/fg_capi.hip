@@ -147,6 +147,8 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       if (value != FG_MIXING_VOIGT && value != FG_MIXING_LAMINATE) throw std::runtime_error("Unknown mixing rule");
       o.mixing = (int)value;
     } else if (k == "update_ref") o.update_ref = value != 0;
+    else if (k == "fuse_x") o.fuse_x = value != 0;
+    else if (k == "fuse_stress_div") o.fuse_stress_div = value != 0;
     else throw std::runtime_error("unknown option '" + k + "'");
   });
 }

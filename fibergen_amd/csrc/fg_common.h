@@ -37,12 +37,16 @@ FG_HD cplx cconj(cplx a) { return cmake(a.re, -a.im); }
 FG_HD cplx cmul_mi(cplx a) { return cmake(a.im, -a.re); }
 FG_HD cplx cmul_pi(cplx a) { return cmake(-a.im, a.re); }
 
-// Geometry of one padded field component (reference layout):
-// real  [nx][ny][nzp], nzp = 2*(nz/2+1), z fastest; complex view [nx][ny][nzc].
+// Geometry of one padded field component: the reference's in-place r2c layout,
+// real [nx][ny][nzp], z fastest, complex view [nx][ny][nzc] on the same bytes -- except that the
+// row pitch is rounded up to 128 bytes (8 complex) so that every row, FFT tile and halo plane
+// starts on a cache-line boundary (nz/2+1 = 257 complex = 4112 B rows made every strided FFT pass
+// fetch 1.5x its bytes).  nzf = nz/2+1 is the number of frequencies actually stored per row.
 struct Grid {
   int nx, ny, nz;
-  int nzc;      // nz/2+1
-  int nzp;      // 2*nzc
+  int nzf;      // nz/2+1 complex coefficients per row
+  int nzc;      // complex row pitch >= nzf (multiple of 8 for nz >= 64)
+  int nzp;      // real row pitch = 2*nzc
   long nyzp;    // ny*nzp
   long n;       // nx*ny*nzp padded reals per component
   long nxyz;    // nx*ny*nz
@@ -53,7 +57,8 @@ struct Grid {
 FG_HD Grid make_grid(int nx, int ny, int nz, double dx, double dy, double dz) {
   Grid g;
   g.nx = nx; g.ny = ny; g.nz = nz;
-  g.nzc = nz / 2 + 1;
+  g.nzf = nz / 2 + 1;
+  g.nzc = (nz >= 64) ? ((g.nzf + 7) / 8) * 8 : g.nzf;
   g.nzp = 2 * g.nzc;
   g.nyzp = (long)ny * g.nzp;
   g.n = (long)nx * g.nyzp;

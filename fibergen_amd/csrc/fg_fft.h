@@ -12,6 +12,14 @@
 
 namespace fg {
 
+// Green-operator inputs of the fused pass: separable k tables (kpm[a], kp[a]; for the axis that is
+// transformed the table index is the frequency, tables 1 and 2 are indexed by ky / kz) and c10, c20.
+struct G0Params {
+  const double* kpm[3];
+  const cplx* kp[3];
+  double c10, c20;
+};
+
 class Fft3 {
  public:
   Fft3(const Grid& g, hipStream_t stream);
@@ -29,6 +37,8 @@ class Fft3 {
   void c2c_x(double* data, int ncomp, long comp_stride, int dir, double scale);
   void c2r_z(double* data, int ncomp, long comp_stride);
   void scale(double* data, int ncomp, long comp_stride, double scale);
+  bool can_fuse(int axis) const;
+  void fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0);
 
   bool fast_x() const { return fast_[0]; }
   bool fast_y() const { return fast_[1]; }

@@ -49,6 +49,24 @@ __global__ __launch_bounds__(K::THREADS) void k_zpass(ZArgs a, long comp_stride)
   DevicePhases<K, ZArgs, 0>::run(r, blockIdx.x, threadIdx.x, lds, a);
 }
 
+template <class K, int PH>
+struct DevicePhasesX {
+  __device__ __forceinline__ static void run(typename K::Regs& r, int block, int tid, double* lds, const XFusedArgs& a) {
+    K::template phase<PH>(r, block, tid, lds, a);
+    if constexpr (PH + 1 < K::NPHASE) {
+      if constexpr (K::barrier_after(PH)) __syncthreads();
+      DevicePhasesX<K, PH + 1>::run(r, block, tid, lds, a);
+    }
+  }
+};
+
+template <class K>
+__global__ __launch_bounds__(K::THREADS) void k_xfused(XFusedArgs a) {
+  extern __shared__ __align__(16) double lds[];
+  typename K::Regs r;
+  DevicePhasesX<K, 0>::run(r, blockIdx.x, threadIdx.x, lds, a);
+}
+
 __global__ void k_dft_strided_generic(const cplx* src, cplx* dst, long ls, long os, int ncols, int nouter, int n,
                                       int dir, double scale, const cplx* w) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,6 +134,23 @@ void launch_z(const ZArgs& a, int ncomp, long comp_stride, int lines, hipStream_
   }
   long nblocks = (a.nrows + lines - 1) / lines;
   hipLaunchKernelGGL(k_zpass<K>, dim3((unsigned)nblocks, ncomp), dim3(K::THREADS), lds, s, a, comp_stride);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+template <int N>
+void xfused_n(XFusedArgs a, int nouter, hipStream_t s) {
+  constexpr int C = XTileCols<N>::value;
+  using K = XFusedKernel<N, C>;
+  static bool configured = false;
+  const size_t lds = K::LDS_DOUBLES * sizeof(double);
+  if (!configured) {
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused<K>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  a.tiles_per_outer = (a.ncols + C - 1) / C;
+  const long nblocks = (long)a.tiles_per_outer * nouter;
+  hipLaunchKernelGGL(k_xfused<K>, dim3((unsigned)nblocks), dim3(K::THREADS), lds, s, a);
   FG_HIP_CHECK(hipGetLastError());
 }
 
@@ -201,6 +236,48 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
                        reinterpret_cast<cplx*>(scratch_), ls, os, ncols, nouter, n, dir, scale, wgen_[axis]);
     FG_HIP_CHECK(hipGetLastError());
     FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+  }
+}
+
+// forward transform along `axis` (0 = x of [nx][ny][nzc], 1 = y, used for the x lines of a y-slab),
+// scale, Green operator, inverse transform -- one kernel for the three components.
+bool Fft3::can_fuse(int axis) const {
+  const int n = axis == 0 ? g_.nx : g_.ny;
+  return fast_[axis] && n <= 512;
+}
+
+void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0) {
+  if (!can_fuse(axis)) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
+  const int n = axis == 0 ? g_.nx : g_.ny;
+  XFusedArgs a;
+  a.data = reinterpret_cast<cplx*>(data);
+  a.comp_stride = comp_stride / 2;
+  a.ls = axis == 0 ? (long)g_.ny * g_.nzc : g_.nzc;
+  a.os = axis == 0 ? 0 : (long)g_.ny * g_.nzc;
+  a.ncols = axis == 0 ? g_.ny * g_.nzc : g_.nzc;
+  a.tiles_per_outer = 0;
+  a.flat_cols = axis == 0 ? 1 : 0;
+  a.nzc = g_.nzc;
+  a.nzf = g_.nzf;
+  a.jj0 = jj0;
+  a.scale = scale;
+  a.c10 = gp.c10;
+  a.c20 = gp.c20;
+  a.tw = tw_[axis];
+  for (int k = 0; k < 3; ++k) {
+    a.kpm[k] = gp.kpm[k];
+    a.kp[k] = gp.kp[k];
+  }
+  const int nouter = axis == 0 ? 1 : g_.nx;
+  switch (n) {
+    case 8: xfused_n<8>(a, nouter, stream_); break;
+    case 16: xfused_n<16>(a, nouter, stream_); break;
+    case 32: xfused_n<32>(a, nouter, stream_); break;
+    case 64: xfused_n<64>(a, nouter, stream_); break;
+    case 128: xfused_n<128>(a, nouter, stream_); break;
+    case 256: xfused_n<256>(a, nouter, stream_); break;
+    case 512: xfused_n<512>(a, nouter, stream_); break;
+    default: throw std::runtime_error("fft: unsupported fused length");
   }
 }
 

@@ -21,6 +21,13 @@ struct ZLines {
   static constexpr int value = (2048 / M) > 4 ? (2048 / M) : 4;
 };
 
+// Tile width of the fused x pass: 256-thread blocks, so that two blocks share a CU at 256 VGPRs
+// and one block's loads / barriers overlap the other's butterflies.
+template <int N>
+struct XTileCols {
+  static constexpr int value = (2048 / N) > 8 ? (2048 / N) : 8;  // 64-B segments (C = 4) measured 35 % slower
+};
+
 // ------------------------------------------------------------------ strided c2c
 // Lines of N points, `ls` complex apart, for `ncols` adjacent columns (stride 1)
 // and `nouter` repetitions `os` apart.  A block transforms a tile of C columns.
@@ -223,6 +230,132 @@ FG_HD void c2r_point(const cplx* xrow, double* orow, int nz, int m, const cplx* 
   if (nz % 2 == 0 && nz > 1) s += (m % 2 == 0 ? 1.0 : -1.0) * xrow[nz / 2].re;
   orow[m] = s;
 }
+
+}  // namespace fft
+}  // namespace fg
+
+// ------------------------------------------------------------------ fused x pass
+// forward x-FFT (x 1/N)  ->  Green operator G0  ->  inverse x-FFT, for the 3 components of a
+// tile of C columns, in one kernel: the spectrum never leaves the registers, which removes the
+// Green-operator sweep and one write + one read of the three components per iteration
+// (SURVEY 8d "maximum legal fusion").  G0OperatorFourierStaggeredGeneral  F:19834-19927.
+#include "fg_stage_math.h"
+
+namespace fg {
+namespace fft {
+
+struct XFusedArgs {
+  cplx* data;          // component 0
+  long comp_stride;    // complex elements between components
+  long ls, os;         // line stride / outer stride (complex elements)
+  int ncols, tiles_per_outer;
+  int flat_cols;       // 1: columns are the flattened (ky,kz) index of [nx][ny][nzc]; 0: column = kz, outer = ky - jj0
+  int nzc, nzf, jj0;
+  double scale;        // 1/N applied to the forward spectrum (F:18501-18506)
+  double c10, c20;
+  const cplx* tw;
+  const double* kpm[3];
+  const cplx* kp[3];
+};
+
+template <int N, int C>
+struct XFusedKernel {
+  static constexpr int T = N / 8;
+  static constexpr int THREADS = T * C;
+  static constexpr int PN = N + N / 8;
+  static constexpr int NPL = Line<N>::NPHASE;   // phases of one line transform
+  // with two exchanges per transform the LDS image is double-buffered: the barrier after a gather
+  // can then be dropped (the next scatter goes to the other buffer), 12 instead of 24 per tile
+  static constexpr bool PINGPONG = num_passes(N) == 3;
+  static constexpr int BUF_DOUBLES = 2 * PN * C;
+  static constexpr int LDS_DOUBLES = (PINGPONG ? 2 : 1) * BUF_DOUBLES;
+  static constexpr int NPHASE = 6 * NPL;        // 3 forward + 3 inverse transforms
+  struct Regs {
+    cplx v[3][8];
+    long base;
+    int jt, t, jj, kk;
+    bool valid;
+  };
+  // register slot of the inverse transform's input that holds forward output slot q
+  // (last pass of radix R: slot q = (b, r) holds point jt + b*T + r*N/R = jt + (b + r*8/R)*T)
+  static constexpr int RL = pass_radix(N, num_passes(N) - 1);
+  static constexpr int inv_slot(int q) { return q / RL + (q % RL) * (8 / RL); }
+
+  template <int PH>
+  FG_HD static void phase(Regs& r, int block, int tid, double* lds, const XFusedArgs& a) {
+    const LdsMap L = {C, 1, PN * C};
+    constexpr int TR = PH / NPL;   // transform number: 0..2 forward comp TR, 3..5 inverse comp TR-3
+    constexpr int LP = PH % NPL;   // phase inside the transform
+    constexpr int comp = TR % 3;
+    if (PINGPONG) lds += ((LP / 2) % 2) * BUF_DOUBLES;
+    if (PH == 0) {
+      r.t = tid % C;
+      r.jt = tid / C;
+      const int o = block / a.tiles_per_outer;
+      const int col = (block % a.tiles_per_outer) * C + r.t;
+      r.valid = col < a.ncols;
+      r.base = (long)o * a.os + col;
+      if (a.flat_cols) {
+        r.jj = col / a.nzc;
+        r.kk = col - r.jj * a.nzc;
+      } else {
+        r.jj = a.jj0 + o;
+        r.kk = col;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          r.v[c][q] = r.valid ? a.data[c * a.comp_stride + r.base + (long)Line<N>::first_index(r.jt, q) * a.ls]
+                              : cmake(0.0, 0.0);
+    }
+    if (TR < 3) {
+      Line<N>::template phase<-1, LP>(r.v[comp], r.jt, lds, L, r.t, a.tw);
+      if (TR == 2 && LP == NPL - 1) {
+        // all three spectra are in registers: slot q holds kx = last_index(jt, q)
+        const bool live = r.valid && r.kk < a.nzf;
+        const double kpm1 = live ? a.kpm[1][r.jj] : 1.0, kpm2 = live ? a.kpm[2][r.kk] : 1.0;
+        const cplx kp1 = live ? a.kp[1][r.jj] : cmake(0.0, 0.0), kp2 = live ? a.kp[2][r.kk] : cmake(0.0, 0.0);
+        cplx w[3][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kx = Line<N>::last_index(r.jt, q);
+          cplx t0 = cscale(a.scale, r.v[0][q]), t1 = cscale(a.scale, r.v[1][q]), t2 = cscale(a.scale, r.v[2][q]);
+          cplx e0 = t0, e1 = t1, e2 = t2;
+          if (live) {
+            if (kx == 0 && r.jj == 0 && r.kk == 0) {
+              e0 = e1 = e2 = cmake(0.0, 0.0);   // zero frequency  F:19924-19926
+            } else {
+              g0_point(t0, t1, t2, a.kpm[0][kx], kpm1, kpm2, a.kp[0][kx], kp1, kp2, a.c10, a.c20, &e0, &e1, &e2);
+            }
+          }
+          w[0][q] = e0;
+          w[1][q] = e1;
+          w[2][q] = e2;
+        }
+        // re-order for the inverse transform's first pass (same point set, different slot order)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          r.v[c][inv_slot(0)] = w[c][0]; r.v[c][inv_slot(1)] = w[c][1]; r.v[c][inv_slot(2)] = w[c][2];
+          r.v[c][inv_slot(3)] = w[c][3]; r.v[c][inv_slot(4)] = w[c][4]; r.v[c][inv_slot(5)] = w[c][5];
+          r.v[c][inv_slot(6)] = w[c][6]; r.v[c][inv_slot(7)] = w[c][7];
+        }
+      }
+    } else {
+      Line<N>::template phase<+1, LP>(r.v[comp], r.jt, lds, L, r.t, a.tw);
+      if (LP == NPL - 1 && r.valid) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          a.data[comp * a.comp_stride + r.base + (long)Line<N>::last_index(r.jt, q) * a.ls] = r.v[comp][q];
+      }
+    }
+  }
+  // a barrier is needed between consecutive phases except at a transform boundary
+  // (the last phase of a transform does not touch LDS and the previous gather is already fenced)
+  static constexpr bool barrier_after(int ph) {
+    return (ph % NPL) != NPL - 1 && (!PINGPONG || (ph % NPL) % 2 == 0);
+  }
+};
 
 }  // namespace fft
 }  // namespace fg

@@ -35,6 +35,42 @@ __device__ __forceinline__ PairPos pair_pos(long pidx, const Grid& g) {
   return p;
 }
 
+// L2-aware traversal for the stencil kernels.  The pair space is re-ordered as
+// [y-chunk of ry rows][x][row in chunk][z pair] and every block sweeps one contiguous run of it;
+// blocks that share an XCD (blockIdx % 8, guide section 1) get adjacent runs.  The +-1 neighbours in
+// y (same chunk) and in x (next step of the sweep, ry rows x 9 arrays ~ 300 KB apart) are then served
+// by that XCD's 4 MiB L2 instead of being fetched again: the row-major sweep read every neighbour
+// from HBM (FETCH_SIZE 2.1x / 3.4x the algorithmic bytes for div / eps, profiles/r01_pmc_*).
+struct BlockRun {
+  long first, stride, count;  // pieces of kBlock pairs: first, first + stride, ...
+};
+
+// Piece r of block b is r*gridDim + remap(b): at any time the resident blocks work on one contiguous
+// window of the re-ordered pair space (a block that owned a long contiguous run of its own would make
+// the XCD's L2 juggle hundreds of far-apart streams -- measured: no reuse at all).
+__device__ __forceinline__ BlockRun block_run(long npieces) {
+  const long nb = gridDim.x, b = blockIdx.x;
+  BlockRun r;
+  r.first = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+  r.stride = nb;
+  r.count = r.first < npieces ? (npieces - r.first + nb - 1) / nb : 0;
+  return r;
+}
+
+__device__ __forceinline__ PairPos pair_pos_tiled(long q, const Grid& g, int ry) {
+  PairPos p;
+  long t = q / g.nzc;
+  p.k = 2 * (int)(q - t * g.nzc);
+  const int jr = (int)(t % ry);
+  t /= ry;
+  p.i = (int)(t % g.nx);
+  const int jc = (int)(t / g.nx);
+  p.j = jc * ry + jr;
+  p.row = (long)p.i * g.ny + p.j;
+  p.off = p.row * g.nzp + p.k;
+  return p;
+}
+
 // Deterministic block reduction of NV values per thread: wave shuffle tree, then
 // LDS across the 4 waves, lane 0 of wave 0 holds the result.
 template <int NV, class Op>
@@ -85,11 +121,17 @@ __global__ __launch_bounds__(kBlock) void k_stress(Grid g, StressParams sp, Fiel
     for (int c = 0; c < 6; ++c) e[c] = ld2(eps.p[c], p.off);
 #pragma unroll
     for (int q = 0; q < NPH; ++q) f[q] = q < sp.pt.n ? ld2(phi.p[q], p.off) : make_double2(0.0, 0.0);
+    nn[0] = nn[1] = nn[2] = make_double2(0.0, 0.0);
     if (MIX == kMixLaminate) {
+      // the normal is only used at composite voxels (some 0 < phi < 1): skip the 24 B/voxel elsewhere
+      bool mixed = false;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) nn[c] = ld2(normals.p[c], p.off);
-    } else {
-      nn[0] = nn[1] = nn[2] = make_double2(0.0, 0.0);
+      for (int q = 0; q < NPH; ++q)
+        mixed = mixed || (f[q].x != 0.0 && f[q].x != 1.0) || (f[q].y != 0.0 && f[q].y != 1.0);
+      if (mixed) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nn[c] = ld2(normals.p[c], p.off);
+      }
     }
     double F[6], ph[NPH], nv[3], P0[6], P1[6];
 #pragma unroll
@@ -130,11 +172,14 @@ __global__ __launch_bounds__(kBlock) void k_stress(Grid g, StressParams sp, Fiel
 // ----------------------------------------------------------------------------- divergence
 // divOperatorStaggered  F:18853-18908:
 //  f0 = D-x t0 + D+y t5 + D+z t4 ; f1 = D+x t5 + D-y t1 + D+z t3 ; f2 = D+x t4 + D+y t3 + D-z t2
-__global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtrs<3> f, XHalo h) {
+__global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtrs<3> f, XHalo h, int ry) {
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
-  for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
-    const PairPos p = pair_pos(pidx, g);
+  const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
+  for (long it = 0; it < run.count; ++it) {
+    const long pidx = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    if (pidx >= npairs) continue;
+    const PairPos p = pair_pos_tiled(pidx, g, ry);
     if (p.k >= g.nz) continue;
     const bool second = p.k + 1 < g.nz;
     // periodic neighbour offsets (F:14867-14891)
@@ -177,6 +222,129 @@ __global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtr
   }
 }
 
+// ----------------------------------------------------------------------------- stress + divergence, fused
+// f = div[(C - C0) : eps] in one sweep for Voigt mixing: the polarisation is never stored.  Each thread
+// re-evaluates the few tau components it needs at the six neighbours (a Hooke law is ~10 flops; the
+// neighbour loads are L1/L2 hits thanks to the L2-aware sweep), which removes the 6-component write and
+// read of tau: 176 -> 88 algorithmic bytes per voxel.  Bit-identical to k_stress followed by k_div.
+template <int NPH>
+struct VoxelIn {
+  double2 e[6];
+  double2 f[NPH];
+};
+
+template <int NPH>
+__global__ __launch_bounds__(kBlock) void k_stress_div_voigt(Grid g, StressParams sp, FieldPtrs<6> eps,
+                                                             FieldPtrs<kMaxPhases> phi, FieldPtrs<3> fo, int ry) {
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
+  for (long it = 0; it < run.count; ++it) {
+    const long pidx = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    if (pidx >= npairs) continue;
+    const PairPos p = pair_pos_tiled(pidx, g, ry);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+    const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+    const long rowoff = p.off - p.k;
+    const int kb = p.k == 0 ? g.nz - 1 : p.k - 1;
+    const int kf2 = (p.k + 2 >= g.nz) ? p.k + 2 - g.nz : p.k + 2;
+
+    double ph[NPH];
+    // ---- centre pair: all six components
+    double2 e[6], fc[NPH];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) e[c] = ld2(eps.p[c], p.off);
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) fc[q] = q < sp.pt.n ? ld2(phi.p[q], p.off) : make_double2(0.0, 0.0);
+    double2 t[6];
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) ph[q] = fc[q].x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c].x = voigt_tau_normal<NPH>(e[c].x, e[0].x, e[1].x, e[2].x, ph, sp);
+#pragma unroll
+    for (int c = 3; c < 6; ++c) t[c].x = voigt_tau_shear<NPH>(e[c].x, ph, sp);
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) ph[q] = fc[q].y;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c].y = voigt_tau_normal<NPH>(e[c].y, e[0].y, e[1].y, e[2].y, ph, sp);
+#pragma unroll
+    for (int c = 3; c < 6; ++c) t[c].y = voigt_tau_shear<NPH>(e[c].y, ph, sp);
+
+    // ---- neighbours: only the components the divergence uses
+    auto normal_at = [&](long off, int c) {  // tau_c (c < 3) of the pair at element offset off
+      const double2 a0 = ld2(eps.p[0], off), a1 = ld2(eps.p[1], off), a2 = ld2(eps.p[2], off);
+      double2 pf[NPH];
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) pf[q] = q < sp.pt.n ? ld2(phi.p[q], off) : make_double2(0.0, 0.0);
+      double pp[NPH];
+      double2 r;
+      const double2 ac = c == 0 ? a0 : (c == 1 ? a1 : a2);
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) pp[q] = pf[q].x;
+      r.x = voigt_tau_normal<NPH>(ac.x, a0.x, a1.x, a2.x, pp, sp);
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) pp[q] = pf[q].y;
+      r.y = voigt_tau_normal<NPH>(ac.y, a0.y, a1.y, a2.y, pp, sp);
+      return r;
+    };
+    auto shear2_at = [&](long off, int ca, int cb, double2* ra, double2* rb) {  // two shear components
+      const double2 a = ld2(eps.p[ca], off), b = ld2(eps.p[cb], off);
+      double2 pf[NPH];
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) pf[q] = q < sp.pt.n ? ld2(phi.p[q], off) : make_double2(0.0, 0.0);
+      double pp[NPH];
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) pp[q] = pf[q].x;
+      ra->x = voigt_tau_shear<NPH>(a.x, pp, sp);
+      rb->x = voigt_tau_shear<NPH>(b.x, pp, sp);
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) pp[q] = pf[q].y;
+      ra->y = voigt_tau_shear<NPH>(a.y, pp, sp);
+      rb->y = voigt_tau_shear<NPH>(b.y, pp, sp);
+    };
+    const double2 t0xb = normal_at(p.off + xb, 0);
+    const double2 t1yb = normal_at(p.off + yb, 1);
+    double2 t5xf, t4xf, t5yf, t3yf;
+    shear2_at(p.off + xf, 5, 4, &t5xf, &t4xf);
+    shear2_at(p.off + yf, 5, 3, &t5yf, &t3yf);
+    // z neighbours inside the row: voxel k-1 (tau2) and voxel k+2 (tau4, tau3), scalar
+    double t2zb, t4zf2, t3zf2;
+    {
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) ph[q] = q < sp.pt.n ? phi.p[q][rowoff + kb] : 0.0;
+      const double a0 = eps.p[0][rowoff + kb], a1 = eps.p[1][rowoff + kb], a2 = eps.p[2][rowoff + kb];
+      t2zb = voigt_tau_normal<NPH>(a2, a0, a1, a2, ph, sp);
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) ph[q] = q < sp.pt.n ? phi.p[q][rowoff + kf2] : 0.0;
+      t4zf2 = voigt_tau_shear<NPH>(eps.p[4][rowoff + kf2], ph, sp);
+      t3zf2 = voigt_tau_shear<NPH>(eps.p[3][rowoff + kf2], ph, sp);
+    }
+    double t4zf1 = t[4].y, t3zf1 = t[3].y;
+    if (!second) {  // odd nz, last pair: z+1 of the first voxel wraps to k = 0
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) ph[q] = q < sp.pt.n ? phi.p[q][rowoff] : 0.0;
+      t4zf1 = voigt_tau_shear<NPH>(eps.p[4][rowoff], ph, sp);
+      t3zf1 = voigt_tau_shear<NPH>(eps.p[3][rowoff], ph, sp);
+    }
+
+    double2 f0, f1, f2;  // same expressions as k_div  (F:18853-18908)
+    f0.x = (t[0].x - t0xb.x) * hx + (t5yf.x - t[5].x) * hy + (t4zf1 - t[4].x) * hz;
+    f1.x = (t5xf.x - t[5].x) * hx + (t[1].x - t1yb.x) * hy + (t3zf1 - t[3].x) * hz;
+    f2.x = (t4xf.x - t[4].x) * hx + (t3yf.x - t[3].x) * hy + (t[2].x - t2zb) * hz;
+    f0.y = (t[0].y - t0xb.y) * hx + (t5yf.y - t[5].y) * hy + (t4zf2 - t[4].y) * hz;
+    f1.y = (t5xf.y - t[5].y) * hx + (t[1].y - t1yb.y) * hy + (t3zf2 - t[3].y) * hz;
+    f2.y = (t4xf.y - t[4].y) * hx + (t3yf.y - t[3].y) * hy + (t[2].y - t[2].x) * hz;
+    if (!second) f0.y = f1.y = f2.y = 0.0;
+    st2(fo.p[0], p.off, f0);
+    st2(fo.p[1], p.off, f1);
+    st2(fo.p[2], p.off, f2);
+  }
+}
+
 // ----------------------------------------------------------------------------- Green operator
 // G0OperatorFourierStaggeredGeneral  F:19834-19927, in place on 3 complex components.
 // layout.transposed == 0: [nx][ny][nzc] (g = full grid).  transposed == 1 (y-slab of the slab-decomposed
@@ -187,6 +355,7 @@ __global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < nfreq; idx += (long)gridDim.x * blockDim.x) {
     const long row = idx / g.nzc;
     const int kk = (int)(idx - row * g.nzc);
+    if (kk >= g.nzf) continue;  // row padding
     int ii, jj;
     if (lay.transposed) {
       const int jl = (int)(row / g.nx);
@@ -216,13 +385,16 @@ __global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables
 // epsOperatorStaggered  F:18614-18692, followed by eps += R (applyBCProjector  F:20263-20270)
 // and the per-component sums of squares of component_norm (F:10088-10138) fused in.
 __global__ __launch_bounds__(kBlock) void k_eps_norm(Grid g, FieldPtrs<3> u, FieldPtrs<6> eps, Vec6 E, Vec6 R, int add_R,
-                                                     double* partial, XHalo h) {
+                                                     double* partial, XHalo h, int ry) {
   __shared__ double smem[4 * 6];
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
   double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
-    const PairPos p = pair_pos(pidx, g);
+  const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
+  for (long it = 0; it < run.count; ++it) {
+    const long pidx = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    if (pidx >= npairs) continue;
+    const PairPos p = pair_pos_tiled(pidx, g, ry);
     if (p.k >= g.nz) continue;
     const bool second = p.k + 1 < g.nz;
     const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
@@ -410,6 +582,16 @@ __global__ __launch_bounds__(kBlock) void k_fold(const double* partial, int nblo
   }
 }
 
+// rows per y-chunk of the L2-aware sweep
+int chunk_rows(const Grid& g) { return g.ny % 8 == 0 ? 8 : (g.ny % 4 == 0 ? 4 : (g.ny % 2 == 0 ? 2 : 1)); }
+
+// blocks of a stencil sweep: one 256-pair piece per block, capped (runs of pieces beyond), multiple of 8
+int sweep_blocks(long npairs) {
+  long b = (npairs + kBlock - 1) / kBlock;
+  if (b >= 8) b = ((b + 7) / 8) * 8;   // multiple of 8 so that the XCD remap applies; surplus blocks find no piece
+  return (int)(b < 1 ? 1 : b);
+}
+
 int grid_for(long nwork, int max_blocks) {
   long b = (nwork + kBlock - 1) / kBlock;
   if (b > max_blocks) b = max_blocks;
@@ -463,9 +645,21 @@ void launch_stress_const(const Grid& g, double mu_0, double lambda_0, const Fiel
   FG_HIP_CHECK(hipGetLastError());
 }
 
+void launch_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
+                            const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& f, hipStream_t s) {
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  if (sp.pt.n <= 2)
+    hipLaunchKernelGGL((k_stress_div_voigt<2>), dim3(sweep_blocks(npairs)), dim3(kBlock), 0, s, g, sp, eps, phi, f,
+                       chunk_rows(g));
+  else
+    hipLaunchKernelGGL((k_stress_div_voigt<kMaxPhases>), dim3(sweep_blocks(npairs)), dim3(kBlock), 0, s, g, sp, eps, phi,
+                       f, chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+}
+
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s) {
   const long npairs = (long)g.nx * g.ny * g.nzc;
-  hipLaunchKernelGGL(k_div, dim3(grid_for(npairs, 1 << 20)), dim3(kBlock), 0, s, g, tau, f, h);
+  hipLaunchKernelGGL(k_div, dim3(sweep_blocks(npairs)), dim3(kBlock), 0, s, g, tau, f, h, chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
 }
 
@@ -479,7 +673,8 @@ void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double
 void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps, const Vec6& E, const Vec6& R,
                      bool add_R, double* partial, double* sumsq6, const XHalo& h, hipStream_t s) {
   const int nb = reduce_blocks(g);
-  hipLaunchKernelGGL(k_eps_norm, dim3(nb), dim3(kBlock), 0, s, g, u, eps, E, R, add_R ? 1 : 0, partial, h);
+  hipLaunchKernelGGL(k_eps_norm, dim3(nb), dim3(kBlock), 0, s, g, u, eps, E, R, add_R ? 1 : 0, partial, h,
+                     chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, sumsq6);
   FG_HIP_CHECK(hipGetLastError());

@@ -35,6 +35,8 @@ struct SolverOptions {
   double lambda_0 = 0.0;
   double eps_g = 2.220446049250313e-16;          // laminate tolerances F:13110-13111
   double eps_a = 3.666852862501036e-11;          // eps^(2/3)
+  int fuse_stress_div = 1;      // Voigt mixing: polarisation + divergence in one sweep
+  int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
 };
 
 enum Stage {

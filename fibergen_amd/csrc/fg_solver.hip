@@ -293,23 +293,31 @@ void Solver::basic_scheme(const double* E6) {
 
   if (opt_.bc_relax != 1.0) mean_strain(F00_);  // F:20563-20565
 
-  time_begin(0);
-  launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
-  time_end(0);
-
-  // initBCProjector  F:20228-20239
+  // initBCProjector  F:20228-20239 needs <tau> only for mixed boundary conditions
   double F0[6] = {0, 0, 0, 0, 0, 0};
   const bool mq_zero = frobenius(BC_MQ_) < kEps;
-  if (!mq_zero) {
-    launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);
-    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    FG_HIP_CHECK(hipStreamSynchronize(stream_));
-    for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)nglobal_;
+  // Voigt mixing: polarisation and divergence in one sweep (tau never stored); the laminate rule keeps the
+  // two-kernel form (its per-voxel Newton solve is too costly to repeat at the six neighbours)
+  const bool fuse_sd = opt_.fuse_stress_div && opt_.mixing == kMixVoigt && mq_zero;
+  if (fuse_sd) {
+    time_begin(0);
+    launch_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, ptrs3(fu_), stream_);
+    time_end(0);
+  } else {
+    time_begin(0);
+    launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
+    time_end(0);
+    if (!mq_zero) {
+      launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);
+      FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      FG_HIP_CHECK(hipStreamSynchronize(stream_));
+      for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)nglobal_;
+    }
+    time_begin(1);
+    launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
+    time_end(1);
   }
-
-  time_begin(1);
-  launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
-  time_end(1);
+  bool fuse_x = false;
   {
     // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
     const double scale = 1 / (double)nglobal_;
@@ -320,27 +328,38 @@ void Solver::basic_scheme(const double* E6) {
     time_begin(3);
     fft_->c2c_y(fu_, 3, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
     time_end(3);
-    time_begin(4);
-    fft_->c2c_x(fu_, 3, g_.n, -1, has_x ? scale : 1.0);
-    time_end(4);
-    if (!has_x && !has_y) fft_->scale(fu_, 3, g_.n, scale);
+    fuse_x = opt_.fuse_x && fft_->can_fuse(0);
+    if (!fuse_x) {
+      time_begin(4);
+      fft_->c2c_x(fu_, 3, g_.n, -1, has_x ? scale : 1.0);
+      time_end(4);
+      if (!has_x && !has_y) fft_->scale(fu_, 3, g_.n, scale);
+    }
   }
-  time_begin(5);
   {
     // G0OperatorFourierStaggered  F:19749-19755
-    const double c10 = -alpha / (opt_.mu_0);
-    const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    G0Params gp;
+    gp.c10 = -alpha / (opt_.mu_0);
+    gp.c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
     G0Tables tb;
     for (int a = 0; a < 3; ++a) {
-      tb.kpm[a] = g0_kpm_[a];
-      tb.kp[a] = g0_kp_[a];
+      tb.kpm[a] = gp.kpm[a] = g0_kpm_[a];
+      tb.kp[a] = gp.kp[a] = g0_kp_[a];
     }
-    launch_g0(g_, ptrs3(fu_), tb, c10, c20, G0Layout{0, 0, 0}, stream_);
+    time_begin(5);
+    if (fuse_x) {
+      // x transform, 1/N, Green operator and inverse x transform in one kernel (spectrum stays in registers)
+      fft_->fused_g0(fu_, g_.n, 0, 1 / (double)nglobal_, gp, 0);
+    } else {
+      launch_g0(g_, ptrs3(fu_), tb, gp.c10, gp.c20, G0Layout{0, 0, 0}, stream_);
+    }
+    time_end(5);
   }
-  time_end(5);
-  time_begin(6);
-  fft_->c2c_x(fu_, 3, g_.n, +1, 1.0);
-  time_end(6);
+  if (!fuse_x) {
+    time_begin(6);
+    fft_->c2c_x(fu_, 3, g_.n, +1, 1.0);
+    time_end(6);
+  }
   time_begin(7);
   fft_->c2c_y(fu_, 3, g_.n, +1, 1.0);
   time_end(7);
@@ -756,9 +775,10 @@ void Solver::get_field(const std::string& name, double* out) {
     for (int c = 0; c < 6; ++c) out[c] = sumsq_[c];
     return;
   }
-  if (name == "f_hat") {  // complex [3][nx][ny][nzc] interleaved = the padded buffer as is
+  if (name == "f_hat") {  // complex [3][nx][ny][nz/2+1], row padding stripped
     FG_HIP_CHECK(hipStreamSynchronize(stream_));
-    FG_HIP_CHECK(hipMemcpy(out, fu_, 3 * g_.n * sizeof(double), hipMemcpyDeviceToHost));
+    FG_HIP_CHECK(hipMemcpy2D(out, g_.nzf * sizeof(cplx), fu_, g_.nzc * sizeof(cplx), g_.nzf * sizeof(cplx),
+                             (size_t)3 * g_.nx * g_.ny, hipMemcpyDeviceToHost));
     return;
   }
   if (name == "sigma") {  // calcStress with C0 = 0  F:15496-15508
@@ -802,7 +822,8 @@ void Solver::set_field(const std::string& name, const double* in) {
   FG_HIP_CHECK(hipSetDevice(device_));
   if (name == "f_hat") {
     FG_HIP_CHECK(hipStreamSynchronize(stream_));
-    FG_HIP_CHECK(hipMemcpy(fu_, in, 3 * g_.n * sizeof(double), hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy2D(fu_, g_.nzc * sizeof(cplx), in, g_.nzf * sizeof(cplx), g_.nzf * sizeof(cplx),
+                             (size_t)3 * g_.nx * g_.ny, hipMemcpyHostToDevice));
     return;
   }
   if (name == "normals") {

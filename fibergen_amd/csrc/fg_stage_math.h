@@ -233,6 +233,52 @@ FG_HD int stress_voxel(const double* F, const double* phi, const double* normal,
   return err;
 }
 
+// Single components of the Voigt-mixed polarisation tau = P(F) + beta F + gamma tr(F) I, evaluated
+// with exactly the operations stress_voxel performs for that component (the components of
+// pk1_voigt/hooke6 are independent), so that a kernel which needs only tau_c at a neighbour voxel
+// reproduces the stored field bit for bit.   F:12752-12761, F:11375-11396, F:18162-18172
+template <int NPH>
+FG_HD double voigt_tau_normal(double Ec, double E0, double E1, double E2, const double* phi, const StressParams& sp) {
+  const double threshold = 10 * 2.220446049250313e-16;
+  double P = 0.0;
+  bool any = false;
+#pragma unroll
+  for (int p = 0; p < NPH; ++p) {
+    if (p >= sp.pt.n) break;
+    if (phi[p] <= threshold) continue;
+    const double a = phi[p] * sp.alpha;
+    const double two_mu = 2 * a * sp.pt.mu[p];
+    const double lambda_tr_E = a * sp.pt.lambda[p] * (E0 + E1 + E2);
+    if (any) P += Ec * two_mu + lambda_tr_E;
+    else P = Ec * two_mu + lambda_tr_E;
+    any = true;
+  }
+  const double beta = -sp.alpha * 2 * sp.mu_0;
+  const double gamma = -sp.alpha * sp.lambda_0;
+  if (beta != 0) P += beta * Ec;
+  if (gamma != 0) P += gamma * (E0 + E1 + E2);
+  return P;
+}
+
+template <int NPH>
+FG_HD double voigt_tau_shear(double Ec, const double* phi, const StressParams& sp) {
+  const double threshold = 10 * 2.220446049250313e-16;
+  double P = 0.0;
+  bool any = false;
+#pragma unroll
+  for (int p = 0; p < NPH; ++p) {
+    if (p >= sp.pt.n) break;
+    if (phi[p] <= threshold) continue;
+    const double two_mu = 2 * (phi[p] * sp.alpha) * sp.pt.mu[p];
+    if (any) P += Ec * two_mu;
+    else P = Ec * two_mu;
+    any = true;
+  }
+  const double beta = -sp.alpha * 2 * sp.mu_0;
+  if (beta != 0) P += beta * Ec;
+  return P;
+}
+
 // Tangent spectrum of one voxel for the reference-material scan
 // (getRefMaterial/eig  F:12153-12236, F:12472-12559).  For isotropic phases the
 // Voigt tangent (F:12763-12771) and the laminate tangent="approx" (F:13611-13624)

@@ -274,6 +274,13 @@ class DistributedLSSolver:
             torch.cuda.synchronize()
         self.comm_time += time.perf_counter() - t0
 
+    @staticmethod
+    def _sync_copies(t):
+        # torch copies run on torch's stream, the next phase on the solver's: order them on the host
+        if t.is_cuda:
+            import torch
+            torch.cuda.synchronize()
+
     def _halo(self):
         b = self.backend
         s_lo, s_hi, r_lo, r_hi = (b.buffer(n) for n in ("halo_send_lo", "halo_send_hi", "halo_recv_lo", "halo_recv_hi"))
@@ -281,6 +288,7 @@ class DistributedLSSolver:
             self.backend.synchronize()
             r_lo.copy_(s_hi)   # my last plane is my own x-1 neighbour (periodic)
             r_hi.copy_(s_lo)
+            self._sync_copies(r_lo)
             return
         left, right = (self.rank - 1) % self.nranks, (self.rank + 1) % self.nranks
         self._exchange([(s_hi, right), (s_lo, left)], [(r_lo, left), (r_hi, right)])
@@ -293,6 +301,7 @@ class DistributedLSSolver:
         if P == 1:
             self.backend.synchronize()
             recv.copy_(send)
+            self._sync_copies(recv)
             return
         me = self.rank
         self.backend.synchronize()

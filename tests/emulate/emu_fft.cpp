@@ -90,6 +90,41 @@ int emu_c2r(int nz, double* data, long nrows) {
 #undef CASE
   return 1;
 }
+// fused x pass: data[3][N][ncols] complex (ls = ncols, comp stride N*ncols), columns flattened (ky,kz)
+int emu_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, double c10, double c20,
+               const double* kpm0, const double* kp0, const double* kpm1, const double* kp1, const double* kpm2,
+               const double* kp2) {
+  std::vector<cplx> tw = make_pass_twiddles(N);
+  XFusedArgs a;
+  a.data = reinterpret_cast<cplx*>(data);
+  a.ncols = ny * nzc;
+  a.comp_stride = (long)N * a.ncols;
+  a.ls = a.ncols;
+  a.os = 0;
+  a.flat_cols = 1;
+  a.nzc = nzc;
+  a.nzf = nzf;
+  a.jj0 = 0;
+  a.scale = scale;
+  a.c10 = c10;
+  a.c20 = c20;
+  a.tw = tw.data();
+  a.kpm[0] = kpm0; a.kpm[1] = kpm1; a.kpm[2] = kpm2;
+  a.kp[0] = reinterpret_cast<const cplx*>(kp0);
+  a.kp[1] = reinterpret_cast<const cplx*>(kp1);
+  a.kp[2] = reinterpret_cast<const cplx*>(kp2);
+#define CASE(n)                                                               \
+  if (N == n) {                                                               \
+    constexpr int C = XTileCols<n>::value;                                    \
+    a.tiles_per_outer = (a.ncols + C - 1) / C;                                \
+    run_blocks<XFusedKernel<n, C>, XFusedArgs>((long)a.tiles_per_outer, a);   \
+    return 0;                                                                 \
+  }
+  CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) CASE(512)
+#undef CASE
+  return 1;
+}
+
 // generic fall-backs
 void emu_dft_strided(const double* src, double* dst, int n, int ncols, int nouter, int dir, double scale) {
   std::vector<cplx> w = make_unit_roots(n, n);

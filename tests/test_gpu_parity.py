@@ -249,3 +249,30 @@ def test_error_paths():
     s2 = make_gpu_solver((8, 8, 8))
     s2.set_phase(1, float("nan"), 1.0)
     assert s2.run(np.array([1.0, 0, 0, 0, 0, 0])) is True
+
+
+@pytest.mark.parametrize("grid,dims", [((16, 16, 16), (1.0, 1.0, 1.0)), ((32, 16, 64), (1.0, 2.0, 0.5)),
+                                       ((12, 10, 6), (1.0, 1.0, 1.0)), ((8, 16, 5), (1.0, 1.0, 1.0)),
+                                       ((64, 64, 64), (1.0, 1.0, 1.0)), ((128, 16, 128), (1.0, 1.0, 1.0))])
+def test_fused_kernels_match_unfused_pipeline(grid, dims):
+    """The fused kernels (polarisation+divergence; x-FFT + Green operator + x-FFT^-1) against the
+    one-kernel-per-reference-routine pipeline: the stress/div fusion must be bit-identical, the FFT
+    fusion agrees to FFT rounding."""
+    rng = np.random.default_rng(21)
+    eps = 0.1 * rng.standard_normal((6,) + grid)
+    E = np.array([1.0, 0.2, -0.3, 0.1, 0.0, 0.4])
+    out = {}
+    for name, opts in (("plain", dict(fuse_stress_div=0, fuse_x=0)), ("sd", dict(fuse_stress_div=1, fuse_x=0)),
+                       ("x", dict(fuse_stress_div=0, fuse_x=1)), ("both", dict(fuse_stress_div=1, fuse_x=1))):
+        s = make_gpu_solver(grid, dims, mu_0=0.9, lambda_0=0.2)
+        for k, v in opts.items():
+            s._check(s._lib.fg_set_option_i(s._h, k.encode(), v))
+        s.set_field("epsilon", eps)
+        s.run_stage("iteration", E)
+        out[name] = s.get_field("epsilon")
+    assert np.array_equal(out["sd"], out["plain"])
+    assert np.array_equal(out["both"], out["x"])
+    assert rel_err(out["x"], out["plain"]) < 1e-12
+    o = make_oracle(grid, dims)
+    o.mu_0, o.lambda_0 = 0.9, 0.2
+    assert rel_err(out["both"], o.basic_scheme(E, eps)) < 1e-12
