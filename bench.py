@@ -221,12 +221,21 @@ def main():
         kern = {}
         for k, ms in times.items():
             avg = ms / max(cnt, 1)
-            kern[k] = {"avg_ms": avg, "alg_GB": ab[k] / 1e9, "GBps": (ab[k] / 1e9) / (avg / 1e3) if avg > 0 else 0.0}
+            if avg <= 0:
+                continue   # stage absorbed by a fused kernel
+            name, alg = k, ab[k]
+            if k == "stress" and times["div"] == 0:
+                # polarisation + divergence in one sweep: 6 eps + phi in, 3 f out (SURVEY 8d "S + div: 80")
+                name, alg = "stress_div", 80 * n[0] * n[1] * n[2]
+            if k == "g0" and times["c2c_x_fwd"] == 0:
+                # x-FFT, Green operator, inverse x-FFT: 3 complex components in, 3 out (48 B/voxel)
+                name = "xfft_g0_xifft"
+            kern[name] = {"avg_ms": avg, "alg_GB": alg / 1e9, "GBps": (alg / 1e9) / (avg / 1e3)}
         dom = max(kern, key=lambda k: kern[k]["avg_ms"])
         N = n[0] * n[1] * n[2]
         roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
-                "alg_bytes_per_launch": ab[dom], "avg_launch_ms": kern[dom]["avg_ms"]}
+                "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]}
         out = {
             "metric": "LS iterations/sec (basic scheme, staggered grid, linear elastic)",
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
