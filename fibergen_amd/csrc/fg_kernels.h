@@ -50,6 +50,9 @@ void launch_stress_const(const Grid& g, double mu_0, double lambda_0, const Fiel
                          hipStream_t s);
 void launch_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
                             const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& f, hipStream_t s);
+void launch_u_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u,
+                               const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& f, const Vec6& E, double* partial,
+                               double* sumsq6, hipStream_t s);
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);
 void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
                hipStream_t s);

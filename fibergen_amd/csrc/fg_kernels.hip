@@ -345,6 +345,149 @@ __global__ __launch_bounds__(kBlock) void k_stress_div_voigt(Grid g, StressParam
   }
 }
 
+// ----------------------------------------------------------------------------- displacement-based pass
+// f = div[(C - C0) : (E + sym grad u)] straight from the displacement of the previous pass, plus the
+// sums of squares of the strain.  The strain field is never stored inside the loop: the strain operator
+// of pass k (epsOperatorStaggered F:18614-18692), the polarisation (calcStress F:18134-18184, Voigt
+// mixing) and the divergence (divOperatorStaggered F:18853-18908) of pass k+1 become one sweep that
+// reads 3 + n_phase arrays and writes 3 (64 B/voxel for two phases instead of 72 + 88).  Every value is
+// computed with the expressions of k_eps_norm / stress_voxel / k_div, so the pass is bit-identical to
+// the three-kernel form.  Row vectors hold the values at z = k-1, k, k+1, k+2 of one (x,y) row.
+struct Row4 {
+  double v[4];
+};
+
+__device__ __forceinline__ Row4 load_row(const double* a, long ro, int k, int kb, int kf2, bool second, bool m1, bool p2) {
+  Row4 r;
+  const double2 d = ld2(a, ro + k);
+  r.v[1] = d.x;
+  r.v[2] = second ? d.y : a[ro];  // odd nz, last pair: k+1 wraps to 0
+  r.v[0] = m1 ? a[ro + kb] : 0.0;
+  r.v[3] = p2 ? a[ro + kf2] : 0.0;
+  return r;
+}
+
+template <int NPH>
+struct PhiRows {
+  Row4 r[NPH];
+};
+
+template <int NPH>
+__device__ __forceinline__ PhiRows<NPH> load_phi(const FieldPtrs<kMaxPhases>& phi, int n, long ro, int k, int kb, int kf2,
+                                                 bool second, bool wide) {
+  PhiRows<NPH> o;
+#pragma unroll
+  for (int q = 0; q < NPH; ++q) {
+    if (q < n) o.r[q] = load_row(phi.p[q], ro, k, kb, kf2, second, wide, wide);
+    else o.r[q].v[0] = o.r[q].v[1] = o.r[q].v[2] = o.r[q].v[3] = 0.0;
+  }
+  return o;
+}
+
+template <int NPH>
+__global__ __launch_bounds__(kBlock) void k_u_stress_div_voigt(Grid g, StressParams sp, FieldPtrs<3> u,
+                                                               FieldPtrs<kMaxPhases> phi, FieldPtrs<3> fo, Vec6 E,
+                                                               double* partial, int ry) {
+  __shared__ double smem[4 * 6];
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
+  for (long it = 0; it < run.count; ++it) {
+    const long pidx = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    if (pidx >= npairs) continue;
+    const PairPos p = pair_pos_tiled(pidx, g, ry);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+    const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+    const long ro = p.off - p.k;
+    const int k = p.k;
+    const int kb = k == 0 ? g.nz - 1 : k - 1;
+    const int kf2 = (k + 2 >= g.nz) ? k + 2 - g.nz : k + 2;
+#define FG_ROW(a, off, m1, p2) load_row(a, ro + (off), k, kb, kf2, second, m1, p2)
+    const Row4 U0c = FG_ROW(u.p[0], 0, true, true), U0xf = FG_ROW(u.p[0], xf, true, false);
+    const Row4 U0yb = FG_ROW(u.p[0], yb, false, false), U0xb = FG_ROW(u.p[0], xb, false, false);
+    const Row4 U0xfyb = FG_ROW(u.p[0], xf + yb, false, false), U0yf = FG_ROW(u.p[0], yf, false, false);
+    const Row4 U1c = FG_ROW(u.p[1], 0, true, true), U1yf = FG_ROW(u.p[1], yf, true, false);
+    const Row4 U1xb = FG_ROW(u.p[1], xb, false, false), U1xbyf = FG_ROW(u.p[1], xb + yf, false, false);
+    const Row4 U1yb = FG_ROW(u.p[1], yb, false, false), U1xf = FG_ROW(u.p[1], xf, false, false);
+    const Row4 U2c = FG_ROW(u.p[2], 0, true, true), U2yb = FG_ROW(u.p[2], yb, false, true);
+    const Row4 U2xb = FG_ROW(u.p[2], xb, false, true), U2xf = FG_ROW(u.p[2], xf, false, false);
+    const Row4 U2yf = FG_ROW(u.p[2], yf, false, false);
+#undef FG_ROW
+    const PhiRows<NPH> Pc = load_phi<NPH>(phi, sp.pt.n, ro, k, kb, kf2, second, true);
+    const PhiRows<NPH> Pxb = load_phi<NPH>(phi, sp.pt.n, ro + xb, k, kb, kf2, second, false);
+    const PhiRows<NPH> Pxf = load_phi<NPH>(phi, sp.pt.n, ro + xf, k, kb, kf2, second, false);
+    const PhiRows<NPH> Pyb = load_phi<NPH>(phi, sp.pt.n, ro + yb, k, kb, kf2, second, false);
+    const PhiRows<NPH> Pyf = load_phi<NPH>(phi, sp.pt.n, ro + yf, k, kb, kf2, second, false);
+
+    double fout[2][3], eout[2][6];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int i0 = s + 1;  // index of this voxel's own z position in the row vectors
+      // strain at the voxel  (F:18632-18686)
+      const double e0 = E.v[0] + (U0xf.v[i0] - U0c.v[i0]) * hx;
+      const double e1 = E.v[1] + (U1yf.v[i0] - U1c.v[i0]) * hy;
+      const double e2 = E.v[2] + (U2c.v[i0 + 1] - U2c.v[i0]) * hz;
+      const double e3 = E.v[3] + 0.5 * ((U2c.v[i0] - U2yb.v[i0]) * hy + (U1c.v[i0] - U1c.v[i0 - 1]) * hz);
+      const double e4 = E.v[4] + 0.5 * ((U2c.v[i0] - U2xb.v[i0]) * hx + (U0c.v[i0] - U0c.v[i0 - 1]) * hz);
+      const double e5 = E.v[5] + 0.5 * ((U1c.v[i0] - U1xb.v[i0]) * hx + (U0c.v[i0] - U0yb.v[i0]) * hy);
+      eout[s][0] = e0; eout[s][1] = e1; eout[s][2] = e2; eout[s][3] = e3; eout[s][4] = e4; eout[s][5] = e5;
+      // strains of the six neighbours, only the components their tau needs
+      const double e0xb = E.v[0] + (U0c.v[i0] - U0xb.v[i0]) * hx;
+      const double e1xb = E.v[1] + (U1xbyf.v[i0] - U1xb.v[i0]) * hy;
+      const double e2xb = E.v[2] + (U2xb.v[i0 + 1] - U2xb.v[i0]) * hz;
+      const double e0yb = E.v[0] + (U0xfyb.v[i0] - U0yb.v[i0]) * hx;
+      const double e1yb = E.v[1] + (U1c.v[i0] - U1yb.v[i0]) * hy;
+      const double e2yb = E.v[2] + (U2yb.v[i0 + 1] - U2yb.v[i0]) * hz;
+      const double e0zb = E.v[0] + (U0xf.v[i0 - 1] - U0c.v[i0 - 1]) * hx;
+      const double e1zb = E.v[1] + (U1yf.v[i0 - 1] - U1c.v[i0 - 1]) * hy;
+      const double e2zb = E.v[2] + (U2c.v[i0] - U2c.v[i0 - 1]) * hz;
+      const double e5xf = E.v[5] + 0.5 * ((U1xf.v[i0] - U1c.v[i0]) * hx + (U0xf.v[i0] - U0xfyb.v[i0]) * hy);
+      const double e4xf = E.v[4] + 0.5 * ((U2xf.v[i0] - U2c.v[i0]) * hx + (U0xf.v[i0] - U0xf.v[i0 - 1]) * hz);
+      const double e5yf = E.v[5] + 0.5 * ((U1yf.v[i0] - U1xbyf.v[i0]) * hx + (U0yf.v[i0] - U0c.v[i0]) * hy);
+      const double e3yf = E.v[3] + 0.5 * ((U2yf.v[i0] - U2c.v[i0]) * hy + (U1yf.v[i0] - U1yf.v[i0 - 1]) * hz);
+      const double e4zf = E.v[4] + 0.5 * ((U2c.v[i0 + 1] - U2xb.v[i0 + 1]) * hx + (U0c.v[i0 + 1] - U0c.v[i0]) * hz);
+      const double e3zf = E.v[3] + 0.5 * ((U2c.v[i0 + 1] - U2yb.v[i0 + 1]) * hy + (U1c.v[i0 + 1] - U1c.v[i0]) * hz);
+      double pc[NPH], pxb[NPH], pxf[NPH], pyb[NPH], pyf[NPH], pzb[NPH], pzf[NPH];
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) {
+        pc[q] = Pc.r[q].v[i0]; pzb[q] = Pc.r[q].v[i0 - 1]; pzf[q] = Pc.r[q].v[i0 + 1];
+        pxb[q] = Pxb.r[q].v[i0]; pxf[q] = Pxf.r[q].v[i0]; pyb[q] = Pyb.r[q].v[i0]; pyf[q] = Pyf.r[q].v[i0];
+      }
+      const double t0 = voigt_tau_normal<NPH>(e0, e0, e1, e2, pc, sp);
+      const double t1 = voigt_tau_normal<NPH>(e1, e0, e1, e2, pc, sp);
+      const double t2 = voigt_tau_normal<NPH>(e2, e0, e1, e2, pc, sp);
+      const double t3 = voigt_tau_shear<NPH>(e3, pc, sp), t4 = voigt_tau_shear<NPH>(e4, pc, sp);
+      const double t5 = voigt_tau_shear<NPH>(e5, pc, sp);
+      const double t0xb = voigt_tau_normal<NPH>(e0xb, e0xb, e1xb, e2xb, pxb, sp);
+      const double t1yb = voigt_tau_normal<NPH>(e1yb, e0yb, e1yb, e2yb, pyb, sp);
+      const double t2zb = voigt_tau_normal<NPH>(e2zb, e0zb, e1zb, e2zb, pzb, sp);
+      const double t5xf = voigt_tau_shear<NPH>(e5xf, pxf, sp), t4xf = voigt_tau_shear<NPH>(e4xf, pxf, sp);
+      const double t5yf = voigt_tau_shear<NPH>(e5yf, pyf, sp), t3yf = voigt_tau_shear<NPH>(e3yf, pyf, sp);
+      const double t4zf = voigt_tau_shear<NPH>(e4zf, pzf, sp), t3zf = voigt_tau_shear<NPH>(e3zf, pzf, sp);
+      fout[s][0] = (t0 - t0xb) * hx + (t5yf - t5) * hy + (t4zf - t4) * hz;
+      fout[s][1] = (t5xf - t5) * hx + (t1 - t1yb) * hy + (t3zf - t3) * hz;
+      fout[s][2] = (t4xf - t4) * hx + (t3yf - t3) * hy + (t2 - t2zb) * hz;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double ey = second ? eout[1][c] : 0.0;
+      acc[c] += eout[0][c] * eout[0][c] + ey * ey;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st2(fo.p[c], p.off, make_double2(fout[0][c], second ? fout[1][c] : 0.0));
+  }
+  block_reduce<6>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+  }
+}
+
 // ----------------------------------------------------------------------------- Green operator
 // G0OperatorFourierStaggeredGeneral  F:19834-19927, in place on 3 complex components.
 // layout.transposed == 0: [nx][ny][nzc] (g = full grid).  transposed == 1 (y-slab of the slab-decomposed
@@ -654,6 +797,21 @@ void launch_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldP
   else
     hipLaunchKernelGGL((k_stress_div_voigt<kMaxPhases>), dim3(sweep_blocks(npairs)), dim3(kBlock), 0, s, g, sp, eps, phi,
                        f, chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_u_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u,
+                               const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& f, const Vec6& E, double* partial,
+                               double* sumsq6, hipStream_t s) {
+  const int nb = reduce_blocks(g);
+  if (sp.pt.n <= 2)
+    hipLaunchKernelGGL((k_u_stress_div_voigt<2>), dim3(nb), dim3(kBlock), 0, s, g, sp, u, phi, f, E, partial,
+                       chunk_rows(g));
+  else
+    hipLaunchKernelGGL((k_u_stress_div_voigt<kMaxPhases>), dim3(nb), dim3(kBlock), 0, s, g, sp, u, phi, f, E, partial,
+                       chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, sumsq6);
   FG_HIP_CHECK(hipGetLastError());
 }
 

@@ -35,6 +35,7 @@ struct SolverOptions {
   double lambda_0 = 0.0;
   double eps_g = 2.220446049250313e-16;          // laminate tolerances F:13110-13111
   double eps_a = 3.666852862501036e-11;          // eps^(2/3)
+  int u_loop = 1;               // Voigt, pure strain BC: displacement-based pass, strain not stored in the loop
   int fuse_stress_div = 1;      // Voigt mixing: polarisation + divergence in one sweep
   int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
 };
@@ -118,6 +119,11 @@ class Solver {
 
  private:
   void basic_scheme(const double* E6);
+  bool u_loop_eligible() const;
+  void u_pass_front(const double* E6);  // u_k (fu_) -> sums of squares of eps_k, f_{k+1} (fu_alt_)
+  void u_pass_back();                   // f_{k+1} -> u_{k+1}, buffers swapped
+  void fft_g0_chain(double* buf);       // r2c, y, x + Green operator + x^-1, y^-1, c2r on 3 components
+  void ensure_eps();                    // materialise eps = E + sym grad u if the loop left it implicit
   void recompute_bc();
   double bc_error(const double* E_cur, const double* S_cur);
   StressParams stress_params(double mu_0, double lambda_0, double alpha) const;
@@ -144,7 +150,8 @@ class Solver {
 
   double* eps_ = nullptr;      // 6 padded components
   double* tau_ = nullptr;      // 6
-  double* fu_ = nullptr;       // 3 (real f / u, complex f_hat / u_hat)
+  double* fu_ = nullptr;       // 3 (real f / u, complex f_hat / u_hat); after a pass it holds u
+  double* fu_alt_ = nullptr;   // 3: second f/u buffer of the displacement-based loop (swapped with fu_)
   double* phi_ = nullptr;      // nphase
   double* normals_ = nullptr;  // 3 (allocated on demand)
   double* partial_ = nullptr;  // reduction partials
@@ -166,6 +173,11 @@ class Solver {
   double solve_time_ = 0.0;
   double sumsq_[6];
 
+  bool u_valid_ = false;    // fu_ holds the displacement belonging to the current strain state
+  bool eps_stale_ = false;  // eps_ has not been written since fu_ changed
+  bool in_run_ = false;
+  double E_cur_[6] = {0, 0, 0, 0, 0, 0};   // prescribed strain the current (u, eps) state was built with
+  double E_next_[6] = {0, 0, 0, 0, 0, 0};
   bool timing_ = false;
   StageTimes times_;
   hipEvent_t ev_[2];

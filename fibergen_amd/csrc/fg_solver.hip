@@ -20,7 +20,8 @@ constexpr int kSlotSumSq = 0;    // 6
 constexpr int kSlotMean = 6;     // 6
 constexpr int kSlotMinMax = 12;  // 2
 constexpr int kSlotMisc = 14;    // 2
-constexpr int kNumSlots = 16;
+constexpr int kSlotScratch = 16; // 6: sums nobody reads (strain materialisation)
+constexpr int kNumSlots = 24;
 
 double now_seconds() {
   using clk = std::chrono::steady_clock;
@@ -59,6 +60,8 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   FG_HIP_CHECK(hipMalloc(&eps_, 6 * comp));
   FG_HIP_CHECK(hipMalloc(&tau_, 6 * comp));
   FG_HIP_CHECK(hipMalloc(&fu_, 3 * comp));
+  FG_HIP_CHECK(hipMalloc(&fu_alt_, 3 * comp));
+  FG_HIP_CHECK(hipMemsetAsync(fu_alt_, 0, 3 * comp, stream_));
   FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * comp, stream_));
   FG_HIP_CHECK(hipMemsetAsync(tau_, 0, 6 * comp, stream_));
   FG_HIP_CHECK(hipMemsetAsync(fu_, 0, 3 * comp, stream_));
@@ -120,7 +123,7 @@ Solver::~Solver() {
   fft_t_.reset();
   for (int k = 0; k < 4; ++k)
     if (halo_[k]) (void)hipFree(halo_[k]);
-  double* bufs[] = {eps_, tau_, fu_, phi_, normals_, partial_, dscal_};
+  double* bufs[] = {eps_, tau_, fu_, fu_alt_, phi_, normals_, partial_, dscal_};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (hscal_) (void)hipHostFree(hscal_);
@@ -291,6 +294,7 @@ void Solver::basic_scheme(const double* E6) {
   for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
   const double alpha = -1.0;  // GammaOperator(..., -1)  F:20575
 
+  ensure_eps();  // the displacement-based loop may have left the strain implicit
   if (opt_.bc_relax != 1.0) mean_strain(F00_);  // F:20563-20565
 
   // initBCProjector  F:20228-20239 needs <tau> only for mixed boundary conditions
@@ -317,55 +321,7 @@ void Solver::basic_scheme(const double* E6) {
     launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
     time_end(1);
   }
-  bool fuse_x = false;
-  {
-    // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
-    const double scale = 1 / (double)nglobal_;
-    const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
-    time_begin(2);
-    fft_->r2c_z(fu_, 3, g_.n);
-    time_end(2);
-    time_begin(3);
-    fft_->c2c_y(fu_, 3, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
-    time_end(3);
-    fuse_x = opt_.fuse_x && fft_->can_fuse(0);
-    if (!fuse_x) {
-      time_begin(4);
-      fft_->c2c_x(fu_, 3, g_.n, -1, has_x ? scale : 1.0);
-      time_end(4);
-      if (!has_x && !has_y) fft_->scale(fu_, 3, g_.n, scale);
-    }
-  }
-  {
-    // G0OperatorFourierStaggered  F:19749-19755
-    G0Params gp;
-    gp.c10 = -alpha / (opt_.mu_0);
-    gp.c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
-    G0Tables tb;
-    for (int a = 0; a < 3; ++a) {
-      tb.kpm[a] = gp.kpm[a] = g0_kpm_[a];
-      tb.kp[a] = gp.kp[a] = g0_kp_[a];
-    }
-    time_begin(5);
-    if (fuse_x) {
-      // x transform, 1/N, Green operator and inverse x transform in one kernel (spectrum stays in registers)
-      fft_->fused_g0(fu_, g_.n, 0, 1 / (double)nglobal_, gp, 0);
-    } else {
-      launch_g0(g_, ptrs3(fu_), tb, gp.c10, gp.c20, G0Layout{0, 0, 0}, stream_);
-    }
-    time_end(5);
-  }
-  if (!fuse_x) {
-    time_begin(6);
-    fft_->c2c_x(fu_, 3, g_.n, +1, 1.0);
-    time_end(6);
-  }
-  time_begin(7);
-  fft_->c2c_y(fu_, 3, g_.n, +1, 1.0);
-  time_end(7);
-  time_begin(8);
-  fft_->c2r_z(fu_, 3, g_.n);
-  time_end(8);
+  fft_g0_chain(fu_);
 
   // applyBCProjector  F:20247-20270: R = alpha*(bc_relax*MQ:F0 - (1-bc_relax)*M:(QC0:F00))
   Vec6 E, R;
@@ -384,16 +340,135 @@ void Solver::basic_scheme(const double* E6) {
                   XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
   time_end(9);
   if (timing_) times_.count++;
+  // fu_ now holds the displacement this strain was built from (eps = E + sym grad u when R == 0)
+  u_valid_ = !add_R;
+  eps_stale_ = false;
+  for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
+}
+
+void Solver::fft_g0_chain(double* buf) {
+  const double alpha = -1.0;  // GammaOperator(..., -1)  F:20575
+  bool fuse_x = false;
+  {
+    // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
+    const double scale = 1 / (double)nglobal_;
+    const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
+    time_begin(2);
+    fft_->r2c_z(buf, 3, g_.n);
+    time_end(2);
+    time_begin(3);
+    fft_->c2c_y(buf, 3, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
+    time_end(3);
+    fuse_x = opt_.fuse_x && fft_->can_fuse(0);
+    if (!fuse_x) {
+      time_begin(4);
+      fft_->c2c_x(buf, 3, g_.n, -1, has_x ? scale : 1.0);
+      time_end(4);
+      if (!has_x && !has_y) fft_->scale(buf, 3, g_.n, scale);
+    }
+  }
+  {
+    // G0OperatorFourierStaggered  F:19749-19755
+    G0Params gp;
+    gp.c10 = -alpha / (opt_.mu_0);
+    gp.c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    G0Tables tb;
+    for (int a = 0; a < 3; ++a) {
+      tb.kpm[a] = gp.kpm[a] = g0_kpm_[a];
+      tb.kp[a] = gp.kp[a] = g0_kp_[a];
+    }
+    time_begin(5);
+    if (fuse_x) {
+      // x transform, 1/N, Green operator and inverse x transform in one kernel (spectrum stays in registers)
+      fft_->fused_g0(buf, g_.n, 0, 1 / (double)nglobal_, gp, 0);
+    } else {
+      launch_g0(g_, ptrs3(buf), tb, gp.c10, gp.c20, G0Layout{0, 0, 0}, stream_);
+    }
+    time_end(5);
+  }
+  if (!fuse_x) {
+    time_begin(6);
+    fft_->c2c_x(buf, 3, g_.n, +1, 1.0);
+    time_end(6);
+  }
+  time_begin(7);
+  fft_->c2c_y(buf, 3, g_.n, +1, 1.0);
+  time_end(7);
+  time_begin(8);
+  fft_->c2r_z(buf, 3, g_.n);
+  time_end(8);
+
+}
+
+// ------------------------------------------------------------------ displacement-based pass
+// eps_k = E + sym grad u_k is implied by the displacement of the previous pass, so the loop can carry
+// u (3 components) instead of eps (6): one sweep turns u_k into the sums of squares of eps_k (the
+// error estimator of pass k) and f_{k+1} = div (C - C0):eps_k, then the transform chain gives u_{k+1}.
+// Same values as strain operator + polarisation + divergence (bit for bit), 2 kernels fewer per pass.
+bool Solver::u_loop_eligible() const {
+  return opt_.u_loop && nranks_ == 1 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
+         frobenius(BC_MQ_) < kEps;
+}
+
+void Solver::u_pass_front(const double* E6) {
+  FieldPtrs<kMaxPhases> phi;
+  for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+  // the strain that belongs to u_k was built with the prescribed strain of ITS pass (E_cur_);
+  // E6 is the prescribed strain of the pass being started and takes effect with u_{k+1}
+  Vec6 E;
+  for (int c = 0; c < 6; ++c) {
+    E.v[c] = E_cur_[c];
+    E_next_[c] = E6[c];
+  }
+  time_begin(0);
+  launch_u_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, ptrs3(fu_alt_), E,
+                            partial_, dscal_ + kSlotSumSq, stream_);
+  time_end(0);
+  eps_stale_ = true;
+}
+
+void Solver::u_pass_back() {
+  fft_g0_chain(fu_alt_);
+  double* t = fu_;
+  fu_ = fu_alt_;
+  fu_alt_ = t;
+  u_valid_ = true;
+  eps_stale_ = true;
+  for (int c = 0; c < 6; ++c) E_cur_[c] = E_next_[c];
+  if (timing_) times_.count++;
+}
+
+void Solver::ensure_eps() {
+  if (!eps_stale_ || !u_valid_) return;
+  Vec6 E, R;
+  for (int c = 0; c < 6; ++c) E.v[c] = E_cur_[c], R.v[c] = 0.0;
+  launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), E, R, false, partial_, dscal_ + kSlotScratch,
+                  XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
+  eps_stale_ = false;
 }
 
 void Solver::iterate(const double* E6, int n) {
   FG_HIP_CHECK(hipSetDevice(device_));
-  for (int i = 0; i < n; ++i) basic_scheme(E6);
+  int i = 0;
+  if (u_loop_eligible()) {
+    if (!u_valid_ && n > 0) {
+      ensure_eps();
+      basic_scheme(E6);  // leaves u in fu_ and eps in eps_
+      ++i;
+    }
+    for (; i < n; ++i) {
+      u_pass_front(E6);
+      u_pass_back();
+    }
+    return;
+  }
+  for (; i < n; ++i) basic_scheme(E6);
 }
 
 // ------------------------------------------------------------------ means
 void Solver::mean_stress(double* out6) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  ensure_eps();
   if (pt_.n < 1) throw std::runtime_error("No materials specified");
   FieldPtrs<kMaxPhases> phi;
   for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
@@ -409,6 +484,7 @@ void Solver::mean_stress(double* out6) {
 
 void Solver::mean_strain(double* out6) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  ensure_eps();
   launch_sum6(g_, ptrs6(eps_), false, partial_, dscal_ + kSlotMean, stream_);
   FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -485,6 +561,18 @@ bool Solver::run(const double* E6, const double* S6) {
   const double t_start = now_seconds();
   FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * g_.n * sizeof(double), stream_));  // F:21379
   for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
+  u_valid_ = false;
+  eps_stale_ = false;
+  // Displacement-based loop: eps_0 = 0 gives tau = 0, u_1 = 0 and eps_1 = E, so the loop starts from
+  // u = 0 and every pass is [u_k -> norms of eps_k, f_{k+1}] + [f_{k+1} -> u_{k+1}] (see u_pass_front).
+  bool uloop = u_loop_eligible();
+  if (uloop) {
+    FG_HIP_CHECK(hipMemsetAsync(fu_, 0, 3 * g_.n * sizeof(double), stream_));
+    u_valid_ = true;
+    eps_stale_ = true;
+    for (int i = 0; i < 6; ++i) E_cur_[i] = E0[i];
+  }
+  in_run_ = true;
 
   // EpsilonErrorEstimator  F:14591-14637: norms of the zero field at construction
   double prev = 0.0;
@@ -506,7 +594,16 @@ bool Solver::run(const double* E6, const double* S6) {
       for (int i = 0; i < 6; ++i) E[i] = E0[i] + opt_.bc_relax * t3[i];
       update_ref = false;
     }
-    basic_scheme(E);
+    bool pending_back = false;
+    if (uloop && u_valid_) {
+      if (iter == 1)
+        for (int i = 0; i < 6; ++i) E_cur_[i] = E[i];  // eps_1 = E (u_1 = 0)
+      u_pass_front(E);
+      pending_back = true;
+    } else {
+      uloop = false;
+      basic_scheme(E);
+    }
     FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
     check_device_error("stress");
 
@@ -543,9 +640,12 @@ bool Solver::run(const double* E6, const double* S6) {
       const double bc_err = bc_error(E0, S0);
       if (bc_err <= opt_.bc_tol) break;
     }
+    if (pending_back) u_pass_back();
     iter++;
   }
+  in_run_ = false;
   iterations_ = iter;
+  ensure_eps();
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
   solve_time_ += now_seconds() - t_start;
   return failed;
@@ -560,6 +660,7 @@ bool Solver::run(const double* E6, const double* S6) {
 // a2a_send / a2a_recv alias tau components 0-2 / 3-5 (tau is dead once the divergence is taken).
 void Solver::slab_phase(int phase, const double* E6, const double* R6) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  u_valid_ = false;
   if (pt_.n < 1) throw std::runtime_error("No materials specified");
   if (opt_.mixing == kMixLaminate && !normals_) throw std::runtime_error("laminate mixing needs interface normals");
   const long plane = g_.nyzp;
@@ -655,6 +756,7 @@ double* Solver::exchange_buffer(const std::string& name, size_t* bytes) {
 // them over ranks in rank order.
 void Solver::local_sums(const std::string& what, double* out) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  ensure_eps();
   FieldPtrs<kMaxPhases> phi;
   for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
   FieldPtrs<3> nrm;
@@ -694,6 +796,8 @@ void Solver::local_sums(const std::string& what, double* out) {
 // ------------------------------------------------------------------ stages and fields
 void Solver::run_stage(int stage, const double* E6) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  ensure_eps();
+  if (stage != kStageIteration) u_valid_ = false;  // the stage buffers are being used as scratch
   FieldPtrs<kMaxPhases> phi;
   for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
   FieldPtrs<3> nrm;
@@ -771,6 +875,8 @@ double* Solver::device_component(const std::string& name, int c) {
 // get_raw_field  F:15396-15684 (epsilon, sigma, u, phi, normals) + raw stage buffers for the tests
 void Solver::get_field(const std::string& name, double* out) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  ensure_eps();
+  if (name == "u") u_valid_ = false;  // fu_ is overwritten by the displacement reconstruction
   if (name == "sumsq") {
     for (int c = 0; c < 6; ++c) out[c] = sumsq_[c];
     return;
@@ -820,6 +926,8 @@ void Solver::get_field(const std::string& name, double* out) {
 
 void Solver::set_field(const std::string& name, const double* in) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  ensure_eps();
+  u_valid_ = false;
   if (name == "f_hat") {
     FG_HIP_CHECK(hipStreamSynchronize(stream_));
     FG_HIP_CHECK(hipMemcpy2D(fu_, g_.nzc * sizeof(cplx), in, g_.nzf * sizeof(cplx), g_.nzf * sizeof(cplx),

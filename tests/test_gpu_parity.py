@@ -276,3 +276,46 @@ def test_fused_kernels_match_unfused_pipeline(grid, dims):
     o = make_oracle(grid, dims)
     o.mu_0, o.lambda_0 = 0.9, 0.2
     assert rel_err(out["both"], o.basic_scheme(E, eps)) < 1e-12
+
+
+@pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (32, 16, 64), (8, 16, 5)])
+def test_displacement_based_loop_is_bit_identical(grid):
+    """The displacement-based loop (strain never stored inside the loop, one sweep u_k -> norms of
+    eps_k and f_{k+1}) against the strain-based loop of the reference: same iteration count, identical
+    residual history and bit-identical converged fields."""
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    res = {}
+    for flag in (0, 1):
+        s = make_gpu_solver(grid, tol=1e-8)
+        s._check(s._lib.fg_set_option_i(s._h, b"u_loop", flag))
+        assert s.run(E) is False
+        res[flag] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.get_field("sigma"), s.mean_stress())
+        # a second load case on the same solver object, then raw passes
+        assert s.run(np.array([0, 0, 1.0, 0.3, 0, 0])) is False
+        s.iterate(E, 3)
+        res[flag] += (s.iterations, s.get_field("epsilon"))
+    a, b = res[0], res[1]
+    assert a[0] == b[0] and a[5] == b[5]
+    assert np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert np.array_equal(a[6], b[6])
+    o = make_oracle(grid, tol=1e-8)
+    assert o.run(E) is False
+    assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9
+
+
+def test_callback_field_access_inside_displacement_loop():
+    """Accessors called from the convergence callback materialise the strain on demand."""
+    s = make_gpu_solver((16, 16, 16), tol=1e-8)
+    o = make_oracle((16, 16, 16), tol=1e-8)
+    seen = []
+
+    def cb():
+        seen.append((s.mean_stress().copy(), s.get_field("u").copy()))
+        return False
+    s.set_convergence_callback(cb)
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    assert s.run(E) is False and o.run(E) is False
+    assert s.iterations == o.iterations and len(seen) == o.iterations
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(seen[-1][0], o.mean_stress()) < 1e-10
