@@ -224,7 +224,11 @@ def main():
             if avg <= 0:
                 continue   # stage absorbed by a fused kernel
             name, alg = k, ab[k]
-            if k == "stress" and times["div"] == 0:
+            if k == "stress" and times["div"] == 0 and times["eps_norm"] == 0:
+                # displacement-based sweep: strain operator + polarisation + divergence + norms,
+                # 3 u + phi in, 3 f out
+                name, alg = "u_eps_stress_div", 56 * n[0] * n[1] * n[2]
+            elif k == "stress" and times["div"] == 0:
                 # polarisation + divergence in one sweep: 6 eps + phi in, 3 f out (SURVEY 8d "S + div: 80")
                 name, alg = "stress_div", 80 * n[0] * n[1] * n[2]
             if k == "g0" and times["c2c_x_fwd"] == 0:

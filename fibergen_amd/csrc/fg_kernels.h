@@ -61,6 +61,9 @@ void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& e
 void launch_transpose_A(const double* src, double* dst, int nxl, int ny, int nyl, int nzc, bool to_blocks, hipStream_t s);
 void launch_transpose_B(const double* src, double* dst, int nx, int nxl, int nyl, int nzc, bool to_blocks, hipStream_t s);
 void launch_copy(const double* src, double* dst, long ndoubles, hipStream_t s);
+void launch_cg(int mode, const Grid& g, const FieldPtrs<6>& x, const FieldPtrs<6>& y, const FieldPtrs<6>& z, const Vec6& E,
+               double a, double* partial, double* out6, hipStream_t s);
+void launch_set_const6(const Grid& g, const FieldPtrs<6>& x, const Vec6& E, hipStream_t s);
 void launch_sum6(const Grid& g, const FieldPtrs<6>& x, bool square, double* partial, double* out6, hipStream_t s);
 void launch_sum1(const Grid& g, const double* x, double* partial, double* out1, hipStream_t s);
 void launch_tangent_minmax(const Grid& g, const PhaseTable& pt, int mixing, const FieldPtrs<kMaxPhases>& phi,

@@ -14,6 +14,9 @@ namespace fg {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef FG_K1_WAVES
+#define FG_K1_WAVES 2
+#endif
 
 __device__ __forceinline__ double2 ld2(const double* p, long i) { return *reinterpret_cast<const double2*>(p + i); }
 __device__ __forceinline__ void st2(double* p, long i, double2 v) { *reinterpret_cast<double2*>(p + i) = v; }
@@ -385,7 +388,7 @@ __device__ __forceinline__ PhiRows<NPH> load_phi(const FieldPtrs<kMaxPhases>& ph
 }
 
 template <int NPH>
-__global__ __launch_bounds__(kBlock) void k_u_stress_div_voigt(Grid g, StressParams sp, FieldPtrs<3> u,
+__global__ __launch_bounds__(kBlock, FG_K1_WAVES) void k_u_stress_div_voigt(Grid g, StressParams sp, FieldPtrs<3> u,
                                                                FieldPtrs<kMaxPhases> phi, FieldPtrs<3> fo, Vec6 E,
                                                                double* partial, int ry) {
   __shared__ double smem[4 * 6];
@@ -615,6 +618,86 @@ __global__ __launch_bounds__(kBlock) void k_sum(Grid g, FieldPtrs<NC> x, double*
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) partial[(long)blockIdx.x * NC + c] = acc[c];
+  }
+}
+
+// ----------------------------------------------------------------------------- CG vector kernels
+// runCGElasticity  F:23153-23247.  One kernel per vector update, each fused with the reduction that
+// follows it in the algorithm.  MODE:
+//   0  r <- r + (E - eps)                      [adjustResidual F:10012]       sum r:r
+//   1  (no update)                                                             sum p:(p - w)
+//   2  eps <- eps + a*p                        [xpay F:9819]                   per-component sum eps_c^2
+//   3  r <- r + a*(p - w)   (a = -alpha)       [xpaymz F:9993]                 sum r:r
+//   4  p <- r + a*p         (a = beta)         [xpay]
+// ":" is innerProductL2  F:20955-21038: shear products doubled.  x, y, z are 6-component fields.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_cg(Grid g, FieldPtrs<6> x, FieldPtrs<6> y, FieldPtrs<6> z, Vec6 E, double a,
+                                               double* partial) {
+  __shared__ double smem[4 * 6];
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
+    const PairPos p = pair_pos(pidx, g);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    double2 d[6];  // per component: the two terms of the weighted product (or eps for MODE 2)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      if (MODE == 0) {  // x = r, y = eps
+        double2 r = ld2(x.p[c], p.off);
+        const double2 e = ld2(y.p[c], p.off);
+        r.x += E.v[c] - e.x;
+        r.y += E.v[c] - e.y;
+        st2(x.p[c], p.off, r);
+        d[c] = make_double2(r.x * r.x, r.y * r.y);
+      } else if (MODE == 1) {  // x = p, y = w
+        const double2 pp = ld2(x.p[c], p.off), w = ld2(y.p[c], p.off);
+        d[c] = make_double2(pp.x * (pp.x - w.x), pp.y * (pp.y - w.y));
+      } else if (MODE == 2) {  // x = eps, y = p
+        double2 e = ld2(x.p[c], p.off);
+        const double2 pp = ld2(y.p[c], p.off);
+        e.x = e.x + a * pp.x;
+        e.y = e.y + a * pp.y;
+        st2(x.p[c], p.off, e);
+        d[c] = e;
+      } else if (MODE == 3) {  // x = r, y = p, z = w
+        double2 r = ld2(x.p[c], p.off);
+        const double2 pp = ld2(y.p[c], p.off), w = ld2(z.p[c], p.off);
+        r.x = r.x + a * (pp.x - w.x);
+        r.y = r.y + a * (pp.y - w.y);
+        st2(x.p[c], p.off, r);
+        d[c] = make_double2(r.x * r.x, r.y * r.y);
+      } else {  // x = p, y = r
+        double2 pp = ld2(x.p[c], p.off);
+        const double2 r = ld2(y.p[c], p.off);
+        pp.x = r.x + a * pp.x;
+        pp.y = r.y + a * pp.y;
+        st2(x.p[c], p.off, pp);
+      }
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] += d[c].x * d[c].x + (second ? d[c].y * d[c].y : 0.0);
+    } else if (MODE != 4) {
+      const double sx = d[0].x + d[1].x + d[2].x + 2 * (d[3].x + d[4].x + d[5].x);
+      const double sy = d[0].y + d[1].y + d[2].y + 2 * (d[3].y + d[4].y + d[5].y);
+      acc[0] += sx + (second ? sy : 0.0);
+    }
+  }
+  if (MODE != 4) {
+    block_reduce<6>(acc, smem, OpSum());
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+    }
+  }
+}
+
+// eps <- constant tensor E  (setConstant  F:10026)
+__global__ __launch_bounds__(kBlock) void k_set_const6(long n2, FieldPtrs<6> x, Vec6 E) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) st2(x.p[c], 2 * i, make_double2(E.v[c], E.v[c]));
   }
 }
 
@@ -855,6 +938,29 @@ void launch_transpose_B(const double* src, double* dst, int nx, int nxl, int nyl
 void launch_copy(const double* src, double* dst, long ndoubles, hipStream_t s) {
   const long n2 = ndoubles / 2;
   hipLaunchKernelGGL(k_copy, dim3(grid_for(n2, 1 << 16)), dim3(kBlock), 0, s, src, dst, n2);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_cg(int mode, const Grid& g, const FieldPtrs<6>& x, const FieldPtrs<6>& y, const FieldPtrs<6>& z, const Vec6& E,
+               double a, double* partial, double* out6, hipStream_t s) {
+  const int nb = reduce_blocks(g);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((k_cg<0>), dim3(nb), dim3(kBlock), 0, s, g, x, y, z, E, a, partial); break;
+    case 1: hipLaunchKernelGGL((k_cg<1>), dim3(nb), dim3(kBlock), 0, s, g, x, y, z, E, a, partial); break;
+    case 2: hipLaunchKernelGGL((k_cg<2>), dim3(nb), dim3(kBlock), 0, s, g, x, y, z, E, a, partial); break;
+    case 3: hipLaunchKernelGGL((k_cg<3>), dim3(nb), dim3(kBlock), 0, s, g, x, y, z, E, a, partial); break;
+    default: hipLaunchKernelGGL((k_cg<4>), dim3(nb), dim3(kBlock), 0, s, g, x, y, z, E, a, partial); break;
+  }
+  FG_HIP_CHECK(hipGetLastError());
+  if (mode != 4) {
+    hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, out6);
+    FG_HIP_CHECK(hipGetLastError());
+  }
+}
+
+void launch_set_const6(const Grid& g, const FieldPtrs<6>& x, const Vec6& E, hipStream_t s) {
+  const long n2 = g.n / 2;
+  hipLaunchKernelGGL(k_set_const6, dim3(grid_for(n2, 1 << 16)), dim3(kBlock), 0, s, n2, x, E);
   FG_HIP_CHECK(hipGetLastError());
 }
 

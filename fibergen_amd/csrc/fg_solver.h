@@ -35,6 +35,7 @@ struct SolverOptions {
   double lambda_0 = 0.0;
   double eps_g = 2.220446049250313e-16;          // laminate tolerances F:13110-13111
   double eps_a = 3.666852862501036e-11;          // eps^(2/3)
+  int method = 0;               // 0 = basic scheme (runBasic F:21716), 1 = conjugate gradients (runCGElasticity F:23153)
   int u_loop = 1;               // Voigt, pure strain BC: displacement-based pass, strain not stored in the loop
   int fuse_stress_div = 1;      // Voigt mixing: polarisation + divergence in one sweep
   int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
@@ -118,7 +119,9 @@ class Solver {
   void reset_stage_times();
 
  private:
-  void basic_scheme(const double* E6);
+  // one pass  dst = E - Gamma0 : (C - C0) : src  (defaults: the solver's strain field, in place)
+  void basic_scheme(const double* E6, double* src = nullptr, double* dst = nullptr);
+  bool run_cg(const double* E0, const double* S0);
   bool u_loop_eligible() const;
   void u_pass_front(const double* E6);  // u_k (fu_) -> sums of squares of eps_k, f_{k+1} (fu_alt_)
   void u_pass_back();                   // f_{k+1} -> u_{k+1}, buffers swapped
@@ -151,6 +154,7 @@ class Solver {
   double* eps_ = nullptr;      // 6 padded components
   double* tau_ = nullptr;      // 6
   double* fu_ = nullptr;       // 3 (real f / u, complex f_hat / u_hat); after a pass it holds u
+  double *cg_r_ = nullptr, *cg_p_ = nullptr, *cg_w_ = nullptr;  // CG residual, direction, operator image (6 each)
   double* fu_alt_ = nullptr;   // 3: second f/u buffer of the displacement-based loop (swapped with fu_)
   double* phi_ = nullptr;      // nphase
   double* normals_ = nullptr;  // 3 (allocated on demand)

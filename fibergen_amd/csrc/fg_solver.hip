@@ -123,7 +123,7 @@ Solver::~Solver() {
   fft_t_.reset();
   for (int k = 0; k < 4; ++k)
     if (halo_[k]) (void)hipFree(halo_[k]);
-  double* bufs[] = {eps_, tau_, fu_, fu_alt_, phi_, normals_, partial_, dscal_};
+  double* bufs[] = {eps_, tau_, fu_, fu_alt_, phi_, normals_, partial_, dscal_, cg_r_, cg_p_, cg_w_};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (hscal_) (void)hipHostFree(hscal_);
@@ -284,7 +284,9 @@ void Solver::time_end(int stage) {
 // ------------------------------------------------------------------ one pass of the basic scheme
 // basicScheme  F:20558-20578 + GammaOperatorStaggered  F:20288-20300:
 //   tau = (C - C0):eps ; f = div tau ; u = G0 f ; eps = E + sym grad u (+ R)
-void Solver::basic_scheme(const double* E6) {
+void Solver::basic_scheme(const double* E6, double* src, double* dst) {
+  if (!src) src = eps_;
+  if (!dst) dst = eps_;
   if (nranks_ != 1) throw std::runtime_error("basic_scheme: slab solvers are driven phase by phase (fg_slab_phase)");
   if (pt_.n < 1) throw std::runtime_error("No materials specified");
   if (opt_.mixing == kMixLaminate && !normals_) throw std::runtime_error("laminate mixing needs interface normals");
@@ -295,7 +297,12 @@ void Solver::basic_scheme(const double* E6) {
   const double alpha = -1.0;  // GammaOperator(..., -1)  F:20575
 
   ensure_eps();  // the displacement-based loop may have left the strain implicit
-  if (opt_.bc_relax != 1.0) mean_strain(F00_);  // F:20563-20565
+  if (opt_.bc_relax != 1.0) {  // F:20563-20565: mean of the operator's argument
+    launch_sum6(g_, ptrs6(src), false, partial_, dscal_ + kSlotMean, stream_);
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    for (int c = 0; c < 6; ++c) F00_[c] = hscal_[kSlotMean + c] / (double)nglobal_;
+  }
 
   // initBCProjector  F:20228-20239 needs <tau> only for mixed boundary conditions
   double F0[6] = {0, 0, 0, 0, 0, 0};
@@ -305,11 +312,11 @@ void Solver::basic_scheme(const double* E6) {
   const bool fuse_sd = opt_.fuse_stress_div && opt_.mixing == kMixVoigt && mq_zero;
   if (fuse_sd) {
     time_begin(0);
-    launch_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, ptrs3(fu_), stream_);
+    launch_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, ptrs3(fu_), stream_);
     time_end(0);
   } else {
     time_begin(0);
-    launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
+    launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, nrm, ptrs6(tau_), derr_, stream_);
     time_end(0);
     if (!mq_zero) {
       launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);
@@ -336,13 +343,13 @@ void Solver::basic_scheme(const double* E6) {
     if (R.v[c] != 0.0) add_R = true;
   }
   time_begin(9);
-  launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), E, R, add_R, partial_, dscal_ + kSlotSumSq,
+  launch_eps_norm(g_, ptrs3(fu_), ptrs6(dst), E, R, add_R, partial_, dscal_ + kSlotSumSq,
                   XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
   time_end(9);
   if (timing_) times_.count++;
   // fu_ now holds the displacement this strain was built from (eps = E + sym grad u when R == 0)
-  u_valid_ = !add_R;
-  eps_stale_ = false;
+  u_valid_ = !add_R && dst == eps_;
+  if (dst == eps_) eps_stale_ = false;
   for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
 }
 
@@ -558,6 +565,7 @@ bool Solver::run(const double* E6, const double* S6) {
     voigt_mv(BC_Q_, E0, t);
     if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
   }
+  if (opt_.method == 1) return run_cg(E0, S0);
   const double t_start = now_seconds();
   FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * g_.n * sizeof(double), stream_));  // F:21379
   for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
@@ -646,6 +654,92 @@ bool Solver::run(const double* E6, const double* S6) {
   in_run_ = false;
   iterations_ = iter;
   ensure_eps();
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  solve_time_ += now_seconds() - t_start;
+  return failed;
+}
+
+// ------------------------------------------------------------------ conjugate gradients
+// runCGElasticity  F:23153-23247 on the operator  eps -> -Gamma0 : (C - C0) : eps  (krylovOperator
+// F:20583-20587 = one basicScheme pass with E = 0), l2 inner product, epsilon error estimator.
+bool Solver::run_cg(const double* E0, const double* S0) {
+  if (nranks_ != 1) throw std::runtime_error("method=cg is not available on slab-decomposed solvers");
+  const double t_start = now_seconds();
+  const size_t f6 = 6 * (size_t)g_.n * sizeof(double);
+  for (double** b : {&cg_r_, &cg_p_, &cg_w_})
+    if (!*b) FG_HIP_CHECK(hipMalloc(b, f6));
+  FG_HIP_CHECK(hipMemsetAsync(eps_, 0, f6, stream_));  // F:21379
+  for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
+  u_valid_ = false;
+  eps_stale_ = false;
+  in_run_ = true;
+  const double small = std::numeric_limits<double>::min();
+  if (opt_.update_ref) calc_ref_material();
+  Vec6 E, Z;
+  {
+    double t1[6], t2[6], t3[6];  // calcBCMean  F:20242-20245
+    voigt_mv(BC_QC0_, E0, t1);
+    for (int i = 0; i < 6; ++i) t2[i] = S0[i] - t1[i];
+    voigt_mv(BC_M_, t2, t3);
+    for (int i = 0; i < 6; ++i) E.v[i] = E0[i] + opt_.bc_relax * t3[i], Z.v[i] = 0.0;
+  }
+  double prev = 0.0;  // estimator constructed on the zero field
+  auto fetch = [&](int slot, int n) {
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + slot, dscal_ + slot, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    check_device_error("cg");
+  };
+  const FieldPtrs<6> e = ptrs6(eps_), r = ptrs6(cg_r_), p = ptrs6(cg_p_), w = ptrs6(cg_w_);
+  launch_set_const6(g_, e, E, stream_);
+  basic_scheme(Z.v, eps_, cg_r_);                                                  // r = -Gamma0 (C - C0) eps
+  launch_cg(0, g_, r, e, e, E, 0.0, partial_, dscal_ + kSlotMean, stream_);        // r += E - eps ; r:r
+  fetch(kSlotMean, 1);
+  double gamma = hscal_[kSlotMean] / (double)nglobal_ + small;
+  FG_HIP_CHECK(hipMemcpyAsync(cg_p_, cg_r_, f6, hipMemcpyDeviceToDevice, stream_));  // p = r
+  long iter = 0;
+  bool failed = false;
+  for (;;) {
+    basic_scheme(Z.v, cg_p_, cg_w_);                                               // w = -Gamma0 (C - C0) p
+    launch_cg(1, g_, p, w, w, E, 0.0, partial_, dscal_ + kSlotMean, stream_);      // p:(p - w)
+    fetch(kSlotMean, 1);
+    double alpha = hscal_[kSlotMean] / (double)nglobal_ + small;
+    alpha = gamma / alpha;
+    launch_cg(2, g_, e, p, p, E, alpha, partial_, dscal_ + kSlotSumSq, stream_);   // eps += alpha p ; norms
+    fetch(kSlotSumSq, 6);
+    double m[6], s9 = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      sumsq_[c] = hscal_[kSlotSumSq + c];
+      m[c] = std::sqrt(sumsq_[c] / (double)nglobal_);
+    }
+    for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
+    for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
+    const double cur = std::sqrt(s9);
+    const double abs_err = std::fabs(prev - cur);
+    const double rel_err = abs_err / (small + cur);
+    prev = cur;
+    if (std::isnan(rel_err) || cancel_) {  // _converged  F:21177-21244
+      failed = true;
+      break;
+    }
+    residuals_.push_back(rel_err);
+    if (cb_ && cb_(cb_user_)) break;
+    if (cancel_) {
+      failed = true;
+      break;
+    }
+    if (iter >= opt_.maxiter) break;
+    if (rel_err <= opt_.tol || abs_err <= opt_.abs_tol) {
+      if (bc_error(E0, S0) <= opt_.bc_tol) break;
+    }
+    iter++;
+    launch_cg(3, g_, r, p, w, E, -alpha, partial_, dscal_ + kSlotMean, stream_);   // r -= alpha (p - w) ; r:r
+    fetch(kSlotMean, 1);
+    const double delta = hscal_[kSlotMean] / (double)nglobal_ + small;
+    const double beta = delta / gamma;
+    gamma = delta;
+    launch_cg(4, g_, p, r, r, E, beta, partial_, dscal_ + kSlotMean, stream_);     // p = r + beta p
+  }
+  in_run_ = false;
+  iterations_ = iter;
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
   solve_time_ += now_seconds() - t_start;
   return failed;

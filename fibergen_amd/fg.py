@@ -236,9 +236,6 @@ class FG:
         method = self._child_value(solver, "method", "cg", str)
         if method not in ("basic", "cg"):
             raise RuntimeError("Unknown solver method '%s'" % method)
-        if method == "cg":
-            warnings.warn("method=cg is not available on the MI355X path yet; the basic scheme is used "
-                          "(same fixed point, different iteration history)")
         self._method = method
         scheme = self._child_value(solver, "gamma_scheme", "auto", str)
         if scheme == "auto":
@@ -253,7 +250,7 @@ class FG:
             raise RuntimeError("Unknown mixing rule '%s'" % mixing)
 
         lss = LSSolver(nx, ny, nz, dx, dy, dz, device=self._device)
-        opts = {"mixing_rule": mixing}
+        opts = {"mixing_rule": mixing, "method": method}
         for k in _SOLVER_DOUBLE_KEYS:
             v = self._child_value(solver, k, None)
             if v is not None:

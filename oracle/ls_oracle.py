@@ -760,6 +760,68 @@ class LSOracle:
         self.iterations = it
         return False
 
+    # -- CG on the same operator ---------------------------------------------------------
+    def inner_l2(self, a, b, c=None):
+        """innerProductL2  F:20871-20953 (3 arguments: a:(b-c)), F:20955-21038: sum a:b with the
+        shear terms doubled, divided by N."""
+        d = b if c is None else (b - c)
+        s = a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + 2 * (a[3] * d[3] + a[4] * d[4] + a[5] * d[5])
+        return float(s.sum()) / self.N
+
+    def run_cg(self, E0, S0=None, P=None):
+        """LSSolver::run with method=cg: runCGElasticity  F:23153-23247 (l2 inner product,
+        epsilon error estimator, no residual re-initialisation)."""
+        E0 = np.asarray(E0, dtype=np.float64)
+        S0 = np.zeros(6) if S0 is None else np.asarray(S0, dtype=np.float64)
+        self.residuals = []
+        self.error = None
+        if P is not None:
+            self.BC_P = np.asarray(P, dtype=np.float64)
+        self._set_bc_projector(self.BC_P)
+        self.eps = np.zeros((6, self.nx, self.ny, self.nz))
+        self._F00 = np.zeros(6)
+        if self.update_ref != "never":
+            self.calc_ref_material()
+        E = self.calc_bc_mean(E0, S0)
+        prev = self._norm9(self.component_norm(self.eps))   # estimator constructed on the zero field
+        Z = np.zeros(6)
+        eps = np.empty_like(self.eps)
+        eps[:] = E[:, None, None, None]
+        r = self.basic_scheme(Z, eps)            # krylovOperator: -Gamma0 (C - C0) eps
+        r = r + (E[:, None, None, None] - eps)   # adjustResidual  F:10012-10022
+        gamma = self.inner_l2(r, r) + SMALLEST
+        p = r.copy()
+        it = 0
+        while True:
+            w = self.basic_scheme(Z, p)
+            alpha = self.inner_l2(p, p, w) + SMALLEST
+            alpha = gamma / alpha
+            eps = eps + alpha * p
+            self.eps = eps
+            cur = self._norm9(self.component_norm(eps))
+            abs_err = abs(prev - cur)
+            rel_err = abs_err / (SMALLEST + cur)
+            prev = cur
+            if math.isnan(rel_err):
+                self.error = "NaN detected in solution. Aborting."
+                return True
+            self.residuals.append(rel_err)
+            if self.callback is not None and self.callback():
+                break
+            if it >= self.maxiter:
+                break
+            if rel_err <= self.tol or abs_err <= self.abs_tol:
+                if self.bc_error(E0, S0) <= self.bc_tol:
+                    break
+            it += 1
+            r = r + (-alpha) * (p - w)           # xpaymz  F:9993-10010
+            delta = self.inner_l2(r, r) + SMALLEST
+            beta = delta / gamma
+            gamma = delta
+            p = r + beta * p                     # xpay  F:9819-9838
+        self.iterations = it
+        return False
+
     def calc_effective_properties(self):
         """calc_effective_properties  F:26030-26088: six unit load cases,
         Ceff = S E^-1 (E = identity), last three columns halved."""

@@ -319,3 +319,40 @@ def test_callback_field_access_inside_displacement_loop():
     assert s.iterations == o.iterations and len(seen) == o.iterations
     assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
     assert rel_err(seen[-1][0], o.mean_stress()) < 1e-10
+
+
+@pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6)])
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_cg_solver_matches_oracle(grid, mixing):
+    """method=cg (runCGElasticity F:23153-23247, the reference's default): same iteration count,
+    residual history and fields as the oracle's restatement; and the same fixed point as the basic scheme."""
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    o = make_oracle(grid, mixing=mixing, tol=1e-10)
+    s = make_gpu_solver(grid, mixing=mixing, tol=1e-10, method="cg")
+    assert o.run_cg(E) is False
+    assert s.run(E) is False
+    assert s.iterations == o.iterations and len(s.residuals) == len(o.residuals)
+    assert np.abs(np.array(s.residuals) - np.array(o.residuals)).max() < 1e-10
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-9
+    b = make_gpu_solver(grid, mixing=mixing, tol=1e-12)
+    assert b.run(E) is False
+    assert s.iterations < b.iterations / 3
+    assert rel_err(s.mean_stress(), b.mean_stress()) < 1e-5
+
+
+def test_cg_mixed_bc_and_maxiter():
+    grid = (16, 16, 16)
+    o = make_oracle(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    s = make_gpu_solver(grid, tol=1e-9, bc_tol=1e-8, maxiter=400, method="cg")
+    P = np.zeros((6, 6))
+    P[0, 0] = 1.0
+    E = np.array([0.01, 0, 0, 0, 0, 0])
+    assert o.run_cg(E, S0=np.zeros(6), P=P) is False
+    s.set_bc_projector(P)
+    assert s.run(E, np.zeros(6)) is False
+    assert s.iterations == o.iterations
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-7
+    s.set_options(maxiter=2)
+    assert s.run(E, np.zeros(6)) is False
+    assert s.iterations == 2 and len(s.residuals) == 3
