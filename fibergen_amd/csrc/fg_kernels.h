@@ -40,6 +40,7 @@ struct G0Layout {
 constexpr int kMaxReduceBlocks = 4096;  // partial-sum rows of the two-stage reductions
 
 int reduce_blocks(const Grid& g);
+long partial_rows(const Grid& g);  // rows (of up to 8 doubles) the partial-sum buffer must hold
 
 void launch_stress(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps, const FieldPtrs<kMaxPhases>& phi,
                    const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, int* error_flag, hipStream_t s);
@@ -53,6 +54,10 @@ void launch_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldP
 void launch_u_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u,
                                const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& f, const Vec6& E, double* partial,
                                double* sumsq6, hipStream_t s);
+void launch_effective_moduli(const Grid& g, const PhaseTable& pt, const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<2>& mod,
+                             hipStream_t s);
+void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
+                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s);
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);
 void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
                hipStream_t s);

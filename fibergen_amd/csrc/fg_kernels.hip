@@ -8,101 +8,14 @@
 #include "fg_kernels.h"
 
 #include "fg_hip_util.h"
+#include "fg_kernels_common.h"
 
 namespace fg {
 
 namespace {
-
-constexpr int kBlock = 256;
 #ifndef FG_K1_WAVES
 #define FG_K1_WAVES 2
 #endif
-
-__device__ __forceinline__ double2 ld2(const double* p, long i) { return *reinterpret_cast<const double2*>(p + i); }
-__device__ __forceinline__ void st2(double* p, long i, double2 v) { *reinterpret_cast<double2*>(p + i) = v; }
-
-// Decompose a pair index into (row, k): rows are (i,j) lines of nzc pairs.
-struct PairPos {
-  long row;   // i*ny + j
-  int i, j, k;
-  long off;   // element offset of (i,j,k)
-};
-
-__device__ __forceinline__ PairPos pair_pos(long pidx, const Grid& g) {
-  PairPos p;
-  p.row = pidx / g.nzc;
-  p.k = 2 * (int)(pidx - p.row * g.nzc);
-  p.i = (int)(p.row / g.ny);
-  p.j = (int)(p.row - (long)p.i * g.ny);
-  p.off = p.row * g.nzp + p.k;
-  return p;
-}
-
-// L2-aware traversal for the stencil kernels.  The pair space is re-ordered as
-// [y-chunk of ry rows][x][row in chunk][z pair] and every block sweeps one contiguous run of it;
-// blocks that share an XCD (blockIdx % 8, guide section 1) get adjacent runs.  The +-1 neighbours in
-// y (same chunk) and in x (next step of the sweep, ry rows x 9 arrays ~ 300 KB apart) are then served
-// by that XCD's 4 MiB L2 instead of being fetched again: the row-major sweep read every neighbour
-// from HBM (FETCH_SIZE 2.1x / 3.4x the algorithmic bytes for div / eps, profiles/r01_pmc_*).
-struct BlockRun {
-  long first, stride, count;  // pieces of kBlock pairs: first, first + stride, ...
-};
-
-// Piece r of block b is r*gridDim + remap(b): at any time the resident blocks work on one contiguous
-// window of the re-ordered pair space (a block that owned a long contiguous run of its own would make
-// the XCD's L2 juggle hundreds of far-apart streams -- measured: no reuse at all).
-__device__ __forceinline__ BlockRun block_run(long npieces) {
-  const long nb = gridDim.x, b = blockIdx.x;
-  BlockRun r;
-  r.first = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
-  r.stride = nb;
-  r.count = r.first < npieces ? (npieces - r.first + nb - 1) / nb : 0;
-  return r;
-}
-
-__device__ __forceinline__ PairPos pair_pos_tiled(long q, const Grid& g, int ry) {
-  PairPos p;
-  long t = q / g.nzc;
-  p.k = 2 * (int)(q - t * g.nzc);
-  const int jr = (int)(t % ry);
-  t /= ry;
-  p.i = (int)(t % g.nx);
-  const int jc = (int)(t / g.nx);
-  p.j = jc * ry + jr;
-  p.row = (long)p.i * g.ny + p.j;
-  p.off = p.row * g.nzp + p.k;
-  return p;
-}
-
-// Deterministic block reduction of NV values per thread: wave shuffle tree, then
-// LDS across the 4 waves, lane 0 of wave 0 holds the result.
-template <int NV, class Op>
-__device__ __forceinline__ void block_reduce(double* v, double* smem, Op op) {
-#pragma unroll
-  for (int q = 0; q < NV; ++q) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v[q] = op(v[q], __shfl_down(v[q], s, 64));
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q) smem[wave * NV + q] = v[q];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int nw = blockDim.x >> 6;
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      double a = smem[q];
-      for (int w = 1; w < nw; ++w) a = op(a, smem[w * NV + q]);
-      v[q] = a;
-    }
-  }
-}
-
-struct OpSum { __device__ double operator()(double a, double b) const { return a + b; } };
-struct OpMin { __device__ double operator()(double a, double b) const { return a < b ? a : b; } };
-struct OpMax { __device__ double operator()(double a, double b) const { return a > b ? a : b; } };
 
 // ----------------------------------------------------------------------------- stress
 // calcStress  F:18134-18184.  REDUCE = false: tau <- P(eps) - C0:eps written out.
@@ -356,20 +269,6 @@ __global__ __launch_bounds__(kBlock) void k_stress_div_voigt(Grid g, StressParam
 // reads 3 + n_phase arrays and writes 3 (64 B/voxel for two phases instead of 72 + 88).  Every value is
 // computed with the expressions of k_eps_norm / stress_voxel / k_div, so the pass is bit-identical to
 // the three-kernel form.  Row vectors hold the values at z = k-1, k, k+1, k+2 of one (x,y) row.
-struct Row4 {
-  double v[4];
-};
-
-__device__ __forceinline__ Row4 load_row(const double* a, long ro, int k, int kb, int kf2, bool second, bool m1, bool p2) {
-  Row4 r;
-  const double2 d = ld2(a, ro + k);
-  r.v[1] = d.x;
-  r.v[2] = second ? d.y : a[ro];  // odd nz, last pair: k+1 wraps to 0
-  r.v[0] = m1 ? a[ro + kb] : 0.0;
-  r.v[3] = p2 ? a[ro + kf2] : 0.0;
-  return r;
-}
-
 template <int NPH>
 struct PhiRows {
   Row4 r[NPH];
@@ -789,35 +688,6 @@ __global__ __launch_bounds__(kBlock) void k_stress_const(long n2, double two_mu,
   }
 }
 
-// second stage: one block folds nblocks x NV partials in a fixed order
-template <class Op>
-__global__ __launch_bounds__(kBlock) void k_fold(const double* partial, int nblocks, int nv, double init, double* out) {
-  __shared__ double smem[kBlock];
-  Op op;
-  for (int q = 0; q < nv; ++q) {
-    double a = init;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) a = op(a, partial[(long)b * nv + q]);
-    smem[threadIdx.x] = a;
-    __syncthreads();
-    for (int s = kBlock / 2; s >= 1; s >>= 1) {
-      if ((int)threadIdx.x < s) smem[threadIdx.x] = op(smem[threadIdx.x], smem[threadIdx.x + s]);
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[q] = smem[0];
-    __syncthreads();
-  }
-}
-
-// rows per y-chunk of the L2-aware sweep
-int chunk_rows(const Grid& g) { return g.ny % 8 == 0 ? 8 : (g.ny % 4 == 0 ? 4 : (g.ny % 2 == 0 ? 2 : 1)); }
-
-// blocks of a stencil sweep: one 256-pair piece per block, capped (runs of pieces beyond), multiple of 8
-int sweep_blocks(long npairs) {
-  long b = (npairs + kBlock - 1) / kBlock;
-  if (b >= 8) b = ((b + 7) / 8) * 8;   // multiple of 8 so that the XCD remap applies; surplus blocks find no piece
-  return (int)(b < 1 ? 1 : b);
-}
-
 int grid_for(long nwork, int max_blocks) {
   long b = (nwork + kBlock - 1) / kBlock;
   if (b > max_blocks) b = max_blocks;
@@ -845,6 +715,11 @@ void stress_dispatch(dim3 grid, const Grid& g, const StressParams& sp, const Fie
   FG_HIP_CHECK(hipGetLastError());
 }
 }  // namespace
+
+long partial_rows(const Grid& g) {
+  const long nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
+  return nb + (nb + 511) / 512 + 8;  // sweep partials + one intermediate fold level
+}
 
 int reduce_blocks(const Grid& g) { return grid_for((long)g.nx * g.ny * g.nzc, kMaxReduceBlocks); }
 
@@ -886,7 +761,7 @@ void launch_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldP
 void launch_u_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u,
                                const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& f, const Vec6& E, double* partial,
                                double* sumsq6, hipStream_t s) {
-  const int nb = reduce_blocks(g);
+  const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
   if (sp.pt.n <= 2)
     hipLaunchKernelGGL((k_u_stress_div_voigt<2>), dim3(nb), dim3(kBlock), 0, s, g, sp, u, phi, f, E, partial,
                        chunk_rows(g));
@@ -894,7 +769,7 @@ void launch_u_stress_div_voigt(const Grid& g, const StressParams& sp, const Fiel
     hipLaunchKernelGGL((k_u_stress_div_voigt<kMaxPhases>), dim3(nb), dim3(kBlock), 0, s, g, sp, u, phi, f, E, partial,
                        chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, sumsq6);
+  fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
 }
 
@@ -913,11 +788,11 @@ void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double
 
 void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps, const Vec6& E, const Vec6& R,
                      bool add_R, double* partial, double* sumsq6, const XHalo& h, hipStream_t s) {
-  const int nb = reduce_blocks(g);
+  const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
   hipLaunchKernelGGL(k_eps_norm, dim3(nb), dim3(kBlock), 0, s, g, u, eps, E, R, add_R ? 1 : 0, partial, h,
                      chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, sumsq6);
+  fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
 }
 

@@ -36,7 +36,8 @@ struct SolverOptions {
   double eps_g = 2.220446049250313e-16;          // laminate tolerances F:13110-13111
   double eps_a = 3.666852862501036e-11;          // eps^(2/3)
   int method = 0;               // 0 = basic scheme (runBasic F:21716), 1 = conjugate gradients (runCGElasticity F:23153)
-  int u_loop = 1;               // Voigt, pure strain BC: displacement-based pass, strain not stored in the loop
+  int u_loop = 2;               // Voigt, pure strain BC: displacement-based pass (0 off, 1 exact operation order,
+                                // 2 precomputed effective moduli + FMA, agrees with 1 to rounding)
   int fuse_stress_div = 1;      // Voigt mixing: polarisation + divergence in one sweep
   int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
 };
@@ -155,6 +156,8 @@ class Solver {
   double* tau_ = nullptr;      // 6
   double* fu_ = nullptr;       // 3 (real f / u, complex f_hat / u_hat); after a pass it holds u
   double *cg_r_ = nullptr, *cg_p_ = nullptr, *cg_w_ = nullptr;  // CG residual, direction, operator image (6 each)
+  double* mod_ = nullptr;      // 2: per-voxel effective moduli (sum phi 2 mu, sum phi lambda) of the fast sweep
+  bool mod_dirty_ = true;
   double* fu_alt_ = nullptr;   // 3: second f/u buffer of the displacement-based loop (swapped with fu_)
   double* phi_ = nullptr;      // nphase
   double* normals_ = nullptr;  // 3 (allocated on demand)

@@ -1,5 +1,6 @@
 #include "fg_solver.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <complex>
@@ -65,7 +66,10 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * comp, stream_));
   FG_HIP_CHECK(hipMemsetAsync(tau_, 0, 6 * comp, stream_));
   FG_HIP_CHECK(hipMemsetAsync(fu_, 0, 3 * comp, stream_));
-  FG_HIP_CHECK(hipMalloc(&partial_, (size_t)kMaxReduceBlocks * 8 * sizeof(double)));
+  {
+    const long rows = std::max<long>(partial_rows(g_), kMaxReduceBlocks);
+    FG_HIP_CHECK(hipMalloc(&partial_, (size_t)rows * 8 * sizeof(double)));
+  }
   FG_HIP_CHECK(hipMalloc(&dscal_, kNumSlots * sizeof(double)));
   FG_HIP_CHECK(hipHostMalloc(&hscal_, kNumSlots * sizeof(double)));
   FG_HIP_CHECK(hipMalloc(&derr_, sizeof(int)));
@@ -123,7 +127,7 @@ Solver::~Solver() {
   fft_t_.reset();
   for (int k = 0; k < 4; ++k)
     if (halo_[k]) (void)hipFree(halo_[k]);
-  double* bufs[] = {eps_, tau_, fu_, fu_alt_, phi_, normals_, partial_, dscal_, cg_r_, cg_p_, cg_w_};
+  double* bufs[] = {eps_, tau_, fu_, fu_alt_, phi_, normals_, partial_, dscal_, cg_r_, cg_p_, cg_w_, mod_};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (hscal_) (void)hipHostFree(hscal_);
@@ -147,16 +151,19 @@ void Solver::set_num_phases(int n) {
   FG_HIP_CHECK(hipMalloc(&phi_, (size_t)n * g_.n * sizeof(double)));
   FG_HIP_CHECK(hipMemset(phi_, 0, (size_t)n * g_.n * sizeof(double)));
   pt_.n = n;
+  mod_dirty_ = true;
 }
 
 void Solver::set_phase_material(int p, double mu, double lambda) {
   if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
+  mod_dirty_ = true;
   pt_.mu[p] = mu;
   pt_.lambda[p] = lambda;
 }
 
 void Solver::set_phase_field(int p, const double* phi_host) {
   if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
+  mod_dirty_ = true;
   upload_padded(phi_ + (long)p * g_.n, phi_host);
 }
 
@@ -428,8 +435,24 @@ void Solver::u_pass_front(const double* E6) {
     E_next_[c] = E6[c];
   }
   time_begin(0);
-  launch_u_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, ptrs3(fu_alt_), E,
-                            partial_, dscal_ + kSlotSumSq, stream_);
+  if (opt_.u_loop >= 2) {
+    // fast variant: per-voxel effective moduli instead of the per-phase accumulation
+    if (!mod_) {
+      FG_HIP_CHECK(hipMalloc(&mod_, 2 * (size_t)g_.n * sizeof(double)));
+      mod_dirty_ = true;
+    }
+    FieldPtrs<2> mod;
+    mod.p[0] = mod_;
+    mod.p[1] = mod_ + g_.n;
+    if (mod_dirty_) {
+      launch_effective_moduli(g_, pt_, phi, mod, stream_);
+      mod_dirty_ = false;
+    }
+    launch_u_fast(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, stream_);
+  } else {
+    launch_u_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, ptrs3(fu_alt_), E,
+                              partial_, dscal_ + kSlotSumSq, stream_);
+  }
   time_end(0);
   eps_stale_ = true;
 }

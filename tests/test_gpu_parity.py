@@ -285,7 +285,7 @@ def test_displacement_based_loop_is_bit_identical(grid):
     residual history and bit-identical converged fields."""
     E = np.array([1.0, 0, 0, 0, 0, 0.5])
     res = {}
-    for flag in (0, 1):
+    for flag in (0, 1, 2):
         s = make_gpu_solver(grid, tol=1e-8)
         s._check(s._lib.fg_set_option_i(s._h, b"u_loop", flag))
         assert s.run(E) is False
@@ -294,14 +294,20 @@ def test_displacement_based_loop_is_bit_identical(grid):
         assert s.run(np.array([0, 0, 1.0, 0.3, 0, 0])) is False
         s.iterate(E, 3)
         res[flag] += (s.iterations, s.get_field("epsilon"))
-    a, b = res[0], res[1]
+    a, b, c = res[0], res[1], res[2]
+    # u_loop = 1: the exact-operation-order sweep is bit-identical to the strain-based loop
     assert a[0] == b[0] and a[5] == b[5]
     assert np.array_equal(a[1], b[1])
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     assert np.array_equal(a[6], b[6])
+    # u_loop = 2 (default): precomputed effective moduli + FMA, equal to rounding
+    assert a[0] == c[0] and a[5] == c[5]
+    assert np.abs(a[1] - c[1]).max() < 1e-12
+    assert rel_err(c[2], a[2]) < 1e-11 and rel_err(c[3], a[3]) < 1e-11 and rel_err(c[4], a[4]) < 1e-12
+    assert rel_err(c[6], a[6]) < 1e-11
     o = make_oracle(grid, tol=1e-8)
     assert o.run(E) is False
-    assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9
+    assert o.iterations == c[0] and rel_err(c[2], o.eps) < 1e-9
 
 
 def test_callback_field_access_inside_displacement_loop():
