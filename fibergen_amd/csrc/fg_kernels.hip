@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_stress(Grid g, StressParams sp, Fiel
 // ----------------------------------------------------------------------------- divergence
 // divOperatorStaggered  F:18853-18908:
 //  f0 = D-x t0 + D+y t5 + D+z t4 ; f1 = D+x t5 + D-y t1 + D+z t3 ; f2 = D+x t4 + D+y t3 + D-z t2
-__global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtrs<3> f, XHalo h, int ry) {
+__global__ __launch_bounds__(kBlock) void k_div(Grid g, FieldPtrs<6> t, FieldPtrs<3> f, XHalo h, Sweep ry) {
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
   const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
@@ -151,7 +151,7 @@ struct VoxelIn {
 
 template <int NPH>
 __global__ __launch_bounds__(kBlock) void k_stress_div_voigt(Grid g, StressParams sp, FieldPtrs<6> eps,
-                                                             FieldPtrs<kMaxPhases> phi, FieldPtrs<3> fo, int ry) {
+                                                             FieldPtrs<kMaxPhases> phi, FieldPtrs<3> fo, Sweep ry) {
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
   const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
@@ -289,7 +289,7 @@ __device__ __forceinline__ PhiRows<NPH> load_phi(const FieldPtrs<kMaxPhases>& ph
 template <int NPH>
 __global__ __launch_bounds__(kBlock, FG_K1_WAVES) void k_u_stress_div_voigt(Grid g, StressParams sp, FieldPtrs<3> u,
                                                                FieldPtrs<kMaxPhases> phi, FieldPtrs<3> fo, Vec6 E,
-                                                               double* partial, int ry) {
+                                                               double* partial, Sweep ry) {
   __shared__ double smem[4 * 6];
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables
 // epsOperatorStaggered  F:18614-18692, followed by eps += R (applyBCProjector  F:20263-20270)
 // and the per-component sums of squares of component_norm (F:10088-10138) fused in.
 __global__ __launch_bounds__(kBlock) void k_eps_norm(Grid g, FieldPtrs<3> u, FieldPtrs<6> eps, Vec6 E, Vec6 R, int add_R,
-                                                     double* partial, XHalo h, int ry) {
+                                                     double* partial, XHalo h, Sweep ry) {
   __shared__ double smem[4 * 6];
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;

@@ -2,6 +2,8 @@
 // no FMA contraction; fg_kernels_fast.hip: precomputed moduli, FMA contraction).
 #pragma once
 
+#include <stdexcept>
+
 #include "fg_kernels.h"
 
 namespace fg {
@@ -39,52 +41,95 @@ struct BlockRun {
   long first, stride, count;  // pieces of kBlock pairs: first, first + stride, ...
 };
 
-// Piece r of block b is r*gridDim + remap(b): at any time the resident blocks work on one contiguous
-// window of the re-ordered pair space (a block that owned a long contiguous run of its own would make
-// the XCD's L2 juggle hundreds of far-apart streams -- measured: no reuse at all).
+// Block b works on piece remap(b) of kBlock pairs (sweep_blocks launches at least one block per piece):
+// at any time the resident blocks work on one contiguous window of the re-ordered pair space.  (Blocks
+// that owned a long contiguous run of their own made the XCD's L2 juggle hundreds of far-apart streams --
+// measured: no reuse at all; blocks looping over strided pieces drifted out of step, 2-3x over-fetch.)
 __device__ __forceinline__ BlockRun block_run(long npieces) {
-  const long nb = gridDim.x, b = blockIdx.x;
+  const unsigned nb = gridDim.x, b = blockIdx.x;
   BlockRun r;
   r.first = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
   r.stride = nb;
-  r.count = r.first < npieces ? (npieces - r.first + nb - 1) / nb : 0;
+  r.count = r.first < npieces ? 1 : 0;
   return r;
 }
 
-__device__ __forceinline__ PairPos pair_pos_tiled(long q, const Grid& g, int ry) {
+// Division by a run-time constant without the 64-bit divide sequence: for 0 <= n < 2^31 and
+// l = ceil(log2 d), m = ceil(2^(31+l) / d) < 2^32 gives n / d == (n * m) >> (31 + l) exactly
+// (Granlund-Montgomery round-up; the error term n e / (d 2^(31+l)) stays below 2^-l <= 1/d).
+struct FastDiv {
+  unsigned d, mul, sh;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  const unsigned long long p = 1ull << (31 + l);
+  return FastDiv{d, (unsigned)((p + d - 1) / d), 31 + l};
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) {
+  return (unsigned)(((unsigned long long)n * f.mul) >> f.sh);
+}
+
+// parameters of the L2-aware sweep: rows per y-chunk (a power of two) and the dividers of its index map
+struct Sweep {
+  FastDiv by_nzc, by_nx;
+  int ry, ry_shift;
+};
+
+__device__ __forceinline__ PairPos pair_pos_tiled(long q, const Grid& g, const Sweep& sw) {
   PairPos p;
-  long t = q / g.nzc;
-  p.k = 2 * (int)(q - t * g.nzc);
-  const int jr = (int)(t % ry);
-  t /= ry;
-  p.i = (int)(t % g.nx);
-  const int jc = (int)(t / g.nx);
-  p.j = jc * ry + jr;
+  unsigned t = fast_div((unsigned)q, sw.by_nzc);  // launches guarantee npairs < 2^31
+  p.k = 2 * (int)((unsigned)q - t * (unsigned)g.nzc);
+  const int jr = (int)(t & (unsigned)(sw.ry - 1));
+  t >>= sw.ry_shift;
+  const unsigned jc = fast_div(t, sw.by_nx);
+  p.i = (int)(t - jc * (unsigned)g.nx);
+  p.j = (int)jc * sw.ry + jr;
   p.row = (long)p.i * g.ny + p.j;
   p.off = p.row * g.nzp + p.k;
   return p;
 }
 
-// Deterministic block reduction of NV values per thread: wave shuffle tree, then
-// LDS across the 4 waves, lane 0 of wave 0 holds the result.
+// Lane permutations as DPP moves (VALU only, no LDS traffic).  CTRL: 0x120+n = row_ror:n (rotate
+// within each row of 16 lanes), 0x138 = wave_shr:1 (lane i <- i-1), 0x130 = wave_shl:1 (lane i <- i+1).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Deterministic block reduction of NV values per thread: fixed rotate tree inside each row of 16
+// lanes, the four row totals and then the four waves combined in a fixed order; thread 0 holds the result.
 template <int NV, class Op>
 __device__ __forceinline__ void block_reduce(double* v, double* smem, Op op) {
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v[q] = op(v[q], __shfl_down(v[q], s, 64));
+    double a = v[q];
+    a = op(a, dpp_move<0x128>(a));
+    a = op(a, dpp_move<0x124>(a));
+    a = op(a, dpp_move<0x122>(a));
+    a = op(a, dpp_move<0x121>(a));
+    v[q] = op(op(read_lane(a, 0), read_lane(a, 16)), op(read_lane(a, 32), read_lane(a, 48)));
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int nw = kBlock / 64;
   if (lane == 0) {
 #pragma unroll
     for (int q = 0; q < NV; ++q) smem[wave * NV + q] = v[q];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int nw = blockDim.x >> 6;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       double a = smem[q];
+#pragma unroll
       for (int w = 1; w < nw; ++w) a = op(a, smem[w * NV + q]);
       v[q] = a;
     }
@@ -175,7 +220,15 @@ inline void fold_sum(double* partial, long nrows, int nv, double* out, hipStream
 }
 
 // rows per y-chunk of the L2-aware sweep
-inline int chunk_rows(const Grid& g) { return g.ny % 8 == 0 ? 8 : (g.ny % 4 == 0 ? 4 : (g.ny % 2 == 0 ? 2 : 1)); }
+inline Sweep chunk_rows(const Grid& g) {
+  if ((long)g.nx * g.ny * g.nzc >= (1L << 31)) throw std::runtime_error("grid too large for the 31-bit pair index of the sweeps");
+  Sweep sw;
+  sw.ry = g.ny % 8 == 0 ? 8 : (g.ny % 4 == 0 ? 4 : (g.ny % 2 == 0 ? 2 : 1));
+  sw.ry_shift = sw.ry == 8 ? 3 : (sw.ry == 4 ? 2 : (sw.ry == 2 ? 1 : 0));
+  sw.by_nzc = make_fastdiv((unsigned)g.nzc);
+  sw.by_nx = make_fastdiv((unsigned)g.nx);
+  return sw;
+}
 
 }  // namespace
 }  // namespace fg

@@ -13,19 +13,28 @@ namespace fg {
 
 namespace {
 
+// The sweep holds, per (x,y) row it touches, the vector [z = k-1, k, k+1, k+2]: the pair (k, k+1) is one
+// 16-byte load; the outer two values are the neighbouring lanes' pair halves, fetched by a wave shift.
+// Only the first / last lane of a wave and the lanes at the ends of a z row load them from memory (edge
+// loads, grouped so that they are issued together).  All 64 lanes stay active up to the stores.
+// ODD: nz is odd, the last pair of a row holds one voxel and z+1 wraps to 0.
+template <bool ODD>
 __global__ __launch_bounds__(kBlock) void k_u_fast(Grid g, double beta, double gamma, FieldPtrs<3> u, FieldPtrs<2> mod,
-                                                   FieldPtrs<3> fo, Vec6 E, double* partial, int ry) {
+                                                   FieldPtrs<3> fo, Vec6 E, double* partial, Sweep ry) {
   __shared__ double smem[4 * 6];
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
   for (long it = 0; it < run.count; ++it) {
-    const long pidx = (run.first + it * run.stride) * kBlock + threadIdx.x;
-    if (pidx >= npairs) continue;
+    const long pidx_raw = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    const long pidx = pidx_raw < npairs ? pidx_raw : npairs - 1;  // clamped lanes discard their result
     const PairPos p = pair_pos_tiled(pidx, g, ry);
-    if (p.k >= g.nz) continue;
-    const bool second = p.k + 1 < g.nz;
+    const bool valid = pidx_raw < npairs && p.k < g.nz;
+    const bool second = !ODD || p.k + 1 < g.nz;
+    const int lane = threadIdx.x & 63;
+    const bool prev_ok = lane > 0 && p.k > 0;
+    const bool next_ok = lane < 63 && p.k + 2 < g.nz && pidx_raw + 1 < npairs;
     const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
     const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
     const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
@@ -34,25 +43,46 @@ __global__ __launch_bounds__(kBlock) void k_u_fast(Grid g, double beta, double g
     const int k = p.k;
     const int kb = k == 0 ? g.nz - 1 : k - 1;
     const int kf2 = (k + 2 >= g.nz) ? k + 2 - g.nz : k + 2;
-#define FG_ROW(a, off, m1, p2) load_row(a, ro + (off), k, kb, kf2, second, m1, p2)
-    const Row4 U0c = FG_ROW(u.p[0], 0, true, true), U0xf = FG_ROW(u.p[0], xf, true, false);
-    const Row4 U0yb = FG_ROW(u.p[0], yb, false, false), U0xb = FG_ROW(u.p[0], xb, false, false);
-    const Row4 U0xfyb = FG_ROW(u.p[0], xf + yb, false, false), U0yf = FG_ROW(u.p[0], yf, false, false);
-    const Row4 U1c = FG_ROW(u.p[1], 0, true, true), U1yf = FG_ROW(u.p[1], yf, true, false);
-    const Row4 U1xb = FG_ROW(u.p[1], xb, false, false), U1xbyf = FG_ROW(u.p[1], xb + yf, false, false);
-    const Row4 U1yb = FG_ROW(u.p[1], yb, false, false), U1xf = FG_ROW(u.p[1], xf, false, false);
-    const Row4 U2c = FG_ROW(u.p[2], 0, true, true), U2yb = FG_ROW(u.p[2], yb, false, true);
-    const Row4 U2xb = FG_ROW(u.p[2], xb, false, true), U2xf = FG_ROW(u.p[2], xf, false, false);
-    const Row4 U2yf = FG_ROW(u.p[2], yf, false, false);
-#undef FG_ROW
+    const double* const u0 = u.p[0];
+    const double* const u1 = u.p[1];
+    const double* const u2 = u.p[2];
+    const double* const mA = mod.p[0];
+    const double* const mB = mod.p[1];
+
+    // edge loads: z = k-1 of {U0c, U0xf, U1c, U1yf, U2c, Ac, Bc}, z = k+2 of {U0c, U1c, U2c, U2yb, U2xb, Ac, Bc}
+    double em[7] = {0, 0, 0, 0, 0, 0, 0}, ep[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (!prev_ok) {
+      const long o = ro + kb;
+      em[0] = u0[o]; em[1] = u0[o + xf]; em[2] = u1[o]; em[3] = u1[o + yf]; em[4] = u2[o]; em[5] = mA[o]; em[6] = mB[o];
+    }
+    if (!next_ok) {
+      const long o = ro + kf2;
+      ep[0] = u0[o]; ep[1] = u1[o]; ep[2] = u2[o]; ep[3] = u2[o + yb]; ep[4] = u2[o + xb]; ep[5] = mA[o]; ep[6] = mB[o];
+    }
+    const long rk = ro + k;
+#define FG_ROW(name, a, off)                      \
+    Row4 name;                                      \
+    {                                               \
+      const double2 d_ = ld2(a, rk + (off));        \
+      name.v[1] = d_.x;                             \
+      name.v[2] = d_.y;                             \
+      if (ODD && !second) name.v[2] = (a)[ro + (off)]; \
+    }
+    FG_ROW(U0c, u0, 0) FG_ROW(U0xf, u0, xf) FG_ROW(U0yb, u0, yb) FG_ROW(U0xb, u0, xb) FG_ROW(U0xfyb, u0, xf + yb)
+    FG_ROW(U0yf, u0, yf)
+    FG_ROW(U1c, u1, 0) FG_ROW(U1yf, u1, yf) FG_ROW(U1xb, u1, xb) FG_ROW(U1xbyf, u1, xb + yf) FG_ROW(U1yb, u1, yb)
+    FG_ROW(U1xf, u1, xf)
+    FG_ROW(U2c, u2, 0) FG_ROW(U2yb, u2, yb) FG_ROW(U2xb, u2, xb) FG_ROW(U2xf, u2, xf) FG_ROW(U2yf, u2, yf)
     // effective moduli rows: A = sum_p phi_p 2 mu_p, B = sum_p phi_p lambda_p (precomputed per voxel)
-    const Row4 Ac = load_row(mod.p[0], ro, k, kb, kf2, second, true, true), Bc = load_row(mod.p[1], ro, k, kb, kf2, second, true, true);
-    const Row4 Axb = load_row(mod.p[0], ro + xb, k, kb, kf2, second, false, false);
-    const Row4 Bxb = load_row(mod.p[1], ro + xb, k, kb, kf2, second, false, false);
-    const Row4 Axf = load_row(mod.p[0], ro + xf, k, kb, kf2, second, false, false);
-    const Row4 Ayb = load_row(mod.p[0], ro + yb, k, kb, kf2, second, false, false);
-    const Row4 Byb = load_row(mod.p[1], ro + yb, k, kb, kf2, second, false, false);
-    const Row4 Ayf = load_row(mod.p[0], ro + yf, k, kb, kf2, second, false, false);
+    FG_ROW(Ac, mA, 0) FG_ROW(Bc, mB, 0) FG_ROW(Axb, mA, xb) FG_ROW(Bxb, mB, xb) FG_ROW(Axf, mA, xf)
+    FG_ROW(Ayb, mA, yb) FG_ROW(Byb, mB, yb) FG_ROW(Ayf, mA, yf)
+#undef FG_ROW
+#define FG_PREV(row, i) { const double t_ = dpp_move<0x138>(row.v[2]); row.v[0] = prev_ok ? t_ : em[i]; }
+#define FG_NEXT(row, i) { const double t_ = dpp_move<0x130>(row.v[1]); row.v[3] = next_ok ? t_ : ep[i]; }
+    FG_PREV(U0c, 0) FG_PREV(U0xf, 1) FG_PREV(U1c, 2) FG_PREV(U1yf, 3) FG_PREV(U2c, 4) FG_PREV(Ac, 5) FG_PREV(Bc, 6)
+    FG_NEXT(U0c, 0) FG_NEXT(U1c, 1) FG_NEXT(U2c, 2) FG_NEXT(U2yb, 3) FG_NEXT(U2xb, 4) FG_NEXT(Ac, 5) FG_NEXT(Bc, 6)
+#undef FG_PREV
+#undef FG_NEXT
 
     double fout[2][3], eout[2][6];
 #pragma unroll
@@ -98,13 +128,15 @@ __global__ __launch_bounds__(kBlock) void k_u_fast(Grid g, double beta, double g
       fout[s][1] = (t5xf - t5) * hx + (t1 - t1yb) * hy + (t3zf - t3) * hz;
       fout[s][2] = (t4xf - t4) * hx + (t3yf - t3) * hy + (t2 - t2zb) * hz;
     }
+    if (valid) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const double ey = second ? eout[1][c] : 0.0;
-      acc[c] += eout[0][c] * eout[0][c] + ey * ey;
+      for (int c = 0; c < 6; ++c) {
+        const double ey = second ? eout[1][c] : 0.0;
+        acc[c] += eout[0][c] * eout[0][c] + ey * ey;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) st2(fo.p[c], p.off, make_double2(fout[0][c], second ? fout[1][c] : 0.0));
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) st2(fo.p[c], p.off, make_double2(fout[0][c], second ? fout[1][c] : 0.0));
   }
   block_reduce<6>(acc, smem, OpSum());
   if (threadIdx.x == 0) {
@@ -144,8 +176,12 @@ void launch_effective_moduli(const Grid& g, const PhaseTable& pt, const FieldPtr
 void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s) {
   const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
-  hipLaunchKernelGGL(k_u_fast, dim3(nb), dim3(kBlock), 0, s, g, -2 * mu_0, -lambda_0, u, mod, f, E, partial,
-                     chunk_rows(g));
+  if (g.nz % 2)
+    hipLaunchKernelGGL(k_u_fast<true>, dim3(nb), dim3(kBlock), 0, s, g, -2 * mu_0, -lambda_0, u, mod, f, E, partial,
+                       chunk_rows(g));
+  else
+    hipLaunchKernelGGL(k_u_fast<false>, dim3(nb), dim3(kBlock), 0, s, g, -2 * mu_0, -lambda_0, u, mod, f, E, partial,
+                       chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
