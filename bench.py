@@ -140,6 +140,29 @@ def guarded_slab_section(args, n, K, rank, world, local_rank, dist, torch, out):
         timer.cancel()
 
 
+# HIP-event slot name -> kernel name in the rocprofv3 counter summaries under profiles/
+PMC_KERNEL = {"u_eps_stress_div": "k_u_fast", "stress_div": "k_stress_div_voigt", "xfft_g0_xifft": "k_xfused",
+              "eps_norm": "k_eps_norm", "stress": "k_stress", "div": "k_div", "g0": "k_g0"}
+
+
+def committed_traffic(n, slot):
+    """HBM bytes per launch of kernel `slot` from the committed PMC summary of this workload
+    (profiles/*pmc_hbm_traffic_<n>cubed*.csv: separate FETCH_SIZE / WRITE_SIZE passes of this same
+    bench command, FETCH_SIZE doubled for gfx950).  A counter pass cannot run inside the timed
+    process, so the figure is read back from the file; None when no pass exists for this grid."""
+    import csv
+    import glob
+    want = PMC_KERNEL.get(slot)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                          "*pmc_hbm_traffic_%dcubed*.csv" % n)))  # latest by name
+    if not want or not files:
+        return None, None
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"].startswith(want):
+            return float(row["total_GB"]) * 1e9, "profiles/" + os.path.basename(files[-1])
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,8 +260,9 @@ def main():
             kern[name] = {"avg_ms": avg, "alg_GB": alg / 1e9, "GBps": (alg / 1e9) / (avg / 1e3)}
         dom = max(kern, key=lambda k: kern[k]["avg_ms"])
         N = n[0] * n[1] * n[2]
+        traffic, traffic_src = committed_traffic(args.n, dom)
         roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]}
         out = {
             "metric": "LS iterations/sec (basic scheme, staggered grid, linear elastic)",

@@ -1,0 +1,27 @@
+"""HBM traffic per launch from separate rocprofv3 FETCH_SIZE / WRITE_SIZE passes.
+usage: python tools/traffic_csv.py <fetch dir> <write dir> > profiles/<name>.csv
+FETCH_SIZE is doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section); both are KB."""
+import csv, glob, sys, collections, re
+
+def short(name):
+    m = re.search(r"(k_[a-z0-9_]+(<[A-Za-z0-9_:]+<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+def per_kernel(d, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+print("kernel,FETCH_SIZE_x2_GB_per_launch,WRITE_SIZE_GB_per_launch,total_GB")
+for k in sorted(fetch):
+    if "rocclr" in k or "k_fold" in k:
+        continue
+    f = 2 * fetch[k] * 1024 / 1e9
+    w = write.get(k, 0.0) * 1024 / 1e9
+    print('"%s",%.3f,%.3f,%.3f' % (k, f, w, f + w))
