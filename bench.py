@@ -141,7 +141,7 @@ def guarded_slab_section(args, n, K, rank, world, local_rank, dist, torch, out):
 
 
 # HIP-event slot name -> kernel name in the rocprofv3 counter summaries under profiles/
-PMC_KERNEL = {"u_eps_stress_div": "k_u_fast", "stress_div": "k_stress_div_voigt", "xfft_g0_xifft": "k_xfused",
+PMC_KERNEL = {"u_eps_stress_div": "k_u_fast", "u_eps_stress_div_r2cz": "k_u_fast_z", "stress_div": "k_stress_div_voigt", "xfft_g0_xifft": "k_xfused",
               "eps_norm": "k_eps_norm", "stress": "k_stress", "div": "k_div", "g0": "k_g0"}
 
 
@@ -158,7 +158,7 @@ def committed_traffic(n, slot):
     if not want or not files:
         return None, None
     for row in csv.DictReader(open(files[-1])):
-        if row["kernel"].startswith(want):
+        if row["kernel"].split("<")[0] == want:
             return float(row["total_GB"]) * 1e9, "profiles/" + os.path.basename(files[-1])
     return None, None
 
@@ -251,6 +251,10 @@ def main():
                 # displacement-based sweep: strain operator + polarisation + divergence + norms,
                 # 3 u + phi in, 3 f out
                 name, alg = "u_eps_stress_div", 56 * n[0] * n[1] * n[2]
+                if times["r2c_z"] == 0:
+                    # ... with the z r2c attached: the half spectrum of f goes out instead of f (3 x 16 B x nzf/nz)
+                    name = "u_eps_stress_div_r2cz"
+                    alg = (32 * n[2] + 48 * (n[2] // 2 + 1)) * n[0] * n[1]
             elif k == "stress" and times["div"] == 0:
                 # polarisation + divergence in one sweep: 6 eps + phi in, 3 f out (SURVEY 8d "S + div: 80")
                 name, alg = "stress_div", 80 * n[0] * n[1] * n[2]

@@ -44,6 +44,8 @@ class Fft3 {
   bool fast_y() const { return fast_[1]; }
   bool fast_z() const { return fast_[2]; }
   const cplx* x_twiddles() const { return tw_[0]; }
+  const cplx* z_twiddles() const { return tw_[2]; }  // pass twiddles of M = nz/2 (fast z path)
+  const cplx* z_roots() const { return wz_; }        // e^{-2 pi i k/nz}, k = 0..nz/2
 
  private:
   void strided(double* data, int ncomp, long comp_stride, int axis, int dir, double scale);

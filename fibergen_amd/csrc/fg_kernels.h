@@ -58,6 +58,12 @@ void launch_effective_moduli(const Grid& g, const PhaseTable& pt, const FieldPtr
                              hipStream_t s);
 void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s);
+// the same sweep with the z transform attached (f is replaced by its half spectrum along z); tw_z / w_z are
+// the z-pass tables of the FFT plan (Fft3::z_twiddles, Fft3::z_roots)
+bool u_fast_z_supported(const Grid& g);
+void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
+                     const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, const cplx* tw_z,
+                     const cplx* w_z, hipStream_t s);
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);
 void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
                hipStream_t s);

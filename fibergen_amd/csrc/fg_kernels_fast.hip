@@ -6,6 +6,7 @@
 // relative per operation, asserted to 1e-12 on fields); the exact kernels remain available (u_loop = 1).
 #include "fg_kernels.h"
 
+#include "fg_fft_core.h"
 #include "fg_hip_util.h"
 #include "fg_kernels_common.h"
 
@@ -13,129 +14,149 @@ namespace fg {
 
 namespace {
 
+// Position of a thread's z pair for the displacement sweep.
+struct UPos {
+  int i, j, k;          // voxel (i, j, k) and (i, j, k+1)
+  long ro;              // element offset of row (i, j)
+  bool second;          // the pair holds two voxels (false only for the last pair of an odd nz)
+  bool prev_ok, next_ok;  // lanes -1 / +1 of the wave hold the adjacent pairs of the same row
+};
+
+// u_k -> strain of the two voxels of a pair (eout) and the divergence of their polarisation (fout).
 // The sweep holds, per (x,y) row it touches, the vector [z = k-1, k, k+1, k+2]: the pair (k, k+1) is one
 // 16-byte load; the outer two values are the neighbouring lanes' pair halves, fetched by a wave shift.
-// Only the first / last lane of a wave and the lanes at the ends of a z row load them from memory (edge
-// loads, grouped so that they are issued together).  All 64 lanes stay active up to the stores.
+// Only the lanes where prev_ok / next_ok is false load them from memory (edge loads, grouped so that
+// they are issued together).  Must be called by all 64 lanes of a wave.
 // ODD: nz is odd, the last pair of a row holds one voxel and z+1 wraps to 0.
 template <bool ODD>
-__global__ __launch_bounds__(kBlock) void k_u_fast(Grid g, double beta, double gamma, FieldPtrs<3> u, FieldPtrs<2> mod,
-                                                   FieldPtrs<3> fo, Vec6 E, double* partial, Sweep ry) {
-  __shared__ double smem[4 * 6];
+__device__ __forceinline__ void u_fast_pair(const Grid& g, double beta, double gamma, const FieldPtrs<3>& u,
+                                            const FieldPtrs<2>& mod, const Vec6& E, const UPos& p, double (&fout)[2][3],
+                                            double (&eout)[2][6]) {
   const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const bool second = p.second, prev_ok = p.prev_ok, next_ok = p.next_ok;
+  const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+  const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+  const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+  const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+  const long ro = p.ro;
+  const int k = p.k;
+  const int kb = k == 0 ? g.nz - 1 : k - 1;
+  const int kf2 = (k + 2 >= g.nz) ? k + 2 - g.nz : k + 2;
+  const double* const u0 = u.p[0];
+  const double* const u1 = u.p[1];
+  const double* const u2 = u.p[2];
+  const double* const mA = mod.p[0];
+  const double* const mB = mod.p[1];
+
+  // edge loads: z = k-1 of {U0c, U0xf, U1c, U1yf, U2c, Ac, Bc}, z = k+2 of {U0c, U1c, U2c, U2yb, U2xb, Ac, Bc}
+  double em[7] = {0, 0, 0, 0, 0, 0, 0}, ep[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (!prev_ok) {
+    const long o = ro + kb;
+    em[0] = u0[o]; em[1] = u0[o + xf]; em[2] = u1[o]; em[3] = u1[o + yf]; em[4] = u2[o]; em[5] = mA[o]; em[6] = mB[o];
+  }
+  if (!next_ok) {
+    const long o = ro + kf2;
+    ep[0] = u0[o]; ep[1] = u1[o]; ep[2] = u2[o]; ep[3] = u2[o + yb]; ep[4] = u2[o + xb]; ep[5] = mA[o]; ep[6] = mB[o];
+  }
+  const long rk = ro + k;
+#define FG_ROW(name, a, off)                         \
+  Row4 name;                                         \
+  {                                                  \
+    const double2 d_ = ld2(a, rk + (off));           \
+    name.v[1] = d_.x;                                \
+    name.v[2] = d_.y;                                \
+    if (ODD && !second) name.v[2] = (a)[ro + (off)]; \
+  }
+  FG_ROW(U0c, u0, 0) FG_ROW(U0xf, u0, xf) FG_ROW(U0yb, u0, yb) FG_ROW(U0xb, u0, xb) FG_ROW(U0xfyb, u0, xf + yb)
+  FG_ROW(U0yf, u0, yf)
+  FG_ROW(U1c, u1, 0) FG_ROW(U1yf, u1, yf) FG_ROW(U1xb, u1, xb) FG_ROW(U1xbyf, u1, xb + yf) FG_ROW(U1yb, u1, yb)
+  FG_ROW(U1xf, u1, xf)
+  FG_ROW(U2c, u2, 0) FG_ROW(U2yb, u2, yb) FG_ROW(U2xb, u2, xb) FG_ROW(U2xf, u2, xf) FG_ROW(U2yf, u2, yf)
+  // effective moduli rows: A = sum_p phi_p 2 mu_p, B = sum_p phi_p lambda_p (precomputed per voxel)
+  FG_ROW(Ac, mA, 0) FG_ROW(Bc, mB, 0) FG_ROW(Axb, mA, xb) FG_ROW(Bxb, mB, xb) FG_ROW(Axf, mA, xf)
+  FG_ROW(Ayb, mA, yb) FG_ROW(Byb, mB, yb) FG_ROW(Ayf, mA, yf)
+#undef FG_ROW
+#define FG_PREV(row, i) { const double t_ = dpp_move<0x138>(row.v[2]); row.v[0] = prev_ok ? t_ : em[i]; }
+#define FG_NEXT(row, i) { const double t_ = dpp_move<0x130>(row.v[1]); row.v[3] = next_ok ? t_ : ep[i]; }
+  FG_PREV(U0c, 0) FG_PREV(U0xf, 1) FG_PREV(U1c, 2) FG_PREV(U1yf, 3) FG_PREV(U2c, 4) FG_PREV(Ac, 5) FG_PREV(Bc, 6)
+  FG_NEXT(U0c, 0) FG_NEXT(U1c, 1) FG_NEXT(U2c, 2) FG_NEXT(U2yb, 3) FG_NEXT(U2xb, 4) FG_NEXT(Ac, 5) FG_NEXT(Bc, 6)
+#undef FG_PREV
+#undef FG_NEXT
+
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int i0 = s + 1;  // index of this voxel's own z position in the row vectors
+    // strain at the voxel  (F:18632-18686)
+    const double e0 = E.v[0] + (U0xf.v[i0] - U0c.v[i0]) * hx;
+    const double e1 = E.v[1] + (U1yf.v[i0] - U1c.v[i0]) * hy;
+    const double e2 = E.v[2] + (U2c.v[i0 + 1] - U2c.v[i0]) * hz;
+    const double e3 = E.v[3] + 0.5 * ((U2c.v[i0] - U2yb.v[i0]) * hy + (U1c.v[i0] - U1c.v[i0 - 1]) * hz);
+    const double e4 = E.v[4] + 0.5 * ((U2c.v[i0] - U2xb.v[i0]) * hx + (U0c.v[i0] - U0c.v[i0 - 1]) * hz);
+    const double e5 = E.v[5] + 0.5 * ((U1c.v[i0] - U1xb.v[i0]) * hx + (U0c.v[i0] - U0yb.v[i0]) * hy);
+    eout[s][0] = e0; eout[s][1] = e1; eout[s][2] = e2; eout[s][3] = e3; eout[s][4] = e4; eout[s][5] = e5;
+    // strains of the six neighbours, only the components their tau needs
+    const double e0xb = E.v[0] + (U0c.v[i0] - U0xb.v[i0]) * hx;
+    const double e1xb = E.v[1] + (U1xbyf.v[i0] - U1xb.v[i0]) * hy;
+    const double e2xb = E.v[2] + (U2xb.v[i0 + 1] - U2xb.v[i0]) * hz;
+    const double e0yb = E.v[0] + (U0xfyb.v[i0] - U0yb.v[i0]) * hx;
+    const double e1yb = E.v[1] + (U1c.v[i0] - U1yb.v[i0]) * hy;
+    const double e2yb = E.v[2] + (U2yb.v[i0 + 1] - U2yb.v[i0]) * hz;
+    const double e0zb = E.v[0] + (U0xf.v[i0 - 1] - U0c.v[i0 - 1]) * hx;
+    const double e1zb = E.v[1] + (U1yf.v[i0 - 1] - U1c.v[i0 - 1]) * hy;
+    const double e2zb = E.v[2] + (U2c.v[i0] - U2c.v[i0 - 1]) * hz;
+    const double e5xf = E.v[5] + 0.5 * ((U1xf.v[i0] - U1c.v[i0]) * hx + (U0xf.v[i0] - U0xfyb.v[i0]) * hy);
+    const double e4xf = E.v[4] + 0.5 * ((U2xf.v[i0] - U2c.v[i0]) * hx + (U0xf.v[i0] - U0xf.v[i0 - 1]) * hz);
+    const double e5yf = E.v[5] + 0.5 * ((U1yf.v[i0] - U1xbyf.v[i0]) * hx + (U0yf.v[i0] - U0c.v[i0]) * hy);
+    const double e3yf = E.v[3] + 0.5 * ((U2yf.v[i0] - U2c.v[i0]) * hy + (U1yf.v[i0] - U1yf.v[i0 - 1]) * hz);
+    const double e4zf = E.v[4] + 0.5 * ((U2c.v[i0 + 1] - U2xb.v[i0 + 1]) * hx + (U0c.v[i0 + 1] - U0c.v[i0]) * hz);
+    const double e3zf = E.v[3] + 0.5 * ((U2c.v[i0 + 1] - U2yb.v[i0 + 1]) * hy + (U1c.v[i0 + 1] - U1c.v[i0]) * hz);
+    // tau = (A + beta) eps + (B + gamma) tr(eps) I with the per-voxel effective moduli
+    const double ac = Ac.v[i0] + beta, bc = Bc.v[i0] + gamma;
+    const double trc = e0 + e1 + e2;
+    const double t0 = e0 * ac + bc * trc, t1 = e1 * ac + bc * trc, t2 = e2 * ac + bc * trc;
+    const double t3 = e3 * ac, t4 = e4 * ac, t5 = e5 * ac;
+    const double t0xb = e0xb * (Axb.v[i0] + beta) + (Bxb.v[i0] + gamma) * (e0xb + e1xb + e2xb);
+    const double t1yb = e1yb * (Ayb.v[i0] + beta) + (Byb.v[i0] + gamma) * (e0yb + e1yb + e2yb);
+    const double t2zb = e2zb * (Ac.v[i0 - 1] + beta) + (Bc.v[i0 - 1] + gamma) * (e0zb + e1zb + e2zb);
+    const double axf = Axf.v[i0] + beta, ayf = Ayf.v[i0] + beta, azf = Ac.v[i0 + 1] + beta;
+    const double t5xf = e5xf * axf, t4xf = e4xf * axf;
+    const double t5yf = e5yf * ayf, t3yf = e3yf * ayf;
+    const double t4zf = e4zf * azf, t3zf = e3zf * azf;
+    fout[s][0] = (t0 - t0xb) * hx + (t5yf - t5) * hy + (t4zf - t4) * hz;
+    fout[s][1] = (t5xf - t5) * hx + (t1 - t1yb) * hy + (t3zf - t3) * hz;
+    fout[s][2] = (t4xf - t4) * hx + (t3yf - t3) * hy + (t2 - t2zb) * hz;
+  }
+}
+
+template <bool ODD>
+__global__ __launch_bounds__(kBlock) void k_u_fast(Grid g, double beta, double gamma, FieldPtrs<3> u, FieldPtrs<2> mod,
+                                                   FieldPtrs<3> fo, Vec6 E, double* partial, Sweep sw) {
+  __shared__ double smem[4 * 6];
   const long npairs = (long)g.nx * g.ny * g.nzc;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
   for (long it = 0; it < run.count; ++it) {
     const long pidx_raw = (run.first + it * run.stride) * kBlock + threadIdx.x;
     const long pidx = pidx_raw < npairs ? pidx_raw : npairs - 1;  // clamped lanes discard their result
-    const PairPos p = pair_pos_tiled(pidx, g, ry);
-    const bool valid = pidx_raw < npairs && p.k < g.nz;
-    const bool second = !ODD || p.k + 1 < g.nz;
+    const PairPos pp = pair_pos_tiled(pidx, g, sw);
+    const bool valid = pidx_raw < npairs && pp.k < g.nz;
     const int lane = threadIdx.x & 63;
-    const bool prev_ok = lane > 0 && p.k > 0;
-    const bool next_ok = lane < 63 && p.k + 2 < g.nz && pidx_raw + 1 < npairs;
-    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
-    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
-    const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
-    const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
-    const long ro = p.off - p.k;
-    const int k = p.k;
-    const int kb = k == 0 ? g.nz - 1 : k - 1;
-    const int kf2 = (k + 2 >= g.nz) ? k + 2 - g.nz : k + 2;
-    const double* const u0 = u.p[0];
-    const double* const u1 = u.p[1];
-    const double* const u2 = u.p[2];
-    const double* const mA = mod.p[0];
-    const double* const mB = mod.p[1];
-
-    // edge loads: z = k-1 of {U0c, U0xf, U1c, U1yf, U2c, Ac, Bc}, z = k+2 of {U0c, U1c, U2c, U2yb, U2xb, Ac, Bc}
-    double em[7] = {0, 0, 0, 0, 0, 0, 0}, ep[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (!prev_ok) {
-      const long o = ro + kb;
-      em[0] = u0[o]; em[1] = u0[o + xf]; em[2] = u1[o]; em[3] = u1[o + yf]; em[4] = u2[o]; em[5] = mA[o]; em[6] = mB[o];
-    }
-    if (!next_ok) {
-      const long o = ro + kf2;
-      ep[0] = u0[o]; ep[1] = u1[o]; ep[2] = u2[o]; ep[3] = u2[o + yb]; ep[4] = u2[o + xb]; ep[5] = mA[o]; ep[6] = mB[o];
-    }
-    const long rk = ro + k;
-#define FG_ROW(name, a, off)                      \
-    Row4 name;                                      \
-    {                                               \
-      const double2 d_ = ld2(a, rk + (off));        \
-      name.v[1] = d_.x;                             \
-      name.v[2] = d_.y;                             \
-      if (ODD && !second) name.v[2] = (a)[ro + (off)]; \
-    }
-    FG_ROW(U0c, u0, 0) FG_ROW(U0xf, u0, xf) FG_ROW(U0yb, u0, yb) FG_ROW(U0xb, u0, xb) FG_ROW(U0xfyb, u0, xf + yb)
-    FG_ROW(U0yf, u0, yf)
-    FG_ROW(U1c, u1, 0) FG_ROW(U1yf, u1, yf) FG_ROW(U1xb, u1, xb) FG_ROW(U1xbyf, u1, xb + yf) FG_ROW(U1yb, u1, yb)
-    FG_ROW(U1xf, u1, xf)
-    FG_ROW(U2c, u2, 0) FG_ROW(U2yb, u2, yb) FG_ROW(U2xb, u2, xb) FG_ROW(U2xf, u2, xf) FG_ROW(U2yf, u2, yf)
-    // effective moduli rows: A = sum_p phi_p 2 mu_p, B = sum_p phi_p lambda_p (precomputed per voxel)
-    FG_ROW(Ac, mA, 0) FG_ROW(Bc, mB, 0) FG_ROW(Axb, mA, xb) FG_ROW(Bxb, mB, xb) FG_ROW(Axf, mA, xf)
-    FG_ROW(Ayb, mA, yb) FG_ROW(Byb, mB, yb) FG_ROW(Ayf, mA, yf)
-#undef FG_ROW
-#define FG_PREV(row, i) { const double t_ = dpp_move<0x138>(row.v[2]); row.v[0] = prev_ok ? t_ : em[i]; }
-#define FG_NEXT(row, i) { const double t_ = dpp_move<0x130>(row.v[1]); row.v[3] = next_ok ? t_ : ep[i]; }
-    FG_PREV(U0c, 0) FG_PREV(U0xf, 1) FG_PREV(U1c, 2) FG_PREV(U1yf, 3) FG_PREV(U2c, 4) FG_PREV(Ac, 5) FG_PREV(Bc, 6)
-    FG_NEXT(U0c, 0) FG_NEXT(U1c, 1) FG_NEXT(U2c, 2) FG_NEXT(U2yb, 3) FG_NEXT(U2xb, 4) FG_NEXT(Ac, 5) FG_NEXT(Bc, 6)
-#undef FG_PREV
-#undef FG_NEXT
-
+    UPos p;
+    p.i = pp.i; p.j = pp.j; p.k = pp.k;
+    p.ro = pp.off - pp.k;
+    p.second = !ODD || pp.k + 1 < g.nz;
+    p.prev_ok = lane > 0 && pp.k > 0;
+    p.next_ok = lane < 63 && pp.k + 2 < g.nz && pidx_raw + 1 < npairs;
     double fout[2][3], eout[2][6];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int i0 = s + 1;  // index of this voxel's own z position in the row vectors
-      // strain at the voxel  (F:18632-18686)
-      const double e0 = E.v[0] + (U0xf.v[i0] - U0c.v[i0]) * hx;
-      const double e1 = E.v[1] + (U1yf.v[i0] - U1c.v[i0]) * hy;
-      const double e2 = E.v[2] + (U2c.v[i0 + 1] - U2c.v[i0]) * hz;
-      const double e3 = E.v[3] + 0.5 * ((U2c.v[i0] - U2yb.v[i0]) * hy + (U1c.v[i0] - U1c.v[i0 - 1]) * hz);
-      const double e4 = E.v[4] + 0.5 * ((U2c.v[i0] - U2xb.v[i0]) * hx + (U0c.v[i0] - U0c.v[i0 - 1]) * hz);
-      const double e5 = E.v[5] + 0.5 * ((U1c.v[i0] - U1xb.v[i0]) * hx + (U0c.v[i0] - U0yb.v[i0]) * hy);
-      eout[s][0] = e0; eout[s][1] = e1; eout[s][2] = e2; eout[s][3] = e3; eout[s][4] = e4; eout[s][5] = e5;
-      // strains of the six neighbours, only the components their tau needs
-      const double e0xb = E.v[0] + (U0c.v[i0] - U0xb.v[i0]) * hx;
-      const double e1xb = E.v[1] + (U1xbyf.v[i0] - U1xb.v[i0]) * hy;
-      const double e2xb = E.v[2] + (U2xb.v[i0 + 1] - U2xb.v[i0]) * hz;
-      const double e0yb = E.v[0] + (U0xfyb.v[i0] - U0yb.v[i0]) * hx;
-      const double e1yb = E.v[1] + (U1c.v[i0] - U1yb.v[i0]) * hy;
-      const double e2yb = E.v[2] + (U2yb.v[i0 + 1] - U2yb.v[i0]) * hz;
-      const double e0zb = E.v[0] + (U0xf.v[i0 - 1] - U0c.v[i0 - 1]) * hx;
-      const double e1zb = E.v[1] + (U1yf.v[i0 - 1] - U1c.v[i0 - 1]) * hy;
-      const double e2zb = E.v[2] + (U2c.v[i0] - U2c.v[i0 - 1]) * hz;
-      const double e5xf = E.v[5] + 0.5 * ((U1xf.v[i0] - U1c.v[i0]) * hx + (U0xf.v[i0] - U0xfyb.v[i0]) * hy);
-      const double e4xf = E.v[4] + 0.5 * ((U2xf.v[i0] - U2c.v[i0]) * hx + (U0xf.v[i0] - U0xf.v[i0 - 1]) * hz);
-      const double e5yf = E.v[5] + 0.5 * ((U1yf.v[i0] - U1xbyf.v[i0]) * hx + (U0yf.v[i0] - U0c.v[i0]) * hy);
-      const double e3yf = E.v[3] + 0.5 * ((U2yf.v[i0] - U2c.v[i0]) * hy + (U1yf.v[i0] - U1yf.v[i0 - 1]) * hz);
-      const double e4zf = E.v[4] + 0.5 * ((U2c.v[i0 + 1] - U2xb.v[i0 + 1]) * hx + (U0c.v[i0 + 1] - U0c.v[i0]) * hz);
-      const double e3zf = E.v[3] + 0.5 * ((U2c.v[i0 + 1] - U2yb.v[i0 + 1]) * hy + (U1c.v[i0 + 1] - U1c.v[i0]) * hz);
-      // tau = (A + beta) eps + (B + gamma) tr(eps) I with the per-voxel effective moduli
-      const double ac = Ac.v[i0] + beta, bc = Bc.v[i0] + gamma;
-      const double trc = e0 + e1 + e2;
-      const double t0 = e0 * ac + bc * trc, t1 = e1 * ac + bc * trc, t2 = e2 * ac + bc * trc;
-      const double t3 = e3 * ac, t4 = e4 * ac, t5 = e5 * ac;
-      const double t0xb = e0xb * (Axb.v[i0] + beta) + (Bxb.v[i0] + gamma) * (e0xb + e1xb + e2xb);
-      const double t1yb = e1yb * (Ayb.v[i0] + beta) + (Byb.v[i0] + gamma) * (e0yb + e1yb + e2yb);
-      const double t2zb = e2zb * (Ac.v[i0 - 1] + beta) + (Bc.v[i0 - 1] + gamma) * (e0zb + e1zb + e2zb);
-      const double axf = Axf.v[i0] + beta, ayf = Ayf.v[i0] + beta, azf = Ac.v[i0 + 1] + beta;
-      const double t5xf = e5xf * axf, t4xf = e4xf * axf;
-      const double t5yf = e5yf * ayf, t3yf = e3yf * ayf;
-      const double t4zf = e4zf * azf, t3zf = e3zf * azf;
-      fout[s][0] = (t0 - t0xb) * hx + (t5yf - t5) * hy + (t4zf - t4) * hz;
-      fout[s][1] = (t5xf - t5) * hx + (t1 - t1yb) * hy + (t3zf - t3) * hz;
-      fout[s][2] = (t4xf - t4) * hx + (t3yf - t3) * hy + (t2 - t2zb) * hz;
-    }
+    u_fast_pair<ODD>(g, beta, gamma, u, mod, E, p, fout, eout);
     if (valid) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        const double ey = second ? eout[1][c] : 0.0;
+        const double ey = p.second ? eout[1][c] : 0.0;
         acc[c] += eout[0][c] * eout[0][c] + ey * ey;
       }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) st2(fo.p[c], p.off, make_double2(fout[0][c], second ? fout[1][c] : 0.0));
+      for (int c = 0; c < 3; ++c) st2(fo.p[c], pp.off, make_double2(fout[0][c], p.second ? fout[1][c] : 0.0));
     }
   }
   block_reduce<6>(acc, smem, OpSum());
@@ -145,6 +166,117 @@ __global__ __launch_bounds__(kBlock) void k_u_fast(Grid g, double beta, double g
   }
 }
 
+// The same sweep with the z transform of the divergence attached: a workgroup owns whole z rows (M = nz/2
+// pairs each), so the packed-real r2c of those rows (F:7232, see fg_fft_kernels.h R2CKernel) runs on the
+// freshly computed f in LDS and the half spectrum is what goes to memory -- f itself is never stored, which
+// removes the r2c pass (one read + one write of the three components per iteration).
+// LDS: two images of 3*LINES lines (re / im planes, padded as in fg_fft_core.h) used in turn by the stages:
+//   stencil -> image 0 | pass 0: image 0 -> 1 | pass 1: 1 -> 0 | ... | split: image NP%2 -> global
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_u_fast_z(Grid g, double beta, double gamma, FieldPtrs<3> u, FieldPtrs<2> mod,
+                                                     FieldPtrs<3> fo, Vec6 E, double* partial, Sweep sw, const cplx* tw,
+                                                     const cplx* wz) {
+  using namespace fft;
+  constexpr int LINES = kBlock / M;  // z rows per workgroup
+  constexpr int T = M / 8;           // FFT threads per line
+  constexpr int NL = 3 * LINES;      // FFT lines per workgroup (3 components)
+  constexpr int LS = M + M / 8 + 2;  // line stride in doubles
+  constexpr int IMG = 2 * LS * NL;   // doubles per LDS image
+  constexpr int NP = num_passes(M);
+  __shared__ double lds[2 * IMG];
+  __shared__ double smem[4 * 6];
+  __shared__ long rowoff[LINES];
+  const LdsMap L = {1, LS, LS * NL};
+  const long nrows = (long)g.nx * g.ny;
+  const BlockRun run = block_run((nrows + LINES - 1) / LINES);
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  if (run.count > 0) {  // uniform per workgroup
+    const int l = threadIdx.x / M, m = threadIdx.x % M;
+    const long t_raw = run.first * LINES + l;
+    const bool valid = t_raw < nrows;
+    // row ordinal in the L2-aware order [y chunk][x][row in chunk] -> (i, j)
+    unsigned t = (unsigned)(valid ? t_raw : nrows - 1);
+    const int jr = (int)(t & (unsigned)(sw.ry - 1));
+    t >>= sw.ry_shift;
+    const unsigned jc = fast_div(t, sw.by_nx);
+    const int lane = threadIdx.x & 63;
+    UPos p;
+    p.i = (int)(t - jc * (unsigned)g.nx);
+    p.j = (int)jc * sw.ry + jr;
+    p.k = 2 * m;
+    p.ro = ((long)p.i * g.ny + p.j) * g.nzp;
+    p.second = true;
+    p.prev_ok = lane > 0 && m > 0;
+    p.next_ok = lane < 63 && m + 1 < M;
+    if (m == 0) rowoff[l] = valid ? p.ro : -1;
+    double fout[2][3], eout[2][6];
+    u_fast_pair<false>(g, beta, gamma, u, mod, E, p, fout, eout);
+    if (valid) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] = eout[0][c] * eout[0][c] + eout[1][c] * eout[1][c];
+    }
+    // packed line point m of component c: z_m = f[2m] + i f[2m+1]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lds_put(lds, L, m, c * LINES + l, cmake(fout[0][c], fout[1][c]));
+    __syncthreads();
+
+    const bool fft_thread = threadIdx.x < NL * T;
+    const int line = threadIdx.x / T, jt = threadIdx.x % T;  // line = comp * LINES + row in workgroup
+    cplx v[8];
+    if (fft_thread) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = lds_get(lds, L, Line<M>::first_index(jt, q), line);
+      Pass<M, 0>::template compute<-1>(v, jt, tw + tw_offset(M, 0));
+      Pass<M, 0>::to_lds(v, jt, lds + IMG, L, line);
+    }
+    __syncthreads();
+    if (fft_thread) {
+      Pass<M, 1>::from_lds(v, jt, lds + IMG, L, line);
+      Pass<M, 1>::template compute<-1>(v, jt, tw + tw_offset(M, 1));
+      if (NP > 2) {
+        Pass<M, 1>::to_lds(v, jt, lds, L, line);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lds_put(lds, L, Line<M>::last_index(jt, q), line, v[q]);
+      }
+    }
+    __syncthreads();
+    if (NP > 2) {
+      if (fft_thread) {
+        Pass<M, (NP > 2 ? 2 : 1)>::from_lds(v, jt, lds, L, line);
+        Pass<M, (NP > 2 ? 2 : 1)>::template compute<-1>(v, jt, tw + tw_offset(M, (NP > 2 ? 2 : 1)));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lds_put(lds + IMG, L, Line<M>::last_index(jt, q), line, v[q]);
+      }
+      __syncthreads();
+    }
+    // natural-order spectrum of the packed line -> half spectrum of the real line (r2c_split)
+    const double* spec = lds + (NP % 2) * IMG;
+    if (fft_thread) {
+      const int comp = line / LINES;
+      const long off = rowoff[line % LINES];
+      if (off >= 0) {
+        cplx* out = reinterpret_cast<cplx*>(fo.p[comp] + off);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kk = jt + q * T;
+          const cplx zk = lds_get(spec, L, kk, line);
+          const cplx zm = lds_get(spec, L, (M - kk) % M, line);
+          out[kk] = r2c_split(zk, zm, wz[kk]);
+        }
+        if (jt == 0) {  // k = M (Nyquist): Z[M] := Z[0]
+          const cplx z0 = lds_get(spec, L, 0, line);
+          out[M] = r2c_split(z0, z0, wz[M]);
+        }
+      }
+    }
+  }
+  block_reduce<6>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+  }
+}
 
 // A = sum_p phi_p 2 mu_p, B = sum_p phi_p lambda_p with the Voigt rule's threshold (F:12736)
 __global__ __launch_bounds__(kBlock) void k_effective_moduli(long n2, PhaseTable pt, FieldPtrs<kMaxPhases> phi,
@@ -182,6 +314,34 @@ void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
   else
     hipLaunchKernelGGL(k_u_fast<false>, dim3(nb), dim3(kBlock), 0, s, g, -2 * mu_0, -lambda_0, u, mod, f, E, partial,
                        chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 6, sumsq6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+bool u_fast_z_supported(const Grid& g) {
+  const int M = g.nz / 2;
+  return g.nz % 2 == 0 && (M == 32 || M == 64 || M == 128 || M == 256) && g.nzc >= M + 1;
+}
+
+void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
+                     const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, const cplx* tw_z,
+                     const cplx* w_z, hipStream_t s) {
+  const int M = g.nz / 2;
+  const long nrows = (long)g.nx * g.ny;
+  const int lines = kBlock / M;
+  long nbl = (nrows + lines - 1) / lines;
+  if (nbl >= 8) nbl = ((nbl + 7) / 8) * 8;
+  const int nb = (int)nbl;
+  const Sweep sw = chunk_rows(g);
+  const double beta = -2 * mu_0, gamma = -lambda_0;
+  switch (M) {
+    case 32: hipLaunchKernelGGL(k_u_fast_z<32>, dim3(nb), dim3(kBlock), 0, s, g, beta, gamma, u, mod, fhat, E, partial, sw, tw_z, w_z); break;
+    case 64: hipLaunchKernelGGL(k_u_fast_z<64>, dim3(nb), dim3(kBlock), 0, s, g, beta, gamma, u, mod, fhat, E, partial, sw, tw_z, w_z); break;
+    case 128: hipLaunchKernelGGL(k_u_fast_z<128>, dim3(nb), dim3(kBlock), 0, s, g, beta, gamma, u, mod, fhat, E, partial, sw, tw_z, w_z); break;
+    case 256: hipLaunchKernelGGL(k_u_fast_z<256>, dim3(nb), dim3(kBlock), 0, s, g, beta, gamma, u, mod, fhat, E, partial, sw, tw_z, w_z); break;
+    default: throw std::runtime_error("launch_u_fast_z: unsupported nz");
+  }
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());

@@ -360,16 +360,18 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
   for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
 }
 
-void Solver::fft_g0_chain(double* buf) {
+void Solver::fft_g0_chain(double* buf, bool z_done) {
   const double alpha = -1.0;  // GammaOperator(..., -1)  F:20575
   bool fuse_x = false;
   {
     // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
     const double scale = 1 / (double)nglobal_;
     const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
-    time_begin(2);
-    fft_->r2c_z(buf, 3, g_.n);
-    time_end(2);
+    if (!z_done) {  // the displacement sweep may already have written the z spectrum
+      time_begin(2);
+      fft_->r2c_z(buf, 3, g_.n);
+      time_end(2);
+    }
     time_begin(3);
     fft_->c2c_y(buf, 3, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
     time_end(3);
@@ -448,8 +450,15 @@ void Solver::u_pass_front(const double* E6) {
       launch_effective_moduli(g_, pt_, phi, mod, stream_);
       mod_dirty_ = false;
     }
-    launch_u_fast(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, stream_);
+    const bool want_z = opt_.fuse_z > 0 || (opt_.fuse_z < 0 && (long)g_.nx * g_.ny * g_.nz <= (1L << 22));
+    z_done_ = want_z && fft_->fast_z() && u_fast_z_supported(g_);
+    if (z_done_)
+      launch_u_fast_z(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
+                      fft_->z_twiddles(), fft_->z_roots(), stream_);
+    else
+      launch_u_fast(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, stream_);
   } else {
+    z_done_ = false;
     launch_u_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, ptrs3(fu_alt_), E,
                               partial_, dscal_ + kSlotSumSq, stream_);
   }
@@ -458,7 +467,7 @@ void Solver::u_pass_front(const double* E6) {
 }
 
 void Solver::u_pass_back() {
-  fft_g0_chain(fu_alt_);
+  fft_g0_chain(fu_alt_, z_done_);
   double* t = fu_;
   fu_ = fu_alt_;
   fu_alt_ = t;

@@ -87,7 +87,7 @@ class LSSolver:
                 if v not in ("basic", "cg"):
                     raise RuntimeError("Unknown solver method '%s'" % v)
                 self._check(self._lib.fg_set_option_i(self._h, b"method", 1 if v == "cg" else 0))
-            elif k in ("u_loop", "fuse_x", "fuse_stress_div"):
+            elif k in ("u_loop", "fuse_x", "fuse_z", "fuse_stress_div"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
             elif k in ("maxiter",):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))

@@ -73,7 +73,7 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * Keys (integer): maxiter, mixing_rule (FG_MIXING_*), update_ref (0 = "never"),
  * method (0 = basic scheme, runBasic F:21716-21805; 1 = conjugate gradients, runCGElasticity
  * F:23153-23247, the reference's default), and the implementation switches u_loop,
- * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline). */
+ * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), fuse_z (1, 0, -1 = by size). */
 int fg_set_option_d(fg_solver* s, const char* key, double value);
 int fg_set_option_i(fg_solver* s, const char* key, long value);
 
