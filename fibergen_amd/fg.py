@@ -24,7 +24,6 @@ import gzip
 import logging
 import math
 import os
-import warnings
 
 import numpy as np
 
@@ -461,6 +460,19 @@ class FG:
         ix, iy, iz = rng(range_x, data.shape[1]), rng(range_y, data.shape[2]), rng(range_z, data.shape[3])
         return np.ascontiguousarray(data[np.ix_(ic, ix, iy, iz)])
 
+    def write_vtk(self, filename):
+        """LSSolver::writeVTK  F:23317-23451: phase fractions, strain, stress and displacement of the current
+        state as a legacy VTK file (format from <res_format>, value type from <restype>, F:25300, F:26552)."""
+        from . import vtk
+        self.init_lss()
+        self.init_phase()
+        st = self._settings()
+        lss = self._lss
+        vtk.write_results(filename, lss.shape, self._dims, self._x0, self._phase_names, lss.get_field("phi"),
+                          lss.get_field("epsilon"), lss.get_field("sigma"), lss.get_field("u"),
+                          binary=self._child_value(st, "res_format", "binary", str) == "binary",
+                          dtype=self._child_value(st, "restype", "float", str))
+
     # ------------------------------------------------------------------ running
     def _on_iteration(self):
         if self._error is not None:
@@ -606,11 +618,30 @@ class FG:
                 return EXIT_FAILURE
             outfile = self._attr(act, "outfile", "", str)
             if outfile:
-                warnings.warn("VTK output is not available yet (outfile='%s' ignored)" % outfile)
+                self.write_vtk(outfile)
+            return None
+        if name in ("write_lss_vtk", "write_vtk2"):
+            # FG::run_actions  F:25374-25380 (filename=) and F:25427-25436 (outfile=)
+            fn = self._attr(act, "filename" if name == "write_lss_vtk" else "outfile", None, str)
+            if not fn:
+                raise RuntimeError("%s needs a file name" % name)
+            self.write_vtk(fn)
+            return None
+        if name == "write_vtk_phase":
+            self.init_lss()
+            self.init_phase()
+            from . import vtk
+            m = self._material_id(self._attr(act, "name", "", str))
+            st = self._settings()
+            vtk.write_phase(self._attr(act, "outfile", None, str), self._lss.shape, self._dims, self._x0,
+                            self._phase_names[m], self._lss.get_field("phi")[m],
+                            binary=self._child_value(st, "res_format", "binary", str) == "binary",
+                            dtype=self._child_value(st, "restype", "float", str))
             return None
         if name == "calc_effective_properties":
             self.init_lss()
             self.init_phase()
+            outdir = self._attr(act, "outdir", "", str)
             S = np.zeros((6, 6))
             for i in range(6):
                 Ep = np.zeros(6)
@@ -621,6 +652,8 @@ class FG:
                     self._error = self._error or "NaN detected in solution. Aborting."
                     return EXIT_FAILURE
                 S[:, i] = self._lss.mean_stress()
+                if outdir:
+                    self.write_vtk("%s/results_%d.vtk" % (outdir, i + 1))  # F:26056-26062
             Ceff = S @ np.linalg.inv(np.eye(6))  # Ceff = S E^-1 with unit experiments  F:26072-26075
             Cv = Ceff.copy()
             Cv[:, 3:6] *= 0.5                     # F:26083-26088
