@@ -37,6 +37,13 @@ struct G0Layout {
   int nyl, jj0;
 };
 
+// Scalar modes (heat / porous): conductivities of the phases, calcStress factors (beta = -alpha 2 mu0)
+struct ScalarParams {
+  int n;
+  double mu[kMaxPhases];
+  double alpha, beta;
+};
+
 constexpr int kMaxReduceBlocks = 4096;  // partial-sum rows of the two-stage reductions
 
 int reduce_blocks(const Grid& g);
@@ -77,6 +84,19 @@ void launch_cg(int mode, const Grid& g, const FieldPtrs<6>& x, const FieldPtrs<6
 void launch_set_const6(const Grid& g, const FieldPtrs<6>& x, const Vec6& E, hipStream_t s);
 void launch_sum6(const Grid& g, const FieldPtrs<6>& x, bool square, double* partial, double* out6, hipStream_t s);
 void launch_sum1(const Grid& g, const double* x, double* partial, double* out1, hipStream_t s);
+// scalar modes (fg_kernels_scalar.hip)
+void launch_sc_sweep(const Grid& g, const ScalarParams& sp, const double* T, const FieldPtrs<kMaxPhases>& phi, double* f,
+                     const Vec6& E, double* partial, double* sumsq6, hipStream_t s);
+void launch_sc_grad(const Grid& g, const double* T, const FieldPtrs<3>& out, const Vec6& E, double* partial,
+                    double* sumsq6, hipStream_t s);
+void launch_sc_flux(const Grid& g, const ScalarParams& sp, const FieldPtrs<3>& gr, const FieldPtrs<kMaxPhases>& phi,
+                    const FieldPtrs<3>& out, hipStream_t s);
+void launch_sc_flux_mean(const Grid& g, const ScalarParams& sp, const FieldPtrs<3>& gr, const FieldPtrs<kMaxPhases>& phi,
+                         double* partial, double* out6, hipStream_t s);
+void launch_sc_div(const Grid& g, const FieldPtrs<3>& x, double scale, double* y, hipStream_t s);
+void launch_g0_heat(const Grid& g, double* fh, const G0Tables& tb, double c10, hipStream_t s);
+void launch_sc_minmax(const Grid& g, const ScalarParams& sp, const FieldPtrs<kMaxPhases>& phi, double* partial,
+                      double* out2, hipStream_t s);
 void launch_tangent_minmax(const Grid& g, const PhaseTable& pt, int mixing, const FieldPtrs<kMaxPhases>& phi,
                            double* partial, double* out2, int* error_flag, hipStream_t s);
 

@@ -360,8 +360,40 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
   for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
 }
 
-void Solver::fft_g0_chain(double* buf, bool z_done) {
-  const double alpha = -1.0;  // GammaOperator(..., -1)  F:20575
+void Solver::fft_g0_chain(double* buf, bool z_done, double alpha) {  // alpha = -1: GammaOperator(..., -1)  F:20575
+  if (opt_.mode == 1) {
+    // G0OperatorStaggeredHeat  F:20118-20135 on one component: fftVector(., 1), c1 = c10/|k|^2, fftInvVector
+    const double scale = 1 / (double)nglobal_;
+    const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
+    time_begin(2);
+    fft_->r2c_z(buf, 1, g_.n);
+    time_end(2);
+    time_begin(3);
+    fft_->c2c_y(buf, 1, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
+    time_end(3);
+    time_begin(4);
+    fft_->c2c_x(buf, 1, g_.n, -1, has_x ? scale : 1.0);
+    time_end(4);
+    if (!has_x && !has_y) fft_->scale(buf, 1, g_.n, scale);
+    G0Tables tb;
+    for (int a = 0; a < 3; ++a) {
+      tb.kpm[a] = g0_kpm_[a];
+      tb.kp[a] = g0_kp_[a];
+    }
+    time_begin(5);
+    launch_g0_heat(g_, buf, tb, -alpha / (2 * opt_.mu_0), stream_);  // G0OperatorFourierStaggeredHeat  F:19759-19764
+    time_end(5);
+    time_begin(6);
+    fft_->c2c_x(buf, 1, g_.n, +1, 1.0);
+    time_end(6);
+    time_begin(7);
+    fft_->c2c_y(buf, 1, g_.n, +1, 1.0);
+    time_end(7);
+    time_begin(8);
+    fft_->c2r_z(buf, 1, g_.n);
+    time_end(8);
+    return;
+  }
   bool fuse_x = false;
   {
     // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
@@ -421,7 +453,30 @@ void Solver::fft_g0_chain(double* buf, bool z_done) {
 // u (3 components) instead of eps (6): one sweep turns u_k into the sums of squares of eps_k (the
 // error estimator of pass k) and f_{k+1} = div (C - C0):eps_k, then the transform chain gives u_{k+1}.
 // Same values as strain operator + polarisation + divergence (bit for bit), 2 kernels fewer per pass.
+ScalarParams Solver::scalar_params(double mu_0, double alpha) const {
+  ScalarParams sp;
+  sp.n = pt_.n;
+  for (int q = 0; q < kMaxPhases; ++q) sp.mu[q] = q < pt_.n ? pt_.mu[q] : 0.0;
+  sp.alpha = alpha;
+  sp.beta = -alpha * 2 * mu_0;  // calcStress  F:18138
+  return sp;
+}
+
+FieldPtrs<kMaxPhases> Solver::phase_ptrs() const {
+  FieldPtrs<kMaxPhases> phi;
+  for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+  return phi;
+}
+
 bool Solver::u_loop_eligible() const {
+  if (opt_.mode == 1) {
+    // the scalar modes only have the potential-based loop
+    if (nranks_ != 1) throw std::runtime_error("heat / porous mode is not available on slab-decomposed solvers");
+    if (opt_.mixing != kMixVoigt) throw std::runtime_error("heat / porous mode supports Voigt mixing only");
+    if (opt_.bc_relax != 1.0 || frobenius(BC_MQ_) >= kEps)
+      throw std::runtime_error("heat / porous mode supports prescribed mean gradients only (projector = identity)");
+    return pt_.n >= 1;
+  }
   return opt_.u_loop && nranks_ == 1 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
          frobenius(BC_MQ_) < kEps;
 }
@@ -437,7 +492,10 @@ void Solver::u_pass_front(const double* E6) {
     E_next_[c] = E6[c];
   }
   time_begin(0);
-  if (opt_.u_loop >= 2) {
+  if (opt_.mode == 1) {
+    z_done_ = false;
+    launch_sc_sweep(g_, scalar_params(opt_.mu_0, 1.0), fu_, phase_ptrs(), fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
+  } else if (opt_.u_loop >= 2) {
     // fast variant: per-voxel effective moduli instead of the per-phase accumulation
     if (!mod_) {
       FG_HIP_CHECK(hipMalloc(&mod_, 2 * (size_t)g_.n * sizeof(double)));
@@ -481,6 +539,11 @@ void Solver::ensure_eps() {
   if (!eps_stale_ || !u_valid_) return;
   Vec6 E, R;
   for (int c = 0; c < 6; ++c) E.v[c] = E_cur_[c], R.v[c] = 0.0;
+  if (opt_.mode == 1) {
+    launch_sc_grad(g_, fu_, ptrs3(eps_), E, partial_, dscal_ + kSlotScratch, stream_);
+    eps_stale_ = false;
+    return;
+  }
   launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), E, R, false, partial_, dscal_ + kSlotScratch,
                   XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
   eps_stale_ = false;
@@ -490,6 +553,13 @@ void Solver::iterate(const double* E6, int n) {
   FG_HIP_CHECK(hipSetDevice(device_));
   int i = 0;
   if (u_loop_eligible()) {
+    if (!u_valid_ && n > 0 && opt_.mode == 1) {
+      // no potential yet: the zero gradient field is E = 0, T = 0
+      FG_HIP_CHECK(hipMemsetAsync(fu_, 0, g_.n * sizeof(double), stream_));
+      for (int c = 0; c < 6; ++c) E_cur_[c] = 0.0;
+      u_valid_ = true;
+      eps_stale_ = true;
+    }
     if (!u_valid_ && n > 0) {
       ensure_eps();
       basic_scheme(E6);  // leaves u in fu_ and eps in eps_
@@ -509,6 +579,14 @@ void Solver::mean_stress(double* out6) {
   FG_HIP_CHECK(hipSetDevice(device_));
   ensure_eps();
   if (pt_.n < 1) throw std::runtime_error("No materials specified");
+  if (opt_.mode == 1) {
+    launch_sc_flux_mean(g_, scalar_params(0.0, 1.0 / (double)nglobal_), ptrs3(eps_), phase_ptrs(), partial_,
+                        dscal_ + kSlotMean, stream_);
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    for (int c = 0; c < 6; ++c) out6[c] = c < 3 ? hscal_[kSlotMean + c] : 0.0;
+    return;
+  }
   FieldPtrs<kMaxPhases> phi;
   for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
   FieldPtrs<3> nrm;
@@ -545,7 +623,10 @@ void Solver::calc_ref_material() {
   if (pt_.n < 1) throw std::runtime_error("No materials specified");
   FieldPtrs<kMaxPhases> phi;
   for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
-  launch_tangent_minmax(g_, pt_, opt_.mixing, phi, partial_, dscal_ + kSlotMinMax, derr_, stream_);
+  if (opt_.mode == 1)
+    launch_sc_minmax(g_, scalar_params(0.0, 1.0), phi, partial_, dscal_ + kSlotMinMax, stream_);
+  else
+    launch_tangent_minmax(g_, pt_, opt_.mixing, phi, partial_, dscal_ + kSlotMinMax, derr_, stream_);
   FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMinMax, dscal_ + kSlotMinMax, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
   check_device_error("reference material");
   double lambda_min = hscal_[kSlotMinMax], lambda_max = -hscal_[kSlotMinMax + 1];
@@ -597,6 +678,7 @@ bool Solver::run(const double* E6, const double* S6) {
     voigt_mv(BC_Q_, E0, t);
     if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
   }
+  if (opt_.method == 1 && opt_.mode == 1) throw std::runtime_error("method=cg is not available in heat / porous mode (use basic)");
   if (opt_.method == 1) return run_cg(E0, S0);
   const double t_start = now_seconds();
   FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * g_.n * sizeof(double), stream_));  // F:21379
@@ -922,6 +1004,12 @@ void Solver::local_sums(const std::string& what, double* out) {
 // ------------------------------------------------------------------ stages and fields
 void Solver::run_stage(int stage, const double* E6) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  if (opt_.mode == 1) {
+    if (stage != kStageIteration) throw std::runtime_error("single stages are not available in heat / porous mode");
+    iterate(E6, 1);
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    return;
+  }
   ensure_eps();
   if (stage != kStageIteration) u_valid_ = false;  // the stage buffers are being used as scratch
   FieldPtrs<kMaxPhases> phi;
@@ -981,6 +1069,13 @@ void Solver::run_stage(int stage, const double* E6) {
 }
 
 int Solver::field_components(const std::string& name) const {
+  if (opt_.mode == 1) {
+    if (name == "epsilon" || name == "sigma") return 3;
+    if (name == "u") return 1;
+    if (name == "phi") return pt_.n;
+    if (name == "sumsq") return 6;
+    return 0;
+  }
   if (name == "epsilon" || name == "sigma" || name == "tau") return 6;
   if (name == "u" || name == "f" || name == "normals") return 3;
   if (name == "f_hat") return 3;
@@ -1002,7 +1097,8 @@ double* Solver::device_component(const std::string& name, int c) {
 void Solver::get_field(const std::string& name, double* out) {
   FG_HIP_CHECK(hipSetDevice(device_));
   ensure_eps();
-  if (name == "u") u_valid_ = false;  // fu_ is overwritten by the displacement reconstruction
+  // fu_ is overwritten by the displacement reconstruction (scalar modes: by an equivalent potential, still valid)
+  if (name == "u" && opt_.mode != 1) u_valid_ = false;
   if (name == "sumsq") {
     for (int c = 0; c < 6; ++c) out[c] = sumsq_[c];
     return;
@@ -1011,6 +1107,21 @@ void Solver::get_field(const std::string& name, double* out) {
     FG_HIP_CHECK(hipStreamSynchronize(stream_));
     FG_HIP_CHECK(hipMemcpy2D(out, g_.nzf * sizeof(cplx), fu_, g_.nzc * sizeof(cplx), g_.nzf * sizeof(cplx),
                              (size_t)3 * g_.nx * g_.ny, hipMemcpyDeviceToHost));
+    return;
+  }
+  if (opt_.mode == 1 && name == "sigma") {  // calcStress with C0 = 0  F:15496-15508: the flux
+    if (pt_.n < 1) throw std::runtime_error("No materials specified");
+    launch_sc_flux(g_, scalar_params(0.0, 1.0), ptrs3(eps_), phase_ptrs(), ptrs3(tau_), stream_);
+    for (int c = 0; c < 3; ++c) download_unpadded(tau_ + (long)c * g_.n, out + (long)c * g_.nxyz);
+    return;
+  }
+  if (opt_.mode == 1 && name == "u") {  // potential T = G0 div(C0 : g), alpha = 1  F:15536-15541
+    launch_sc_div(g_, ptrs3(eps_), 2 * opt_.mu_0, fu_, stream_);   // calcStressConst + divOperatorStaggeredHeat
+    const bool timing = timing_;
+    timing_ = false;
+    fft_g0_chain(fu_, false, 1.0);
+    timing_ = timing;
+    download_unpadded(fu_, out);
     return;
   }
   if (name == "sigma") {  // calcStress with C0 = 0  F:15496-15508
@@ -1052,6 +1163,7 @@ void Solver::get_field(const std::string& name, double* out) {
 
 void Solver::set_field(const std::string& name, const double* in) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  if (opt_.mode == 1) throw std::runtime_error("fields cannot be set in heat / porous mode");
   ensure_eps();
   u_valid_ = false;
   if (name == "f_hat") {

@@ -81,6 +81,7 @@ class FG:
         self._normals = None
         self._want_normals = False
         self._method = "cg"
+        self._mode = "elasticity"
         self._real_vf = {}
 
     def reset(self):
@@ -230,11 +231,17 @@ class FG:
         self._dims = (dx, dy, dz)
         self._x0 = x0
         mode = self._child_value(solver, "mode", "elasticity", str)
-        if mode != "elasticity":
-            raise RuntimeError("mode '%s' is not available on the MI355X path (elasticity only)" % mode)
+        if mode not in ("elasticity", "heat", "porous"):
+            raise RuntimeError("mode '%s' is not available on the MI355X path (elasticity, heat, porous)" % mode)
+        self._mode = mode
+        scalar = mode != "elasticity"
         method = self._child_value(solver, "method", "cg", str)
         if method not in ("basic", "cg"):
             raise RuntimeError("Unknown solver method '%s'" % method)
+        if scalar and method == "cg":
+            # same fixed point, different iteration history; the scalar modes run the basic scheme
+            log.info("heat / porous mode: method=cg is replaced by the basic scheme on the MI355X path")
+            method = "basic"
         self._method = method
         scheme = self._child_value(solver, "gamma_scheme", "auto", str)
         if scheme == "auto":
@@ -247,9 +254,11 @@ class FG:
         mixing = self._child_value(solver, "mixing_rule", "voigt", str)
         if mixing not in ("voigt", "laminate"):
             raise RuntimeError("Unknown mixing rule '%s'" % mixing)
+        if scalar and mixing != "voigt":
+            raise RuntimeError("mixing rule '%s' is not available in %s mode (voigt only)" % (mixing, mode))
 
         lss = LSSolver(nx, ny, nz, dx, dy, dz, device=self._device)
-        opts = {"mixing_rule": mixing, "method": method}
+        opts = {"mode": mode, "mixing_rule": mixing, "method": method}
         for k in _SOLVER_DOUBLE_KEYS:
             v = self._child_value(solver, k, None)
             if v is not None:
@@ -276,6 +285,9 @@ class FG:
                     continue
                 attrs = dict(m.attrib)
                 if m.tag == "ref":
+                    if scalar:
+                        opts["mu_0"] = self._eval(attrs.get("mu", "1"))
+                        continue
                     c = _materials.material_constants(attrs, self._eval)
                     opts["mu_0"], opts["lambda_0"] = c["mu"], c["lambda"]
                     continue
@@ -288,7 +300,11 @@ class FG:
                 if law != "iso":
                     raise RuntimeError("Unknown material law '%s'" % law)
                 names.append(m.tag)
-                consts.append(_materials.material_constants(attrs, self._eval))
+                if scalar:
+                    # ScalarLinearIsotropicMaterialLaw::readSettings  F:11170-11173: one constant, mu (default 1)
+                    consts.append({"mu": self._eval(attrs.get("mu", "1")), "lambda": 0.0})
+                else:
+                    consts.append(_materials.material_constants(attrs, self._eval))
         if not names:
             raise RuntimeError("No materials specified")
         lss.set_num_phases(len(names))
@@ -408,6 +424,8 @@ class FG:
         self.init_lss()
         s = self._lss.get_field("sigma")
         e = self._lss.get_field("epsilon")
+        if self._mode != "elasticity":
+            return float(0.5 * (s * e).sum(axis=0).mean())
         w = (s[:3] * e[:3]).sum(axis=0) + 2 * (s[3:] * e[3:]).sum(axis=0)
         return float(0.5 * w.mean())
 
@@ -471,7 +489,7 @@ class FG:
         vtk.write_results(filename, lss.shape, self._dims, self._x0, self._phase_names, lss.get_field("phi"),
                           lss.get_field("epsilon"), lss.get_field("sigma"), lss.get_field("u"),
                           binary=self._child_value(st, "res_format", "binary", str) == "binary",
-                          dtype=self._child_value(st, "restype", "float", str))
+                          dtype=self._child_value(st, "restype", "float", str), mode=self._mode)
 
     # ------------------------------------------------------------------ running
     def _on_iteration(self):
@@ -597,15 +615,23 @@ class FG:
             self.init_phase()
             return None
         if name == "run_load_case":
+            self.init_lss()
+            scalar = self._mode != "elasticity"
             E = self._voigt_vector(act, "e")
             S = self._voigt_vector(act, "s")
             P = np.diag([1.0, 1.0, 1.0, 0.5, 0.5, 0.5])
-            for i in range(6):
-                for j in range(6):
+            dim = 3 if scalar else 6
+            for i in range(dim):
+                for j in range(dim):
                     key = "p%d%d" % (i + 1, j + 1)
                     if key in act.attrib:
                         P[i, j] = P[j, i] = self._eval(act.attrib[key])
-            self.init_lss()
+            if scalar:
+                # heat / porous branch  F:26002-26024: 3-vectors e1..e3 (or e11, e22, e33), projector Id(3)
+                if np.abs(P[:3, :3] - np.eye(3)).max() > 0 or np.abs(S[:3]).max() > 0:
+                    raise RuntimeError("%s mode supports prescribed mean gradients only on the MI355X path" % self._mode)
+                E, S = E[:3], None
+                P = np.diag([1.0, 1.0, 1.0, 0.5, 0.5, 0.5])
             self.init_phase()
             self._lss.set_bc_projector(P)
             failed = self._lss.run(E, S)
@@ -642,6 +668,24 @@ class FG:
             self.init_lss()
             self.init_phase()
             outdir = self._attr(act, "outdir", "", str)
+            if self._mode != "elasticity":
+                # heat / porous branch  F:26115-26165: three unit gradients, Ceff = S E^-1 (3x3)
+                S = np.zeros((3, 3))
+                for i in range(3):
+                    Ep = np.zeros(3)
+                    Ep[i] = 1.0
+                    failed = self._lss.run(Ep)
+                    stop = self._loadstep_callback is not None and self._loadstep_callback()
+                    if failed or stop or self._error is not None:
+                        self._error = self._error or "NaN detected in solution. Aborting."
+                        return EXIT_FAILURE
+                    S[:, i] = self._lss.mean_stress()
+                    if outdir:
+                        self.write_vtk("%s/results_%d.vtk" % (outdir, i + 1))
+                self._Ceff_voigt = S @ np.linalg.inv(np.eye(3))
+                log.info("Effective %s matrix:\n%s", "conductivity" if self._mode == "heat" else "permeability",
+                         self._Ceff_voigt)
+                return None
             S = np.zeros((6, 6))
             for i in range(6):
                 Ep = np.zeros(6)

@@ -36,6 +36,7 @@ class LSSolver:
             raise RuntimeError(self._lib.fg_last_error(None).decode())
         self._cb_keepalive = None
         self.nphases = 0
+        self.scalar = False  # heat / porous mode: 3-component gradient / flux, 1-component potential
 
     # -- plumbing ---------------------------------------------------------
     def close(self):
@@ -87,6 +88,11 @@ class LSSolver:
                 if v not in ("basic", "cg"):
                     raise RuntimeError("Unknown solver method '%s'" % v)
                 self._check(self._lib.fg_set_option_i(self._h, b"method", 1 if v == "cg" else 0))
+            elif k == "mode":
+                if v not in ("elasticity", "heat", "porous"):
+                    raise RuntimeError("mode '%s' is not available on the MI355X path" % v)
+                self.scalar = v != "elasticity"
+                self._check(self._lib.fg_set_option_i(self._h, b"mode", 1 if self.scalar else 0))
             elif k in ("u_loop", "fuse_x", "fuse_z", "fuse_stress_div"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
             elif k in ("maxiter",):
@@ -116,24 +122,33 @@ class LSSolver:
         self._check(self._lib.fg_cancel(self._h))
 
     # -- running ------------------------------------------------------------
+    def _load6(self, v):
+        """prescribed mean value as the 6 doubles the ABI takes (heat / porous: 3 entries, zero padded)"""
+        v = np.asarray(v, dtype=np.float64).ravel()
+        if self.scalar and v.size == 3:
+            v = np.concatenate([v, np.zeros(3)])
+        if v.size != 6:
+            raise ValueError("prescribed mean value must have %d entries" % (3 if self.scalar else 6))
+        return np.ascontiguousarray(v)
+
     def run(self, E, S=None):
         """LSSolver::run; returns True on error like the reference."""
-        E = np.ascontiguousarray(E, dtype=np.float64)
+        E = self._load6(E)
         Sp = None
         if S is not None:
-            S = np.ascontiguousarray(S, dtype=np.float64)
+            S = self._load6(S)
             Sp = _dp(S)
         failed = ctypes.c_int(0)
         self._check(self._lib.fg_run_load_case(self._h, _dp(E), Sp, ctypes.byref(failed)))
         return bool(failed.value)
 
     def iterate(self, E, n):
-        E = np.ascontiguousarray(E, dtype=np.float64)
+        E = self._load6(E)
         self._check(self._lib.fg_iterate(self._h, _dp(E), int(n)))
 
     def time_iterations(self, E, n):
         """n basic-scheme passes bracketed by HIP events on the solver stream -> milliseconds."""
-        E = np.ascontiguousarray(E, dtype=np.float64)
+        E = self._load6(E)
         ms = ctypes.c_double(0.0)
         self._check(self._lib.fg_time_iterations(self._h, _dp(E), int(n), ctypes.byref(ms)))
         return ms.value
@@ -168,12 +183,12 @@ class LSSolver:
     def mean_stress(self):
         out = np.zeros(6)
         self._check(self._lib.fg_mean_stress(self._h, _dp(out)))
-        return out
+        return out[:3] if self.scalar else out
 
     def mean_strain(self):
         out = np.zeros(6)
         self._check(self._lib.fg_mean_strain(self._h, _dp(out)))
-        return out
+        return out[:3] if self.scalar else out
 
     def volume_fraction(self, p):
         out = ctypes.c_double(0.0)

@@ -1,0 +1,195 @@
+"""NumPy restatement of fibergen's basic scheme in the scalar modes (mode=heat / mode=porous).
+
+TEST INFRASTRUCTURE ONLY -- the checker, never the product path (see oracle/ls_oracle.py).
+
+The scalar modes (BASELINE config 5) solve  div((kappa - kappa0) g) ... for the gradient
+field g = E + grad T of a potential T (temperature / pressure): fields have 3 components, the potential
+one.  ``F`` = /root/reference/src/fibergen.cpp.  Each method cites the routine it restates.
+
+Pinning (tests/test_oracle_pins.py::test_scalar_*): the reference holds no numeric fixtures for these modes;
+pinned against closed forms that the reference's discretisation reproduces exactly -- layered media
+(series = harmonic mean across the layers, parallel = arithmetic mean along them), the homogeneous medium,
+the Wiener and Hashin-Shtrikman bounds -- and the operator identity  grad(G0(div(2 mu0 grad T))) = grad T.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .ls_oracle import EPS, SMALLEST, LSOracle
+
+VOIGT_THRESHOLD = 10 * EPS
+
+
+class ScalarOracle:
+    """LSSolver<double,double,3> with mode=heat|porous, method=basic, gamma_scheme=staggered,
+    mixing_rule=voigt, law="iso" (ScalarLinearIsotropicMaterialLaw F:11158-11215: flux = mu * gradient)."""
+
+    def __init__(self, nx, ny, nz, mus, phis, dx=1.0, dy=1.0, dz=1.0, tol=1e-4, abs_tol=EPS, bc_tol=1e-3,
+                 maxiter=10000, ref_scale=1.0, mu_0=float("nan"), update_ref="loadstep"):
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.dx, self.dy, self.dz = dx, dy, dz
+        self.mus = list(mus)
+        self.phis = [np.asarray(p, dtype=np.float64) for p in phis]
+        self.tol, self.abs_tol, self.bc_tol, self.maxiter = tol, abs_tol, bc_tol, maxiter
+        self.ref_scale, self.mu_0, self.update_ref = ref_scale, mu_0, update_ref
+        self.N = nx * ny * nz
+        self.eps = np.zeros((3, nx, ny, nz))
+        self.residuals = []
+        self.callback = None
+        self.error = None
+        # Green-operator tables are those of the elasticity path (same k+ / k- factors, F:19766-19815)
+        self._tables = LSOracle(nx, ny, nz, dx, dy, dz).g0_axis_tables()
+
+    # -- constitutive ------------------------------------------------------------------------
+    def pk1(self, g, alpha=1.0):
+        """VoigtMixedMaterialLaw<.,.,3>::PK1  F:12752-12761 over ScalarLinearIsotropicMaterialLaw::PK1
+        F:11182-11198: S_m (+)= E_m * ((phi*alpha)*mu), phases with phi <= 10 eps skipped."""
+        P = np.zeros_like(g)
+        first = np.ones(g.shape[1:], dtype=bool)
+        for phi, mu in zip(self.phis, self.mus):
+            live = phi > VOIGT_THRESHOLD
+            alpha_mu = (phi * alpha) * mu
+            for m in range(3):
+                term = g[m] * alpha_mu
+                P[m] = np.where(live, np.where(first, term, P[m] + term), P[m])
+            first &= ~live
+        return P
+
+    def calc_stress(self, mu_0, g, alpha=1.0):
+        """calcStress  F:18134-18184 with dim 3: tau = P(g) + beta g, beta = -alpha 2 mu0 (lambda0 = 0)."""
+        beta = -alpha * 2 * mu_0
+        P = self.pk1(g, alpha)
+        if beta != 0:
+            P = P + beta * g
+        return P
+
+    def mean_stress(self, g=None):
+        """calcMeanStress -> meanPK1  F:17793-17811, F:12312-12351"""
+        g = self.eps if g is None else g
+        return self.pk1(g, 1.0 / self.N).reshape(3, -1).sum(axis=1)
+
+    def mean_strain(self):
+        return self.eps.reshape(3, -1).sum(axis=1) / self.N
+
+    # -- difference operators ----------------------------------------------------------------
+    def _h(self):
+        return self.nx / self.dx, self.ny / self.dy, self.nz / self.dz
+
+    def div_heat(self, x):
+        """divOperatorStaggeredHeat  F:18914-18975: backward differences, accumulated x, y, z."""
+        hx, hy, hz = self._h()
+        y = (x[0] - np.roll(x[0], 1, axis=0)) * hx
+        y = y + (x[1] - np.roll(x[1], 1, axis=1)) * hy
+        y = y + (x[2] - np.roll(x[2], 1, axis=2)) * hz
+        return y
+
+    def eps_heat(self, E, T):
+        """epsOperatorStaggeredHeat  F:18697-18760: forward differences of the potential plus E."""
+        hx, hy, hz = self._h()
+        y = np.empty((3,) + T.shape)
+        y[0] = E[0] + (np.roll(T, -1, axis=0) - T) * hx
+        y[1] = E[1] + (np.roll(T, -1, axis=1) - T) * hy
+        y[2] = E[2] + (np.roll(T, -1, axis=2) - T) * hz
+        return y
+
+    # -- Green operator ------------------------------------------------------------------------
+    def g0_heat(self, mu_0, f, alpha=1.0):
+        """G0OperatorStaggeredHeat  F:20118-20135: fftVector(.,1) (1/N forward, F:18481-18510),
+        G0OperatorFourierStaggeredHeat  F:19759-19823 (c1 = c10/|k|^2, c10 = -alpha/(2 mu0), zero mode 0),
+        fftInvVector."""
+        fh = np.fft.rfftn(f, axes=(0, 1, 2)) * (1 / float(self.N))
+        c10 = -alpha / (2 * mu_0)
+        (s0, _), (s1, _), (s2, _) = self._tables
+        norm2 = (s0 * s0)[:, None, None] + (s1 * s1)[None, :, None] + (s2 * s2)[None, None, :]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            th = (c10 / norm2) * fh
+        th[0, 0, 0] = 0
+        return np.fft.irfftn(th, s=(self.nx, self.ny, self.nz), axes=(0, 1, 2)) * float(self.N)
+
+    def potential(self):
+        """get_raw_field("u") in the scalar modes  F:15536-15541: T = G0(div(C0 : g)) with alpha = 1."""
+        sigma = 2 * self.mu_0 * self.eps       # calcStressConst with lambda0 = 0  F:17973-18020
+        return self.g0_heat(self.mu_0, self.div_heat(sigma), 1.0)
+
+    # -- reference material --------------------------------------------------------------------------
+    def calc_ref_material(self):
+        """calcRefMaterial  F:22283-22313 over getRefMaterial / eig  F:12153-12236, F:12472-12559: the
+        3x3 tangent of the Voigt-mixed scalar law is (sum_p phi_p mu_p) I."""
+        mu_bar = np.zeros((self.nx, self.ny, self.nz))
+        first = np.ones(mu_bar.shape, dtype=bool)
+        for phi, mu in zip(self.phis, self.mus):
+            live = phi > VOIGT_THRESHOLD
+            t = (phi * 1.0) * mu
+            mu_bar = np.where(live, np.where(first, t, mu_bar + t), mu_bar)
+            first &= ~live
+        lo, hi = float(mu_bar.min()), float(mu_bar.max())
+        if lo < 0:
+            lo = 0.0
+        self.mu_0 = 0.5 * (lo + hi) * (0.5 * self.ref_scale)
+
+    # -- iteration ---------------------------------------------------------------------------------------
+    def basic_scheme(self, E, g):
+        """basicScheme  F:20558-20578 -> GammaOperatorStaggeredHeat  F:20342-20351 (alpha = -1):
+        g <- E + grad G0(div((C - C0) g)); pure gradient loading (P = Id: Q = 0, no projector term)."""
+        tau = self.calc_stress(self.mu_0, g)
+        T = self.g0_heat(self.mu_0, self.div_heat(tau), -1.0)
+        return self.eps_heat(E, T)
+
+    def component_norm(self, g):
+        return np.sqrt((g.reshape(3, -1) ** 2).sum(axis=1) / self.N)
+
+    def run(self, E0):
+        """LSSolver::run -> runBasic  F:21247-21398, F:21716-21805 with the stop rule _converged  F:21177-21244
+        and EpsilonErrorEstimator  F:14591-14637 (fix_dim zeroes entries 3..8 for dim 3, F:12122-12124)."""
+        E0 = np.asarray(E0, dtype=np.float64)
+        self.residuals = []
+        self.error = None
+        self.eps = np.zeros((3, self.nx, self.ny, self.nz))
+        prev = float(np.linalg.norm(self.component_norm(self.eps)))
+        it = 1
+        update_ref = self.update_ref != "never"
+        while True:
+            if update_ref:
+                self.calc_ref_material()
+                update_ref = False
+            self.eps = self.basic_scheme(E0, self.eps)
+            cur = float(np.linalg.norm(self.component_norm(self.eps)))
+            abs_err = abs(prev - cur)
+            rel_err = abs_err / (SMALLEST + cur)
+            prev = cur
+            if math.isnan(rel_err):
+                self.error = "NaN detected in solution. Aborting."
+                return True
+            self.residuals.append(rel_err)
+            if self.callback is not None and self.callback():
+                break
+            if it >= self.maxiter:
+                break
+            if rel_err <= self.tol or abs_err <= self.abs_tol:
+                if self.bc_error(E0) <= self.bc_tol:
+                    break
+            it += 1
+        self.iterations = it
+        return False
+
+    def bc_error(self, E_cur):
+        """bc_error  F:21129-21161 with P = Id, S = 0: only the gradient part can be non-zero."""
+        Emean = self.mean_strain()
+        nE = float(np.linalg.norm(E_cur))
+        return float(np.linalg.norm(Emean - E_cur)) / (1 if nE < self.bc_tol else nE)
+
+    def calc_effective_properties(self):
+        """calc_effective_properties, heat / porous branch  F:26115-26165: three unit gradients,
+        Ceff = S E^-1 (3x3, no Voigt halving)."""
+        S = np.zeros((3, 3))
+        self.ceff_iterations = []
+        for i in range(3):
+            Ep = np.zeros(3)
+            Ep[i] = 1.0
+            if self.run(Ep):
+                raise RuntimeError(self.error)
+            S[:, i] = self.mean_stress()
+            self.ceff_iterations.append(self.iterations)
+        return S

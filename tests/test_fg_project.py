@@ -155,7 +155,7 @@ def test_unknown_settings_raise_like_reference(monkeypatch):
     fg = FG()
     fg.set_xml(XML)
     fg._init_python()
-    fg.set("solver.mode", "heat")
+    fg.set("solver.mode", "hyperelasticity")
 
     class Dummy:
         def __init__(self, *a, **k):

@@ -1,0 +1,132 @@
+"""GPU parity of the scalar modes (mode=heat / porous, BASELINE config 5): the potential-based HIP loop through the
+C ABI against oracle/scalar_oracle.py on the same phase fields."""
+import numpy as np
+import pytest
+
+from helpers import rel_err, sphere_phi
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(grid, mus, phis, dims=(1.0, 1.0, 1.0), **kw):
+    from fibergen_amd import LSSolver
+    s = LSSolver(*grid, *dims)
+    s.set_options(mode="porous")
+    s.set_num_phases(len(mus))
+    for p, (mu, phi) in enumerate(zip(mus, phis)):
+        s.set_phase(p, mu, 0.0, phi)
+    s.set_options(**kw)
+    return s
+
+
+def _oracle(grid, mus, phis, dims=(1.0, 1.0, 1.0), **kw):
+    from oracle.scalar_oracle import ScalarOracle
+    return ScalarOracle(*grid, mus=mus, phis=phis, dx=dims[0], dy=dims[1], dz=dims[2], **kw)
+
+
+@pytest.mark.parametrize("grid,dims", [((16, 16, 16), (1, 1, 1)), ((12, 10, 6), (2.0, 1.0, 0.5)), ((9, 7, 5), (1, 1, 1)),
+                                       ((32, 16, 64), (1, 1, 1)), ((8, 16, 5), (1, 1, 1))])
+def test_scalar_run_matches_oracle(grid, dims):
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 12.0], [1 - phi1, phi1]
+    E = np.array([1.0, -0.5, 0.25])
+    s = _solver(grid, mus, phis, dims, tol=1e-9)
+    o = _oracle(grid, mus, phis, dims, tol=1e-9)
+    assert s.run(E) is False and o.run(E) is False
+    assert s.iterations == o.iterations
+    assert s.ref_material[0] == o.mu_0
+    np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-11)
+    g = s.get_field("epsilon")
+    assert g.shape == (3,) + grid
+    assert rel_err(g, o.eps) < 1e-10
+    assert rel_err(s.get_field("sigma"), o.pk1(o.eps)) < 1e-10
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-11
+    np.testing.assert_allclose(s.mean_strain(), E, atol=1e-12)
+    T = s.get_field("u")
+    assert T.shape == (1,) + grid
+    To = o.potential()
+    assert np.abs(T[0] - To).max() < 1e-10 * max(1.0, np.abs(To).max())
+    # a second load case on the same object, then raw passes continue from the state
+    assert s.run([0, 0, 1.0]) is False and o.run([0, 0, 1.0]) is False
+    assert s.iterations == o.iterations and rel_err(s.get_field("epsilon"), o.eps) < 1e-10
+    s.iterate([0, 0, 1.0], 2)
+    g2 = o.basic_scheme(np.array([0, 0, 1.0]), o.basic_scheme(np.array([0, 0, 1.0]), o.eps))
+    assert rel_err(s.get_field("epsilon"), g2) < 1e-10
+    s.close()
+
+
+def test_scalar_effective_conductivity_of_layers_is_exact():
+    """series / parallel means (see tests/test_oracle_pins.py) from the HIP path"""
+    shape, mus, fr = (20, 4, 6), [1.0, 5.0, 0.5], [0.2, 0.3, 0.5]
+    edges = np.round(np.cumsum([0.0] + fr) * shape[0]).astype(int)
+    phis = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        p = np.zeros(shape)
+        p[a:b] = 1.0
+        phis.append(p)
+    s = _solver(shape, mus, phis, tol=1e-13, maxiter=2000)
+    K = np.zeros((3, 3))
+    for i in range(3):
+        assert s.run(np.eye(3)[i]) is False
+        K[:, i] = s.mean_stress()
+    assert K[0, 0] == pytest.approx(1.0 / sum(f / m for f, m in zip(fr, mus)), rel=1e-10)
+    assert K[1, 1] == pytest.approx(sum(f * m for f, m in zip(fr, mus)), rel=1e-12)
+    assert np.abs(K - np.diag(np.diag(K))).max() < 1e-12
+
+
+def test_scalar_callback_and_errors():
+    grid = (16, 16, 16)
+    phi1 = sphere_phi(grid, 0.3)
+    s = _solver(grid, [1.0, 12.0], [1 - phi1, phi1], tol=1e-9)
+    o = _oracle(grid, [1.0, 12.0], [1 - phi1, phi1], tol=1e-9)
+    seen = []
+
+    def cb():
+        seen.append((s.get_field("u").copy(), s.mean_stress().copy()))
+        return False
+    s.set_convergence_callback(cb)
+    assert s.run([1.0, 0, 0]) is False and o.run([1.0, 0, 0]) is False
+    assert s.iterations == o.iterations == len(seen)
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-10
+    assert rel_err(seen[-1][1], o.mean_stress()) < 1e-10
+    s.set_convergence_callback(None)
+    s.set_options(method="cg")
+    with pytest.raises(RuntimeError, match="cg"):
+        s.run([1.0, 0, 0])
+    s.set_options(method="basic", mixing_rule="laminate")
+    with pytest.raises(RuntimeError, match="Voigt"):
+        s.run([1.0, 0, 0])
+    with pytest.raises(RuntimeError):
+        s.set_field("epsilon", np.zeros((3,) + grid))
+    s.close()
+
+
+POROUS_XML = """
+<settings><solver n="16"><mode>%s</mode><tol>1e-9</tol>
+  <materials><matrix mu="1" /><incl mu="12" /></materials></solver>
+  <actions><select_material name="incl" /><place_fiber R="0.3" />
+  <run_load_case e1="1" e3="0.5" outfile="%s" />
+  <calc_effective_properties /></actions></settings>"""
+
+
+@pytest.mark.parametrize("mode", ["heat", "porous"])
+def test_fg_scalar_project(tmp_path, mode):
+    """XML project in heat / porous mode through FG: 3x3 effective matrix = the oracle's on the same phase field;
+    result file with gradient, flux and potential (writeVTK heat branch  F:23436-23450)."""
+    from fibergen_amd import FG, vtk
+    fn = str(tmp_path / "r.vtk")
+    fg = FG()
+    fg.set_xml(POROUS_XML % (mode, fn))
+    assert fg.run() == 0
+    K = np.array(fg.get_effective_property())
+    assert K.shape == (3, 3)
+    phi = fg.get_field("phi")
+    o = _oracle((16, 16, 16), [1.0, 12.0], [phi[0], phi[1]], tol=1e-9)
+    Ko = o.calc_effective_properties()
+    assert rel_err(K, Ko) < 1e-9
+    assert fg.get_field("epsilon").shape == (3, 16, 16, 16) and fg.get_field("u").shape == (1, 16, 16, 16)
+    assert len(fg.get_mean_stress()) == 3
+    h, f = vtk.read_legacy(fn)
+    assert list(f) == ["phi_matrix", "phi_incl", "epsilon_11", "epsilon_22", "epsilon_33", "sigma_11", "sigma_22",
+                       "sigma_33", "T" if mode == "heat" else "p"]
+    assert abs(f["epsilon_11"].mean() - 1.0) < 1e-6 and abs(f["epsilon_33"].mean() - 0.5) < 1e-6

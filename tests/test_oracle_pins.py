@@ -270,3 +270,71 @@ def test_mixed_bc_projector_uniaxial_stress():
     assert s[0] == pytest.approx(2.0 * 0.01, rel=1e-8)
     assert np.abs(s[1:]).max() < 1e-10
     assert e[1] == pytest.approx(-0.3 * 0.01, rel=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------
+# scalar modes (heat / porous): oracle/scalar_oracle.py
+# ---------------------------------------------------------------------------------------------------
+def _layers_x(shape, fractions):
+    """phase fields of layers stacked along x with voxel-aligned interfaces"""
+    nx = shape[0]
+    edges = np.round(np.cumsum([0.0] + list(fractions)) * nx).astype(int)
+    phis = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        p = np.zeros(shape)
+        p[a:b] = 1.0
+        phis.append(p)
+    return phis
+
+
+def test_scalar_layered_medium_series_and_parallel_means():
+    """Layers across x: the discrete solution has a constant flux across the layers, so the effective
+    conductivity is the harmonic mean across and the arithmetic mean along the layers -- exactly, for any
+    solver tolerance (the scalar counterpart of calc_isotropic_laminate  F:26405-26446)."""
+    from oracle.scalar_oracle import ScalarOracle
+    shape, mus, fr = (20, 4, 6), [1.0, 5.0, 0.5], [0.2, 0.3, 0.5]
+    o = ScalarOracle(*shape, mus=mus, phis=_layers_x(shape, fr), tol=1e-13, maxiter=2000)
+    K = o.calc_effective_properties()
+    harm = 1.0 / sum(f / m for f, m in zip(fr, mus))
+    arit = sum(f * m for f, m in zip(fr, mus))
+    assert K[0, 0] == pytest.approx(harm, rel=1e-10)
+    assert K[1, 1] == pytest.approx(arit, rel=1e-12) and K[2, 2] == pytest.approx(arit, rel=1e-12)
+    assert np.abs(K - np.diag(np.diag(K))).max() < 1e-12
+
+
+def test_scalar_homogeneous_medium_and_operator_identity():
+    from oracle.scalar_oracle import ScalarOracle
+    shape = (6, 5, 4)
+    one = np.ones(shape)
+    o = ScalarOracle(*shape, mus=[3.0, 7.0], phis=[one, 0 * one], dx=2.0, dy=1.0, dz=0.5)
+    assert o.run([1.0, -2.0, 0.5]) is False
+    assert o.iterations <= 2 and o.mu_0 == pytest.approx(0.5 * 0.5 * (3.0 + 3.0))
+    np.testing.assert_allclose(o.eps, np.array([1.0, -2.0, 0.5])[:, None, None, None] * np.ones((3,) + shape), atol=1e-14)
+    np.testing.assert_allclose(o.mean_stress(), [3.0, -6.0, 1.5], rtol=1e-13)
+    # grad(G0(div(2 mu0 grad T))) = grad T: the scalar Green operator inverts the discrete Laplacian
+    rng = np.random.default_rng(5)
+    T = rng.standard_normal(shape)
+    T -= T.mean()
+    Z = np.zeros(3)
+    T2 = o.g0_heat(o.mu_0, o.div_heat(2 * o.mu_0 * o.eps_heat(Z, T)), 1.0)
+    np.testing.assert_allclose(T2, T, atol=1e-12)
+
+
+def test_scalar_sphere_within_bounds_and_isotropic():
+    """Wiener (harmonic / arithmetic) and Hashin-Shtrikman bounds for a sphere inclusion; cubic symmetry."""
+    from oracle.scalar_oracle import ScalarOracle
+    from helpers import sphere_phi
+    n, k0, k1 = 16, 1.0, 8.0
+    phi1 = sphere_phi((n, n, n), 0.3)
+    o = ScalarOracle(n, n, n, mus=[k0, k1], phis=[1 - phi1, phi1], tol=1e-9)
+    K = o.calc_effective_properties()
+    c1 = phi1.mean()
+    lo = 1 / ((1 - c1) / k0 + c1 / k1)
+    hi = (1 - c1) * k0 + c1 * k1
+    hs_lo = k0 + c1 / (1 / (k1 - k0) + (1 - c1) / (3 * k0))
+    hs_hi = k1 + (1 - c1) / (1 / (k0 - k1) + c1 / (3 * k1))
+    for i in range(3):
+        assert lo < K[i, i] < hi
+        assert hs_lo * (1 - 2e-2) < K[i, i] < hs_hi
+    assert K[0, 0] == pytest.approx(K[1, 1], rel=1e-8) and K[1, 1] == pytest.approx(K[2, 2], rel=1e-8)
+    assert np.abs(K - K.T).max() < 1e-8
