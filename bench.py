@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=256, help="grid size per axis (128, 256, 512)")
     ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
+    ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat"],
+                    help="porous / heat: BASELINE config 5 (scalar potential, 3-component gradient; 256^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-slab", action="store_true", help="N > 1: skip the slab-decomposed measurement")
@@ -199,9 +201,12 @@ def main():
     K = int(round(40 * scale ** 3)) if args.n >= 128 else 5
     phi, normals = synthetic_fiber_rve(n, K=K, R=0.05 / scale, L=0.4 / scale, seed=0,
                                        with_normals=(args.mixing == "laminate"))
+    scalar = args.mode != "elasticity"
     s = LSSolver(*n, device=local_rank)
+    if scalar:
+        s.set_options(mode=args.mode)
     s.set_num_phases(2)
-    mats = [lame(**MATRIX), lame(**INCLUSION)]
+    mats = [(1.0, 0.0), (10.0, 0.0)] if scalar else [lame(**MATRIX), lame(**INCLUSION)]  # contrast 10
     s.set_phase(0, mats[0][0], mats[0][1], 1.0 - phi)
     s.set_phase(1, mats[1][0], mats[1][1], phi)
     if normals is not None:
@@ -210,9 +215,9 @@ def main():
     vf = float(phi.mean())
     del phi, normals
     s.calc_ref_material()
-    # each rank its own load case (calc_effective_properties' unit strains)
-    E = np.zeros(6)
-    E[rank % 6] = 1.0
+    # each rank its own load case (calc_effective_properties' unit strains / gradients)
+    E = np.zeros(3 if scalar else 6)
+    E[rank % E.size] = 1.0
 
     def sync():
         s.synchronize()  # the solver's own HIP stream carries all the work
@@ -241,13 +246,20 @@ def main():
         times, cnt = s.stage_times()
         s.enable_stage_timing(False)
         ab = algorithmic_bytes(n, 2, args.mixing)
+        if scalar:
+            # one component through the FFT chain; the sweep reads T and phi and writes f
+            F = n[0] * n[1] * (n[2] // 2 + 1)
+            ab = {k: 32 * F for k in ab}
+            ab["stress"] = 24 * n[0] * n[1] * n[2]
         kern = {}
         for k, ms in times.items():
             avg = ms / max(cnt, 1)
             if avg <= 0:
                 continue   # stage absorbed by a fused kernel
             name, alg = k, ab[k]
-            if k == "stress" and times["div"] == 0 and times["eps_norm"] == 0:
+            if scalar and k == "stress":
+                name = "T_grad_flux_div"
+            elif k == "stress" and times["div"] == 0 and times["eps_norm"] == 0:
                 # displacement-based sweep: strain operator + polarisation + divergence + norms,
                 # 3 u + phi in, 3 f out
                 name, alg = "u_eps_stress_div", 56 * n[0] * n[1] * n[2]
@@ -269,22 +281,30 @@ def main():
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]}
         out = {
-            "metric": "LS iterations/sec (basic scheme, staggered grid, linear elastic)",
+            "metric": "LS iterations/sec (basic scheme, staggered grid, %s)" % ("linear elastic" if not scalar else
+                                                                               args.mode + " scalar mode"),
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d^3 two-phase fibre RVE (K=%d capsules, vf=%.3f), contrast 10, mixing=%s, "
                                    "one load case per GPU" % (args.n, K, vf, args.mixing),
-                       "grid": list(n), "mixing_rule": args.mixing, "parallelism": "loadcase x%d" % world},
+                       "grid": list(n), "mixing_rule": args.mixing, "mode": args.mode,
+                       "parallelism": "loadcase x%d" % world},
             "roofline": roof,
             "loop_GBps_Amin": A_MIN_BYTES_PER_VOXEL * N * (args.steps / dt) / 1e9,
             "loop_GBps_Astage": A_STAGE_BYTES_PER_VOXEL * N * (args.steps / dt) / 1e9,
             "kernels": kern,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if scalar:
+            # the loop-level figures use the elasticity byte counts; per voxel the scalar loop moves
+            # 24 (sweep) + 7 x 16 (six 1-component FFT passes + Green operator) bytes
+            per = 24 + 7 * 16
+            out["loop_GBps_Amin"] = per * N * (args.steps / dt) / 1e9
+            out["loop_GBps_Astage"] = out["loop_GBps_Amin"]
+        if world == 1 and not args.no_cpu_baseline and not scalar:
             s.close()
             out["cpu_baseline"] = cpu_baseline(n, args.mixing, args.cpu_budget)
-    if world > 1 and not args.no_slab:
+    if world > 1 and not args.no_slab and not scalar:
         # Second measurement: ONE problem slab-decomposed over all ranks (x-slabs, two RCCL
         # all-to-alls per pass).  Guarded: a failure or a stall here must not cost the line above.
         s.close()

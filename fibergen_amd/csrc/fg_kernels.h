@@ -87,6 +87,9 @@ void launch_sum1(const Grid& g, const double* x, double* partial, double* out1, 
 // scalar modes (fg_kernels_scalar.hip)
 void launch_sc_sweep(const Grid& g, const ScalarParams& sp, const double* T, const FieldPtrs<kMaxPhases>& phi, double* f,
                      const Vec6& E, double* partial, double* sumsq6, hipStream_t s);
+// fast variant: a = per-voxel effective conductivity (launch_effective_moduli with 2 mu_p := mu_p, first array)
+void launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
+                          double* partial, double* sumsq6, hipStream_t s);
 void launch_sc_grad(const Grid& g, const double* T, const FieldPtrs<3>& out, const Vec6& E, double* partial,
                     double* sumsq6, hipStream_t s);
 void launch_sc_flux(const Grid& g, const ScalarParams& sp, const FieldPtrs<3>& gr, const FieldPtrs<kMaxPhases>& phi,

@@ -278,6 +278,77 @@ __global__ __launch_bounds__(kBlock) void k_u_fast_z(Grid g, double beta, double
   }
 }
 
+// Scalar modes (heat / porous), fast variant of k_sc_sweep (fg_kernels_scalar.hip): the per-voxel effective
+// conductivity a = sum_p phi_p mu_p is precomputed (k_effective_moduli stores it in the first moduli array with
+// 2 mu_p := mu_p), z neighbours come from the adjacent lanes.  T_k -> sums of squares of g_k = E + grad+ T_k and
+// f = div-((a - 2 mu0) g_k).
+__global__ __launch_bounds__(kBlock) void k_sc_sweep_fast(Grid g, double beta, const double* T, const double* a, double* f,
+                                                          Vec6 E, double* partial, Sweep sw) {
+  __shared__ double smem[4 * 6];
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
+  for (long it = 0; it < run.count; ++it) {
+    const long pidx_raw = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    const long pidx = pidx_raw < npairs ? pidx_raw : npairs - 1;  // clamped lanes discard their result
+    const PairPos p = pair_pos_tiled(pidx, g, sw);
+    const bool valid = pidx_raw < npairs && p.k < g.nz;
+    const bool second = p.k + 1 < g.nz;
+    const int lane = threadIdx.x & 63;
+    const bool prev_ok = lane > 0 && p.k > 0;
+    const bool next_ok = lane < 63 && p.k + 2 < g.nz && pidx_raw + 1 < npairs;
+    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+    const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+    const long ro = p.off - p.k;
+    const int k = p.k;
+    const int kb = k == 0 ? g.nz - 1 : k - 1;
+    const int kf2 = (k + 2 >= g.nz) ? k + 2 - g.nz : k + 2;
+    double eTm = 0, eam = 0, eTp = 0;
+    if (!prev_ok) {
+      eTm = T[ro + kb];
+      eam = a[ro + kb];
+    }
+    if (!next_ok) eTp = T[ro + kf2];
+    const long rk = ro + k;
+    double2 Tc = ld2(T, rk), Txf = ld2(T, rk + xf), Txb = ld2(T, rk + xb), Tyf = ld2(T, rk + yf), Tyb = ld2(T, rk + yb);
+    double2 ac = ld2(a, rk), axb = ld2(a, rk + xb), ayb = ld2(a, rk + yb);
+    if (!second) {  // odd nz, last pair: z+1 wraps to 0
+      Tc.y = T[ro];
+      Txf.y = T[ro + xf]; Txb.y = T[ro + xb]; Tyf.y = T[ro + yf]; Tyb.y = T[ro + yb];
+    }
+    const double t_prev = dpp_move<0x138>(Tc.y), a_prev = dpp_move<0x138>(ac.y), t_next = dpp_move<0x130>(Tc.x);
+    const double Tm = prev_ok ? t_prev : eTm;   // T at z = k-1
+    const double am = prev_ok ? a_prev : eam;   // a at z = k-1
+    const double Tp = next_ok ? t_next : eTp;   // T at z = k+2
+    // voxel z = k
+    const double g0 = E.v[0] + (Txf.x - Tc.x) * hx, g1 = E.v[1] + (Tyf.x - Tc.x) * hy, g2 = E.v[2] + (Tc.y - Tc.x) * hz;
+    const double g0b = E.v[0] + (Tc.x - Txb.x) * hx, g1b = E.v[1] + (Tc.x - Tyb.x) * hy, g2b = E.v[2] + (Tc.x - Tm) * hz;
+    const double c0 = ac.x + beta;
+    const double f0 = (c0 * g0 - (axb.x + beta) * g0b) * hx + (c0 * g1 - (ayb.x + beta) * g1b) * hy +
+                      (c0 * g2 - (am + beta) * g2b) * hz;
+    // voxel z = k+1
+    const double h0 = E.v[0] + (Txf.y - Tc.y) * hx, h1 = E.v[1] + (Tyf.y - Tc.y) * hy, h2 = E.v[2] + (Tp - Tc.y) * hz;
+    const double h0b = E.v[0] + (Tc.y - Txb.y) * hx, h1b = E.v[1] + (Tc.y - Tyb.y) * hy;
+    const double c1 = ac.y + beta;
+    const double f1 = (c1 * h0 - (axb.y + beta) * h0b) * hx + (c1 * h1 - (ayb.y + beta) * h1b) * hy +
+                      (c1 * h2 - c0 * g2) * hz;   // the z-backward neighbour of k+1 is voxel k itself
+    if (valid) {
+      acc[0] += g0 * g0 + (second ? h0 * h0 : 0.0);
+      acc[1] += g1 * g1 + (second ? h1 * h1 : 0.0);
+      acc[2] += g2 * g2 + (second ? h2 * h2 : 0.0);
+      st2(f, p.off, make_double2(f0, second ? f1 : 0.0));
+    }
+  }
+  block_reduce<6>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+  }
+}
+
 // A = sum_p phi_p 2 mu_p, B = sum_p phi_p lambda_p with the Voigt rule's threshold (F:12736)
 __global__ __launch_bounds__(kBlock) void k_effective_moduli(long n2, PhaseTable pt, FieldPtrs<kMaxPhases> phi,
                                                              FieldPtrs<2> mod) {
@@ -314,6 +385,15 @@ void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
   else
     hipLaunchKernelGGL(k_u_fast<false>, dim3(nb), dim3(kBlock), 0, s, g, -2 * mu_0, -lambda_0, u, mod, f, E, partial,
                        chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 6, sumsq6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
+                          double* partial, double* sumsq6, hipStream_t s) {
+  const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
+  hipLaunchKernelGGL(k_sc_sweep_fast, dim3(nb), dim3(kBlock), 0, s, g, -2 * mu_0, T, a, f, E, partial, chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());

@@ -494,7 +494,25 @@ void Solver::u_pass_front(const double* E6) {
   time_begin(0);
   if (opt_.mode == 1) {
     z_done_ = false;
-    launch_sc_sweep(g_, scalar_params(opt_.mu_0, 1.0), fu_, phase_ptrs(), fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
+    if (opt_.u_loop >= 2) {
+      // fast variant: effective conductivity a = sum_p phi_p mu_p precomputed (first moduli array)
+      if (!mod_) {
+        FG_HIP_CHECK(hipMalloc(&mod_, 2 * (size_t)g_.n * sizeof(double)));
+        mod_dirty_ = true;
+      }
+      if (mod_dirty_) {
+        PhaseTable half = pt_;  // k_effective_moduli stores sum phi 2 mu: feed mu / 2
+        for (int q = 0; q < kMaxPhases; ++q) half.mu[q] = 0.5 * pt_.mu[q], half.lambda[q] = 0.0;
+        FieldPtrs<2> mod;
+        mod.p[0] = mod_;
+        mod.p[1] = mod_ + g_.n;
+        launch_effective_moduli(g_, half, phase_ptrs(), mod, stream_);
+        mod_dirty_ = false;
+      }
+      launch_sc_sweep_fast(g_, opt_.mu_0, fu_, mod_, fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
+    } else {
+      launch_sc_sweep(g_, scalar_params(opt_.mu_0, 1.0), fu_, phase_ptrs(), fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
+    }
   } else if (opt_.u_loop >= 2) {
     // fast variant: per-voxel effective moduli instead of the per-phase accumulation
     if (!mod_) {

@@ -26,11 +26,14 @@ def _oracle(grid, mus, phis, dims=(1.0, 1.0, 1.0), **kw):
 
 @pytest.mark.parametrize("grid,dims", [((16, 16, 16), (1, 1, 1)), ((12, 10, 6), (2.0, 1.0, 0.5)), ((9, 7, 5), (1, 1, 1)),
                                        ((32, 16, 64), (1, 1, 1)), ((8, 16, 5), (1, 1, 1))])
-def test_scalar_run_matches_oracle(grid, dims):
+@pytest.mark.parametrize("u_loop", [1, 2])
+def test_scalar_run_matches_oracle(grid, dims, u_loop):
+    """u_loop = 1: per-phase accumulation in the reference's order; 2 (default): precomputed effective
+    conductivity + FMA + lane shifts."""
     phi1 = sphere_phi(grid, 0.3)
     mus, phis = [1.0, 12.0], [1 - phi1, phi1]
     E = np.array([1.0, -0.5, 0.25])
-    s = _solver(grid, mus, phis, dims, tol=1e-9)
+    s = _solver(grid, mus, phis, dims, tol=1e-9, u_loop=u_loop)
     o = _oracle(grid, mus, phis, dims, tol=1e-9)
     assert s.run(E) is False and o.run(E) is False
     assert s.iterations == o.iterations
