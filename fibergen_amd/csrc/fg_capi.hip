@@ -151,6 +151,10 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       if (value != 0 && value != 1) throw std::runtime_error("mode must be 0 (elasticity) or 1 (heat / porous)");
       o.mode = (int)value;
     }
+    else if (k == "gamma_scheme") {
+      if (value != 0 && value != 1) throw std::runtime_error("gamma_scheme must be 0 (staggered) or 1 (collocated)");
+      o.gamma_scheme = (int)value;
+    }
     else if (k == "fuse_x") o.fuse_x = value != 0;
     else if (k == "fuse_z") o.fuse_z = value < 0 ? -1 : (value != 0);
     else if (k == "u_loop") o.u_loop = (int)value;

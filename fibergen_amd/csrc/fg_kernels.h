@@ -32,6 +32,11 @@ struct XHalo {
   const double* hi[2];
 };
 
+// collocated scheme: xi_a[m] = m_signed / d_a per axis (F:19385, 19411-19424), the z table holds nzc entries
+struct XiTables {
+  const double* xi[3];
+};
+
 struct G0Layout {
   int transposed;  // 0: [nx][ny][nzc]   1: y-slab [nyl][nx][nzc]
   int nyl, jj0;
@@ -74,6 +79,8 @@ void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);
 void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
                hipStream_t s);
+void launch_gamma_collocated(const Grid& g, const FieldPtrs<6>& th, const XiTables& xt, double c10, double c20, double beta,
+                             const Vec6& E, hipStream_t s);
 void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps, const Vec6& E, const Vec6& R,
                      bool add_R, double* partial, double* sumsq6, const XHalo& h, hipStream_t s);
 void launch_transpose_A(const double* src, double* dst, int nxl, int ny, int nyl, int nzc, bool to_blocks, hipStream_t s);

@@ -426,6 +426,78 @@ __global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables
   }
 }
 
+// ----------------------------------------------------------------------------- collocated Gamma operator
+// GammaOperatorFourierCollocated  F:19381-19608 (freq_hack off): per frequency the real symmetric 6x6
+// Gamma0_hat built from xi = m/d (F:19434-19456), eta_hat_i = sum_j g_ij tau_hat_j (x2 for the shear columns)
+// + beta tau_hat_i, in place on the six complex components; the zero frequency is set to E (F:19605-19607).
+__global__ __launch_bounds__(kBlock) void k_gamma_collocated(Grid g, FieldPtrs<6> th, XiTables xt, double c10, double c20,
+                                                             double beta, Vec6 E) {
+  const long nfreq = (long)g.nx * g.ny * g.nzc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < nfreq; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / g.nzc;
+    const int kk = (int)(idx - row * g.nzc);
+    if (kk >= g.nzf) continue;  // row padding
+    const int ii = (int)(row / g.ny);
+    const int jj = (int)(row - (long)ii * g.ny);
+    cplx t[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) t[c] = reinterpret_cast<const cplx*>(th.p[c])[idx];
+    cplx ey[6];
+    if (ii == 0 && jj == 0 && kk == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) ey[c] = cmake(E.v[c], 0.0);
+    } else {
+      const double xi0 = xt.xi[0][ii], xi1 = xt.xi[1][jj], xi2 = xt.xi[2][kk];
+      const double xi00 = xi0 * xi0, xi01 = xi0 * xi1, xi11 = xi1 * xi1;
+      const double xi02 = xi0 * xi2, xi12 = xi1 * xi2, xi22 = xi2 * xi2;
+      const double norm_xi2 = xi00 + xi11 + xi22;
+      const double c1 = c10 / (norm_xi2);
+      const double c12 = c1 * 2;
+      const double c2 = c20 / (norm_xi2 * norm_xi2);
+      const double c3 = (c12 + c2 * xi00);
+      const double c4 = (c12 + c2 * xi11);
+      const double c5 = (c12 + c2 * xi22);
+      double G[6][6];
+      G[0][0] = (c12 + c3) * xi00;
+      G[1][0] = c2 * xi00 * xi11;
+      G[2][0] = c2 * xi00 * xi22;
+      G[3][0] = c2 * xi00 * xi12;
+      G[4][0] = c3 * xi02;
+      G[5][0] = c3 * xi01;
+      G[1][1] = (c12 + c4) * xi11;
+      G[2][1] = c2 * xi11 * xi22;
+      G[3][1] = c4 * xi12;
+      G[4][1] = c2 * xi11 * xi02;
+      G[5][1] = c4 * xi01;
+      G[2][2] = (c12 + c5) * xi22;
+      G[3][2] = c5 * xi12;
+      G[4][2] = c5 * xi02;
+      G[5][2] = c2 * xi22 * xi01;
+      G[3][3] = (c1 * (xi11 + xi22) + c2 * xi11 * xi22);
+      G[4][3] = (c1 + c2 * xi22) * xi01;
+      G[5][3] = (c1 + c2 * xi11) * xi02;
+      G[4][4] = (c1 * (xi00 + xi22) + c2 * xi00 * xi22);
+      G[5][4] = (c1 + c2 * xi00) * xi12;
+      G[5][5] = (c1 * (xi00 + xi11) + c2 * xi00 * xi11);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) G[i][j] = G[j][i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        // tau0*g0 + tau1*g1 + tau2*g2 + (tau3*g3 + tau4*g4 + tau5*g5)*2, real and imaginary parts alike
+        const double ar = t[0].re * G[i][0] + t[1].re * G[i][1] + t[2].re * G[i][2] +
+                          (t[3].re * G[i][3] + t[4].re * G[i][4] + t[5].re * G[i][5]) * 2.0;
+        const double ai = t[0].im * G[i][0] + t[1].im * G[i][1] + t[2].im * G[i][2] +
+                          (t[3].im * G[i][3] + t[4].im * G[i][4] + t[5].im * G[i][5]) * 2.0;
+        ey[i] = cmake(ar + beta * t[i].re, ai + beta * t[i].im);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) reinterpret_cast<cplx*>(th.p[c])[idx] = ey[c];
+  }
+}
+
 // ----------------------------------------------------------------------------- strain + norm
 // epsOperatorStaggered  F:18614-18692, followed by eps += R (applyBCProjector  F:20263-20270)
 // and the per-component sums of squares of component_norm (F:10088-10138) fused in.
@@ -783,6 +855,13 @@ void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double
                hipStream_t s) {
   const long nfreq = lay.transposed ? (long)lay.nyl * g.nx * g.nzc : (long)g.nx * g.ny * g.nzc;
   hipLaunchKernelGGL(k_g0, dim3(grid_for(nfreq, 1 << 20)), dim3(kBlock), 0, s, g, fh, tb, c10, c20, lay);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_gamma_collocated(const Grid& g, const FieldPtrs<6>& th, const XiTables& xt, double c10, double c20, double beta,
+                             const Vec6& E, hipStream_t s) {
+  const long nfreq = (long)g.nx * g.ny * g.nzc;
+  hipLaunchKernelGGL(k_gamma_collocated, dim3(grid_for(nfreq, 1 << 20)), dim3(kBlock), 0, s, g, th, xt, c10, c20, beta, E);
   FG_HIP_CHECK(hipGetLastError());
 }
 

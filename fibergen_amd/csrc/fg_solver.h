@@ -36,6 +36,7 @@ struct SolverOptions {
   double eps_g = 2.220446049250313e-16;          // laminate tolerances F:13110-13111
   double eps_a = 3.666852862501036e-11;          // eps^(2/3)
   int mode = 0;                 // 0 = elasticity, 1 = scalar (heat / porous: 3-component gradient, 1-component potential)
+  int gamma_scheme = 0;         // 0 = staggered (GammaOperatorStaggered F:20288), 1 = collocated (GammaOperatorCollocated F:20302)
   int method = 0;               // 0 = basic scheme (runBasic F:21716), 1 = conjugate gradients (runCGElasticity F:23153)
   int u_loop = 2;               // Voigt, pure strain BC: displacement-based pass (0 off, 1 exact operation order,
                                 // 2 precomputed effective moduli + FMA, agrees with 1 to rounding)
@@ -174,6 +175,7 @@ class Solver {
   int* herr_ = nullptr;
   double* g0_kpm_[3] = {nullptr, nullptr, nullptr};
   cplx* g0_kp_[3] = {nullptr, nullptr, nullptr};
+  double* xi_[3] = {nullptr, nullptr, nullptr};  // collocated scheme: signed frequency / cell size per axis
 
   hostmath::Mat6 BC_P_, BC_Q_, BC_M_, BC_MQ_, BC_QC0_;
   double F00_[6];

@@ -111,6 +111,12 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
     FG_HIP_CHECK(hipMalloc(&g0_kp_[a], cnt * sizeof(cplx)));
     FG_HIP_CHECK(hipMemcpy(g0_kpm_[a], kpm.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(g0_kp_[a], kp.data(), cnt * sizeof(cplx), hipMemcpyHostToDevice));
+    // GammaOperatorFourierCollocated  F:19385, 19411-19424: xi = (1/d) * signed index
+    std::vector<double> xi(cnt);
+    const double xi_c0 = 1 / d[a];
+    for (size_t i = 0; i < (size_t)cnt; ++i) xi[i] = xi_c0 * ((i <= half) ? (double)i : ((double)i - (double)n));
+    FG_HIP_CHECK(hipMalloc(&xi_[a], cnt * sizeof(double)));
+    FG_HIP_CHECK(hipMemcpy(xi_[a], xi.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
   }
 
   BC_P_ = voigt_id4();
@@ -136,6 +142,7 @@ Solver::~Solver() {
   for (int a = 0; a < 3; ++a) {
     if (g0_kpm_[a]) (void)hipFree(g0_kpm_[a]);
     if (g0_kp_[a]) (void)hipFree(g0_kp_[a]);
+    if (xi_[a]) (void)hipFree(xi_[a]);
   }
   (void)hipEventDestroy(ev_[0]);
   (void)hipEventDestroy(ev_[1]);
@@ -311,6 +318,39 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     for (int c = 0; c < 6; ++c) F00_[c] = hscal_[kSlotMean + c] / (double)nglobal_;
   }
 
+  if (opt_.gamma_scheme == 1) {
+    // GammaOperatorCollocated  F:20302-20310: fftTensor, Gamma0_hat, fftInvTensor on the six components
+    if (frobenius(BC_MQ_) >= kEps || opt_.bc_relax != 1.0)
+      throw std::runtime_error("gamma_scheme=collocated supports prescribed mean strains only (projector = identity)");
+    time_begin(0);
+    launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, nrm, ptrs6(tau_), derr_, stream_);
+    time_end(0);
+    time_begin(2);
+    fft_->forward(tau_, 6, g_.n, 1 / (double)nglobal_);   // fftTensor: 1/N on the forward transform  F:18531-18560
+    time_end(2);
+    XiTables xt;
+    for (int a = 0; a < 3; ++a) xt.xi[a] = xi_[a];
+    Vec6 Ev;
+    for (int c = 0; c < 6; ++c) Ev.v[c] = E6[c];
+    const double c10 = alpha / (4 * opt_.mu_0);
+    const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    time_begin(5);
+    launch_gamma_collocated(g_, ptrs6(tau_), xt, c10, c20, 0.0, Ev, stream_);
+    time_end(5);
+    time_begin(8);
+    fft_->inverse(tau_, 6, g_.n);
+    time_end(8);
+    time_begin(9);
+    launch_copy(tau_, dst, 6 * g_.n, stream_);
+    launch_sum6(g_, ptrs6(dst), true, partial_, dscal_ + kSlotSumSq, stream_);
+    time_end(9);
+    if (timing_) times_.count++;
+    u_valid_ = false;
+    if (dst == eps_) eps_stale_ = false;
+    for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
+    return;
+  }
+
   // initBCProjector  F:20228-20239 needs <tau> only for mixed boundary conditions
   double F0[6] = {0, 0, 0, 0, 0, 0};
   const bool mq_zero = frobenius(BC_MQ_) < kEps;
@@ -477,7 +517,7 @@ bool Solver::u_loop_eligible() const {
       throw std::runtime_error("heat / porous mode supports prescribed mean gradients only (projector = identity)");
     return pt_.n >= 1;
   }
-  return opt_.u_loop && nranks_ == 1 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
+  return opt_.u_loop && opt_.gamma_scheme == 0 && nranks_ == 1 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
          frobenius(BC_MQ_) < kEps;
 }
 

@@ -246,8 +246,8 @@ class FG:
         scheme = self._child_value(solver, "gamma_scheme", "auto", str)
         if scheme == "auto":
             scheme = "staggered"
-        if scheme != "staggered":
-            raise RuntimeError("Unknown gamma scheme '%s' (MI355X path: staggered)" % scheme)
+        if scheme not in ("staggered", "collocated") or (scheme == "collocated" and scalar):
+            raise RuntimeError("Unknown gamma scheme '%s' (MI355X path: staggered, collocated for elasticity)" % scheme)
         est = self._child_value(solver, "error_estimator", "epsilon", str)
         if est != "epsilon":
             raise RuntimeError("error estimator '%s' is not available (epsilon only)" % est)
@@ -258,7 +258,7 @@ class FG:
             raise RuntimeError("mixing rule '%s' is not available in %s mode (voigt only)" % (mixing, mode))
 
         lss = LSSolver(nx, ny, nz, dx, dy, dz, device=self._device)
-        opts = {"mode": mode, "mixing_rule": mixing, "method": method}
+        opts = {"mode": mode, "mixing_rule": mixing, "method": method, "gamma_scheme": scheme}
         for k in _SOLVER_DOUBLE_KEYS:
             v = self._child_value(solver, k, None)
             if v is not None:

@@ -88,6 +88,10 @@ class LSSolver:
                 if v not in ("basic", "cg"):
                     raise RuntimeError("Unknown solver method '%s'" % v)
                 self._check(self._lib.fg_set_option_i(self._h, b"method", 1 if v == "cg" else 0))
+            elif k == "gamma_scheme":
+                if v not in ("staggered", "collocated"):
+                    raise RuntimeError("Unknown gamma scheme '%s'" % v)
+                self._check(self._lib.fg_set_option_i(self._h, b"gamma_scheme", 1 if v == "collocated" else 0))
             elif k == "mode":
                 if v not in ("elasticity", "heat", "porous"):
                     raise RuntimeError("mode '%s' is not available on the MI355X path" % v)

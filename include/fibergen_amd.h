@@ -73,6 +73,7 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * Keys (integer): maxiter, mixing_rule (FG_MIXING_*), update_ref (0 = "never"), mode (0 = elasticity, 1 = heat /
  * porous F:15224-15228: fields "epsilon" / "sigma" have 3 components (gradient, flux), "u" one (the potential); mu of
  * fg_set_phase is the conductivity; E6 / S6 / out6 arrays carry 3 values followed by zeros; Voigt mixing, basic scheme),
+ * gamma_scheme (0 = staggered, 1 = collocated: GammaOperatorCollocated F:20302-20310, Fourier-space 6x6 Gamma0),
  * method (0 = basic scheme, runBasic F:21716-21805; 1 = conjugate gradients, runCGElasticity
  * F:23153-23247, the reference's default), and the implementation switches u_loop,
  * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), fuse_z (1, 0, -1 = by size). */

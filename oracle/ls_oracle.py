@@ -12,6 +12,7 @@ boost / FFTW / LAPACK are absent).
 Pinning (see tests/test_oracle_pins.py): the reference holds no numeric
 fixtures; the oracle is pinned against the reference's own known answers:
   * "staggered epsG0div identity" self-test          F:24129-24151 (tol sqrt(eps))
+  * "collocated epsG0div identity" self-test         F:24085-24105 (tol sqrt(eps))
   * closed-form isotropic laminate                   F:26405-26474 / demo/elasticity/laminate
   * Hashin coated sphere <sigma> = 12.9152 I         demo/elasticity/hashin/project.xml:30-32
   * homogeneous medium => eps == E after one pass
@@ -402,6 +403,7 @@ class LSOracle:
     mu_0: float = float("nan")
     lambda_0: float = 0.0
     update_ref: str = "loadstep"
+    gamma_scheme: str = "staggered"               # or "collocated" (GammaOperatorCollocated F:20302-20310)
 
     def __post_init__(self):
         self.N = self.nx * self.ny * self.nz
@@ -681,10 +683,67 @@ class LSOracle:
         eta = eta + R[:, None, None, None]
         return eta
 
+    def gamma_collocated(self, E, mu_0, lambda_0, tau, alpha=-1.0, beta=0.0):
+        """GammaOperatorCollocated  F:20302-20310 = fftTensor (1/N, F:18531-18560),
+        GammaOperatorFourierCollocated  F:19381-19608 (freq_hack off), fftInvTensor; pure strain BC."""
+        if np.linalg.norm(self.BC_MQ) >= EPS:
+            raise RuntimeError("collocated restatement: prescribed mean strains only")
+        th = np.fft.rfftn(tau, axes=(1, 2, 3)) * (1 / float(self.N))
+        xi = []
+        for n, d in ((self.nx, self.dx), (self.ny, self.dy), (self.nz, self.dz)):
+            half = (n // 2 - 1) if (n % 2 == 0) else n // 2
+            xi.append(np.array([(1 / d) * (float(i) if i <= half else (float(i) - float(n))) for i in range(n)]))
+        nzc = self.nz // 2 + 1
+        xi0 = xi[0][:, None, None]
+        xi1 = xi[1][None, :, None]
+        xi2 = xi[2][None, None, :nzc]
+        xi00, xi01, xi11 = xi0 * xi0, xi0 * xi1, xi1 * xi1
+        xi02, xi12, xi22 = xi0 * xi2, xi1 * xi2, xi2 * xi2
+        c10 = alpha / (4 * mu_0)
+        c20 = -alpha / (mu_0 * (1 + mu_0 / (lambda_0 + mu_0)))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            norm_xi2 = xi00 + xi11 + xi22
+            c1 = c10 / norm_xi2
+            c12 = c1 * 2
+            c2 = c20 / (norm_xi2 * norm_xi2)
+            c3, c4, c5 = c12 + c2 * xi00, c12 + c2 * xi11, c12 + c2 * xi22
+            G = {}
+            G[0, 0] = (c12 + c3) * xi00
+            G[1, 0] = c2 * xi00 * xi11
+            G[2, 0] = c2 * xi00 * xi22
+            G[3, 0] = c2 * xi00 * xi12
+            G[4, 0] = c3 * xi02
+            G[5, 0] = c3 * xi01
+            G[1, 1] = (c12 + c4) * xi11
+            G[2, 1] = c2 * xi11 * xi22
+            G[3, 1] = c4 * xi12
+            G[4, 1] = c2 * xi11 * xi02
+            G[5, 1] = c4 * xi01
+            G[2, 2] = (c12 + c5) * xi22
+            G[3, 2] = c5 * xi12
+            G[4, 2] = c5 * xi02
+            G[5, 2] = c2 * xi22 * xi01
+            G[3, 3] = c1 * (xi11 + xi22) + c2 * xi11 * xi22
+            G[4, 3] = (c1 + c2 * xi22) * xi01
+            G[5, 3] = (c1 + c2 * xi11) * xi02
+            G[4, 4] = c1 * (xi00 + xi22) + c2 * xi00 * xi22
+            G[5, 4] = (c1 + c2 * xi00) * xi12
+            G[5, 5] = c1 * (xi00 + xi11) + c2 * xi00 * xi11
+            g = lambda i, j: G[(i, j)] if i >= j else G[(j, i)]
+            eh = np.empty_like(th)
+            for i in range(6):
+                ey = th[0] * g(i, 0) + th[1] * g(i, 1) + th[2] * g(i, 2) + \
+                    (th[3] * g(i, 3) + th[4] * g(i, 4) + th[5] * g(i, 5)) * 2.0
+                eh[i] = ey + beta * th[i]
+        eh[:, 0, 0, 0] = np.asarray(E, dtype=np.float64)   # F:19605-19607
+        return np.fft.irfftn(eh, s=(self.nx, self.ny, self.nz), axes=(1, 2, 3)) * float(self.N)
+
     def basic_scheme(self, E, eps):
         """basicScheme  F:20558-20578: eps <- E - Gamma0 : (C - C0) : eps"""
         self._F00 = eps.reshape(6, -1).sum(axis=1) / self.N if self.bc_relax != 1.0 else np.zeros(6)
         tau = self.calc_stress(self.mu_0, self.lambda_0, eps)
+        if self.gamma_scheme == "collocated":
+            return self.gamma_collocated(E, self.mu_0, self.lambda_0, tau, -1.0)
         return self.gamma_staggered(E, self.mu_0, self.lambda_0, tau, -1.0)
 
     def component_norm(self, eps):

@@ -306,3 +306,19 @@ def test_vtk_output_of_a_load_case(tmp_path):
     np.testing.assert_allclose(fp["phi_incl"][0], fg.get_field("incl")[0], rtol=1e-6, atol=1e-7)  # restype applies too
     for i in range(1, 7):
         assert os.path.exists(out + "/results_%d.vtk" % i)
+
+
+def test_fg_collocated_scheme_project():
+    """<gamma_scheme>collocated</gamma_scheme> through FG: Ceff equals the oracle's collocated loop on the same phases."""
+    fg = FG()
+    fg.set_xml("""
+    <settings><solver n="15"><method>basic</method><gamma_scheme>collocated</gamma_scheme><tol>1e-8</tol>
+      <materials><matrix E="1" nu="0.3" /><incl E="10" nu="0.2" /></materials></solver>
+      <actions><select_material name="incl" /><place_fiber R="0.3" /><calc_effective_properties /></actions></settings>""")
+    assert fg.run() == 0
+    C = np.array(fg.get_effective_property())
+    phi = fg.get_field("phi")
+    m0, m1 = material_from_pair(E=1, nu=0.3), material_from_pair(E=10, nu=0.2)
+    o = LSOracle(15, 15, 15, mats=[(m0["mu"], m0["lambda"]), (m1["mu"], m1["lambda"])], phis=[phi[0], phi[1]],
+                 tol=1e-8, gamma_scheme="collocated")
+    assert rel_err(C, o.calc_effective_properties()) < 1e-9

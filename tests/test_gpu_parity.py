@@ -386,3 +386,51 @@ def test_cg_mixed_bc_and_maxiter():
     s.set_options(maxiter=2)
     assert s.run(E, np.zeros(6)) is False
     assert s.iterations == 2 and len(s.residuals) == 3
+
+
+# ------------------------------------------------------------------------------------------------
+# gamma_scheme = collocated (GammaOperatorCollocated  F:20302-20310), SURVEY 8a row "Gamma c"
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("grid,dims", [((9, 7, 5), (1.0, 1.0, 1.0)), ((16, 16, 16), (1.0, 1.0, 1.0)),
+                                       ((12, 10, 6), (2.0, 1.0, 0.5)), ((32, 16, 64), (1.0, 1.0, 1.0))])
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_collocated_pass_and_run_match_oracle(grid, dims, mixing):
+    E = np.array([1.0, 0.2, -0.3, 0.1, 0.0, 0.5])
+    rng = np.random.default_rng(11)
+    eps0 = rng.standard_normal((6,) + grid)
+    s = make_gpu_solver(grid, dims, mixing, tol=1e-8, gamma_scheme="collocated", mu_0=0.9, lambda_0=0.2)
+    o = make_oracle(grid, dims, mixing, tol=1e-8, gamma_scheme="collocated")
+    o.mu_0, o.lambda_0 = 0.9, 0.2
+    s.set_field("epsilon", eps0)
+    s.run_stage("iteration", E)
+    one = s.get_field("epsilon")
+    ref = o.basic_scheme(E, eps0)
+    assert rel_err(one, ref) < 1e-12
+    np.testing.assert_allclose(one.reshape(6, -1).mean(axis=1), E, atol=1e-12)   # zero frequency = E
+    # converged run
+    s2 = make_gpu_solver(grid, dims, mixing, tol=1e-8, gamma_scheme="collocated")
+    o2 = make_oracle(grid, dims, mixing, tol=1e-8, gamma_scheme="collocated")
+    assert s2.run(E) is False and o2.run(E) is False
+    assert s2.iterations == o2.iterations
+    np.testing.assert_allclose(s2.residuals, o2.residuals, rtol=0, atol=1e-11)
+    assert rel_err(s2.get_field("epsilon"), o2.eps) < 1e-9
+    assert rel_err(s2.mean_stress(), o2.mean_stress()) < 1e-10
+    s.close()
+    s2.close()
+
+
+def test_collocated_cg_and_restrictions():
+    grid = (9, 9, 9)
+    E = np.array([0.0, 1.0, 0, 0, 0.3, 0])
+    s = make_gpu_solver(grid, tol=1e-8, gamma_scheme="collocated", method="cg")
+    o = make_oracle(grid, tol=1e-8, gamma_scheme="collocated")
+    assert s.run(E) is False and o.run_cg(E) is False
+    assert s.iterations == o.iterations
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
+    # mixed boundary conditions are a staggered-scheme feature here
+    P = np.diag([1.0, 1.0, 0.0, 0.5, 0.5, 0.5])
+    s.set_options(method="basic")
+    s.set_bc_projector(P)
+    with pytest.raises(RuntimeError, match="collocated"):
+        s.run(np.array([1.0, 0, 0, 0, 0, 0]))
+    s.close()

@@ -63,6 +63,48 @@ def test_staggered_epsG0div_identity(grid, dims):
     assert np.linalg.norm(diff) <= SQRT_EPS * scale
 
 
+@pytest.mark.parametrize("grid,dims", [
+    ((2, 1, 1), (1, 1, 1)),                # F:27261
+    ((41, 33, 11), (1, 1, 1)),             # F:27266
+    ((41, 33, 11), (41, 33, 11)),          # F:27271
+    ((7, 5, 9), (1.1, 10.4, 2.23)),
+])
+def test_collocated_epsG0div_identity(grid, dims):
+    """'collocated epsG0div identity'  F:24085-24105: eta = Gamma(tau) with alpha = 1, E = 0 is a compatible
+    zero-mean field, and Gamma(C0 : eta) gives it back; C0 = (324.2, 1324.3) F:24007-24008.  The reference runs
+    it on its three active self-test grids (F:27258-27273); the even-sized fourth one is disabled there
+    (F:27274-27280) -- at a Nyquist plane the operator is not Hermitian-consistent and the identity fails."""
+    nx, ny, nz = grid
+    o = LSOracle(nx, ny, nz, *dims, gamma_scheme="collocated")
+    lam0, mu0 = 324.2, 1324.3
+    rng = np.random.default_rng(3)
+    tau = rng.standard_normal((6, nx, ny, nz))
+    Z = np.zeros(6)
+    org = o.gamma_collocated(Z, mu0, lam0, tau, 1.0)
+    back = o.gamma_collocated(Z, mu0, lam0, o.calc_stress_const(mu0, lam0, org), 1.0)
+    diff = np.abs(back - org).reshape(6, -1).max(axis=1)
+    assert np.linalg.norm(diff) <= SQRT_EPS * max(1.0, np.abs(org).max())
+    assert np.abs(org.reshape(6, -1).mean(axis=1)).max() < 1e-12   # zero frequency = E = 0
+
+
+def test_collocated_scheme_same_laminate_as_staggered():
+    """Layered medium: both discretisations reproduce the closed-form laminate (calc_isotropic_laminate F:26405-26446)."""
+    from oracle.ls_oracle import isotropic_laminate_ceff
+    shape = (11, 1, 1)   # odd: no Nyquist plane (see the identity test)
+    ms = [material_from_pair(E=100.0, nu=0.4), material_from_pair(E=25.0, nu=0.25), material_from_pair(E=50.0, nu=0.3)]
+    fr = [2 / 11, 3 / 11, 6 / 11]
+    edges = np.round(np.cumsum([0.0] + fr) * 11).astype(int)
+    phis = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        p = np.zeros(shape)
+        p[a:b] = 1.0
+        phis.append(p)
+    o = LSOracle(*shape, mats=[(m["mu"], m["lambda"]) for m in ms], phis=phis, tol=1e-12, gamma_scheme="collocated")
+    C = o.calc_effective_properties()
+    Cl = isotropic_laminate_ceff([(f, m["mu"], m["lambda"]) for f, m in zip(fr, ms)])
+    assert np.abs(C - Cl).max() / np.abs(Cl).max() < 1e-8
+
+
 def test_isotropic_material_derivative():
     """'isotropic material derivative'  F:24058-24083: dPK1 == PK1 by linearity."""
     rng = np.random.default_rng(2)
