@@ -170,8 +170,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=256, help="grid size per axis (128, 256, 512)")
     ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
-    ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat"],
-                    help="porous / heat: BASELINE config 5 (scalar potential, 3-component gradient; 256^3)")
+    ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat", "viscosity"],
+                    help="porous / heat: scalar potential, 3-component gradient; viscosity: dual Stokes scheme "
+                         "(BASELINE config 5, 256^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-slab", action="store_true", help="N > 1: skip the slab-decomposed measurement")
@@ -201,12 +202,15 @@ def main():
     K = int(round(40 * scale ** 3)) if args.n >= 128 else 5
     phi, normals = synthetic_fiber_rve(n, K=K, R=0.05 / scale, L=0.4 / scale, seed=0,
                                        with_normals=(args.mixing == "laminate"))
-    scalar = args.mode != "elasticity"
+    scalar = args.mode in ("porous", "heat")
+    stokes = args.mode == "viscosity"
     s = LSSolver(*n, device=local_rank)
-    if scalar:
+    if scalar or stokes:
         s.set_options(mode=args.mode)
     s.set_num_phases(2)
     mats = [(1.0, 0.0), (10.0, 0.0)] if scalar else [lame(**MATRIX), lame(**INCLUSION)]  # contrast 10
+    if stokes:
+        mats = [(1.0, 0.0), (0.1, 0.0)]   # fluid with ten times more viscous particles (fluidity constants)
     s.set_phase(0, mats[0][0], mats[0][1], 1.0 - phi)
     s.set_phase(1, mats[1][0], mats[1][1], phi)
     if normals is not None:
@@ -218,6 +222,9 @@ def main():
     # each rank its own load case (calc_effective_properties' unit strains / gradients)
     E = np.zeros(3 if scalar else 6)
     E[rank % E.size] = 1.0
+    if stokes:   # traceless prescribed stresses (F:26257-26261)
+        E = [np.array([1.0, -1, 0, 0, 0, 0]), np.array([0, 1.0, -1, 0, 0, 0]), np.array([0, 0, 0, 1.0, 0, 0]),
+             np.array([0, 0, 0, 0, 1.0, 0]), np.array([0, 0, 0, 0, 0, 1.0])][rank % 5]
 
     def sync():
         s.synchronize()  # the solver's own HIP stream carries all the work
@@ -281,7 +288,7 @@ def main():
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]}
         out = {
-            "metric": "LS iterations/sec (basic scheme, staggered grid, %s)" % ("linear elastic" if not scalar else
+            "metric": "LS iterations/sec (basic scheme, staggered grid, %s)" % (("linear elastic" if not stokes else "Stokes flow, dual scheme") if not scalar else
                                                                                args.mode + " scalar mode"),
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -301,10 +308,10 @@ def main():
             per = 24 + 7 * 16
             out["loop_GBps_Amin"] = per * N * (args.steps / dt) / 1e9
             out["loop_GBps_Astage"] = out["loop_GBps_Amin"]
-        if world == 1 and not args.no_cpu_baseline and not scalar:
+        if world == 1 and not args.no_cpu_baseline and not scalar and not stokes:
             s.close()
             out["cpu_baseline"] = cpu_baseline(n, args.mixing, args.cpu_budget)
-    if world > 1 and not args.no_slab and not scalar:
+    if world > 1 and not args.no_slab and not scalar and not stokes:
         # Second measurement: ONE problem slab-decomposed over all ranks (x-slabs, two RCCL
         # all-to-alls per pass).  Guarded: a failure or a stall here must not cost the line above.
         s.close()

@@ -148,7 +148,7 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       o.mixing = (int)value;
     } else if (k == "update_ref") o.update_ref = value != 0;
     else if (k == "mode") {
-      if (value != 0 && value != 1) throw std::runtime_error("mode must be 0 (elasticity) or 1 (heat / porous)");
+      if (value < 0 || value > 2) throw std::runtime_error("mode must be 0 (elasticity), 1 (heat / porous) or 2 (viscosity)");
       o.mode = (int)value;
     }
     else if (k == "gamma_scheme") {

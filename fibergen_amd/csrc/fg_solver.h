@@ -35,7 +35,8 @@ struct SolverOptions {
   double lambda_0 = 0.0;
   double eps_g = 2.220446049250313e-16;          // laminate tolerances F:13110-13111
   double eps_a = 3.666852862501036e-11;          // eps^(2/3)
-  int mode = 0;                 // 0 = elasticity, 1 = scalar (heat / porous: 3-component gradient, 1-component potential)
+  int mode = 0;                 // 0 = elasticity, 1 = scalar (heat / porous: 3-component gradient, 1-component potential),
+                                // 2 = viscosity (dual Stokes scheme: DeltaOperatorStaggered F:20422-20460, 6 components)
   int gamma_scheme = 0;         // 0 = staggered (GammaOperatorStaggered F:20288), 1 = collocated (GammaOperatorCollocated F:20302)
   int method = 0;               // 0 = basic scheme (runBasic F:21716), 1 = conjugate gradients (runCGElasticity F:23153)
   int u_loop = 2;               // Voigt, pure strain BC: displacement-based pass (0 off, 1 exact operation order,
@@ -131,13 +132,15 @@ class Solver {
   void u_pass_front(const double* E6);  // u_k (fu_) -> sums of squares of eps_k, f_{k+1} (fu_alt_)
   void u_pass_back();                   // f_{k+1} -> u_{k+1}, buffers swapped
   // r2c (unless z_done: buf already holds the z spectrum), y, x + Green operator + x^-1, y^-1, c2r on 3 components
-  void fft_g0_chain(double* buf, bool z_done = false, double alpha = -1.0);
+  // c12: optional {c10, c20} replacing the factors derived from (mu_0, lambda_0, alpha)
+  void fft_g0_chain(double* buf, bool z_done = false, double alpha = -1.0, const double* c12 = nullptr);
   void ensure_eps();                    // materialise eps = E + sym grad u if the loop left it implicit
   void recompute_bc();
   double bc_error(const double* E_cur, const double* S_cur);
   StressParams stress_params(double mu_0, double lambda_0, double alpha) const;
   ScalarParams scalar_params(double mu_0, double alpha) const;
   FieldPtrs<kMaxPhases> phase_ptrs() const;
+  PhaseTable phase_table() const;  // constants the kernels see (viscosity: Hooke constants equivalent to the scalar law)
   FieldPtrs<6> ptrs6(double* base) const;
   FieldPtrs<3> ptrs3(double* base) const;
   void check_device_error(const char* where);

@@ -241,9 +241,19 @@ FieldPtrs<3> Solver::ptrs3(double* base) const {
   return f;
 }
 
+// mode = viscosity: ScalarLinearIsotropicMaterialLaw(6) with mu *= 0.5 (F:15234-15239), S = E * (alpha * mu / 2).
+// The Hooke kernels give S = E * (2 alpha mu') + alpha lambda' tr(E): mu' = mu / 4, lambda' = 0 is the same
+// arithmetic (scalings by powers of two are exact, the added zero changes nothing).
+PhaseTable Solver::phase_table() const {
+  PhaseTable t = pt_;
+  if (opt_.mode == 2)
+    for (int q = 0; q < kMaxPhases; ++q) t.mu[q] = 0.25 * pt_.mu[q], t.lambda[q] = 0.0;
+  return t;
+}
+
 StressParams Solver::stress_params(double mu_0, double lambda_0, double alpha) const {
   StressParams sp;
-  sp.pt = pt_;
+  sp.pt = phase_table();
   sp.mixing = opt_.mixing;
   sp.mu_0 = mu_0;
   sp.lambda_0 = lambda_0;
@@ -318,6 +328,44 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     for (int c = 0; c < 6; ++c) F00_[c] = hscal_[kSlotMean + c] / (double)nglobal_;
   }
 
+  if (opt_.mode == 2) {
+    // DeltaOperatorStaggered  F:20422-20460 (dual Stokes scheme), called with alpha = -1 by basicScheme:
+    //   m = 1/(4 mu0);  adj = E - 2 alpha m <tau>;  eta = GammaStaggered(adj; mu = -1/(4 m), lambda = inf)(tau)
+    //   + 2 alpha m tau.   lambda0 = inf makes c20 = c10 in G0OperatorFourierStaggered (F:19749-19755).
+    if (opt_.gamma_scheme != 0) throw std::runtime_error("viscosity mode supports gamma_scheme=staggered only");
+    if (opt_.mixing != kMixVoigt) throw std::runtime_error("viscosity mode supports Voigt mixing only");
+    if (frobenius(BC_MQ_) >= kEps || opt_.bc_relax != 1.0)
+      throw std::runtime_error("viscosity mode supports prescribed mean values only (projector = identity)");
+    const double m = 1 / (4 * opt_.mu_0);
+    time_begin(0);
+    launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, nrm, ptrs6(tau_), derr_, stream_);
+    time_end(0);
+    launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);   // tau_copy->average()
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    Vec6 adj, R;
+    for (int c = 0; c < 6; ++c) {
+      adj.v[c] = E6[c] - 2 * alpha * m * (hscal_[kSlotMean + c] / (double)nglobal_);
+      R.v[c] = 0.0;
+    }
+    time_begin(1);
+    launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
+    time_end(1);
+    const double mu_g = -1.0 / (4 * m);
+    const double c12[2] = {-alpha / mu_g, -alpha / mu_g};
+    fft_g0_chain(fu_, false, alpha, c12);
+    time_begin(9);
+    launch_eps_norm(g_, ptrs3(fu_), ptrs6(dst), adj, R, false, partial_, dscal_ + kSlotScratch,
+                    XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
+    // eta.xpay(eta, 2 alpha m, tau_copy)  F:20452, with the sums of squares of the result
+    launch_cg(2, g_, ptrs6(dst), ptrs6(tau_), ptrs6(tau_), adj, 2 * alpha * m, partial_, dscal_ + kSlotSumSq, stream_);
+    time_end(9);
+    if (timing_) times_.count++;
+    u_valid_ = false;
+    if (dst == eps_) eps_stale_ = false;
+    for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
+    return;
+  }
   if (opt_.gamma_scheme == 1) {
     // GammaOperatorCollocated  F:20302-20310: fftTensor, Gamma0_hat, fftInvTensor on the six components
     if (frobenius(BC_MQ_) >= kEps || opt_.bc_relax != 1.0)
@@ -400,7 +448,7 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
   for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
 }
 
-void Solver::fft_g0_chain(double* buf, bool z_done, double alpha) {  // alpha = -1: GammaOperator(..., -1)  F:20575
+void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* c12) {  // alpha = -1: GammaOperator(..., -1)  F:20575
   if (opt_.mode == 1) {
     // G0OperatorStaggeredHeat  F:20118-20135 on one component: fftVector(., 1), c1 = c10/|k|^2, fftInvVector
     const double scale = 1 / (double)nglobal_;
@@ -460,6 +508,7 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha) {  // alpha = 
     G0Params gp;
     gp.c10 = -alpha / (opt_.mu_0);
     gp.c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    if (c12) gp.c10 = c12[0], gp.c20 = c12[1];
     G0Tables tb;
     for (int a = 0; a < 3; ++a) {
       tb.kpm[a] = gp.kpm[a] = g0_kpm_[a];
@@ -517,7 +566,7 @@ bool Solver::u_loop_eligible() const {
       throw std::runtime_error("heat / porous mode supports prescribed mean gradients only (projector = identity)");
     return pt_.n >= 1;
   }
-  return opt_.u_loop && opt_.gamma_scheme == 0 && nranks_ == 1 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
+  return opt_.u_loop && opt_.mode == 0 && opt_.gamma_scheme == 0 && nranks_ == 1 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
          frobenius(BC_MQ_) < kEps;
 }
 
@@ -563,7 +612,7 @@ void Solver::u_pass_front(const double* E6) {
     mod.p[0] = mod_;
     mod.p[1] = mod_ + g_.n;
     if (mod_dirty_) {
-      launch_effective_moduli(g_, pt_, phi, mod, stream_);
+      launch_effective_moduli(g_, phase_table(), phi, mod, stream_);
       mod_dirty_ = false;
     }
     const bool want_z = opt_.fuse_z > 0 || (opt_.fuse_z < 0 && (long)g_.nx * g_.ny * g_.nz <= (1L << 22));
@@ -684,7 +733,7 @@ void Solver::calc_ref_material() {
   if (opt_.mode == 1)
     launch_sc_minmax(g_, scalar_params(0.0, 1.0), phi, partial_, dscal_ + kSlotMinMax, stream_);
   else
-    launch_tangent_minmax(g_, pt_, opt_.mixing, phi, partial_, dscal_ + kSlotMinMax, derr_, stream_);
+    launch_tangent_minmax(g_, phase_table(), opt_.mixing, phi, partial_, dscal_ + kSlotMinMax, derr_, stream_);
   FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMinMax, dscal_ + kSlotMinMax, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
   check_device_error("reference material");
   double lambda_min = hscal_[kSlotMinMax], lambda_max = -hscal_[kSlotMinMax + 1];
@@ -736,7 +785,7 @@ bool Solver::run(const double* E6, const double* S6) {
     voigt_mv(BC_Q_, E0, t);
     if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
   }
-  if (opt_.method == 1 && opt_.mode == 1) throw std::runtime_error("method=cg is not available in heat / porous mode (use basic)");
+  if (opt_.method == 1 && opt_.mode != 0) throw std::runtime_error("method=cg is only available in elasticity mode (use basic)");
   if (opt_.method == 1) return run_cg(E0, S0);
   const double t_start = now_seconds();
   FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * g_.n * sizeof(double), stream_));  // F:21379
@@ -1041,7 +1090,7 @@ void Solver::local_sums(const std::string& what, double* out) {
                        dscal_ + kSlotMean, derr_, stream_);
   } else if (what == "tangent_minmax") {
     if (pt_.n < 1) throw std::runtime_error("No materials specified");
-    launch_tangent_minmax(g_, pt_, opt_.mixing, phi, partial_, dscal_ + kSlotMinMax, derr_, stream_);
+    launch_tangent_minmax(g_, phase_table(), opt_.mixing, phi, partial_, dscal_ + kSlotMinMax, derr_, stream_);
     n = 2;
     slot = kSlotMinMax;
   } else if (what.rfind("phi:", 0) == 0) {
@@ -1191,6 +1240,23 @@ void Solver::get_field(const std::string& name, double* out) {
     launch_stress(g_, stress_params(0.0, 0.0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
     check_device_error("sigma");
     for (int c = 0; c < 6; ++c) download_unpadded(tau_ + (long)c * g_.n, out + (long)c * g_.nxyz);
+    return;
+  }
+  if (name == "u" && opt_.mode == 2) {
+    // velocity  F:15528-15535: calcStressDiff, div, G0(1/(4 mu0), inf, alpha = 1/(2 mu0)): c10 = c20 = -alpha/mu = -2
+    FieldPtrs<kMaxPhases> phi = phase_ptrs();
+    FieldPtrs<3> nrm;
+    for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+    launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
+    check_device_error("u");
+    launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
+    const double a = 1 / (2 * opt_.mu_0), mu_g = 1 / (4 * opt_.mu_0);
+    const double c12[2] = {-a / mu_g, -a / mu_g};
+    const bool timing = timing_;
+    timing_ = false;
+    fft_g0_chain(fu_, false, a, c12);
+    timing_ = timing;
+    for (int c = 0; c < 3; ++c) download_unpadded(fu_ + (long)c * g_.n, out + (long)c * g_.nxyz);
     return;
   }
   if (name == "u") {  // u = G0 div (C0 : eps), alpha = 1  F:15509-15521

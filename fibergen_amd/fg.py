@@ -231,22 +231,22 @@ class FG:
         self._dims = (dx, dy, dz)
         self._x0 = x0
         mode = self._child_value(solver, "mode", "elasticity", str)
-        if mode not in ("elasticity", "heat", "porous"):
-            raise RuntimeError("mode '%s' is not available on the MI355X path (elasticity, heat, porous)" % mode)
+        if mode not in ("elasticity", "heat", "porous", "viscosity"):
+            raise RuntimeError("mode '%s' is not available on the MI355X path (elasticity, heat, porous, viscosity)" % mode)
         self._mode = mode
-        scalar = mode != "elasticity"
+        scalar = mode != "elasticity"      # laws with the single constant mu (ScalarLinearIsotropicMaterialLaw)
         method = self._child_value(solver, "method", "cg", str)
         if method not in ("basic", "cg"):
             raise RuntimeError("Unknown solver method '%s'" % method)
         if scalar and method == "cg":
             # same fixed point, different iteration history; the scalar modes run the basic scheme
-            log.info("heat / porous mode: method=cg is replaced by the basic scheme on the MI355X path")
+            log.info("%s mode: method=cg is replaced by the basic scheme on the MI355X path", mode)
             method = "basic"
         self._method = method
         scheme = self._child_value(solver, "gamma_scheme", "auto", str)
         if scheme == "auto":
             scheme = "staggered"
-        if scheme not in ("staggered", "collocated") or (scheme == "collocated" and scalar):
+        if scheme not in ("staggered", "collocated") or (scheme == "collocated" and scalar):  # scalar: any non-elastic mode
             raise RuntimeError("Unknown gamma scheme '%s' (MI355X path: staggered, collocated for elasticity)" % scheme)
         est = self._child_value(solver, "error_estimator", "epsilon", str)
         if est != "epsilon":
@@ -478,6 +478,44 @@ class FG:
         ix, iy, iz = rng(range_x, data.shape[1]), rng(range_y, data.shape[2]), rng(range_z, data.shape[3])
         return np.ascontiguousarray(data[np.ix_(ic, ix, iy, iz)])
 
+    def _effective_viscosity(self, outdir):
+        """calc_effective_properties, viscosity branch  F:26252-26347: five traceless stress experiments,
+        Ceff55 = E55 S55^-1, completion to 6x6 by tracelessness, row shift of the first three columns,
+        Voigt halving of the last three."""
+        E = np.zeros((6, 5))
+        E[0, 0] = E[1, 1] = 1
+        E[1, 0] = E[2, 1] = -1
+        E[3, 2] = E[4, 3] = E[5, 4] = 1
+        S = np.zeros((6, 5))
+        for i in range(5):
+            failed = self._lss.run(E[:, i])
+            stop = self._loadstep_callback is not None and self._loadstep_callback()
+            if failed or stop or self._error is not None:
+                self._error = self._error or "NaN detected in solution. Aborting."
+                return EXIT_FAILURE
+            S[:, i] = self._lss.mean_stress()
+            if outdir:
+                self.write_vtk("%s/results_%d.vtk" % (outdir, i + 1))
+        E55, S55 = E[1:6, :], S[1:6, :]
+        try:
+            C55 = E55 @ np.linalg.inv(S55)
+        except np.linalg.LinAlgError:
+            C55 = np.eye(5) * np.inf
+        C = np.zeros((6, 6))
+        C[1:6, 1:6] = C55
+        for i in range(5):
+            if S[0, i] != 0:
+                for j in range(1, 6):
+                    C[j, 0] = (E[j, i] - C[j, 1:6] @ S[1:6, i]) / S[0, i]
+                break
+        C[0, :] = -(C[1, :] + C[2, :])
+        C[:, :3] -= C[:, :3].min(axis=1)[:, None]
+        Cv = C.copy()
+        Cv[:, 3:6] *= 0.5
+        self._Ceff_voigt = Cv
+        log.info("Effective viscosity matrix \"2*eta\" (Voigt notation):\n%s", Cv)
+        return None
+
     def write_vtk(self, filename):
         """LSSolver::writeVTK  F:23317-23451: phase fractions, strain, stress and displacement of the current
         state as a legacy VTK file (format from <res_format>, value type from <restype>, F:25300, F:26552)."""
@@ -486,10 +524,16 @@ class FG:
         self.init_phase()
         st = self._settings()
         lss = self._lss
+        eps, sig = lss.get_field("epsilon"), lss.get_field("sigma")
+        if self._mode == "viscosity":
+            # dual scheme: the solver's "epsilon" is the fluid stress, its "sigma" the shear rate (F:23403-23416);
+            # the pressure field of the reference's file (a Poisson solve, F:23418-23430) is not written
+            eps, sig = sig, eps
         vtk.write_results(filename, lss.shape, self._dims, self._x0, self._phase_names, lss.get_field("phi"),
-                          lss.get_field("epsilon"), lss.get_field("sigma"), lss.get_field("u"),
+                          eps, sig, lss.get_field("u"),
                           binary=self._child_value(st, "res_format", "binary", str) == "binary",
-                          dtype=self._child_value(st, "restype", "float", str), mode=self._mode)
+                          dtype=self._child_value(st, "restype", "float", str),
+                          mode="elasticity" if self._mode == "viscosity" else self._mode)
 
     # ------------------------------------------------------------------ running
     def _on_iteration(self):
@@ -616,7 +660,7 @@ class FG:
             return None
         if name == "run_load_case":
             self.init_lss()
-            scalar = self._mode != "elasticity"
+            scalar = self._mode in ("heat", "porous")
             E = self._voigt_vector(act, "e")
             S = self._voigt_vector(act, "s")
             P = np.diag([1.0, 1.0, 1.0, 0.5, 0.5, 0.5])
@@ -632,6 +676,13 @@ class FG:
                     raise RuntimeError("%s mode supports prescribed mean gradients only on the MI355X path" % self._mode)
                 E, S = E[:3], None
                 P = np.diag([1.0, 1.0, 1.0, 0.5, 0.5, 0.5])
+            if self._mode == "viscosity":
+                # F:25975-25989: prescribed fluid stress and shear rate must be traceless
+                tol = 100.0 * np.finfo(np.float64).eps
+                if abs(E[0] + E[1] + E[2]) > tol:
+                    raise RuntimeError("Prescibed fluid stress %s has not zero trace!" % E)
+                if abs(S[0] + S[1] + S[2]) > tol:
+                    raise RuntimeError("Prescibed fluid strain %s has not zero trace!" % S)
             self.init_phase()
             self._lss.set_bc_projector(P)
             failed = self._lss.run(E, S)
@@ -668,6 +719,8 @@ class FG:
             self.init_lss()
             self.init_phase()
             outdir = self._attr(act, "outdir", "", str)
+            if self._mode == "viscosity":
+                return self._effective_viscosity(outdir)
             if self._mode != "elasticity":
                 # heat / porous branch  F:26115-26165: three unit gradients, Ceff = S E^-1 (3x3)
                 S = np.zeros((3, 3))

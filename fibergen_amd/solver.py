@@ -93,10 +93,10 @@ class LSSolver:
                     raise RuntimeError("Unknown gamma scheme '%s'" % v)
                 self._check(self._lib.fg_set_option_i(self._h, b"gamma_scheme", 1 if v == "collocated" else 0))
             elif k == "mode":
-                if v not in ("elasticity", "heat", "porous"):
+                if v not in ("elasticity", "heat", "porous", "viscosity"):
                     raise RuntimeError("mode '%s' is not available on the MI355X path" % v)
-                self.scalar = v != "elasticity"
-                self._check(self._lib.fg_set_option_i(self._h, b"mode", 1 if self.scalar else 0))
+                self.scalar = v in ("heat", "porous")
+                self._check(self._lib.fg_set_option_i(self._h, b"mode", {"elasticity": 0, "viscosity": 2}.get(v, 1)))
             elif k in ("u_loop", "fuse_x", "fuse_z", "fuse_stress_div"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
             elif k in ("maxiter",):

@@ -72,7 +72,9 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * ref_scale, bc_relax, mu_0, lambda_0 (the <ref> material), eps_g, eps_a (<laminate_mixing>).
  * Keys (integer): maxiter, mixing_rule (FG_MIXING_*), update_ref (0 = "never"), mode (0 = elasticity, 1 = heat /
  * porous F:15224-15228: fields "epsilon" / "sigma" have 3 components (gradient, flux), "u" one (the potential); mu of
- * fg_set_phase is the conductivity; E6 / S6 / out6 arrays carry 3 values followed by zeros; Voigt mixing, basic scheme),
+ * fg_set_phase is the conductivity; E6 / S6 / out6 arrays carry 3 values followed by zeros; Voigt mixing, basic scheme;
+ * 2 = viscosity F:15234-15239: dual Stokes scheme DeltaOperatorStaggered F:20422-20460, mu of fg_set_phase is the
+ * fluidity constant of the XML, "epsilon" holds the fluid stress, "sigma" the shear rate; Voigt mixing, basic scheme),
  * gamma_scheme (0 = staggered, 1 = collocated: GammaOperatorCollocated F:20302-20310, Fourier-space 6x6 Gamma0),
  * method (0 = basic scheme, runBasic F:21716-21805; 1 = conjugate gradients, runCGElasticity
  * F:23153-23247, the reference's default), and the implementation switches u_loop,

@@ -1,0 +1,102 @@
+"""GPU parity of mode=viscosity (dual Stokes scheme, DeltaOperatorStaggered F:20422-20460) against
+oracle/viscosity_oracle.py through the C ABI, and the FG project layer."""
+import numpy as np
+import pytest
+
+from helpers import rel_err, sphere_phi
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(grid, mus, phis, dims=(1.0, 1.0, 1.0), **kw):
+    from fibergen_amd import LSSolver
+    from oracle.viscosity_oracle import ViscosityOracle
+    s = LSSolver(*grid, *dims)
+    s.set_options(mode="viscosity")
+    s.set_num_phases(len(mus))
+    for p, (mu, phi) in enumerate(zip(mus, phis)):
+        s.set_phase(p, mu, 0.0, phi)
+    s.set_options(**kw)
+    o = ViscosityOracle(*grid, *dims, mats=[(m, 0.0) for m in mus], phis=phis, **kw)
+    return s, o
+
+
+@pytest.mark.parametrize("grid,dims", [((16, 16, 16), (1, 1, 1)), ((12, 10, 6), (2.0, 1.0, 0.5)), ((9, 7, 5), (1, 1, 1)),
+                                       ((32, 16, 64), (1, 1, 1))])
+def test_viscosity_run_matches_oracle(grid, dims):
+    phi1 = sphere_phi(grid, 0.3)
+    s, o = _pair(grid, [1.0, 0.05], [1 - phi1, phi1], dims, tol=1e-8)   # nearly rigid inclusion in a fluid
+    E = np.array([0.5, -0.5, 0.0, 0.2, 0.0, 1.0])
+    assert s.run(E) is False and o.run(E) is False
+    assert s.iterations == o.iterations
+    assert s.ref_material[0] == o.mu_0
+    np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-11)
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(s.get_field("sigma"), o.pk1(o.eps)) < 1e-9
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-10
+    np.testing.assert_allclose(s.mean_strain(), E, atol=1e-12)
+    assert rel_err(s.get_field("u"), o.velocity()) < 1e-8
+    # one raw pass from a random state
+    rng = np.random.default_rng(3)
+    e0 = rng.standard_normal((6,) + grid)
+    s.set_field("epsilon", e0)
+    s.run_stage("iteration", E)
+    assert rel_err(s.get_field("epsilon"), o.basic_scheme(E, e0)) < 1e-12
+    s.close()
+
+
+def test_viscosity_layered_fluid_means():
+    shape, fr, mus = (12, 4, 6), [0.25, 0.25, 0.5], [1.0, 4.0, 0.5]
+    edges = np.round(np.cumsum([0.0] + fr) * shape[0]).astype(int)
+    phis = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        p = np.zeros(shape)
+        p[a:b] = 1.0
+        phis.append(p)
+    s, _ = _pair(shape, mus, phis, tol=1e-12, maxiter=3000)
+    assert s.run(np.array([0, 0, 0, 0, 0, 1.0])) is False
+    assert s.mean_stress()[5] == pytest.approx(sum(f * m / 2 for f, m in zip(fr, mus)), rel=1e-13)
+    assert s.run(np.array([0, 0, 0, 1.0, 0, 0])) is False
+    assert s.mean_stress()[3] == pytest.approx(1 / sum(f / (m / 2) for f, m in zip(fr, mus)), rel=1e-9)
+    e = s.get_field("epsilon")
+    assert np.abs(e[0] + e[1] + e[2]).max() < 1e-13
+    s.set_options(method="cg")
+    with pytest.raises(RuntimeError, match="cg"):
+        s.run(np.array([0, 0, 0, 1.0, 0, 0]))
+    s.close()
+
+
+def test_fg_viscosity_project():
+    """mode=viscosity through FG: the five-experiment effective viscosity (F:26252-26347) equals the same
+    assembly on the oracle's mean shear rates; prescribed stresses must be traceless (F:25975-25989)."""
+    from fibergen_amd import FG
+    from oracle.viscosity_oracle import ViscosityOracle
+    fg = FG()
+    fg.set_xml("""
+    <settings><solver n="12"><mode>viscosity</mode><tol>1e-8</tol>
+      <materials><fluid mu="1" /><particle mu="0.05" /></materials></solver>
+      <actions><select_material name="particle" /><place_fiber R="0.3" />
+      <calc_effective_properties /></actions></settings>""")
+    assert fg.run() == 0
+    C = np.array(fg.get_effective_property())
+    assert C.shape == (6, 6)
+    phi = fg.get_field("phi")
+    o = ViscosityOracle(12, 12, 12, mats=[(1.0, 0.0), (0.05, 0.0)], phis=[phi[0], phi[1]], tol=1e-8)
+    E = np.zeros((6, 5))
+    E[0, 0] = E[1, 1] = 1
+    E[1, 0] = E[2, 1] = -1
+    E[3, 2] = E[4, 3] = E[5, 4] = 1
+    S = np.zeros((6, 5))
+    for i in range(5):
+        assert o.run(E[:, i]) is False
+        S[:, i] = o.mean_stress()
+    C55 = E[1:6] @ np.linalg.inv(S[1:6])
+    assert rel_err(C[3:6, 3:6], 0.5 * C55[2:5, 2:5]) < 1e-8
+    # suspension of nearly rigid spheres: effective viscosity above the fluid's (2 eta = 1/(mu/2) = 2)
+    assert C[3, 3] * 2 > 2.0 and C[3, 3] == pytest.approx(C[4, 4], rel=1e-6)
+    fg2 = FG()
+    fg2.set_xml("""
+    <settings><solver n="8"><mode>viscosity</mode><materials><fluid mu="1" /></materials></solver>
+      <actions><run_load_case e11="1" /></actions></settings>""")
+    with pytest.raises(RuntimeError, match="zero trace"):
+        fg2.run()

@@ -380,3 +380,46 @@ def test_scalar_sphere_within_bounds_and_isotropic():
         assert hs_lo * (1 - 2e-2) < K[i, i] < hs_hi
     assert K[0, 0] == pytest.approx(K[1, 1], rel=1e-8) and K[1, 1] == pytest.approx(K[2, 2], rel=1e-8)
     assert np.abs(K - K.T).max() < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------------
+# mode = viscosity (dual Stokes scheme): oracle/viscosity_oracle.py
+# ---------------------------------------------------------------------------------------------------
+def test_viscosity_layered_fluid_and_incompressibility():
+    """Layers across x.  Shear stress s12 acts across the layers: traction continuity makes it uniform, the
+    mean shear rate is the arithmetic mean of (fluidity/2) times it, reached at once.  In-plane shear s23 and the
+    planar extension s11 = -s22 see a uniform shear rate: harmonic mean.  The fields stay traceless."""
+    from oracle.viscosity_oracle import ViscosityOracle
+    shape, fr, mus = (12, 4, 6), [0.25, 0.25, 0.5], [1.0, 4.0, 0.5]
+    o = ViscosityOracle(*shape, mats=[(m, 0.0) for m in mus], phis=_layers_x(shape, fr), tol=1e-12, maxiter=3000)
+    arit = sum(f * m / 2 for f, m in zip(fr, mus))
+    harm = 1 / sum(f / (m / 2) for f, m in zip(fr, mus))
+    assert o.run(np.array([0, 0, 0, 0, 0, 1.0])) is False
+    assert o.iterations <= 2 and o.mean_stress()[5] == pytest.approx(arit, rel=1e-13)
+    assert o.run(np.array([0, 0, 0, 1.0, 0, 0])) is False
+    assert o.mean_stress()[3] == pytest.approx(harm, rel=1e-9)
+    assert o.run(np.array([1.0, -1.0, 0, 0, 0, 0])) is False
+    S = o.mean_stress()
+    assert S[0] == pytest.approx(harm, rel=1e-9) and S[1] == pytest.approx(-harm, rel=1e-9) and abs(S[2]) < 1e-12
+    assert np.abs(o.eps[0] + o.eps[1] + o.eps[2]).max() < 1e-13
+    np.testing.assert_allclose(o.mean_strain(), [1.0, -1.0, 0, 0, 0, 0], atol=1e-13)
+
+
+def test_viscosity_homogeneous_fluid_and_velocity_is_divergence_free():
+    from oracle.viscosity_oracle import ViscosityOracle
+    from helpers import sphere_phi
+    shape = (8, 6, 10)
+    one = np.ones(shape)
+    o = ViscosityOracle(*shape, mats=[(3.0, 0.0), (7.0, 0.0)], phis=[one, 0 * one])
+    E = np.array([0.5, -0.2, -0.3, 0.1, 0.0, 0.7])
+    assert o.run(E) is False and o.iterations <= 2
+    np.testing.assert_allclose(o.eps, E[:, None, None, None] * np.ones((6,) + shape), atol=1e-14)
+    np.testing.assert_allclose(o.mean_stress(), 1.5 * E, rtol=1e-13)
+    # heterogeneous: the velocity field of get_field("u") is discretely divergence free (lambda0 = infinity)
+    phi1 = sphere_phi(shape, 0.3)
+    o = ViscosityOracle(*shape, mats=[(1.0, 0.0), (0.05, 0.0)], phis=[1 - phi1, phi1], tol=1e-8)
+    assert o.run(np.array([0, 0, 0, 0, 0, 1.0])) is False
+    u = o.velocity()
+    hx, hy, hz = shape[0] / o.dx, shape[1] / o.dy, shape[2] / o.dz
+    div = (np.roll(u[0], -1, 0) - u[0]) * hx + (np.roll(u[1], -1, 1) - u[1]) * hy + (np.roll(u[2], -1, 2) - u[2]) * hz
+    assert np.abs(div).max() < 1e-10 * max(1.0, np.abs(u).max() * hx)
