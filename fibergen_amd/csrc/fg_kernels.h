@@ -76,6 +76,10 @@ bool u_fast_z_supported(const Grid& g);
 void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, const cplx* tw_z,
                      const cplx* w_z, hipStream_t s);
+// u_k -> sums of squares of eps_k and tau = (C - C0) : eps_k for any mixing rule (strain never stored)
+void launch_u_stress(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
+                     const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, const Vec6& E, double* partial, double* sumsq6,
+                     int* error_flag, hipStream_t s);
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);
 void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
                hipStream_t s);

@@ -564,6 +564,103 @@ __global__ __launch_bounds__(kBlock) void k_eps_norm(Grid g, FieldPtrs<3> u, Fie
   }
 }
 
+// ----------------------------------------------------------------------------- strain + stress from u
+// Displacement-based pass for any mixing rule (the laminate rule in particular): eps_k = E + sym grad u_k is
+// formed in registers exactly as k_eps_norm does (epsOperatorStaggered  F:18614-18692), its sums of squares
+// are accumulated (component_norm  F:10127), and tau = P(eps_k) - C0 : eps_k (calcStress  F:18134-18184) is
+// what goes to memory -- the strain is never stored (saves its 6 writes + 6 reads per voxel); the
+// divergence follows as its own sweep (the laminate Newton solve is too costly to repeat at six neighbours).
+template <int MIX, int NPH>
+__global__ __launch_bounds__(kBlock, 2) void k_u_stress(Grid g, StressParams sp, FieldPtrs<3> u, FieldPtrs<kMaxPhases> phi,
+                                                        FieldPtrs<3> normals, FieldPtrs<6> tau, Vec6 E, double* partial,
+                                                        int* error_flag, Sweep ry) {
+  __shared__ double smem[4 * 6];
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
+  for (long it = 0; it < run.count; ++it) {
+    const long pidx = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    if (pidx >= npairs) continue;
+    const PairPos p = pair_pos_tiled(pidx, g, ry);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+    const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+    const long rowoff = p.off - p.k;
+    const int kb = p.k == 0 ? g.nz - 1 : p.k - 1;
+    const int kf2 = (p.k + 2 >= g.nz) ? p.k + 2 - g.nz : p.k + 2;
+
+    const double2 u0 = ld2(u.p[0], p.off), u1 = ld2(u.p[1], p.off), u2 = ld2(u.p[2], p.off);
+    const double2 u0xf = ld2(u.p[0], p.off + xf), u1xb = ld2(u.p[1], p.off + xb), u2xb = ld2(u.p[2], p.off + xb);
+    const double2 u0yb = ld2(u.p[0], p.off + yb), u1yf = ld2(u.p[1], p.off + yf), u2yb = ld2(u.p[2], p.off + yb);
+    const double u0zb = u.p[0][rowoff + kb], u1zb = u.p[1][rowoff + kb];
+    const double u2zf2 = u.p[2][rowoff + kf2];
+    const double u2zf1 = second ? u2.y : u.p[2][rowoff];
+    double2 f[NPH], nn[3];
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) f[q] = q < sp.pt.n ? ld2(phi.p[q], p.off) : make_double2(0.0, 0.0);
+    nn[0] = nn[1] = nn[2] = make_double2(0.0, 0.0);
+    if (MIX == kMixLaminate) {
+      bool mixed = false;
+#pragma unroll
+      for (int q = 0; q < NPH; ++q)
+        mixed = mixed || (f[q].x != 0.0 && f[q].x != 1.0) || (f[q].y != 0.0 && f[q].y != 1.0);
+      if (mixed) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nn[c] = ld2(normals.p[c], p.off);
+      }
+    }
+
+    double2 e[6];
+    e[3].x = E.v[3] + 0.5 * ((u2.x - u2yb.x) * hy + (u1.x - u1zb) * hz);
+    e[4].x = E.v[4] + 0.5 * ((u2.x - u2xb.x) * hx + (u0.x - u0zb) * hz);
+    e[5].x = E.v[5] + 0.5 * ((u1.x - u1xb.x) * hx + (u0.x - u0yb.x) * hy);
+    e[0].x = E.v[0] + (u0xf.x - u0.x) * hx;
+    e[1].x = E.v[1] + (u1yf.x - u1.x) * hy;
+    e[2].x = E.v[2] + (u2zf1 - u2.x) * hz;
+    e[3].y = E.v[3] + 0.5 * ((u2.y - u2yb.y) * hy + (u1.y - u1.x) * hz);
+    e[4].y = E.v[4] + 0.5 * ((u2.y - u2xb.y) * hx + (u0.y - u0.x) * hz);
+    e[5].y = E.v[5] + 0.5 * ((u1.y - u1xb.y) * hx + (u0.y - u0yb.y) * hy);
+    e[0].y = E.v[0] + (u0xf.y - u0.y) * hx;
+    e[1].y = E.v[1] + (u1yf.y - u1.y) * hy;
+    e[2].y = E.v[2] + (u2zf2 - u2.y) * hz;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      if (!second) e[c].y = 0.0;
+      acc[c] += e[c].x * e[c].x + e[c].y * e[c].y;
+    }
+    double F[6], ph[NPH], nv[3], P0[6], P1[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) F[c] = e[c].x;
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) ph[q] = f[q].x;
+    nv[0] = nn[0].x; nv[1] = nn[1].x; nv[2] = nn[2].x;
+    int err = stress_voxel<NPH>(F, ph, nv, sp, P0);
+    if (second) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) F[c] = e[c].y;
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) ph[q] = f[q].y;
+      nv[0] = nn[0].y; nv[1] = nn[1].y; nv[2] = nn[2].y;
+      err |= stress_voxel<NPH>(F, ph, nv, sp, P1);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) P1[c] = 0.0;
+    }
+    if (err) atomicOr(error_flag, 1);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) st2(tau.p[c], p.off, make_double2(P0[c], P1[c]));
+  }
+  block_reduce<6>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+  }
+}
+
 // ----------------------------------------------------------------------------- plain reductions
 // Per-component sums (TensorField::average F:10171-10210) or sums of squares over the
 // valid voxels of NC components.
@@ -840,6 +937,27 @@ void launch_u_stress_div_voigt(const Grid& g, const StressParams& sp, const Fiel
   else
     hipLaunchKernelGGL((k_u_stress_div_voigt<kMaxPhases>), dim3(nb), dim3(kBlock), 0, s, g, sp, u, phi, f, E, partial,
                        chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 6, sumsq6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_u_stress(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
+                     const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, const Vec6& E, double* partial, double* sumsq6,
+                     int* error_flag, hipStream_t s) {
+  const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
+  const Sweep sw = chunk_rows(g);
+  const bool two = sp.pt.n <= 2;
+#define FG_LAUNCH(MIX, NPH) \
+  hipLaunchKernelGGL((k_u_stress<MIX, NPH>), dim3(nb), dim3(kBlock), 0, s, g, sp, u, phi, normals, tau, E, partial, error_flag, sw)
+  if (sp.mixing == kMixLaminate) {
+    if (two) FG_LAUNCH(kMixLaminate, 2);
+    else FG_LAUNCH(kMixLaminate, kMaxPhases);
+  } else {
+    if (two) FG_LAUNCH(kMixVoigt, 2);
+    else FG_LAUNCH(kMixVoigt, kMaxPhases);
+  }
+#undef FG_LAUNCH
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());

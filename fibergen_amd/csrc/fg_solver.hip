@@ -566,7 +566,8 @@ bool Solver::u_loop_eligible() const {
       throw std::runtime_error("heat / porous mode supports prescribed mean gradients only (projector = identity)");
     return pt_.n >= 1;
   }
-  return opt_.u_loop && opt_.mode == 0 && opt_.gamma_scheme == 0 && nranks_ == 1 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
+  return opt_.u_loop && opt_.mode == 0 && opt_.gamma_scheme == 0 && nranks_ == 1 && pt_.n >= 1 &&
+         (opt_.mixing == kMixVoigt || (opt_.mixing == kMixLaminate && normals_)) && opt_.bc_relax == 1.0 &&
          frobenius(BC_MQ_) < kEps;
 }
 
@@ -602,6 +603,19 @@ void Solver::u_pass_front(const double* E6) {
     } else {
       launch_sc_sweep(g_, scalar_params(opt_.mu_0, 1.0), fu_, phase_ptrs(), fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
     }
+  } else if (opt_.mixing != kMixVoigt) {
+    // laminate mixing: strain + polarisation from u in one sweep (tau stored), divergence as its own sweep
+    z_done_ = false;
+    FieldPtrs<3> nrm;
+    for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+    launch_u_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, ptrs6(tau_), E, partial_,
+                    dscal_ + kSlotSumSq, derr_, stream_);
+    time_end(0);
+    time_begin(1);
+    launch_div(g_, ptrs6(tau_), ptrs3(fu_alt_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
+    time_end(1);
+    eps_stale_ = true;
+    return;
   } else if (opt_.u_loop >= 2) {
     // fast variant: per-voxel effective moduli instead of the per-phase accumulation
     if (!mod_) {

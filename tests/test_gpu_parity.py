@@ -434,3 +434,26 @@ def test_collocated_cg_and_restrictions():
     with pytest.raises(RuntimeError, match="collocated"):
         s.run(np.array([1.0, 0, 0, 0, 0, 0]))
     s.close()
+
+
+@pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (32, 16, 64)])
+def test_displacement_based_loop_with_laminate_mixing_is_bit_identical(grid):
+    """Laminate mixing in the displacement-based loop: one sweep u_k -> (norms of eps_k, tau), then the divergence.
+    Same operations as the strain-based pipeline, so iterates are bit-identical."""
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    res = {}
+    for flag in (0, 2):
+        s = make_gpu_solver(grid, mixing="laminate", tol=1e-8)
+        s._check(s._lib.fg_set_option_i(s._h, b"u_loop", flag))
+        assert s.run(E) is False
+        res[flag] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.get_field("sigma"), s.mean_stress())
+        s.iterate(E, 2)
+        res[flag] += (s.get_field("epsilon"),)
+        s.close()
+    a, b = res[0], res[2]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    for i in (2, 3, 4, 5):
+        assert np.array_equal(a[i], b[i])
+    o = make_oracle(grid, mixing="laminate", tol=1e-8)
+    assert o.run(E) is False
+    assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9
