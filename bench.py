@@ -281,6 +281,21 @@ def main():
                 # x-FFT, Green operator, inverse x-FFT: 3 complex components in, 3 out (48 B/voxel)
                 name = "xfft_g0_xifft"
             kern[name] = {"avg_ms": avg, "alg_GB": alg / 1e9, "GBps": (alg / 1e9) / (avg / 1e3)}
+        g0_alone = None
+        if not scalar and not stokes:
+            # north_star names the Green-operator apply on its own (">= 50 % of the HBM roofline in the
+            # Gamma0-apply kernel"): in the default pipeline it is fused into the x pass, so time the
+            # stand-alone kernel of the one-kernel-per-routine pipeline as well (96 B per frequency)
+            s.set_options(fuse_x=0)
+            s.enable_stage_timing(True)
+            s.iterate(E, 5)
+            t2, c2 = s.stage_times()   # accumulators continue from the measurement above
+            s.enable_stage_timing(False)
+            s.set_options(fuse_x=1)
+            if c2 > cnt and t2["g0"] > times["g0"]:
+                ms = (t2["g0"] - times["g0"]) / (c2 - cnt)
+                g0_alone = {"kernel": "k_g0 (fuse_x=0)", "avg_ms": ms, "alg_GB": ab["g0"] / 1e9,
+                            "GBps": ab["g0"] / 1e9 / (ms / 1e3), "frac_of_hbm_peak": ab["g0"] / 1e9 / (ms / 1e3) / HBM_PEAK_GBS}
         dom = max(kern, key=lambda k: kern[k]["avg_ms"])
         N = n[0] * n[1] * n[2]
         traffic, traffic_src = committed_traffic(args.n, dom)
@@ -302,6 +317,8 @@ def main():
             "loop_GBps_Astage": A_STAGE_BYTES_PER_VOXEL * N * (args.steps / dt) / 1e9,
             "kernels": kern,
         }
+        if g0_alone is not None:
+            out["gamma0_apply_standalone"] = g0_alone
         if scalar:
             # the loop-level figures use the elasticity byte counts; per voxel the scalar loop moves
             # 24 (sweep) + 7 x 16 (six 1-component FFT passes + Green operator) bytes
