@@ -155,6 +155,10 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       if (value != 0 && value != 1) throw std::runtime_error("gamma_scheme must be 0 (staggered) or 1 (collocated)");
       o.gamma_scheme = (int)value;
     }
+    else if (k == "u_tile") {
+      if (value != 0 && value != 8 && value != 12 && value != 16) throw std::runtime_error("u_tile must be 0, 8, 12 or 16");
+      o.u_tile = (int)value;
+    }
     else if (k == "fuse_x") o.fuse_x = value != 0;
     else if (k == "fuse_z") o.fuse_z = value < 0 ? -1 : (value != 0);
     else if (k == "u_loop") o.u_loop = (int)value;

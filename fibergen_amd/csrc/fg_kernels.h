@@ -72,6 +72,10 @@ void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s);
 // the same sweep with the z transform attached (f is replaced by its half spectrum along z); tw_z / w_z are
 // the z-pass tables of the FFT plan (Fft3::z_twiddles, Fft3::z_roots)
+// tiled variant (every strain / polarisation value computed once; y neighbours through LDS, x by marching)
+bool u_tile_supported(const Grid& g);
+void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
+                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s);
 bool u_fast_z_supported(const Grid& g);
 void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, const cplx* tw_z,

@@ -6,6 +6,8 @@
 // relative per operation, asserted to 1e-12 on fields); the exact kernels remain available (u_loop = 1).
 #include "fg_kernels.h"
 
+#include <cstdlib>
+
 #include "fg_fft_core.h"
 #include "fg_hip_util.h"
 #include "fg_kernels_common.h"
@@ -278,6 +280,170 @@ __global__ __launch_bounds__(kBlock) void k_u_fast_z(Grid g, double beta, double
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tiled variant of the displacement sweep: every strain and every polarisation component is computed ONCE.
+//
+// k_u_fast recomputes the strain of the six face neighbours in registers (3.5x redundant arithmetic, 25 row
+// loads per voxel pair) and is bound by VALU issue.  Here a workgroup of TYR waves owns a brick: wave r is the
+// y row j0-1+r of the tile, its 64 lanes are consecutive z pairs, and the workgroup marches along x.
+//   * x neighbours are the thread's own values of the previous / next plane (registers);
+//   * y neighbours (u and tau of rows r-1, r+1) go through LDS, one exchange each per plane;
+//   * z neighbours are the adjacent lanes (DPP wave shifts).
+// Row 0, row TYR-1, lane 0 and lane 63 are halo: they compute their strain and polarisation like everyone
+// else but own no output, so no lane needs a value from outside the workgroup (no edge loads, no recomputation).
+// FULLROW: nz/2 == 64, a wave is a whole periodic z row (wave rotates, no halo lanes).
+// Per plane and thread: 5 16-byte global loads (u x3, A, B), 6 LDS writes + 6 LDS reads, 2 barriers.
+// f0 of plane q is complete at step q; f1, f2 need tau5, tau4 of plane q+1 and are finished one step later.
+template <int TYR, bool FULLROW>
+__global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double gamma, FieldPtrs<3> u, FieldPtrs<2> mod,
+                                                     FieldPtrs<3> fo, Vec6 E, double* partial, int nty, int ntz, int LX) {
+  constexpr int TYU = TYR - 2;            // rows with output
+  constexpr int TZU = FULLROW ? 64 : 62;  // lanes with output
+  extern __shared__ __align__(16) double2 tile_lds[];
+  double2(*Ub)[TYR][64] = reinterpret_cast<double2(*)[TYR][64]>(tile_lds);                  // [3][TYR][64]
+  double2(*Tb)[TYR][64] = reinterpret_cast<double2(*)[TYR][64]>(tile_lds + 3 * TYR * 64);   // [3][TYR][64]
+  __shared__ double red[TYR * 6];
+
+  const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int nzh = g.nz / 2;
+  int b = blockIdx.x;
+  const int tz = b % ntz;
+  b /= ntz;
+  const int ty = b % nty;
+  const int tx = b / nty;
+  const int j0 = min(ty * TYU, g.ny - TYU), kp0 = min(tz * TZU, nzh - TZU), x0 = tx * LX;
+  const int jr = j0 - 1 + r;                              // may be -1 or ny
+  const int j = jr < 0 ? jr + g.ny : (jr >= g.ny ? jr - g.ny : jr);
+  const int kr = FULLROW ? l : kp0 - 1 + l;
+  const int kp = kr < 0 ? kr + nzh : (kr >= nzh ? kr - nzh : kr);
+  const bool own = r >= 1 && r <= TYU && jr >= ty * TYU && (FULLROW || (l >= 1 && l <= TZU && kr >= tz * TZU));
+  const long rowoff = (long)j * g.nzp + 2 * kp;
+  const int rm = r > 0 ? r - 1 : 0, rp = r + 1 < TYR ? r + 1 : TYR - 1;
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const int nsteps = (x0 + LX <= g.nx ? LX : g.nx - x0);
+
+  auto plane = [&](int q) {  // element offset of x plane q (periodic)
+    int x = q % g.nx;
+    if (x < 0) x += g.nx;
+    return (long)x * g.nyzp + rowoff;
+  };
+  auto prev_y = [&](double v) { return FULLROW ? dpp_move<0x13C>(v) : dpp_move<0x138>(v); };  // lane i <- i-1
+  auto next_x = [&](double v) { return FULLROW ? dpp_move<0x134>(v) : dpp_move<0x130>(v); };  // lane i <- i+1
+
+  double2 uc[3], un[3], u2[3], Ac, Bc, An, Bn;
+  {
+    const long o0 = plane(x0 - 1), o1 = plane(x0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      uc[c] = ld2(u.p[c], o0);
+      un[c] = ld2(u.p[c], o1);
+    }
+    Ac = ld2(mod.p[0], o0);
+    Bc = ld2(mod.p[1], o0);
+  }
+  double2 dx1 = make_double2(0.0, 0.0), dx2 = dx1;          // U1, U2 minus their previous plane (warm-up: unused)
+  double2 t0m = dx1, t5m = dx1, t4m = dx1, part1 = dx1, part2 = dx1;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+
+  for (int st = -1; st <= nsteps; ++st) {
+    const int q = x0 + st;                                   // plane of this step
+    {
+      const long o2 = plane(q + 2), o1 = plane(q + 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) u2[c] = ld2(u.p[c], o2);
+      An = ld2(mod.p[0], o1);
+      Bn = ld2(mod.p[1], o1);
+    }
+    // ---- y neighbours of u through LDS
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Ub[c][r][l] = uc[c];
+    __syncthreads();
+    const double2 U0yb = Ub[0][rm][l], U1yf = Ub[1][rp][l], U2yb = Ub[2][rm][l];
+    const double U0zb = prev_y(uc[0].y), U1zb = prev_y(uc[1].y), U2zf = next_x(uc[2].x);
+    // ---- strain of the two voxels  (F:18632-18686)
+    double2 e0, e1, e2, e3, e4, e5;
+    e0.x = E.v[0] + (un[0].x - uc[0].x) * hx;
+    e0.y = E.v[0] + (un[0].y - uc[0].y) * hx;
+    e1.x = E.v[1] + (U1yf.x - uc[1].x) * hy;
+    e1.y = E.v[1] + (U1yf.y - uc[1].y) * hy;
+    e2.x = E.v[2] + (uc[2].y - uc[2].x) * hz;
+    e2.y = E.v[2] + (U2zf - uc[2].y) * hz;
+    e3.x = E.v[3] + 0.5 * ((uc[2].x - U2yb.x) * hy + (uc[1].x - U1zb) * hz);
+    e3.y = E.v[3] + 0.5 * ((uc[2].y - U2yb.y) * hy + (uc[1].y - uc[1].x) * hz);
+    e4.x = E.v[4] + 0.5 * (dx2.x * hx + (uc[0].x - U0zb) * hz);
+    e4.y = E.v[4] + 0.5 * (dx2.y * hx + (uc[0].y - uc[0].x) * hz);
+    e5.x = E.v[5] + 0.5 * (dx1.x * hx + (uc[0].x - U0yb.x) * hy);
+    e5.y = E.v[5] + 0.5 * (dx1.y * hx + (uc[0].y - U0yb.y) * hy);
+    // ---- polarisation  tau = (A - 2 mu0) eps + (B - lambda0) tr(eps) I
+    const double ax = Ac.x + beta, ay = Ac.y + beta, bx = Bc.x + gamma, by = Bc.y + gamma;
+    const double trx = e0.x + e1.x + e2.x, try_ = e0.y + e1.y + e2.y;
+    double2 t0, t1, t2, t3, t4, t5;
+    t0.x = e0.x * ax + bx * trx; t0.y = e0.y * ay + by * try_;
+    t1.x = e1.x * ax + bx * trx; t1.y = e1.y * ay + by * try_;
+    t2.x = e2.x * ax + bx * trx; t2.y = e2.y * ay + by * try_;
+    t3.x = e3.x * ax; t3.y = e3.y * ay;
+    t4.x = e4.x * ax; t4.y = e4.y * ay;
+    t5.x = e5.x * ax; t5.y = e5.y * ay;
+    const bool inside = st >= 0 && st < nsteps;
+    if (own && inside) {
+      acc[0] += e0.x * e0.x + e0.y * e0.y; acc[1] += e1.x * e1.x + e1.y * e1.y; acc[2] += e2.x * e2.x + e2.y * e2.y;
+      acc[3] += e3.x * e3.x + e3.y * e3.y; acc[4] += e4.x * e4.x + e4.y * e4.y; acc[5] += e5.x * e5.x + e5.y * e5.y;
+    }
+    // ---- y neighbours of tau through LDS
+    Tb[0][r][l] = t1;
+    Tb[1][r][l] = t5;
+    Tb[2][r][l] = t3;
+    __syncthreads();
+    const double2 t1yb = Tb[0][rm][l], t5yf = Tb[1][rp][l], t3yf = Tb[2][rp][l];
+    const double t2zb = prev_y(t2.y), t3zf = next_x(t3.x), t4zf = next_x(t4.x);
+    // ---- divergence: f0 of this plane, f1 / f2 of the previous one
+    if (own) {
+      if (inside) {
+        double2 f0;
+        f0.x = (t0.x - t0m.x) * hx + (t5yf.x - t5.x) * hy + (t4.y - t4.x) * hz;
+        f0.y = (t0.y - t0m.y) * hx + (t5yf.y - t5.y) * hy + (t4zf - t4.y) * hz;
+        st2(fo.p[0], plane(q), f0);
+      }
+      if (st >= 1) {
+        const long op = plane(q - 1);
+        st2(fo.p[1], op, make_double2((t5.x - t5m.x) * hx + part1.x, (t5.y - t5m.y) * hx + part1.y));
+        st2(fo.p[2], op, make_double2((t4.x - t4m.x) * hx + part2.x, (t4.y - t4m.y) * hx + part2.y));
+      }
+    }
+    part1.x = (t1.x - t1yb.x) * hy + (t3.y - t3.x) * hz;
+    part1.y = (t1.y - t1yb.y) * hy + (t3zf - t3.y) * hz;
+    part2.x = (t3yf.x - t3.x) * hy + (t2.x - t2zb) * hz;
+    part2.y = (t3yf.y - t3.y) * hy + (t2.y - t2.x) * hz;
+    // ---- advance one plane
+    t0m = t0; t5m = t5; t4m = t4;
+    dx1.x = un[1].x - uc[1].x; dx1.y = un[1].y - uc[1].y;
+    dx2.x = un[2].x - uc[2].x; dx2.y = un[2].y - uc[2].y;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { uc[c] = un[c]; un[c] = u2[c]; }
+    Ac = An; Bc = Bn;
+  }
+  // ---- sums of squares: fixed-order reduction over the workgroup
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double a = acc[c];
+    a += dpp_move<0x128>(a);
+    a += dpp_move<0x124>(a);
+    a += dpp_move<0x122>(a);
+    a += dpp_move<0x121>(a);
+    acc[c] = (read_lane(a, 0) + read_lane(a, 16)) + (read_lane(a, 32) + read_lane(a, 48));
+  }
+  if (l == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) red[r * 6 + c] = acc[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double a = 0.0;
+    for (int w = 0; w < TYR; ++w) a += red[w * 6 + threadIdx.x];
+    partial[(long)blockIdx.x * 6 + threadIdx.x] = a;
+  }
+}
+
 // Scalar modes (heat / porous), fast variant of k_sc_sweep (fg_kernels_scalar.hip): the per-voxel effective
 // conductivity a = sum_p phi_p mu_p is precomputed (k_effective_moduli stores it in the first moduli array with
 // 2 mu_p := mu_p), z neighbours come from the adjacent lanes.  T_k -> sums of squares of g_k = E + grad+ T_k and
@@ -388,6 +554,50 @@ void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
+}
+
+bool u_tile_supported(const Grid& g) {
+  const int nzh = g.nz / 2;
+  return g.nz % 2 == 0 && nzh >= 62 && g.ny >= 14 && g.nx >= 4;
+}
+
+template <int TYR, bool FULLROW>
+void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
+                     const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s) {
+  constexpr int TYU = TYR - 2, TZU = FULLROW ? 64 : 62;
+  const int nzh = g.nz / 2;
+  const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
+  static const int lx_env = getenv("FG_TILE_LX") ? atoi(getenv("FG_TILE_LX")) : 32;  // tuning knob
+  const int LX = g.nx < lx_env ? g.nx : lx_env;
+  const int ntx = (g.nx + LX - 1) / LX;
+  const int nb = nty * ntz * ntx;
+  const size_t lds = 6 * TYR * 64 * sizeof(double2);
+  static bool configured = false;
+  if (!configured) {
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, FULLROW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_u_tile<TYR, FULLROW>), dim3(nb), dim3(TYR * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E, partial,
+                     nty, ntz, LX);
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 6, sumsq6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
+                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s) {
+  const bool full = g.nz / 2 == 64;
+  if (rows == 8) {
+    if (full) launch_u_tile_t<8, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+    else launch_u_tile_t<8, false>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+  } else if (rows == 12) {
+    if (full) launch_u_tile_t<12, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+    else launch_u_tile_t<12, false>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+  } else {
+    if (full) launch_u_tile_t<16, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+    else launch_u_tile_t<16, false>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+  }
 }
 
 void launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,

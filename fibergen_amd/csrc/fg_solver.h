@@ -43,8 +43,10 @@ struct SolverOptions {
                                 // 2 precomputed effective moduli + FMA, agrees with 1 to rounding)
   int fuse_stress_div = 1;      // Voigt mixing: polarisation + divergence in one sweep
   int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
-  int fuse_z = -1;              // attach the z r2c transform to the fast displacement sweep (u_loop = 2): 1 on, 0 off,
-                                // -1 auto (on up to 2^22 voxels: measured +3 % at 128^3, -1 % at 256^3, -5 % at 512^3)
+  int u_tile = 8;               // fast displacement sweep (u_loop = 2) as the LDS-tiled marching kernel where the grid allows:
+                                // rows per workgroup (8, 12, 16), 0 = off.  512^3: 2.8 -> 1.95 ms per sweep
+  int fuse_z = 0;               // attach the z r2c transform to the untiled fast sweep (u_tile = 0): 1 on, 0 off, -1 by size
+                                // (measured +3 % at 128^3, -1 % at 256^3, -5 % at 512^3 against the untiled sweep)
 };
 
 enum Stage {

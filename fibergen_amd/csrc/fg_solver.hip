@@ -631,7 +631,11 @@ void Solver::u_pass_front(const double* E6) {
     }
     const bool want_z = opt_.fuse_z > 0 || (opt_.fuse_z < 0 && (long)g_.nx * g_.ny * g_.nz <= (1L << 22));
     z_done_ = want_z && fft_->fast_z() && u_fast_z_supported(g_);
-    if (z_done_)
+    if (opt_.u_tile && u_tile_supported(g_)) {
+      z_done_ = false;
+      launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
+                    opt_.u_tile, stream_);
+    } else if (z_done_)
       launch_u_fast_z(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
                       fft_->z_twiddles(), fft_->z_roots(), stream_);
     else

@@ -78,7 +78,8 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * gamma_scheme (0 = staggered, 1 = collocated: GammaOperatorCollocated F:20302-20310, Fourier-space 6x6 Gamma0),
  * method (0 = basic scheme, runBasic F:21716-21805; 1 = conjugate gradients, runCGElasticity
  * F:23153-23247, the reference's default), and the implementation switches u_loop,
- * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), fuse_z (1, 0, -1 = by size). */
+ * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (rows per workgroup of
+ * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled), fuse_z (untiled sweep with the z transform attached). */
 int fg_set_option_d(fg_solver* s, const char* key, double value);
 int fg_set_option_i(fg_solver* s, const char* key, long value);
 

@@ -319,6 +319,7 @@ def test_displacement_sweep_with_z_transform_attached(grid):
     res = {}
     for flag in (0, 1):
         s = make_gpu_solver(grid, tol=1e-8)
+        s.set_options(u_tile=0)
         s._check(s._lib.fg_set_option_i(s._h, b"fuse_z", flag))
         assert s.run(E) is False
         res[flag] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.get_field("u"), s.mean_stress())
@@ -457,3 +458,22 @@ def test_displacement_based_loop_with_laminate_mixing_is_bit_identical(grid):
     o = make_oracle(grid, mixing="laminate", tol=1e-8)
     assert o.run(E) is False
     assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9
+
+
+@pytest.mark.parametrize("rows", [8, 16])
+@pytest.mark.parametrize("grid", [(16, 16, 128), (8, 16, 124), (32, 32, 256), (5, 14, 128), (6, 20, 130), (40, 30, 128)])
+def test_tiled_displacement_sweep(grid, rows):
+    """u_tile: the LDS-tiled marching variant of the fast sweep (each strain / polarisation value computed once;
+    halo rows and lanes, overlapping last tiles, periodic wrap in all directions) gives the same iterates."""
+    E = np.array([0.2, -0.1, 1.0, 0.3, 0, 0.5])
+    res = {}
+    for flag in (0, rows):
+        s = make_gpu_solver(grid, tol=1e-8)
+        s.set_options(u_tile=flag, fuse_z=0)
+        assert s.run(E) is False
+        res[flag] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress())
+        s.close()
+    a, b = res[0], res[rows]
+    assert a[0] == b[0]
+    assert np.abs(a[1] - b[1]).max() < 1e-12
+    assert rel_err(b[2], a[2]) < 1e-11 and rel_err(b[3], a[3]) < 1e-12
