@@ -306,12 +306,19 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
 
   const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int nzh = g.nz / 2;
+  // workgroups of one XCD (blockIdx % 8) take a contiguous run of tiles: z- and y-adjacent tiles, which share halo
+  // rows and 128-byte segments, then meet in that XCD's L2 (FETCH_SIZE 2.1x -> see profiles/ for the effect)
   int b = blockIdx.x;
+  {
+    const int nb = gridDim.x;
+    if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
+  }
   const int tz = b % ntz;
   b /= ntz;
   const int ty = b % nty;
   const int tx = b / nty;
-  const int j0 = min(ty * TYU, g.ny - TYU), kp0 = min(tz * TZU, nzh - TZU), x0 = tx * LX;
+  const bool surplus = tx * LX >= g.nx;   // padding workgroup (grid rounded up to a multiple of 8)
+  const int j0 = min(ty * TYU, g.ny - TYU), kp0 = min(tz * TZU, nzh - TZU), x0 = surplus ? 0 : tx * LX;
   const int jr = j0 - 1 + r;                              // may be -1 or ny
   const int j = jr < 0 ? jr + g.ny : (jr >= g.ny ? jr - g.ny : jr);
   const int kr = FULLROW ? l : kp0 - 1 + l;
@@ -320,17 +327,16 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
   const long rowoff = (long)j * g.nzp + 2 * kp;
   const int rm = r > 0 ? r - 1 : 0, rp = r + 1 < TYR ? r + 1 : TYR - 1;
   const double hx = g.hx, hy = g.hy, hz = g.hz;
-  const int nsteps = (x0 + LX <= g.nx ? LX : g.nx - x0);
+  const int nsteps = surplus ? -2 : (x0 + LX <= g.nx ? LX : g.nx - x0);   // surplus: no steps at all
 
-  auto plane = [&](int q) {  // element offset of x plane q (periodic)
-    int x = q % g.nx;
-    if (x < 0) x += g.nx;
+  auto plane = [&](int q) {  // element offset of x plane q (periodic; q in [-1, 2 nx))
+    const int x = q < 0 ? q + g.nx : (q >= g.nx ? q - g.nx : q);
     return (long)x * g.nyzp + rowoff;
   };
   auto prev_y = [&](double v) { return FULLROW ? dpp_move<0x13C>(v) : dpp_move<0x138>(v); };  // lane i <- i-1
   auto next_x = [&](double v) { return FULLROW ? dpp_move<0x134>(v) : dpp_move<0x130>(v); };  // lane i <- i+1
 
-  double2 uc[3], un[3], u2[3], Ac, Bc, An, Bn;
+  double2 uc[3], un[3], u2[3];
   {
     const long o0 = plane(x0 - 1), o1 = plane(x0);
 #pragma unroll
@@ -338,8 +344,6 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
       uc[c] = ld2(u.p[c], o0);
       un[c] = ld2(u.p[c], o1);
     }
-    Ac = ld2(mod.p[0], o0);
-    Bc = ld2(mod.p[1], o0);
   }
   double2 dx1 = make_double2(0.0, 0.0), dx2 = dx1;          // U1, U2 minus their previous plane (warm-up: unused)
   double2 t0m = dx1, t5m = dx1, t4m = dx1, part1 = dx1, part2 = dx1;
@@ -347,13 +351,11 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
 
   for (int st = -1; st <= nsteps; ++st) {
     const int q = x0 + st;                                   // plane of this step
-    {
-      const long o2 = plane(q + 2), o1 = plane(q + 1);
+    // u two planes ahead (consumed next step); the moduli of this plane are first needed after the LDS exchange
+    const long o2 = plane(q + 2), oq = plane(q);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) u2[c] = ld2(u.p[c], o2);
-      An = ld2(mod.p[0], o1);
-      Bn = ld2(mod.p[1], o1);
-    }
+    for (int c = 0; c < 3; ++c) u2[c] = ld2(u.p[c], o2);
+    const double2 Ac = ld2(mod.p[0], oq), Bc = ld2(mod.p[1], oq);
     // ---- y neighbours of u through LDS
 #pragma unroll
     for (int c = 0; c < 3; ++c) Ub[c][r][l] = uc[c];
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
         double2 f0;
         f0.x = (t0.x - t0m.x) * hx + (t5yf.x - t5.x) * hy + (t4.y - t4.x) * hz;
         f0.y = (t0.y - t0m.y) * hx + (t5yf.y - t5.y) * hy + (t4zf - t4.y) * hz;
-        st2(fo.p[0], plane(q), f0);
+        st2(fo.p[0], oq, f0);
       }
       if (st >= 1) {
         const long op = plane(q - 1);
@@ -420,7 +422,6 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
     dx2.x = un[2].x - uc[2].x; dx2.y = un[2].y - uc[2].y;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { uc[c] = un[c]; un[c] = u2[c]; }
-    Ac = An; Bc = Bn;
   }
   // ---- sums of squares: fixed-order reduction over the workgroup
 #pragma unroll
@@ -570,7 +571,8 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   static const int lx_env = getenv("FG_TILE_LX") ? atoi(getenv("FG_TILE_LX")) : 32;  // tuning knob
   const int LX = g.nx < lx_env ? g.nx : lx_env;
   const int ntx = (g.nx + LX - 1) / LX;
-  const int nb = nty * ntz * ntx;
+  int nb = nty * ntz * ntx;
+  if (nb >= 8) nb = ((nb + 7) / 8) * 8;
   const size_t lds = 6 * TYR * 64 * sizeof(double2);
   static bool configured = false;
   if (!configured) {
