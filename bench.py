@@ -141,7 +141,7 @@ def guarded_slab_section(args, n, K, rank, world, local_rank, dist, torch, out):
 
 
 # HIP-event slot name -> kernel name in the rocprofv3 counter summaries under profiles/
-PMC_KERNEL = {"u_eps_stress_div": "k_u_fast", "u_eps_stress_div_r2cz": "k_u_fast_z", "stress_div": "k_stress_div_voigt", "xfft_g0_xifft": "k_xfused",
+PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"), "u_eps_stress_div_r2cz": "k_u_fast_z", "stress_div": "k_stress_div_voigt", "xfft_g0_xifft": "k_xfused",
               "eps_norm": "k_eps_norm", "stress": "k_stress", "div": "k_div", "g0": "k_g0"}
 
 
@@ -157,9 +157,11 @@ def committed_traffic(n, slot):
                                           "*pmc_hbm_traffic_%dcubed*.csv" % n)))  # latest by name
     if not want or not files:
         return None, None
-    for row in csv.DictReader(open(files[-1])):
-        if row["kernel"].split("<")[0] == want:
-            return float(row["total_GB"]) * 1e9, "profiles/" + os.path.basename(files[-1])
+    rows = list(csv.DictReader(open(files[-1])))
+    for w in (want if isinstance(want, tuple) else (want,)):
+        for row in rows:
+            if row["kernel"].split("<")[0] == w:
+                return float(row["total_GB"]) * 1e9, "profiles/" + os.path.basename(files[-1])
     return None, None
 
 
