@@ -9,6 +9,7 @@
 // component (correctness path for the odd grids of the reference's self tests).
 #include "fg_fft.h"
 
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -65,6 +66,32 @@ __global__ __launch_bounds__(K::THREADS) void k_xfused(XFusedArgs a) {
   extern __shared__ __align__(16) double lds[];
   typename K::Regs r;
   DevicePhasesX<K, 0>::run(r, blockIdx.x, threadIdx.x, lds, a);
+}
+
+// Persistent form: a workgroup takes tiles b, b + gridDim, ... (at any time the chip works on one contiguous
+// window of columns -- DRAM page locality), and components 0 and 1 of the next tile are loaded into their
+// registers as soon as the current tile has stored them (see XFusedKernel::phase, PERSIST).
+template <class K, int PH>
+struct DevicePhasesXP {
+  __device__ __forceinline__ static void run(typename K::Regs& r, int block, int tid, double* lds, const XFusedArgs& a) {
+    K::template phase<PH, true>(r, block, tid, lds, a);
+    if constexpr (PH + 1 < K::NPHASE) {
+      if constexpr (K::barrier_after(PH)) __syncthreads();
+      DevicePhasesXP<K, PH + 1>::run(r, block, tid, lds, a);
+    }
+  }
+};
+
+template <class K>
+__global__ __launch_bounds__(K::THREADS) void k_xfused_persistent(XFusedArgs a, int ntiles) {
+  extern __shared__ __align__(16) double lds[];
+  typename K::Regs r;
+  r.have = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    r.next_block = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : -1;
+    DevicePhasesXP<K, 0>::run(r, tile, threadIdx.x, lds, a);
+    r.have = r.next_block >= 0 ? 3 : 0;
+  }
 }
 
 __global__ void k_dft_strided_generic(const cplx* src, cplx* dst, long ls, long os, int ncols, int nouter, int n,
@@ -150,7 +177,24 @@ void xfused_n(XFusedArgs a, int nouter, hipStream_t s) {
   }
   a.tiles_per_outer = (a.ncols + C - 1) / C;
   const long nblocks = (long)a.tiles_per_outer * nouter;
-  hipLaunchKernelGGL(k_xfused<K>, dim3((unsigned)nblocks), dim3(K::THREADS), lds, s, a);
+  static int resident = 0;  // workgroups that fit the device at once
+  static const int persist_env = getenv("FG_XFUSED_PERSIST") ? atoi(getenv("FG_XFUSED_PERSIST")) : 1;
+  if (!resident) {
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused_persistent<K>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int dev = 0, cus = 0, per_cu = 0;
+    FG_HIP_CHECK(hipGetDevice(&dev));
+    FG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    FG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_xfused_persistent<K>, K::THREADS, lds));
+    resident = cus * (per_cu < 1 ? 1 : per_cu);
+  }
+  // measured: 256^3 0.313 -> 0.284 ms; at N = 512 the extra live state pushes the 512-thread kernel further into
+  // scratch (160 -> 336 B) and it loses (2.53 -> 3.08 ms), so the persistent form is used for N <= 256 only
+  if (persist_env && N <= 256 && nblocks > 2L * resident) {
+    hipLaunchKernelGGL(k_xfused_persistent<K>, dim3((unsigned)resident), dim3(K::THREADS), lds, s, a, (int)nblocks);
+  } else {
+    hipLaunchKernelGGL(k_xfused<K>, dim3((unsigned)nblocks), dim3(K::THREADS), lds, s, a);
+  }
   FG_HIP_CHECK(hipGetLastError());
 }
 

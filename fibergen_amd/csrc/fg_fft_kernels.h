@@ -275,13 +275,31 @@ struct XFusedKernel {
     long base;
     int jt, t, jj, kk;
     bool valid;
+    // persistent variant only: the tile after this one (its components 0 and 1 are loaded into v[0], v[1] as soon
+    // as the current tile has stored them, so two thirds of the next tile's loads overlap the inverse transforms)
+    long base_n;
+    int jj_n, kk_n, next_block, have;
+    bool valid_n;
   };
+  FG_HD static void locate(int block, int t, const XFusedArgs& a, long* base, int* jj, int* kk, bool* valid) {
+    const int o = block / a.tiles_per_outer;
+    const int col = (block % a.tiles_per_outer) * C + t;
+    *valid = col < a.ncols;
+    *base = (long)o * a.os + col;
+    if (a.flat_cols) {
+      *jj = col / a.nzc;
+      *kk = col - *jj * a.nzc;
+    } else {
+      *jj = a.jj0 + o;
+      *kk = col;
+    }
+  }
   // register slot of the inverse transform's input that holds forward output slot q
   // (last pass of radix R: slot q = (b, r) holds point jt + b*T + r*N/R = jt + (b + r*8/R)*T)
   static constexpr int RL = pass_radix(N, num_passes(N) - 1);
   static constexpr int inv_slot(int q) { return q / RL + (q % RL) * (8 / RL); }
 
-  template <int PH>
+  template <int PH, bool PERSIST = false>
   FG_HD static void phase(Regs& r, int block, int tid, double* lds, const XFusedArgs& a) {
     const LdsMap L = {C, 1, PN * C};
     constexpr int TR = PH / NPL;   // transform number: 0..2 forward comp TR, 3..5 inverse comp TR-3
@@ -291,23 +309,21 @@ struct XFusedKernel {
     if (PH == 0) {
       r.t = tid % C;
       r.jt = tid / C;
-      const int o = block / a.tiles_per_outer;
-      const int col = (block % a.tiles_per_outer) * C + r.t;
-      r.valid = col < a.ncols;
-      r.base = (long)o * a.os + col;
-      if (a.flat_cols) {
-        r.jj = col / a.nzc;
-        r.kk = col - r.jj * a.nzc;
+      int have = 0;
+      if (PERSIST && r.have) {  // position and components 0, 1 were fetched while the previous tile finished
+        r.base = r.base_n; r.jj = r.jj_n; r.kk = r.kk_n; r.valid = r.valid_n;
+        have = r.have;
       } else {
-        r.jj = a.jj0 + o;
-        r.kk = col;
+        locate(block, r.t, a, &r.base, &r.jj, &r.kk, &r.valid);
       }
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < 3; ++c) {
+        if (PERSIST && ((have >> c) & 1)) continue;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           r.v[c][q] = r.valid ? a.data[c * a.comp_stride + r.base + (long)Line<N>::first_index(r.jt, q) * a.ls]
                               : cmake(0.0, 0.0);
+      }
     }
     if (TR < 3) {
       Line<N>::template phase<-1, LP>(r.v[comp], r.jt, lds, L, r.t, a.tw);
@@ -347,6 +363,14 @@ struct XFusedKernel {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           a.data[comp * a.comp_stride + r.base + (long)Line<N>::last_index(r.jt, q) * a.ls] = r.v[comp][q];
+      }
+      if (PERSIST && LP == NPL - 1 && comp < 2 && r.next_block >= 0) {
+        // v[comp] is free now: fetch the same component of the next tile into it
+        if (comp == 0) locate(r.next_block, r.t, a, &r.base_n, &r.jj_n, &r.kk_n, &r.valid_n);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          r.v[comp][q] = r.valid_n ? a.data[comp * a.comp_stride + r.base_n + (long)Line<N>::first_index(r.jt, q) * a.ls]
+                                   : cmake(0.0, 0.0);
       }
     }
   }
