@@ -82,13 +82,21 @@ struct DevicePhasesXP {
   }
 };
 
-template <class K>
+// UNIT consecutive tiles form one unit of the round-robin (UNIT = 2 for half-segment tiles, C = 4: the two halves of
+// the same 128-byte segments are processed back to back by one workgroup, the second half is a cache hit).
+template <class K, int UNIT>
 __global__ __launch_bounds__(K::THREADS) void k_xfused_persistent(XFusedArgs a, int ntiles) {
   extern __shared__ __align__(16) double lds[];
   typename K::Regs r;
   r.have = 0;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    r.next_block = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : -1;
+  const int nunits = (ntiles + UNIT - 1) / UNIT;
+  const int mine = (int)blockIdx.x < nunits ? (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  auto tile_of = [&](int i) { return ((int)blockIdx.x + (i / UNIT) * (int)gridDim.x) * UNIT + i % UNIT; };
+  for (int i = 0; i < mine * UNIT; ++i) {
+    const int tile = tile_of(i);
+    if (tile >= ntiles) break;   // only the very last unit can be short
+    const int nxt = i + 1 < mine * UNIT ? tile_of(i + 1) : -1;
+    r.next_block = nxt < ntiles ? nxt : -1;
     DevicePhasesXP<K, 0>::run(r, tile, threadIdx.x, lds, a);
     r.have = r.next_block >= 0 ? 3 : 0;
   }
@@ -164,9 +172,17 @@ void launch_z(const ZArgs& a, int ncomp, long comp_stride, int lines, hipStream_
   FG_HIP_CHECK(hipGetLastError());
 }
 
+template <int N, int C>
+void xfused_nc(XFusedArgs a, int nouter, hipStream_t s);
+
 template <int N>
 void xfused_n(XFusedArgs a, int nouter, hipStream_t s) {
-  constexpr int C = XTileCols<N>::value;
+  // (half-segment tiles, C = 4, were measured for N = 512 in the persistent form too: 3.03 ms against 2.44 ms)
+  xfused_nc<N, XTileCols<N>::value>(a, nouter, s);
+}
+
+template <int N, int C>
+void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
   using K = XFusedKernel<N, C>;
   static bool configured = false;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
@@ -180,18 +196,20 @@ void xfused_n(XFusedArgs a, int nouter, hipStream_t s) {
   static int resident = 0;  // workgroups that fit the device at once
   static const int persist_env = getenv("FG_XFUSED_PERSIST") ? atoi(getenv("FG_XFUSED_PERSIST")) : 1;
   if (!resident) {
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused_persistent<K>),
+    constexpr int UNIT = C >= 8 ? 1 : 8 / C;
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused_persistent<K, UNIT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int dev = 0, cus = 0, per_cu = 0;
     FG_HIP_CHECK(hipGetDevice(&dev));
     FG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    FG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_xfused_persistent<K>, K::THREADS, lds));
+    FG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_xfused_persistent<K, UNIT>, K::THREADS, lds));
     resident = cus * (per_cu < 1 ? 1 : per_cu);
   }
   // measured: 256^3 0.313 -> 0.284 ms; at N = 512 the extra live state pushes the 512-thread kernel further into
   // scratch (160 -> 336 B) and it loses (2.53 -> 3.08 ms), so the persistent form is used for N <= 256 only
-  if (persist_env && N <= 256 && nblocks > 2L * resident) {
-    hipLaunchKernelGGL(k_xfused_persistent<K>, dim3((unsigned)resident), dim3(K::THREADS), lds, s, a, (int)nblocks);
+  if (persist_env && (N <= 256 || C < 8) && nblocks > 2L * resident) {
+    constexpr int UNIT = C >= 8 ? 1 : 8 / C;
+    hipLaunchKernelGGL((k_xfused_persistent<K, UNIT>), dim3((unsigned)resident), dim3(K::THREADS), lds, s, a, (int)nblocks);
   } else {
     hipLaunchKernelGGL(k_xfused<K>, dim3((unsigned)nblocks), dim3(K::THREADS), lds, s, a);
   }
