@@ -172,18 +172,19 @@ void launch_z(const ZArgs& a, int ncomp, long comp_stride, int lines, hipStream_
   FG_HIP_CHECK(hipGetLastError());
 }
 
-template <int N, int C>
+template <int N, int C, int NC>
 void xfused_nc(XFusedArgs a, int nouter, hipStream_t s);
 
 template <int N>
-void xfused_n(XFusedArgs a, int nouter, hipStream_t s) {
+void xfused_n(XFusedArgs a, int nouter, int ncomp, hipStream_t s) {
   // (half-segment tiles, C = 4, were measured for N = 512 in the persistent form too: 3.03 ms against 2.44 ms)
-  xfused_nc<N, XTileCols<N>::value>(a, nouter, s);
+  if (ncomp == 1) xfused_nc<N, XTileCols<N>::value, 1>(a, nouter, s);
+  else xfused_nc<N, XTileCols<N>::value, 3>(a, nouter, s);
 }
 
-template <int N, int C>
+template <int N, int C, int NC>
 void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
-  using K = XFusedKernel<N, C>;
+  using K = XFusedKernel<N, C, NC>;
   static bool configured = false;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
   if (!configured) {
@@ -207,7 +208,7 @@ void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
   }
   // measured: 256^3 0.313 -> 0.284 ms; at N = 512 the extra live state pushes the 512-thread kernel further into
   // scratch (160 -> 336 B) and it loses (2.53 -> 3.08 ms), so the persistent form is used for N <= 256 only
-  if (persist_env && (N <= 256 || C < 8) && nblocks > 2L * resident) {
+  if (persist_env && NC == 3 && (N <= 256 || C < 8) && nblocks > 2L * resident) {
     constexpr int UNIT = C >= 8 ? 1 : 8 / C;
     hipLaunchKernelGGL((k_xfused_persistent<K, UNIT>), dim3((unsigned)resident), dim3(K::THREADS), lds, s, a, (int)nblocks);
   } else {
@@ -308,7 +309,8 @@ bool Fft3::can_fuse(int axis) const {
   return fast_[axis] && n <= 512;
 }
 
-void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0) {
+void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp) {
+  if (ncomp != 1 && ncomp != 3) throw std::runtime_error("fft: fused Green-operator pass takes 1 or 3 components");
   if (!can_fuse(axis)) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
   const int n = axis == 0 ? g_.nx : g_.ny;
   XFusedArgs a;
@@ -332,13 +334,13 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
   }
   const int nouter = axis == 0 ? 1 : g_.nx;
   switch (n) {
-    case 8: xfused_n<8>(a, nouter, stream_); break;
-    case 16: xfused_n<16>(a, nouter, stream_); break;
-    case 32: xfused_n<32>(a, nouter, stream_); break;
-    case 64: xfused_n<64>(a, nouter, stream_); break;
-    case 128: xfused_n<128>(a, nouter, stream_); break;
-    case 256: xfused_n<256>(a, nouter, stream_); break;
-    case 512: xfused_n<512>(a, nouter, stream_); break;
+    case 8: xfused_n<8>(a, nouter, ncomp, stream_); break;
+    case 16: xfused_n<16>(a, nouter, ncomp, stream_); break;
+    case 32: xfused_n<32>(a, nouter, ncomp, stream_); break;
+    case 64: xfused_n<64>(a, nouter, ncomp, stream_); break;
+    case 128: xfused_n<128>(a, nouter, ncomp, stream_); break;
+    case 256: xfused_n<256>(a, nouter, ncomp, stream_); break;
+    case 512: xfused_n<512>(a, nouter, ncomp, stream_); break;
     default: throw std::runtime_error("fft: unsupported fused length");
   }
 }

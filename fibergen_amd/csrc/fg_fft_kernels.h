@@ -258,7 +258,9 @@ struct XFusedArgs {
   const cplx* kp[3];
 };
 
-template <int N, int C>
+// NC = 3: the three components of the elastic problem and G0OperatorFourierStaggeredGeneral; NC = 1: the scalar modes
+// (one potential, G0OperatorFourierStaggeredGeneralHeat  F:19779-19823: c1 = c10 / |k|^2).
+template <int N, int C, int NC = 3>
 struct XFusedKernel {
   static constexpr int T = N / 8;
   static constexpr int THREADS = T * C;
@@ -269,9 +271,9 @@ struct XFusedKernel {
   static constexpr bool PINGPONG = num_passes(N) == 3;
   static constexpr int BUF_DOUBLES = 2 * PN * C;
   static constexpr int LDS_DOUBLES = (PINGPONG ? 2 : 1) * BUF_DOUBLES;
-  static constexpr int NPHASE = 6 * NPL;        // 3 forward + 3 inverse transforms
+  static constexpr int NPHASE = 2 * NC * NPL;   // NC forward + NC inverse transforms
   struct Regs {
-    cplx v[3][8];
+    cplx v[NC][8];
     long base;
     int jt, t, jj, kk;
     bool valid;
@@ -302,9 +304,9 @@ struct XFusedKernel {
   template <int PH, bool PERSIST = false>
   FG_HD static void phase(Regs& r, int block, int tid, double* lds, const XFusedArgs& a) {
     const LdsMap L = {C, 1, PN * C};
-    constexpr int TR = PH / NPL;   // transform number: 0..2 forward comp TR, 3..5 inverse comp TR-3
+    constexpr int TR = PH / NPL;   // transform number: 0..NC-1 forward comp TR, NC..2NC-1 inverse comp TR-NC
     constexpr int LP = PH % NPL;   // phase inside the transform
-    constexpr int comp = TR % 3;
+    constexpr int comp = TR % NC;
     if (PINGPONG) lds += ((LP / 2) % 2) * BUF_DOUBLES;
     if (PH == 0) {
       r.t = tid % C;
@@ -317,7 +319,7 @@ struct XFusedKernel {
         locate(block, r.t, a, &r.base, &r.jj, &r.kk, &r.valid);
       }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < NC; ++c) {
         if (PERSIST && ((have >> c) & 1)) continue;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
@@ -325,9 +327,32 @@ struct XFusedKernel {
                               : cmake(0.0, 0.0);
       }
     }
-    if (TR < 3) {
+    if (TR < NC) {
       Line<N>::template phase<-1, LP>(r.v[comp], r.jt, lds, L, r.t, a.tw);
-      if (TR == 2 && LP == NPL - 1) {
+      if constexpr (NC == 1) if (LP == NPL - 1) {
+        // scalar Green operator on the spectrum in registers
+        const bool live = r.valid && r.kk < a.nzf;
+        const double kpm1 = live ? a.kpm[1][r.jj] : 1.0, kpm2 = live ? a.kpm[2][r.kk] : 1.0;
+        cplx w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kx = Line<N>::last_index(r.jt, q);
+          cplx e = cscale(a.scale, r.v[0][q]);
+          if (live) {
+            if (kx == 0 && r.jj == 0 && r.kk == 0) {
+              e = cmake(0.0, 0.0);
+            } else {
+              const double kpm0 = a.kpm[0][kx];
+              const double norm_kp2 = kpm0 * kpm0 + kpm1 * kpm1 + kpm2 * kpm2;
+              e = cscale(a.c10 / norm_kp2, e);
+            }
+          }
+          w[q] = e;
+        }
+        r.v[0][inv_slot(0)] = w[0]; r.v[0][inv_slot(1)] = w[1]; r.v[0][inv_slot(2)] = w[2]; r.v[0][inv_slot(3)] = w[3];
+        r.v[0][inv_slot(4)] = w[4]; r.v[0][inv_slot(5)] = w[5]; r.v[0][inv_slot(6)] = w[6]; r.v[0][inv_slot(7)] = w[7];
+      }
+      if constexpr (NC == 3) if (TR == 2 && LP == NPL - 1) {
         // all three spectra are in registers: slot q holds kx = last_index(jt, q)
         const bool live = r.valid && r.kk < a.nzf;
         const double kpm1 = live ? a.kpm[1][r.jj] : 1.0, kpm2 = live ? a.kpm[2][r.kk] : 1.0;
@@ -364,7 +389,7 @@ struct XFusedKernel {
         for (int q = 0; q < 8; ++q)
           a.data[comp * a.comp_stride + r.base + (long)Line<N>::last_index(r.jt, q) * a.ls] = r.v[comp][q];
       }
-      if (PERSIST && LP == NPL - 1 && comp < 2 && r.next_block >= 0) {
+      if (PERSIST && LP == NPL - 1 && comp < 2 && comp + 1 < NC && r.next_block >= 0) {
         // v[comp] is free now: fetch the same component of the next tile into it
         if (comp == 0) locate(r.next_block, r.t, a, &r.base_n, &r.jj_n, &r.kk_n, &r.valid_n);
 #pragma unroll

@@ -459,21 +459,33 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     time_begin(3);
     fft_->c2c_y(buf, 1, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
     time_end(3);
-    time_begin(4);
-    fft_->c2c_x(buf, 1, g_.n, -1, has_x ? scale : 1.0);
-    time_end(4);
-    if (!has_x && !has_y) fft_->scale(buf, 1, g_.n, scale);
-    G0Tables tb;
-    for (int a = 0; a < 3; ++a) {
-      tb.kpm[a] = g0_kpm_[a];
-      tb.kp[a] = g0_kp_[a];
+    const double c10 = -alpha / (2 * opt_.mu_0);  // G0OperatorFourierStaggeredHeat  F:19759-19764
+    if (opt_.fuse_x && fft_->can_fuse(0) && has_x) {
+      // x transform, 1/N, scalar Green operator and inverse x transform in one kernel
+      G0Params gp;
+      for (int a = 0; a < 3; ++a) gp.kpm[a] = g0_kpm_[a], gp.kp[a] = g0_kp_[a];
+      gp.c10 = c10;
+      gp.c20 = 0.0;
+      time_begin(5);
+      fft_->fused_g0(buf, g_.n, 0, scale, gp, 0, 1);
+      time_end(5);
+    } else {
+      time_begin(4);
+      fft_->c2c_x(buf, 1, g_.n, -1, has_x ? scale : 1.0);
+      time_end(4);
+      if (!has_x && !has_y) fft_->scale(buf, 1, g_.n, scale);
+      G0Tables tb;
+      for (int a = 0; a < 3; ++a) {
+        tb.kpm[a] = g0_kpm_[a];
+        tb.kp[a] = g0_kp_[a];
+      }
+      time_begin(5);
+      launch_g0_heat(g_, buf, tb, c10, stream_);
+      time_end(5);
+      time_begin(6);
+      fft_->c2c_x(buf, 1, g_.n, +1, 1.0);
+      time_end(6);
     }
-    time_begin(5);
-    launch_g0_heat(g_, buf, tb, -alpha / (2 * opt_.mu_0), stream_);  // G0OperatorFourierStaggeredHeat  F:19759-19764
-    time_end(5);
-    time_begin(6);
-    fft_->c2c_x(buf, 1, g_.n, +1, 1.0);
-    time_end(6);
     time_begin(7);
     fft_->c2c_y(buf, 1, g_.n, +1, 1.0);
     time_end(7);

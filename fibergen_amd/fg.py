@@ -704,6 +704,32 @@ class FG:
                 raise RuntimeError("%s needs a file name" % name)
             self.write_vtk(fn)
             return None
+        if name == "write_raw_data":
+            # FG::run_actions  F:25448-25493 + writeRawPhase  F:17004-17074: phase fraction * scale cast to dtype
+            # (C truncation), column order = x fastest in the file (default) or row order = z fastest; .gz compressed
+            fn = self._attr(act, "filename", None, str)
+            dtype = self._attr(act, "dtype", "uint8", str)
+            col = self._attr(act, "order", "col", str) == "col"
+            self.init_lss()
+            m = self._material_id(self._attr(act, "material", "", str))
+            self.init_phase()
+            types = {"uint8": (np.uint8, 0.9999 + 0xff), "uint16": (np.uint16, 0.9999 + 0xffff),
+                     "uint32": (np.uint32, 0.9999 + 0xffffffff), "float": (np.float32, 1.0), "double": (np.float64, 1.0)}
+            if dtype not in types:
+                raise RuntimeError("Unknown dtype '%s'" % dtype)
+            typ, scale = types[dtype]
+            scale = self._attr(act, "scale", scale)
+            phi = self._lss.get_field("phi")[m] * scale
+            data = phi.astype(typ)  # float -> integer conversion truncates like the C cast
+            raw = (data.transpose(2, 1, 0) if col else data).tobytes()
+            if fn.endswith(".gz"):
+                import gzip
+                with gzip.open(fn, "wb") as f:
+                    f.write(raw)
+            else:
+                with open(fn, "wb") as f:
+                    f.write(raw)
+            return None
         if name == "write_vtk_phase":
             self.init_lss()
             self.init_phase()

@@ -322,3 +322,27 @@ def test_fg_collocated_scheme_project():
     o = LSOracle(15, 15, 15, mats=[(m0["mu"], m0["lambda"]), (m1["mu"], m1["lambda"])], phis=[phi[0], phi[1]],
                  tol=1e-8, gamma_scheme="collocated")
     assert rel_err(C, o.calc_effective_properties()) < 1e-9
+
+
+def test_write_raw_data_round_trips_through_read_raw_data(tmp_path):
+    """write_raw_data  F:25448-25493 / writeRawPhase  F:17004-17074 and read_raw_data are inverse to each other
+    (uint8 quantisation 1/255; double exact) in both orders."""
+    fn8, fnd = str(tmp_path / "phi.raw.gz"), str(tmp_path / "phi_d.raw")
+    fg = FG()
+    fg.set_xml("""
+    <settings><solver nx="12" ny="10" nz="8"><materials><matrix E="1" nu="0.3" /><incl E="10" nu="0.2" /></materials></solver>
+      <actions><select_material name="incl" /><place_fiber R="0.3" /><init_phase />
+      <write_raw_data filename="%s" material="incl" />
+      <write_raw_data filename="%s" material="incl" dtype="double" order="row" /></actions></settings>""" % (fn8, fnd))
+    assert fg.run() == 0
+    phi = fg.get_field("incl")[0]
+    raw = np.frombuffer(gzip.open(fn8, "rb").read(), dtype=np.uint8).reshape(8, 10, 12).transpose(2, 1, 0)
+    assert np.array_equal(raw, (phi * (0.9999 + 255)).astype(np.uint8))
+    rawd = np.fromfile(fnd, dtype=np.float64).reshape(12, 10, 8)
+    assert np.array_equal(rawd, phi)
+    fg2 = FG()
+    fg2.set_xml("""
+    <settings><solver nx="12" ny="10" nz="8"><materials><matrix E="1" nu="0.3" /><incl E="10" nu="0.2" /></materials></solver>
+      <actions><read_raw_data filename="%s" material="incl" dtype="double" order="row" /><init_phase /></actions></settings>""" % fnd)
+    assert fg2.run() == 0
+    assert np.array_equal(fg2.get_field("incl")[0], phi)
