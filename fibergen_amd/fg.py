@@ -79,6 +79,7 @@ class FG:
         self._matrix_mat = 0
         self._phi = None        # host copy of the phase fields [nphase][nx][ny][nz]
         self._normals = None
+        self._raw_normals = None
         self._want_normals = False
         self._method = "cg"
         self._mode = "elasticity"
@@ -349,6 +350,9 @@ class FG:
             if self._injected_normals.shape != (3,) + shape:
                 raise RuntimeError("normals must have shape (3, nx, ny, nz)")
             self._normals = self._injected_normals
+        elif self._raw_phase and getattr(self, "_raw_normals", None) is not None and \
+                (self._want_normals or self._mixing == "laminate"):
+            self._normals = self._raw_normals   # initMultiphase centroid normals  F:16861-16907
         if self._raw_phase:
             phi = self._phi
         else:
@@ -872,9 +876,44 @@ class FG:
             if not known.all():
                 raise RuntimeError("Material value %d not mapped!" % int(cls[~known].flat[0]))
             ns = s[0] * s[1] * s[2]
-            for m in range(len(self._phase_names)):
+            nph = len(self._phase_names)
+            counts = np.zeros((nph,) + shape)
+            cent = np.zeros((nph, 3) + shape)
+            off = [np.arange(s[a]) + 0.5 for a in range(3)]
+            for m in range(nph):
                 vals = [v for v, mm in mapping.items() if mm == m]
-                self._phi[m] = np.isin(cls, vals).sum(axis=(1, 3, 5)) / float(ns) if vals else 0.0
+                if not vals:
+                    continue
+                sel = np.isin(cls, vals)
+                counts[m] = sel.sum(axis=(1, 3, 5))
+                # centroid sums of the fine voxels of class m inside each coarse voxel  F:16826-16832
+                cent[m, 0] = (sel * off[0][None, :, None, None, None, None]).sum(axis=(1, 3, 5))
+                cent[m, 1] = (sel * off[1][None, None, None, :, None, None]).sum(axis=(1, 3, 5))
+                cent[m, 2] = (sel * off[2][None, None, None, None, None, :]).sum(axis=(1, 3, 5))
+                self._phi[m] = counts[m] / float(ns)
+            for m in range(nph):
+                if not any(mm == m for mm in mapping.values()):
+                    self._phi[m] = 0.0
+            # interface normals of the down-sampled data  F:16861-16907: from the voxel centre to the centroid of the
+            # material with the largest share; the search starts at the class of the last fine voxel visited
+            last_cls = cls[:, -1, :, -1, :, -1]
+            cur = np.vectorize(mapping.get)(last_cls).astype(np.int64)
+            for m in range(nph):
+                take = counts[m] > np.take_along_axis(counts, cur[None], axis=0)[0]
+                cur = np.where(take, m, cur)
+            cnt = np.take_along_axis(counts, cur[None], axis=0)[0]
+            nrm = np.stack([np.take_along_axis(cent[:, a], cur[None], axis=0)[0] / cnt - 0.5 * s[a] for a in range(3)])
+            mag = np.sqrt((nrm * nrm).sum(axis=0))
+            flat = mag < 1e-9
+            if flat.any():
+                # "random" normal e_(kk % 3), kk = index in the reference's padded layout (nzp = 2 (nz/2 + 1))
+                nzp_ref = 2 * (shape[2] // 2 + 1)
+                ii, jj, kk3 = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+                k3 = (ii * shape[1] * nzp_ref + jj * nzp_ref + kk3) % 3
+                for a in range(3):
+                    nrm[a] = np.where(flat, (k3 == a).astype(np.float64), nrm[a])
+                mag = np.where(flat, 1.0, mag)
+            self._raw_normals = nrm / mag
         self._phase_valid = False
         return None
 

@@ -346,3 +346,37 @@ def test_write_raw_data_round_trips_through_read_raw_data(tmp_path):
       <actions><read_raw_data filename="%s" material="incl" dtype="double" order="row" /><init_phase /></actions></settings>""" % fnd)
     assert fg2.run() == 0
     assert np.array_equal(fg2.get_field("incl")[0], phi)
+
+
+def test_raw_class_data_downsampled_with_centroid_normals(tmp_path):
+    """initMultiphase  F:16761-16922: class data at twice the solver resolution -> volume fractions by counting and
+    interface normals from the voxel centre to the centroid of the dominant material; laminate mixing runs on them."""
+    n, f = 16, 2
+    N = n * f
+    x = (np.arange(N) + 0.5) / N - 0.5
+    r = np.sqrt(x[:, None, None] ** 2 + x[None, :, None] ** 2 + x[None, None, :] ** 2)
+    cls = (r < 0.3).astype(np.uint8)
+    fn = tmp_path / "cls.raw"
+    fn.write_bytes(cls.transpose(2, 1, 0).tobytes())
+    fg = FG()
+    fg.set_xml("""
+    <settings><solver n="%d"><method>basic</method><tol>1e-6</tol><mixing_rule>laminate</mixing_rule>
+      <materials><matrix E="1" nu="0.3" /><incl E="10" nu="0.2" /></materials></solver>
+      <actions><read_raw_data filename="%s" n="%d" scale="1" material_0="matrix" material_1="incl" />
+      <init_phase normals="1" /><run_load_case e11="1" /></actions></settings>""" % (n, fn, N))
+    assert fg.run() == 0
+    phi = fg.get_field("incl")[0]
+    assert np.array_equal(phi, cls.reshape(n, f, n, f, n, f).mean(axis=(1, 3, 5)))
+    nrm = fg.get_field("normals")
+    assert np.allclose((nrm * nrm).sum(axis=0), 1.0, atol=1e-12)
+    mixed = (phi > 0) & (phi < 1)
+    assert mixed.sum() > 50
+    c = (np.arange(n) + 0.5) / n - 0.5
+    rad = np.stack(np.broadcast_arrays(c[:, None, None], c[None, :, None], c[None, None, :]))
+    rad = rad / np.sqrt((rad * rad).sum(axis=0))
+    cosang = (nrm * rad).sum(axis=0)[mixed]
+    # the centroid of the dominant material lies inward where the inclusion dominates, outward otherwise
+    dom_incl = phi[mixed] > 0.5
+    assert np.all(cosang[dom_incl] < 0.2) and np.all(cosang[~dom_incl & (phi[mixed] < 0.5)] > -0.2)
+    assert np.mean(np.abs(cosang)) > 0.7
+    assert np.isfinite(np.array(fg.get_mean_stress())).all()
