@@ -91,6 +91,9 @@ void launch_gamma_collocated(const Grid& g, const FieldPtrs<6>& th, const XiTabl
                              const Vec6& E, hipStream_t s);
 void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps, const Vec6& E, const Vec6& R,
                      bool add_R, double* partial, double* sumsq6, const XHalo& h, hipStream_t s);
+// viscosity: eta = (E - coef tau_sum / nvox) + sym grad u + coef tau, sums of squares (tau_sum on the device)
+void launch_eps_delta(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& tau, const double* tau_sum, double nvox,
+                      const Vec6& E, double coef, const FieldPtrs<6>& eps, double* partial, double* sumsq6, hipStream_t s);
 void launch_transpose_A(const double* src, double* dst, int nxl, int ny, int nyl, int nzc, bool to_blocks, hipStream_t s);
 void launch_transpose_B(const double* src, double* dst, int nx, int nxl, int nyl, int nzc, bool to_blocks, hipStream_t s);
 void launch_copy(const double* src, double* dst, long ndoubles, hipStream_t s);

@@ -661,6 +661,69 @@ __global__ __launch_bounds__(kBlock, 2) void k_u_stress(Grid g, StressParams sp,
   }
 }
 
+// ----------------------------------------------------------------------------- viscosity: strain + Delta-operator tail
+// DeltaOperatorStaggered  F:20438-20452 after the Green operator:  eta = (E - coef <tau>) + sym grad u + coef tau  with
+// coef = 2 alpha / (4 mu0), the mean <tau> = tau_sum / N read from device memory (no host round trip), and the sums of
+// squares of eta.  Same operation order as k_eps_norm followed by xpay.
+__global__ __launch_bounds__(kBlock) void k_eps_delta(Grid g, FieldPtrs<3> u, FieldPtrs<6> tau, const double* tau_sum,
+                                                      double nvox, Vec6 E, double coef, FieldPtrs<6> eps, double* partial,
+                                                      Sweep ry) {
+  __shared__ double smem[4 * 6];
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  double adj[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) adj[c] = E.v[c] - coef * (tau_sum[c] / nvox);
+  const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
+  for (long it = 0; it < run.count; ++it) {
+    const long pidx = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    if (pidx >= npairs) continue;
+    const PairPos p = pair_pos_tiled(pidx, g, ry);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+    const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+    const long rowoff = p.off - p.k;
+    const int kb = p.k == 0 ? g.nz - 1 : p.k - 1;
+    const int kf2 = (p.k + 2 >= g.nz) ? p.k + 2 - g.nz : p.k + 2;
+    const double2 u0 = ld2(u.p[0], p.off), u1 = ld2(u.p[1], p.off), u2 = ld2(u.p[2], p.off);
+    const double2 u0xf = ld2(u.p[0], p.off + xf), u1xb = ld2(u.p[1], p.off + xb), u2xb = ld2(u.p[2], p.off + xb);
+    const double2 u0yb = ld2(u.p[0], p.off + yb), u1yf = ld2(u.p[1], p.off + yf), u2yb = ld2(u.p[2], p.off + yb);
+    const double u0zb = u.p[0][rowoff + kb], u1zb = u.p[1][rowoff + kb];
+    const double u2zf2 = u.p[2][rowoff + kf2];
+    const double u2zf1 = second ? u2.y : u.p[2][rowoff];
+    double2 e[6];
+    e[3].x = adj[3] + 0.5 * ((u2.x - u2yb.x) * hy + (u1.x - u1zb) * hz);
+    e[4].x = adj[4] + 0.5 * ((u2.x - u2xb.x) * hx + (u0.x - u0zb) * hz);
+    e[5].x = adj[5] + 0.5 * ((u1.x - u1xb.x) * hx + (u0.x - u0yb.x) * hy);
+    e[0].x = adj[0] + (u0xf.x - u0.x) * hx;
+    e[1].x = adj[1] + (u1yf.x - u1.x) * hy;
+    e[2].x = adj[2] + (u2zf1 - u2.x) * hz;
+    e[3].y = adj[3] + 0.5 * ((u2.y - u2yb.y) * hy + (u1.y - u1.x) * hz);
+    e[4].y = adj[4] + 0.5 * ((u2.y - u2xb.y) * hx + (u0.y - u0.x) * hz);
+    e[5].y = adj[5] + 0.5 * ((u1.y - u1xb.y) * hx + (u0.y - u0yb.y) * hy);
+    e[0].y = adj[0] + (u0xf.y - u0.y) * hx;
+    e[1].y = adj[1] + (u1yf.y - u1.y) * hy;
+    e[2].y = adj[2] + (u2zf2 - u2.y) * hz;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double2 t = ld2(tau.p[c], p.off);
+      e[c].x = e[c].x + coef * t.x;
+      e[c].y = second ? e[c].y + coef * t.y : 0.0;
+      acc[c] += e[c].x * e[c].x + e[c].y * e[c].y;
+      st2(eps.p[c], p.off, e[c]);
+    }
+  }
+  block_reduce<6>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+  }
+}
+
 // ----------------------------------------------------------------------------- plain reductions
 // Per-component sums (TensorField::average F:10171-10210) or sums of squares over the
 // valid voxels of NC components.
@@ -987,6 +1050,16 @@ void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& e
                      bool add_R, double* partial, double* sumsq6, const XHalo& h, hipStream_t s) {
   const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
   hipLaunchKernelGGL(k_eps_norm, dim3(nb), dim3(kBlock), 0, s, g, u, eps, E, R, add_R ? 1 : 0, partial, h,
+                     chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 6, sumsq6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_eps_delta(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& tau, const double* tau_sum, double nvox,
+                      const Vec6& E, double coef, const FieldPtrs<6>& eps, double* partial, double* sumsq6, hipStream_t s) {
+  const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
+  hipLaunchKernelGGL(k_eps_delta, dim3(nb), dim3(kBlock), 0, s, g, u, tau, tau_sum, nvox, E, coef, eps, partial,
                      chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);

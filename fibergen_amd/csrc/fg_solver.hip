@@ -340,25 +340,19 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     time_begin(0);
     launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, nrm, ptrs6(tau_), derr_, stream_);
     time_end(0);
-    launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);   // tau_copy->average()
-    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    FG_HIP_CHECK(hipStreamSynchronize(stream_));
-    Vec6 adj, R;
-    for (int c = 0; c < 6; ++c) {
-      adj.v[c] = E6[c] - 2 * alpha * m * (hscal_[kSlotMean + c] / (double)nglobal_);
-      R.v[c] = 0.0;
-    }
+    launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);   // tau_copy->average(), stays on the device
     time_begin(1);
     launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
     time_end(1);
     const double mu_g = -1.0 / (4 * m);
     const double c12[2] = {-alpha / mu_g, -alpha / mu_g};
     fft_g0_chain(fu_, false, alpha, c12);
+    // adj = E - 2 alpha m <tau>;  eta = adj + sym grad u;  eta.xpay(eta, 2 alpha m, tau_copy)  F:20438-20452, one sweep
+    Vec6 Ev;
+    for (int c = 0; c < 6; ++c) Ev.v[c] = E6[c];
     time_begin(9);
-    launch_eps_norm(g_, ptrs3(fu_), ptrs6(dst), adj, R, false, partial_, dscal_ + kSlotScratch,
-                    XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
-    // eta.xpay(eta, 2 alpha m, tau_copy)  F:20452, with the sums of squares of the result
-    launch_cg(2, g_, ptrs6(dst), ptrs6(tau_), ptrs6(tau_), adj, 2 * alpha * m, partial_, dscal_ + kSlotSumSq, stream_);
+    launch_eps_delta(g_, ptrs3(fu_), ptrs6(tau_), dscal_ + kSlotMean, (double)nglobal_, Ev, 2 * alpha * m, ptrs6(dst), partial_,
+                     dscal_ + kSlotSumSq, stream_);
     time_end(9);
     if (timing_) times_.count++;
     u_valid_ = false;
