@@ -77,8 +77,9 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   FG_HIP_CHECK(hipMemsetAsync(derr_, 0, sizeof(int), stream_));
 
   fft_.reset(new Fft3(g_, stream_));
-  if (nranks_ > 1 || true) {
-    // x-lines in the y-slab layout [nyl][nx][nzc] are "y lines" of a (nyl, nx, nz) grid
+  {
+    // slab phases (also driven with nranks = 1 by the tests): x-lines in the y-slab layout [nyl][nx][nzc] are
+    // "y lines" of a (nyl, nx, nz) grid
     fft_t_.reset(new Fft3(make_grid(nyl_, nxg_, nz, 1.0, 1.0, 1.0), stream_));
     const size_t plane = (size_t)g_.nyzp * sizeof(double);
     for (int k = 0; k < 4; ++k) {
