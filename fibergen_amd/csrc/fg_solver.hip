@@ -1231,8 +1231,10 @@ void Solver::get_field(const std::string& name, double* out) {
   ensure_eps();
   // fu_ is overwritten by the displacement reconstruction (scalar modes: by an equivalent potential, still valid)
   if (name == "u" && opt_.mode != 1) u_valid_ = false;
-  if (name == "sumsq") {
-    for (int c = 0; c < 6; ++c) out[c] = sumsq_[c];
+  if (name == "sumsq") {  // the six sums of squares of the last norm sweep (device slot; the displacement loop keeps them there)
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    for (int c = 0; c < 6; ++c) out[c] = sumsq_[c] = hscal_[kSlotSumSq + c];
     return;
   }
   if (name == "f_hat") {  // complex [3][nx][ny][nz/2+1], row padding stripped

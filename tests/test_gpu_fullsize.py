@@ -1,0 +1,106 @@
+"""Parity at BASELINE.json's full sizes (256^3 default config, 512^3 roofline config) through size-independent
+properties: the oracle cannot run there in seconds, so the fast pipeline is checked against the exact-order
+pipeline of the same library (itself bit-exact against the oracle at small sizes, tests/test_gpu_parity.py),
+and against analytic facts: mean strain = prescribed strain after every pass, homogeneous medium, the
+staggered eps-G0-div identity (F:24129-24151), linearity of the pass."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _lattice_phi(n, R=0.31):
+    """periodic lattice of 4^3 spheres, voxel-centre sampling with a smooth rim (values in [0, 1])"""
+    c = ((np.arange(n) + 0.5) / n * 4) % 1.0 - 0.5
+    d = np.sqrt(c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2)
+    return np.clip((R - d) * n / 4 + 0.5, 0.0, 1.0)
+
+
+def _solver(n, **kw):
+    from fibergen_amd import LSSolver
+    from helpers import INCLUSION, MATRIX, lame
+    phi = _lattice_phi(n)
+    s = LSSolver(n, n, n)
+    s.set_num_phases(2)
+    m0, m1 = lame(**MATRIX), lame(**INCLUSION)
+    s.set_phase(0, m0[0], m0[1], 1.0 - phi)
+    s.set_phase(1, m1[0], m1[1], phi)
+    s.set_options(**kw)
+    return s
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_fast_pipeline_equals_exact_pipeline_at_full_size(n):
+    """k iterations of the default pipeline (tiled sweep, fused x pass) against the exact-order displacement loop and
+    the strain-state pipeline: same residual norms to rounding, same mean stress, mean strain = E."""
+    E = np.array([1.0, 0.0, 0.0, 0.0, 0.0, 0.5])
+    res = {}
+    for name, opts in (("fast", {}), ("exact", dict(u_loop=1)), ("plain", dict(u_loop=0, fuse_x=0, fuse_stress_div=0))):
+        s = _solver(n, **opts)
+        s.calc_ref_material()
+        if name == "plain":
+            # the displacement loop's norm sweep belongs to the strain of the previous pass: compare like with like
+            s.iterate(E, 5)
+            ss = s.get_field("sumsq")
+            s.iterate(E, 1)
+        else:
+            s.iterate(E, 6)
+            ss = s.get_field("sumsq")
+        res[name] = (ss, s.mean_stress(), s.mean_strain(), s.ref_material)
+        s.close()
+    for other in ("exact", "plain"):
+        assert res["fast"][3] == res[other][3]
+        np.testing.assert_allclose(res["fast"][0], res[other][0], rtol=1e-11)
+        np.testing.assert_allclose(res["fast"][1], res[other][1], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(res["fast"][2], E, atol=1e-12)
+    assert np.array_equal(res["exact"][0], res["plain"][0]) or np.allclose(res["exact"][0], res["plain"][0], rtol=1e-13)
+
+
+def test_homogeneous_medium_and_identity_at_256():
+    """(i) one phase everywhere: eps == E after one pass for any start; (ii) staggered epsG0div identity on a random
+    displacement field: eps(G0(div(C0 : eps(u)))) == eps(u)  (F:24129-24151) at 256^3."""
+    from fibergen_amd import LSSolver
+    n = 256
+    s = LSSolver(n, n, n)
+    s.set_num_phases(1)
+    s.set_phase(0, 0.7, 1.1, np.ones((n, n, n)))
+    s.set_options(mu_0=0.7, lambda_0=1.1, update_ref="never")
+    E = np.array([0.3, -0.2, 0.1, 0.05, 0.0, 0.4])
+    s.iterate(E, 3)
+    ss = s.get_field("sumsq")
+    np.testing.assert_allclose(ss / n ** 3, E * E, rtol=1e-12, atol=1e-26)
+    np.testing.assert_allclose(s.mean_strain(), E, atol=1e-14)
+    # identity: u random -> eps0 = grad_s u ; tau = C0 : eps0 ; f = div tau ; u' = G0 f (alpha = 1) ; eps1 = grad_s u'
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal((3, n, n, n))
+    s.set_field("u", u)
+    s.run_stage("eps", np.zeros(6))
+    e0 = s.get_field("epsilon")
+    s.run_stage("stress_const", None)
+    s.run_stage("div", None)
+    s.run_stage("fft_forward", None)
+    s.run_stage("g0", np.array([1.0, 0, 0, 0, 0, 0]))
+    s.run_stage("fft_inverse", None)
+    s.run_stage("eps", np.zeros(6))
+    e1 = s.get_field("epsilon")
+    assert np.abs(e1 - e0).max() <= 1.5e-8 * max(1.0, np.abs(e0).max())   # the reference's tolerance sqrt(eps)
+    assert np.abs(e1 - e0).max() <= 1e-9 * np.abs(e0).max()
+    s.close()
+
+
+def test_pass_is_affine_at_256():
+    """One pass is affine in the strain: B(a e1 + (1-a) e2) == a B(e1) + (1-a) B(e2)."""
+    n = 256
+    s = _solver(n, u_loop=0, mu_0=0.9, lambda_0=0.2, update_ref="never")
+    rng = np.random.default_rng(1)
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    e1 = rng.standard_normal((6, n, n, n))
+    e2 = rng.standard_normal((6, n, n, n))
+    out = []
+    for e in (e1, e2, 0.25 * e1 + 0.75 * e2):
+        s.set_field("epsilon", e)
+        s.run_stage("iteration", E)
+        out.append(s.get_field("epsilon"))
+    s.close()
+    ref = 0.25 * out[0] + 0.75 * out[1]
+    assert np.abs(out[2] - ref).max() <= 1e-11 * np.abs(ref).max()
