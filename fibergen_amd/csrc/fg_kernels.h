@@ -84,6 +84,13 @@ void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 void launch_u_stress(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
                      const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, const Vec6& E, double* partial, double* sumsq6,
                      int* error_flag, hipStream_t s);
+// interface voxels (some phase fraction strictly between 0 and 1): count (list == nullptr) or fill the list of their
+// element offsets; then the laminate polarisation at those voxels only
+unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned* list, unsigned* count_dev,
+                           hipStream_t s);
+void launch_laminate_fix(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
+                         const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, const Vec6& E, const unsigned* list, unsigned n,
+                         int* error_flag, hipStream_t s);
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);
 void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
                hipStream_t s);

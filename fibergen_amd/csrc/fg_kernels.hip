@@ -661,6 +661,65 @@ __global__ __launch_bounds__(kBlock, 2) void k_u_stress(Grid g, StressParams sp,
   }
 }
 
+// ----------------------------------------------------------------------------- laminate rule at interface voxels only
+// The laminate rule differs from Voigt mixing only where a voxel holds two phases (pure voxels take the same Hooke
+// branch, F:13464-13470 vs F:12752-12761), and its one-step Newton solve is ~400 flop with a large register
+// footprint.  So the sweep over all voxels runs the cheap Voigt form of k_u_stress, and this kernel then re-evaluates
+// the polarisation at the interface voxels alone, from a compact list built once per geometry.
+__global__ __launch_bounds__(kBlock) void k_mixed_list(Grid g, int nph, FieldPtrs<kMaxPhases> phi, unsigned* list,
+                                                       unsigned* count) {
+  const long nvox = (long)g.nx * g.ny * g.nz;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long)gridDim.x * blockDim.x) {
+    const long row = v / g.nz;
+    const int k = (int)(v - row * g.nz);
+    const long off = row * g.nzp + k;
+    bool mixed = false;
+    for (int q = 0; q < nph; ++q) {
+      const double f = phi.p[q][off];
+      mixed = mixed || (f != 0.0 && f != 1.0);
+    }
+    if (mixed) {
+      const unsigned slot = atomicAdd(count, 1u);
+      if (list) list[slot] = (unsigned)off;   // order is irrelevant: every entry writes its own voxel
+    }
+  }
+}
+
+template <int NPH>
+__global__ __launch_bounds__(kBlock) void k_laminate_fix(Grid g, StressParams sp, FieldPtrs<3> u, FieldPtrs<kMaxPhases> phi,
+                                                         FieldPtrs<3> normals, FieldPtrs<6> tau, Vec6 E,
+                                                         const unsigned* list, unsigned n, int* error_flag) {
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const long off = list[idx];
+    const long row = off / g.nzp;
+    const int k = (int)(off - row * g.nzp);
+    const int i = (int)(row / g.ny), j = (int)(row - (long)i * g.ny);
+    const long xf = (i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long xb = (i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    const long yf = (j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+    const long yb = (j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+    const long zf = (k + 1 == g.nz ? -(long)(g.nz - 1) : 1L);
+    const long zb = (k == 0 ? (long)(g.nz - 1) : -1L);
+    const double u0 = u.p[0][off], u1 = u.p[1][off], u2 = u.p[2][off];
+    double F[6];
+    // epsOperatorStaggered  F:18632-18686, the expressions of k_u_stress for one voxel
+    F[3] = E.v[3] + 0.5 * ((u2 - u.p[2][off + yb]) * hy + (u1 - u.p[1][off + zb]) * hz);
+    F[4] = E.v[4] + 0.5 * ((u2 - u.p[2][off + xb]) * hx + (u0 - u.p[0][off + zb]) * hz);
+    F[5] = E.v[5] + 0.5 * ((u1 - u.p[1][off + xb]) * hx + (u0 - u.p[0][off + yb]) * hy);
+    F[0] = E.v[0] + (u.p[0][off + xf] - u0) * hx;
+    F[1] = E.v[1] + (u.p[1][off + yf] - u1) * hy;
+    F[2] = E.v[2] + (u.p[2][off + zf] - u2) * hz;
+    double ph[NPH], nv[3], P[6];
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) ph[q] = q < sp.pt.n ? phi.p[q][off] : 0.0;
+    nv[0] = normals.p[0][off]; nv[1] = normals.p[1][off]; nv[2] = normals.p[2][off];
+    if (stress_voxel<NPH>(F, ph, nv, sp, P)) atomicOr(error_flag, 1);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tau.p[c][off] = P[c];
+  }
+}
+
 // ----------------------------------------------------------------------------- viscosity: strain + Delta-operator tail
 // DeltaOperatorStaggered  F:20438-20452 after the Green operator:  eta = (E - coef <tau>) + sym grad u + coef tau  with
 // coef = 2 alpha / (4 mu0), the mean <tau> = tau_sum / N read from device memory (no host round trip), and the sums of
@@ -1023,6 +1082,32 @@ void launch_u_stress(const Grid& g, const StressParams& sp, const FieldPtrs<3>& 
 #undef FG_LAUNCH
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned* list, unsigned* count_dev,
+                           hipStream_t s) {
+  if ((long)g.nx * g.ny * g.nzp >= (1L << 32)) throw std::runtime_error("grid too large for the 32-bit interface list");
+  FG_HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(unsigned), s));
+  const long nvox = (long)g.nx * g.ny * g.nz;
+  hipLaunchKernelGGL(k_mixed_list, dim3(grid_for(nvox, 1 << 16)), dim3(kBlock), 0, s, g, nph, phi, list, count_dev);
+  FG_HIP_CHECK(hipGetLastError());
+  unsigned n = 0;
+  FG_HIP_CHECK(hipMemcpyAsync(&n, count_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  FG_HIP_CHECK(hipStreamSynchronize(s));
+  return n;
+}
+
+void launch_laminate_fix(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
+                         const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, const Vec6& E, const unsigned* list, unsigned n,
+                         int* error_flag, hipStream_t s) {
+  if (n == 0) return;
+  const dim3 grid(grid_for((long)n, 1 << 16));
+  if (sp.pt.n <= 2)
+    hipLaunchKernelGGL((k_laminate_fix<2>), grid, dim3(kBlock), 0, s, g, sp, u, phi, normals, tau, E, list, n, error_flag);
+  else
+    hipLaunchKernelGGL((k_laminate_fix<kMaxPhases>), grid, dim3(kBlock), 0, s, g, sp, u, phi, normals, tau, E, list, n,
+                       error_flag);
   FG_HIP_CHECK(hipGetLastError());
 }
 

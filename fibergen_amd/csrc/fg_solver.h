@@ -168,6 +168,10 @@ class Solver {
   double* tau_ = nullptr;      // 6
   double* fu_ = nullptr;       // 3 (real f / u, complex f_hat / u_hat); after a pass it holds u
   double *cg_r_ = nullptr, *cg_p_ = nullptr, *cg_w_ = nullptr;  // CG residual, direction, operator image (6 each)
+  unsigned* mixed_list_ = nullptr;  // element offsets of the interface voxels (laminate mixing, displacement loop)
+  unsigned* mixed_count_dev_ = nullptr;
+  unsigned mixed_n_ = 0;
+  bool mixed_dirty_ = true;
   double* mod_ = nullptr;      // 2: per-voxel effective moduli (sum phi 2 mu, sum phi lambda) of the fast sweep
   bool mod_dirty_ = true;
   double* fu_alt_ = nullptr;   // 3: second f/u buffer of the displacement-based loop (swapped with fu_)

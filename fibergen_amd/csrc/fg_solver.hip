@@ -134,6 +134,8 @@ Solver::~Solver() {
   fft_t_.reset();
   for (int k = 0; k < 4; ++k)
     if (halo_[k]) (void)hipFree(halo_[k]);
+  if (mixed_list_) (void)hipFree(mixed_list_);
+  if (mixed_count_dev_) (void)hipFree(mixed_count_dev_);
   double* bufs[] = {eps_, tau_, fu_, fu_alt_, phi_, normals_, partial_, dscal_, cg_r_, cg_p_, cg_w_, mod_};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
@@ -160,11 +162,13 @@ void Solver::set_num_phases(int n) {
   FG_HIP_CHECK(hipMemset(phi_, 0, (size_t)n * g_.n * sizeof(double)));
   pt_.n = n;
   mod_dirty_ = true;
+  mixed_dirty_ = true;
 }
 
 void Solver::set_phase_material(int p, double mu, double lambda) {
   if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
   mod_dirty_ = true;
+  mixed_dirty_ = true;
   pt_.mu[p] = mu;
   pt_.lambda[p] = lambda;
 }
@@ -172,6 +176,7 @@ void Solver::set_phase_material(int p, double mu, double lambda) {
 void Solver::set_phase_field(int p, const double* phi_host) {
   if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
   mod_dirty_ = true;
+  mixed_dirty_ = true;
   upload_padded(phi_ + (long)p * g_.n, phi_host);
 }
 
@@ -596,6 +601,7 @@ void Solver::u_pass_front(const double* E6) {
       if (!mod_) {
         FG_HIP_CHECK(hipMalloc(&mod_, 2 * (size_t)g_.n * sizeof(double)));
         mod_dirty_ = true;
+  mixed_dirty_ = true;
       }
       if (mod_dirty_) {
         PhaseTable half = pt_;  // k_effective_moduli stores sum phi 2 mu: feed mu / 2
@@ -615,8 +621,29 @@ void Solver::u_pass_front(const double* E6) {
     z_done_ = false;
     FieldPtrs<3> nrm;
     for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
-    launch_u_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, ptrs6(tau_), E, partial_,
-                    dscal_ + kSlotSumSq, derr_, stream_);
+    if (opt_.u_loop >= 2) {
+      // all voxels with the cheap Voigt form (identical at pure voxels), then the laminate rule at the interface
+      // voxels only, from a list built once per geometry
+      if (mixed_dirty_ || !mixed_count_dev_) {
+        if (!mixed_count_dev_) FG_HIP_CHECK(hipMalloc(&mixed_count_dev_, sizeof(unsigned)));
+        if (mixed_list_) FG_HIP_CHECK(hipFree(mixed_list_));
+        mixed_list_ = nullptr;
+        mixed_n_ = launch_mixed_list(g_, pt_.n, phi, nullptr, mixed_count_dev_, stream_);
+        if (mixed_n_) {
+          FG_HIP_CHECK(hipMalloc(&mixed_list_, (size_t)mixed_n_ * sizeof(unsigned)));
+          launch_mixed_list(g_, pt_.n, phi, mixed_list_, mixed_count_dev_, stream_);
+        }
+        mixed_dirty_ = false;
+      }
+      StressParams spv = stress_params(opt_.mu_0, opt_.lambda_0, 1.0);
+      spv.mixing = kMixVoigt;
+      launch_u_stress(g_, spv, ptrs3(fu_), phi, nrm, ptrs6(tau_), E, partial_, dscal_ + kSlotSumSq, derr_, stream_);
+      launch_laminate_fix(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, ptrs6(tau_), E, mixed_list_,
+                          mixed_n_, derr_, stream_);
+    } else {
+      launch_u_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, ptrs6(tau_), E, partial_,
+                      dscal_ + kSlotSumSq, derr_, stream_);
+    }
     time_end(0);
     time_begin(1);
     launch_div(g_, ptrs6(tau_), ptrs3(fu_alt_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
@@ -628,6 +655,7 @@ void Solver::u_pass_front(const double* E6) {
     if (!mod_) {
       FG_HIP_CHECK(hipMalloc(&mod_, 2 * (size_t)g_.n * sizeof(double)));
       mod_dirty_ = true;
+  mixed_dirty_ = true;
     }
     FieldPtrs<2> mod;
     mod.p[0] = mod_;
