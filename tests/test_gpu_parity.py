@@ -477,3 +477,32 @@ def test_tiled_displacement_sweep(grid, rows):
     assert a[0] == b[0]
     assert np.abs(a[1] - b[1]).max() < 1e-12
     assert rel_err(b[2], a[2]) < 1e-11 and rel_err(b[3], a[3]) < 1e-12
+
+
+@pytest.mark.parametrize("grid", [(16, 16, 16), (8, 14, 128)])
+def test_three_phase_voigt_all_loop_variants(grid):
+    """Three phases (nested spheres: core, coating, matrix) with Voigt mixing: strain-state pipeline, exact
+    displacement loop and the fast (effective moduli; tiled where nz/2 >= 62) loop against the oracle."""
+    from fibergen_amd import LSSolver
+    from helpers import sphere_phi
+    from oracle.ls_oracle import LSOracle
+    core = sphere_phi(grid, 0.2)
+    both = sphere_phi(grid, 0.35)
+    phis = [1.0 - both, both - core, core]
+    mats = [(0.4, 0.6), (2.0, 1.0), (6.0, 8.0)]
+    E = np.array([0.5, -0.25, 1.0, 0.1, 0.2, 0.3])
+    o = LSOracle(*grid, mats=mats, phis=phis, tol=1e-8)
+    assert o.run(E) is False
+    for u_loop in (0, 1, 2):
+        s = LSSolver(*grid)
+        s.set_num_phases(3)
+        for p in range(3):
+            s.set_phase(p, mats[p][0], mats[p][1], phis[p])
+        s.set_options(tol=1e-8, u_loop=u_loop)
+        assert s.run(E) is False
+        assert s.iterations == o.iterations
+        np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-11)
+        assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
+        assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-10
+        assert s.volume_fraction(2) == pytest.approx(core.mean(), rel=1e-13)
+        s.close()
