@@ -146,6 +146,9 @@ class Solver {
   FieldPtrs<6> ptrs6(double* base) const;
   FieldPtrs<3> ptrs3(double* base) const;
   void check_device_error(const char* where);
+  void fetch_norms_and_errors(const char* where);  // D2H of the sums of squares + error flag, waits for those copies only
+  void launch_pending_back();
+  void adopt_back();
   void upload_padded(double* dst, const double* src_unpadded);
   void download_unpadded(const double* src, double* dst_unpadded);
   void time_begin(int stage);
@@ -206,6 +209,9 @@ class Solver {
   bool timing_ = false;
   StageTimes times_;
   hipEvent_t ev_[2];
+  hipEvent_t ev_copy_;
+  bool pending_back_ = false;  // run(): the sweep of this pass is enqueued, its FFT chain not yet
+  bool back_ready_ = false;    // the FFT chain is enqueued (fu_alt_ will hold u_{k+1}) but not adopted
 };
 
 }  // namespace fg

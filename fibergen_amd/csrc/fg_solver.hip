@@ -52,6 +52,7 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   FG_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   FG_HIP_CHECK(hipEventCreate(&ev_[0]));
   FG_HIP_CHECK(hipEventCreate(&ev_[1]));
+  FG_HIP_CHECK(hipEventCreateWithFlags(&ev_copy_, hipEventDisableTiming));
   pt_.n = 0;
   for (int i = 0; i < kMaxPhases; ++i) pt_.mu[i] = pt_.lambda[i] = 0.0;
   opt_.mu_0 = std::numeric_limits<double>::quiet_NaN();  // F:15340
@@ -149,6 +150,7 @@ Solver::~Solver() {
   }
   (void)hipEventDestroy(ev_[0]);
   (void)hipEventDestroy(ev_[1]);
+  (void)hipEventDestroy(ev_copy_);
   (void)hipStreamDestroy(stream_);
 }
 
@@ -292,6 +294,41 @@ void Solver::check_device_error(const char* where) {
       throw std::runtime_error(std::string("The laminate mixing rule supports only two phase mixtures (") + where + ")");
     throw std::runtime_error(std::string("device kernel reported an error (") + where + ")");
   }
+}
+
+// The same check, but the host waits only for the copies enqueued so far (an event), not for work enqueued after them.
+void Solver::fetch_norms_and_errors(const char* where) {
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  FG_HIP_CHECK(hipEventRecord(ev_copy_, stream_));
+  if (pending_back_) launch_pending_back();   // speculative: u_{k+1} is built while the host looks at the norms of eps_k
+  FG_HIP_CHECK(hipEventSynchronize(ev_copy_));
+  if (*herr_ != 0) {
+    FG_HIP_CHECK(hipMemsetAsync(derr_, 0, sizeof(int), stream_));
+    if (opt_.mixing == kMixLaminate)
+      throw std::runtime_error(std::string("The laminate mixing rule supports only two phase mixtures (") + where + ")");
+    throw std::runtime_error(std::string("device kernel reported an error (") + where + ")");
+  }
+}
+
+// FFT / Green-operator chain of the displacement loop, enqueued without touching the host-side state: fu_alt_ then holds
+// u_{k+1}; adopt_back() makes it the current state.  If the iteration stops first, it is simply never adopted.
+void Solver::launch_pending_back() {
+  fft_g0_chain(fu_alt_, z_done_);
+  pending_back_ = false;
+  back_ready_ = true;
+}
+
+void Solver::adopt_back() {
+  if (!back_ready_) launch_pending_back();
+  back_ready_ = false;
+  double* t = fu_;
+  fu_ = fu_alt_;
+  fu_alt_ = t;
+  u_valid_ = true;
+  eps_stale_ = true;
+  for (int c = 0; c < 6; ++c) E_cur_[c] = E_next_[c];
+  if (timing_) times_.count++;
 }
 
 void Solver::enable_stage_timing(bool on) { timing_ = on; }
@@ -685,14 +722,9 @@ void Solver::u_pass_front(const double* E6) {
 }
 
 void Solver::u_pass_back() {
-  fft_g0_chain(fu_alt_, z_done_);
-  double* t = fu_;
-  fu_ = fu_alt_;
-  fu_alt_ = t;
-  u_valid_ = true;
-  eps_stale_ = true;
-  for (int c = 0; c < 6; ++c) E_cur_[c] = E_next_[c];
-  if (timing_) times_.count++;
+  back_ready_ = false;
+  launch_pending_back();
+  adopt_back();
 }
 
 void Solver::ensure_eps() {
@@ -877,17 +909,18 @@ bool Solver::run(const double* E6, const double* S6) {
       update_ref = false;
     }
     bool pending_back = false;
+    pending_back_ = back_ready_ = false;
     if (uloop && u_valid_) {
       if (iter == 1)
         for (int i = 0; i < 6; ++i) E_cur_[i] = E[i];  // eps_1 = E (u_1 = 0)
       u_pass_front(E);
       pending_back = true;
+      pending_back_ = true;   // fetch_norms_and_errors enqueues the FFT chain behind the copies
     } else {
       uloop = false;
       basic_scheme(E);
     }
-    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    check_device_error("stress");
+    fetch_norms_and_errors("stress");
 
     // component_norm + fix_dim + norm_2 over 9 mirrored entries  F:10127-10138, F:14600-14609, F:14627
     double m[6], s9 = 0.0;
@@ -922,9 +955,10 @@ bool Solver::run(const double* E6, const double* S6) {
       const double bc_err = bc_error(E0, S0);
       if (bc_err <= opt_.bc_tol) break;
     }
-    if (pending_back) u_pass_back();
+    if (pending_back) adopt_back();
     iter++;
   }
+  pending_back_ = back_ready_ = false;
   in_run_ = false;
   iterations_ = iter;
   ensure_eps();
