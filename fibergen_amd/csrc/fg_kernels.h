@@ -84,6 +84,12 @@ void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 void launch_u_stress(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
                      const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, const Vec6& E, double* partial, double* sumsq6,
                      int* error_flag, hipStream_t s);
+// CG in displacement space: inner products of staggered gradients (mode 0: p:(p-w) -> out[0]; mode 1: sums of squares of
+// E + grad_s a -> out[0..5] and grad_s b : grad_s b -> out[6]) and the point-wise vector updates
+void launch_cgu_dot(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldPtrs<3>& b, const Vec6& E, double* partial,
+                    double* out7, hipStream_t s);
+void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r,
+                     const FieldPtrs<3>& w, double a, hipStream_t s);
 // interface voxels (some phase fraction strictly between 0 and 1): count (list == nullptr) or fill the list of their
 // element offsets; then the laminate polarisation at those voxels only
 unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned* list, unsigned* count_dev,

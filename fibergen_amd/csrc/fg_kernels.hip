@@ -661,6 +661,125 @@ __global__ __launch_bounds__(kBlock, 2) void k_u_stress(Grid g, StressParams sp,
   }
 }
 
+// ----------------------------------------------------------------------------- CG in displacement space
+// runCGElasticity  F:23153-23247 keeps the strain-like vectors eps, r, p, w.  With prescribed mean strains every one of
+// them is a staggered symmetric gradient (eps = E + grad_s u_e; r, p, w = grad_s u_r, u_p, u_w: the operator
+// -Gamma0 (C - C0) maps onto such fields), so the solver can carry the 3-component displacements instead of the
+// 6-component strains: the vector updates become point-wise on half the data, the inner products (innerProductL2
+// F:20955-21038, shear products doubled) evaluate the gradients on the fly.
+struct StrainPair {
+  double2 e[6];
+};
+
+// staggered symmetric gradient of u at the pair p (epsOperatorStaggered  F:18632-18686 without E)
+__device__ __forceinline__ StrainPair grad_s_pair(const Grid& g, const FieldPtrs<3>& u, const PairPos& p, bool second) {
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+  const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+  const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+  const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+  const long rowoff = p.off - p.k;
+  const int kb = p.k == 0 ? g.nz - 1 : p.k - 1;
+  const int kf2 = (p.k + 2 >= g.nz) ? p.k + 2 - g.nz : p.k + 2;
+  const double2 u0 = ld2(u.p[0], p.off), u1 = ld2(u.p[1], p.off), u2 = ld2(u.p[2], p.off);
+  const double2 u0xf = ld2(u.p[0], p.off + xf), u1xb = ld2(u.p[1], p.off + xb), u2xb = ld2(u.p[2], p.off + xb);
+  const double2 u0yb = ld2(u.p[0], p.off + yb), u1yf = ld2(u.p[1], p.off + yf), u2yb = ld2(u.p[2], p.off + yb);
+  const double u0zb = u.p[0][rowoff + kb], u1zb = u.p[1][rowoff + kb];
+  const double u2zf2 = u.p[2][rowoff + kf2];
+  const double u2zf1 = second ? u2.y : u.p[2][rowoff];
+  StrainPair s;
+  s.e[3].x = 0.5 * ((u2.x - u2yb.x) * hy + (u1.x - u1zb) * hz);
+  s.e[4].x = 0.5 * ((u2.x - u2xb.x) * hx + (u0.x - u0zb) * hz);
+  s.e[5].x = 0.5 * ((u1.x - u1xb.x) * hx + (u0.x - u0yb.x) * hy);
+  s.e[0].x = (u0xf.x - u0.x) * hx;
+  s.e[1].x = (u1yf.x - u1.x) * hy;
+  s.e[2].x = (u2zf1 - u2.x) * hz;
+  s.e[3].y = 0.5 * ((u2.y - u2yb.y) * hy + (u1.y - u1.x) * hz);
+  s.e[4].y = 0.5 * ((u2.y - u2xb.y) * hx + (u0.y - u0.x) * hz);
+  s.e[5].y = 0.5 * ((u1.y - u1xb.y) * hx + (u0.y - u0yb.y) * hy);
+  s.e[0].y = (u0xf.y - u0.y) * hx;
+  s.e[1].y = (u1yf.y - u1.y) * hy;
+  s.e[2].y = (u2zf2 - u2.y) * hz;
+  if (!second) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s.e[c].y = 0.0;
+  }
+  return s;
+}
+
+// MODE 0:  out[0] = sum grad_s a : (grad_s a - grad_s b)                                  (p : (p - w))
+// MODE 1:  out[0..5] = sum (E + grad_s a)_c^2 ,  out[6] = sum grad_s b : grad_s b         (norms of eps, r : r)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_cgu_dot(Grid g, FieldPtrs<3> a, FieldPtrs<3> b, Vec6 E, double* partial, Sweep ry) {
+  __shared__ double smem[4 * 7];
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
+  for (long it = 0; it < run.count; ++it) {
+    const long pidx = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    if (pidx >= npairs) continue;
+    const PairPos p = pair_pos_tiled(pidx, g, ry);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    const StrainPair ea = grad_s_pair(g, a, p, second), eb = grad_s_pair(g, b, p, second);
+    if (MODE == 0) {
+      double sx = 0.0, sy = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double wgt = c < 3 ? 1.0 : 2.0;
+        sx += wgt * (ea.e[c].x * (ea.e[c].x - eb.e[c].x));
+        sy += wgt * (ea.e[c].y * (ea.e[c].y - eb.e[c].y));
+      }
+      acc[0] += sx + sy;
+    } else {
+      double sx = 0.0, sy = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double ex = E.v[c] + ea.e[c].x, ey = second ? E.v[c] + ea.e[c].y : 0.0;
+        acc[c] += ex * ex + ey * ey;
+        const double wgt = c < 3 ? 1.0 : 2.0;
+        sx += wgt * (eb.e[c].x * eb.e[c].x);
+        sy += wgt * (eb.e[c].y * eb.e[c].y);
+      }
+      acc[6] += sx + sy;
+    }
+  }
+  block_reduce<7>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 7; ++c) partial[(long)blockIdx.x * 7 + c] = acc[c];
+  }
+}
+
+// point-wise vector updates on 3-component fields (padding included: harmless)
+//   MODE 0:  x += a y ;  r -= a (y - w)          (u_e += alpha u_p ; u_r -= alpha (u_p - u_w))
+//   MODE 1:  y = r + a y                          (u_p = u_r + beta u_p)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_cgu_axpy(long n2, FieldPtrs<3> x, FieldPtrs<3> y, FieldPtrs<3> r, FieldPtrs<3> w,
+                                                     double a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (MODE == 0) {
+        double2 xv = ld2(x.p[c], 2 * i), rv = ld2(r.p[c], 2 * i);
+        const double2 yv = ld2(y.p[c], 2 * i), wv = ld2(w.p[c], 2 * i);
+        xv.x = xv.x + a * yv.x;
+        xv.y = xv.y + a * yv.y;
+        rv.x = rv.x - a * (yv.x - wv.x);
+        rv.y = rv.y - a * (yv.y - wv.y);
+        st2(x.p[c], 2 * i, xv);
+        st2(r.p[c], 2 * i, rv);
+      } else {
+        double2 yv = ld2(y.p[c], 2 * i);
+        const double2 rv = ld2(r.p[c], 2 * i);
+        yv.x = rv.x + a * yv.x;
+        yv.y = rv.y + a * yv.y;
+        st2(y.p[c], 2 * i, yv);
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------- laminate rule at interface voxels only
 // The laminate rule differs from Voigt mixing only where a voxel holds two phases (pure voxels take the same Hooke
 // branch, F:13464-13470 vs F:12752-12761), and its one-step Newton solve is ~400 flop with a large register
@@ -1082,6 +1201,26 @@ void launch_u_stress(const Grid& g, const StressParams& sp, const FieldPtrs<3>& 
 #undef FG_LAUNCH
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_cgu_dot(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldPtrs<3>& b, const Vec6& E, double* partial,
+                    double* out7, hipStream_t s) {
+  const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
+  const Sweep sw = chunk_rows(g);
+  if (mode == 0) hipLaunchKernelGGL((k_cgu_dot<0>), dim3(nb), dim3(kBlock), 0, s, g, a, b, E, partial, sw);
+  else hipLaunchKernelGGL((k_cgu_dot<1>), dim3(nb), dim3(kBlock), 0, s, g, a, b, E, partial, sw);
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 7, out7, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r,
+                     const FieldPtrs<3>& w, double a, hipStream_t s) {
+  const long n2 = g.n / 2;
+  const dim3 grid(grid_for(n2, 1 << 16));
+  if (mode == 0) hipLaunchKernelGGL((k_cgu_axpy<0>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, a);
+  else hipLaunchKernelGGL((k_cgu_axpy<1>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, a);
   FG_HIP_CHECK(hipGetLastError());
 }
 

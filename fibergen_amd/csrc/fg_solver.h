@@ -130,6 +130,7 @@ class Solver {
   // one pass  dst = E - Gamma0 : (C - C0) : src  (defaults: the solver's strain field, in place)
   void basic_scheme(const double* E6, double* src = nullptr, double* dst = nullptr);
   bool run_cg(const double* E0, const double* S0);
+  bool run_cg_u(const double* E0);      // the same CG carried in displacement space (Voigt, prescribed mean strains)
   bool u_loop_eligible() const;
   void u_pass_front(const double* E6);  // u_k (fu_) -> sums of squares of eps_k, f_{k+1} (fu_alt_)
   void u_pass_back();                   // f_{k+1} -> u_{k+1}, buffers swapped
@@ -204,6 +205,7 @@ class Solver {
   bool z_done_ = false;     // the last displacement sweep wrote the z spectrum of f (not f)
   bool eps_stale_ = false;  // eps_ has not been written since fu_ changed
   bool in_run_ = false;
+  bool cg_u_active_ = false;  // displacement-space CG is iterating: fu_ is the iterate u_e, fu_alt_ is free between steps
   double E_cur_[6] = {0, 0, 0, 0, 0, 0};   // prescribed strain the current (u, eps) state was built with
   double E_next_[6] = {0, 0, 0, 0, 0, 0};
   bool timing_ = false;

@@ -853,6 +853,7 @@ bool Solver::run(const double* E6, const double* S6) {
   FG_HIP_CHECK(hipSetDevice(device_));
   if (pt_.n < 1) throw std::runtime_error("No materials specified");
   solve_time_ = 0.0;
+  cg_u_active_ = false;
   residuals_.clear();
   iterations_ = 0;
   cancel_ = false;
@@ -970,8 +971,112 @@ bool Solver::run(const double* E6, const double* S6) {
 // ------------------------------------------------------------------ conjugate gradients
 // runCGElasticity  F:23153-23247 on the operator  eps -> -Gamma0 : (C - C0) : eps  (krylovOperator
 // F:20583-20587 = one basicScheme pass with E = 0), l2 inner product, epsilon error estimator.
+// The same iteration carried in displacement space (see k_cgu_dot): eps = E + grad_s u_e, r / p / w = grad_s u_r / u_p / u_w.
+//   u_e = fu_ (so the strain is materialised from it afterwards), u_w = fu_alt_ (output of the FFT chain),
+//   u_r, u_p = the two halves of the 6-component buffer cg_r_.
+// Per iteration: one displacement sweep (the K1 of the basic scheme with E = 0) + FFT chain, one gradient dot product,
+// one point-wise update of u_e and u_r, one gradient norm sweep, one point-wise update of u_p.
+bool Solver::run_cg_u(const double* E0) {
+  const double t_start = now_seconds();
+  const size_t f3 = 3 * (size_t)g_.n * sizeof(double);
+  if (!cg_r_) FG_HIP_CHECK(hipMalloc(&cg_r_, 2 * f3));
+  double* u_r = cg_r_;
+  double* u_p = cg_r_ + 3 * g_.n;
+  for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
+  in_run_ = true;
+  cg_u_active_ = true;
+  const double small = std::numeric_limits<double>::min();
+  if (opt_.update_ref) calc_ref_material();
+  Vec6 E, Z;
+  for (int i = 0; i < 6; ++i) E.v[i] = E0[i], Z.v[i] = 0.0;   // Q = 0: calcBCMean leaves E0
+  auto fetch = [&](int slot, int n) {
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + slot, dscal_ + slot, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    check_device_error("cg");
+  };
+  // the operator on a displacement: u -> f = div((C - C0)(Eadd + grad_s u)) -> FFT chain (alpha = -1) -> fu_alt_
+  auto apply = [&](double* u_in, const double* Eadd) {
+    double* keep = fu_;
+    fu_ = u_in;
+    for (int c = 0; c < 6; ++c) E_cur_[c] = Eadd[c];
+    u_pass_front(Eadd);   // sweeps fu_ (with E_cur_) into fu_alt_; its norm sums are not used here
+    fu_ = keep;
+    fft_g0_chain(fu_alt_, z_done_);
+  };
+  // eps_0 = E (u_e = 0);  r = -Gamma0 (C - C0) E  (+ E - eps_0 = 0, adjustResidual F:10012-10022)
+  FG_HIP_CHECK(hipMemsetAsync(fu_, 0, f3, stream_));
+  apply(fu_, E.v);
+  FG_HIP_CHECK(hipMemcpyAsync(u_r, fu_alt_, f3, hipMemcpyDeviceToDevice, stream_));
+  FG_HIP_CHECK(hipMemcpyAsync(u_p, fu_alt_, f3, hipMemcpyDeviceToDevice, stream_));   // p = r
+  launch_cgu_dot(1, g_, ptrs3(fu_), ptrs3(u_r), E, partial_, dscal_ + kSlotSumSq, stream_);
+  fetch(kSlotSumSq, 7);
+  double gamma = hscal_[kSlotSumSq + 6] / (double)nglobal_ + small;
+  double prev = 0.0;  // estimator constructed on the zero field
+  long iter = 0;
+  bool failed = false;
+  for (;;) {
+    apply(u_p, Z.v);                                                                  // u_w = operator(u_p)
+    launch_cgu_dot(0, g_, ptrs3(u_p), ptrs3(fu_alt_), Z, partial_, dscal_ + kSlotMean, stream_);   // p : (p - w)
+    fetch(kSlotMean, 1);
+    double alpha = hscal_[kSlotMean] / (double)nglobal_ + small;
+    alpha = gamma / alpha;
+    launch_cgu_axpy(0, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), alpha, stream_);     // eps += alpha p ; r -= alpha (p - w)
+    launch_cgu_dot(1, g_, ptrs3(fu_), ptrs3(u_r), E, partial_, dscal_ + kSlotSumSq, stream_);       // norms of eps ; r : r
+    fetch(kSlotSumSq, 7);
+    const double rr = hscal_[kSlotSumSq + 6];   // slot 6 is shared with the mean-value slot the accessors below use
+    // state for accessors called from the callback / bc_error: eps = E + grad_s fu_
+    u_valid_ = true;
+    eps_stale_ = true;
+    for (int c = 0; c < 6; ++c) E_cur_[c] = E.v[c];
+    double m[6], s9 = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      sumsq_[c] = hscal_[kSlotSumSq + c];
+      m[c] = std::sqrt(sumsq_[c] / (double)nglobal_);
+    }
+    for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
+    for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
+    const double cur = std::sqrt(s9);
+    const double abs_err = std::fabs(prev - cur);
+    const double rel_err = abs_err / (small + cur);
+    prev = cur;
+    if (std::isnan(rel_err) || cancel_) {  // _converged  F:21177-21244
+      failed = true;
+      break;
+    }
+    residuals_.push_back(rel_err);
+    if (cb_ && cb_(cb_user_)) break;
+    if (cancel_) {
+      failed = true;
+      break;
+    }
+    if (iter >= opt_.maxiter) break;
+    if (rel_err <= opt_.tol || abs_err <= opt_.abs_tol) {
+      double S0[6] = {0, 0, 0, 0, 0, 0};
+      if (bc_error(E0, S0) <= opt_.bc_tol) break;
+    }
+    iter++;
+    const double delta = rr / (double)nglobal_ + small;
+    const double beta = delta / gamma;
+    gamma = delta;
+    launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), beta, stream_);       // p = r + beta p
+  }
+  in_run_ = false;
+  cg_u_active_ = false;
+  iterations_ = iter;
+  u_valid_ = true;
+  eps_stale_ = true;
+  for (int c = 0; c < 6; ++c) E_cur_[c] = E.v[c];
+  ensure_eps();
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  solve_time_ += now_seconds() - t_start;
+  return failed;
+}
+
 bool Solver::run_cg(const double* E0, const double* S0) {
   if (nranks_ != 1) throw std::runtime_error("method=cg is not available on slab-decomposed solvers");
+  if (opt_.u_loop >= 2 && opt_.mixing == kMixVoigt && u_loop_eligible() && norm2(S0, 6) == 0.0) {
+    FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * (size_t)g_.n * sizeof(double), stream_));
+    return run_cg_u(E0);
+  }
   const double t_start = now_seconds();
   const size_t f6 = 6 * (size_t)g_.n * sizeof(double);
   for (double** b : {&cg_r_, &cg_p_, &cg_w_})
@@ -1291,8 +1396,9 @@ double* Solver::device_component(const std::string& name, int c) {
 void Solver::get_field(const std::string& name, double* out) {
   FG_HIP_CHECK(hipSetDevice(device_));
   ensure_eps();
-  // fu_ is overwritten by the displacement reconstruction (scalar modes: by an equivalent potential, still valid)
-  if (name == "u" && opt_.mode != 1) u_valid_ = false;
+  // fu_ is overwritten by the displacement reconstruction (scalar modes: by an equivalent potential, still valid;
+  // displacement-space CG: the reconstruction goes to the free buffer fu_alt_, fu_ is the iterate itself)
+  if (name == "u" && opt_.mode != 1 && !cg_u_active_) u_valid_ = false;
   if (name == "sumsq") {  // the six sums of squares of the last norm sweep (device slot; the displacement loop keeps them there)
     FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
     FG_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1349,9 +1455,10 @@ void Solver::get_field(const std::string& name, double* out) {
     return;
   }
   if (name == "u") {  // u = G0 div (C0 : eps), alpha = 1  F:15509-15521
+    double* const ub = cg_u_active_ ? fu_alt_ : fu_;
     launch_stress_const(g_, opt_.mu_0, opt_.lambda_0, ptrs6(eps_), ptrs6(tau_), stream_);
-    launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
-    fft_->forward(fu_, 3, g_.n, 1 / (double)nglobal_);
+    launch_div(g_, ptrs6(tau_), ptrs3(ub), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
+    fft_->forward(ub, 3, g_.n, 1 / (double)nglobal_);
     const double alpha = 1.0;
     const double c10 = -alpha / (opt_.mu_0);
     const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
@@ -1360,9 +1467,9 @@ void Solver::get_field(const std::string& name, double* out) {
       tb.kpm[a] = g0_kpm_[a];
       tb.kp[a] = g0_kp_[a];
     }
-    launch_g0(g_, ptrs3(fu_), tb, c10, c20, G0Layout{0, 0, 0}, stream_);
-    fft_->inverse(fu_, 3, g_.n);
-    for (int c = 0; c < 3; ++c) download_unpadded(fu_ + (long)c * g_.n, out + (long)c * g_.nxyz);
+    launch_g0(g_, ptrs3(ub), tb, c10, c20, G0Layout{0, 0, 0}, stream_);
+    fft_->inverse(ub, 3, g_.n);
+    for (int c = 0; c < 3; ++c) download_unpadded(ub + (long)c * g_.n, out + (long)c * g_.nxyz);
     return;
   }
   const int nc = field_components(name);

@@ -506,3 +506,34 @@ def test_three_phase_voigt_all_loop_variants(grid):
         assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-10
         assert s.volume_fraction(2) == pytest.approx(core.mean(), rel=1e-13)
         s.close()
+
+
+@pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (8, 14, 128)])
+def test_cg_in_displacement_space(grid):
+    """method=cg with u_loop=2 (default) carries the CG vectors as displacements; u_loop=0 keeps the strain vectors of
+    runCGElasticity.  Same iteration counts and residual histories (to rounding) as each other and as the oracle;
+    accessors called from the convergence callback see the current iterate."""
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    o = make_oracle(grid, tol=1e-10)
+    assert o.run_cg(E) is False
+    out = {}
+    for flag in (0, 2):
+        s = make_gpu_solver(grid, tol=1e-10, method="cg", u_loop=flag)
+        seen = []
+
+        def cb():
+            seen.append((s.mean_stress().copy(), s.get_field("u").copy(), s.get_field("epsilon").copy()))
+            return False
+        s.set_convergence_callback(cb)
+        assert s.run(E) is False
+        out[flag] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress(), s.get_field("u"), seen)
+        s.close()
+    for flag in (0, 2):
+        it, res, eps, sig, u, seen = out[flag]
+        assert it == o.iterations and len(res) == len(o.residuals) == len(seen)
+        assert np.abs(res - np.array(o.residuals)).max() < 1e-10
+        assert rel_err(eps, o.eps) < 1e-8 and rel_err(sig, o.mean_stress()) < 1e-9
+        assert rel_err(seen[-1][2], eps) < 1e-12 and rel_err(seen[-1][0], sig) < 1e-12
+        assert np.abs(seen[-1][1] - u).max() < 1e-12 * max(1.0, np.abs(u).max())
+    assert rel_err(out[2][2], out[0][2]) < 1e-9
+    assert np.abs(out[2][4] - out[0][4]).max() < 1e-9 * max(1.0, np.abs(out[0][4]).max())
