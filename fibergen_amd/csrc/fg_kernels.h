@@ -129,6 +129,10 @@ void launch_sc_flux_mean(const Grid& g, const ScalarParams& sp, const FieldPtrs<
                          double* partial, double* out6, hipStream_t s);
 void launch_sc_div(const Grid& g, const FieldPtrs<3>& x, double scale, double* y, hipStream_t s);
 void launch_g0_heat(const Grid& g, double* fh, const G0Tables& tb, double c10, hipStream_t s);
+// CG in potential space (scalar modes): dot products of forward-difference gradients, point-wise updates
+void launch_sc_cg_dot(int mode, const Grid& g, const double* a, const double* b, const Vec6& E, double* partial, double* out7,
+                      hipStream_t s);
+void launch_sc_cg_axpy(int mode, const Grid& g, double* x, double* y, double* r, const double* w, double a, hipStream_t s);
 void launch_sc_minmax(const Grid& g, const ScalarParams& sp, const FieldPtrs<kMaxPhases>& phi, double* partial,
                       double* out2, hipStream_t s);
 void launch_tangent_minmax(const Grid& g, const PhaseTable& pt, int mixing, const FieldPtrs<kMaxPhases>& phi,

@@ -249,6 +249,79 @@ __global__ __launch_bounds__(kBlock) void k_sc_minmax(Grid g, ScalarParams sp, F
   }
 }
 
+// CG in potential space (see k_cgu_dot in fg_kernels.hip): gradients are forward differences of the potentials.
+//   MODE 0:  out[0] = sum grad a . (grad a - grad b)                              (p . (p - w))
+//   MODE 1:  out[0..2] = sum (E + grad a)_c^2 ,  out[6] = sum grad b . grad b      (norms of g, r . r)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_sc_cg_dot(Grid g, const double* a, const double* b, Vec6 E, double* partial, Sweep sw) {
+  __shared__ double smem[4 * 7];
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
+  for (long it = 0; it < run.count; ++it) {
+    const long pidx = (run.first + it * run.stride) * kBlock + threadIdx.x;
+    if (pidx >= npairs) continue;
+    const PairPos p = pair_pos_tiled(pidx, g, sw);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+    const long ro = p.off - p.k;
+    const int k = p.k;
+    const int kf2 = (k + 2 >= g.nz) ? k + 2 - g.nz : k + 2;
+    const Row4 Ac = load_row(a, ro, k, 0, kf2, second, false, true), Axf = load_row(a, ro + xf, k, 0, kf2, second, false, false);
+    const Row4 Ayf = load_row(a, ro + yf, k, 0, kf2, second, false, false);
+    const Row4 Bc = load_row(b, ro, k, 0, kf2, second, false, true), Bxf = load_row(b, ro + xf, k, 0, kf2, second, false, false);
+    const Row4 Byf = load_row(b, ro + yf, k, 0, kf2, second, false, false);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s == 1 && !second) break;
+      const int i0 = s + 1;
+      const double ga[3] = {(Axf.v[i0] - Ac.v[i0]) * hx, (Ayf.v[i0] - Ac.v[i0]) * hy, (Ac.v[i0 + 1] - Ac.v[i0]) * hz};
+      const double gb[3] = {(Bxf.v[i0] - Bc.v[i0]) * hx, (Byf.v[i0] - Bc.v[i0]) * hy, (Bc.v[i0 + 1] - Bc.v[i0]) * hz};
+      if (MODE == 0) {
+        acc[0] += ga[0] * (ga[0] - gb[0]) + ga[1] * (ga[1] - gb[1]) + ga[2] * (ga[2] - gb[2]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double e = E.v[c] + ga[c];
+          acc[c] += e * e;
+        }
+        acc[6] += gb[0] * gb[0] + gb[1] * gb[1] + gb[2] * gb[2];
+      }
+    }
+  }
+  block_reduce<7>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 7; ++c) partial[(long)blockIdx.x * 7 + c] = acc[c];
+  }
+}
+
+// MODE 0:  x += a y ; r -= a (y - w)      MODE 1:  y = r + a y       (one-component fields)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_sc_cg_axpy(long n2, double* x, double* y, double* r, const double* w, double a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+    if (MODE == 0) {
+      double2 xv = ld2(x, 2 * i), rv = ld2(r, 2 * i);
+      const double2 yv = ld2(y, 2 * i), wv = ld2(w, 2 * i);
+      xv.x = xv.x + a * yv.x;
+      xv.y = xv.y + a * yv.y;
+      rv.x = rv.x - a * (yv.x - wv.x);
+      rv.y = rv.y - a * (yv.y - wv.y);
+      st2(x, 2 * i, xv);
+      st2(r, 2 * i, rv);
+    } else {
+      double2 yv = ld2(y, 2 * i);
+      const double2 rv = ld2(r, 2 * i);
+      yv.x = rv.x + a * yv.x;
+      yv.y = rv.y + a * yv.y;
+      st2(y, 2 * i, yv);
+    }
+  }
+}
+
 int grid_cap(long nwork, int max_blocks) {
   long b = (nwork + kBlock - 1) / kBlock;
   if (b > max_blocks) b = max_blocks;
@@ -300,6 +373,25 @@ void launch_sc_div(const Grid& g, const FieldPtrs<3>& x, double scale, double* y
 void launch_g0_heat(const Grid& g, double* fh, const G0Tables& tb, double c10, hipStream_t s) {
   const long nfreq = (long)g.nx * g.ny * g.nzc;
   hipLaunchKernelGGL(k_g0_heat, dim3(grid_cap(nfreq, 1 << 20)), dim3(kBlock), 0, s, g, reinterpret_cast<cplx*>(fh), tb, c10);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_sc_cg_dot(int mode, const Grid& g, const double* a, const double* b, const Vec6& E, double* partial, double* out7,
+                      hipStream_t s) {
+  const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
+  const Sweep sw = chunk_rows(g);
+  if (mode == 0) hipLaunchKernelGGL((k_sc_cg_dot<0>), dim3(nb), dim3(kBlock), 0, s, g, a, b, E, partial, sw);
+  else hipLaunchKernelGGL((k_sc_cg_dot<1>), dim3(nb), dim3(kBlock), 0, s, g, a, b, E, partial, sw);
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 7, out7, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_sc_cg_axpy(int mode, const Grid& g, double* x, double* y, double* r, const double* w, double a, hipStream_t s) {
+  const long n2 = g.n / 2;
+  const dim3 grid(grid_cap(n2, 1 << 16));
+  if (mode == 0) hipLaunchKernelGGL((k_sc_cg_axpy<0>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, a);
+  else hipLaunchKernelGGL((k_sc_cg_axpy<1>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, a);
   FG_HIP_CHECK(hipGetLastError());
 }
 

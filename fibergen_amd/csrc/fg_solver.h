@@ -130,6 +130,7 @@ class Solver {
   // one pass  dst = E - Gamma0 : (C - C0) : src  (defaults: the solver's strain field, in place)
   void basic_scheme(const double* E6, double* src = nullptr, double* dst = nullptr);
   bool run_cg(const double* E0, const double* S0);
+  bool run_cg_scalar(const double* E0);  // heat / porous: CG in potential space
   bool run_cg_u(const double* E0);      // the same CG carried in displacement space (Voigt, prescribed mean strains)
   bool u_loop_eligible() const;
   void u_pass_front(const double* E6);  // u_k (fu_) -> sums of squares of eps_k, f_{k+1} (fu_alt_)

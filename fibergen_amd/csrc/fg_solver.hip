@@ -871,7 +871,12 @@ bool Solver::run(const double* E6, const double* S6) {
     voigt_mv(BC_Q_, E0, t);
     if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
   }
-  if (opt_.method == 1 && opt_.mode != 0) throw std::runtime_error("method=cg is only available in elasticity mode (use basic)");
+  if (opt_.method == 1 && opt_.mode == 2) throw std::runtime_error("method=cg is not available in viscosity mode (use basic)");
+  if (opt_.method == 1 && opt_.mode == 1) {
+    (void)u_loop_eligible();   // throws for configurations the scalar modes do not support
+    FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * (size_t)g_.n * sizeof(double), stream_));
+    return run_cg_scalar(E0);
+  }
   if (opt_.method == 1) return run_cg(E0, S0);
   const double t_start = now_seconds();
   FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * g_.n * sizeof(double), stream_));  // F:21379
@@ -1058,6 +1063,99 @@ bool Solver::run_cg_u(const double* E0) {
     const double beta = delta / gamma;
     gamma = delta;
     launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), beta, stream_);       // p = r + beta p
+  }
+  in_run_ = false;
+  cg_u_active_ = false;
+  iterations_ = iter;
+  u_valid_ = true;
+  eps_stale_ = true;
+  for (int c = 0; c < 6; ++c) E_cur_[c] = E.v[c];
+  ensure_eps();
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  solve_time_ += now_seconds() - t_start;
+  return failed;
+}
+
+// Scalar modes: the same CG in potential space (g = E + grad T_e; r, p, w = grad T_r, T_p, T_w): runCG dispatches every
+// non-hyperelastic mode to runCGElasticity (F:22056-22066), whose inner product is the plain sum for 3 components
+// (F:20961-20980).  T_e = fu_[0], T_w = fu_alt_[0], T_r / T_p = components 1, 2 of fu_alt_'s buffer mate cg_r_.
+bool Solver::run_cg_scalar(const double* E0) {
+  const double t_start = now_seconds();
+  const size_t f1 = (size_t)g_.n * sizeof(double);
+  if (!cg_r_) FG_HIP_CHECK(hipMalloc(&cg_r_, 6 * f1));
+  double* T_r = cg_r_;
+  double* T_p = cg_r_ + g_.n;
+  in_run_ = true;
+  cg_u_active_ = true;
+  const double small = std::numeric_limits<double>::min();
+  if (opt_.update_ref) calc_ref_material();
+  Vec6 E, Z;
+  for (int i = 0; i < 6; ++i) E.v[i] = i < 3 ? E0[i] : 0.0, Z.v[i] = 0.0;
+  auto fetch = [&](int slot, int n) {
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + slot, dscal_ + slot, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    check_device_error("cg");
+  };
+  auto apply = [&](double* T_in, const double* Eadd) {   // T -> f = div((C - C0)(Eadd + grad T)) -> FFT chain -> fu_alt_
+    double* keep = fu_;
+    fu_ = T_in;
+    for (int c = 0; c < 6; ++c) E_cur_[c] = Eadd[c];
+    u_pass_front(Eadd);
+    fu_ = keep;
+    fft_g0_chain(fu_alt_, false);
+  };
+  FG_HIP_CHECK(hipMemsetAsync(fu_, 0, f1, stream_));
+  apply(fu_, E.v);
+  FG_HIP_CHECK(hipMemcpyAsync(T_r, fu_alt_, f1, hipMemcpyDeviceToDevice, stream_));
+  FG_HIP_CHECK(hipMemcpyAsync(T_p, fu_alt_, f1, hipMemcpyDeviceToDevice, stream_));
+  launch_sc_cg_dot(1, g_, fu_, T_r, E, partial_, dscal_ + kSlotSumSq, stream_);
+  fetch(kSlotSumSq, 7);
+  double gamma = hscal_[kSlotSumSq + 6] / (double)nglobal_ + small;
+  double prev = 0.0;
+  long iter = 0;
+  bool failed = false;
+  for (;;) {
+    apply(T_p, Z.v);
+    launch_sc_cg_dot(0, g_, T_p, fu_alt_, Z, partial_, dscal_ + kSlotMean, stream_);
+    fetch(kSlotMean, 1);
+    double alpha = hscal_[kSlotMean] / (double)nglobal_ + small;
+    alpha = gamma / alpha;
+    launch_sc_cg_axpy(0, g_, fu_, T_p, T_r, fu_alt_, alpha, stream_);
+    launch_sc_cg_dot(1, g_, fu_, T_r, E, partial_, dscal_ + kSlotSumSq, stream_);
+    fetch(kSlotSumSq, 7);
+    const double rr = hscal_[kSlotSumSq + 6];
+    u_valid_ = true;
+    eps_stale_ = true;
+    for (int c = 0; c < 6; ++c) E_cur_[c] = E.v[c];
+    double s3 = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      sumsq_[c] = c < 3 ? hscal_[kSlotSumSq + c] : 0.0;
+      const double m = std::sqrt(sumsq_[c] / (double)nglobal_);
+      s3 += m * m;
+    }
+    const double cur = std::sqrt(s3);
+    const double abs_err = std::fabs(prev - cur);
+    const double rel_err = abs_err / (small + cur);
+    prev = cur;
+    if (std::isnan(rel_err) || cancel_) {
+      failed = true;
+      break;
+    }
+    residuals_.push_back(rel_err);
+    if (cb_ && cb_(cb_user_)) break;
+    if (cancel_) {
+      failed = true;
+      break;
+    }
+    if (iter >= opt_.maxiter) break;
+    if (rel_err <= opt_.tol || abs_err <= opt_.abs_tol) {
+      double S0[6] = {0, 0, 0, 0, 0, 0};
+      if (bc_error(E.v, S0) <= opt_.bc_tol) break;
+    }
+    iter++;
+    const double delta = rr / (double)nglobal_ + small;
+    const double beta = delta / gamma;
+    gamma = delta;
+    launch_sc_cg_axpy(1, g_, fu_, T_p, T_r, fu_alt_, beta, stream_);
   }
   in_run_ = false;
   cg_u_active_ = false;
@@ -1418,12 +1516,13 @@ void Solver::get_field(const std::string& name, double* out) {
     return;
   }
   if (opt_.mode == 1 && name == "u") {  // potential T = G0 div(C0 : g), alpha = 1  F:15536-15541
-    launch_sc_div(g_, ptrs3(eps_), 2 * opt_.mu_0, fu_, stream_);   // calcStressConst + divOperatorStaggeredHeat
+    double* const tb = cg_u_active_ ? fu_alt_ : fu_;               // during CG fu_ is the iterate, fu_alt_ is free
+    launch_sc_div(g_, ptrs3(eps_), 2 * opt_.mu_0, tb, stream_);    // calcStressConst + divOperatorStaggeredHeat
     const bool timing = timing_;
     timing_ = false;
-    fft_g0_chain(fu_, false, 1.0);
+    fft_g0_chain(tb, false, 1.0);
     timing_ = timing;
-    download_unpadded(fu_, out);
+    download_unpadded(tb, out);
     return;
   }
   if (name == "sigma") {  // calcStress with C0 = 0  F:15496-15508

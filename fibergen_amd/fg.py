@@ -239,8 +239,8 @@ class FG:
         method = self._child_value(solver, "method", "cg", str)
         if method not in ("basic", "cg"):
             raise RuntimeError("Unknown solver method '%s'" % method)
-        if scalar and method == "cg":
-            # same fixed point, different iteration history; the scalar modes run the basic scheme
+        if mode == "viscosity" and method == "cg":
+            # same fixed point, different iteration history; the viscosity mode runs the basic scheme
             log.info("%s mode: method=cg is replaced by the basic scheme on the MI355X path", mode)
             method = "basic"
         self._method = method

@@ -174,6 +174,59 @@ class ScalarOracle:
         self.iterations = it
         return False
 
+    def inner_l2(self, a, b, c=None):
+        """innerProductL2, dim 3 branch  F:20955-20980 (three-argument form a:(b-c)  F:20871-20953): plain sum / N"""
+        d = b if c is None else (b - c)
+        return float((a[0] * d[0] + a[1] * d[1] + a[2] * d[2]).sum()) / self.N
+
+    def run_cg(self, E0):
+        """LSSolver::run with method=cg in the scalar modes: runCG -> runCGElasticity  F:22056-22066, F:23153-23247
+        (the routine is dimension-generic: krylovOperator = one basic-scheme pass with E = 0)."""
+        E0 = np.asarray(E0, dtype=np.float64)
+        self.residuals = []
+        self.error = None
+        self.eps = np.zeros((3, self.nx, self.ny, self.nz))
+        if self.update_ref != "never":
+            self.calc_ref_material()
+        prev = float(np.linalg.norm(self.component_norm(self.eps)))
+        Z = np.zeros(3)
+        eps = np.empty_like(self.eps)
+        eps[:] = E0[:, None, None, None]
+        r = self.basic_scheme(Z, eps)
+        r = r + (E0[:, None, None, None] - eps)
+        gamma = self.inner_l2(r, r) + SMALLEST
+        p = r.copy()
+        it = 0
+        while True:
+            w = self.basic_scheme(Z, p)
+            alpha = self.inner_l2(p, p, w) + SMALLEST
+            alpha = gamma / alpha
+            eps = eps + alpha * p
+            self.eps = eps
+            cur = float(np.linalg.norm(self.component_norm(eps)))
+            abs_err = abs(prev - cur)
+            rel_err = abs_err / (SMALLEST + cur)
+            prev = cur
+            if math.isnan(rel_err):
+                self.error = "NaN detected in solution. Aborting."
+                return True
+            self.residuals.append(rel_err)
+            if self.callback is not None and self.callback():
+                break
+            if it >= self.maxiter:
+                break
+            if rel_err <= self.tol or abs_err <= self.abs_tol:
+                if self.bc_error(E0) <= self.bc_tol:
+                    break
+            it += 1
+            r = r + (-alpha) * (p - w)
+            delta = self.inner_l2(r, r) + SMALLEST
+            beta = delta / gamma
+            gamma = delta
+            p = r + beta * p
+        self.iterations = it
+        return False
+
     def bc_error(self, E_cur):
         """bc_error  F:21129-21161 with P = Id, S = 0: only the gradient part can be non-zero."""
         Emean = self.mean_strain()
