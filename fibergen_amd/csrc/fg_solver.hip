@@ -871,7 +871,6 @@ bool Solver::run(const double* E6, const double* S6) {
     voigt_mv(BC_Q_, E0, t);
     if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
   }
-  if (opt_.method == 1 && opt_.mode == 2) throw std::runtime_error("method=cg is not available in viscosity mode (use basic)");
   if (opt_.method == 1 && opt_.mode == 1) {
     (void)u_loop_eligible();   // throws for configurations the scalar modes do not support
     FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * (size_t)g_.n * sizeof(double), stream_));

@@ -239,10 +239,6 @@ class FG:
         method = self._child_value(solver, "method", "cg", str)
         if method not in ("basic", "cg"):
             raise RuntimeError("Unknown solver method '%s'" % method)
-        if mode == "viscosity" and method == "cg":
-            # same fixed point, different iteration history; the viscosity mode runs the basic scheme
-            log.info("%s mode: method=cg is replaced by the basic scheme on the MI355X path", mode)
-            method = "basic"
         self._method = method
         scheme = self._child_value(solver, "gamma_scheme", "auto", str)
         if scheme == "auto":

@@ -77,5 +77,5 @@ class ViscosityOracle(LSOracle):
         tau = self.calc_stress(self.mu_0, self.lambda_0, self.eps)
         return self.g0_staggered(1 / (4 * self.mu_0), math.inf, self.div_staggered(tau), 1 / (2 * self.mu_0))
 
-    def run_cg(self, *a, **k):
-        raise RuntimeError("viscosity restatement: basic scheme only")
+    # run_cg is inherited: runCG sends every non-hyperelastic mode to runCGElasticity (F:22056-22066), whose Krylov
+    # operator is one basic-scheme pass with E = 0 -- here the Delta operator above.

@@ -60,10 +60,26 @@ def test_viscosity_layered_fluid_means():
     assert s.mean_stress()[3] == pytest.approx(1 / sum(f / (m / 2) for f, m in zip(fr, mus)), rel=1e-9)
     e = s.get_field("epsilon")
     assert np.abs(e[0] + e[1] + e[2]).max() < 1e-13
-    s.set_options(method="cg")
-    with pytest.raises(RuntimeError, match="cg"):
-        s.run(np.array([0, 0, 0, 1.0, 0, 0]))
     s.close()
+
+
+def test_viscosity_cg_matches_oracle():
+    """method=cg in viscosity mode: runCGElasticity on the Delta operator (strain-space vectors)."""
+    grid = (12, 10, 6)
+    phi1 = sphere_phi(grid, 0.3)
+    s, o = _pair(grid, [1.0, 0.05], [1 - phi1, phi1], tol=1e-9)
+    s.set_options(method="cg")
+    E = np.array([0.5, -0.5, 0.0, 0.2, 0.0, 1.0])
+    assert s.run(E) is False and o.run_cg(E) is False
+    assert s.iterations == o.iterations
+    np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-10)
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-9
+    b, _ = _pair(grid, [1.0, 0.05], [1 - phi1, phi1], tol=1e-9)
+    assert b.run(E) is False and s.iterations < b.iterations
+    assert rel_err(s.mean_stress(), b.mean_stress()) < 1e-5
+    s.close()
+    b.close()
 
 
 def test_fg_viscosity_project():
@@ -87,8 +103,8 @@ def test_fg_viscosity_project():
     E[1, 0] = E[2, 1] = -1
     E[3, 2] = E[4, 3] = E[5, 4] = 1
     S = np.zeros((6, 5))
-    for i in range(5):
-        assert o.run(E[:, i]) is False
+    for i in range(5):   # no <method> in the project: the reference's default, cg
+        assert o.run_cg(E[:, i]) is False
         S[:, i] = o.mean_stress()
     C55 = E[1:6] @ np.linalg.inv(S[1:6])
     assert rel_err(C[3:6, 3:6], 0.5 * C55[2:5, 2:5]) < 1e-8
