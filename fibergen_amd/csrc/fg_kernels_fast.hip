@@ -291,20 +291,29 @@ __global__ __launch_bounds__(kBlock) void k_u_fast_z(Grid g, double beta, double
 //   * z neighbours are the adjacent lanes (DPP wave shifts).
 // Row 0, row TYR-1, lane 0 and lane 63 are halo: they compute their strain and polarisation like everyone
 // else but own no output, so no lane needs a value from outside the workgroup (no edge loads, no recomputation).
-// FULLROW: nz/2 == 64, a wave is a whole periodic z row (wave rotates, no halo lanes).
+// ZS >= 1: nz/2 == 64 ZS, a z row is ZS whole waves of the workgroup (no halo lanes; the first / last lane of a wave takes
+// its z neighbour from the adjacent wave's entry in LDS, periodically).  ZS == 0: general nz, lanes 0 and 63 are halo.
 // Per plane and thread: 5 16-byte global loads (u x3, A, B), 6 LDS writes + 6 LDS reads, 2 barriers.
 // f0 of plane q is complete at step q; f1, f2 need tau5, tau4 of plane q+1 and are finished one step later.
-template <int TYR, bool FULLROW>
-__global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double gamma, FieldPtrs<3> u, FieldPtrs<2> mod,
-                                                     FieldPtrs<3> fo, Vec6 E, double* partial, int nty, int ntz, int LX) {
+template <int TYR, int ZS>
+__global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, double beta, double gamma, FieldPtrs<3> u,
+                                                                      FieldPtrs<2> mod, FieldPtrs<3> fo, Vec6 E, double* partial,
+                                                                      int nty, int ntz, int LX) {
+  constexpr bool FULLROW = ZS > 0;
+  constexpr int NZS = ZS ? ZS : 1;        // waves per row
   constexpr int TYU = TYR - 2;            // rows with output
-  constexpr int TZU = FULLROW ? 64 : 62;  // lanes with output
+  constexpr int TZU = FULLROW ? 64 * NZS : 62;  // pairs with output per tile row
+  constexpr int RW = NZS * 64;            // LDS entries per row
   extern __shared__ __align__(16) double2 tile_lds[];
-  double2(*Ub)[TYR][64] = reinterpret_cast<double2(*)[TYR][64]>(tile_lds);                  // [3][TYR][64]
-  double2(*Tb)[TYR][64] = reinterpret_cast<double2(*)[TYR][64]>(tile_lds + 3 * TYR * 64);   // [3][TYR][64]
-  __shared__ double red[TYR * 6];
+  double2(*Ub)[TYR][RW] = reinterpret_cast<double2(*)[TYR][RW]>(tile_lds);                  // [3][TYR][RW]
+  double2(*Tb)[TYR][RW] = reinterpret_cast<double2(*)[TYR][RW]>(tile_lds + 3 * TYR * RW);   // [3][TYR][RW]
+  __shared__ double red[TYR * NZS * 6];
+  __shared__ double edge[3][TYR][NZS];    // tau2.y of lane 63, tau3.x and tau4.x of lane 0 of every wave (ZS >= 1)
 
-  const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int r = wv / NZS, zs = wv % NZS;  // tile row, z segment of the row
+  const int li = zs * 64 + l;             // entry of this thread in an LDS row
+  const int zprev = (zs + NZS - 1) % NZS, znext = (zs + 1) % NZS;
   const int nzh = g.nz / 2;
   // workgroups of one XCD (blockIdx % 8) take a contiguous run of tiles: z- and y-adjacent tiles, which share halo
   // rows and 128-byte segments, then meet in that XCD's L2 (FETCH_SIZE 2.1x -> see profiles/ for the effect)
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
   const int j0 = min(ty * TYU, g.ny - TYU), kp0 = min(tz * TZU, nzh - TZU), x0 = surplus ? 0 : tx * LX;
   const int jr = j0 - 1 + r;                              // may be -1 or ny
   const int j = jr < 0 ? jr + g.ny : (jr >= g.ny ? jr - g.ny : jr);
-  const int kr = FULLROW ? l : kp0 - 1 + l;
+  const int kr = FULLROW ? li : kp0 - 1 + l;
   const int kp = kr < 0 ? kr + nzh : (kr >= nzh ? kr - nzh : kr);
   const bool own = r >= 1 && r <= TYU && jr >= ty * TYU && (FULLROW || (l >= 1 && l <= TZU && kr >= tz * TZU));
   const long rowoff = (long)j * g.nzp + 2 * kp;
@@ -333,8 +342,8 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
     const int x = q < 0 ? q + g.nx : (q >= g.nx ? q - g.nx : q);
     return (long)x * g.nyzp + rowoff;
   };
-  auto prev_y = [&](double v) { return FULLROW ? dpp_move<0x13C>(v) : dpp_move<0x138>(v); };  // lane i <- i-1
-  auto next_x = [&](double v) { return FULLROW ? dpp_move<0x134>(v) : dpp_move<0x130>(v); };  // lane i <- i+1
+  auto prev_y = [&](double v) { return dpp_move<0x138>(v); };  // lane i <- i-1 (lane 0: fixed up below when ZS >= 1)
+  auto next_x = [&](double v) { return dpp_move<0x130>(v); };  // lane i <- i+1 (lane 63: likewise)
 
   double2 uc[3], un[3], u2[3];
   {
@@ -358,10 +367,17 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
     const double2 Ac = ld2(mod.p[0], oq), Bc = ld2(mod.p[1], oq);
     // ---- y neighbours of u through LDS
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Ub[c][r][l] = uc[c];
+    for (int c = 0; c < 3; ++c) Ub[c][r][li] = uc[c];
     __syncthreads();
-    const double2 U0yb = Ub[0][rm][l], U1yf = Ub[1][rp][l], U2yb = Ub[2][rm][l];
-    const double U0zb = prev_y(uc[0].y), U1zb = prev_y(uc[1].y), U2zf = next_x(uc[2].x);
+    const double2 U0yb = Ub[0][rm][li], U1yf = Ub[1][rp][li], U2yb = Ub[2][rm][li];
+    double U0zb = prev_y(uc[0].y), U1zb = prev_y(uc[1].y), U2zf = next_x(uc[2].x);
+    if (FULLROW) {   // wave edges: the neighbour pair lives in the adjacent wave of the same row
+      if (l == 0) {
+        U0zb = Ub[0][r][zprev * 64 + 63].y;
+        U1zb = Ub[1][r][zprev * 64 + 63].y;
+      }
+      if (l == 63) U2zf = Ub[2][r][znext * 64].x;
+    }
     // ---- strain of the two voxels  (F:18632-18686)
     double2 e0, e1, e2, e3, e4, e5;
     e0.x = E.v[0] + (un[0].x - uc[0].x) * hx;
@@ -392,12 +408,26 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
       acc[3] += e3.x * e3.x + e3.y * e3.y; acc[4] += e4.x * e4.x + e4.y * e4.y; acc[5] += e5.x * e5.x + e5.y * e5.y;
     }
     // ---- y neighbours of tau through LDS
-    Tb[0][r][l] = t1;
-    Tb[1][r][l] = t5;
-    Tb[2][r][l] = t3;
+    Tb[0][r][li] = t1;
+    Tb[1][r][li] = t5;
+    Tb[2][r][li] = t3;
+    if (FULLROW) {
+      if (l == 63) edge[0][r][zs] = t2.y;
+      if (l == 0) {
+        edge[1][r][zs] = t3.x;
+        edge[2][r][zs] = t4.x;
+      }
+    }
     __syncthreads();
-    const double2 t1yb = Tb[0][rm][l], t5yf = Tb[1][rp][l], t3yf = Tb[2][rp][l];
-    const double t2zb = prev_y(t2.y), t3zf = next_x(t3.x), t4zf = next_x(t4.x);
+    const double2 t1yb = Tb[0][rm][li], t5yf = Tb[1][rp][li], t3yf = Tb[2][rp][li];
+    double t2zb = prev_y(t2.y), t3zf = next_x(t3.x), t4zf = next_x(t4.x);
+    if (FULLROW) {
+      if (l == 0) t2zb = edge[0][r][zprev];
+      if (l == 63) {
+        t3zf = edge[1][r][znext];
+        t4zf = edge[2][r][znext];
+      }
+    }
     // ---- divergence: f0 of this plane, f1 / f2 of the previous one
     if (own) {
       if (inside) {
@@ -435,12 +465,12 @@ __global__ __launch_bounds__(TYR * 64) void k_u_tile(Grid g, double beta, double
   }
   if (l == 0) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) red[r * 6 + c] = acc[c];
+    for (int c = 0; c < 6; ++c) red[wv * 6 + c] = acc[c];
   }
   __syncthreads();
   if (threadIdx.x < 6) {
     double a = 0.0;
-    for (int w = 0; w < TYR; ++w) a += red[w * 6 + threadIdx.x];
+    for (int w = 0; w < TYR * NZS; ++w) a += red[w * 6 + threadIdx.x];
     partial[(long)blockIdx.x * 6 + threadIdx.x] = a;
   }
 }
@@ -562,10 +592,11 @@ bool u_tile_supported(const Grid& g) {
   return g.nz % 2 == 0 && nzh >= 62 && g.ny >= 14 && g.nx >= 4;
 }
 
-template <int TYR, bool FULLROW>
+template <int TYR, int ZS>
 void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s) {
-  constexpr int TYU = TYR - 2, TZU = FULLROW ? 64 : 62;
+  constexpr int NZS = ZS ? ZS : 1;
+  constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
   const int nzh = g.nz / 2;
   const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
   static const int lx_env = getenv("FG_TILE_LX") ? atoi(getenv("FG_TILE_LX")) : 32;  // tuning knob
@@ -573,15 +604,15 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   const int ntx = (g.nx + LX - 1) / LX;
   int nb = nty * ntz * ntx;
   if (nb >= 8) nb = ((nb + 7) / 8) * 8;
-  const size_t lds = 6 * TYR * 64 * sizeof(double2);
+  const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
   static bool configured = false;
   if (!configured) {
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, FULLROW>),
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, ZS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
-  hipLaunchKernelGGL((k_u_tile<TYR, FULLROW>), dim3(nb), dim3(TYR * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E, partial,
-                     nty, ntz, LX);
+  hipLaunchKernelGGL((k_u_tile<TYR, ZS>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E,
+                     partial, nty, ntz, LX);
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
@@ -589,17 +620,20 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s) {
-  const bool full = g.nz / 2 == 64;
-  if (rows == 8) {
-    if (full) launch_u_tile_t<8, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
-    else launch_u_tile_t<8, false>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
-  } else if (rows == 12) {
-    if (full) launch_u_tile_t<12, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
-    else launch_u_tile_t<12, false>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
-  } else {
-    if (full) launch_u_tile_t<16, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
-    else launch_u_tile_t<16, false>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+  const int nzh = g.nz / 2;
+#define FG_TILE(R, Z) launch_u_tile_t<R, Z>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s)
+  if (nzh == 64) {          // a z row is one wave
+    if (rows == 16) FG_TILE(16, 1);
+    else if (rows == 12) FG_TILE(12, 1);
+    else FG_TILE(8, 1);
+  } else if (nzh == 128) {  // a z row is two waves: 6 rows x 2 segments (256^3: 0.268 ms against 0.325 ms with halo lanes;
+    FG_TILE(6, 2);          // 8 x 2 = 16 waves in lock-step 0.38 ms, 4 x 2 0.31 ms)
+  } else {                  // general: tiles of 62 pairs with halo lanes
+    if (rows == 16) FG_TILE(16, 0);
+    else if (rows == 12) FG_TILE(12, 0);
+    else FG_TILE(8, 0);
   }
+#undef FG_TILE
 }
 
 void launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
