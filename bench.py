@@ -141,7 +141,7 @@ def guarded_slab_section(args, n, K, rank, world, local_rank, dist, torch, out):
 
 
 # HIP-event slot name -> kernel name in the rocprofv3 counter summaries under profiles/
-PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"), "u_eps_stress_div_r2cz": "k_u_fast_z", "stress_div": "k_stress_div_voigt", "xfft_g0_xifft": "k_xfused",
+PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"), "u_eps_stress_div_r2cz": "k_u_fast_z", "stress_div": "k_stress_div_voigt", "xfft_g0_xifft": ("k_xfused_persistent", "k_xfused"),
               "eps_norm": "k_eps_norm", "stress": "k_stress", "div": "k_div", "g0": "k_g0"}
 
 
