@@ -37,6 +37,25 @@ FG_HD cplx cconj(cplx a) { return cmake(a.re, -a.im); }
 FG_HD cplx cmul_mi(cplx a) { return cmake(a.im, -a.re); }
 FG_HD cplx cmul_pi(cplx a) { return cmake(-a.im, a.re); }
 
+// Store of one complex value by an FFT pass.  The passes write every line exactly once and never read it back within
+// the kernel; when the fields are larger than the Infinity Cache the store bypasses the cache allocation (nt != 0:
+// 512^3 y pass -7 %, whole iteration 100 -> 105 it/s; 256^3 812 -> 863 it/s).  Small grids live in the cache from one
+// kernel to the next and keep plain stores (128^3 lost 9 % with nt).  Plain on the host.
+FG_HD void cstore_stream(cplx* p, cplx v, int nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (nt) {
+    typedef double fg_v2d __attribute__((ext_vector_type(2)));
+    fg_v2d t;
+    t.x = v.re;
+    t.y = v.im;
+    __builtin_nontemporal_store(t, reinterpret_cast<fg_v2d*>(p));
+    return;
+  }
+#endif
+  (void)nt;
+  *p = v;
+}
+
 // Geometry of one padded field component: the reference's in-place r2c layout,
 // real [nx][ny][nzp], z fastest, complex view [nx][ny][nzc] on the same bytes -- except that the
 // row pitch is rounded up to 128 bytes (8 complex) so that every row, FFT tile and halo plane

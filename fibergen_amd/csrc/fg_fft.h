@@ -53,6 +53,7 @@ class Fft3 {
   Grid g_;
   hipStream_t stream_;
   bool fast_[3];
+  int stream_stores_ = 0;  // FFT passes use cache-bypassing stores (fields larger than the Infinity Cache)
   cplx* tw_[3];      // per-axis pass twiddles (fast path) ; z: for M = nz/2
   cplx* wz_;         // w^k = e^{-2 pi i k/nz}, k = 0..nz/2   (fast z path)
   cplx* wgen_[3];    // e^{-2 pi i k/n}, k = 0..n-1           (generic path)

@@ -249,6 +249,8 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
   }
   if (fast_[2]) wz_ = upload(make_unit_roots(g.nz, g.nz / 2 + 1));
   if (need_scratch) FG_HIP_CHECK(hipMalloc(&scratch_, g.n * sizeof(double)));
+  // three components larger than the 256 MB Infinity Cache: nothing a pass writes is still cached when the next reads it
+  stream_stores_ = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
 }
 
 Fft3::~Fft3() {
@@ -276,6 +278,7 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
     a.tiles_per_outer = 0;
     a.scale = scale;
     a.tw = tw_[axis];
+    a.nt = stream_stores_;
     const long cs = comp_stride / 2;
     switch (n) {
       case 8: strided_n<8>(a, nouter, dir, ncomp, cs, stream_); break;
@@ -328,6 +331,7 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
   a.c10 = gp.c10;
   a.c20 = gp.c20;
   a.tw = tw_[axis];
+  a.nt = stream_stores_;
   for (int k = 0; k < 3; ++k) {
     a.kpm[k] = gp.kpm[k];
     a.kp[k] = gp.kp[k];
@@ -355,7 +359,7 @@ void Fft3::c2c_x(double* data, int ncomp, long comp_stride, int dir, double scal
 void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
   const long nrows = (long)g_.nx * g_.ny;
   if (fast_[2]) {
-    ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_};
+    ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_};
     switch (g_.nz / 2) {
 #define FG_CASE(m) case m: launch_z<R2CKernel<m, ZLines<m>::value>>(a, ncomp, comp_stride, ZLines<m>::value, stream_); break;
       FG_CASE(8) FG_CASE(16) FG_CASE(32) FG_CASE(64) FG_CASE(128) FG_CASE(256) FG_CASE(512) FG_CASE(1024)
@@ -378,7 +382,7 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
 void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
   const long nrows = (long)g_.nx * g_.ny;
   if (fast_[2]) {
-    ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_};
+    ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_};
     switch (g_.nz / 2) {
 #define FG_CASE(m) case m: launch_z<C2RKernel<m, ZLines<m>::value>>(a, ncomp, comp_stride, ZLines<m>::value, stream_); break;
       FG_CASE(8) FG_CASE(16) FG_CASE(32) FG_CASE(64) FG_CASE(128) FG_CASE(256) FG_CASE(512) FG_CASE(1024)

@@ -39,6 +39,7 @@ struct StridedArgs {
   int ncols, tiles_per_outer;
   double scale;     // applied at the store (1.0 = none)
   const cplx* tw;   // pass twiddles of N
+  int nt;           // streaming (cache-bypassing) stores, see cstore_stream
 };
 
 template <int N, int C, int DIR>
@@ -74,7 +75,7 @@ struct StridedKernel {
       for (int q = 0; q < 8; ++q) {
         cplx o = r.v[q];
         if (a.scale != 1.0) o = cscale(a.scale, o);
-        a.data[r.base + (long)Line<N>::last_index(r.jt, q) * a.ls] = o;
+        cstore_stream(&a.data[r.base + (long)Line<N>::last_index(r.jt, q) * a.ls], o, a.nt);
       }
     }
   }
@@ -88,6 +89,7 @@ struct ZArgs {
   int nzp;
   const cplx* tw;   // pass twiddles of M
   const cplx* wz;   // e^{-2 pi i k/nz}, k = 0..M
+  int nt;           // streaming stores
 };
 
 template <int M, int LINES>
@@ -131,11 +133,11 @@ struct R2CKernel {
         int k = r.jt + q * T;
         cplx zk = lds_get(lds, L, k, r.l);
         cplx zm = lds_get(lds, L, (M - k) % M, r.l);
-        out[k] = r2c_split(zk, zm, a.wz[k]);
+        cstore_stream(&out[k], r2c_split(zk, zm, a.wz[k]), a.nt);
       }
       if (r.jt == 0) {  // k = M (Nyquist): Z[M] := Z[0]
         cplx z0 = lds_get(lds, L, 0, r.l);
-        out[M] = r2c_split(z0, z0, a.wz[M]);
+        cstore_stream(&out[M], r2c_split(z0, z0, a.wz[M]), a.nt);
       }
     }
   }
@@ -182,7 +184,7 @@ struct C2RKernel {
     if (PH == NPHASE - 1 && r.valid) {
       cplx* out = reinterpret_cast<cplx*>(r.row);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) out[Line<M>::last_index(r.jt, q)] = r.v[q];
+      for (int q = 0; q < 8; ++q) cstore_stream(&out[Line<M>::last_index(r.jt, q)], r.v[q], a.nt);
     }
   }
 };
@@ -256,6 +258,7 @@ struct XFusedArgs {
   const cplx* tw;
   const double* kpm[3];
   const cplx* kp[3];
+  int nt;              // streaming stores
 };
 
 // NC = 3: the three components of the elastic problem and G0OperatorFourierStaggeredGeneral; NC = 1: the scalar modes
@@ -387,7 +390,7 @@ struct XFusedKernel {
       if (LP == NPL - 1 && r.valid) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          a.data[comp * a.comp_stride + r.base + (long)Line<N>::last_index(r.jt, q) * a.ls] = r.v[comp][q];
+          cstore_stream(&a.data[comp * a.comp_stride + r.base + (long)Line<N>::last_index(r.jt, q) * a.ls], r.v[comp][q], a.nt);
       }
       if (PERSIST && LP == NPL - 1 && comp < 2 && comp + 1 < NC && r.next_block >= 0) {
         // v[comp] is free now: fetch the same component of the next tile into it

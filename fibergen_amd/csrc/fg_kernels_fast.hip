@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void k_u_fast_z(Grid g, double beta, double
 template <int TYR, int ZS>
 __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, double beta, double gamma, FieldPtrs<3> u,
                                                                       FieldPtrs<2> mod, FieldPtrs<3> fo, Vec6 E, double* partial,
-                                                                      int nty, int ntz, int LX) {
+                                                                      int nty, int ntz, int LX, int nt) {
   constexpr bool FULLROW = ZS > 0;
   constexpr int NZS = ZS ? ZS : 1;        // waves per row
   constexpr int TYU = TYR - 2;            // rows with output
@@ -341,6 +341,19 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   auto plane = [&](int q) {  // element offset of x plane q (periodic; q in [-1, 2 nx))
     const int x = q < 0 ? q + g.nx : (q >= g.nx ? q - g.nx : q);
     return (long)x * g.nyzp + rowoff;
+  };
+  // f is read back by the z pass only after the whole sweep: with fields larger than the Infinity Cache it is stored
+  // past the cache (nt), see cstore_stream
+  auto store_f = [&](double* base, long off, double2 v) {
+    if (nt) {
+      typedef double fg_v2d __attribute__((ext_vector_type(2)));
+      fg_v2d t;
+      t.x = v.x;
+      t.y = v.y;
+      __builtin_nontemporal_store(t, reinterpret_cast<fg_v2d*>(base + off));
+    } else {
+      st2(base, off, v);
+    }
   };
   auto prev_y = [&](double v) { return dpp_move<0x138>(v); };  // lane i <- i-1 (lane 0: fixed up below when ZS >= 1)
   auto next_x = [&](double v) { return dpp_move<0x130>(v); };  // lane i <- i+1 (lane 63: likewise)
@@ -434,12 +447,12 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
         double2 f0;
         f0.x = (t0.x - t0m.x) * hx + (t5yf.x - t5.x) * hy + (t4.y - t4.x) * hz;
         f0.y = (t0.y - t0m.y) * hx + (t5yf.y - t5.y) * hy + (t4zf - t4.y) * hz;
-        st2(fo.p[0], oq, f0);
+        store_f(fo.p[0], oq, f0);
       }
       if (st >= 1) {
         const long op = plane(q - 1);
-        st2(fo.p[1], op, make_double2((t5.x - t5m.x) * hx + part1.x, (t5.y - t5m.y) * hx + part1.y));
-        st2(fo.p[2], op, make_double2((t4.x - t4m.x) * hx + part2.x, (t4.y - t4m.y) * hx + part2.y));
+        store_f(fo.p[1], op, make_double2((t5.x - t5m.x) * hx + part1.x, (t5.y - t5m.y) * hx + part1.y));
+        store_f(fo.p[2], op, make_double2((t4.x - t4m.x) * hx + part2.x, (t4.y - t4m.y) * hx + part2.y));
       }
     }
     part1.x = (t1.x - t1yb.x) * hy + (t3.y - t3.x) * hz;
@@ -611,8 +624,9 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
+  const int nt = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
   hipLaunchKernelGGL((k_u_tile<TYR, ZS>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E,
-                     partial, nty, ntz, LX);
+                     partial, nty, ntz, LX, nt);
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());

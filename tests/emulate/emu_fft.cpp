@@ -41,6 +41,7 @@ extern "C" {
 int emu_strided(int N, int dir, double* data, int ncols, int nouter, double scale) {
   std::vector<cplx> tw = make_pass_twiddles(N);
   StridedArgs a;
+  a.nt = 0;
   a.data = reinterpret_cast<cplx*>(data);
   a.ls = ncols;
   a.os = (long)N * ncols;
@@ -96,6 +97,7 @@ int emu_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, doub
                const double* kp2) {
   std::vector<cplx> tw = make_pass_twiddles(N);
   XFusedArgs a;
+  a.nt = 0;
   a.data = reinterpret_cast<cplx*>(data);
   a.ncols = ny * nzc;
   a.comp_stride = (long)N * a.ncols;
