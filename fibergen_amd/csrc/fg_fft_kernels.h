@@ -273,7 +273,12 @@ struct XFusedKernel {
   // can then be dropped (the next scatter goes to the other buffer), 12 instead of 24 per tile
   static constexpr bool PINGPONG = num_passes(N) == 3;
   static constexpr int BUF_DOUBLES = 2 * PN * C;
-  static constexpr int LDS_DOUBLES = (PINGPONG ? 2 : 1) * BUF_DOUBLES;
+  // N = 512: the pass twiddles sit in LDS behind the exchange buffers (14 KB, the tile then uses 158 of 160 KB).
+  // A twiddle read through the vector memory path shares its in-order counter with the tile's loads and
+  // stores, so every twiddled pass waited for the stores of the previous component to be acknowledged.
+  static constexpr bool TW_LDS = N >= 512 && NC == 3;
+  static constexpr int TW_OFF = (PINGPONG ? 2 : 1) * BUF_DOUBLES;
+  static constexpr int LDS_DOUBLES = TW_OFF + (TW_LDS ? 2 * tw_total(N) : 0);
   static constexpr int NPHASE = 2 * NC * NPL;   // NC forward + NC inverse transforms
   struct Regs {
     cplx v[NC][8];
@@ -310,6 +315,11 @@ struct XFusedKernel {
     constexpr int TR = PH / NPL;   // transform number: 0..NC-1 forward comp TR, NC..2NC-1 inverse comp TR-NC
     constexpr int LP = PH % NPL;   // phase inside the transform
     constexpr int comp = TR % NC;
+    const cplx* tw = TW_LDS ? reinterpret_cast<const cplx*>(lds + TW_OFF) : a.tw;
+    if (TW_LDS && PH == 0 && !(PERSIST && r.have)) {
+      cplx* dst = reinterpret_cast<cplx*>(lds + TW_OFF);
+      for (int i = tid; i < tw_total(N); i += THREADS) dst[i] = a.tw[i];   // fenced by the barrier after phase 0
+    }
     if (PINGPONG) lds += ((LP / 2) % 2) * BUF_DOUBLES;
     if (PH == 0) {
       r.t = tid % C;
@@ -331,7 +341,7 @@ struct XFusedKernel {
       }
     }
     if (TR < NC) {
-      Line<N>::template phase<-1, LP>(r.v[comp], r.jt, lds, L, r.t, a.tw);
+      Line<N>::template phase<-1, LP>(r.v[comp], r.jt, lds, L, r.t, tw);
       if constexpr (NC == 1) if (LP == NPL - 1) {
         // scalar Green operator on the spectrum in registers
         const bool live = r.valid && r.kk < a.nzf;
@@ -370,7 +380,7 @@ struct XFusedKernel {
             if (kx == 0 && r.jj == 0 && r.kk == 0) {
               e0 = e1 = e2 = cmake(0.0, 0.0);   // zero frequency  F:19924-19926
             } else {
-              g0_point(t0, t1, t2, a.kpm[0][kx], kpm1, kpm2, a.kp[0][kx], kp1, kp2, a.c10, a.c20, &e0, &e1, &e2);
+              g0_point_rcp(t0, t1, t2, a.kpm[0][kx], kpm1, kpm2, a.kp[0][kx], kp1, kp2, a.c10, a.c20, &e0, &e1, &e2);
             }
           }
           w[0][q] = e0;
@@ -386,7 +396,7 @@ struct XFusedKernel {
         }
       }
     } else {
-      Line<N>::template phase<+1, LP>(r.v[comp], r.jt, lds, L, r.t, a.tw);
+      Line<N>::template phase<+1, LP>(r.v[comp], r.jt, lds, L, r.t, tw);
       if (LP == NPL - 1 && r.valid) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)

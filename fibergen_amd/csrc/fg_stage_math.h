@@ -327,4 +327,18 @@ FG_HD void g0_point(cplx t0, cplx t1, cplx t2, double kpm0, double kpm1, double 
   *e2 = cadd(cscale(c1, t2), cmul(c2_fkp, km2));
 }
 
+// The same body with one division: c1 = c10 / |k|^2, c2 = c20 / |k|^4 from a single reciprocal.  Used by the
+// fused FFT pass, which has no bit-exactness contract (the FFT itself replaces FFTW); differs from g0_point by a few ulp.
+FG_HD void g0_point_rcp(cplx t0, cplx t1, cplx t2, double kpm0, double kpm1, double kpm2, cplx kp0, cplx kp1, cplx kp2,
+                        double c10, double c20, cplx* e0, cplx* e1, cplx* e2) {
+  const double inv = 1.0 / (kpm0 * kpm0 + kpm1 * kpm1 + kpm2 * kpm2);
+  const double c1 = c10 * inv;
+  const double c2 = c20 * inv * inv;
+  const cplx s = cadd(cadd(cmul(t0, kp0), cmul(t1, kp1)), cmul(t2, kp2));
+  const cplx c2_fkp = cscale(c2, s);
+  *e0 = cadd(cscale(c1, t0), cmul(c2_fkp, cmake(-kp0.re, kp0.im)));
+  *e1 = cadd(cscale(c1, t1), cmul(c2_fkp, cmake(-kp1.re, kp1.im)));
+  *e2 = cadd(cscale(c1, t2), cmul(c2_fkp, cmake(-kp2.re, kp2.im)));
+}
+
 }  // namespace fg
