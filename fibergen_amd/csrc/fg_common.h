@@ -56,6 +56,19 @@ FG_HD void cstore_stream(cplx* p, cplx v, int nt) {
   *p = v;
 }
 
+// The matching load (nt & 2): a line an FFT pass reads once.
+FG_HD cplx cload_stream(const cplx* p, int nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (nt & 2) {
+    typedef double fg_v2d __attribute__((ext_vector_type(2)));
+    const fg_v2d t = __builtin_nontemporal_load(reinterpret_cast<const fg_v2d*>(p));
+    return cmake(t.x, t.y);
+  }
+#endif
+  (void)nt;
+  return *p;
+}
+
 // Geometry of one padded field component: the reference's in-place r2c layout,
 // real [nx][ny][nzp], z fastest, complex view [nx][ny][nzc] on the same bytes -- except that the
 // row pitch is rounded up to 128 bytes (8 complex) so that every row, FFT tile and halo plane

@@ -156,6 +156,11 @@ __global__ void k_scale(double* x, long n, double s) {
   if (i < n) x[i] *= s;
 }
 
+int nt_loads_env() {
+  static const int v = getenv("FG_NT_LOADS") ? atoi(getenv("FG_NT_LOADS")) : 7;
+  return v;
+}
+
 bool fast_len(int n) { return is_pow2(n) && n >= 8 && n <= 1024; }
 
 cplx* upload(const std::vector<cplx>& v) {
@@ -228,7 +233,7 @@ void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
   }
   // measured: 256^3 0.313 -> 0.284 ms; at N = 512 the extra live state pushes the 512-thread kernel further into
   // scratch (160 -> 336 B) and it loses (2.53 -> 3.08 ms), so the persistent form is used for N <= 256 only
-  if (persist_env && NC == 3 && (N <= 256 || C < 8) && nblocks > 2L * resident) {
+  if (persist_env && NC == 3 && (N <= 256 || C < 8 || persist_env == 2) && nblocks > 2L * resident) {
     constexpr int UNIT = C >= 8 ? 1 : 8 / C;
     hipLaunchKernelGGL((k_xfused_persistent<K, UNIT>), dim3((unsigned)resident), dim3(K::THREADS), lds, s, a, (int)nblocks);
   } else {
@@ -298,7 +303,7 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
     a.tiles_per_outer = 0;
     a.scale = scale;
     a.tw = tw_[axis];
-    a.nt = stream_stores_;
+    a.nt = stream_stores_ ? (1 | ((nt_loads_env() & 1) ? 2 : 0)) : 0;
     const long cs = comp_stride / 2;
     switch (n) {
       case 8: strided_n<8>(a, nouter, dir, ncomp, cs, stream_); break;
@@ -351,7 +356,7 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
   a.c10 = gp.c10;
   a.c20 = gp.c20;
   a.tw = tw_[axis];
-  a.nt = stream_stores_;
+  a.nt = stream_stores_ ? (1 | ((nt_loads_env() & 2) ? 2 : 0)) : 0;
   for (int k = 0; k < 3; ++k) {
     a.kpm[k] = gp.kpm[k];
     a.kp[k] = gp.kp[k];
@@ -379,7 +384,7 @@ void Fft3::c2c_x(double* data, int ncomp, long comp_stride, int dir, double scal
 void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
   const long nrows = (long)g_.nx * g_.ny;
   if (fast_[2]) {
-    ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_};
+    ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_ ? (1 | ((nt_loads_env() & 4) ? 2 : 0)) : 0};
     switch (g_.nz / 2) {
 #define FG_CASE(m) case m: launch_z<R2CKernel<m, ZLines<m>::value>>(a, ncomp, comp_stride, ZLines<m>::value, stream_); break;
       FG_CASE(8) FG_CASE(16) FG_CASE(32) FG_CASE(64) FG_CASE(128) FG_CASE(256) FG_CASE(512) FG_CASE(1024)
@@ -402,7 +407,7 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
 void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
   const long nrows = (long)g_.nx * g_.ny;
   if (fast_[2]) {
-    ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_};
+    ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_ ? (1 | ((nt_loads_env() & 8) ? 2 : 0)) : 0};
     switch (g_.nz / 2) {
 #define FG_CASE(m) case m: launch_z<C2RKernel<m, ZLines<m>::value>>(a, ncomp, comp_stride, ZLines<m>::value, stream_); break;
       FG_CASE(8) FG_CASE(16) FG_CASE(32) FG_CASE(64) FG_CASE(128) FG_CASE(256) FG_CASE(512) FG_CASE(1024)

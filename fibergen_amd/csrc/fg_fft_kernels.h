@@ -67,7 +67,7 @@ struct StridedKernel {
       r.base = (long)o * a.os + col;
 #pragma unroll
       for (int q = 0; q < 8; ++q)
-        r.v[q] = r.valid ? a.data[r.base + (long)Line<N>::first_index(r.jt, q) * a.ls] : cmake(0.0, 0.0);
+        r.v[q] = r.valid ? cload_stream(&a.data[r.base + (long)Line<N>::first_index(r.jt, q) * a.ls], a.nt) : cmake(0.0, 0.0);
     }
     Line<N>::template phase<DIR, PH>(r.v, r.jt, lds, L, r.t, a.tw);
     if (PH == NPHASE - 1 && r.valid) {
@@ -117,7 +117,7 @@ struct R2CKernel {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         int m = Line<M>::first_index(r.jt, q);
-        r.v[q] = r.valid ? reinterpret_cast<const cplx*>(r.row)[m] : cmake(0.0, 0.0);
+        r.v[q] = r.valid ? cload_stream(&reinterpret_cast<const cplx*>(r.row)[m], a.nt) : cmake(0.0, 0.0);
       }
     }
     if (PH < NPHASE - 1) {
@@ -172,8 +172,8 @@ struct C2RKernel {
         int m = Line<M>::first_index(r.jt, q);
         cplx xk = cmake(0.0, 0.0), xm = cmake(0.0, 0.0);
         if (r.valid) {
-          xk = in[m];
-          xm = in[M - m];
+          xk = cload_stream(&in[m], a.nt);
+          xm = cload_stream(&in[M - m], a.nt);
           // FFTW's c2r ignores the imaginary parts of the DC and Nyquist bins
           if (m == 0) { xk.im = 0.0; xm.im = 0.0; }
         }
@@ -276,7 +276,7 @@ struct XFusedKernel {
   // N = 512: the pass twiddles sit in LDS behind the exchange buffers (14 KB, the tile then uses 158 of 160 KB).
   // A twiddle read through the vector memory path shares its in-order counter with the tile's loads and
   // stores, so every twiddled pass waited for the stores of the previous component to be acknowledged.
-  static constexpr bool TW_LDS = N >= 512 && NC == 3;
+  static constexpr bool TW_LDS = N >= 64 && NC == 3;
   static constexpr int TW_OFF = (PINGPONG ? 2 : 1) * BUF_DOUBLES;
   static constexpr int LDS_DOUBLES = TW_OFF + (TW_LDS ? 2 * tw_total(N) : 0);
   static constexpr int NPHASE = 2 * NC * NPL;   // NC forward + NC inverse transforms
@@ -336,7 +336,7 @@ struct XFusedKernel {
         if (PERSIST && ((have >> c) & 1)) continue;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          r.v[c][q] = r.valid ? a.data[c * a.comp_stride + r.base + (long)Line<N>::first_index(r.jt, q) * a.ls]
+          r.v[c][q] = r.valid ? cload_stream(&a.data[c * a.comp_stride + r.base + (long)Line<N>::first_index(r.jt, q) * a.ls], a.nt)
                               : cmake(0.0, 0.0);
       }
     }
