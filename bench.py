@@ -101,6 +101,8 @@ def slab_section(args, n, K, rank, world, local_rank, dist, torch):
     if normals is not None:
         s.set_normals(s.slab(normals))
     s.set_options(mixing_rule=args.mixing)
+    if os.environ.get("FG_SLAB_FUSE_X"):
+        s.set_options(fuse_x=int(os.environ["FG_SLAB_FUSE_X"]))
     del phi, normals
     s.calc_ref_material()
     E = np.array([1.0, 0, 0, 0, 0, 0])
@@ -180,6 +182,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-slab", action="store_true", help="N > 1: skip the slab-decomposed measurement")
     ap.add_argument("--slab-timeout", type=int, default=240)
+    ap.add_argument("--force-slab", action="store_true",
+                    help="also at N = 1: run the slab-decomposed driver (one slab, exchanges become local copies)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,11 +193,16 @@ def main():
     # BEFORE libfibergen_amd.so is loaded so that both share one HIP runtime (same soname).
     torch = None
     dist = None
-    if world > 1:
+    if world > 1 or args.force_slab:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from fibergen_amd import LSSolver
     from fibergen_amd.rve import synthetic_fiber_rve
@@ -333,7 +342,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not scalar and not stokes:
             s.close()
             out["cpu_baseline"] = cpu_baseline(n, args.mixing, args.cpu_budget)
-    if world > 1 and not args.no_slab and not scalar and not stokes:
+    if (world > 1 or args.force_slab) and not args.no_slab and not scalar and not stokes:
         # Second measurement: ONE problem slab-decomposed over all ranks (x-slabs, two RCCL
         # all-to-alls per pass).  Guarded: a failure or a stall here must not cost the line above.
         s.close()

@@ -1297,10 +1297,23 @@ void Solver::slab_phase(int phase, const double* E6, const double* R6) {
       launch_transpose_B(a2a_recv, fu_, nxg_, g_.nx, nyl_, g_.nzc, false, stream_);
       const long cs = (long)nyl_ * nxg_ * g_.nzp;
       const double scale = 1 / (double)nglobal_;
-      if (nxg_ > 1) fft_t_->c2c_y(fu_, 3, cs, -1, scale);
-      else fft_t_->scale(fu_, 3, cs, scale);
       const double c10 = -alpha / (opt_.mu_0);
       const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+      if (opt_.fuse_x && nxg_ > 1 && fft_t_->can_fuse(1)) {
+        // the single-GPU loop's fused pass on the y-slab: x is the middle axis here, ky = rank*nyl + outer index
+        G0Params gp;
+        gp.c10 = c10;
+        gp.c20 = c20;
+        for (int a = 0; a < 3; ++a) {
+          gp.kpm[a] = g0_kpm_[a];
+          gp.kp[a] = g0_kp_[a];
+        }
+        fft_t_->fused_g0(fu_, cs, 1, scale, gp, rank_ * nyl_);
+        launch_transpose_B(fu_, a2a_send, nxg_, g_.nx, nyl_, g_.nzc, true, stream_);
+        break;
+      }
+      if (nxg_ > 1) fft_t_->c2c_y(fu_, 3, cs, -1, scale);
+      else fft_t_->scale(fu_, 3, cs, scale);
       G0Tables tb;
       for (int a = 0; a < 3; ++a) {
         tb.kpm[a] = g0_kpm_[a];

@@ -222,7 +222,7 @@ class DistributedLSSolver:
             self.maxiter = int(kw["maxiter"])
         if "update_ref" in kw:
             self.update_ref = kw["update_ref"] not in ("never", 0, False)
-        fwd = {k: v for k, v in kw.items() if k in ("mixing_rule", "eps_g", "eps_a", "mu_0", "lambda_0")}
+        fwd = {k: v for k, v in kw.items() if k in ("mixing_rule", "eps_g", "eps_a", "mu_0", "lambda_0", "fuse_x")}
         if fwd:
             self.backend.set_options(**fwd)
 
