@@ -90,13 +90,18 @@ void launch_cgu_dot(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldP
                     double* out7, hipStream_t s);
 void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r,
                      const FieldPtrs<3>& w, double a, hipStream_t s);
-// interface voxels (some phase fraction strictly between 0 and 1): count (list == nullptr) or fill the list of their
-// element offsets; then the laminate polarisation at those voxels only
-unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned* list, unsigned* count_dev,
-                           hipStream_t s);
-void launch_laminate_fix(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
-                         const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, const Vec6& E, const unsigned* list, unsigned n,
-                         int* error_flag, hipStream_t s);
+// interface voxels (some phase fraction strictly between 0 and 1): allocates and fills the list of their element
+// offsets in voxel order (*list, hipFree by the caller), returns the count
+unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned** list, hipStream_t s);
+// laminate mixing as a correction of the Voigt sweep (see k_laminate_delta): the voxels whose divergence stencil touches
+// an interface voxel, in voxel order, with 8 slots each (*aff, *slots allocated here); per pass the polarisation
+// difference at the interface voxels [n][6] and its divergence added to f
+unsigned launch_affected_list(const Grid& g, const unsigned* list, unsigned n, unsigned** aff, int** slots, hipStream_t s);
+void launch_laminate_delta(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
+                           const FieldPtrs<3>& normals, const Vec6& E, const unsigned* list, unsigned n, double* dtau,
+                           int* error_flag, hipStream_t s);
+void launch_delta_div(const Grid& g, const unsigned* aff, const int* slots, unsigned n, const double* dtau,
+                      const FieldPtrs<3>& f, hipStream_t s);
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);
 void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
                hipStream_t s);

@@ -785,57 +785,168 @@ __global__ __launch_bounds__(kBlock) void k_cgu_axpy(long n2, FieldPtrs<3> x, Fi
 // branch, F:13464-13470 vs F:12752-12761), and its one-step Newton solve is ~400 flop with a large register
 // footprint.  So the sweep over all voxels runs the cheap Voigt form of k_u_stress, and this kernel then re-evaluates
 // the polarisation at the interface voxels alone, from a compact list built once per geometry.
+// Ordered stream compaction for the voxel lists below: a workgroup owns kCompactChunk consecutive voxels, counts its
+// flagged voxels (pass 1, offsets == nullptr), and after an exclusive scan of the workgroup counts writes them in
+// voxel order (pass 2).  Sorted lists keep the gathers of the per-pass kernels on neighbouring cache lines, and the
+// order does not depend on the schedule.
+constexpr int kCompactChunk = 16 * kBlock;
+
+__device__ __forceinline__ unsigned ordered_slot(bool flag, unsigned& base, unsigned* wcount) {
+  const unsigned long long m = __ballot(flag);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wcount[w] = (unsigned)__popcll(m);
+  __syncthreads();
+  unsigned before = 0, total = 0;
+  for (int i = 0; i < kBlock / 64; ++i) {
+    const unsigned c = wcount[i];
+    if (i < w) before += c;
+    total += c;
+  }
+  const unsigned slot = base + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+  base += total;
+  __syncthreads();
+  return slot;
+}
+
+__global__ void k_scan_counts(unsigned* counts, int n) {   // exclusive scan in place, total -> counts[n]; set-up only
+  unsigned run = 0;
+  for (int i = 0; i < n; ++i) {
+    const unsigned c = counts[i];
+    counts[i] = run;
+    run += c;
+  }
+  counts[n] = run;
+}
+
 __global__ __launch_bounds__(kBlock) void k_mixed_list(Grid g, int nph, FieldPtrs<kMaxPhases> phi, unsigned* list,
-                                                       unsigned* count) {
+                                                       unsigned* counts) {
+  __shared__ unsigned wcount[kBlock / 64];
   const long nvox = (long)g.nx * g.ny * g.nz;
-  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long)gridDim.x * blockDim.x) {
-    const long row = v / g.nz;
-    const int k = (int)(v - row * g.nz);
-    const long off = row * g.nzp + k;
+  unsigned base = list ? counts[blockIdx.x] : 0u;
+  for (int r = 0; r < kCompactChunk / kBlock; ++r) {
+    const long v = (long)blockIdx.x * kCompactChunk + r * kBlock + threadIdx.x;
     bool mixed = false;
-    for (int q = 0; q < nph; ++q) {
-      const double f = phi.p[q][off];
-      mixed = mixed || (f != 0.0 && f != 1.0);
+    long off = 0;
+    if (v < nvox) {
+      const long row = v / g.nz;
+      off = row * g.nzp + (v - row * g.nz);
+      for (int q = 0; q < nph; ++q) {
+        const double f = phi.p[q][off];
+        mixed = mixed || (f != 0.0 && f != 1.0);
+      }
     }
-    if (mixed) {
-      const unsigned slot = atomicAdd(count, 1u);
-      if (list) list[slot] = (unsigned)off;   // order is irrelevant: every entry writes its own voxel
+    const unsigned slot = ordered_slot(mixed, base, wcount);
+    if (mixed && list) list[slot] = (unsigned)off;
+  }
+  if (!list && threadIdx.x == 0) counts[blockIdx.x] = base;
+}
+
+// Laminate mixing in the displacement loop (u_loop = 2).  The divergence is linear in the polarisation, so
+//   f = div tau_voigt + div (tau_laminate - tau_voigt),
+// and the second term lives on the interface voxels only: the tiled Voigt sweep runs unchanged over all voxels, then
+//   k_laminate_delta   d_j = P_laminate(eps_j) - P_voigt(eps_j) for every interface voxel j (eps from u by the strain
+//                      stencil, the one-step Newton solve of laminate_split), stored compactly [j][6];
+//   k_delta_div        every voxel whose divergence stencil touches an interface voxel adds div d to its f, gathering d
+//                      through seven precomputed slots (self, x-1, x+1, y-1, y+1, z-1, z+1; -1 = not an interface voxel).
+// One writer per voxel, fixed operation order: deterministic, no atomics.  The lists are built once per geometry.
+__global__ __launch_bounds__(kBlock) void k_fill_int(int* p, long n, int v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_mixed_map(const unsigned* list, unsigned n, int* map) {
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) map[list[j]] = (int)j;
+}
+
+struct VoxelNeighbours {
+  long xf, xb, yf, yb, zf, zb;
+};
+__device__ __forceinline__ VoxelNeighbours voxel_neighbours(const Grid& g, int i, int j, int k) {
+  VoxelNeighbours n;
+  n.xf = (i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+  n.xb = (i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+  n.yf = (j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
+  n.yb = (j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
+  n.zf = (k + 1 == g.nz ? -(long)(g.nz - 1) : 1L);
+  n.zb = (k == 0 ? (long)(g.nz - 1) : -1L);
+  return n;
+}
+
+// aff == nullptr: count only.  slots: 8 ints per entry (self, xb, xf, yb, yf, zb, zf, unused).
+__global__ __launch_bounds__(kBlock) void k_affected_list(Grid g, const int* map, unsigned* aff, int* slots, unsigned* counts) {
+  __shared__ unsigned wcount[kBlock / 64];
+  const long nvox = (long)g.nx * g.ny * g.nz;
+  unsigned base = aff ? counts[blockIdx.x] : 0u;
+  for (int r = 0; r < kCompactChunk / kBlock; ++r) {
+    const long v = (long)blockIdx.x * kCompactChunk + r * kBlock + threadIdx.x;
+    bool any = false;
+    long off = 0;
+    int sl[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    if (v < nvox) {
+      const long row = v / g.nz;
+      const int k = (int)(v - row * g.nz);
+      const int i = (int)(row / g.ny), j = (int)(row - (long)i * g.ny);
+      off = row * g.nzp + k;
+      const VoxelNeighbours nb = voxel_neighbours(g, i, j, k);
+      sl[0] = map[off]; sl[1] = map[off + nb.xb]; sl[2] = map[off + nb.xf]; sl[3] = map[off + nb.yb];
+      sl[4] = map[off + nb.yf]; sl[5] = map[off + nb.zb]; sl[6] = map[off + nb.zf];
+      for (int t = 0; t < 7; ++t) any = any || sl[t] >= 0;
+    }
+    const unsigned e = ordered_slot(any, base, wcount);
+    if (any && aff) {
+      aff[e] = (unsigned)off;
+      for (int t = 0; t < 8; ++t) slots[(long)e * 8 + t] = sl[t];
     }
   }
+  if (!aff && threadIdx.x == 0) counts[blockIdx.x] = base;
 }
 
 template <int NPH>
-__global__ __launch_bounds__(kBlock) void k_laminate_fix(Grid g, StressParams sp, FieldPtrs<3> u, FieldPtrs<kMaxPhases> phi,
-                                                         FieldPtrs<3> normals, FieldPtrs<6> tau, Vec6 E,
-                                                         const unsigned* list, unsigned n, int* error_flag) {
+__global__ __launch_bounds__(kBlock) void k_laminate_delta(Grid g, StressParams sp, FieldPtrs<3> u, FieldPtrs<kMaxPhases> phi,
+                                                           FieldPtrs<3> normals, Vec6 E, const unsigned* list, unsigned n,
+                                                           double* dtau, int* error_flag) {
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
     const long off = list[idx];
     const long row = off / g.nzp;
     const int k = (int)(off - row * g.nzp);
     const int i = (int)(row / g.ny), j = (int)(row - (long)i * g.ny);
-    const long xf = (i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
-    const long xb = (i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
-    const long yf = (j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
-    const long yb = (j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
-    const long zf = (k + 1 == g.nz ? -(long)(g.nz - 1) : 1L);
-    const long zb = (k == 0 ? (long)(g.nz - 1) : -1L);
+    const VoxelNeighbours nb = voxel_neighbours(g, i, j, k);
     const double u0 = u.p[0][off], u1 = u.p[1][off], u2 = u.p[2][off];
     double F[6];
     // epsOperatorStaggered  F:18632-18686, the expressions of k_u_stress for one voxel
-    F[3] = E.v[3] + 0.5 * ((u2 - u.p[2][off + yb]) * hy + (u1 - u.p[1][off + zb]) * hz);
-    F[4] = E.v[4] + 0.5 * ((u2 - u.p[2][off + xb]) * hx + (u0 - u.p[0][off + zb]) * hz);
-    F[5] = E.v[5] + 0.5 * ((u1 - u.p[1][off + xb]) * hx + (u0 - u.p[0][off + yb]) * hy);
-    F[0] = E.v[0] + (u.p[0][off + xf] - u0) * hx;
-    F[1] = E.v[1] + (u.p[1][off + yf] - u1) * hy;
-    F[2] = E.v[2] + (u.p[2][off + zf] - u2) * hz;
-    double ph[NPH], nv[3], P[6];
+    F[3] = E.v[3] + 0.5 * ((u2 - u.p[2][off + nb.yb]) * hy + (u1 - u.p[1][off + nb.zb]) * hz);
+    F[4] = E.v[4] + 0.5 * ((u2 - u.p[2][off + nb.xb]) * hx + (u0 - u.p[0][off + nb.zb]) * hz);
+    F[5] = E.v[5] + 0.5 * ((u1 - u.p[1][off + nb.xb]) * hx + (u0 - u.p[0][off + nb.yb]) * hy);
+    F[0] = E.v[0] + (u.p[0][off + nb.xf] - u0) * hx;
+    F[1] = E.v[1] + (u.p[1][off + nb.yf] - u1) * hy;
+    F[2] = E.v[2] + (u.p[2][off + nb.zf] - u2) * hz;
+    double ph[NPH], nv[3], Pl[6], Pv[6];
 #pragma unroll
     for (int q = 0; q < NPH; ++q) ph[q] = q < sp.pt.n ? phi.p[q][off] : 0.0;
     nv[0] = normals.p[0][off]; nv[1] = normals.p[1][off]; nv[2] = normals.p[2][off];
-    if (stress_voxel<NPH>(F, ph, nv, sp, P)) atomicOr(error_flag, 1);
+    // the reference-medium part of the polarisation is the same in both and cancels
+    if (pk1_laminate<NPH>(F, ph, nv, sp.pt, sp.alpha, false, sp.eps_g, sp.eps_a, Pl)) atomicOr(error_flag, 1);
+    pk1_voigt<NPH>(F, ph, sp.pt, sp.alpha, false, Pv);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) tau.p[c][off] = P[c];
+    for (int c = 0; c < 6; ++c) dtau[(long)idx * 6 + c] = Pl[c] - Pv[c];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_delta_div(Grid g, const unsigned* aff, const int* slots, unsigned n,
+                                                      const double* dtau, FieldPtrs<3> f) {
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const long off = aff[e];
+    const int4 sa = reinterpret_cast<const int4*>(slots)[2 * (long)e];       // self, xb, xf, yb
+    const int4 sb = reinterpret_cast<const int4*>(slots)[2 * (long)e + 1];   // yf, zb, zf, -
+    auto d = [&](int slot, int c) { return slot < 0 ? 0.0 : dtau[(long)slot * 6 + c]; };
+    // divOperatorStaggered  F:18853-18908 applied to the difference field
+    const double d0 = (d(sa.x, 0) - d(sa.y, 0)) * hx + (d(sb.x, 5) - d(sa.x, 5)) * hy + (d(sb.z, 4) - d(sa.x, 4)) * hz;
+    const double d1 = (d(sa.z, 5) - d(sa.x, 5)) * hx + (d(sa.x, 1) - d(sa.w, 1)) * hy + (d(sb.z, 3) - d(sa.x, 3)) * hz;
+    const double d2 = (d(sa.z, 4) - d(sa.x, 4)) * hx + (d(sb.x, 3) - d(sa.x, 3)) * hy + (d(sa.x, 2) - d(sb.y, 2)) * hz;
+    f.p[0][off] += d0;
+    f.p[1][off] += d1;
+    f.p[2][off] += d2;
   }
 }
 
@@ -1224,29 +1335,78 @@ void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const Field
   FG_HIP_CHECK(hipGetLastError());
 }
 
-unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned* list, unsigned* count_dev,
-                           hipStream_t s) {
-  if ((long)g.nx * g.ny * g.nzp >= (1L << 32)) throw std::runtime_error("grid too large for the 32-bit interface list");
-  FG_HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(unsigned), s));
-  const long nvox = (long)g.nx * g.ny * g.nz;
-  hipLaunchKernelGGL(k_mixed_list, dim3(grid_for(nvox, 1 << 16)), dim3(kBlock), 0, s, g, nph, phi, list, count_dev);
+namespace {
+int compact_blocks(const Grid& g) { return (int)(((long)g.nx * g.ny * g.nz + kCompactChunk - 1) / kCompactChunk); }
+unsigned scan_counts(unsigned* counts, int nb, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1), 0, s, counts, nb);
   FG_HIP_CHECK(hipGetLastError());
-  unsigned n = 0;
-  FG_HIP_CHECK(hipMemcpyAsync(&n, count_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  unsigned total = 0;
+  FG_HIP_CHECK(hipMemcpyAsync(&total, counts + nb, sizeof(unsigned), hipMemcpyDeviceToHost, s));
   FG_HIP_CHECK(hipStreamSynchronize(s));
+  return total;
+}
+}  // namespace
+
+unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned** list, hipStream_t s) {
+  if ((long)g.nx * g.ny * g.nzp >= (1L << 31)) throw std::runtime_error("grid too large for the 32-bit interface list");
+  const int nb = compact_blocks(g);
+  unsigned* counts = nullptr;
+  FG_HIP_CHECK(hipMalloc(&counts, ((size_t)nb + 1) * sizeof(unsigned)));
+  hipLaunchKernelGGL(k_mixed_list, dim3(nb), dim3(kBlock), 0, s, g, nph, phi, (unsigned*)nullptr, counts);
+  const unsigned n = scan_counts(counts, nb, s);
+  *list = nullptr;
+  if (n) {
+    FG_HIP_CHECK(hipMalloc(list, (size_t)n * sizeof(unsigned)));
+    hipLaunchKernelGGL(k_mixed_list, dim3(nb), dim3(kBlock), 0, s, g, nph, phi, *list, counts);
+    FG_HIP_CHECK(hipGetLastError());
+    FG_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  FG_HIP_CHECK(hipFree(counts));
   return n;
 }
 
-void launch_laminate_fix(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
-                         const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, const Vec6& E, const unsigned* list, unsigned n,
-                         int* error_flag, hipStream_t s) {
+unsigned launch_affected_list(const Grid& g, const unsigned* list, unsigned n, unsigned** aff, int** slots, hipStream_t s) {
+  // map: scratch of g.n ints (element offset -> index in the interface list or -1), needed during the build only
+  const int nb = compact_blocks(g);
+  int* map = nullptr;
+  unsigned* counts = nullptr;
+  FG_HIP_CHECK(hipMalloc(&map, (size_t)g.n * sizeof(int)));
+  FG_HIP_CHECK(hipMalloc(&counts, ((size_t)nb + 1) * sizeof(unsigned)));
+  hipLaunchKernelGGL(k_fill_int, dim3(grid_for(g.n, 1 << 16)), dim3(kBlock), 0, s, map, g.n, -1);
+  if (n) hipLaunchKernelGGL(k_mixed_map, dim3(grid_for((long)n, 1 << 16)), dim3(kBlock), 0, s, list, n, map);
+  hipLaunchKernelGGL(k_affected_list, dim3(nb), dim3(kBlock), 0, s, g, map, (unsigned*)nullptr, (int*)nullptr, counts);
+  const unsigned m = scan_counts(counts, nb, s);
+  *aff = nullptr;
+  *slots = nullptr;
+  if (m) {
+    FG_HIP_CHECK(hipMalloc(aff, (size_t)m * sizeof(unsigned)));
+    FG_HIP_CHECK(hipMalloc(slots, (size_t)m * 8 * sizeof(int)));
+    hipLaunchKernelGGL(k_affected_list, dim3(nb), dim3(kBlock), 0, s, g, map, *aff, *slots, counts);
+    FG_HIP_CHECK(hipGetLastError());
+    FG_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  FG_HIP_CHECK(hipFree(map));
+  FG_HIP_CHECK(hipFree(counts));
+  return m;
+}
+
+void launch_laminate_delta(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
+                           const FieldPtrs<3>& normals, const Vec6& E, const unsigned* list, unsigned n, double* dtau,
+                           int* error_flag, hipStream_t s) {
   if (n == 0) return;
   const dim3 grid(grid_for((long)n, 1 << 16));
   if (sp.pt.n <= 2)
-    hipLaunchKernelGGL((k_laminate_fix<2>), grid, dim3(kBlock), 0, s, g, sp, u, phi, normals, tau, E, list, n, error_flag);
+    hipLaunchKernelGGL((k_laminate_delta<2>), grid, dim3(kBlock), 0, s, g, sp, u, phi, normals, E, list, n, dtau, error_flag);
   else
-    hipLaunchKernelGGL((k_laminate_fix<kMaxPhases>), grid, dim3(kBlock), 0, s, g, sp, u, phi, normals, tau, E, list, n,
+    hipLaunchKernelGGL((k_laminate_delta<kMaxPhases>), grid, dim3(kBlock), 0, s, g, sp, u, phi, normals, E, list, n, dtau,
                        error_flag);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_delta_div(const Grid& g, const unsigned* aff, const int* slots, unsigned n, const double* dtau,
+                      const FieldPtrs<3>& f, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_delta_div, dim3(grid_for((long)n, 1 << 16)), dim3(kBlock), 0, s, g, aff, slots, n, dtau, f);
   FG_HIP_CHECK(hipGetLastError());
 }
 

@@ -133,6 +133,7 @@ class Solver {
   bool run_cg_scalar(const double* E0);  // heat / porous: CG in potential space
   bool run_cg_u(const double* E0);      // the same CG carried in displacement space (Voigt, prescribed mean strains)
   bool u_loop_eligible() const;
+  void build_laminate_lists();          // interface / affected voxel lists of the laminate correction (once per geometry)
   void u_pass_front(const double* E6);  // u_k (fu_) -> sums of squares of eps_k, f_{k+1} (fu_alt_)
   void u_pass_back();                   // f_{k+1} -> u_{k+1}, buffers swapped
   // r2c (unless z_done: buf already holds the z spectrum), y, x + Green operator + x^-1, y^-1, c2r on 3 components
@@ -174,9 +175,12 @@ class Solver {
   double* fu_ = nullptr;       // 3 (real f / u, complex f_hat / u_hat); after a pass it holds u
   double *cg_r_ = nullptr, *cg_p_ = nullptr, *cg_w_ = nullptr;  // CG residual, direction, operator image (6 each)
   unsigned* mixed_list_ = nullptr;  // element offsets of the interface voxels (laminate mixing, displacement loop)
-  unsigned* mixed_count_dev_ = nullptr;
   unsigned mixed_n_ = 0;
   bool mixed_dirty_ = true;
+  unsigned* aff_list_ = nullptr;    // voxels whose divergence stencil touches an interface voxel
+  int* aff_slots_ = nullptr;        // 8 per entry: interface-list index of self, x-1, x+1, y-1, y+1, z-1, z+1 (or -1)
+  unsigned aff_n_ = 0;
+  double* dtau_ = nullptr;          // [mixed_n_][6] tau_laminate - tau_voigt of the current pass
   double* mod_ = nullptr;      // 2: per-voxel effective moduli (sum phi 2 mu, sum phi lambda) of the fast sweep
   bool mod_dirty_ = true;
   double* fu_alt_ = nullptr;   // 3: second f/u buffer of the displacement-based loop (swapped with fu_)

@@ -136,7 +136,9 @@ Solver::~Solver() {
   for (int k = 0; k < 4; ++k)
     if (halo_[k]) (void)hipFree(halo_[k]);
   if (mixed_list_) (void)hipFree(mixed_list_);
-  if (mixed_count_dev_) (void)hipFree(mixed_count_dev_);
+  if (aff_list_) (void)hipFree(aff_list_);
+  if (aff_slots_) (void)hipFree(aff_slots_);
+  if (dtau_) (void)hipFree(dtau_);
   double* bufs[] = {eps_, tau_, fu_, fu_alt_, phi_, normals_, partial_, dscal_, cg_r_, cg_p_, cg_w_, mod_};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
@@ -620,6 +622,24 @@ bool Solver::u_loop_eligible() const {
          frobenius(BC_MQ_) < kEps;
 }
 
+void Solver::build_laminate_lists() {
+  if (!mixed_dirty_) return;
+  FieldPtrs<kMaxPhases> phi;
+  for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
+  for (void* p : {(void*)mixed_list_, (void*)aff_list_, (void*)aff_slots_, (void*)dtau_})
+    if (p) FG_HIP_CHECK(hipFree(p));
+  mixed_list_ = aff_list_ = nullptr;
+  aff_slots_ = nullptr;
+  dtau_ = nullptr;
+  aff_n_ = 0;
+  mixed_n_ = launch_mixed_list(g_, pt_.n, phi, &mixed_list_, stream_);
+  if (mixed_n_) {
+    FG_HIP_CHECK(hipMalloc(&dtau_, (size_t)mixed_n_ * 6 * sizeof(double)));
+    aff_n_ = launch_affected_list(g_, mixed_list_, mixed_n_, &aff_list_, &aff_slots_, stream_);
+  }
+  mixed_dirty_ = false;
+}
+
 void Solver::u_pass_front(const double* E6) {
   FieldPtrs<kMaxPhases> phi;
   for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
@@ -653,34 +673,13 @@ void Solver::u_pass_front(const double* E6) {
     } else {
       launch_sc_sweep(g_, scalar_params(opt_.mu_0, 1.0), fu_, phase_ptrs(), fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
     }
-  } else if (opt_.mixing != kMixVoigt) {
-    // laminate mixing: strain + polarisation from u in one sweep (tau stored), divergence as its own sweep
+  } else if (opt_.mixing != kMixVoigt && opt_.u_loop < 2) {
+    // laminate mixing, exact order: strain + polarisation from u in one sweep (tau stored), divergence as its own sweep
     z_done_ = false;
     FieldPtrs<3> nrm;
     for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
-    if (opt_.u_loop >= 2) {
-      // all voxels with the cheap Voigt form (identical at pure voxels), then the laminate rule at the interface
-      // voxels only, from a list built once per geometry
-      if (mixed_dirty_ || !mixed_count_dev_) {
-        if (!mixed_count_dev_) FG_HIP_CHECK(hipMalloc(&mixed_count_dev_, sizeof(unsigned)));
-        if (mixed_list_) FG_HIP_CHECK(hipFree(mixed_list_));
-        mixed_list_ = nullptr;
-        mixed_n_ = launch_mixed_list(g_, pt_.n, phi, nullptr, mixed_count_dev_, stream_);
-        if (mixed_n_) {
-          FG_HIP_CHECK(hipMalloc(&mixed_list_, (size_t)mixed_n_ * sizeof(unsigned)));
-          launch_mixed_list(g_, pt_.n, phi, mixed_list_, mixed_count_dev_, stream_);
-        }
-        mixed_dirty_ = false;
-      }
-      StressParams spv = stress_params(opt_.mu_0, opt_.lambda_0, 1.0);
-      spv.mixing = kMixVoigt;
-      launch_u_stress(g_, spv, ptrs3(fu_), phi, nrm, ptrs6(tau_), E, partial_, dscal_ + kSlotSumSq, derr_, stream_);
-      launch_laminate_fix(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, ptrs6(tau_), E, mixed_list_,
-                          mixed_n_, derr_, stream_);
-    } else {
-      launch_u_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, ptrs6(tau_), E, partial_,
-                      dscal_ + kSlotSumSq, derr_, stream_);
-    }
+    launch_u_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, ptrs6(tau_), E, partial_,
+                    dscal_ + kSlotSumSq, derr_, stream_);
     time_end(0);
     time_begin(1);
     launch_div(g_, ptrs6(tau_), ptrs3(fu_alt_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
@@ -701,7 +700,8 @@ void Solver::u_pass_front(const double* E6) {
       launch_effective_moduli(g_, phase_table(), phi, mod, stream_);
       mod_dirty_ = false;
     }
-    const bool want_z = opt_.fuse_z > 0 || (opt_.fuse_z < 0 && (long)g_.nx * g_.ny * g_.nz <= (1L << 22));
+    const bool laminate = opt_.mixing != kMixVoigt;
+    const bool want_z = !laminate && (opt_.fuse_z > 0 || (opt_.fuse_z < 0 && (long)g_.nx * g_.ny * g_.nz <= (1L << 22)));
     z_done_ = want_z && fft_->fast_z() && u_fast_z_supported(g_);
     if (opt_.u_tile && u_tile_supported(g_)) {
       z_done_ = false;
@@ -712,6 +712,16 @@ void Solver::u_pass_front(const double* E6) {
                       fft_->z_twiddles(), fft_->z_roots(), stream_);
     else
       launch_u_fast(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, stream_);
+    if (laminate) {
+      // laminate mixing = the Voigt sweep over all voxels + the divergence of (tau_laminate - tau_voigt), which lives
+      // on the interface voxels (lists built once per geometry, see k_laminate_delta)
+      build_laminate_lists();
+      FieldPtrs<3> nrm;
+      for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+      launch_laminate_delta(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, E, mixed_list_, mixed_n_,
+                            dtau_, derr_, stream_);
+      launch_delta_div(g_, aff_list_, aff_slots_, aff_n_, dtau_, ptrs3(fu_alt_), stream_);
+    }
   } else {
     z_done_ = false;
     launch_u_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, ptrs3(fu_alt_), E,

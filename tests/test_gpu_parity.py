@@ -439,11 +439,11 @@ def test_collocated_cg_and_restrictions():
 
 @pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (32, 16, 64)])
 def test_displacement_based_loop_with_laminate_mixing_is_bit_identical(grid):
-    """Laminate mixing in the displacement-based loop: one sweep u_k -> (norms of eps_k, tau), then the divergence.
-    Same operations as the strain-based pipeline, so iterates are bit-identical."""
+    """Laminate mixing in the displacement-based loop, exact-order form (u_loop=1): one sweep u_k -> (norms of eps_k,
+    tau), then the divergence.  Same operations as the strain-based pipeline, so iterates are bit-identical."""
     E = np.array([1.0, 0, 0, 0, 0, 0.5])
     res = {}
-    for flag in (0, 2):
+    for flag in (0, 1):
         s = make_gpu_solver(grid, mixing="laminate", tol=1e-8)
         s._check(s._lib.fg_set_option_i(s._h, b"u_loop", flag))
         assert s.run(E) is False
@@ -451,13 +451,37 @@ def test_displacement_based_loop_with_laminate_mixing_is_bit_identical(grid):
         s.iterate(E, 2)
         res[flag] += (s.get_field("epsilon"),)
         s.close()
-    a, b = res[0], res[2]
+    a, b = res[0], res[1]
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
     for i in (2, 3, 4, 5):
         assert np.array_equal(a[i], b[i])
     o = make_oracle(grid, mixing="laminate", tol=1e-8)
     assert o.run(E) is False
     assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9
+
+
+@pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (32, 16, 64), (16, 16, 128), (6, 20, 130), (8, 14, 256)])
+def test_laminate_mixing_as_correction_of_the_voigt_sweep(grid):
+    """u_loop=2 with laminate mixing: f = div tau_voigt (the tiled / fast sweep over all voxels) + div (tau_laminate -
+    tau_voigt) gathered at the voxels next to an interface.  Same iterates as the strain-state pipeline up to rounding,
+    run-to-run reproducible (no atomics), periodic wrap of the correction in all three directions."""
+    E = np.array([1.0, -0.2, 0.1, 0.3, 0, 0.5])
+    res = {}
+    for flag in (0, 2, 2):
+        s = make_gpu_solver(grid, mixing="laminate", tol=1e-8)
+        s._check(s._lib.fg_set_option_i(s._h, b"u_loop", flag))
+        assert s.run(E) is False
+        res.setdefault(flag, []).append((s.iterations, np.array(s.residuals), s.get_field("epsilon"),
+                                         s.get_field("sigma"), s.mean_stress()))
+        s.close()
+    a, b, b2 = res[0][0], res[2][0], res[2][1]
+    assert a[0] == b[0]
+    assert np.abs(a[1] - b[1]).max() < 1e-12
+    assert rel_err(b[2], a[2]) < 1e-11 and rel_err(b[3], a[3]) < 1e-11 and rel_err(b[4], a[4]) < 1e-12
+    assert np.array_equal(b[1], b2[1]) and np.array_equal(b[2], b2[2])      # reproducible
+    o = make_oracle(grid, mixing="laminate", tol=1e-8)
+    assert o.run(E) is False
+    assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9 and rel_err(b[3], o.get_field("sigma")) < 1e-9
 
 
 @pytest.mark.parametrize("rows", [8, 16])
