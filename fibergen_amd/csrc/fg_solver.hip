@@ -1180,7 +1180,7 @@ bool Solver::run_cg_scalar(const double* E0) {
 
 bool Solver::run_cg(const double* E0, const double* S0) {
   if (nranks_ != 1) throw std::runtime_error("method=cg is not available on slab-decomposed solvers");
-  if (opt_.u_loop >= 2 && opt_.mixing == kMixVoigt && u_loop_eligible() && norm2(S0, 6) == 0.0) {
+  if (opt_.u_loop >= 2 && u_loop_eligible() && norm2(S0, 6) == 0.0) {
     FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * (size_t)g_.n * sizeof(double), stream_));
     return run_cg_u(E0);
   }

@@ -532,17 +532,18 @@ def test_three_phase_voigt_all_loop_variants(grid):
         s.close()
 
 
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
 @pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (8, 14, 128)])
-def test_cg_in_displacement_space(grid):
+def test_cg_in_displacement_space(grid, mixing):
     """method=cg with u_loop=2 (default) carries the CG vectors as displacements; u_loop=0 keeps the strain vectors of
     runCGElasticity.  Same iteration counts and residual histories (to rounding) as each other and as the oracle;
     accessors called from the convergence callback see the current iterate."""
     E = np.array([1.0, 0, 0, 0, 0, 0.5])
-    o = make_oracle(grid, tol=1e-10)
+    o = make_oracle(grid, mixing=mixing, tol=1e-10)
     assert o.run_cg(E) is False
     out = {}
     for flag in (0, 2):
-        s = make_gpu_solver(grid, tol=1e-10, method="cg", u_loop=flag)
+        s = make_gpu_solver(grid, mixing=mixing, tol=1e-10, method="cg", u_loop=flag)
         seen = []
 
         def cb():
