@@ -88,40 +88,6 @@ __global__ __launch_bounds__(K::THREADS) void k_xfused(XFusedArgs a) {
   DevicePhasesX<K, 0>::run(r, blockIdx.x, threadIdx.x, lds, a);
 }
 
-// Persistent form: a workgroup takes tiles b, b + gridDim, ... (at any time the chip works on one contiguous
-// window of columns -- DRAM page locality), and components 0 and 1 of the next tile are loaded into their
-// registers as soon as the current tile has stored them (see XFusedKernel::phase, PERSIST).
-template <class K, int PH>
-struct DevicePhasesXP {
-  __device__ __forceinline__ static void run(typename K::Regs& r, int block, int tid, double* lds, const XFusedArgs& a) {
-    K::template phase<PH, true>(r, block, tid, lds, a);
-    if constexpr (PH + 1 < K::NPHASE) {
-      if constexpr (K::barrier_after(PH)) __syncthreads();
-      DevicePhasesXP<K, PH + 1>::run(r, block, tid, lds, a);
-    }
-  }
-};
-
-// UNIT consecutive tiles form one unit of the round-robin (UNIT = 2 for half-segment tiles, C = 4: the two halves of
-// the same 128-byte segments are processed back to back by one workgroup, the second half is a cache hit).
-template <class K, int UNIT>
-__global__ __launch_bounds__(K::THREADS) void k_xfused_persistent(XFusedArgs a, int ntiles) {
-  extern __shared__ __align__(16) double lds[];
-  typename K::Regs r;
-  r.have = 0;
-  const int nunits = (ntiles + UNIT - 1) / UNIT;
-  const int mine = (int)blockIdx.x < nunits ? (nunits - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  auto tile_of = [&](int i) { return ((int)blockIdx.x + (i / UNIT) * (int)gridDim.x) * UNIT + i % UNIT; };
-  for (int i = 0; i < mine * UNIT; ++i) {
-    const int tile = tile_of(i);
-    if (tile >= ntiles) break;   // only the very last unit can be short
-    const int nxt = i + 1 < mine * UNIT ? tile_of(i + 1) : -1;
-    r.next_block = nxt < ntiles ? nxt : -1;
-    DevicePhasesXP<K, 0>::run(r, tile, threadIdx.x, lds, a);
-    r.have = r.next_block >= 0 ? 3 : 0;
-  }
-}
-
 __global__ void k_dft_strided_generic(const cplx* src, cplx* dst, long ls, long os, int ncols, int nouter, int n,
                                       int dir, double scale, const cplx* w) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +168,7 @@ void xfused_nc(XFusedArgs a, int nouter, hipStream_t s);
 
 template <int N>
 void xfused_n(XFusedArgs a, int nouter, int ncomp, hipStream_t s) {
-  // (half-segment tiles, C = 4, were measured for N = 512 in the persistent form too: 3.03 ms against 2.44 ms)
+  // (half-segment tiles, C = 4, were measured for N = 512: 2.96 ms against 2.5 ms)
   if (ncomp == 1) xfused_nc<N, XTileCols<N>::value, 1>(a, nouter, s);
   else xfused_nc<N, XTileCols<N>::value, 3>(a, nouter, s);
 }
@@ -219,26 +185,8 @@ void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
   }
   a.tiles_per_outer = (a.ncols + C - 1) / C;
   const long nblocks = (long)a.tiles_per_outer * nouter;
-  static int resident = 0;  // workgroups that fit the device at once
-  static const int persist_env = getenv("FG_XFUSED_PERSIST") ? atoi(getenv("FG_XFUSED_PERSIST")) : 1;
-  if (!resident) {
-    constexpr int UNIT = C >= 8 ? 1 : 8 / C;
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused_persistent<K, UNIT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0, cus = 0, per_cu = 0;
-    FG_HIP_CHECK(hipGetDevice(&dev));
-    FG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    FG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_xfused_persistent<K, UNIT>, K::THREADS, lds));
-    resident = cus * (per_cu < 1 ? 1 : per_cu);
-  }
-  // measured: 256^3 0.313 -> 0.284 ms; at N = 512 the extra live state pushes the 512-thread kernel further into
-  // scratch (160 -> 336 B) and it loses (2.53 -> 3.08 ms), so the persistent form is used for N <= 256 only
-  if (persist_env && NC == 3 && (N <= 256 || C < 8 || persist_env == 2) && nblocks > 2L * resident) {
-    constexpr int UNIT = C >= 8 ? 1 : 8 / C;
-    hipLaunchKernelGGL((k_xfused_persistent<K, UNIT>), dim3((unsigned)resident), dim3(K::THREADS), lds, s, a, (int)nblocks);
-  } else {
-    hipLaunchKernelGGL(k_xfused<K>, dim3((unsigned)nblocks), dim3(K::THREADS), lds, s, a);
-  }
+  // (persistent / looping forms of this kernel lose to fresh workgroups: DESIGN 3.4, 3.6)
+  hipLaunchKernelGGL(k_xfused<K>, dim3((unsigned)nblocks), dim3(K::THREADS), lds, s, a);
   FG_HIP_CHECK(hipGetLastError());
 }
 

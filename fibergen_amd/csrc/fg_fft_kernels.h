@@ -273,9 +273,11 @@ struct XFusedKernel {
   // can then be dropped (the next scatter goes to the other buffer), 12 instead of 24 per tile
   static constexpr bool PINGPONG = num_passes(N) == 3;
   static constexpr int BUF_DOUBLES = 2 * PN * C;
-  // N = 512: the pass twiddles sit in LDS behind the exchange buffers (14 KB, the tile then uses 158 of 160 KB).
-  // A twiddle read through the vector memory path shares its in-order counter with the tile's loads and
-  // stores, so every twiddled pass waited for the stores of the previous component to be acknowledged.
+  // The pass twiddles sit in LDS behind the exchange buffers (N = 512: 14 KB, the tile then uses 158 of 160 KB).
+  // A twiddle read through the vector memory path shares its in-order counter (vmcnt) with the tile's loads and
+  // stores, so every twiddled pass waited for the stores of the previous component to be acknowledged
+  // (N = 512: 2.55 -> 1.85 ms; for the same reason a workgroup handles ONE tile: in a loop over tiles the next
+  // tile's loads would queue behind the stores of the previous one).
   static constexpr bool TW_LDS = N >= 64 && NC == 3;
   static constexpr int TW_OFF = (PINGPONG ? 2 : 1) * BUF_DOUBLES;
   static constexpr int LDS_DOUBLES = TW_OFF + (TW_LDS ? 2 * tw_total(N) : 0);
@@ -285,11 +287,6 @@ struct XFusedKernel {
     long base;
     int jt, t, jj, kk;
     bool valid;
-    // persistent variant only: the tile after this one (its components 0 and 1 are loaded into v[0], v[1] as soon
-    // as the current tile has stored them, so two thirds of the next tile's loads overlap the inverse transforms)
-    long base_n;
-    int jj_n, kk_n, next_block, have;
-    bool valid_n;
   };
   FG_HD static void locate(int block, int t, const XFusedArgs& a, long* base, int* jj, int* kk, bool* valid) {
     const int o = block / a.tiles_per_outer;
@@ -309,14 +306,14 @@ struct XFusedKernel {
   static constexpr int RL = pass_radix(N, num_passes(N) - 1);
   static constexpr int inv_slot(int q) { return q / RL + (q % RL) * (8 / RL); }
 
-  template <int PH, bool PERSIST = false>
+  template <int PH>
   FG_HD static void phase(Regs& r, int block, int tid, double* lds, const XFusedArgs& a) {
     const LdsMap L = {C, 1, PN * C};
     constexpr int TR = PH / NPL;   // transform number: 0..NC-1 forward comp TR, NC..2NC-1 inverse comp TR-NC
     constexpr int LP = PH % NPL;   // phase inside the transform
     constexpr int comp = TR % NC;
     const cplx* tw = TW_LDS ? reinterpret_cast<const cplx*>(lds + TW_OFF) : a.tw;
-    if (TW_LDS && PH == 0 && !(PERSIST && r.have)) {
+    if (TW_LDS && PH == 0) {
       cplx* dst = reinterpret_cast<cplx*>(lds + TW_OFF);
       for (int i = tid; i < tw_total(N); i += THREADS) dst[i] = a.tw[i];   // fenced by the barrier after phase 0
     }
@@ -324,16 +321,9 @@ struct XFusedKernel {
     if (PH == 0) {
       r.t = tid % C;
       r.jt = tid / C;
-      int have = 0;
-      if (PERSIST && r.have) {  // position and components 0, 1 were fetched while the previous tile finished
-        r.base = r.base_n; r.jj = r.jj_n; r.kk = r.kk_n; r.valid = r.valid_n;
-        have = r.have;
-      } else {
-        locate(block, r.t, a, &r.base, &r.jj, &r.kk, &r.valid);
-      }
+      locate(block, r.t, a, &r.base, &r.jj, &r.kk, &r.valid);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        if (PERSIST && ((have >> c) & 1)) continue;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           r.v[c][q] = r.valid ? cload_stream(&a.data[c * a.comp_stride + r.base + (long)Line<N>::first_index(r.jt, q) * a.ls], a.nt)
@@ -401,14 +391,6 @@ struct XFusedKernel {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           cstore_stream(&a.data[comp * a.comp_stride + r.base + (long)Line<N>::last_index(r.jt, q) * a.ls], r.v[comp][q], a.nt);
-      }
-      if (PERSIST && LP == NPL - 1 && comp < 2 && comp + 1 < NC && r.next_block >= 0) {
-        // v[comp] is free now: fetch the same component of the next tile into it
-        if (comp == 0) locate(r.next_block, r.t, a, &r.base_n, &r.jj_n, &r.kk_n, &r.valid_n);
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          r.v[comp][q] = r.valid_n ? a.data[comp * a.comp_stride + r.base_n + (long)Line<N>::first_index(r.jt, q) * a.ls]
-                                   : cmake(0.0, 0.0);
       }
     }
   }
