@@ -39,8 +39,9 @@ struct SolverOptions {
                                 // 2 = viscosity (dual Stokes scheme: DeltaOperatorStaggered F:20422-20460, 6 components)
   int gamma_scheme = 0;         // 0 = staggered (GammaOperatorStaggered F:20288), 1 = collocated (GammaOperatorCollocated F:20302)
   int method = 0;               // 0 = basic scheme (runBasic F:21716), 1 = conjugate gradients (runCGElasticity F:23153)
-  int u_loop = 2;               // Voigt, pure strain BC: displacement-based pass (0 off, 1 exact operation order,
-                                // 2 precomputed effective moduli + FMA, agrees with 1 to rounding)
+  int u_loop = 2;               // pure strain BC: displacement-based pass (0 off, 1 exact operation order: bit-identical
+                                // to 0, 2 precomputed effective moduli + FMA, agrees with 1 to rounding; with laminate
+                                // mixing 2 = the Voigt sweep + divergence of (tau_laminate - tau_voigt) at the interface)
   int fuse_stress_div = 1;      // Voigt mixing: polarisation + divergence in one sweep
   int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
   int u_tile = 8;               // fast displacement sweep (u_loop = 2) as the LDS-tiled marching kernel where the grid allows:

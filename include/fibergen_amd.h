@@ -77,7 +77,9 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * fluidity constant of the XML, "epsilon" holds the fluid stress, "sigma" the shear rate; Voigt mixing, basic scheme),
  * gamma_scheme (0 = staggered, 1 = collocated: GammaOperatorCollocated F:20302-20310, Fourier-space 6x6 Gamma0),
  * method (0 = basic scheme, runBasic F:21716-21805; 1 = conjugate gradients, runCGElasticity
- * F:23153-23247, the reference's default), and the implementation switches u_loop,
+ * F:23153-23247, the reference's default), and the implementation switches u_loop (2 = default: the loop carries the
+ * displacement, fast kernels; 1 = the same with the reference's operation order, iterates bit-identical to 0; 0 = the
+ * strain field is the state, one kernel per reference routine where fuse_* are 0 too),
  * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (rows per workgroup of
  * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled), fuse_z (untiled sweep with the z transform attached). */
 int fg_set_option_d(fg_solver* s, const char* key, double value);
