@@ -295,6 +295,21 @@ __global__ __launch_bounds__(kBlock) void k_u_fast_z(Grid g, double beta, double
 // its z neighbour from the adjacent wave's entry in LDS, periodically).  ZS == 0: general nz, lanes 0 and 63 are halo.
 // Per plane and thread: 5 16-byte global loads (u x3, A, B), 6 LDS writes + 6 LDS reads, 2 barriers.
 // f0 of plane q is complete at step q; f1, f2 need tau5, tau4 of plane q+1 and are finished one step later.
+// tools/utile_probe.hip compiles this file with -DFG_PROBE_K1: cycle stamps (s_memtime) of one wave per sampled
+// workgroup inside one marching step of the tiled sweep.  Empty in the library.
+#ifdef FG_PROBE_K1
+constexpr int kK1ProbeBlocks = 64, kK1ProbeSlots = 16;
+__device__ unsigned long long g_k1_probe[kK1ProbeBlocks][kK1ProbeSlots];
+#define FG_K1_MARK(slot)                                                                                   \
+  do {                                                                                                     \
+    if ((st == FG_PROBE_K1_STEP || (slot) == 0 || (slot) >= 8) && threadIdx.x == FG_PROBE_K1_THREAD &&     \
+        blockIdx.x % FG_PROBE_K1_STRIDE == 0 && blockIdx.x / FG_PROBE_K1_STRIDE < kK1ProbeBlocks)           \
+      g_k1_probe[blockIdx.x / FG_PROBE_K1_STRIDE][(slot)] = __builtin_readcyclecounter();                  \
+  } while (0)
+#else
+#define FG_K1_MARK(slot) do { } while (0)
+#endif
+
 template <int TYR, int ZS>
 __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, double beta, double gamma, FieldPtrs<3> u,
                                                                       FieldPtrs<2> mod, FieldPtrs<3> fo, Vec6 E, double* partial,
@@ -370,9 +385,14 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   double2 dx1 = make_double2(0.0, 0.0), dx2 = dx1;          // U1, U2 minus their previous plane (warm-up: unused)
   double2 t0m = dx1, t5m = dx1, t4m = dx1, part1 = dx1, part2 = dx1;
   double acc[6] = {0, 0, 0, 0, 0, 0};
+  {
+    const int st = -100;
+    FG_K1_MARK(0);   // workgroup start (after the first loads were issued)
+  }
 
   for (int st = -1; st <= nsteps; ++st) {
     const int q = x0 + st;                                   // plane of this step
+    FG_K1_MARK(1);
     // u two planes ahead (consumed next step); the moduli of this plane are first needed after the LDS exchange
     const long o2 = plane(q + 2), oq = plane(q);
 #pragma unroll
@@ -381,7 +401,9 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
     // ---- y neighbours of u through LDS
 #pragma unroll
     for (int c = 0; c < 3; ++c) Ub[c][r][li] = uc[c];
+    FG_K1_MARK(2);
     __syncthreads();
+    FG_K1_MARK(3);
     const double2 U0yb = Ub[0][rm][li], U1yf = Ub[1][rp][li], U2yb = Ub[2][rm][li];
     double U0zb = prev_y(uc[0].y), U1zb = prev_y(uc[1].y), U2zf = next_x(uc[2].x);
     if (FULLROW) {   // wave edges: the neighbour pair lives in the adjacent wave of the same row
@@ -420,6 +442,7 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
       acc[0] += e0.x * e0.x + e0.y * e0.y; acc[1] += e1.x * e1.x + e1.y * e1.y; acc[2] += e2.x * e2.x + e2.y * e2.y;
       acc[3] += e3.x * e3.x + e3.y * e3.y; acc[4] += e4.x * e4.x + e4.y * e4.y; acc[5] += e5.x * e5.x + e5.y * e5.y;
     }
+    FG_K1_MARK(4);
     // ---- y neighbours of tau through LDS
     Tb[0][r][li] = t1;
     Tb[1][r][li] = t5;
@@ -431,7 +454,9 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
         edge[2][r][zs] = t4.x;
       }
     }
+    FG_K1_MARK(5);
     __syncthreads();
+    FG_K1_MARK(6);
     const double2 t1yb = Tb[0][rm][li], t5yf = Tb[1][rp][li], t3yf = Tb[2][rp][li];
     double t2zb = prev_y(t2.y), t3zf = next_x(t3.x), t4zf = next_x(t4.x);
     if (FULLROW) {
@@ -465,6 +490,11 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
     dx2.x = un[2].x - uc[2].x; dx2.y = un[2].y - uc[2].y;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { uc[c] = un[c]; un[c] = u2[c]; }
+    FG_K1_MARK(7);
+  }
+  {
+    const int st = -100;
+    FG_K1_MARK(8);   // end of the march
   }
   // ---- sums of squares: fixed-order reduction over the workgroup
 #pragma unroll
