@@ -386,7 +386,7 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   double2 t0m = dx1, t5m = dx1, t4m = dx1, part1 = dx1, part2 = dx1;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   {
-    const int st = -100;
+    [[maybe_unused]] const int st = -100;
     FG_K1_MARK(0);   // workgroup start (after the first loads were issued)
   }
 
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
     FG_K1_MARK(7);
   }
   {
-    const int st = -100;
+    [[maybe_unused]] const int st = -100;
     FG_K1_MARK(8);   // end of the march
   }
   // ---- sums of squares: fixed-order reduction over the workgroup
