@@ -110,6 +110,14 @@ void launch_gamma_collocated(const Grid& g, const FieldPtrs<6>& th, const XiTabl
 void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps, const Vec6& E, const Vec6& R,
                      bool add_R, double* partial, double* sumsq6, const XHalo& h, hipStream_t s);
 // viscosity: eta = (E - coef tau_sum / nvox) + sym grad u + coef tau, sums of squares (tau_sum on the device)
+// viscosity mode without a stored polarisation: divergence of the polarisation with its six sums (<tau>), and the
+// Delta-operator tail re-evaluating the polarisation from the strain the pass started from
+void launch_stress_div_sum_voigt(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
+                                const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& f, double* partial, double* sum6,
+                                hipStream_t s);
+void launch_eps_delta_recompute(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps_old, const StressParams& sp,
+                                const FieldPtrs<kMaxPhases>& phi, const double* tau_sum, double nvox, const Vec6& E,
+                                double coef, const FieldPtrs<6>& eps, double* partial, double* sumsq6, hipStream_t s);
 void launch_eps_delta(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& tau, const double* tau_sum, double nvox,
                       const Vec6& E, double coef, const FieldPtrs<6>& eps, double* partial, double* sumsq6, hipStream_t s);
 void launch_transpose_A(const double* src, double* dst, int nxl, int ny, int nyl, int nzc, bool to_blocks, hipStream_t s);

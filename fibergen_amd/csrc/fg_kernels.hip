@@ -149,9 +149,12 @@ struct VoxelIn {
   double2 f[NPH];
 };
 
-template <int NPH>
+template <int NPH, bool SUM>
 __global__ __launch_bounds__(kBlock) void k_stress_div_voigt(Grid g, StressParams sp, FieldPtrs<6> eps,
-                                                             FieldPtrs<kMaxPhases> phi, FieldPtrs<3> fo, Sweep ry) {
+                                                             FieldPtrs<kMaxPhases> phi, FieldPtrs<3> fo, double* partial,
+                                                             Sweep ry) {
+  __shared__ double smem[SUM ? 4 * 6 : 1];
+  double acc[6] = {0, 0, 0, 0, 0, 0};   // SUM: sums of the polarisation components (viscosity mode needs <tau>)
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
   const BlockRun run = block_run((npairs + kBlock - 1) / kBlock);
@@ -258,6 +261,17 @@ __global__ __launch_bounds__(kBlock) void k_stress_div_voigt(Grid g, StressParam
     st2(fo.p[0], p.off, f0);
     st2(fo.p[1], p.off, f1);
     st2(fo.p[2], p.off, f2);
+    if (SUM) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] += t[c].x + (second ? t[c].y : 0.0);
+    }
+  }
+  if (SUM) {
+    block_reduce<6>(acc, smem, OpSum());
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+    }
   }
 }
 
@@ -954,9 +968,12 @@ __global__ __launch_bounds__(kBlock) void k_delta_div(Grid g, const unsigned* af
 // DeltaOperatorStaggered  F:20438-20452 after the Green operator:  eta = (E - coef <tau>) + sym grad u + coef tau  with
 // coef = 2 alpha / (4 mu0), the mean <tau> = tau_sum / N read from device memory (no host round trip), and the sums of
 // squares of eta.  Same operation order as k_eps_norm followed by xpay.
+// NPH > 0: no stored tau; `tau` holds the strain the pass started from and the polarisation is re-evaluated from it
+// (a point-wise function of that strain: same arithmetic as k_stress, so the same values).
+template <int NPH>
 __global__ __launch_bounds__(kBlock) void k_eps_delta(Grid g, FieldPtrs<3> u, FieldPtrs<6> tau, const double* tau_sum,
                                                       double nvox, Vec6 E, double coef, FieldPtrs<6> eps, double* partial,
-                                                      Sweep ry) {
+                                                      StressParams sp, FieldPtrs<kMaxPhases> phi, Sweep ry) {
   __shared__ double smem[4 * 6];
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const long npairs = (long)g.nx * g.ny * g.nzc;
@@ -997,11 +1014,34 @@ __global__ __launch_bounds__(kBlock) void k_eps_delta(Grid g, FieldPtrs<3> u, Fi
     e[0].y = adj[0] + (u0xf.y - u0.y) * hx;
     e[1].y = adj[1] + (u1yf.y - u1.y) * hy;
     e[2].y = adj[2] + (u2zf2 - u2.y) * hz;
+    double2 tt[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tt[c] = ld2(tau.p[c], p.off);
+    if constexpr (NPH > 0) {
+      double2 fc[NPH > 0 ? NPH : 1];
+      double ph[NPH > 0 ? NPH : 1];
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) fc[q] = q < sp.pt.n ? ld2(phi.p[q], p.off) : make_double2(0.0, 0.0);
+      double2 o[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) o[c] = tt[c];
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) ph[q] = fc[q].x;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tt[c].x = voigt_tau_normal<NPH>(o[c].x, o[0].x, o[1].x, o[2].x, ph, sp);
+#pragma unroll
+      for (int c = 3; c < 6; ++c) tt[c].x = voigt_tau_shear<NPH>(o[c].x, ph, sp);
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) ph[q] = fc[q].y;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tt[c].y = voigt_tau_normal<NPH>(o[c].y, o[0].y, o[1].y, o[2].y, ph, sp);
+#pragma unroll
+      for (int c = 3; c < 6; ++c) tt[c].y = voigt_tau_shear<NPH>(o[c].y, ph, sp);
+    }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const double2 t = ld2(tau.p[c], p.off);
-      e[c].x = e[c].x + coef * t.x;
-      e[c].y = second ? e[c].y + coef * t.y : 0.0;
+      e[c].x = e[c].x + coef * tt[c].x;
+      e[c].y = second ? e[c].y + coef * tt[c].y : 0.0;
       acc[c] += e[c].x * e[c].x + e[c].y * e[c].y;
       st2(eps.p[c], p.off, e[c]);
     }
@@ -1271,11 +1311,27 @@ void launch_stress_div_voigt(const Grid& g, const StressParams& sp, const FieldP
                             const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& f, hipStream_t s) {
   const long npairs = (long)g.nx * g.ny * g.nzc;
   if (sp.pt.n <= 2)
-    hipLaunchKernelGGL((k_stress_div_voigt<2>), dim3(sweep_blocks(npairs)), dim3(kBlock), 0, s, g, sp, eps, phi, f,
+    hipLaunchKernelGGL((k_stress_div_voigt<2, false>), dim3(sweep_blocks(npairs)), dim3(kBlock), 0, s, g, sp, eps, phi, f,
+                       (double*)nullptr, chunk_rows(g));
+  else
+    hipLaunchKernelGGL((k_stress_div_voigt<kMaxPhases, false>), dim3(sweep_blocks(npairs)), dim3(kBlock), 0, s, g, sp, eps,
+                       phi, f, (double*)nullptr, chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_stress_div_sum_voigt(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
+                                const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& f, double* partial, double* sum6,
+                                hipStream_t s) {
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  const int nb = sweep_blocks(npairs);
+  if (sp.pt.n <= 2)
+    hipLaunchKernelGGL((k_stress_div_voigt<2, true>), dim3(nb), dim3(kBlock), 0, s, g, sp, eps, phi, f, partial,
                        chunk_rows(g));
   else
-    hipLaunchKernelGGL((k_stress_div_voigt<kMaxPhases>), dim3(sweep_blocks(npairs)), dim3(kBlock), 0, s, g, sp, eps, phi,
-                       f, chunk_rows(g));
+    hipLaunchKernelGGL((k_stress_div_voigt<kMaxPhases, true>), dim3(nb), dim3(kBlock), 0, s, g, sp, eps, phi, f, partial,
+                       chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 6, sum6, s);
   FG_HIP_CHECK(hipGetLastError());
 }
 
@@ -1443,8 +1499,23 @@ void launch_eps_norm(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& e
 void launch_eps_delta(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& tau, const double* tau_sum, double nvox,
                       const Vec6& E, double coef, const FieldPtrs<6>& eps, double* partial, double* sumsq6, hipStream_t s) {
   const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
-  hipLaunchKernelGGL(k_eps_delta, dim3(nb), dim3(kBlock), 0, s, g, u, tau, tau_sum, nvox, E, coef, eps, partial,
-                     chunk_rows(g));
+  hipLaunchKernelGGL(k_eps_delta<0>, dim3(nb), dim3(kBlock), 0, s, g, u, tau, tau_sum, nvox, E, coef, eps, partial,
+                     StressParams(), FieldPtrs<kMaxPhases>(), chunk_rows(g));
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 6, sumsq6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_eps_delta_recompute(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& eps_old, const StressParams& sp,
+                                const FieldPtrs<kMaxPhases>& phi, const double* tau_sum, double nvox, const Vec6& E,
+                                double coef, const FieldPtrs<6>& eps, double* partial, double* sumsq6, hipStream_t s) {
+  const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
+  if (sp.pt.n <= 2)
+    hipLaunchKernelGGL(k_eps_delta<2>, dim3(nb), dim3(kBlock), 0, s, g, u, eps_old, tau_sum, nvox, E, coef, eps, partial, sp,
+                       phi, chunk_rows(g));
+  else
+    hipLaunchKernelGGL(k_eps_delta<kMaxPhases>, dim3(nb), dim3(kBlock), 0, s, g, u, eps_old, tau_sum, nvox, E, coef, eps,
+                       partial, sp, phi, chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());

@@ -382,13 +382,23 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     if (frobenius(BC_MQ_) >= kEps || opt_.bc_relax != 1.0)
       throw std::runtime_error("viscosity mode supports prescribed mean values only (projector = identity)");
     const double m = 1 / (4 * opt_.mu_0);
-    time_begin(0);
-    launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, nrm, ptrs6(tau_), derr_, stream_);
-    time_end(0);
-    launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);   // tau_copy->average(), stays on the device
-    time_begin(1);
-    launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
-    time_end(1);
+    const bool fused = opt_.fuse_stress_div != 0;
+    if (fused) {
+      // the polarisation is a point-wise function of the strain: it is evaluated inside the divergence sweep (with its
+      // six sums) and again in the tail sweep, and never stored
+      time_begin(0);
+      launch_stress_div_sum_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, ptrs3(fu_), partial_,
+                                  dscal_ + kSlotMean, stream_);
+      time_end(0);
+    } else {
+      time_begin(0);
+      launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, nrm, ptrs6(tau_), derr_, stream_);
+      time_end(0);
+      launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);   // tau_copy->average(), stays on the device
+      time_begin(1);
+      launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
+      time_end(1);
+    }
     const double mu_g = -1.0 / (4 * m);
     const double c12[2] = {-alpha / mu_g, -alpha / mu_g};
     fft_g0_chain(fu_, false, alpha, c12);
@@ -396,8 +406,13 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     Vec6 Ev;
     for (int c = 0; c < 6; ++c) Ev.v[c] = E6[c];
     time_begin(9);
-    launch_eps_delta(g_, ptrs3(fu_), ptrs6(tau_), dscal_ + kSlotMean, (double)nglobal_, Ev, 2 * alpha * m, ptrs6(dst), partial_,
-                     dscal_ + kSlotSumSq, stream_);
+    if (fused)
+      launch_eps_delta_recompute(g_, ptrs3(fu_), ptrs6(src), stress_params(opt_.mu_0, opt_.lambda_0, 1.0), phi,
+                                 dscal_ + kSlotMean, (double)nglobal_, Ev, 2 * alpha * m, ptrs6(dst), partial_,
+                                 dscal_ + kSlotSumSq, stream_);
+    else
+      launch_eps_delta(g_, ptrs3(fu_), ptrs6(tau_), dscal_ + kSlotMean, (double)nglobal_, Ev, 2 * alpha * m, ptrs6(dst),
+                       partial_, dscal_ + kSlotSumSq, stream_);
     time_end(9);
     if (timing_) times_.count++;
     u_valid_ = false;
