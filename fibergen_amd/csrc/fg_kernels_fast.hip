@@ -690,8 +690,173 @@ void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
 #undef FG_TILE
 }
 
+// Tiled marching form of the scalar sweep, the one-component sibling of k_u_tile: a workgroup of TYR rows (one or ZS
+// waves each, lanes = z pairs) marches along x.  x neighbours are the thread's own values of the previous / next plane,
+// y neighbours (T of rows j-1 and j+1, the conductivity of row j-1) come from one LDS exchange per plane -- two
+// images, so one barrier per step --, z neighbours from the adjacent lanes.  Rows 0 and TYR-1 and, for ZS = 0, lanes
+// 0 and 63 are halo.  T_k -> sums of squares of g_k = E + grad+ T_k and f = div-((a - 2 mu0) g_k), every T and a value
+// loaded once per tile (k_sc_sweep_fast: 8 loads per pair out of L2).
+template <int TYR, int ZS>
+__global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, double beta, const double* T, const double* a,
+                                                                       double* fo, Vec6 E, double* partial, int nty, int ntz,
+                                                                       int LX, int nt) {
+  constexpr bool FULLROW = ZS > 0;
+  constexpr int NZS = ZS ? ZS : 1;
+  constexpr int TYU = TYR - 2;
+  constexpr int TZU = FULLROW ? 64 * NZS : 62;
+  constexpr int RW = NZS * 64;
+  __shared__ double2 Tb[2][TYR][RW];
+  __shared__ double2 Cb[2][TYR][RW];
+  __shared__ double red[TYR * NZS * 3];
+
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int r = wv / NZS, zs = wv % NZS;
+  const int li = zs * 64 + l;
+  const int zprev = (zs + NZS - 1) % NZS, znext = (zs + 1) % NZS;
+  const int nzh = g.nz / 2;
+  int b = blockIdx.x;
+  {
+    const int nb = gridDim.x;
+    if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;   // one XCD takes a contiguous run of tiles
+  }
+  const int tz = b % ntz;
+  b /= ntz;
+  const int ty = b % nty;
+  const int tx = b / nty;
+  const bool surplus = tx * LX >= g.nx;
+  const int j0 = min(ty * TYU, g.ny - TYU), kp0 = min(tz * TZU, nzh - TZU), x0 = surplus ? 0 : tx * LX;
+  const int jr = j0 - 1 + r;
+  const int j = jr < 0 ? jr + g.ny : (jr >= g.ny ? jr - g.ny : jr);
+  const int kr = FULLROW ? li : kp0 - 1 + l;
+  const int kp = kr < 0 ? kr + nzh : (kr >= nzh ? kr - nzh : kr);
+  const bool own = r >= 1 && r <= TYU && jr >= ty * TYU && (FULLROW || (l >= 1 && l <= TZU && kr >= tz * TZU));
+  const long rowoff = (long)j * g.nzp + 2 * kp;
+  const int rm = r > 0 ? r - 1 : 0, rp = r + 1 < TYR ? r + 1 : TYR - 1;
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const int nsteps = surplus ? 0 : (x0 + LX <= g.nx ? LX : g.nx - x0);
+
+  auto plane = [&](int q) {
+    const int x = q < 0 ? q + g.nx : (q >= g.nx ? q - g.nx : q);
+    return (long)x * g.nyzp + rowoff;
+  };
+  auto store_f = [&](long off, double2 v) {
+    if (nt) {
+      typedef double fg_v2d __attribute__((ext_vector_type(2)));
+      fg_v2d t;
+      t.x = v.x;
+      t.y = v.y;
+      __builtin_nontemporal_store(t, reinterpret_cast<fg_v2d*>(fo + off));
+    } else {
+      st2(fo, off, v);
+    }
+  };
+
+  // plane x0 - 1 gives the x flux entering plane x0
+  double2 Tc = ld2(T, plane(x0 - 1)), Tn = ld2(T, plane(x0)), T2 = ld2(T, plane(x0 + 1));
+  double2 ac = ld2(a, plane(x0 - 1)), an = ld2(a, plane(x0));
+  double2 q0m;   // x flux of the previous plane
+  q0m.x = (ac.x + beta) * (E.v[0] + (Tn.x - Tc.x) * hx);
+  q0m.y = (ac.y + beta) * (E.v[0] + (Tn.y - Tc.y) * hx);
+  Tc = Tn; Tn = T2; ac = an;
+  double acc[3] = {0, 0, 0};
+
+  for (int st = 0; st < nsteps; ++st) {
+    const int q = x0 + st;
+    const long oq = plane(q);
+    T2 = ld2(T, plane(q + 2));   // two planes ahead of T, one of a (the last step's are unused but in range)
+    an = ld2(a, plane(q + 1));
+    const double2 cc = make_double2(ac.x + beta, ac.y + beta);
+    const int img = st & 1;
+    Tb[img][r][li] = Tc;
+    Cb[img][r][li] = cc;
+    __syncthreads();
+    const double2 Tyf = Tb[img][rp][li], Tyb = Tb[img][rm][li], cyb = Cb[img][rm][li];
+    double Tzb = dpp_move<0x138>(Tc.y), czb = dpp_move<0x138>(cc.y), Tzf = dpp_move<0x130>(Tc.x);
+    if (FULLROW) {
+      if (l == 0) {
+        Tzb = Tb[img][r][zprev * 64 + 63].y;
+        czb = Cb[img][r][zprev * 64 + 63].y;
+      }
+      if (l == 63) Tzf = Tb[img][r][znext * 64].x;
+    }
+    // gradient at the two voxels (forward differences) and the backward-neighbour fluxes
+    const double g0x = E.v[0] + (Tn.x - Tc.x) * hx, g0y = E.v[0] + (Tn.y - Tc.y) * hx;
+    const double g1x = E.v[1] + (Tyf.x - Tc.x) * hy, g1y = E.v[1] + (Tyf.y - Tc.y) * hy;
+    const double g2x = E.v[2] + (Tc.y - Tc.x) * hz, g2y = E.v[2] + (Tzf - Tc.y) * hz;
+    const double q0x = cc.x * g0x, q0y = cc.y * g0y;
+    const double q1bx = cyb.x * (E.v[1] + (Tc.x - Tyb.x) * hy), q1by = cyb.y * (E.v[1] + (Tc.y - Tyb.y) * hy);
+    const double q2bx = czb * (E.v[2] + (Tc.x - Tzb) * hz);
+    double2 f;
+    f.x = (q0x - q0m.x) * hx + (cc.x * g1x - q1bx) * hy + (cc.x * g2x - q2bx) * hz;
+    f.y = (q0y - q0m.y) * hx + (cc.y * g1y - q1by) * hy + (cc.y * g2y - cc.x * g2x) * hz;
+    if (own) {
+      acc[0] += g0x * g0x + g0y * g0y;
+      acc[1] += g1x * g1x + g1y * g1y;
+      acc[2] += g2x * g2x + g2y * g2y;
+      store_f(oq, f);
+    }
+    q0m.x = q0x; q0m.y = q0y;
+    Tc = Tn; Tn = T2; ac = an;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double v = acc[c];
+    v += dpp_move<0x128>(v);
+    v += dpp_move<0x124>(v);
+    v += dpp_move<0x122>(v);
+    v += dpp_move<0x121>(v);
+    acc[c] = (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+  }
+  if (l == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) red[wv * 3 + c] = acc[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = 0.0;
+    if (threadIdx.x < 3)
+      for (int w = 0; w < TYR * NZS; ++w) v += red[w * 3 + threadIdx.x];
+    partial[(long)blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+template <int TYR, int ZS>
+void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E, double* partial,
+                      double* sumsq6, hipStream_t s) {
+  constexpr int NZS = ZS ? ZS : 1;
+  constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
+  const int nzh = g.nz / 2;
+  const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    FG_HIP_CHECK(hipGetDevice(&dev));
+    FG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  int LX = 32;
+  if ((long)nty * ntz * ((g.nx + 31) / 32) < 2L * cus) LX = 16;
+  if (LX > g.nx) LX = g.nx;
+  const int ntx = (g.nx + LX - 1) / LX;
+  int nb = nty * ntz * ntx;
+  if (nb >= 8) nb = ((nb + 7) / 8) * 8;
+  const int nt = (double)g.n * sizeof(double) > 128.0 * 1024 * 1024 ? 1 : 0;
+  hipLaunchKernelGGL((k_sc_tile<TYR, ZS>), dim3(nb), dim3(TYR * NZS * 64), 0, s, g, -2 * mu_0, T, a, f, E, partial, nty, ntz,
+                     LX, nt);
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 6, sumsq6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
 void launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
                           double* partial, double* sumsq6, hipStream_t s) {
+  static const int tile_env = getenv("FG_SC_TILE") ? atoi(getenv("FG_SC_TILE")) : 1;
+  if (tile_env && u_tile_supported(g)) {
+    const int nzh = g.nz / 2;
+    if (nzh == 64) launch_sc_tile_t<8, 1>(g, mu_0, T, a, f, E, partial, sumsq6, s);
+    else if (nzh == 128) launch_sc_tile_t<6, 2>(g, mu_0, T, a, f, E, partial, sumsq6, s);   // 48 KB of LDS images
+    else launch_sc_tile_t<8, 0>(g, mu_0, T, a, f, E, partial, sumsq6, s);
+    return;
+  }
   const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
   hipLaunchKernelGGL(k_sc_sweep_fast, dim3(nb), dim3(kBlock), 0, s, g, -2 * mu_0, T, a, f, E, partial, chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());

@@ -58,6 +58,31 @@ def test_scalar_run_matches_oracle(grid, dims, u_loop):
     s.close()
 
 
+@pytest.mark.parametrize("grid,dims", [((16, 16, 128), (1, 1, 1)), ((8, 14, 124), (1.0, 2.0, 0.5)), ((6, 20, 130), (1, 1, 1)),
+                                       ((40, 30, 128), (1, 1, 1)), ((12, 16, 256), (1, 1, 1)), ((5, 14, 256), (2, 1, 1))])
+def test_tiled_scalar_sweep(grid, dims):
+    """u_loop = 2 on grids the LDS-tiled marching sweep k_sc_tile takes (nz/2 >= 62: halo lanes; nz/2 = 64 / 128: whole
+    rows of one / two waves; overlapping last tiles, periodic wrap in all directions): same iterates as the exact-order
+    sweep (u_loop = 1) and as the oracle."""
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 12.0], [1 - phi1, phi1]
+    E = np.array([1.0, -0.5, 0.25])
+    res = {}
+    for flag in (1, 2):
+        s = _solver(grid, mus, phis, dims, tol=1e-9, u_loop=flag)
+        assert s.run(E) is False
+        res[flag] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress(), s.get_field("u"))
+        s.close()
+    a, b = res[1], res[2]
+    assert a[0] == b[0]
+    assert np.abs(a[1] - b[1]).max() < 1e-12
+    assert rel_err(b[2], a[2]) < 1e-11 and rel_err(b[3], a[3]) < 1e-12
+    assert np.abs(b[4] - a[4]).max() < 1e-11 * max(1.0, np.abs(a[4]).max())
+    o = _oracle(grid, mus, phis, dims, tol=1e-9)
+    assert o.run(E) is False
+    assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-10
+
+
 def test_scalar_effective_conductivity_of_layers_is_exact():
     """series / parallel means (see tests/test_oracle_pins.py) from the HIP path"""
     shape, mus, fr = (20, 4, 6), [1.0, 5.0, 0.5], [0.2, 0.3, 0.5]
