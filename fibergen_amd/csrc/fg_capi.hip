@@ -150,6 +150,7 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
     else if (k == "mode") {
       if (value < 0 || value > 2) throw std::runtime_error("mode must be 0 (elasticity), 1 (heat / porous) or 2 (viscosity)");
       o.mode = (int)value;
+      v.invalidate_moduli();   // the precomputed effective moduli depend on the mode's phase table
     }
     else if (k == "gamma_scheme") {
       if (value != 0 && value != 1) throw std::runtime_error("gamma_scheme must be 0 (staggered) or 1 (collocated)");

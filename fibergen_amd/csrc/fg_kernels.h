@@ -74,6 +74,10 @@ void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
 // the z-pass tables of the FFT plan (Fft3::z_twiddles, Fft3::z_roots)
 // tiled variant (every strain / polarisation value computed once; y neighbours through LDS, x by marching)
 bool u_tile_supported(const Grid& g);
+// the polarisation + divergence half of the tiled sweep for a stored strain field (same grids as u_tile_supported):
+// f = div((C - C0) : eps) with the effective moduli of k_effective_moduli, sum6 = sums of the polarisation components
+void launch_eps_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<6>& eps, const FieldPtrs<2>& mod,
+                     const FieldPtrs<3>& f, double* partial, double* sum6, hipStream_t s);
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s);
 bool u_fast_z_supported(const Grid& g);

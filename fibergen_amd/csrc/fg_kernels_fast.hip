@@ -518,6 +518,170 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   }
 }
 
+// The second half of k_u_tile on its own, for passes whose state is the strain field (viscosity mode; mixed boundary
+// conditions): eps -> f = div((C - C0) : eps) and the six sums of the polarisation, Voigt mixing with the precomputed
+// effective moduli.  Same tiling (rows = waves, lanes = z pairs, march along x, y neighbours of tau through LDS -- two
+// images, one barrier per plane --, z neighbours by DPP); the strain of the next plane is requested one step ahead.
+template <int TYR, int ZS>
+__global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_eps_tile(Grid g, double beta, double gamma, FieldPtrs<6> eps,
+                                                                        FieldPtrs<2> mod, FieldPtrs<3> fo, double* partial,
+                                                                        int nty, int ntz, int LX, int nt) {
+  constexpr bool FULLROW = ZS > 0;
+  constexpr int NZS = ZS ? ZS : 1;
+  constexpr int TYU = TYR - 2;
+  constexpr int TZU = FULLROW ? 64 * NZS : 62;
+  constexpr int RW = NZS * 64;
+  extern __shared__ __align__(16) double2 tile_lds[];
+  double2(*Tb)[3][TYR][RW] = reinterpret_cast<double2(*)[3][TYR][RW]>(tile_lds);   // [2][3][TYR][RW]
+  __shared__ double red[TYR * NZS * 6];
+  __shared__ double edge[2][3][TYR][NZS];
+
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int r = wv / NZS, zs = wv % NZS;
+  const int li = zs * 64 + l;
+  const int zprev = (zs + NZS - 1) % NZS, znext = (zs + 1) % NZS;
+  const int nzh = g.nz / 2;
+  int b = blockIdx.x;
+  {
+    const int nb = gridDim.x;
+    if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
+  }
+  const int tz = b % ntz;
+  b /= ntz;
+  const int ty = b % nty;
+  const int tx = b / nty;
+  const bool surplus = tx * LX >= g.nx;
+  const int j0 = min(ty * TYU, g.ny - TYU), kp0 = min(tz * TZU, nzh - TZU), x0 = surplus ? 0 : tx * LX;
+  const int jr = j0 - 1 + r;
+  const int j = jr < 0 ? jr + g.ny : (jr >= g.ny ? jr - g.ny : jr);
+  const int kr = FULLROW ? li : kp0 - 1 + l;
+  const int kp = kr < 0 ? kr + nzh : (kr >= nzh ? kr - nzh : kr);
+  const bool own = r >= 1 && r <= TYU && jr >= ty * TYU && (FULLROW || (l >= 1 && l <= TZU && kr >= tz * TZU));
+  const long rowoff = (long)j * g.nzp + 2 * kp;
+  const int rm = r > 0 ? r - 1 : 0, rp = r + 1 < TYR ? r + 1 : TYR - 1;
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const int nsteps = surplus ? -2 : (x0 + LX <= g.nx ? LX : g.nx - x0);
+
+  auto plane = [&](int q) {
+    const int x = q < 0 ? q + g.nx : (q >= g.nx ? q - g.nx : q);
+    return (long)x * g.nyzp + rowoff;
+  };
+  auto store_f = [&](double* base, long off, double2 v) {
+    if (nt) {
+      typedef double fg_v2d __attribute__((ext_vector_type(2)));
+      fg_v2d t;
+      t.x = v.x;
+      t.y = v.y;
+      __builtin_nontemporal_store(t, reinterpret_cast<fg_v2d*>(base + off));
+    } else {
+      st2(base, off, v);
+    }
+  };
+  auto prev_y = [&](double v) { return dpp_move<0x138>(v); };
+  auto next_x = [&](double v) { return dpp_move<0x130>(v); };
+
+  double2 en[6], An, Bn;   // inputs of the coming step
+  {
+    const long o = plane(x0 - 1);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) en[c] = ld2(eps.p[c], o);
+    An = ld2(mod.p[0], o);
+    Bn = ld2(mod.p[1], o);
+  }
+  double2 zero = make_double2(0.0, 0.0);
+  double2 t0m = zero, t5m = zero, t4m = zero, part1 = zero, part2 = zero;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+
+  for (int st = -1; st <= nsteps; ++st) {
+    const int q = x0 + st;
+    const long oq = plane(q);
+    double2 e0 = en[0], e1 = en[1], e2 = en[2], e3 = en[3], e4 = en[4], e5 = en[5];
+    const double2 Ac = An, Bc = Bn;
+    if (st < nsteps) {
+      const long on = plane(q + 1);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) en[c] = ld2(eps.p[c], on);
+      An = ld2(mod.p[0], on);
+      Bn = ld2(mod.p[1], on);
+    }
+    // ---- polarisation  tau = (A - 2 mu0) eps + (B - lambda0) tr(eps) I
+    const double ax = Ac.x + beta, ay = Ac.y + beta, bx = Bc.x + gamma, by = Bc.y + gamma;
+    const double trx = e0.x + e1.x + e2.x, try_ = e0.y + e1.y + e2.y;
+    double2 t0, t1, t2, t3, t4, t5;
+    t0.x = e0.x * ax + bx * trx; t0.y = e0.y * ay + by * try_;
+    t1.x = e1.x * ax + bx * trx; t1.y = e1.y * ay + by * try_;
+    t2.x = e2.x * ax + bx * trx; t2.y = e2.y * ay + by * try_;
+    t3.x = e3.x * ax; t3.y = e3.y * ay;
+    t4.x = e4.x * ax; t4.y = e4.y * ay;
+    t5.x = e5.x * ax; t5.y = e5.y * ay;
+    const bool inside = st >= 0 && st < nsteps;
+    if (own && inside) {
+      acc[0] += t0.x + t0.y; acc[1] += t1.x + t1.y; acc[2] += t2.x + t2.y;
+      acc[3] += t3.x + t3.y; acc[4] += t4.x + t4.y; acc[5] += t5.x + t5.y;
+    }
+    // ---- y neighbours of tau through LDS (image st & 1)
+    const int img = (st + 1) & 1;
+    Tb[img][0][r][li] = t1;
+    Tb[img][1][r][li] = t5;
+    Tb[img][2][r][li] = t3;
+    if (FULLROW) {
+      if (l == 63) edge[img][0][r][zs] = t2.y;
+      if (l == 0) {
+        edge[img][1][r][zs] = t3.x;
+        edge[img][2][r][zs] = t4.x;
+      }
+    }
+    __syncthreads();
+    const double2 t1yb = Tb[img][0][rm][li], t5yf = Tb[img][1][rp][li], t3yf = Tb[img][2][rp][li];
+    double t2zb = prev_y(t2.y), t3zf = next_x(t3.x), t4zf = next_x(t4.x);
+    if (FULLROW) {
+      if (l == 0) t2zb = edge[img][0][r][zprev];
+      if (l == 63) {
+        t3zf = edge[img][1][r][znext];
+        t4zf = edge[img][2][r][znext];
+      }
+    }
+    // ---- divergence: f0 of this plane, f1 / f2 of the previous one
+    if (own) {
+      if (inside) {
+        double2 f0;
+        f0.x = (t0.x - t0m.x) * hx + (t5yf.x - t5.x) * hy + (t4.y - t4.x) * hz;
+        f0.y = (t0.y - t0m.y) * hx + (t5yf.y - t5.y) * hy + (t4zf - t4.y) * hz;
+        store_f(fo.p[0], oq, f0);
+      }
+      if (st >= 1) {
+        const long op = plane(q - 1);
+        store_f(fo.p[1], op, make_double2((t5.x - t5m.x) * hx + part1.x, (t5.y - t5m.y) * hx + part1.y));
+        store_f(fo.p[2], op, make_double2((t4.x - t4m.x) * hx + part2.x, (t4.y - t4m.y) * hx + part2.y));
+      }
+    }
+    part1.x = (t1.x - t1yb.x) * hy + (t3.y - t3.x) * hz;
+    part1.y = (t1.y - t1yb.y) * hy + (t3zf - t3.y) * hz;
+    part2.x = (t3yf.x - t3.x) * hy + (t2.x - t2zb) * hz;
+    part2.y = (t3yf.y - t3.y) * hy + (t2.y - t2.x) * hz;
+    t0m = t0; t5m = t5; t4m = t4;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double a = acc[c];
+    a += dpp_move<0x128>(a);
+    a += dpp_move<0x124>(a);
+    a += dpp_move<0x122>(a);
+    a += dpp_move<0x121>(a);
+    acc[c] = (read_lane(a, 0) + read_lane(a, 16)) + (read_lane(a, 32) + read_lane(a, 48));
+  }
+  if (l == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) red[wv * 6 + c] = acc[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double a = 0.0;
+    for (int w = 0; w < TYR * NZS; ++w) a += red[w * 6 + threadIdx.x];
+    partial[(long)blockIdx.x * 6 + threadIdx.x] = a;
+  }
+}
+
 // Scalar modes (heat / porous), fast variant of k_sc_sweep (fg_kernels_scalar.hip): the per-voxel effective
 // conductivity a = sum_p phi_p mu_p is precomputed (k_effective_moduli stores it in the first moduli array with
 // 2 mu_p := mu_p), z neighbours come from the adjacent lanes.  T_k -> sums of squares of g_k = E + grad+ T_k and
@@ -862,6 +1026,48 @@ void launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const dou
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
+}
+
+template <int TYR, int ZS>
+void launch_eps_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<6>& eps, const FieldPtrs<2>& mod,
+                       const FieldPtrs<3>& f, double* partial, double* sum6, hipStream_t s) {
+  constexpr int NZS = ZS ? ZS : 1;
+  constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
+  const int nzh = g.nz / 2;
+  const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    FG_HIP_CHECK(hipGetDevice(&dev));
+    FG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  int LX = 32;
+  if ((long)nty * ntz * ((g.nx + 31) / 32) < cus) LX = 16;
+  if (LX > g.nx) LX = g.nx;
+  const int ntx = (g.nx + LX - 1) / LX;
+  int nb = nty * ntz * ntx;
+  if (nb >= 8) nb = ((nb + 7) / 8) * 8;
+  const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
+  static bool configured = false;
+  if (!configured) {
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eps_tile<TYR, ZS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  const int nt = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
+  hipLaunchKernelGGL((k_eps_tile<TYR, ZS>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, eps, mod, f,
+                     partial, nty, ntz, LX, nt);
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 6, sum6, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_eps_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<6>& eps, const FieldPtrs<2>& mod,
+                     const FieldPtrs<3>& f, double* partial, double* sum6, hipStream_t s) {
+  const int nzh = g.nz / 2;
+  if (nzh == 64) launch_eps_tile_t<8, 1>(g, mu_0, lambda_0, eps, mod, f, partial, sum6, s);
+  else if (nzh == 128) launch_eps_tile_t<6, 2>(g, mu_0, lambda_0, eps, mod, f, partial, sum6, s);
+  else launch_eps_tile_t<8, 0>(g, mu_0, lambda_0, eps, mod, f, partial, sum6, s);
 }
 
 bool u_fast_z_supported(const Grid& g) {

@@ -387,8 +387,12 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
       // the polarisation is a point-wise function of the strain: it is evaluated inside the divergence sweep (with its
       // six sums) and again in the tail sweep, and never stored
       time_begin(0);
-      launch_stress_div_sum_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, ptrs3(fu_), partial_,
-                                  dscal_ + kSlotMean, stream_);
+      if (opt_.u_loop >= 2 && u_tile_supported(g_))   // fast kernels allowed: the LDS-tiled marching form
+        launch_eps_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs6(src), effective_moduli(), ptrs3(fu_), partial_,
+                        dscal_ + kSlotMean, stream_);
+      else
+        launch_stress_div_sum_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, ptrs3(fu_), partial_,
+                                    dscal_ + kSlotMean, stream_);
       time_end(0);
     } else {
       time_begin(0);
@@ -459,7 +463,20 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
   // Voigt mixing: polarisation and divergence in one sweep (tau never stored); the laminate rule keeps the
   // two-kernel form (its per-voxel Newton solve is too costly to repeat at the six neighbours)
   const bool fuse_sd = opt_.fuse_stress_div && opt_.mixing == kMixVoigt && mq_zero;
-  if (fuse_sd) {
+  // with the fast kernels allowed (u_loop = 2) the LDS-tiled form takes over where the grid fits; it also delivers
+  // the sums of tau, so mixed boundary conditions keep the fused sweep
+  const bool tile_sd = opt_.fuse_stress_div && opt_.mixing == kMixVoigt && opt_.u_loop >= 2 && u_tile_supported(g_);
+  if (tile_sd) {
+    time_begin(0);
+    launch_eps_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs6(src), effective_moduli(), ptrs3(fu_), partial_, dscal_ + kSlotMean,
+                    stream_);
+    time_end(0);
+    if (!mq_zero) {
+      FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      FG_HIP_CHECK(hipStreamSynchronize(stream_));
+      for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)nglobal_;
+    }
+  } else if (fuse_sd) {
     time_begin(0);
     launch_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, ptrs3(fu_), stream_);
     time_end(0);
@@ -637,6 +654,22 @@ bool Solver::u_loop_eligible() const {
          frobenius(BC_MQ_) < kEps;
 }
 
+// A = sum_p phi_p 2 mu_p, B = sum_p phi_p lambda_p per voxel (k_effective_moduli), computed once per geometry
+FieldPtrs<2> Solver::effective_moduli() {
+  if (!mod_) {
+    FG_HIP_CHECK(hipMalloc(&mod_, 2 * (size_t)g_.n * sizeof(double)));
+    mod_dirty_ = true;
+  }
+  FieldPtrs<2> mod;
+  mod.p[0] = mod_;
+  mod.p[1] = mod_ + g_.n;
+  if (mod_dirty_) {
+    launch_effective_moduli(g_, phase_table(), phase_ptrs(), mod, stream_);
+    mod_dirty_ = false;
+  }
+  return mod;
+}
+
 void Solver::build_laminate_lists() {
   if (!mixed_dirty_) return;
   FieldPtrs<kMaxPhases> phi;
@@ -703,18 +736,7 @@ void Solver::u_pass_front(const double* E6) {
     return;
   } else if (opt_.u_loop >= 2) {
     // fast variant: per-voxel effective moduli instead of the per-phase accumulation
-    if (!mod_) {
-      FG_HIP_CHECK(hipMalloc(&mod_, 2 * (size_t)g_.n * sizeof(double)));
-      mod_dirty_ = true;
-  mixed_dirty_ = true;
-    }
-    FieldPtrs<2> mod;
-    mod.p[0] = mod_;
-    mod.p[1] = mod_ + g_.n;
-    if (mod_dirty_) {
-      launch_effective_moduli(g_, phase_table(), phi, mod, stream_);
-      mod_dirty_ = false;
-    }
+    const FieldPtrs<2> mod = effective_moduli();
     const bool laminate = opt_.mixing != kMixVoigt;
     const bool want_z = !laminate && (opt_.fuse_z > 0 || (opt_.fuse_z < 0 && (long)g_.nx * g_.ny * g_.nz <= (1L << 22)));
     z_done_ = want_z && fft_->fast_z() && u_fast_z_supported(g_);

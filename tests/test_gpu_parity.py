@@ -209,9 +209,9 @@ def test_homogeneous_and_callbacks():
     assert s2.iterations == 3 and len(s2.residuals) == 3
 
 
-def test_mixed_bc_uniaxial_stress():
+@pytest.mark.parametrize("grid", [(16, 16, 16), (8, 14, 128)])   # the second grid takes the tiled divergence sweep
+def test_mixed_bc_uniaxial_stress(grid):
     """setBCProjector / calcBCMean / applyBCProjector F:20599-20665 on the GPU path."""
-    grid = (16, 16, 16)
     o = make_oracle(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
     s = make_gpu_solver(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
     P = np.zeros((6, 6))
@@ -256,14 +256,16 @@ def test_error_paths():
                                        ((64, 64, 64), (1.0, 1.0, 1.0)), ((128, 16, 128), (1.0, 1.0, 1.0))])
 def test_fused_kernels_match_unfused_pipeline(grid, dims):
     """The fused kernels (polarisation+divergence; x-FFT + Green operator + x-FFT^-1) against the
-    one-kernel-per-reference-routine pipeline: the stress/div fusion must be bit-identical, the FFT
-    fusion agrees to FFT rounding."""
+    one-kernel-per-reference-routine pipeline: the exact-order stress/div fusion (u_loop <= 1) must be bit-identical, the
+    FFT fusion agrees to FFT rounding, and so does the default (u_loop = 2: effective moduli + FMA, LDS-tiled on the
+    last grid)."""
     rng = np.random.default_rng(21)
     eps = 0.1 * rng.standard_normal((6,) + grid)
     E = np.array([1.0, 0.2, -0.3, 0.1, 0.0, 0.4])
     out = {}
-    for name, opts in (("plain", dict(fuse_stress_div=0, fuse_x=0)), ("sd", dict(fuse_stress_div=1, fuse_x=0)),
-                       ("x", dict(fuse_stress_div=0, fuse_x=1)), ("both", dict(fuse_stress_div=1, fuse_x=1))):
+    for name, opts in (("plain", dict(fuse_stress_div=0, fuse_x=0, u_loop=1)), ("sd", dict(fuse_stress_div=1, fuse_x=0, u_loop=1)),
+                       ("x", dict(fuse_stress_div=0, fuse_x=1, u_loop=1)), ("both", dict(fuse_stress_div=1, fuse_x=1, u_loop=1)),
+                       ("fast", dict())):
         s = make_gpu_solver(grid, dims, mu_0=0.9, lambda_0=0.2)
         for k, v in opts.items():
             s._check(s._lib.fg_set_option_i(s._h, k.encode(), v))
@@ -273,6 +275,7 @@ def test_fused_kernels_match_unfused_pipeline(grid, dims):
     assert np.array_equal(out["sd"], out["plain"])
     assert np.array_equal(out["both"], out["x"])
     assert rel_err(out["x"], out["plain"]) < 1e-12
+    assert rel_err(out["fast"], out["plain"]) < 1e-12
     o = make_oracle(grid, dims)
     o.mu_0, o.lambda_0 = 0.9, 0.2
     assert rel_err(out["both"], o.basic_scheme(E, eps)) < 1e-12

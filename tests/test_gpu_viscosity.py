@@ -22,7 +22,10 @@ def _pair(grid, mus, phis, dims=(1.0, 1.0, 1.0), **kw):
 
 
 @pytest.mark.parametrize("grid,dims", [((16, 16, 16), (1, 1, 1)), ((12, 10, 6), (2.0, 1.0, 0.5)), ((9, 7, 5), (1, 1, 1)),
-                                       ((32, 16, 64), (1, 1, 1))])
+                                       ((32, 16, 64), (1, 1, 1)),
+                                       # grids the LDS-tiled divergence sweep k_eps_tile takes (halo lanes; one / two waves per row)
+                                       ((8, 14, 124), (1.0, 2.0, 0.5)), ((16, 16, 128), (1, 1, 1)), ((6, 20, 130), (1, 1, 1)),
+                                       ((5, 14, 256), (1, 1, 1))])
 def test_viscosity_run_matches_oracle(grid, dims):
     phi1 = sphere_phi(grid, 0.3)
     s, o = _pair(grid, [1.0, 0.05], [1 - phi1, phi1], dims, tol=1e-8)   # nearly rigid inclusion in a fluid
