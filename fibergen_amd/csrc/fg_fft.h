@@ -18,6 +18,7 @@ struct G0Params {
   const double* kpm[3];
   const cplx* kp[3];
   double c10, c20;
+  double inv_h0;   // 2 n / d of the axis the fused pass transforms (physical x)
 };
 
 class Fft3 {
@@ -55,6 +56,7 @@ class Fft3 {
   bool fast_[3];
   int stream_stores_ = 0;  // FFT passes use cache-bypassing stores (fields larger than the Infinity Cache)
   cplx* tw_[3];      // per-axis pass twiddles (fast path) ; z: for M = nz/2
+  cplx* half_root_[2];  // e^{-i pi j/n}, j < n/8, of x and y (fused Green-operator pass)
   cplx* wz_;         // w^k = e^{-2 pi i k/nz}, k = 0..nz/2   (fast z path)
   cplx* wgen_[3];    // e^{-2 pi i k/n}, k = 0..n-1           (generic path)
   double* scratch_;  // one padded component (generic path)

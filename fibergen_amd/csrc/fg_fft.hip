@@ -185,6 +185,17 @@ void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
   }
   a.tiles_per_outer = (a.ncols + C - 1) / C;
   const long nblocks = (long)a.tiles_per_outer * nouter;
+  static cplx xq[8];
+  static bool have_xq = false;
+  if (!have_xq) {
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (int q = 0; q < 8; ++q) {
+      const long double th = pi * (long double)fft::Line<N>::last_index(0, q) / (long double)N;
+      xq[q] = cmake((double)cosl(th), (double)sinl(th));
+    }
+    have_xq = true;
+  }
+  for (int q = 0; q < 8; ++q) a.xq[q] = xq[q];
   // (persistent / looping forms of this kernel lose to fresh workgroups: DESIGN 3.4, 3.6)
   hipLaunchKernelGGL(k_xfused<K>, dim3((unsigned)nblocks), dim3(K::THREADS), lds, s, a);
   FG_HIP_CHECK(hipGetLastError());
@@ -208,6 +219,7 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
     tw_[a] = nullptr;
     wgen_[a] = nullptr;
   }
+  half_root_[0] = half_root_[1] = nullptr;
   fast_[0] = fast_len(g.nx);
   fast_[1] = fast_len(g.ny);
   fast_[2] = (g.nz % 2 == 0) && fast_len(g.nz / 2);
@@ -215,6 +227,7 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
   for (int a = 0; a < 3; ++a) {
     if (fast_[a]) {
       tw_[a] = upload(make_pass_twiddles(a == 2 ? len[a] / 2 : len[a]));
+      if (a < 2) half_root_[a] = upload(make_unit_roots(2 * len[a], len[a] / 8));
     } else {
       wgen_[a] = upload(make_unit_roots(len[a], len[a]));
       need_scratch = true;
@@ -229,6 +242,7 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
 Fft3::~Fft3() {
   for (int a = 0; a < 3; ++a) {
     if (tw_[a]) (void)hipFree(tw_[a]);
+    if (a < 2 && half_root_[a]) (void)hipFree(half_root_[a]);
     if (wgen_[a]) (void)hipFree(wgen_[a]);
   }
   if (wz_) (void)hipFree(wz_);
@@ -304,6 +318,8 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
   a.c10 = gp.c10;
   a.c20 = gp.c20;
   a.tw = tw_[axis];
+  a.half_root = half_root_[axis];
+  a.inv_h = gp.inv_h0;
   a.nt = stream_stores_ ? (1 | ((nt_loads_env() & 2) ? 2 : 0)) : 0;
   for (int k = 0; k < 3; ++k) {
     a.kpm[k] = gp.kpm[k];

@@ -259,6 +259,14 @@ struct XFusedArgs {
   const double* kpm[3];
   const cplx* kp[3];
   int nt;              // streaming stores
+  // The Green-operator factors of the transformed axis are rebuilt in the kernel instead of being looked up per point
+  // (8 dependent table round trips per thread were 12-16 % of a tile): with theta = pi kx / N,
+  //   kpm0^2 = (sin theta / h)^2,  kp0 = (sin theta / h) e^{i theta}   (F:19838-19876; the reference's signed index
+  //   shifts theta by -pi for kx > N/2, which changes neither quantity),
+  // and kx = jt + off(q):  e^{i theta} = half_root[jt] * xq[q].
+  const cplx* half_root;   // e^{-i pi j / N}, j < N/8 (conjugated in the kernel)
+  cplx xq[8];              // e^{+i pi off(q) / N}, off(q) = last_index(0, q)
+  double inv_h;            // 1/h = 2 N / d of the transformed axis
 };
 
 // NC = 3: the three components of the elastic problem and G0OperatorFourierStaggeredGeneral; NC = 1: the scalar modes
@@ -336,6 +344,7 @@ struct XFusedKernel {
         // scalar Green operator on the spectrum in registers
         const bool live = r.valid && r.kk < a.nzf;
         const double kpm1 = live ? a.kpm[1][r.jj] : 1.0, kpm2 = live ? a.kpm[2][r.kk] : 1.0;
+        const cplx rb = cconj(a.half_root[r.jt]);
         cplx w[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -345,7 +354,7 @@ struct XFusedKernel {
             if (kx == 0 && r.jj == 0 && r.kk == 0) {
               e = cmake(0.0, 0.0);
             } else {
-              const double kpm0 = a.kpm[0][kx];
+              const double kpm0 = (rb.im * a.xq[q].re + rb.re * a.xq[q].im) * a.inv_h;
               const double norm_kp2 = kpm0 * kpm0 + kpm1 * kpm1 + kpm2 * kpm2;
               e = cscale(a.c10 / norm_kp2, e);
             }
@@ -360,17 +369,20 @@ struct XFusedKernel {
         const bool live = r.valid && r.kk < a.nzf;
         const double kpm1 = live ? a.kpm[1][r.jj] : 1.0, kpm2 = live ? a.kpm[2][r.kk] : 1.0;
         const cplx kp1 = live ? a.kp[1][r.jj] : cmake(0.0, 0.0), kp2 = live ? a.kp[2][r.kk] : cmake(0.0, 0.0);
+        const cplx rb = cconj(a.half_root[r.jt]);
         cplx w[3][8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int kx = Line<N>::last_index(r.jt, q);
+          const cplx et = cmul(rb, a.xq[q]);          // e^{i theta}
+          const double kpm0 = et.im * a.inv_h;
           cplx t0 = cscale(a.scale, r.v[0][q]), t1 = cscale(a.scale, r.v[1][q]), t2 = cscale(a.scale, r.v[2][q]);
           cplx e0 = t0, e1 = t1, e2 = t2;
           if (live) {
             if (kx == 0 && r.jj == 0 && r.kk == 0) {
               e0 = e1 = e2 = cmake(0.0, 0.0);   // zero frequency  F:19924-19926
             } else {
-              g0_point_rcp(t0, t1, t2, a.kpm[0][kx], kpm1, kpm2, a.kp[0][kx], kp1, kp2, a.c10, a.c20, &e0, &e1, &e2);
+              g0_point_rcp(t0, t1, t2, kpm0, kpm1, kpm2, cscale(kpm0, et), kp1, kp2, a.c10, a.c20, &e0, &e1, &e2);
             }
           }
           w[0][q] = e0;

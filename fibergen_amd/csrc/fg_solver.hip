@@ -537,6 +537,7 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
       for (int a = 0; a < 3; ++a) gp.kpm[a] = g0_kpm_[a], gp.kp[a] = g0_kp_[a];
       gp.c10 = c10;
       gp.c20 = 0.0;
+      gp.inv_h0 = 2.0 * nxg_ / g_.dx;
       time_begin(5);
       fft_->fused_g0(buf, g_.n, 0, scale, gp, 0, 1);
       time_end(5);
@@ -591,6 +592,7 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     G0Params gp;
     gp.c10 = -alpha / (opt_.mu_0);
     gp.c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    gp.inv_h0 = 2.0 * nxg_ / g_.dx;
     if (c12) gp.c10 = c12[0], gp.c20 = c12[1];
     G0Tables tb;
     for (int a = 0; a < 3; ++a) {
@@ -1351,6 +1353,7 @@ void Solver::slab_phase(int phase, const double* E6, const double* R6) {
         G0Params gp;
         gp.c10 = c10;
         gp.c20 = c20;
+        gp.inv_h0 = 2.0 * nxg_ / g_.dx;
         for (int a = 0; a < 3; ++a) {
           gp.kpm[a] = g0_kpm_[a];
           gp.kp[a] = g0_kp_[a];

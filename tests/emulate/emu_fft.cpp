@@ -111,6 +111,11 @@ int emu_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, doub
   a.c10 = c10;
   a.c20 = c20;
   a.tw = tw.data();
+  // the transformed axis' factors are rebuilt from theta = pi kx / N: e^{-i pi j/N} and 1/h read off the table (kpm0[1] = sin(pi/N)/h)
+  std::vector<cplx> half_root = make_unit_roots(2 * N, N / 8 > 0 ? N / 8 : 1);
+  a.half_root = half_root.data();
+  a.inv_h = N > 1 ? kpm0[1] / std::sin(3.14159265358979323846 / N) : 1.0;
+  for (int q = 0; q < 8; ++q) a.xq[q] = cmake(1.0, 0.0);   // filled per N below
   a.kpm[0] = kpm0; a.kpm[1] = kpm1; a.kpm[2] = kpm2;
   a.kp[0] = reinterpret_cast<const cplx*>(kp0);
   a.kp[1] = reinterpret_cast<const cplx*>(kp1);
@@ -119,6 +124,10 @@ int emu_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, doub
   if (N == n) {                                                               \
     constexpr int C = XTileCols<n>::value;                                    \
     a.tiles_per_outer = (a.ncols + C - 1) / C;                                \
+    for (int q = 0; q < 8; ++q) {                                             \
+      const double th = 3.14159265358979323846 * fft::Line<n>::last_index(0, q) / n;      \
+      a.xq[q] = cmake(std::cos(th), std::sin(th));                            \
+    }                                                                         \
     run_blocks<XFusedKernel<n, C>, XFusedArgs>((long)a.tiles_per_outer, a);   \
     return 0;                                                                 \
   }

@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
   }
   gp.c10 = -0.5;
   gp.c20 = 0.25;
+  gp.inv_h0 = 2.0 * n;
   hipEvent_t e0, e1;
   FG_HIP_CHECK(hipEventCreate(&e0));
   FG_HIP_CHECK(hipEventCreate(&e1));
