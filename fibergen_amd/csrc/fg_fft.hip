@@ -23,12 +23,33 @@ using namespace fft;
 
 namespace {
 
+// Kernels whose lines never span two waves (z passes: T threads per line, T divides 64) exchange through LDS inside
+// one wave only: the LDS queue of a wave is in order, so a compiler-level fence replaces the workgroup barrier and
+// the waves of a workgroup drift freely (loads of one overlap the butterflies of another).
+template <class K>
+struct WaveLocal {
+  static constexpr bool value = false;
+};
+template <int M, int LINES>
+struct WaveLocal<R2CKernel<M, LINES>> {
+  static constexpr bool value = (M / 8) <= 64 && 64 % (M / 8) == 0;
+};
+template <int M, int LINES>
+struct WaveLocal<C2RKernel<M, LINES>> {
+  static constexpr bool value = (M / 8) <= 64 && 64 % (M / 8) == 0;
+};
+
 template <class K, class Args, int PH>
 struct DevicePhases {
   __device__ __forceinline__ static void run(typename K::Regs& r, int block, int tid, double* lds, const Args& a) {
     K::template phase<PH>(r, block, tid, lds, a);
     if constexpr (PH + 1 < K::NPHASE) {
-      __syncthreads();
+      if constexpr (WaveLocal<K>::value) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        __syncthreads();
+      }
       DevicePhases<K, Args, PH + 1>::run(r, block, tid, lds, a);
     }
   }
