@@ -79,7 +79,7 @@ bool u_tile_supported(const Grid& g);
 void launch_eps_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<6>& eps, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& f, double* partial, double* sum6, hipStream_t s);
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
-                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s);
+                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s, bool sum_tau = false);
 bool u_fast_z_supported(const Grid& g);
 void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, const cplx* tw_z,

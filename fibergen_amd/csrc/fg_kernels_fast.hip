@@ -310,7 +310,7 @@ __device__ unsigned long long g_k1_probe[kK1ProbeBlocks][kK1ProbeSlots];
 #define FG_K1_MARK(slot) do { } while (0)
 #endif
 
-template <int TYR, int ZS>
+template <int TYR, int ZS, bool SUMT>
 __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, double beta, double gamma, FieldPtrs<3> u,
                                                                       FieldPtrs<2> mod, FieldPtrs<3> fo, Vec6 E, double* partial,
                                                                       int nty, int ntz, int LX, int nt) {
@@ -322,7 +322,9 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   extern __shared__ __align__(16) double2 tile_lds[];
   double2(*Ub)[TYR][RW] = reinterpret_cast<double2(*)[TYR][RW]>(tile_lds);                  // [3][TYR][RW]
   double2(*Tb)[TYR][RW] = reinterpret_cast<double2(*)[TYR][RW]>(tile_lds + 3 * TYR * RW);   // [3][TYR][RW]
-  __shared__ double red[TYR * NZS * 6];
+  // SUMT: also the six sums of the polarisation (<tau> drives the mixed boundary conditions): 12 values per workgroup
+  constexpr int NS = SUMT ? 12 : 6;
+  __shared__ double red[TYR * NZS * NS];
   __shared__ double edge[3][TYR][NZS];    // tau2.y of lane 63, tau3.x and tau4.x of lane 0 of every wave (ZS >= 1)
 
   const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -384,7 +386,9 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   }
   double2 dx1 = make_double2(0.0, 0.0), dx2 = dx1;          // U1, U2 minus their previous plane (warm-up: unused)
   double2 t0m = dx1, t5m = dx1, t4m = dx1, part1 = dx1, part2 = dx1;
-  double acc[6] = {0, 0, 0, 0, 0, 0};
+  double acc[NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) acc[c] = 0.0;
   {
     [[maybe_unused]] const int st = -100;
     FG_K1_MARK(0);   // workgroup start (after the first loads were issued)
@@ -441,6 +445,10 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
     if (own && inside) {
       acc[0] += e0.x * e0.x + e0.y * e0.y; acc[1] += e1.x * e1.x + e1.y * e1.y; acc[2] += e2.x * e2.x + e2.y * e2.y;
       acc[3] += e3.x * e3.x + e3.y * e3.y; acc[4] += e4.x * e4.x + e4.y * e4.y; acc[5] += e5.x * e5.x + e5.y * e5.y;
+      if (SUMT) {
+        acc[NS - 6] += t0.x + t0.y; acc[NS - 5] += t1.x + t1.y; acc[NS - 4] += t2.x + t2.y;
+        acc[NS - 3] += t3.x + t3.y; acc[NS - 2] += t4.x + t4.y; acc[NS - 1] += t5.x + t5.y;
+      }
     }
     FG_K1_MARK(4);
     // ---- y neighbours of tau through LDS
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   }
   // ---- sums of squares: fixed-order reduction over the workgroup
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
+  for (int c = 0; c < NS; ++c) {
     double a = acc[c];
     a += dpp_move<0x128>(a);
     a += dpp_move<0x124>(a);
@@ -508,13 +516,13 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   }
   if (l == 0) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) red[wv * 6 + c] = acc[c];
+    for (int c = 0; c < NS; ++c) red[wv * NS + c] = acc[c];
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < NS) {
     double a = 0.0;
-    for (int w = 0; w < TYR * NZS; ++w) a += red[w * 6 + threadIdx.x];
-    partial[(long)blockIdx.x * 6 + threadIdx.x] = a;
+    for (int w = 0; w < TYR * NZS; ++w) a += red[w * NS + threadIdx.x];
+    partial[(long)blockIdx.x * NS + threadIdx.x] = a;
   }
 }
 
@@ -799,7 +807,7 @@ bool u_tile_supported(const Grid& g) {
   return g.nz % 2 == 0 && nzh >= 62 && g.ny >= 14 && g.nx >= 4;
 }
 
-template <int TYR, int ZS>
+template <int TYR, int ZS, bool SUMT>
 void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s) {
   constexpr int NZS = ZS ? ZS : 1;
@@ -824,22 +832,29 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
   static bool configured = false;
   if (!configured) {
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, ZS>),
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, ZS, SUMT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
   const int nt = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
-  hipLaunchKernelGGL((k_u_tile<TYR, ZS>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E,
+  hipLaunchKernelGGL((k_u_tile<TYR, ZS, SUMT>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E,
                      partial, nty, ntz, LX, nt);
   FG_HIP_CHECK(hipGetLastError());
-  fold_sum(partial, nb, 6, sumsq6, s);
+  fold_sum(partial, nb, SUMT ? 12 : 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
 }
 
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
-                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s) {
+                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s,
+                   bool sum_tau) {
   const int nzh = g.nz / 2;
-#define FG_TILE(R, Z) launch_u_tile_t<R, Z>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s)
+  if (sum_tau) {   // sumsq6[0..5] sums of squares of the strain, sumsq6[6..11] sums of the polarisation
+    if (nzh == 64) launch_u_tile_t<8, 1, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+    else if (nzh == 128) launch_u_tile_t<6, 2, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+    else launch_u_tile_t<8, 0, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
+    return;
+  }
+#define FG_TILE(R, Z) launch_u_tile_t<R, Z, false>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s)
   if (nzh == 64) {          // a z row is one wave
     if (rows == 16) FG_TILE(16, 1);
     else if (rows == 12) FG_TILE(12, 1);

@@ -134,7 +134,7 @@ class Solver {
   bool run_cg(const double* E0, const double* S0);
   bool run_cg_scalar(const double* E0);  // heat / porous: CG in potential space
   bool run_cg_u(const double* E0);      // the same CG carried in displacement space (Voigt, prescribed mean strains)
-  bool u_loop_eligible() const;
+  bool u_loop_eligible(bool allow_mixed_bc = false) const;
   FieldPtrs<2> effective_moduli();      // per-voxel sums of the phase moduli for the fast kernels (allocated on first use)
   void build_laminate_lists();          // interface / affected voxel lists of the laminate correction (once per geometry)
   void u_pass_front(const double* E6);  // u_k (fu_) -> sums of squares of eps_k, f_{k+1} (fu_alt_)

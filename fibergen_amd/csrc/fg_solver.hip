@@ -300,7 +300,9 @@ void Solver::check_device_error(const char* where) {
 
 // The same check, but the host waits only for the copies enqueued so far (an event), not for work enqueued after them.
 void Solver::fetch_norms_and_errors(const char* where) {
-  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  static_assert(kSlotMean == kSlotSumSq + 6, "the displacement sweep writes norms and tau sums as one block of 12");
+  const int nfetch = pending_back_ && !(frobenius(BC_MQ_) < kEps) ? 12 : 6;   // mixed BC in the displacement loop: + sums of tau
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, nfetch * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, stream_));
   FG_HIP_CHECK(hipEventRecord(ev_copy_, stream_));
   if (pending_back_) launch_pending_back();   // speculative: u_{k+1} is built while the host looks at the norms of eps_k
@@ -642,7 +644,7 @@ FieldPtrs<kMaxPhases> Solver::phase_ptrs() const {
   return phi;
 }
 
-bool Solver::u_loop_eligible() const {
+bool Solver::u_loop_eligible(bool allow_mixed_bc) const {
   if (opt_.mode == 1) {
     // the scalar modes only have the potential-based loop
     if (nranks_ != 1) throw std::runtime_error("heat / porous mode is not available on slab-decomposed solvers");
@@ -651,9 +653,13 @@ bool Solver::u_loop_eligible() const {
       throw std::runtime_error("heat / porous mode supports prescribed mean gradients only (projector = identity)");
     return pt_.n >= 1;
   }
-  return opt_.u_loop && opt_.mode == 0 && opt_.gamma_scheme == 0 && nranks_ == 1 && pt_.n >= 1 &&
-         (opt_.mixing == kMixVoigt || (opt_.mixing == kMixLaminate && normals_)) && opt_.bc_relax == 1.0 &&
-         frobenius(BC_MQ_) < kEps;
+  if (!(opt_.u_loop && opt_.mode == 0 && opt_.gamma_scheme == 0 && nranks_ == 1 && pt_.n >= 1 &&
+        (opt_.mixing == kMixVoigt || (opt_.mixing == kMixLaminate && normals_)) && opt_.bc_relax == 1.0))
+    return false;
+  if (frobenius(BC_MQ_) < kEps) return true;
+  // mixed boundary conditions: <tau> of every pass corrects the prescribed mean of the next one; the tiled Voigt sweep
+  // delivers it with the norms (run() only: the correction needs the host between passes)
+  return allow_mixed_bc && opt_.mixing == kMixVoigt && opt_.u_loop >= 2 && opt_.u_tile && u_tile_supported(g_);
 }
 
 // A = sum_p phi_p 2 mu_p, B = sum_p phi_p lambda_p per voxel (k_effective_moduli), computed once per geometry
@@ -745,7 +751,7 @@ void Solver::u_pass_front(const double* E6) {
     if (opt_.u_tile && u_tile_supported(g_)) {
       z_done_ = false;
       launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
-                    opt_.u_tile, stream_);
+                    opt_.u_tile, stream_, !(frobenius(BC_MQ_) < kEps));   // mixed BC: sums of tau land in kSlotMean
     } else if (z_done_)
       launch_u_fast_z(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
                       fft_->z_twiddles(), fft_->z_roots(), stream_);
@@ -933,7 +939,8 @@ bool Solver::run(const double* E6, const double* S6) {
   eps_stale_ = false;
   // Displacement-based loop: eps_0 = 0 gives tau = 0, u_1 = 0 and eps_1 = E, so the loop starts from
   // u = 0 and every pass is [u_k -> norms of eps_k, f_{k+1}] + [f_{k+1} -> u_{k+1}] (see u_pass_front).
-  bool uloop = u_loop_eligible();
+  bool uloop = u_loop_eligible(true);
+  const bool mixed_bc = !(frobenius(BC_MQ_) < kEps);   // (NaN until calcRefMaterial ran: Q != 0)
   if (uloop) {
     FG_HIP_CHECK(hipMemsetAsync(fu_, 0, 3 * g_.n * sizeof(double), stream_));
     u_valid_ = true;
@@ -975,6 +982,13 @@ bool Solver::run(const double* E6, const double* S6) {
       basic_scheme(E);
     }
     fetch_norms_and_errors("stress");
+    if (uloop && mixed_bc) {
+      // applyBCProjector  F:20247-20270 with bc_relax = 1: eps_{k+1} = E + alpha MQ:<tau_k> + sym grad u_{k+1}
+      double F0[6], t1[6];
+      for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)nglobal_;
+      voigt_mv(BC_MQ_, F0, t1);
+      for (int c = 0; c < 6; ++c) E_next_[c] = E[c] - t1[c];   // alpha = -1  (F:20575)
+    }
 
     // component_norm + fix_dim + norm_2 over 9 mirrored entries  F:10127-10138, F:14600-14609, F:14627
     double m[6], s9 = 0.0;
