@@ -333,6 +333,19 @@ def main():
         }
         if g0_alone is not None:
             out["gamma0_apply_standalone"] = g0_alone
+        # the measured roofline: streaming copy / triad of the library on this GPU, 1 GiB arrays
+        try:
+            import ctypes
+            from fibergen_amd import _lib
+            cg, tg = ctypes.c_double(0.0), ctypes.c_double(0.0)
+            if _lib.load().fg_hbm_stream(local_rank, 1024, 3, ctypes.byref(cg), ctypes.byref(tg)) == 0 and tg.value > 0:
+                best = max(cg.value, tg.value)
+                out["hbm_stream"] = {"copy_GBps": cg.value, "triad_GBps": tg.value,
+                                     "dominant_kernel_frac_of_measured": kern[dom]["GBps"] / best}
+                if g0_alone is not None:
+                    out["hbm_stream"]["gamma0_apply_frac_of_measured"] = g0_alone["GBps"] / best
+        except Exception as e:  # noqa: BLE001
+            out["hbm_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if scalar:
             # the loop-level figures use the elasticity byte counts; per voxel the scalar loop moves
             # 24 (sweep) + 7 x 16 (six 1-component FFT passes + Green operator) bytes

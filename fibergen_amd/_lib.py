@@ -57,6 +57,7 @@ SIGNATURES = {
     "fg_run_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p]),
     "fg_enable_stage_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "fg_get_stage_times": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long)]),
+    "fg_hbm_stream": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p]),
     "fg_create_slab": (ctypes.c_void_p, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "fg_slab_phase": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p]),

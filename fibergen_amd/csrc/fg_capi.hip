@@ -30,6 +30,19 @@ int guarded(fg_solver* s, F&& f) {
 }
 }  // namespace
 
+// streaming copy / triad for fg_hbm_stream
+__global__ void fg_stream_kernel(double2* a, const double2* b, const double2* c, long n2, int triad, double s) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  double2 v = b[i];
+  if (triad) {
+    const double2 w = c[i];
+    v.x += s * w.x;
+    v.y += s * w.y;
+  }
+  a[i] = v;
+}
+
 extern "C" {
 
 int fg_abi_version(void) { return FG_ABI_VERSION; }
@@ -292,6 +305,47 @@ int fg_get_stage_times(const fg_solver* s, double* ms, long* count) {
     for (int i = 0; i < fg::kNumTimedKernels; ++i) ms[i] = t.ms[i];
   if (count) *count = t.count;
   return FG_OK;
+}
+
+int fg_hbm_stream(int device, int megabytes, int reps, double* copy_GBps, double* triad_GBps) {
+  try {
+    if (megabytes < 1 || reps < 1) throw std::runtime_error("fg_hbm_stream: megabytes and reps must be positive");
+    FG_HIP_CHECK(hipSetDevice(device));
+    const long n2 = (long)megabytes * 1024 * 1024 / 16;   // double2 elements per array
+    double2 *a = nullptr, *b = nullptr, *c = nullptr;
+    FG_HIP_CHECK(hipMalloc(&a, n2 * sizeof(double2)));
+    FG_HIP_CHECK(hipMalloc(&b, n2 * sizeof(double2)));
+    FG_HIP_CHECK(hipMalloc(&c, n2 * sizeof(double2)));
+    FG_HIP_CHECK(hipMemset(b, 0, n2 * sizeof(double2)));
+    FG_HIP_CHECK(hipMemset(c, 0, n2 * sizeof(double2)));
+    hipEvent_t e0, e1;
+    FG_HIP_CHECK(hipEventCreate(&e0));
+    FG_HIP_CHECK(hipEventCreate(&e1));
+    const unsigned nb = (unsigned)((n2 + 255) / 256);
+    double best[2] = {0.0, 0.0};
+    for (int mode = 0; mode < 2; ++mode)
+      for (int r = 0; r < reps + 1; ++r) {   // first launch is a warm-up
+        FG_HIP_CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(fg_stream_kernel, dim3(nb), dim3(256), 0, 0, a, b, c, n2, mode, 0.5);
+        FG_HIP_CHECK(hipEventRecord(e1, 0));
+        FG_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        FG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double gbps = (mode ? 3.0 : 2.0) * (double)n2 * sizeof(double2) / (ms * 1e-3) / 1e9;
+        if (r > 0 && gbps > best[mode]) best[mode] = gbps;
+      }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    (void)hipFree(c);
+    if (copy_GBps) *copy_GBps = best[0];
+    if (triad_GBps) *triad_GBps = best[1];
+    return FG_OK;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();   // reported by fg_last_error(NULL)
+    return FG_ERROR;
+  }
 }
 
 }  // extern "C"

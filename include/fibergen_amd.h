@@ -137,6 +137,11 @@ int fg_run_stage(fg_solver* s, int stage, const double* E6);
 int fg_enable_stage_timing(fg_solver* s, int enable);
 int fg_get_stage_times(const fg_solver* s, double* ms /* [FG_NUM_TIMED_KERNELS] */, long* count);
 
+/* Measurement helper (no counterpart in the reference): achieved HBM bandwidth of a streaming copy a = b and of the
+ * triad a = b + s*c on `device`, arrays of `megabytes` MB each, best of `reps` launches, in GB/s of bytes moved
+ * (2 resp. 3 arrays).  The "measured roofline" that bench.py reports beside the 8 TB/s peak. */
+int fg_hbm_stream(int device, int megabytes, int reps, double* copy_GBps, double* triad_GBps);
+
 /* ---- slab decomposition over the GPUs of a node ----------------------------
  * The reference is single-process; this is the multi-GPU counterpart of one LSSolver.  Rank r
  * of nranks owns the x-planes [r*nx/nranks, (r+1)*nx/nranks) of every field (nx and ny must be
