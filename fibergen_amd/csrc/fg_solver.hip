@@ -672,7 +672,10 @@ FieldPtrs<2> Solver::effective_moduli() {
   mod.p[0] = mod_;
   mod.p[1] = mod_ + g_.n;
   if (mod_dirty_) {
-    launch_effective_moduli(g_, phase_table(), phase_ptrs(), mod, stream_);
+    PhaseTable t = phase_table();
+    if (opt_.mode == 1)   // scalar modes: k_effective_moduli stores sum phi 2 mu, the sweep wants sum phi mu
+      for (int q = 0; q < kMaxPhases; ++q) t.mu[q] = 0.5 * pt_.mu[q], t.lambda[q] = 0.0;
+    launch_effective_moduli(g_, t, phase_ptrs(), mod, stream_);
     mod_dirty_ = false;
   }
   return mod;
@@ -711,21 +714,7 @@ void Solver::u_pass_front(const double* E6) {
     z_done_ = false;
     if (opt_.u_loop >= 2) {
       // fast variant: effective conductivity a = sum_p phi_p mu_p precomputed (first moduli array)
-      if (!mod_) {
-        FG_HIP_CHECK(hipMalloc(&mod_, 2 * (size_t)g_.n * sizeof(double)));
-        mod_dirty_ = true;
-  mixed_dirty_ = true;
-      }
-      if (mod_dirty_) {
-        PhaseTable half = pt_;  // k_effective_moduli stores sum phi 2 mu: feed mu / 2
-        for (int q = 0; q < kMaxPhases; ++q) half.mu[q] = 0.5 * pt_.mu[q], half.lambda[q] = 0.0;
-        FieldPtrs<2> mod;
-        mod.p[0] = mod_;
-        mod.p[1] = mod_ + g_.n;
-        launch_effective_moduli(g_, half, phase_ptrs(), mod, stream_);
-        mod_dirty_ = false;
-      }
-      launch_sc_sweep_fast(g_, opt_.mu_0, fu_, mod_, fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
+      launch_sc_sweep_fast(g_, opt_.mu_0, fu_, effective_moduli().p[0], fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
     } else {
       launch_sc_sweep(g_, scalar_params(opt_.mu_0, 1.0), fu_, phase_ptrs(), fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
     }
