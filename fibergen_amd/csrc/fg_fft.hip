@@ -150,6 +150,111 @@ int nt_loads_env() {
 
 bool fast_len(int n) { return is_pow2(n) && n >= 8 && n <= 1024; }
 
+// ---------------------------------------------------------------- lengths p * 2^k, p in {3, 5, 7}
+// N = p M: the line is p interleaved sub-lines x_r[m] = x[p m + r] of the power-of-two length M.  Forward: the M-point
+// kernels transform the sub-lines in place (line stride p * ls), Y_r[k] then sits at point p k + r, and one combine
+// sweep forms  X[k + M s] = sum_r w_N^{r k} w_p^{r s} Y_r[k]  (out of place, through the scratch component).
+// Inverse: the combine sweep first,  Z_r[k] = conj(w_N^{r k}) sum_s X[k + M s] conj(w_p^{r s})  to point p k + r,
+// then the M-point inverse kernels on the sub-lines.  3x the traffic of a native pass instead of an O(N^2) DFT.
+int mixed_factor(int n) {   // p if n = p * 2^k with 2^k a fast length, else 0
+  static const int off = getenv("FG_FFT_NO_MIXED") ? atoi(getenv("FG_FFT_NO_MIXED")) : 0;   // A/B knob: O(n^2) path
+  if (off) return 0;
+  for (int p : {3, 5, 7})
+    if (n % p == 0 && fast_len(n / p)) return p;
+  return 0;
+}
+
+constexpr int kMaxOddFactor = 7;
+
+// w: e^{-2 pi i j / N}, j < N
+template <int DIR>
+__global__ __launch_bounds__(256) void k_mixed_combine(const cplx* src, cplx* dst, long ls, long os, int ncols, int nouter,
+                                                       int M, int p, double scale, const cplx* w) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)nouter * M * ncols;
+  if (idx >= total) return;
+  const int col = (int)(idx % ncols);
+  const long rest = idx / ncols;
+  const int k = (int)(rest % M);
+  const long base = (rest / M) * os + col;
+  const int N = p * M;
+  cplx in[kMaxOddFactor];
+  for (int r = 0; r < p; ++r) {
+    // forward: Y_r[k] at point p k + r;  inverse: X[k + M r] at its natural point
+    const long pt = DIR < 0 ? (long)p * k + r : (long)k + (long)M * r;
+    in[r] = src[base + pt * ls];
+  }
+  for (int o = 0; o < p; ++o) {
+    cplx acc = cmake(0.0, 0.0);
+    if (DIR < 0) {   // output s = o:  sum_r w_N^{r k} w_p^{r s} Y_r
+      for (int r = 0; r < p; ++r) {
+        const cplx t = w[(int)(((long)r * k + (long)r * o * M) % N)];
+        acc = cadd(acc, cmul(in[r], t));
+      }
+      dst[base + ((long)k + (long)M * o) * ls] = cscale(scale, acc);
+    } else {         // output r = o:  conj(w_N^{r k}) sum_s X_s conj(w_p^{r s})
+      for (int sidx = 0; sidx < p; ++sidx) {
+        const cplx t = cconj(w[(int)(((long)o * sidx * M) % N)]);
+        acc = cadd(acc, cmul(in[sidx], t));
+      }
+      acc = cmul(acc, cconj(w[(int)(((long)o * k) % N)]));
+      dst[base + ((long)p * k + o) * ls] = cscale(scale, acc);
+    }
+  }
+}
+
+// z axis, nz = 2 M, M = p M': after the M'-point sub-transforms of the packed rows (Y_r[k'] at complex p k' + r), one
+// sweep per row forms the M-point spectrum Z and splits it into the half spectrum of the real row (r2c_split):
+// thread k <= M/2 writes X[k] and X[M - k].  wn: e^{-2 pi i j / nz}, j < nz  (w_M^j = wn[2 j]).
+__global__ __launch_bounds__(256) void k_mixed_r2c_finish(const double* src, double* dst, long nrows, int nzp, int M, int p,
+                                                          const cplx* wn) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = M / 2 + 1;
+  if (idx >= nrows * half) return;
+  const long row = idx / half;
+  const int k = (int)(idx % half);
+  const cplx* in = reinterpret_cast<const cplx*>(src + row * nzp);
+  cplx* out = reinterpret_cast<cplx*>(dst + row * nzp);
+  const int Mp = M / p, nz = 2 * M;
+  auto zfull = [&](int K) {   // Z[K], K in [0, M)
+    const int kk = K % Mp, sidx = K / Mp;
+    cplx acc = cmake(0.0, 0.0);
+    for (int r = 0; r < p; ++r) {
+      const cplx t = wn[(int)((2L * r * kk + 2L * r * sidx * Mp) % nz)];
+      acc = cadd(acc, cmul(in[p * kk + r], t));
+    }
+    return acc;
+  };
+  const cplx zk = zfull(k), zm = zfull((M - k) % M);
+  out[k] = r2c_split(zk, zm, wn[k]);
+  out[M - k] = r2c_split(zm, zk, wn[M - k]);   // k = 0 writes the Nyquist bin X[M] = split(Z[0], Z[0])
+}
+
+// inverse: merge the half spectrum into Z' (c2r_merge), then the inverse combine to the sub-rows:
+// thread k' < M' reads X[k' + M' s], X[M - k' - M' s] and writes Z_r[k'] to complex p k' + r.
+__global__ __launch_bounds__(256) void k_mixed_c2r_start(const double* src, double* dst, long nrows, int nzp, int M, int p,
+                                                         const cplx* wn) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Mp = M / p, nz = 2 * M;
+  if (idx >= nrows * Mp) return;
+  const long row = idx / Mp;
+  const int kk = (int)(idx % Mp);
+  const cplx* in = reinterpret_cast<const cplx*>(src + row * nzp);
+  cplx* out = reinterpret_cast<cplx*>(dst + row * nzp);
+  cplx z[kMaxOddFactor];
+  for (int sidx = 0; sidx < p; ++sidx) {
+    const int K = kk + Mp * sidx;
+    cplx xk = in[K], xm = in[M - K];
+    if (K == 0) { xk.im = 0.0; xm.im = 0.0; }   // FFTW's c2r ignores the imaginary parts of the DC and Nyquist bins
+    z[sidx] = c2r_merge(xk, xm, wn[K]);
+  }
+  for (int r = 0; r < p; ++r) {
+    cplx acc = cmake(0.0, 0.0);
+    for (int sidx = 0; sidx < p; ++sidx) acc = cadd(acc, cmul(z[sidx], cconj(wn[(int)((2L * r * sidx * Mp) % nz)])));
+    out[p * kk + r] = cmul(acc, cconj(wn[(int)((2L * r * kk) % nz)]));
+  }
+}
+
 cplx* upload(const std::vector<cplx>& v) {
   cplx* d = nullptr;
   FG_HIP_CHECK(hipMalloc(&d, v.size() * sizeof(cplx)));
@@ -232,6 +337,20 @@ void strided_n(const StridedArgs& a0, int nouter, int dir, int ncomp, long comp_
   else launch_strided<StridedKernel<N, C, +1>>(a, nblocks, ncomp, comp_stride, s);
 }
 
+void strided_pow2(int n, const StridedArgs& a, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
+  switch (n) {
+    case 8: strided_n<8>(a, nouter, dir, ncomp, cs, s); break;
+    case 16: strided_n<16>(a, nouter, dir, ncomp, cs, s); break;
+    case 32: strided_n<32>(a, nouter, dir, ncomp, cs, s); break;
+    case 64: strided_n<64>(a, nouter, dir, ncomp, cs, s); break;
+    case 128: strided_n<128>(a, nouter, dir, ncomp, cs, s); break;
+    case 256: strided_n<256>(a, nouter, dir, ncomp, cs, s); break;
+    case 512: strided_n<512>(a, nouter, dir, ncomp, cs, s); break;
+    case 1024: strided_n<1024>(a, nouter, dir, ncomp, cs, s); break;
+    default: throw std::runtime_error("fft: unsupported fast length");
+  }
+}
+
 }  // namespace
 
 Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(nullptr), scratch_(nullptr) {
@@ -246,10 +365,15 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
   fast_[2] = (g.nz % 2 == 0) && fast_len(g.nz / 2);
   bool need_scratch = false;
   for (int a = 0; a < 3; ++a) {
+    odd_[a] = 0;
     if (fast_[a]) {
       tw_[a] = upload(make_pass_twiddles(a == 2 ? len[a] / 2 : len[a]));
       if (a < 2) half_root_[a] = upload(make_unit_roots(2 * len[a], len[a] / 8));
     } else {
+      // p * 2^k: power-of-two kernels on the interleaved sub-lines + a combine sweep; anything else: O(n^2) DFT
+      const int m = a == 2 ? (len[a] % 2 == 0 ? len[a] / 2 : 0) : len[a];
+      odd_[a] = m ? mixed_factor(m) : 0;
+      if (odd_[a]) tw_[a] = upload(make_pass_twiddles(m / odd_[a]));
       wgen_[a] = upload(make_unit_roots(len[a], len[a]));
       need_scratch = true;
     }
@@ -287,17 +411,47 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
     a.scale = scale;
     a.tw = tw_[axis];
     a.nt = stream_stores_ ? (1 | ((nt_loads_env() & 1) ? 2 : 0)) : 0;
-    const long cs = comp_stride / 2;
-    switch (n) {
-      case 8: strided_n<8>(a, nouter, dir, ncomp, cs, stream_); break;
-      case 16: strided_n<16>(a, nouter, dir, ncomp, cs, stream_); break;
-      case 32: strided_n<32>(a, nouter, dir, ncomp, cs, stream_); break;
-      case 64: strided_n<64>(a, nouter, dir, ncomp, cs, stream_); break;
-      case 128: strided_n<128>(a, nouter, dir, ncomp, cs, stream_); break;
-      case 256: strided_n<256>(a, nouter, dir, ncomp, cs, stream_); break;
-      case 512: strided_n<512>(a, nouter, dir, ncomp, cs, stream_); break;
-      case 1024: strided_n<1024>(a, nouter, dir, ncomp, cs, stream_); break;
-      default: throw std::runtime_error("fft: unsupported fast length");
+    strided_pow2(n, a, nouter, dir, ncomp, comp_stride / 2, stream_);
+    return;
+  }
+  if (odd_[axis]) {
+    // n = p * m: m-point kernels on the p interleaved sub-lines, combine sweep through the scratch component
+    const int p = odd_[axis], m = n / p;
+    const long total = (long)nouter * m * ncols;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    auto subs = [&]() {
+      for (int r = 0; r < p; ++r) {
+        StridedArgs a;
+        a.data = reinterpret_cast<cplx*>(data) + r * ls;
+        a.ls = ls * p;
+        a.os = os;
+        a.ncols = ncols;
+        a.tiles_per_outer = 0;
+        a.scale = 1.0;
+        a.tw = tw_[axis];
+        a.nt = 0;
+        strided_pow2(m, a, nouter, dir, ncomp, comp_stride / 2, stream_);
+      }
+    };
+    auto combine = [&]() {
+      for (int c = 0; c < ncomp; ++c) {
+        cplx* src = reinterpret_cast<cplx*>(data + c * comp_stride);
+        if (dir < 0)
+          hipLaunchKernelGGL(k_mixed_combine<-1>, dim3(nb), dim3(256), 0, stream_, src, reinterpret_cast<cplx*>(scratch_), ls,
+                             os, ncols, nouter, m, p, scale, wgen_[axis]);
+        else
+          hipLaunchKernelGGL(k_mixed_combine<+1>, dim3(nb), dim3(256), 0, stream_, src, reinterpret_cast<cplx*>(scratch_), ls,
+                             os, ncols, nouter, m, p, scale, wgen_[axis]);
+        FG_HIP_CHECK(hipGetLastError());
+        FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+      }
+    };
+    if (dir < 0) {
+      subs();
+      combine();
+    } else {
+      combine();
+      subs();
     }
     return;
   }
@@ -378,6 +532,30 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
     }
     return;
   }
+  if (odd_[2]) {
+    // nz = 2 M, M = p m: m-point kernels on the sub-rows of the packed real rows ([m][p] complex, line stride p), then
+    // combine + real split per row through the scratch component
+    const int M = g_.nz / 2, p = odd_[2], m = M / p;
+    StridedArgs a;
+    a.data = reinterpret_cast<cplx*>(data);
+    a.ls = p;
+    a.os = g_.nzc;
+    a.ncols = p;
+    a.tiles_per_outer = 0;
+    a.scale = 1.0;
+    a.tw = tw_[2];
+    a.nt = 0;
+    strided_pow2(m, a, (int)nrows, -1, ncomp, comp_stride / 2, stream_);
+    const long total = nrows * (M / 2 + 1);
+    for (int c = 0; c < ncomp; ++c) {
+      double* src = data + c * comp_stride;
+      hipLaunchKernelGGL(k_mixed_r2c_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, src, scratch_, nrows,
+                         g_.nzp, M, p, wgen_[2]);
+      FG_HIP_CHECK(hipGetLastError());
+      FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    }
+    return;
+  }
   const long total = nrows * g_.nzc;
   const int bs = 256;
   for (int c = 0; c < ncomp; ++c) {
@@ -399,6 +577,28 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
 #undef FG_CASE
       default: throw std::runtime_error("fft: unsupported fast z length");
     }
+    return;
+  }
+  if (odd_[2]) {
+    const int M = g_.nz / 2, p = odd_[2], m = M / p;
+    const long total = nrows * m;
+    for (int c = 0; c < ncomp; ++c) {
+      double* src = data + c * comp_stride;
+      hipLaunchKernelGGL(k_mixed_c2r_start, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, src, scratch_, nrows,
+                         g_.nzp, M, p, wgen_[2]);
+      FG_HIP_CHECK(hipGetLastError());
+      FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    }
+    StridedArgs a;
+    a.data = reinterpret_cast<cplx*>(data);
+    a.ls = p;
+    a.os = g_.nzc;
+    a.ncols = p;
+    a.tiles_per_outer = 0;
+    a.scale = 1.0;
+    a.tw = tw_[2];
+    a.nt = 0;
+    strided_pow2(m, a, (int)nrows, +1, ncomp, comp_stride / 2, stream_);
     return;
   }
   const long total = nrows * g_.nz;

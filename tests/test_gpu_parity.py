@@ -25,6 +25,8 @@ GRIDS = [
     ((41, 33, 11), (41.0, 33.0, 11.0)),   # the reference's self-test grid F:27271 (odd, prime)
     ((10, 1, 1), (1.0, 1.0, 1.0)),        # laminate demo grid (demo/elasticity/laminate)
     ((8, 16, 5), (1.0, 1.0, 1.0)),        # odd nz
+    ((24, 40, 48), (1.0, 1.5, 2.0)),      # p * 2^k on every axis (3*8, 5*8, nz/2 = 3*8): sub-line kernels + combine sweep
+    ((56, 16, 80), (1.0, 1.0, 1.0)),      # 7*8, power of two, nz/2 = 5*8
 ]
 EXACT = {}
 
