@@ -150,7 +150,7 @@ int nt_loads_env() {
 
 bool fast_len(int n) { return is_pow2(n) && n >= 8 && n <= 1024; }
 
-// ---------------------------------------------------------------- lengths p * 2^k, p in {3, 5, 7}
+// ---------------------------------------------------------------- lengths p * 2^k, p odd <= 15
 // N = p M: the line is p interleaved sub-lines x_r[m] = x[p m + r] of the power-of-two length M.  Forward: the M-point
 // kernels transform the sub-lines in place (line stride p * ls), Y_r[k] then sits at point p k + r, and one combine
 // sweep forms  X[k + M s] = sum_r w_N^{r k} w_p^{r s} Y_r[k]  (out of place, through the scratch component).
@@ -159,12 +159,12 @@ bool fast_len(int n) { return is_pow2(n) && n >= 8 && n <= 1024; }
 int mixed_factor(int n) {   // p if n = p * 2^k with 2^k a fast length, else 0
   static const int off = getenv("FG_FFT_NO_MIXED") ? atoi(getenv("FG_FFT_NO_MIXED")) : 0;   // A/B knob: O(n^2) path
   if (off) return 0;
-  for (int p : {3, 5, 7})
+  for (int p : {3, 5, 7, 9, 11, 13, 15})
     if (n % p == 0 && fast_len(n / p)) return p;
   return 0;
 }
 
-constexpr int kMaxOddFactor = 7;
+constexpr int kMaxOddFactor = 15;
 
 // w: e^{-2 pi i j / N}, j < N
 template <int DIR>
