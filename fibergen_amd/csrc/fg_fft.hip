@@ -150,6 +150,8 @@ int nt_loads_env() {
 
 bool fast_len(int n) { return is_pow2(n) && n >= 8 && n <= 1024; }
 
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"   // the run-time-p instances keep their loops rolled
 // ---------------------------------------------------------------- lengths p * 2^k, p odd <= 15
 // N = p M: the line is p interleaved sub-lines x_r[m] = x[p m + r] of the power-of-two length M.  Forward: the M-point
 // kernels transform the sub-lines in place (line stride p * ls), Y_r[k] then sits at point p k + r, and one combine
@@ -167,9 +169,10 @@ int mixed_factor(int n) {   // p if n = p * 2^k with 2^k a fast length, else 0
 constexpr int kMaxOddFactor = 15;
 
 // w: e^{-2 pi i j / N}, j < N
-template <int DIR>
+template <int DIR, int P>   // P = 0: run-time p (indexed local arrays); 3, 5, 7: unrolled, everything in registers
 __global__ __launch_bounds__(256) void k_mixed_combine(const cplx* src, cplx* dst, long ls, long os, int ncols, int nouter,
-                                                       int M, int p, double scale, const cplx* w) {
+                                                       int M, int p_rt, double scale, const cplx* w) {
+  const int p = P ? P : p_rt;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)nouter * M * ncols;
   if (idx >= total) return;
@@ -178,21 +181,25 @@ __global__ __launch_bounds__(256) void k_mixed_combine(const cplx* src, cplx* ds
   const int k = (int)(rest % M);
   const long base = (rest / M) * os + col;
   const int N = p * M;
-  cplx in[kMaxOddFactor];
+  cplx in[P ? P : kMaxOddFactor];
+#pragma unroll
   for (int r = 0; r < p; ++r) {
     // forward: Y_r[k] at point p k + r;  inverse: X[k + M r] at its natural point
     const long pt = DIR < 0 ? (long)p * k + r : (long)k + (long)M * r;
     in[r] = src[base + pt * ls];
   }
+#pragma unroll
   for (int o = 0; o < p; ++o) {
     cplx acc = cmake(0.0, 0.0);
     if (DIR < 0) {   // output s = o:  sum_r w_N^{r k} w_p^{r s} Y_r
+#pragma unroll
       for (int r = 0; r < p; ++r) {
         const cplx t = w[(int)(((long)r * k + (long)r * o * M) % N)];
         acc = cadd(acc, cmul(in[r], t));
       }
       dst[base + ((long)k + (long)M * o) * ls] = cscale(scale, acc);
     } else {         // output r = o:  conj(w_N^{r k}) sum_s X_s conj(w_p^{r s})
+#pragma unroll
       for (int sidx = 0; sidx < p; ++sidx) {
         const cplx t = cconj(w[(int)(((long)o * sidx * M) % N)]);
         acc = cadd(acc, cmul(in[sidx], t));
@@ -206,8 +213,10 @@ __global__ __launch_bounds__(256) void k_mixed_combine(const cplx* src, cplx* ds
 // z axis, nz = 2 M, M = p M': after the M'-point sub-transforms of the packed rows (Y_r[k'] at complex p k' + r), one
 // sweep per row forms the M-point spectrum Z and splits it into the half spectrum of the real row (r2c_split):
 // thread k <= M/2 writes X[k] and X[M - k].  wn: e^{-2 pi i j / nz}, j < nz  (w_M^j = wn[2 j]).
-__global__ __launch_bounds__(256) void k_mixed_r2c_finish(const double* src, double* dst, long nrows, int nzp, int M, int p,
+template <int P>
+__global__ __launch_bounds__(256) void k_mixed_r2c_finish(const double* src, double* dst, long nrows, int nzp, int M, int p_rt,
                                                           const cplx* wn) {
+  const int p = P ? P : p_rt;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int half = M / 2 + 1;
   if (idx >= nrows * half) return;
@@ -219,6 +228,7 @@ __global__ __launch_bounds__(256) void k_mixed_r2c_finish(const double* src, dou
   auto zfull = [&](int K) {   // Z[K], K in [0, M)
     const int kk = K % Mp, sidx = K / Mp;
     cplx acc = cmake(0.0, 0.0);
+#pragma unroll
     for (int r = 0; r < p; ++r) {
       const cplx t = wn[(int)((2L * r * kk + 2L * r * sidx * Mp) % nz)];
       acc = cadd(acc, cmul(in[p * kk + r], t));
@@ -232,8 +242,10 @@ __global__ __launch_bounds__(256) void k_mixed_r2c_finish(const double* src, dou
 
 // inverse: merge the half spectrum into Z' (c2r_merge), then the inverse combine to the sub-rows:
 // thread k' < M' reads X[k' + M' s], X[M - k' - M' s] and writes Z_r[k'] to complex p k' + r.
-__global__ __launch_bounds__(256) void k_mixed_c2r_start(const double* src, double* dst, long nrows, int nzp, int M, int p,
+template <int P>
+__global__ __launch_bounds__(256) void k_mixed_c2r_start(const double* src, double* dst, long nrows, int nzp, int M, int p_rt,
                                                          const cplx* wn) {
+  const int p = P ? P : p_rt;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int Mp = M / p, nz = 2 * M;
   if (idx >= nrows * Mp) return;
@@ -241,19 +253,23 @@ __global__ __launch_bounds__(256) void k_mixed_c2r_start(const double* src, doub
   const int kk = (int)(idx % Mp);
   const cplx* in = reinterpret_cast<const cplx*>(src + row * nzp);
   cplx* out = reinterpret_cast<cplx*>(dst + row * nzp);
-  cplx z[kMaxOddFactor];
+  cplx z[P ? P : kMaxOddFactor];
+#pragma unroll
   for (int sidx = 0; sidx < p; ++sidx) {
     const int K = kk + Mp * sidx;
     cplx xk = in[K], xm = in[M - K];
     if (K == 0) { xk.im = 0.0; xm.im = 0.0; }   // FFTW's c2r ignores the imaginary parts of the DC and Nyquist bins
     z[sidx] = c2r_merge(xk, xm, wn[K]);
   }
+#pragma unroll
   for (int r = 0; r < p; ++r) {
     cplx acc = cmake(0.0, 0.0);
+#pragma unroll
     for (int sidx = 0; sidx < p; ++sidx) acc = cadd(acc, cmul(z[sidx], cconj(wn[(int)((2L * r * sidx * Mp) % nz)])));
     out[p * kk + r] = cmul(acc, cconj(wn[(int)((2L * r * kk) % nz)]));
   }
 }
+#pragma clang diagnostic pop
 
 cplx* upload(const std::vector<cplx>& v) {
   cplx* d = nullptr;
@@ -335,6 +351,29 @@ void strided_n(const StridedArgs& a0, int nouter, int dir, int ncomp, long comp_
   long nblocks = (long)a.tiles_per_outer * nouter;
   if (dir < 0) launch_strided<StridedKernel<N, C, -1>>(a, nblocks, ncomp, comp_stride, s);
   else launch_strided<StridedKernel<N, C, +1>>(a, nblocks, ncomp, comp_stride, s);
+}
+
+// the same with 8-column tiles whatever the length (sub-rows of the z pass have only p <= 15 columns)
+template <int N>
+void strided_n8(const StridedArgs& a0, int nouter, int dir, int ncomp, long comp_stride, hipStream_t s) {
+  StridedArgs a = a0;
+  a.tiles_per_outer = (a.ncols + 7) / 8;
+  long nblocks = (long)a.tiles_per_outer * nouter;
+  if (dir < 0) launch_strided<StridedKernel<N, 8, -1>>(a, nblocks, ncomp, comp_stride, s);
+  else launch_strided<StridedKernel<N, 8, +1>>(a, nblocks, ncomp, comp_stride, s);
+}
+void strided_pow2_narrow(int n, const StridedArgs& a, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
+  switch (n) {
+    case 8: strided_n8<8>(a, nouter, dir, ncomp, cs, s); break;
+    case 16: strided_n8<16>(a, nouter, dir, ncomp, cs, s); break;
+    case 32: strided_n8<32>(a, nouter, dir, ncomp, cs, s); break;
+    case 64: strided_n8<64>(a, nouter, dir, ncomp, cs, s); break;
+    case 128: strided_n8<128>(a, nouter, dir, ncomp, cs, s); break;
+    case 256: strided_n8<256>(a, nouter, dir, ncomp, cs, s); break;
+    case 512: strided_n8<512>(a, nouter, dir, ncomp, cs, s); break;
+    case 1024: strided_n8<1024>(a, nouter, dir, ncomp, cs, s); break;
+    default: throw std::runtime_error("fft: unsupported fast length");
+  }
 }
 
 void strided_pow2(int n, const StridedArgs& a, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
@@ -436,12 +475,21 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
     auto combine = [&]() {
       for (int c = 0; c < ncomp; ++c) {
         cplx* src = reinterpret_cast<cplx*>(data + c * comp_stride);
-        if (dir < 0)
-          hipLaunchKernelGGL(k_mixed_combine<-1>, dim3(nb), dim3(256), 0, stream_, src, reinterpret_cast<cplx*>(scratch_), ls,
-                             os, ncols, nouter, m, p, scale, wgen_[axis]);
-        else
-          hipLaunchKernelGGL(k_mixed_combine<+1>, dim3(nb), dim3(256), 0, stream_, src, reinterpret_cast<cplx*>(scratch_), ls,
-                             os, ncols, nouter, m, p, scale, wgen_[axis]);
+#define FG_COMBINE(D, PP)                                                                                              \
+  hipLaunchKernelGGL((k_mixed_combine<D, PP>), dim3(nb), dim3(256), 0, stream_, src, reinterpret_cast<cplx*>(scratch_), ls, \
+                     os, ncols, nouter, m, p, scale, wgen_[axis])
+        if (dir < 0) {
+          if (p == 3) FG_COMBINE(-1, 3);
+          else if (p == 5) FG_COMBINE(-1, 5);
+          else if (p == 7) FG_COMBINE(-1, 7);
+          else FG_COMBINE(-1, 0);
+        } else {
+          if (p == 3) FG_COMBINE(+1, 3);
+          else if (p == 5) FG_COMBINE(+1, 5);
+          else if (p == 7) FG_COMBINE(+1, 7);
+          else FG_COMBINE(+1, 0);
+        }
+#undef FG_COMBINE
         FG_HIP_CHECK(hipGetLastError());
         FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
       }
@@ -545,12 +593,18 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
     a.scale = 1.0;
     a.tw = tw_[2];
     a.nt = 0;
-    strided_pow2(m, a, (int)nrows, -1, ncomp, comp_stride / 2, stream_);
+    strided_pow2_narrow(m, a, (int)nrows, -1, ncomp, comp_stride / 2, stream_);
     const long total = nrows * (M / 2 + 1);
     for (int c = 0; c < ncomp; ++c) {
       double* src = data + c * comp_stride;
-      hipLaunchKernelGGL(k_mixed_r2c_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, src, scratch_, nrows,
-                         g_.nzp, M, p, wgen_[2]);
+#define FG_FINISH(PP)                                                                                                      \
+  hipLaunchKernelGGL(k_mixed_r2c_finish<PP>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, src, scratch_, nrows, \
+                     g_.nzp, M, p, wgen_[2])
+      if (p == 3) FG_FINISH(3);
+      else if (p == 5) FG_FINISH(5);
+      else if (p == 7) FG_FINISH(7);
+      else FG_FINISH(0);
+#undef FG_FINISH
       FG_HIP_CHECK(hipGetLastError());
       FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     }
@@ -584,8 +638,14 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
     const long total = nrows * m;
     for (int c = 0; c < ncomp; ++c) {
       double* src = data + c * comp_stride;
-      hipLaunchKernelGGL(k_mixed_c2r_start, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, src, scratch_, nrows,
-                         g_.nzp, M, p, wgen_[2]);
+#define FG_START(PP)                                                                                                       \
+  hipLaunchKernelGGL(k_mixed_c2r_start<PP>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, src, scratch_, nrows, \
+                     g_.nzp, M, p, wgen_[2])
+      if (p == 3) FG_START(3);
+      else if (p == 5) FG_START(5);
+      else if (p == 7) FG_START(7);
+      else FG_START(0);
+#undef FG_START
       FG_HIP_CHECK(hipGetLastError());
       FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     }
@@ -598,7 +658,7 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
     a.scale = 1.0;
     a.tw = tw_[2];
     a.nt = 0;
-    strided_pow2(m, a, (int)nrows, +1, ncomp, comp_stride / 2, stream_);
+    strided_pow2_narrow(m, a, (int)nrows, +1, ncomp, comp_stride / 2, stream_);
     return;
   }
   const long total = nrows * g_.nz;
