@@ -210,21 +210,68 @@ __global__ __launch_bounds__(256) void k_mixed_combine(const cplx* src, cplx* ds
   }
 }
 
+// The same combine in place: a workgroup owns whole lines (a tile of 8 adjacent columns x all N points), computes every
+// output of the tile into LDS, and only after a barrier writes the tile back -- no scratch component, no copy
+// (2x instead of 3x the traffic of a native pass).  N * 128 bytes of LDS: used while that fits (N <= 1152).
+template <int DIR, int P>
+__global__ __launch_bounds__(256) void k_mixed_combine_tile(cplx* data, long ls, long os, int ncols, int tiles_per_outer, int M,
+                                                            int p_rt, double scale, const cplx* w) {
+  extern __shared__ __align__(16) double lds_raw[];
+  cplx* img = reinterpret_cast<cplx*>(lds_raw);   // [N][8]
+  const int p = P ? P : p_rt;
+  const int N = p * M;
+  const int o = blockIdx.x / tiles_per_outer;
+  const int col0 = (blockIdx.x % tiles_per_outer) * 8;
+  const int t = threadIdx.x & 7;
+  const bool valid = col0 + t < ncols;
+  const long base = (long)o * os + col0 + t;
+  for (int k = (int)(threadIdx.x >> 3); k < M; k += 32) {
+    cplx in[P ? P : kMaxOddFactor];
+#pragma unroll
+    for (int r = 0; r < p; ++r) {
+      const long pt = DIR < 0 ? (long)p * k + r : (long)k + (long)M * r;
+      in[r] = valid ? data[base + pt * ls] : cmake(0.0, 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < p; ++q) {
+      cplx acc = cmake(0.0, 0.0);
+      if (DIR < 0) {
+#pragma unroll
+        for (int r = 0; r < p; ++r) acc = cadd(acc, cmul(in[r], w[(int)(((long)r * k + (long)r * q * M) % N)]));
+        img[(k + M * q) * 8 + t] = cscale(scale, acc);
+      } else {
+#pragma unroll
+        for (int sidx = 0; sidx < p; ++sidx) acc = cadd(acc, cmul(in[sidx], cconj(w[(int)(((long)q * sidx * M) % N)])));
+        img[(p * k + q) * 8 + t] = cscale(scale, cmul(acc, cconj(w[(int)(((long)q * k) % N)])));
+      }
+    }
+  }
+  __syncthreads();
+  if (valid)
+    for (int pt = (int)(threadIdx.x >> 3); pt < N; pt += 32) data[base + (long)pt * ls] = img[pt * 8 + t];
+}
+
 // z axis, nz = 2 M, M = p M': after the M'-point sub-transforms of the packed rows (Y_r[k'] at complex p k' + r), one
 // sweep per row forms the M-point spectrum Z and splits it into the half spectrum of the real row (r2c_split):
 // thread k <= M/2 writes X[k] and X[M - k].  wn: e^{-2 pi i j / nz}, j < nz  (w_M^j = wn[2 j]).
+// Both z sweeps work in place: a workgroup owns `rows` whole rows, forms their outputs in an LDS image and writes them
+// back after a barrier (no scratch component, no copy).
 template <int P>
-__global__ __launch_bounds__(256) void k_mixed_r2c_finish(const double* src, double* dst, long nrows, int nzp, int M, int p_rt,
+__global__ __launch_bounds__(256) void k_mixed_r2c_finish(double* data, long nrows, int nzp, int M, int p_rt, int rows,
                                                           const cplx* wn) {
+  extern __shared__ __align__(16) double lds_raw[];
+  cplx* img = reinterpret_cast<cplx*>(lds_raw);   // [rows][M + 1]
   const int p = P ? P : p_rt;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int half = M / 2 + 1;
-  if (idx >= nrows * half) return;
-  const long row = idx / half;
-  const int k = (int)(idx % half);
-  const cplx* in = reinterpret_cast<const cplx*>(src + row * nzp);
-  cplx* out = reinterpret_cast<cplx*>(dst + row * nzp);
+  const long row0 = (long)blockIdx.x * rows;
   const int Mp = M / p, nz = 2 * M;
+  for (int it = threadIdx.x; it < rows * half; it += 256) {
+  const int lr = it / half;
+  const long row = row0 + lr;
+  if (row >= nrows) break;
+  const int k = it % half;
+  const cplx* in = reinterpret_cast<const cplx*>(data + row * nzp);
+  cplx* out = img + (long)lr * (M + 1);
   auto zfull = [&](int K) {   // Z[K], K in [0, M)
     const int kk = K % Mp, sidx = K / Mp;
     cplx acc = cmake(0.0, 0.0);
@@ -238,21 +285,32 @@ __global__ __launch_bounds__(256) void k_mixed_r2c_finish(const double* src, dou
   const cplx zk = zfull(k), zm = zfull((M - k) % M);
   out[k] = r2c_split(zk, zm, wn[k]);
   out[M - k] = r2c_split(zm, zk, wn[M - k]);   // k = 0 writes the Nyquist bin X[M] = split(Z[0], Z[0])
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < rows * (M + 1); it += 256) {
+    const int lr = it / (M + 1);
+    if (row0 + lr >= nrows) break;
+    reinterpret_cast<cplx*>(data + (row0 + lr) * nzp)[it % (M + 1)] = img[it];
+  }
 }
 
 // inverse: merge the half spectrum into Z' (c2r_merge), then the inverse combine to the sub-rows:
 // thread k' < M' reads X[k' + M' s], X[M - k' - M' s] and writes Z_r[k'] to complex p k' + r.
 template <int P>
-__global__ __launch_bounds__(256) void k_mixed_c2r_start(const double* src, double* dst, long nrows, int nzp, int M, int p_rt,
+__global__ __launch_bounds__(256) void k_mixed_c2r_start(double* data, long nrows, int nzp, int M, int p_rt, int rows,
                                                          const cplx* wn) {
+  extern __shared__ __align__(16) double lds_raw[];
+  cplx* img = reinterpret_cast<cplx*>(lds_raw);   // [rows][M]
   const int p = P ? P : p_rt;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int Mp = M / p, nz = 2 * M;
-  if (idx >= nrows * Mp) return;
-  const long row = idx / Mp;
-  const int kk = (int)(idx % Mp);
-  const cplx* in = reinterpret_cast<const cplx*>(src + row * nzp);
-  cplx* out = reinterpret_cast<cplx*>(dst + row * nzp);
+  const long row0 = (long)blockIdx.x * rows;
+  for (int it = threadIdx.x; it < rows * Mp; it += 256) {
+  const int lr = it / Mp;
+  const long row = row0 + lr;
+  if (row >= nrows) break;
+  const int kk = it % Mp;
+  const cplx* in = reinterpret_cast<const cplx*>(data + row * nzp);
+  cplx* out = img + (long)lr * M;
   cplx z[P ? P : kMaxOddFactor];
 #pragma unroll
   for (int sidx = 0; sidx < p; ++sidx) {
@@ -267,6 +325,13 @@ __global__ __launch_bounds__(256) void k_mixed_c2r_start(const double* src, doub
 #pragma unroll
     for (int sidx = 0; sidx < p; ++sidx) acc = cadd(acc, cmul(z[sidx], cconj(wn[(int)((2L * r * sidx * Mp) % nz)])));
     out[p * kk + r] = cmul(acc, cconj(wn[(int)((2L * r * kk) % nz)]));
+  }
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < rows * M; it += 256) {
+    const int lr = it / M;
+    if (row0 + lr >= nrows) break;
+    reinterpret_cast<cplx*>(data + (row0 + lr) * nzp)[it % M] = img[it];
   }
 }
 #pragma clang diagnostic pop
@@ -472,7 +537,39 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
         strided_pow2(m, a, nouter, dir, ncomp, comp_stride / 2, stream_);
       }
     };
-    auto combine = [&]() {
+    const size_t tile_lds = (size_t)n * 8 * sizeof(cplx);
+    auto combine_tile = [&]() {
+      const int tiles = (ncols + 7) / 8;
+      const dim3 grid((unsigned)((long)tiles * nouter));
+      for (int c = 0; c < ncomp; ++c) {
+        cplx* d = reinterpret_cast<cplx*>(data + c * comp_stride);
+#define FG_TILE_COMBINE(D, PP)                                                                                         \
+  do {                                                                                                                 \
+    static bool configured = false;                                                                                    \
+    if (!configured) {                                                                                                 \
+      FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixed_combine_tile<D, PP>),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
+      configured = true;                                                                                               \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((k_mixed_combine_tile<D, PP>), grid, dim3(256), tile_lds, stream_, d, ls, os, ncols, tiles, m, p, \
+                       scale, wgen_[axis]);                                                                            \
+  } while (0)
+        if (dir < 0) {
+          if (p == 3) FG_TILE_COMBINE(-1, 3);
+          else if (p == 5) FG_TILE_COMBINE(-1, 5);
+          else if (p == 7) FG_TILE_COMBINE(-1, 7);
+          else FG_TILE_COMBINE(-1, 0);
+        } else {
+          if (p == 3) FG_TILE_COMBINE(+1, 3);
+          else if (p == 5) FG_TILE_COMBINE(+1, 5);
+          else if (p == 7) FG_TILE_COMBINE(+1, 7);
+          else FG_TILE_COMBINE(+1, 0);
+        }
+#undef FG_TILE_COMBINE
+        FG_HIP_CHECK(hipGetLastError());
+      }
+    };
+    auto combine_scratch = [&]() {
       for (int c = 0; c < ncomp; ++c) {
         cplx* src = reinterpret_cast<cplx*>(data + c * comp_stride);
 #define FG_COMBINE(D, PP)                                                                                              \
@@ -493,6 +590,10 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
         FG_HIP_CHECK(hipGetLastError());
         FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
       }
+    };
+    auto combine = [&]() {
+      if (tile_lds <= 144 * 1024) combine_tile();   // whole lines in LDS: in place
+      else combine_scratch();
     };
     if (dir < 0) {
       subs();
@@ -594,19 +695,30 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
     a.tw = tw_[2];
     a.nt = 0;
     strided_pow2_narrow(m, a, (int)nrows, -1, ncomp, comp_stride / 2, stream_);
-    const long total = nrows * (M / 2 + 1);
+    if ((size_t)(M + 1) * sizeof(cplx) > 144 * 1024) throw std::runtime_error("fft: z length too large for the sub-line path");
+    int rows = (int)(48 * 1024 / ((M + 1) * sizeof(cplx)));   // rows per workgroup: 48 KB of LDS
+    if (rows < 1) rows = 1;
+    const size_t lds = (size_t)rows * (M + 1) * sizeof(cplx);
+    const unsigned nb = (unsigned)((nrows + rows - 1) / rows);
     for (int c = 0; c < ncomp; ++c) {
       double* src = data + c * comp_stride;
-#define FG_FINISH(PP)                                                                                                      \
-  hipLaunchKernelGGL(k_mixed_r2c_finish<PP>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, src, scratch_, nrows, \
-                     g_.nzp, M, p, wgen_[2])
+#define FG_FINISH(PP)                                                                                             \
+  do {                                                                                                            \
+    static bool configured = false;                                                                               \
+    if (!configured) {                                                                                            \
+      FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixed_r2c_finish<PP>),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
+      configured = true;                                                                                          \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k_mixed_r2c_finish<PP>, dim3(nb), dim3(256), lds, stream_, src, nrows, g_.nzp, M, p, rows, \
+                       wgen_[2]);                                                                                 \
+  } while (0)
       if (p == 3) FG_FINISH(3);
       else if (p == 5) FG_FINISH(5);
       else if (p == 7) FG_FINISH(7);
       else FG_FINISH(0);
 #undef FG_FINISH
       FG_HIP_CHECK(hipGetLastError());
-      FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     }
     return;
   }
@@ -635,19 +747,29 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
   }
   if (odd_[2]) {
     const int M = g_.nz / 2, p = odd_[2], m = M / p;
-    const long total = nrows * m;
+    int rows = (int)(48 * 1024 / ((M + 1) * sizeof(cplx)));
+    if (rows < 1) rows = 1;
+    const size_t lds = (size_t)rows * (M + 1) * sizeof(cplx);
+    const unsigned nb = (unsigned)((nrows + rows - 1) / rows);
     for (int c = 0; c < ncomp; ++c) {
       double* src = data + c * comp_stride;
-#define FG_START(PP)                                                                                                       \
-  hipLaunchKernelGGL(k_mixed_c2r_start<PP>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, src, scratch_, nrows, \
-                     g_.nzp, M, p, wgen_[2])
+#define FG_START(PP)                                                                                             \
+  do {                                                                                                           \
+    static bool configured = false;                                                                              \
+    if (!configured) {                                                                                           \
+      FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixed_c2r_start<PP>),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
+      configured = true;                                                                                         \
+    }                                                                                                            \
+    hipLaunchKernelGGL(k_mixed_c2r_start<PP>, dim3(nb), dim3(256), lds, stream_, src, nrows, g_.nzp, M, p, rows, \
+                       wgen_[2]);                                                                                \
+  } while (0)
       if (p == 3) FG_START(3);
       else if (p == 5) FG_START(5);
       else if (p == 7) FG_START(7);
       else FG_START(0);
 #undef FG_START
       FG_HIP_CHECK(hipGetLastError());
-      FG_HIP_CHECK(hipMemcpyAsync(src, scratch_, g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     }
     StridedArgs a;
     a.data = reinterpret_cast<cplx*>(data);
