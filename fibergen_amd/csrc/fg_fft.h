@@ -54,7 +54,7 @@ class Fft3 {
   Grid g_;
   hipStream_t stream_;
   bool fast_[3];
-  int odd_[3];       // odd p <= 15: the axis length (z: nz/2) is that factor times a fast power of two; 0 otherwise
+  int odd_[3];       // odd p <= 25: the axis length (z: nz/2) is that factor times a fast power of two; 0 otherwise
   int stream_stores_ = 0;  // FFT passes use cache-bypassing stores (fields larger than the Infinity Cache)
   cplx* tw_[3];      // per-axis pass twiddles (fast path) ; z: for M = nz/2
   cplx* half_root_[2];  // e^{-i pi j/n}, j < n/8, of x and y (fused Green-operator pass)

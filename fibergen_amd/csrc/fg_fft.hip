@@ -152,21 +152,23 @@ bool fast_len(int n) { return is_pow2(n) && n >= 8 && n <= 1024; }
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"   // the run-time-p instances keep their loops rolled
-// ---------------------------------------------------------------- lengths p * 2^k, p odd <= 15
+// ---------------------------------------------------------------- lengths p * 2^k, p odd <= 25
 // N = p M: the line is p interleaved sub-lines x_r[m] = x[p m + r] of the power-of-two length M.  Forward: the M-point
 // kernels transform the sub-lines in place (line stride p * ls), Y_r[k] then sits at point p k + r, and one combine
 // sweep forms  X[k + M s] = sum_r w_N^{r k} w_p^{r s} Y_r[k]  (out of place, through the scratch component).
 // Inverse: the combine sweep first,  Z_r[k] = conj(w_N^{r k}) sum_s X[k + M s] conj(w_p^{r s})  to point p k + r,
 // then the M-point inverse kernels on the sub-lines.  3x the traffic of a native pass instead of an O(N^2) DFT.
+constexpr int kMaxOddFactor = 25;   // 25: the decimal sizes 200, 400, 800
+
 int mixed_factor(int n) {   // p if n = p * 2^k with 2^k a fast length, else 0
   static const int off = getenv("FG_FFT_NO_MIXED") ? atoi(getenv("FG_FFT_NO_MIXED")) : 0;   // A/B knob: O(n^2) path
   if (off) return 0;
-  for (int p : {3, 5, 7, 9, 11, 13, 15})
+  for (int p = 3; p <= kMaxOddFactor; p += 2)
     if (n % p == 0 && fast_len(n / p)) return p;
   return 0;
 }
 
-constexpr int kMaxOddFactor = 15;
+
 
 // w: e^{-2 pi i j / N}, j < N
 template <int DIR, int P>   // P = 0: run-time p (indexed local arrays); 3, 5, 7: unrolled, everything in registers
@@ -191,20 +193,27 @@ __global__ __launch_bounds__(256) void k_mixed_combine(const cplx* src, cplx* ds
 #pragma unroll
   for (int o = 0; o < p; ++o) {
     cplx acc = cmake(0.0, 0.0);
-    if (DIR < 0) {   // output s = o:  sum_r w_N^{r k} w_p^{r s} Y_r
+    // the table index r * step mod N advances by step with one conditional subtraction (no division)
+    if (DIR < 0) {   // output s = o:  sum_r w_N^{r (k + M s)} Y_r
+      const int step = k + M * o;   // < N
+      int idx = 0;
 #pragma unroll
       for (int r = 0; r < p; ++r) {
-        const cplx t = w[(int)(((long)r * k + (long)r * o * M) % N)];
-        acc = cadd(acc, cmul(in[r], t));
+        acc = cadd(acc, cmul(in[r], w[idx]));
+        idx += step;
+        if (idx >= N) idx -= N;
       }
       dst[base + ((long)k + (long)M * o) * ls] = cscale(scale, acc);
     } else {         // output r = o:  conj(w_N^{r k}) sum_s X_s conj(w_p^{r s})
+      const int step = (int)(((long)o * M) % N);
+      int idx = 0;
 #pragma unroll
       for (int sidx = 0; sidx < p; ++sidx) {
-        const cplx t = cconj(w[(int)(((long)o * sidx * M) % N)]);
-        acc = cadd(acc, cmul(in[sidx], t));
+        acc = cadd(acc, cmul(in[sidx], cconj(w[idx])));
+        idx += step;
+        if (idx >= N) idx -= N;
       }
-      acc = cmul(acc, cconj(w[(int)(((long)o * k) % N)]));
+      acc = cmul(acc, cconj(w[o * k]));   // o k < N
       dst[base + ((long)p * k + o) * ls] = cscale(scale, acc);
     }
   }
@@ -236,13 +245,25 @@ __global__ __launch_bounds__(256) void k_mixed_combine_tile(cplx* data, long ls,
     for (int q = 0; q < p; ++q) {
       cplx acc = cmake(0.0, 0.0);
       if (DIR < 0) {
+        const int step = k + M * q;
+        int idx = 0;
 #pragma unroll
-        for (int r = 0; r < p; ++r) acc = cadd(acc, cmul(in[r], w[(int)(((long)r * k + (long)r * q * M) % N)]));
+        for (int r = 0; r < p; ++r) {
+          acc = cadd(acc, cmul(in[r], w[idx]));
+          idx += step;
+          if (idx >= N) idx -= N;
+        }
         img[(k + M * q) * 8 + t] = cscale(scale, acc);
       } else {
+        const int step = (int)(((long)q * M) % N);
+        int idx = 0;
 #pragma unroll
-        for (int sidx = 0; sidx < p; ++sidx) acc = cadd(acc, cmul(in[sidx], cconj(w[(int)(((long)q * sidx * M) % N)])));
-        img[(p * k + q) * 8 + t] = cscale(scale, cmul(acc, cconj(w[(int)(((long)q * k) % N)])));
+        for (int sidx = 0; sidx < p; ++sidx) {
+          acc = cadd(acc, cmul(in[sidx], cconj(w[idx])));
+          idx += step;
+          if (idx >= N) idx -= N;
+        }
+        img[(p * k + q) * 8 + t] = cscale(scale, cmul(acc, cconj(w[q * k])));
       }
     }
   }
@@ -275,10 +296,13 @@ __global__ __launch_bounds__(256) void k_mixed_r2c_finish(double* data, long nro
   auto zfull = [&](int K) {   // Z[K], K in [0, M)
     const int kk = K % Mp, sidx = K / Mp;
     cplx acc = cmake(0.0, 0.0);
+    const int step = 2 * (kk + sidx * Mp);   // = 2 K < nz
+    int idx = 0;
 #pragma unroll
     for (int r = 0; r < p; ++r) {
-      const cplx t = wn[(int)((2L * r * kk + 2L * r * sidx * Mp) % nz)];
-      acc = cadd(acc, cmul(in[p * kk + r], t));
+      acc = cadd(acc, cmul(in[p * kk + r], wn[idx]));
+      idx += step;
+      if (idx >= nz) idx -= nz;
     }
     return acc;
   };
@@ -322,9 +346,15 @@ __global__ __launch_bounds__(256) void k_mixed_c2r_start(double* data, long nrow
 #pragma unroll
   for (int r = 0; r < p; ++r) {
     cplx acc = cmake(0.0, 0.0);
+    const int step = (int)((2L * r * Mp) % nz);
+    int idx = 0;
 #pragma unroll
-    for (int sidx = 0; sidx < p; ++sidx) acc = cadd(acc, cmul(z[sidx], cconj(wn[(int)((2L * r * sidx * Mp) % nz)])));
-    out[p * kk + r] = cmul(acc, cconj(wn[(int)((2L * r * kk) % nz)]));
+    for (int sidx = 0; sidx < p; ++sidx) {
+      acc = cadd(acc, cmul(z[sidx], cconj(wn[idx])));
+      idx += step;
+      if (idx >= nz) idx -= nz;
+    }
+    out[p * kk + r] = cmul(acc, cconj(wn[2 * r * kk]));   // 2 r k' < nz
   }
   }
   __syncthreads();
@@ -558,11 +588,17 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
           if (p == 3) FG_TILE_COMBINE(-1, 3);
           else if (p == 5) FG_TILE_COMBINE(-1, 5);
           else if (p == 7) FG_TILE_COMBINE(-1, 7);
+          else if (p == 9) FG_TILE_COMBINE(-1, 9);
+          else if (p == 15) FG_TILE_COMBINE(-1, 15);
+          else if (p == 25) FG_TILE_COMBINE(-1, 25);
           else FG_TILE_COMBINE(-1, 0);
         } else {
           if (p == 3) FG_TILE_COMBINE(+1, 3);
           else if (p == 5) FG_TILE_COMBINE(+1, 5);
           else if (p == 7) FG_TILE_COMBINE(+1, 7);
+          else if (p == 9) FG_TILE_COMBINE(+1, 9);
+          else if (p == 15) FG_TILE_COMBINE(+1, 15);
+          else if (p == 25) FG_TILE_COMBINE(+1, 25);
           else FG_TILE_COMBINE(+1, 0);
         }
 #undef FG_TILE_COMBINE
@@ -716,6 +752,9 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
       if (p == 3) FG_FINISH(3);
       else if (p == 5) FG_FINISH(5);
       else if (p == 7) FG_FINISH(7);
+      else if (p == 9) FG_FINISH(9);
+      else if (p == 15) FG_FINISH(15);
+      else if (p == 25) FG_FINISH(25);
       else FG_FINISH(0);
 #undef FG_FINISH
       FG_HIP_CHECK(hipGetLastError());
@@ -767,6 +806,9 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
       if (p == 3) FG_START(3);
       else if (p == 5) FG_START(5);
       else if (p == 7) FG_START(7);
+      else if (p == 9) FG_START(9);
+      else if (p == 15) FG_START(15);
+      else if (p == 25) FG_START(25);
       else FG_START(0);
 #undef FG_START
       FG_HIP_CHECK(hipGetLastError());

@@ -28,6 +28,7 @@ GRIDS = [
     ((24, 40, 48), (1.0, 1.5, 2.0)),      # p * 2^k on every axis (3*8, 5*8, nz/2 = 3*8): sub-line kernels + combine sweep
     ((56, 16, 80), (1.0, 1.0, 1.0)),      # 7*8, power of two, nz/2 = 5*8
     ((72, 24, 240), (1.0, 1.0, 1.0)),     # 9*8, 3*8, nz/2 = 15*8
+    ((200, 8, 400), (1.0, 1.0, 1.0)),     # 25*8, nz/2 = 25*8
 ]
 EXACT = {}
 
