@@ -104,3 +104,14 @@ def test_pass_is_affine_at_256():
     s.close()
     ref = 0.25 * out[0] + 0.75 * out[1]
     assert np.abs(out[2] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_hbm_stream_helper():
+    """fg_hbm_stream (the measured roofline bench.py reports): plausible copy / triad rates on an MI355X."""
+    import ctypes
+    from fibergen_amd import _lib
+    lib = _lib.load()
+    c, t = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    assert lib.fg_hbm_stream(0, 512, 2, ctypes.byref(c), ctypes.byref(t)) == 0
+    assert 1000.0 < c.value < 8000.0 and 1000.0 < t.value < 8000.0
+    assert lib.fg_hbm_stream(0, 0, 1, ctypes.byref(c), ctypes.byref(t)) != 0   # bad size: error code, no exception
