@@ -79,3 +79,45 @@ def test_generic_dft(emu, n):
     emu.emu_c2r_generic(P(src), P(dst), n, ctypes.c_long(nrows))
     ref = np.fft.irfft(X, n=n, axis=1) * n
     assert np.abs(dst[:, :n] - ref).max() < 1e-12 * max(1, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("N", [8, 32, 64, 128, 256, 512])
+def test_fused_x_pass(emu, N):
+    """The fused kernel of the hot loop (x-FFT, 1/N, Green operator with the transformed axis' factors rebuilt from
+    e^{i pi kx/N}, inverse x-FFT) run thread by thread on the host against numpy: G0OperatorFourierStaggeredGeneral
+    F:19834-19927 per frequency, padding columns (kz >= nzf) passed through, zero frequency set to zero."""
+    rng = np.random.default_rng(N)
+    ny, nzc, nzf = 3, 8, 6           # ragged: 24 columns, the last two kz of every row are padding
+    ncols = ny * nzc
+    x = rng.standard_normal((3, N, ncols)) + 1j * rng.standard_normal((3, N, ncols))
+    h = [1.0 / (2 * N), 2.0 / (2 * ny), 0.5 / (2 * 10)]
+
+    def tables(n, cnt, hh):
+        half = n // 2 - 1 if n % 2 == 0 else n // 2
+        idx = np.arange(cnt)
+        xi = (np.pi / n) * np.where(idx <= half, idx, idx - n)
+        kpm = np.sin(xi) / hh
+        return kpm, kpm * np.exp(1j * xi)
+    kpm0, kp0 = tables(N, N, h[0])
+    kpm1, kp1 = tables(ny, ny, h[1])
+    kpm2, kp2 = tables(10, nzc, h[2])
+    c10, c20, scale = -1.0 / 0.9, -1.0 / (0.9 * (1 + 0.9 / 1.1)), 1.0 / N
+    y = x.copy()
+    args = [np.ascontiguousarray(a) for a in (kpm0, kp0.view(np.float64), kpm1, kp1.view(np.float64), kpm2,
+                                               kp2.view(np.float64))]
+    assert emu.emu_xfused(N, P(y.view(np.float64)), ny, nzc, nzf, ctypes.c_double(scale), ctypes.c_double(c10),
+                          ctypes.c_double(c20), *[P(a) for a in args]) == 0
+    F = np.fft.fft(x, axis=1) * scale
+    jj, kk = np.divmod(np.arange(ncols), nzc)
+    K0, K1, K2 = kp0[:, None], kp1[jj][None, :], kp2[kk][None, :]
+    n2 = (kpm0 ** 2)[:, None] + (kpm1[jj] ** 2)[None, :] + (kpm2[kk] ** 2)[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        c1, c2 = c10 / n2, c20 / (n2 * n2)
+        sdot = F[0] * K0 + F[1] * K1 + F[2] * K2
+        G = np.stack([c1 * F[0] + c2 * sdot * (-np.conj(K0)), c1 * F[1] + c2 * sdot * (-np.conj(K1)),
+                      c1 * F[2] + c2 * sdot * (-np.conj(K2))])
+    G[:, 0, 0] = 0.0                      # zero frequency (kx = ky = kz = 0)
+    live = (kk < nzf)[None, None, :]
+    G = np.where(live, G, F)              # padding columns: scaled spectrum passed through
+    ref = np.fft.ifft(G, axis=1) * N
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-12
