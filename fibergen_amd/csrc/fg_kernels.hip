@@ -770,7 +770,10 @@ __global__ __launch_bounds__(kBlock) void k_cgu_dot(Grid g, FieldPtrs<3> a, Fiel
 //   MODE 1:  y = r + a y                          (u_p = u_r + beta u_p)
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_cgu_axpy(long n2, FieldPtrs<3> x, FieldPtrs<3> y, FieldPtrs<3> r, FieldPtrs<3> w,
-                                                     double a) {
+                                                     const double* sc, int i_num, int i_den, double nvox, double small) {
+  // the CG coefficient stays on the device: a = (sc[num] / N + tiny) / (sc[den] / N + tiny) from the sums the dot
+  // sweeps left there (alpha = gamma / (p:(p - w)),  beta = delta / gamma  F:23201-23240), no host round trip
+  const double a = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -794,11 +797,7 @@ __global__ __launch_bounds__(kBlock) void k_cgu_axpy(long n2, FieldPtrs<3> x, Fi
   }
 }
 
-// ----------------------------------------------------------------------------- laminate rule at interface voxels only
-// The laminate rule differs from Voigt mixing only where a voxel holds two phases (pure voxels take the same Hooke
-// branch, F:13464-13470 vs F:12752-12761), and its one-step Newton solve is ~400 flop with a large register
-// footprint.  So the sweep over all voxels runs the cheap Voigt form of k_u_stress, and this kernel then re-evaluates
-// the polarisation at the interface voxels alone, from a compact list built once per geometry.
+// ----------------------------------------------------------------------------- voxel lists of the laminate correction
 // Ordered stream compaction for the voxel lists below: a workgroup owns kCompactChunk consecutive voxels, counts its
 // flagged voxels (pass 1, offsets == nullptr), and after an exclusive scan of the workgroup counts writes them in
 // voxel order (pass 2).  Sorted lists keep the gathers of the per-pass kernels on neighbouring cache lines, and the
@@ -1383,11 +1382,11 @@ void launch_cgu_dot(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldP
 }
 
 void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r,
-                     const FieldPtrs<3>& w, double a, hipStream_t s) {
+                     const FieldPtrs<3>& w, const double* sc, int i_num, int i_den, double nvox, double small, hipStream_t s) {
   const long n2 = g.n / 2;
   const dim3 grid(grid_for(n2, 1 << 16));
-  if (mode == 0) hipLaunchKernelGGL((k_cgu_axpy<0>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, a);
-  else hipLaunchKernelGGL((k_cgu_axpy<1>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, a);
+  if (mode == 0) hipLaunchKernelGGL((k_cgu_axpy<0>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, sc, i_num, i_den, nvox, small);
+  else hipLaunchKernelGGL((k_cgu_axpy<1>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, sc, i_num, i_den, nvox, small);
   FG_HIP_CHECK(hipGetLastError());
 }
 

@@ -22,7 +22,8 @@ constexpr int kSlotMean = 6;     // 6
 constexpr int kSlotMinMax = 12;  // 2
 constexpr int kSlotMisc = 14;    // 2
 constexpr int kSlotScratch = 16; // 6: sums nobody reads (strain materialisation)
-constexpr int kNumSlots = 24;
+constexpr int kSlotCg = 24;      // displacement CG: two blocks of 8 (norms of eps [6] + r:r, alternating per iteration), then p:(p-w) [8]
+constexpr int kNumSlots = 48;
 
 double now_seconds() {
   using clk = std::chrono::steady_clock;
@@ -1045,10 +1046,6 @@ bool Solver::run_cg_u(const double* E0) {
   if (opt_.update_ref) calc_ref_material();
   Vec6 E, Z;
   for (int i = 0; i < 6; ++i) E.v[i] = E0[i], Z.v[i] = 0.0;   // Q = 0: calcBCMean leaves E0
-  auto fetch = [&](int slot, int n) {
-    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + slot, dscal_ + slot, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    check_device_error("cg");
-  };
   // the operator on a displacement: u -> f = div((C - C0)(Eadd + grad_s u)) -> FFT chain (alpha = -1) -> fu_alt_
   auto apply = [&](double* u_in, const double* Eadd) {
     double* keep = fu_;
@@ -1059,41 +1056,55 @@ bool Solver::run_cg_u(const double* E0) {
     fft_g0_chain(fu_alt_, z_done_);
   };
   // eps_0 = E (u_e = 0);  r = -Gamma0 (C - C0) E  (+ E - eps_0 = 0, adjustResidual F:10012-10022)
+  // The CG scalars stay on the device (k_cgu_axpy forms alpha and beta from the sums the dot sweeps leave in
+  // dscal_): the host fetches only the seven sums of the stop rule, and -- when no callback can look at the state
+  // in between -- has already enqueued the next direction update and operator application when it waits for them.
+  const int blk[2] = {kSlotCg, kSlotCg + 8}, s0 = kSlotCg + 16;
+  const double nvox = (double)nglobal_;
   FG_HIP_CHECK(hipMemsetAsync(fu_, 0, f3, stream_));
   apply(fu_, E.v);
   FG_HIP_CHECK(hipMemcpyAsync(u_r, fu_alt_, f3, hipMemcpyDeviceToDevice, stream_));
   FG_HIP_CHECK(hipMemcpyAsync(u_p, fu_alt_, f3, hipMemcpyDeviceToDevice, stream_));   // p = r
-  launch_cgu_dot(1, g_, ptrs3(fu_), ptrs3(u_r), E, partial_, dscal_ + kSlotSumSq, stream_);
-  fetch(kSlotSumSq, 7);
-  double gamma = hscal_[kSlotSumSq + 6] / (double)nglobal_ + small;
+  launch_cgu_dot(1, g_, ptrs3(fu_), ptrs3(u_r), E, partial_, dscal_ + blk[0], stream_);   // gamma_0 = r:r / N + tiny
   double prev = 0.0;  // estimator constructed on the zero field
   long iter = 0;
   bool failed = false;
+  bool applied = false;   // u_w = operator(u_p) of the coming iteration is already enqueued
   for (;;) {
-    apply(u_p, Z.v);                                                                  // u_w = operator(u_p)
-    launch_cgu_dot(0, g_, ptrs3(u_p), ptrs3(fu_alt_), Z, partial_, dscal_ + kSlotMean, stream_);   // p : (p - w)
-    fetch(kSlotMean, 1);
-    double alpha = hscal_[kSlotMean] / (double)nglobal_ + small;
-    alpha = gamma / alpha;
-    launch_cgu_axpy(0, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), alpha, stream_);     // eps += alpha p ; r -= alpha (p - w)
-    launch_cgu_dot(1, g_, ptrs3(fu_), ptrs3(u_r), E, partial_, dscal_ + kSlotSumSq, stream_);       // norms of eps ; r : r
-    fetch(kSlotSumSq, 7);
-    const double rr = hscal_[kSlotSumSq + 6];   // slot 6 is shared with the mean-value slot the accessors below use
+    const int cur = (int)(iter & 1), nxt = cur ^ 1;
+    if (!applied) apply(u_p, Z.v);                                                    // u_w = operator(u_p)
+    applied = false;
+    launch_cgu_dot(0, g_, ptrs3(u_p), ptrs3(fu_alt_), Z, partial_, dscal_ + s0, stream_);   // p : (p - w)
+    // eps += alpha p ; r -= alpha (p - w),  alpha = gamma / (p:(p - w) / N + tiny)
+    launch_cgu_axpy(0, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), dscal_, blk[cur] + 6, s0, nvox, small, stream_);
+    launch_cgu_dot(1, g_, ptrs3(fu_), ptrs3(u_r), E, partial_, dscal_ + blk[nxt], stream_);   // norms of eps ; r : r
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotCg, dscal_ + blk[nxt], 7 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipEventRecord(ev_copy_, stream_));
+    if (!cb_ && iter < opt_.maxiter) {
+      // p = r + beta p (beta = delta / gamma) and the next operator application, enqueued behind the copies
+      launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), dscal_, blk[nxt] + 6, blk[cur] + 6, nvox, small,
+                      stream_);
+      apply(u_p, Z.v);
+      applied = true;
+    }
+    FG_HIP_CHECK(hipEventSynchronize(ev_copy_));
+    if (*herr_ != 0) check_device_error("cg");
     // state for accessors called from the callback / bc_error: eps = E + grad_s fu_
     u_valid_ = true;
     eps_stale_ = true;
     for (int c = 0; c < 6; ++c) E_cur_[c] = E.v[c];
     double m[6], s9 = 0.0;
     for (int c = 0; c < 6; ++c) {
-      sumsq_[c] = hscal_[kSlotSumSq + c];
+      sumsq_[c] = hscal_[kSlotCg + c];
       m[c] = std::sqrt(sumsq_[c] / (double)nglobal_);
     }
     for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
     for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
-    const double cur = std::sqrt(s9);
-    const double abs_err = std::fabs(prev - cur);
-    const double rel_err = abs_err / (small + cur);
-    prev = cur;
+    const double curn = std::sqrt(s9);
+    const double abs_err = std::fabs(prev - curn);
+    const double rel_err = abs_err / (small + curn);
+    prev = curn;
     if (std::isnan(rel_err) || cancel_) {  // _converged  F:21177-21244
       failed = true;
       break;
@@ -1110,12 +1121,10 @@ bool Solver::run_cg_u(const double* E0) {
       if (bc_error(E0, S0) <= opt_.bc_tol) break;
     }
     iter++;
-    const double delta = rr / (double)nglobal_ + small;
-    const double beta = delta / gamma;
-    gamma = delta;
-    launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), beta, stream_);       // p = r + beta p
+    if (!applied)   // p = r + beta p
+      launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), dscal_, blk[nxt] + 6, blk[cur] + 6, nvox, small,
+                      stream_);
   }
-  in_run_ = false;
   cg_u_active_ = false;
   iterations_ = iter;
   u_valid_ = true;
