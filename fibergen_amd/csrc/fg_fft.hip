@@ -272,6 +272,268 @@ __global__ __launch_bounds__(256) void k_mixed_combine_tile(cplx* data, long ls,
     for (int pt = (int)(threadIdx.x >> 3); pt < N; pt += 32) data[base + (long)pt * ls] = img[pt * 8 + t];
 }
 
+// One kernel for the whole pass where the tile fits (p = 3 or 5, N = p M <= 1024 threads, exchange planes <= 144 KB):
+// the workgroup holds an 8-column tile of whole lines, thread (jt, r, t) runs the M-point transform of sub-line r of
+// column t with the phase code of the power-of-two kernels (the p * 8 sub-lines are just more LDS columns), and the
+// combine step goes through an LDS image of the tile -- one read and one write of the data, like a native pass.
+template <int M, int DIR, int PH>
+struct MixedPhases {
+  __device__ __forceinline__ static void run(cplx* v, int jt, double* lds, const fft::LdsMap& L, int c, const cplx* tw) {
+    fft::Line<M>::template phase<DIR, PH>(v, jt, lds, L, c, tw);
+    if constexpr (PH + 1 < fft::Line<M>::NPHASE) {
+      __syncthreads();
+      MixedPhases<M, DIR, PH + 1>::run(v, jt, lds, L, c, tw);
+    }
+  }
+};
+
+template <int M, int P, int DIR>
+__global__ __launch_bounds__(M * P) void k_strided_mixed(StridedArgs a, long comp_stride, const cplx* wN) {
+  using namespace fft;
+  constexpr int T = M / 8, COLS = P * 8, THREADS = T * COLS, PN = M + M / 8, N = P * M;
+  extern __shared__ __align__(16) double lds[];
+  cplx* img = reinterpret_cast<cplx*>(lds);   // [P][M][8], aliases the exchange planes (never live together)
+  a.data += (long)blockIdx.y * comp_stride;
+  const int tid = threadIdx.x;
+  const int cp = tid % COLS, jt = tid / COLS, r = cp / 8, t = cp % 8;
+  const int o = blockIdx.x / a.tiles_per_outer;
+  const int col = (blockIdx.x % a.tiles_per_outer) * 8 + t;
+  const bool valid = col < a.ncols;
+  const long base = (long)o * a.os + (valid ? col : 0);
+  const LdsMap L = {COLS, 1, PN * COLS};
+  cplx v[8];
+  auto combine = [&](auto&& get, auto&& put) {   // thread (k, t): p inputs -> p outputs
+    for (int k = tid / 8; k < M; k += THREADS / 8) {
+      cplx in[P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) in[q] = get(k, q);
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        cplx acc = cmake(0.0, 0.0);
+        if (DIR < 0) {   // X[k + M q] = sum_r w_N^{r (k + M q)} Y_r[k]
+          const int step = k + M * q;
+          int idx = 0;
+#pragma unroll
+          for (int rr = 0; rr < P; ++rr) {
+            acc = cadd(acc, cmul(in[rr], wN[idx]));
+            idx += step;
+            if (idx >= N) idx -= N;
+          }
+        } else {         // Z_q[k] = conj(w_N^{q k}) sum_s X[k + M s] conj(w_p^{q s})
+          const int step = (q * M) % N;
+          int idx = 0;
+#pragma unroll
+          for (int sidx = 0; sidx < P; ++sidx) {
+            acc = cadd(acc, cmul(in[sidx], cconj(wN[idx])));
+            idx += step;
+            if (idx >= N) idx -= N;
+          }
+          acc = cmul(acc, cconj(wN[q * k]));
+        }
+        put(k, q, acc);
+      }
+    }
+  };
+  if (DIR < 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      v[q] = valid ? a.data[base + ((long)P * Line<M>::first_index(jt, q) + r) * a.ls] : cmake(0.0, 0.0);
+  } else {
+    // inverse: combine first, from memory into the image [r][k][t]
+    combine([&](int k, int q) { return valid ? a.data[base + ((long)k + (long)M * q) * a.ls] : cmake(0.0, 0.0); },
+            [&](int k, int q, cplx z) { img[((long)q * M + k) * 8 + t] = z; });
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = img[((long)r * M + Line<M>::first_index(jt, q)) * 8 + t];
+    __syncthreads();   // the image is overwritten by the exchange planes from here on
+  }
+  // the M-point transform of this thread's sub-line (barrier between phases, as in k_strided)
+  MixedPhases<M, DIR, 0>::run(v, jt, lds, L, cp, a.tw);
+  if (DIR < 0) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) img[((long)r * M + Line<M>::last_index(jt, q)) * 8 + t] = v[q];
+    __syncthreads();
+    combine([&](int k, int q) { return img[((long)q * M + k) * 8 + t]; },
+            [&](int k, int q, cplx z) {
+              if (valid) a.data[base + ((long)k + (long)M * q) * a.ls] = cscale(a.scale, z);
+            });
+  } else if (valid) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a.data[base + ((long)P * Line<M>::last_index(jt, q) + r) * a.ls] = cscale(a.scale, v[q]);
+  }
+}
+
+template <int M, int P>
+bool launch_strided_mixed(const StridedArgs& a0, int nouter, int dir, int ncomp, long cs, const cplx* wN, hipStream_t s) {
+  constexpr int PN = M + M / 8;
+  constexpr size_t lds = 2 * PN * P * 8 * sizeof(double);
+  if constexpr (M * P > 1024 || lds > 144 * 1024) {
+    return false;
+  } else {
+    StridedArgs a = a0;
+    a.tiles_per_outer = (a.ncols + 7) / 8;
+    const dim3 grid((unsigned)((long)a.tiles_per_outer * nouter), ncomp);
+    static bool configured = false;
+    if (!configured) {
+      FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strided_mixed<M, P, -1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strided_mixed<M, P, +1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = true;
+    }
+    if (dir < 0) hipLaunchKernelGGL((k_strided_mixed<M, P, -1>), grid, dim3(M * P), lds, s, a, cs, wN);
+    else hipLaunchKernelGGL((k_strided_mixed<M, P, +1>), grid, dim3(M * P), lds, s, a, cs, wN);
+    FG_HIP_CHECK(hipGetLastError());
+    return true;
+  }
+}
+
+// The z passes in one kernel each, same construction: a workgroup owns LINES packed rows, thread (l, jt, r) runs the
+// MP-point transform of sub-row r of row l (lanes run over (jt, r): the loads p * idx + r are contiguous), the
+// combine + real split (r2c) / merge + inverse combine (c2r) goes through an LDS image [l][r][k'].
+template <int MP, int P, int LINES, bool FWD>
+__global__ __launch_bounds__((MP / 8) * P * LINES) void k_z_mixed(double* data, long nrows, int nzp, long comp_stride,
+                                                                 const cplx* tw, const cplx* wn) {
+  using namespace fft;
+  constexpr int T = MP / 8, COLS = P * LINES, THREADS = T * COLS, PN = MP + MP / 8, M = P * MP, nz = 2 * M;
+  extern __shared__ __align__(16) double lds[];
+  cplx* img = reinterpret_cast<cplx*>(lds);   // [LINES][P][MP]
+  data += (long)blockIdx.y * comp_stride;
+  const int tid = threadIdx.x;
+  // lanes: r fastest, then jt, then the row: global accesses p * idx + r are contiguous along (jt, r)
+  const int r = tid % P, jt = (tid / P) % T, l = tid / (P * T);
+  const int cp = l * P + r;   // LDS column of this sub-row
+  const long row0 = (long)blockIdx.x * LINES;
+  const bool valid = row0 + l < nrows;
+  cplx* row = reinterpret_cast<cplx*>(data + (row0 + (valid ? l : 0)) * nzp);
+  const LdsMap L = {COLS, 1, PN * COLS};
+  cplx v[8];
+  if (FWD) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = valid ? row[P * Line<MP>::first_index(jt, q) + r] : cmake(0.0, 0.0);
+    MixedPhases<MP, -1, 0>::run(v, jt, lds, L, cp, tw);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) img[((long)l * P + r) * MP + Line<MP>::last_index(jt, q)] = v[q];
+    __syncthreads();
+    // combine + split: item (row, k <= M/2) -> X[k], X[M - k]
+    constexpr int half = M / 2 + 1;
+    for (int it = tid; it < LINES * half; it += THREADS) {
+      const int lr = it / half, k = it % half;
+      if (row0 + lr >= nrows) break;
+      const cplx* in = img + (long)lr * P * MP;
+      auto zfull = [&](int K) {
+        const int kk = K % MP, step = 2 * K;
+        cplx acc = cmake(0.0, 0.0);
+        int idx = 0;
+#pragma unroll
+        for (int rr = 0; rr < P; ++rr) {
+          acc = cadd(acc, cmul(in[rr * MP + kk], wn[idx]));
+          idx += step;
+          if (idx >= nz) idx -= nz;
+        }
+        return acc;
+      };
+      const cplx zk = zfull(k), zm = zfull((M - k) % M);
+      cplx* out = reinterpret_cast<cplx*>(data + (row0 + lr) * nzp);
+      out[k] = r2c_split(zk, zm, wn[k]);
+      out[M - k] = r2c_split(zm, zk, wn[M - k]);
+    }
+  } else {
+    // merge + inverse combine: item (row, k' < MP) -> Z_r[k'] for all r
+    for (int it = tid; it < LINES * MP; it += THREADS) {
+      const int lr = it / MP, kk = it % MP;
+      if (row0 + lr >= nrows) break;
+      const cplx* in = reinterpret_cast<const cplx*>(data + (row0 + lr) * nzp);
+      cplx z[P];
+#pragma unroll
+      for (int sidx = 0; sidx < P; ++sidx) {
+        const int K = kk + MP * sidx;
+        cplx xk = in[K], xm = in[M - K];
+        if (K == 0) { xk.im = 0.0; xm.im = 0.0; }
+        z[sidx] = c2r_merge(xk, xm, wn[K]);
+      }
+#pragma unroll
+      for (int rr = 0; rr < P; ++rr) {
+        cplx acc = cmake(0.0, 0.0);
+        const int step = (2 * rr * MP) % nz;
+        int idx = 0;
+#pragma unroll
+        for (int sidx = 0; sidx < P; ++sidx) {
+          acc = cadd(acc, cmul(z[sidx], cconj(wn[idx])));
+          idx += step;
+          if (idx >= nz) idx -= nz;
+        }
+        img[((long)lr * P + rr) * MP + kk] = cmul(acc, cconj(wn[2 * rr * kk]));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = img[((long)l * P + r) * MP + Line<MP>::first_index(jt, q)];
+    __syncthreads();
+    MixedPhases<MP, +1, 0>::run(v, jt, lds, L, cp, tw);
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) row[P * Line<MP>::last_index(jt, q) + r] = v[q];
+    }
+  }
+}
+
+template <int MP, int P>
+bool launch_z_mixed(double* data, long nrows, int nzp, int ncomp, long comp_stride, bool fwd, const cplx* tw, const cplx* wn,
+                    hipStream_t s) {
+  constexpr int LINES = (2048 / (MP * P)) > 1 ? (2048 / (MP * P)) : 1;
+  constexpr int THREADS = (MP / 8) * P * LINES;
+  constexpr int PN = MP + MP / 8;
+  constexpr size_t ex = 2 * PN * P * LINES * sizeof(double), im = (size_t)LINES * P * MP * sizeof(cplx);
+  constexpr size_t lds = ex > im ? ex : im;
+  if constexpr (THREADS > 1024 || lds > 144 * 1024) {
+    return false;
+  } else {
+    const dim3 grid((unsigned)((nrows + LINES - 1) / LINES), ncomp);
+    static bool configured = false;
+    if (!configured) {
+      FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_z_mixed<MP, P, LINES, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_z_mixed<MP, P, LINES, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = true;
+    }
+    if (fwd) hipLaunchKernelGGL((k_z_mixed<MP, P, LINES, true>), grid, dim3(THREADS), lds, s, data, nrows, nzp, comp_stride, tw, wn);
+    else hipLaunchKernelGGL((k_z_mixed<MP, P, LINES, false>), grid, dim3(THREADS), lds, s, data, nrows, nzp, comp_stride, tw, wn);
+    FG_HIP_CHECK(hipGetLastError());
+    return true;
+  }
+}
+
+template <int P>
+bool z_mixed_p(int mp, double* data, long nrows, int nzp, int ncomp, long cs, bool fwd, const cplx* tw, const cplx* wn,
+               hipStream_t s) {
+  switch (mp) {
+    case 8: return launch_z_mixed<8, P>(data, nrows, nzp, ncomp, cs, fwd, tw, wn, s);
+    case 16: return launch_z_mixed<16, P>(data, nrows, nzp, ncomp, cs, fwd, tw, wn, s);
+    case 32: return launch_z_mixed<32, P>(data, nrows, nzp, ncomp, cs, fwd, tw, wn, s);
+    case 64: return launch_z_mixed<64, P>(data, nrows, nzp, ncomp, cs, fwd, tw, wn, s);
+    case 128: return launch_z_mixed<128, P>(data, nrows, nzp, ncomp, cs, fwd, tw, wn, s);
+    case 256: return launch_z_mixed<256, P>(data, nrows, nzp, ncomp, cs, fwd, tw, wn, s);
+    default: return false;
+  }
+}
+
+template <int P>
+bool strided_mixed_p(int m, const StridedArgs& a, int nouter, int dir, int ncomp, long cs, const cplx* wN, hipStream_t s) {
+  switch (m) {
+    case 8: return launch_strided_mixed<8, P>(a, nouter, dir, ncomp, cs, wN, s);
+    case 16: return launch_strided_mixed<16, P>(a, nouter, dir, ncomp, cs, wN, s);
+    case 32: return launch_strided_mixed<32, P>(a, nouter, dir, ncomp, cs, wN, s);
+    case 64: return launch_strided_mixed<64, P>(a, nouter, dir, ncomp, cs, wN, s);
+    case 128: return launch_strided_mixed<128, P>(a, nouter, dir, ncomp, cs, wN, s);
+    case 256: return launch_strided_mixed<256, P>(a, nouter, dir, ncomp, cs, wN, s);
+    default: return false;
+  }
+}
+
 // z axis, nz = 2 M, M = p M': after the M'-point sub-transforms of the packed rows (Y_r[k'] at complex p k' + r), one
 // sweep per row forms the M-point spectrum Z and splits it into the half spectrum of the real row (r2c_split):
 // thread k <= M/2 writes X[k] and X[M - k].  wn: e^{-2 pi i j / nz}, j < nz  (w_M^j = wn[2 j]).
@@ -551,6 +813,20 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
   if (odd_[axis]) {
     // n = p * m: m-point kernels on the p interleaved sub-lines, combine sweep through the scratch component
     const int p = odd_[axis], m = n / p;
+    if (p == 3 || p == 5) {
+      StridedArgs a;
+      a.data = reinterpret_cast<cplx*>(data);
+      a.ls = ls;
+      a.os = os;
+      a.ncols = ncols;
+      a.tiles_per_outer = 0;
+      a.scale = scale;
+      a.tw = tw_[axis];
+      a.nt = 0;
+      const bool done = p == 3 ? strided_mixed_p<3>(m, a, nouter, dir, ncomp, comp_stride / 2, wgen_[axis], stream_)
+                               : strided_mixed_p<5>(m, a, nouter, dir, ncomp, comp_stride / 2, wgen_[axis], stream_);
+      if (done) return;
+    }
     const long total = (long)nouter * m * ncols;
     const unsigned nb = (unsigned)((total + 255) / 256);
     auto subs = [&]() {
@@ -721,6 +997,9 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
     // nz = 2 M, M = p m: m-point kernels on the sub-rows of the packed real rows ([m][p] complex, line stride p), then
     // combine + real split per row through the scratch component
     const int M = g_.nz / 2, p = odd_[2], m = M / p;
+    if ((p == 3 && z_mixed_p<3>(m, data, nrows, g_.nzp, ncomp, comp_stride, true, tw_[2], wgen_[2], stream_)) ||
+        (p == 5 && z_mixed_p<5>(m, data, nrows, g_.nzp, ncomp, comp_stride, true, tw_[2], wgen_[2], stream_)))
+      return;
     StridedArgs a;
     a.data = reinterpret_cast<cplx*>(data);
     a.ls = p;
@@ -786,6 +1065,9 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
   }
   if (odd_[2]) {
     const int M = g_.nz / 2, p = odd_[2], m = M / p;
+    if ((p == 3 && z_mixed_p<3>(m, data, nrows, g_.nzp, ncomp, comp_stride, false, tw_[2], wgen_[2], stream_)) ||
+        (p == 5 && z_mixed_p<5>(m, data, nrows, g_.nzp, ncomp, comp_stride, false, tw_[2], wgen_[2], stream_)))
+      return;
     int rows = (int)(48 * 1024 / ((M + 1) * sizeof(cplx)));
     if (rows < 1) rows = 1;
     const size_t lds = (size_t)rows * (M + 1) * sizeof(cplx);
