@@ -337,10 +337,10 @@ __global__ __launch_bounds__(M * P) void k_strided_mixed(StridedArgs a, long com
   if (DIR < 0) {
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      v[q] = valid ? a.data[base + ((long)P * Line<M>::first_index(jt, q) + r) * a.ls] : cmake(0.0, 0.0);
+      v[q] = valid ? cload_stream(&a.data[base + ((long)P * Line<M>::first_index(jt, q) + r) * a.ls], a.nt) : cmake(0.0, 0.0);
   } else {
     // inverse: combine first, from memory into the image [r][k][t]
-    combine([&](int k, int q) { return valid ? a.data[base + ((long)k + (long)M * q) * a.ls] : cmake(0.0, 0.0); },
+    combine([&](int k, int q) { return valid ? cload_stream(&a.data[base + ((long)k + (long)M * q) * a.ls], a.nt) : cmake(0.0, 0.0); },
             [&](int k, int q, cplx z) { img[((long)q * M + k) * 8 + t] = z; });
     __syncthreads();
 #pragma unroll
@@ -356,11 +356,12 @@ __global__ __launch_bounds__(M * P) void k_strided_mixed(StridedArgs a, long com
     __syncthreads();
     combine([&](int k, int q) { return img[((long)q * M + k) * 8 + t]; },
             [&](int k, int q, cplx z) {
-              if (valid) a.data[base + ((long)k + (long)M * q) * a.ls] = cscale(a.scale, z);
+              if (valid) cstore_stream(&a.data[base + ((long)k + (long)M * q) * a.ls], cscale(a.scale, z), a.nt);
             });
   } else if (valid) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a.data[base + ((long)P * Line<M>::last_index(jt, q) + r) * a.ls] = cscale(a.scale, v[q]);
+    for (int q = 0; q < 8; ++q)
+      cstore_stream(&a.data[base + ((long)P * Line<M>::last_index(jt, q) + r) * a.ls], cscale(a.scale, v[q]), a.nt);
   }
 }
 
@@ -822,7 +823,7 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
       a.tiles_per_outer = 0;
       a.scale = scale;
       a.tw = tw_[axis];
-      a.nt = 0;
+      a.nt = stream_stores_ ? 3 : 0;
       const bool done = p == 3 ? strided_mixed_p<3>(m, a, nouter, dir, ncomp, comp_stride / 2, wgen_[axis], stream_)
                                : strided_mixed_p<5>(m, a, nouter, dir, ncomp, comp_stride / 2, wgen_[axis], stream_);
       if (done) return;
