@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_mixed_combine_tile(cplx* data, long ls,
     for (int pt = (int)(threadIdx.x >> 3); pt < N; pt += 32) data[base + (long)pt * ls] = img[pt * 8 + t];
 }
 
-// One kernel for the whole pass where the tile fits (p = 3 or 5, N = p M <= 1024 threads, exchange planes <= 144 KB):
+// One kernel for the whole pass where the tile fits (p = 3, 5, 7, 9; N = p M <= 1024 threads, exchange planes <= 144 KB):
 // the workgroup holds an 8-column tile of whole lines, thread (jt, r, t) runs the M-point transform of sub-line r of
 // column t with the phase code of the power-of-two kernels (the p * 8 sub-lines are just more LDS columns), and the
 // combine step goes through an LDS image of the tile -- one read and one write of the data, like a native pass.
@@ -814,7 +814,7 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
   if (odd_[axis]) {
     // n = p * m: m-point kernels on the p interleaved sub-lines, combine sweep through the scratch component
     const int p = odd_[axis], m = n / p;
-    if (p == 3 || p == 5) {
+    if (p == 3 || p == 5 || p == 7 || p == 9) {
       StridedArgs a;
       a.data = reinterpret_cast<cplx*>(data);
       a.ls = ls;
@@ -824,8 +824,11 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
       a.scale = scale;
       a.tw = tw_[axis];
       a.nt = stream_stores_ ? 3 : 0;
-      const bool done = p == 3 ? strided_mixed_p<3>(m, a, nouter, dir, ncomp, comp_stride / 2, wgen_[axis], stream_)
-                               : strided_mixed_p<5>(m, a, nouter, dir, ncomp, comp_stride / 2, wgen_[axis], stream_);
+      const long cs2 = comp_stride / 2;
+      const bool done = p == 3   ? strided_mixed_p<3>(m, a, nouter, dir, ncomp, cs2, wgen_[axis], stream_)
+                        : p == 5 ? strided_mixed_p<5>(m, a, nouter, dir, ncomp, cs2, wgen_[axis], stream_)
+                        : p == 7 ? strided_mixed_p<7>(m, a, nouter, dir, ncomp, cs2, wgen_[axis], stream_)
+                                 : strided_mixed_p<9>(m, a, nouter, dir, ncomp, cs2, wgen_[axis], stream_);
       if (done) return;
     }
     const long total = (long)nouter * m * ncols;
@@ -999,7 +1002,9 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
     // combine + real split per row through the scratch component
     const int M = g_.nz / 2, p = odd_[2], m = M / p;
     if ((p == 3 && z_mixed_p<3>(m, data, nrows, g_.nzp, ncomp, comp_stride, true, tw_[2], wgen_[2], stream_)) ||
-        (p == 5 && z_mixed_p<5>(m, data, nrows, g_.nzp, ncomp, comp_stride, true, tw_[2], wgen_[2], stream_)))
+        (p == 5 && z_mixed_p<5>(m, data, nrows, g_.nzp, ncomp, comp_stride, true, tw_[2], wgen_[2], stream_)) ||
+        (p == 7 && z_mixed_p<7>(m, data, nrows, g_.nzp, ncomp, comp_stride, true, tw_[2], wgen_[2], stream_)) ||
+        (p == 9 && z_mixed_p<9>(m, data, nrows, g_.nzp, ncomp, comp_stride, true, tw_[2], wgen_[2], stream_)))
       return;
     StridedArgs a;
     a.data = reinterpret_cast<cplx*>(data);
@@ -1067,7 +1072,9 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
   if (odd_[2]) {
     const int M = g_.nz / 2, p = odd_[2], m = M / p;
     if ((p == 3 && z_mixed_p<3>(m, data, nrows, g_.nzp, ncomp, comp_stride, false, tw_[2], wgen_[2], stream_)) ||
-        (p == 5 && z_mixed_p<5>(m, data, nrows, g_.nzp, ncomp, comp_stride, false, tw_[2], wgen_[2], stream_)))
+        (p == 5 && z_mixed_p<5>(m, data, nrows, g_.nzp, ncomp, comp_stride, false, tw_[2], wgen_[2], stream_)) ||
+        (p == 7 && z_mixed_p<7>(m, data, nrows, g_.nzp, ncomp, comp_stride, false, tw_[2], wgen_[2], stream_)) ||
+        (p == 9 && z_mixed_p<9>(m, data, nrows, g_.nzp, ncomp, comp_stride, false, tw_[2], wgen_[2], stream_)))
       return;
     int rows = (int)(48 * 1024 / ((M + 1) * sizeof(cplx)));
     if (rows < 1) rows = 1;

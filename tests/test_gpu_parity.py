@@ -29,6 +29,7 @@ GRIDS = [
     ((56, 16, 80), (1.0, 1.0, 1.0)),      # 7*8, power of two, nz/2 = 5*8
     ((72, 24, 240), (1.0, 1.0, 1.0)),     # 9*8, 3*8, nz/2 = 15*8
     ((200, 8, 400), (1.0, 1.0, 1.0)),     # 25*8, nz/2 = 25*8
+    ((112, 72, 144), (1.0, 1.0, 1.0)),    # 7*16, 9*8, nz/2 = 9*8: single-kernel passes for p = 7, 9
 ]
 EXACT = {}
 
