@@ -172,7 +172,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=256, help="grid size per axis (128, 256, 512)")
+    ap.add_argument("--n", type=int, default=256, help="grid size per axis (128, 256, 512 are the BASELINE sizes; any size runs)")
     ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
     ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat", "viscosity"],
                     help="porous / heat: scalar potential, 3-component gradient; viscosity: dual Stokes scheme "
