@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
     (4, "16,8,16", "voigt"),
     (2, "12,10,6", "laminate"),      # generic (non power-of-two) FFT path in every direction
     (2, "8,6,5", "voigt"),           # odd nz
+    (2, "24,48,48", "voigt"),        # p * 2^k lengths: single-kernel mixed passes on the slab and on the transposed grid
 ])
 def test_hip_slabs_match_oracle(tmp_path, nproc, grid, mixing):
     g = tuple(int(v) for v in grid.split(","))
