@@ -38,7 +38,7 @@ class Fft3 {
   void c2c_x(double* data, int ncomp, long comp_stride, int dir, double scale);
   void c2r_z(double* data, int ncomp, long comp_stride);
   void scale(double* data, int ncomp, long comp_stride, double scale);
-  bool can_fuse(int axis) const;
+  bool can_fuse(int axis, int ncomp = 3) const;
   // ncomp = 3: elastic Green operator on three components; ncomp = 1: scalar (heat / porous) operator c10 / |k|^2
   void fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp = 3);
 

@@ -522,6 +522,172 @@ bool z_mixed_p(int mp, double* data, long nrows, int nzp, int ncomp, long cs, bo
   }
 }
 
+// The fused pass (x-FFT, 1/N, Green operator, x-iFFT on three components) for N = p M, p = 3 or 5: per component the
+// sub-line transforms and the LDS image as in k_strided_mixed; the combine outputs X[k + M s] of a (k, column) item stay
+// in the registers of the thread that formed them -- the same thread owns every input of the inverse combine of that
+// item, so the Green operator and the inverse combine need no exchange.  One read and one write of the three spectra.
+template <int M, int P>
+__global__ __launch_bounds__(M * P) void k_xfused_mixed(XFusedArgs a, const cplx* wN) {
+  using namespace fft;
+  constexpr int T = M / 8, COLS = P * 8, THREADS = T * COLS, PN = M + M / 8, N = P * M;
+  constexpr int ITEMS = (8 + P - 1) / P;   // (k, column) items per thread: M * 8 items over M * P threads
+  extern __shared__ __align__(16) double lds[];
+  cplx* img = reinterpret_cast<cplx*>(lds);
+  const int tid = threadIdx.x;
+  const int cp = tid % COLS, jt = tid / COLS, r = cp / 8, t = cp % 8;
+  const int o = blockIdx.x / a.tiles_per_outer;
+  const int col = (blockIdx.x % a.tiles_per_outer) * 8 + t;
+  const bool valid = col < a.ncols;
+  const int colc = valid ? col : a.ncols - 1;
+  const long base = (long)o * a.os + colc;
+  int jj, kk;
+  if (a.flat_cols) {
+    jj = colc / a.nzc;
+    kk = colc - jj * a.nzc;
+  } else {
+    jj = a.jj0 + o;
+    kk = colc;
+  }
+  const LdsMap L = {COLS, 1, PN * COLS};
+  cplx v[8];
+  cplx X[ITEMS][3][P];
+  // ---- forward: three components
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const cplx* src = a.data + c * a.comp_stride;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = cload_stream(&src[base + ((long)P * Line<M>::first_index(jt, q) + r) * a.ls], a.nt);
+    MixedPhases<M, -1, 0>::run(v, jt, lds, L, cp, a.tw);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) img[((long)r * M + Line<M>::last_index(jt, q)) * 8 + t] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int k = tid / 8 + i * (THREADS / 8);
+      if (k < M) {
+        cplx in[P];
+#pragma unroll
+        for (int rr = 0; rr < P; ++rr) in[rr] = img[((long)rr * M + k) * 8 + t];
+#pragma unroll
+        for (int sidx = 0; sidx < P; ++sidx) {
+          cplx acc = cmake(0.0, 0.0);
+          const int step = k + M * sidx;
+          int idx = 0;
+#pragma unroll
+          for (int rr = 0; rr < P; ++rr) {
+            acc = cadd(acc, cmul(in[rr], wN[idx]));
+            idx += step;
+            if (idx >= N) idx -= N;
+          }
+          X[i][c][sidx] = cscale(a.scale, acc);
+        }
+      }
+    }
+    __syncthreads();   // the image is overwritten by the next component's exchange planes
+  }
+  // ---- Green operator and inverse combine, in registers
+  const bool live = valid && kk < a.nzf;
+  const double kpm1 = a.kpm[1][jj], kpm2 = a.kpm[2][live ? kk : 0];
+  const cplx kp1 = a.kp[1][jj], kp2 = a.kp[2][live ? kk : 0];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int k = tid / 8 + i * (THREADS / 8);
+    if (k < M) {
+#pragma unroll
+      for (int sidx = 0; sidx < P; ++sidx) {
+        const int kx = k + M * sidx;
+        const cplx t0 = X[i][0][sidx], t1 = X[i][1][sidx], t2 = X[i][2][sidx];
+        if (live) {
+          cplx e0, e1, e2;
+          g0_point_rcp(t0, t1, t2, a.kpm[0][kx], kpm1, kpm2, a.kp[0][kx], kp1, kp2, a.c10, a.c20, &e0, &e1, &e2);
+          const bool zero = kx == 0 && jj == 0 && kk == 0;   // zero frequency  F:19924-19926
+          X[i][0][sidx] = zero ? cmake(0.0, 0.0) : e0;
+          X[i][1][sidx] = zero ? cmake(0.0, 0.0) : e1;
+          X[i][2][sidx] = zero ? cmake(0.0, 0.0) : e2;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        cplx in[P];
+#pragma unroll
+        for (int sidx = 0; sidx < P; ++sidx) in[sidx] = X[i][c][sidx];
+#pragma unroll
+        for (int rr = 0; rr < P; ++rr) {   // Z_r[k] = conj(w_N^{r k}) sum_s X[k + M s] conj(w_p^{r s})
+          cplx acc = cmake(0.0, 0.0);
+          const int step = (rr * M) % N;
+          int idx = 0;
+#pragma unroll
+          for (int sidx = 0; sidx < P; ++sidx) {
+            acc = cadd(acc, cmul(in[sidx], cconj(wN[idx])));
+            idx += step;
+            if (idx >= N) idx -= N;
+          }
+          X[i][c][rr] = cmul(acc, cconj(wN[rr * k]));
+        }
+      }
+    }
+  }
+  // ---- inverse: three components
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int k = tid / 8 + i * (THREADS / 8);
+      if (k < M) {
+#pragma unroll
+        for (int rr = 0; rr < P; ++rr) img[((long)rr * M + k) * 8 + t] = X[i][c][rr];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = img[((long)r * M + Line<M>::first_index(jt, q)) * 8 + t];
+    __syncthreads();
+    MixedPhases<M, +1, 0>::run(v, jt, lds, L, cp, a.tw);
+    if (valid) {
+      cplx* dst = a.data + c * a.comp_stride;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cstore_stream(&dst[base + ((long)P * Line<M>::last_index(jt, q) + r) * a.ls], v[q], a.nt);
+    }
+    __syncthreads();   // exchange planes -> image of the next component
+  }
+}
+
+template <int M, int P>
+bool launch_xfused_mixed(XFusedArgs a, int nouter, const cplx* wN, hipStream_t s, bool probe_only) {
+  constexpr int PN = M + M / 8;
+  constexpr size_t lds = 2 * PN * P * 8 * sizeof(double);
+  // N <= 512 like the power-of-two fused pass: 640 and 768 need 0.9-1.3 KB of scratch per lane
+  if constexpr (M * P > 512 || lds > 144 * 1024) {
+    return false;
+  } else {
+    if (probe_only) return true;
+    a.tiles_per_outer = (a.ncols + 7) / 8;
+    static bool configured = false;
+    if (!configured) {
+      FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused_mixed<M, P>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = true;
+    }
+    hipLaunchKernelGGL((k_xfused_mixed<M, P>), dim3((unsigned)((long)a.tiles_per_outer * nouter)), dim3(M * P), lds, s, a, wN);
+    FG_HIP_CHECK(hipGetLastError());
+    return true;
+  }
+}
+
+template <int P>
+bool xfused_mixed_p(int m, const XFusedArgs& a, int nouter, const cplx* wN, hipStream_t s, bool probe_only) {
+  switch (m) {
+    case 8: return launch_xfused_mixed<8, P>(a, nouter, wN, s, probe_only);
+    case 16: return launch_xfused_mixed<16, P>(a, nouter, wN, s, probe_only);
+    case 32: return launch_xfused_mixed<32, P>(a, nouter, wN, s, probe_only);
+    case 64: return launch_xfused_mixed<64, P>(a, nouter, wN, s, probe_only);
+    case 128: return launch_xfused_mixed<128, P>(a, nouter, wN, s, probe_only);
+    case 256: return launch_xfused_mixed<256, P>(a, nouter, wN, s, probe_only);
+    default: return false;
+  }
+}
+
 template <int P>
 bool strided_mixed_p(int m, const StridedArgs& a, int nouter, int dir, int ncomp, long cs, const cplx* wN, hipStream_t s) {
   switch (m) {
@@ -934,14 +1100,18 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
 
 // forward transform along `axis` (0 = x of [nx][ny][nzc], 1 = y, used for the x lines of a y-slab),
 // scale, Green operator, inverse transform -- one kernel for the three components.
-bool Fft3::can_fuse(int axis) const {
+bool Fft3::can_fuse(int axis, int ncomp) const {
   const int n = axis == 0 ? g_.nx : g_.ny;
-  return fast_[axis] && n <= 512;
+  if (fast_[axis]) return n <= 512;
+  // p * 2^k with p = 3, 5: the three-component form only
+  if (ncomp != 3 || (odd_[axis] != 3 && odd_[axis] != 5)) return false;
+  XFusedArgs a = {};
+  return odd_[axis] == 3 ? xfused_mixed_p<3>(n / 3, a, 0, nullptr, stream_, true) : xfused_mixed_p<5>(n / 5, a, 0, nullptr, stream_, true);
 }
 
 void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp) {
   if (ncomp != 1 && ncomp != 3) throw std::runtime_error("fft: fused Green-operator pass takes 1 or 3 components");
-  if (!can_fuse(axis)) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
+  if (!can_fuse(axis, ncomp)) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
   const int n = axis == 0 ? g_.nx : g_.ny;
   XFusedArgs a;
   a.data = reinterpret_cast<cplx*>(data);
@@ -966,6 +1136,13 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
     a.kp[k] = gp.kp[k];
   }
   const int nouter = axis == 0 ? 1 : g_.nx;
+  if (!fast_[axis]) {
+    a.nt = stream_stores_ ? 3 : 0;
+    const bool ok = odd_[axis] == 3 ? xfused_mixed_p<3>(n / 3, a, nouter, wgen_[axis], stream_, false)
+                                    : xfused_mixed_p<5>(n / 5, a, nouter, wgen_[axis], stream_, false);
+    if (!ok) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
+    return;
+  }
   switch (n) {
     case 8: xfused_n<8>(a, nouter, ncomp, stream_); break;
     case 16: xfused_n<16>(a, nouter, ncomp, stream_); break;

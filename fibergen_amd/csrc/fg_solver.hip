@@ -534,7 +534,7 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     fft_->c2c_y(buf, 1, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
     time_end(3);
     const double c10 = -alpha / (2 * opt_.mu_0);  // G0OperatorFourierStaggeredHeat  F:19759-19764
-    if (opt_.fuse_x && fft_->can_fuse(0) && has_x) {
+    if (opt_.fuse_x && fft_->can_fuse(0, 1) && has_x) {
       // x transform, 1/N, scalar Green operator and inverse x transform in one kernel
       G0Params gp;
       for (int a = 0; a < 3; ++a) gp.kpm[a] = g0_kpm_[a], gp.kp[a] = g0_kp_[a];
