@@ -821,14 +821,30 @@ __device__ __forceinline__ unsigned ordered_slot(bool flag, unsigned& base, unsi
   return slot;
 }
 
-__global__ void k_scan_counts(unsigned* counts, int n) {   // exclusive scan in place, total -> counts[n]; set-up only
+__global__ __launch_bounds__(kBlock) void k_scan_counts(unsigned* counts, int n) {   // exclusive scan in place, total -> counts[n]
+  __shared__ unsigned chunk_sum[kBlock];
+  const int per = (n + kBlock - 1) / kBlock;
+  const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
   unsigned run = 0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = lo; i < hi; ++i) run += counts[i];
+  chunk_sum[threadIdx.x] = run;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned acc = 0;
+    for (int t = 0; t < kBlock; ++t) {
+      const unsigned c = chunk_sum[t];
+      chunk_sum[t] = acc;
+      acc += c;
+    }
+    counts[n] = acc;
+  }
+  __syncthreads();
+  run = chunk_sum[threadIdx.x];
+  for (int i = lo; i < hi; ++i) {
     const unsigned c = counts[i];
     counts[i] = run;
     run += c;
   }
-  counts[n] = run;
 }
 
 __global__ __launch_bounds__(kBlock) void k_mixed_list(Grid g, int nph, FieldPtrs<kMaxPhases> phi, unsigned* list,
@@ -1393,7 +1409,7 @@ void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const Field
 namespace {
 int compact_blocks(const Grid& g) { return (int)(((long)g.nx * g.ny * g.nz + kCompactChunk - 1) / kCompactChunk); }
 unsigned scan_counts(unsigned* counts, int nb, hipStream_t s) {
-  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1), 0, s, counts, nb);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(kBlock), 0, s, counts, nb);
   FG_HIP_CHECK(hipGetLastError());
   unsigned total = 0;
   FG_HIP_CHECK(hipMemcpyAsync(&total, counts + nb, sizeof(unsigned), hipMemcpyDeviceToHost, s));
