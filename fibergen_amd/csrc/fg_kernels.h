@@ -104,6 +104,7 @@ unsigned launch_affected_list(const Grid& g, const unsigned* list, unsigned n, u
 void launch_laminate_delta(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
                            const FieldPtrs<3>& normals, const Vec6& E, const unsigned* list, unsigned n, double* dtau,
                            int* error_flag, hipStream_t s);
+void launch_sum_dtau(const double* dtau, unsigned n, double* partial, double* out6, hipStream_t s);
 void launch_delta_div(const Grid& g, const unsigned* aff, const int* slots, unsigned n, const double* dtau,
                       const FieldPtrs<3>& f, hipStream_t s);
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);

@@ -7,6 +7,8 @@
 // results are bitwise reproducible from run to run.
 #include "fg_kernels.h"
 
+#include <algorithm>
+
 #include "fg_hip_util.h"
 #include "fg_kernels_common.h"
 
@@ -1471,6 +1473,29 @@ void launch_laminate_delta(const Grid& g, const StressParams& sp, const FieldPtr
   else
     hipLaunchKernelGGL((k_laminate_delta<kMaxPhases>), grid, dim3(kBlock), 0, s, g, sp, u, phi, normals, E, list, n, dtau,
                        error_flag);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+// six sums over the compact difference array [n][6] (mixed boundary conditions: <tau_laminate> = <tau_voigt> + this / N)
+__global__ __launch_bounds__(kBlock) void k_sum_dtau(const double* dtau, unsigned n, double* partial) {
+  __shared__ double smem[4 * 6];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[c] += dtau[(long)j * 6 + c];
+  }
+  block_reduce<6>(acc, smem, OpSum());
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
+  }
+}
+
+void launch_sum_dtau(const double* dtau, unsigned n, double* partial, double* out6, hipStream_t s) {
+  const int nb = n ? (int)std::min<long>(((long)n + kBlock - 1) / kBlock, 1024) : 1;
+  hipLaunchKernelGGL(k_sum_dtau, dim3(nb), dim3(kBlock), 0, s, dtau, n, partial);
+  FG_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, out6);
   FG_HIP_CHECK(hipGetLastError());
 }
 

@@ -302,7 +302,10 @@ void Solver::check_device_error(const char* where) {
 // The same check, but the host waits only for the copies enqueued so far (an event), not for work enqueued after them.
 void Solver::fetch_norms_and_errors(const char* where) {
   static_assert(kSlotMean == kSlotSumSq + 6, "the displacement sweep writes norms and tau sums as one block of 12");
-  const int nfetch = pending_back_ && !(frobenius(BC_MQ_) < kEps) ? 12 : 6;   // mixed BC in the displacement loop: + sums of tau
+  const bool mixed_u = pending_back_ && !(frobenius(BC_MQ_) < kEps);
+  const int nfetch = mixed_u ? 12 : 6;
+  if (mixed_u && opt_.mixing != kMixVoigt)
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotScratch, dscal_ + kSlotScratch, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));   // mixed BC in the displacement loop: + sums of tau
   FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, nfetch * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, stream_));
   FG_HIP_CHECK(hipEventRecord(ev_copy_, stream_));
@@ -660,7 +663,7 @@ bool Solver::u_loop_eligible(bool allow_mixed_bc) const {
   if (frobenius(BC_MQ_) < kEps) return true;
   // mixed boundary conditions: <tau> of every pass corrects the prescribed mean of the next one; the tiled Voigt sweep
   // delivers it with the norms (run() only: the correction needs the host between passes)
-  return allow_mixed_bc && opt_.mixing == kMixVoigt && opt_.u_loop >= 2 && opt_.u_tile && u_tile_supported(g_);
+  return allow_mixed_bc && opt_.u_loop >= 2 && opt_.u_tile && u_tile_supported(g_);   // Voigt, or laminate as its correction
 }
 
 // A = sum_p phi_p 2 mu_p, B = sum_p phi_p lambda_p per voxel (k_effective_moduli), computed once per geometry
@@ -756,6 +759,8 @@ void Solver::u_pass_front(const double* E6) {
       launch_laminate_delta(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, E, mixed_list_, mixed_n_,
                             dtau_, derr_, stream_);
       launch_delta_div(g_, aff_list_, aff_slots_, aff_n_, dtau_, ptrs3(fu_alt_), stream_);
+      if (!(frobenius(BC_MQ_) < kEps))   // mixed BC: <tau_laminate> = <tau_voigt> (from the sweep) + sum of the differences / N
+        launch_sum_dtau(dtau_, mixed_n_, partial_, dscal_ + kSlotScratch, stream_);
     }
   } else {
     z_done_ = false;
@@ -976,6 +981,8 @@ bool Solver::run(const double* E6, const double* S6) {
       // applyBCProjector  F:20247-20270 with bc_relax = 1: eps_{k+1} = E + alpha MQ:<tau_k> + sym grad u_{k+1}
       double F0[6], t1[6];
       for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)nglobal_;
+      if (opt_.mixing != kMixVoigt)
+        for (int c = 0; c < 6; ++c) F0[c] += hscal_[kSlotScratch + c] / (double)nglobal_;
       voigt_mv(BC_MQ_, F0, t1);
       for (int c = 0; c < 6; ++c) E_next_[c] = E[c] - t1[c];   // alpha = -1  (F:20575)
     }

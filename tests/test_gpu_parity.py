@@ -214,11 +214,12 @@ def test_homogeneous_and_callbacks():
     assert s2.iterations == 3 and len(s2.residuals) == 3
 
 
-@pytest.mark.parametrize("grid", [(16, 16, 16), (8, 14, 128)])   # the second grid takes the tiled divergence sweep
-def test_mixed_bc_uniaxial_stress(grid):
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+@pytest.mark.parametrize("grid", [(16, 16, 16), (8, 14, 128)])   # the second grid takes the tiled sweeps (displacement loop)
+def test_mixed_bc_uniaxial_stress(grid, mixing):
     """setBCProjector / calcBCMean / applyBCProjector F:20599-20665 on the GPU path."""
-    o = make_oracle(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
-    s = make_gpu_solver(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    o = make_oracle(grid, mixing=mixing, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    s = make_gpu_solver(grid, mixing=mixing, tol=1e-9, bc_tol=1e-8, maxiter=400)
     P = np.zeros((6, 6))
     P[0, 0] = 1.0
     E = np.array([0.01, 0, 0, 0, 0, 0])
