@@ -1,0 +1,29 @@
+import sys, time
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np
+from fibergen_amd import LSSolver
+from fibergen_amd.rve import synthetic_fiber_rve
+from helpers import INCLUSION, MATRIX, lame
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+mixing = sys.argv[2] if len(sys.argv) > 2 else "voigt"
+scale = max(n, 128) / 128.0
+phi, normals = synthetic_fiber_rve((n, n, n), K=int(round(40 * scale ** 3)), R=0.05 / scale, L=0.4 / scale, seed=0,
+                                   with_normals=(mixing == "laminate"))
+for method in ("cg", "basic"):
+    s = LSSolver(n, n, n)
+    s.set_num_phases(2)
+    m0, m1 = lame(**MATRIX), lame(**INCLUSION)
+    s.set_phase(0, m0[0], m0[1], 1 - phi); s.set_phase(1, m1[0], m1[1], phi)
+    if normals is not None:
+        s.set_normals(normals)
+    s.set_options(method=method, tol=1e-6, mixing_rule=mixing)
+    t0 = time.perf_counter()
+    S = np.zeros((6, 6)); its = []
+    for i in range(6):
+        E = np.zeros(6); E[i] = 1.0
+        assert s.run(E) is False
+        S[:, i] = s.mean_stress(); its.append(s.iterations)
+    dt = time.perf_counter() - t0
+    C = S.copy(); C[:, 3:] *= 0.5
+    print(method, mixing, n, "six load cases %.2f s, iterations %s, C11 %.6f C12 %.6f C44 %.6f" % (dt, its, C[0, 0], C[0, 1], C[3, 3]))
+    s.close()
