@@ -56,11 +56,11 @@ def test_fast_pipeline_equals_exact_pipeline_at_full_size(n):
     assert np.array_equal(res["exact"][0], res["plain"][0]) or np.allclose(res["exact"][0], res["plain"][0], rtol=1e-13)
 
 
-def test_homogeneous_medium_and_identity_at_256():
+@pytest.mark.parametrize("n", [256, 192, 320])   # 192 = 3*64, 320 = 5*64: the single-kernel p*2^k FFT passes at size
+def test_homogeneous_medium_and_identity_at_256(n):
     """(i) one phase everywhere: eps == E after one pass for any start; (ii) staggered epsG0div identity on a random
-    displacement field: eps(G0(div(C0 : eps(u)))) == eps(u)  (F:24129-24151) at 256^3."""
+    displacement field: eps(G0(div(C0 : eps(u)))) == eps(u)  (F:24129-24151) at 256^3 (and at two p*2^k sizes)."""
     from fibergen_amd import LSSolver
-    n = 256
     s = LSSolver(n, n, n)
     s.set_num_phases(1)
     s.set_phase(0, 0.7, 1.1, np.ones((n, n, n)))
