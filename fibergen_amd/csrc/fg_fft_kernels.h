@@ -40,6 +40,7 @@ struct StridedArgs {
   double scale;     // applied at the store (1.0 = none)
   const cplx* tw;   // pass twiddles of N
   int nt;           // streaming (cache-bypassing) stores, see cstore_stream
+  int xcd_order;    // 1: blockIdx is remapped so that each XCD works on a contiguous run of tiles
 };
 
 template <int N, int C, int DIR>
@@ -267,6 +268,7 @@ struct XFusedArgs {
   const cplx* half_root;   // e^{-i pi j / N}, j < N/8 (conjugated in the kernel)
   cplx xq[8];              // e^{+i pi off(q) / N}, off(q) = last_index(0, q)
   double inv_h;            // 1/h = 2 N / d of the transformed axis
+  int xcd_order;           // 1: blockIdx is remapped so that each XCD works on a contiguous run of tiles
 };
 
 // NC = 3: the three components of the elastic problem and G0OperatorFourierStaggeredGeneral; NC = 1: the scalar modes

@@ -42,6 +42,7 @@ int emu_strided(int N, int dir, double* data, int ncols, int nouter, double scal
   std::vector<cplx> tw = make_pass_twiddles(N);
   StridedArgs a;
   a.nt = 0;
+  a.xcd_order = 0;
   a.data = reinterpret_cast<cplx*>(data);
   a.ls = ncols;
   a.os = (long)N * ncols;
@@ -98,6 +99,7 @@ int emu_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, doub
   std::vector<cplx> tw = make_pass_twiddles(N);
   XFusedArgs a;
   a.nt = 0;
+  a.xcd_order = 0;
   a.data = reinterpret_cast<cplx*>(data);
   a.ncols = ny * nzc;
   a.comp_stride = (long)N * a.ncols;
