@@ -178,6 +178,7 @@ def main():
                     help="porous / heat: scalar potential, 3-component gradient; viscosity: dual Stokes scheme "
                          "(BASELINE config 5, 256^3)")
     ap.add_argument("--u-tile", type=int, default=None, help="override the solver's u_tile option (0, 8, 16)")
+    ap.add_argument("--fuse-z", type=int, default=None, help="override the solver's fuse_z option (attach the z r2c to the sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-slab", action="store_true", help="N > 1: skip the slab-decomposed measurement")
@@ -230,6 +231,8 @@ def main():
     s.set_options(mixing_rule=args.mixing)
     if args.u_tile is not None:
         s.set_options(u_tile=args.u_tile)
+    if args.fuse_z is not None:
+        s.set_options(fuse_z=args.fuse_z)
     vf = float(phi.mean())
     del phi, normals
     s.calc_ref_material()
