@@ -143,8 +143,8 @@ int fg_set_option_d(fg_solver* s, const char* key, double value) {
     else if (k == "bc_tol") o.bc_tol = value;
     else if (k == "ref_scale") o.ref_scale = value;
     else if (k == "bc_relax") o.bc_relax = value;
-    else if (k == "mu_0") o.mu_0 = value;
-    else if (k == "lambda_0") o.lambda_0 = value;
+    else if (k == "mu_0") { o.mu_0 = value; v.reference_material_changed(); }
+    else if (k == "lambda_0") { o.lambda_0 = value; v.reference_material_changed(); }
     else if (k == "eps_g") o.eps_g = value;
     else if (k == "eps_a") o.eps_a = value;
     else throw std::runtime_error("unknown option '" + k + "'");

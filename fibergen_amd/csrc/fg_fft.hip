@@ -381,13 +381,12 @@ bool launch_strided_mixed(const StridedArgs& a0, int nouter, int dir, int ncomp,
     StridedArgs a = a0;
     a.tiles_per_outer = (a.ncols + 7) / 8;
     const dim3 grid((unsigned)((long)a.tiles_per_outer * nouter), ncomp);
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.first_use()) {
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strided_mixed<M, P, -1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strided_mixed<M, P, +1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = true;
     }
     if (dir < 0) hipLaunchKernelGGL((k_strided_mixed<M, P, -1>), grid, dim3(M * P), lds, s, a, cs, wN);
     else hipLaunchKernelGGL((k_strided_mixed<M, P, +1>), grid, dim3(M * P), lds, s, a, cs, wN);
@@ -499,13 +498,12 @@ bool launch_z_mixed(double* data, long nrows, int nzp, int ncomp, long comp_stri
     return false;
   } else {
     const dim3 grid((unsigned)((nrows + LINES - 1) / LINES), ncomp);
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.first_use()) {
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_z_mixed<MP, P, LINES, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_z_mixed<MP, P, LINES, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = true;
     }
     if (fwd) hipLaunchKernelGGL((k_z_mixed<MP, P, LINES, true>), grid, dim3(THREADS), lds, s, data, nrows, nzp, comp_stride, tw, wn);
     else hipLaunchKernelGGL((k_z_mixed<MP, P, LINES, false>), grid, dim3(THREADS), lds, s, data, nrows, nzp, comp_stride, tw, wn);
@@ -669,11 +667,10 @@ bool launch_xfused_mixed(XFusedArgs a, int nouter, const cplx* wN, hipStream_t s
   } else {
     if (probe_only) return true;
     a.tiles_per_outer = (a.ncols + 7) / 8;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.first_use()) {
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused_mixed<M, P>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = true;
     }
     hipLaunchKernelGGL((k_xfused_mixed<M, P>), dim3((unsigned)((long)a.tiles_per_outer * nouter)), dim3(M * P), lds, s, a, wN);
     FG_HIP_CHECK(hipGetLastError());
@@ -810,12 +807,11 @@ cplx* upload(const std::vector<cplx>& v) {
 
 template <class K>
 void launch_strided(const StridedArgs& a, long nblocks, int ncomp, long comp_stride, hipStream_t s) {
-  static bool configured = false;
+  static PerDeviceOnce configured;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
-  if (!configured) {
+  if (configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strided<K>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   hipLaunchKernelGGL(k_strided<K>, dim3((unsigned)nblocks, ncomp), dim3(K::THREADS), lds, s, a, comp_stride);
   FG_HIP_CHECK(hipGetLastError());
@@ -823,12 +819,11 @@ void launch_strided(const StridedArgs& a, long nblocks, int ncomp, long comp_str
 
 template <class K>
 void launch_z(const ZArgs& a, int ncomp, long comp_stride, int lines, hipStream_t s) {
-  static bool configured = false;
+  static PerDeviceOnce configured;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
-  if (!configured) {
+  if (configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zpass<K>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   long nblocks = (a.nrows + lines - 1) / lines;
   hipLaunchKernelGGL(k_zpass<K>, dim3((unsigned)nblocks, ncomp), dim3(K::THREADS), lds, s, a, comp_stride);
@@ -848,12 +843,11 @@ void xfused_n(XFusedArgs a, int nouter, int ncomp, hipStream_t s) {
 template <int N, int C, int NC>
 void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
   using K = XFusedKernel<N, C, NC>;
-  static bool configured = false;
+  static PerDeviceOnce configured;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
-  if (!configured) {
+  if (configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused<K>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   a.tiles_per_outer = (a.ncols + C - 1) / C;
   const long nblocks = (long)a.tiles_per_outer * nouter;
@@ -1032,11 +1026,10 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
         cplx* d = reinterpret_cast<cplx*>(data + c * comp_stride);
 #define FG_TILE_COMBINE(D, PP)                                                                                         \
   do {                                                                                                                 \
-    static bool configured = false;                                                                                    \
-    if (!configured) {                                                                                                 \
+    static PerDeviceOnce configured;                                                                                    \
+    if (configured.first_use()) {                                                                                                 \
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixed_combine_tile<D, PP>),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
-      configured = true;                                                                                               \
     }                                                                                                                  \
     hipLaunchKernelGGL((k_mixed_combine_tile<D, PP>), grid, dim3(256), tile_lds, stream_, d, ls, os, ncols, tiles, m, p, \
                        scale, wgen_[axis]);                                                                            \
@@ -1214,11 +1207,10 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
       double* src = data + c * comp_stride;
 #define FG_FINISH(PP)                                                                                             \
   do {                                                                                                            \
-    static bool configured = false;                                                                               \
-    if (!configured) {                                                                                            \
+    static PerDeviceOnce configured;                                                                               \
+    if (configured.first_use()) {                                                                                            \
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixed_r2c_finish<PP>),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
-      configured = true;                                                                                          \
     }                                                                                                             \
     hipLaunchKernelGGL(k_mixed_r2c_finish<PP>, dim3(nb), dim3(256), lds, stream_, src, nrows, g_.nzp, M, p, rows, \
                        wgen_[2]);                                                                                 \
@@ -1273,11 +1265,10 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
       double* src = data + c * comp_stride;
 #define FG_START(PP)                                                                                             \
   do {                                                                                                           \
-    static bool configured = false;                                                                              \
-    if (!configured) {                                                                                           \
+    static PerDeviceOnce configured;                                                                              \
+    if (configured.first_use()) {                                                                                           \
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixed_c2r_start<PP>),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
-      configured = true;                                                                                         \
     }                                                                                                            \
     hipLaunchKernelGGL(k_mixed_c2r_start<PP>, dim3(nb), dim3(256), lds, stream_, src, nrows, g_.nzp, M, p, rows, \
                        wgen_[2]);                                                                                \

@@ -815,12 +815,7 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   const int nzh = g.nz / 2;
   const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
   static const int lx_env = getenv("FG_TILE_LX") ? atoi(getenv("FG_TILE_LX")) : 0;  // tuning knob (0 = by size)
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    FG_HIP_CHECK(hipGetDevice(&dev));
-    FG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  const int cus = device_cu_count();
   // march length: 32 planes (3 extra planes of loads per march), 16 when that leaves CUs without a workgroup
   // (128^3: 88 -> 176 workgroups, 0.053 -> 0.039 ms; 8 planes: 0.045 ms)
   int LX = lx_env > 0 ? lx_env : 32;
@@ -830,11 +825,10 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   int nb = nty * ntz * ntx;
   if (nb >= 8) nb = ((nb + 7) / 8) * 8;
   const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
-  static bool configured = false;
-  if (!configured) {
+  static PerDeviceOnce configured;
+  if (configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, ZS, SUMT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   const int nt = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
   hipLaunchKernelGGL((k_u_tile<TYR, ZS, SUMT>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E,
@@ -1006,12 +1000,7 @@ void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double*
   constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
   const int nzh = g.nz / 2;
   const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    FG_HIP_CHECK(hipGetDevice(&dev));
-    FG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  const int cus = device_cu_count();
   int LX = 32;
   if ((long)nty * ntz * ((g.nx + 31) / 32) < 2L * cus) LX = 16;
   if (LX > g.nx) LX = g.nx;
@@ -1050,12 +1039,7 @@ void launch_eps_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldP
   constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
   const int nzh = g.nz / 2;
   const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    FG_HIP_CHECK(hipGetDevice(&dev));
-    FG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  const int cus = device_cu_count();
   int LX = 32;
   if ((long)nty * ntz * ((g.nx + 31) / 32) < cus) LX = 16;
   if (LX > g.nx) LX = g.nx;
@@ -1063,11 +1047,10 @@ void launch_eps_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldP
   int nb = nty * ntz * ntx;
   if (nb >= 8) nb = ((nb + 7) / 8) * 8;
   const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
-  static bool configured = false;
-  if (!configured) {
+  static PerDeviceOnce configured;
+  if (configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eps_tile<TYR, ZS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   const int nt = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
   hipLaunchKernelGGL((k_eps_tile<TYR, ZS>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, eps, mod, f,

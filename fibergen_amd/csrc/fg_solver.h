@@ -80,6 +80,7 @@ class Solver {
   const Grid& grid() const { return g_; }
   SolverOptions& options() { return opt_; }
   void invalidate_moduli() { mod_dirty_ = true; }
+  void reference_material_changed() { recompute_bc(); }   // (mu_0, lambda_0) set from outside: M, MQ depend on C0
   hipStream_t stream() const { return stream_; }
 
   void set_num_phases(int n);

@@ -164,7 +164,7 @@ void Solver::set_num_phases(int n) {
   if (phi_) FG_HIP_CHECK(hipFree(phi_));
   phi_ = nullptr;
   FG_HIP_CHECK(hipMalloc(&phi_, (size_t)n * g_.n * sizeof(double)));
-  FG_HIP_CHECK(hipMemset(phi_, 0, (size_t)n * g_.n * sizeof(double)));
+  FG_HIP_CHECK(hipMemsetAsync(phi_, 0, (size_t)n * g_.n * sizeof(double), stream_));
   pt_.n = n;
   mod_dirty_ = true;
   mixed_dirty_ = true;
@@ -189,7 +189,7 @@ void Solver::set_normals(const double* n_host) {
   FG_HIP_CHECK(hipSetDevice(device_));
   if (!normals_) {
     FG_HIP_CHECK(hipMalloc(&normals_, 3 * g_.n * sizeof(double)));
-    FG_HIP_CHECK(hipMemset(normals_, 0, 3 * g_.n * sizeof(double)));
+    FG_HIP_CHECK(hipMemsetAsync(normals_, 0, 3 * g_.n * sizeof(double), stream_));
   }
   for (int c = 0; c < 3; ++c) upload_padded(normals_ + (long)c * g_.n, n_host + (long)c * g_.nxyz);
 }
