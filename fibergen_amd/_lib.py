@@ -22,6 +22,20 @@ class FgFiber(ctypes.Structure):
                 ("a", ctypes.c_double * 3), ("L", ctypes.c_double), ("R", ctypes.c_double)]
 
 
+class FgXop(ctypes.Structure):
+    """struct fg_xop: one send / receive of an exchange handed to the callback transport"""
+    _fields_ = [("send", ctypes.c_int), ("peer", ctypes.c_int), ("ptr", ctypes.c_void_p), ("bytes", ctypes.c_ulong)]
+
+
+class FgPlanOp(ctypes.Structure):
+    """struct fg_plan_op: one entry of the exchange plan (offsets / counts in doubles)"""
+    _fields_ = [("send", ctypes.c_int), ("peer", ctypes.c_int), ("buffer", ctypes.c_int), ("offset", ctypes.c_long),
+                ("count", ctypes.c_long)]
+
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(FgXop), ctypes.c_int)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int)
+
 # name -> (restype, argtypes); mirrors include/fibergen_amd.h one to one
 SIGNATURES = {
     "fg_abi_version": (ctypes.c_int, []),
@@ -63,6 +77,14 @@ SIGNATURES = {
     "fg_slab_phase": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p]),
     "fg_exchange_buffer": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulong)]),
     "fg_local_sums": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_double_p]),
+    "fg_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "fg_slab_connect_rccl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
+    "fg_slab_group_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "fg_slab_connect_callback": (ctypes.c_int, [ctypes.c_void_p, EXCHANGE_FN, ALLREDUCE_FN, ctypes.c_void_p]),
+    "fg_slab_transport": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "fg_slab_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.POINTER(FgPlanOp), ctypes.c_int, ctypes.POINTER(FgPlanOp)]),
     "fg_voxelize": (ctypes.c_int, [ctypes.POINTER(FgFiber), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_double, ctypes.c_double, ctypes.c_double, c_double_p, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p, c_double_p,

@@ -4,7 +4,13 @@
 #include <string>
 
 #include "../../include/fibergen_amd.h"
+#include <chrono>
+#include <memory>
+#include <vector>
+
 #include "fg_hip_util.h"
+#include "fg_slab.h"
+#include "fg_slab_plan.h"
 #include "fg_solver.h"
 
 struct fg_solver {
@@ -71,7 +77,7 @@ fg_solver* fg_create_slab(int nx, int ny, int nz, double dx, double dy, double d
   try {
     fg_solver* s = new fg_solver();
     try {
-      s->impl = new fg::Solver(nx, ny, nz, dx, dy, dz, device, rank, nranks);
+      s->impl = new fg::Solver(nx, ny, nz, dx, dy, dz, device, rank, nranks, /*slab_layout=*/true);
     } catch (...) {
       delete s;
       throw;
@@ -83,6 +89,89 @@ fg_solver* fg_create_slab(int nx, int ny, int nz, double dx, double dy, double d
     g_create_error = "unknown error";
   }
   return nullptr;
+}
+
+// ---- slab driver below the ABI ------------------------------------------------------------------------------------
+int fg_comm_unique_id(char* id) {
+  try {
+    if (!id) throw std::runtime_error("NULL argument");
+    fg::rccl_unique_id(id);
+    return FG_OK;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+  }
+  return FG_ERROR;
+}
+
+int fg_slab_connect_rccl(fg_solver* s, const char* id) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!id) throw std::runtime_error("NULL argument");
+    if (!v.is_slab()) throw std::runtime_error("not a slab solver (create it with fg_create_slab)");
+    auto comm = fg::make_rccl_comm(id, v.rank(), v.nranks(), v.device());
+    v.connect(std::move(comm), std::make_shared<fg::SlabGroup>(std::vector<fg::Solver*>{&v}));
+  });
+}
+
+int fg_slab_connect_callback(fg_solver* s, fg_exchange_fn exchange, fg_allreduce_fn allreduce, void* user) {
+  return guarded(s, [&](fg::Solver& v) {
+    auto comm = fg::make_callback_comm(v.rank(), v.nranks(), exchange, allreduce, user);
+    v.connect(std::move(comm), std::make_shared<fg::SlabGroup>(std::vector<fg::Solver*>{&v}));
+  });
+}
+
+const char* fg_slab_transport(const fg_solver* s) { return (s && s->impl) ? s->impl->transport() : ""; }
+
+int fg_slab_group_create(int nx, int ny, int nz, double dx, double dy, double dz, int device, int nranks, fg_solver** out) {
+  std::vector<fg_solver*> made;
+  try {
+    if (!out) throw std::runtime_error("NULL argument");
+    if (nranks < 1 || nranks > 16) throw std::runtime_error("in-process slab group: 1..16 members");
+    int ndev = 0;
+    FG_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) throw std::runtime_error("no HIP device available: fibergen_amd needs an AMD GPU (gfx950)");
+    if (device < 0 || device >= ndev) throw std::runtime_error("invalid device index");
+    FG_HIP_CHECK(hipSetDevice(device));
+    hipStream_t stream = nullptr;
+    FG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    auto group = std::make_shared<fg::SlabGroup>(std::vector<fg::Solver*>{}, stream);   // owns the stream
+    auto hub = fg::make_local_hub(nranks);
+    std::vector<fg::Solver*> members;
+    for (int r = 0; r < nranks; ++r) {
+      fg_solver* h = new fg_solver();
+      made.push_back(h);
+      h->impl = new fg::Solver(nx, ny, nz, dx, dy, dz, device, r, nranks, /*slab_layout=*/true, stream);
+      members.push_back(h->impl);
+    }
+    group->set_members(members);
+    for (int r = 0; r < nranks; ++r)
+      members[r]->connect(nranks > 1 ? fg::make_local_comm(hub, r) : std::unique_ptr<fg::Comm>(), group);
+    for (int r = 0; r < nranks; ++r) out[r] = made[r];
+    return FG_OK;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+  } catch (...) {
+    g_create_error = "unknown error";
+  }
+  for (fg_solver* h : made) {
+    delete h->impl;
+    delete h;
+  }
+  return FG_ERROR;
+}
+
+int fg_slab_plan(int nx, int ny, int nz, int nranks, int rank, int what, int comp, fg_plan_op* ops, int capacity,
+                 fg_plan_op* self_copy) {
+  if (nx < 1 || ny < 1 || nz < 1 || nranks < 1 || rank < 0 || rank >= nranks || nx % nranks || ny % nranks) return -1;
+  if (what < FG_PLAN_A2A_FORWARD || what > FG_PLAN_HALO_TAU || comp < 0 || comp > 2) return -1;
+  const fg::SlabPlan p = fg::slab_plan(fg::slab_dims(nx, ny, nz, nranks, rank), what, comp);
+  if ((int)p.ops.size() > capacity && ops) return -1;
+  if (ops)
+    for (size_t i = 0; i < p.ops.size(); ++i) ops[i] = p.ops[i];
+  if (self_copy) {
+    self_copy[0] = p.self_src;
+    self_copy[1] = p.self_dst;
+  }
+  return (int)p.ops.size();
 }
 
 int fg_slab_phase(fg_solver* s, int phase, const double* E6, const double* R6) {
@@ -203,7 +292,7 @@ int fg_cancel(fg_solver* s) {
 int fg_run_load_case(fg_solver* s, const double* E6, const double* S6, int* failed) {
   return guarded(s, [&](fg::Solver& v) {
     if (!E6) throw std::runtime_error("strain pointer is NULL");
-    const bool f = v.run(E6, S6);
+    const bool f = v.is_slab() ? v.slab_group().run(E6, S6) : v.run(E6, S6);   // slab solvers: collective call
     if (failed) *failed = f ? 1 : 0;
   });
 }
@@ -211,13 +300,24 @@ int fg_run_load_case(fg_solver* s, const double* E6, const double* S6, int* fail
 int fg_iterate(fg_solver* s, const double* E6, int n) {
   return guarded(s, [&](fg::Solver& v) {
     if (!E6) throw std::runtime_error("strain pointer is NULL");
-    v.iterate(E6, n);
+    if (v.is_slab()) v.slab_group().iterate(E6, n);
+    else v.iterate(E6, n);
   });
 }
 
 int fg_time_iterations(fg_solver* s, const double* E6, int n, double* elapsed_ms) {
   return guarded(s, [&](fg::Solver& v) {
     if (!E6) throw std::runtime_error("strain pointer is NULL");
+    if (v.is_slab()) {
+      // exchanges run on a second stream: the timed region is bracketed on the host by full synchronisations
+      fg::SlabGroup& grp = v.slab_group();
+      grp.synchronize();
+      const auto t0 = std::chrono::steady_clock::now();
+      grp.iterate(E6, n);
+      grp.synchronize();
+      if (elapsed_ms) *elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      return;
+    }
     hipEvent_t a, b;
     FG_HIP_CHECK(hipEventCreate(&a));
     FG_HIP_CHECK(hipEventCreate(&b));
@@ -247,17 +347,26 @@ int fg_get_residuals(const fg_solver* s, double* out, int capacity) {
 double fg_get_solve_time(const fg_solver* s) { return (s && s->impl) ? s->impl->solve_time() : 0.0; }
 
 int fg_mean_stress(fg_solver* s, double* out6) {
-  return guarded(s, [&](fg::Solver& v) { v.mean_stress(out6); });
+  return guarded(s, [&](fg::Solver& v) {
+    if (v.is_slab()) v.slab_group().mean_stress(out6);
+    else v.mean_stress(out6);
+  });
 }
 int fg_mean_strain(fg_solver* s, double* out6) {
-  return guarded(s, [&](fg::Solver& v) { v.mean_strain(out6); });
+  return guarded(s, [&](fg::Solver& v) {
+    if (v.is_slab()) v.slab_group().mean_strain(out6);
+    else v.mean_strain(out6);
+  });
 }
 int fg_volume_fraction(fg_solver* s, int p, double* out) {
-  return guarded(s, [&](fg::Solver& v) { *out = v.volume_fraction(p); });
+  return guarded(s, [&](fg::Solver& v) { *out = v.is_slab() ? v.slab_group().volume_fraction(p) : v.volume_fraction(p); });
 }
 
 int fg_calc_ref_material(fg_solver* s) {
-  return guarded(s, [&](fg::Solver& v) { v.calc_ref_material(); });
+  return guarded(s, [&](fg::Solver& v) {
+    if (v.is_slab()) v.slab_group().calc_ref_material();
+    else v.calc_ref_material();
+  });
 }
 int fg_get_ref_material(const fg_solver* s, double* mu_0, double* lambda_0) {
   if (!s || !s->impl) return FG_ERROR;
@@ -289,7 +398,10 @@ void* fg_device_pointer(fg_solver* s, const char* name, int comp) {
 }
 void* fg_get_stream(fg_solver* s) { return (s && s->impl) ? (void*)s->impl->stream() : nullptr; }
 int fg_synchronize(fg_solver* s) {
-  return guarded(s, [&](fg::Solver& v) { FG_HIP_CHECK(hipStreamSynchronize(v.stream())); });
+  return guarded(s, [&](fg::Solver& v) {
+    if (v.is_slab()) v.slab_group().synchronize();
+    else FG_HIP_CHECK(hipStreamSynchronize(v.stream()));
+  });
 }
 
 int fg_run_stage(fg_solver* s, int stage, const double* E6) {

@@ -84,6 +84,10 @@ struct Grid {
   long nxyz;    // nx*ny*nz
   double dx, dy, dz;
   double hx, hy, hz;  // voxels per unit length of the GLOBAL grid: n_a / d_a  (F:18618-18620)
+  // x neighbours of the marching displacement sweep: plane q < 0 lives at q + xw_lo, plane q >= nx at q - xw_hi.
+  // Periodic field: both nx.  x-slab of a decomposed grid (the component carries 4 spare planes behind its nx own
+  // ones): plane nx (first plane of the right neighbour) at nx, plane -1 (last plane of the left neighbour) at nx + 3.
+  int xw_lo, xw_hi;
 };
 
 FG_HD Grid make_grid(int nx, int ny, int nz, double dx, double dy, double dz) {
@@ -97,6 +101,7 @@ FG_HD Grid make_grid(int nx, int ny, int nz, double dx, double dy, double dz) {
   g.nxyz = (long)nx * ny * nz;
   g.dx = dx; g.dy = dy; g.dz = dz;
   g.hx = nx / dx; g.hy = ny / dy; g.hz = nz / dz;
+  g.xw_lo = g.xw_hi = nx;
   return g;
 }
 

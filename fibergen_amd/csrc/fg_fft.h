@@ -38,6 +38,11 @@ class Fft3 {
   void c2c_x(double* data, int ncomp, long comp_stride, int dir, double scale);
   void c2r_z(double* data, int ncomp, long comp_stride);
   void scale(double* data, int ncomp, long comp_stride, double scale);
+  // Slab decomposition (x-slab side): the y pass with the all-to-all layout on one side.  Plain layout
+  // [nx][ny][nzc]; blocked layout [q][nx][ny/P][nzc] (block q = what peer q receives / sent), see StridedArgs.
+  // dir = -1: in plain -> out blocked (forward); dir = +1: in blocked -> out plain (inverse).  Component strides in doubles.
+  bool can_block_y(int nranks) const;
+  void c2c_y_blocked(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale, int nranks);
   bool can_fuse(int axis, int ncomp = 3) const;
   // ncomp = 3: elastic Green operator on three components; ncomp = 1: scalar (heat / porous) operator c10 / |k|^2
   void fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp = 3);

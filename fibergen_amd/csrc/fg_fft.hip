@@ -59,6 +59,7 @@ template <class K>
 __global__ __launch_bounds__(K::THREADS) void k_strided(StridedArgs a, long comp_stride) {
   extern __shared__ __align__(16) double lds[];
   a.data += (long)blockIdx.y * comp_stride;
+  if (a.out) a.out += (long)blockIdx.y * a.out_cs;
   typename K::Regs r;
   int b = blockIdx.x;
   if (a.xcd_order && gridDim.x % 8 == 0) b = (b % 8) * (gridDim.x / 8) + b / 8;
@@ -546,8 +547,9 @@ __global__ __launch_bounds__(M * P) void k_xfused_mixed(XFusedArgs a, const cplx
   const long base = (long)o * a.os + colc;
   int jj, kk;
   if (a.flat_cols) {
-    jj = colc / a.nzc;
-    kk = colc - jj * a.nzc;
+    const int jl = colc / a.nzc;
+    jj = a.jj0 + jl;
+    kk = colc - jl * a.nzc;
   } else {
     jj = a.jj0 + o;
     kk = colc;
@@ -1157,6 +1159,44 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
     case 512: xfused_n<512>(a, nouter, ncomp, stream_); break;
     default: throw std::runtime_error("fft: unsupported fused length");
   }
+}
+
+bool Fft3::can_block_y(int nranks) const {
+  if (nranks < 1 || g_.ny % nranks) return false;
+  const int nyl = g_.ny / nranks;
+  return fast_[1] && is_pow2(nyl);
+}
+
+void Fft3::c2c_y_blocked(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale, int nranks) {
+  if (!can_block_y(nranks)) throw std::runtime_error("fft: blocked y pass not available for this length");
+  const int nyl = g_.ny / nranks;
+  int sh = 0;
+  while ((1 << sh) < nyl) ++sh;
+  const long plain_os = (long)g_.ny * g_.nzc, blocked_os = (long)nyl * g_.nzc;
+  const long jump = (long)g_.nx * nyl * g_.nzc - (long)nyl * g_.nzc;
+  StridedArgs a;
+  a.data = reinterpret_cast<cplx*>(in);
+  a.out = reinterpret_cast<cplx*>(out);
+  a.out_cs = out_cs / 2;
+  a.ls = g_.nzc;
+  a.ncols = g_.nzc;
+  a.tiles_per_outer = 0;
+  a.scale = scale;
+  a.tw = tw_[1];
+  a.nt = stream_stores_ ? (1 | ((nt_loads_env() & 1) ? 2 : 0)) : 0;
+  a.xcd_order = 0;
+  if (dir < 0) {
+    a.os = plain_os;
+    a.os_out = blocked_os;
+    a.split_out = sh;
+    a.jump_out = jump;
+  } else {
+    a.os = blocked_os;
+    a.os_out = plain_os;
+    a.split_in = sh;
+    a.jump_in = jump;
+  }
+  strided_pow2(g_.ny, a, g_.nx, dir, ncomp, in_cs / 2, stream_);
 }
 
 void Fft3::c2c_y(double* data, int ncomp, long comp_stride, int dir, double scale) {

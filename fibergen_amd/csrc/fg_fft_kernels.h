@@ -41,6 +41,15 @@ struct StridedArgs {
   const cplx* tw;   // pass twiddles of N
   int nt;           // streaming (cache-bypassing) stores, see cstore_stream
   int xcd_order;    // 1: blockIdx is remapped so that each XCD works on a contiguous run of tiles
+  // Slab decomposition: the y pass writes (forward) / reads (inverse) the all-to-all layout
+  // [peer q][x][ky mod nyl][kz] directly, so the pencil transpose needs no pack / unpack sweeps.  Line point j of the
+  // re-mapped side sits at  j*ls + (j >> split) * jump  (split = log2 nyl, jump = block stride - nyl*ls); the other
+  // side keeps the plain layout.  Defaults = in place, plain layout on both sides.
+  cplx* out = nullptr;       // nullptr: in place
+  long out_cs = 0;           // complex elements between components of `out` (out != nullptr)
+  long os_out = 0;           // outer stride on the store side (out != nullptr)
+  int split_in = 31, split_out = 31;
+  long jump_in = 0, jump_out = 0;
 };
 
 template <int N, int C, int DIR>
@@ -52,7 +61,7 @@ struct StridedKernel {
   static constexpr int NPHASE = Line<N>::NPHASE;
   struct Regs {
     cplx v[8];
-    long base;
+    long base, obase;
     int jt, t;
     bool valid;
   };
@@ -66,17 +75,23 @@ struct StridedKernel {
       int col = (block % a.tiles_per_outer) * C + r.t;
       r.valid = col < a.ncols;
       r.base = (long)o * a.os + col;
+      r.obase = a.out ? (long)o * a.os_out + col : r.base;
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        r.v[q] = r.valid ? cload_stream(&a.data[r.base + (long)Line<N>::first_index(r.jt, q) * a.ls], a.nt) : cmake(0.0, 0.0);
+      for (int q = 0; q < 8; ++q) {
+        const int j = Line<N>::first_index(r.jt, q);
+        r.v[q] = r.valid ? cload_stream(&a.data[r.base + (long)j * a.ls + (long)(j >> a.split_in) * a.jump_in], a.nt)
+                         : cmake(0.0, 0.0);
+      }
     }
     Line<N>::template phase<DIR, PH>(r.v, r.jt, lds, L, r.t, a.tw);
     if (PH == NPHASE - 1 && r.valid) {
+      cplx* const dst = a.out ? a.out : a.data;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         cplx o = r.v[q];
         if (a.scale != 1.0) o = cscale(a.scale, o);
-        cstore_stream(&a.data[r.base + (long)Line<N>::last_index(r.jt, q) * a.ls], o, a.nt);
+        const int j = Line<N>::last_index(r.jt, q);
+        cstore_stream(&dst[r.obase + (long)j * a.ls + (long)(j >> a.split_out) * a.jump_out], o, a.nt);
       }
     }
   }
@@ -304,8 +319,9 @@ struct XFusedKernel {
     *valid = col < a.ncols;
     *base = (long)o * a.os + col;
     if (a.flat_cols) {
-      *jj = col / a.nzc;
-      *kk = col - *jj * a.nzc;
+      const int jl = col / a.nzc;
+      *jj = a.jj0 + jl;           // jj0 != 0: y-slab [nx][ny/P][nzc] of a slab-decomposed grid
+      *kk = col - jl * a.nzc;
     } else {
       *jj = a.jj0 + o;
       *kk = col;

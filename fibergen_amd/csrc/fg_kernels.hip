@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables
       jj = lay.jj0 + jl;
     } else {
       ii = (int)(row / g.ny);
-      jj = (int)(row - (long)ii * g.ny);
+      jj = lay.jj0 + (int)(row - (long)ii * g.ny);   // jj0 != 0: y-slab [nx][ny/P][nzc] of the slab driver
     }
     cplx* c0 = reinterpret_cast<cplx*>(fh.p[0]);
     cplx* c1 = reinterpret_cast<cplx*>(fh.p[1]);

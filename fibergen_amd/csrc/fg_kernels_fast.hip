@@ -355,8 +355,8 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const int nsteps = surplus ? -2 : (x0 + LX <= g.nx ? LX : g.nx - x0);   // surplus: no steps at all
 
-  auto plane = [&](int q) {  // element offset of x plane q (periodic; q in [-1, 2 nx))
-    const int x = q < 0 ? q + g.nx : (q >= g.nx ? q - g.nx : q);
+  auto plane = [&](int q) {  // element offset of x plane q (periodic, or the halo planes of an x-slab; q in [-1, 2 nx))
+    const int x = q < 0 ? q + g.xw_lo : (q >= g.nx ? q - g.xw_hi : q);
     return (long)x * g.nyzp + rowoff;
   };
   // f is read back by the z pass only after the whole sweep: with fields larger than the Infinity Cache it is stored

@@ -1,0 +1,685 @@
+// Slab-decomposed Lippmann-Schwinger loop: per-member steps (Solver::slab_*) and the collective driver (SlabGroup).
+// See fg_slab.h, fg_slab_plan.h (layouts, exchange plan) and fg_comm.h (transports).
+#include "fg_slab.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+#include "fg_hip_util.h"
+#include "fg_slab_plan.h"
+
+namespace fg {
+
+using namespace hostmath;
+using namespace slots;
+
+namespace {
+constexpr double kEps = 2.220446049250313e-16;
+// comm -> compute event slots
+constexpr int kXA2AFwd = 0, kXA2ABwd = 3, kXHaloU = 6, kXHaloTau = 7, kXModuli = 8, kXSums = 9;
+
+double now_seconds() {
+  using clk = std::chrono::steady_clock;
+  return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
+}
+
+// y lengths the blocked FFT pass does not cover: plain [nxl][ny][nzc] <-> blocked [q][nxl][nyl][nzc] copy of one component
+__global__ void k_block_remap(const cplx* in, cplx* out, int nxl, int ny, int nyl, int nzc, int to_blocked) {
+  const long total = (long)nxl * ny * nzc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / nzc;
+    const int k = (int)(idx - row * nzc);
+    const int x = (int)(row / ny);
+    const int j = (int)(row - (long)x * ny);
+    const int q = j / nyl, jl = j - q * nyl;
+    const long b = (long)q * nxl * nyl * nzc + ((long)x * nyl + jl) * nzc + k;
+    if (to_blocked) out[b] = in[idx];
+    else out[idx] = in[b];
+  }
+}
+
+void launch_block_remap(const double* in, double* out, const Grid& g, int nyl, bool to_blocked, hipStream_t s) {
+  const long total = (long)g.nx * g.ny * g.nzc;
+  long nb = (total + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(k_block_remap, dim3((unsigned)nb), dim3(256), 0, s, reinterpret_cast<const cplx*>(in),
+                     reinterpret_cast<cplx*>(out), g.nx, g.ny, nyl, g.nzc, to_blocked ? 1 : 0);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+FieldPtrs<3> strided3(double* base, long stride) {
+  FieldPtrs<3> f;
+  for (int c = 0; c < 3; ++c) f.p[c] = base + c * stride;
+  return f;
+}
+}  // namespace
+
+// ===================================================================================================== member side
+void Solver::connect(std::unique_ptr<Comm> comm, std::shared_ptr<SlabGroup> group) {
+  if (!slab_layout_) throw std::runtime_error("not a slab solver (create it with fg_create_slab or fg_slab_group_create)");
+  if (comm_ || group_) throw std::runtime_error("slab solver is already connected to a transport");
+  if (comm && (comm->size() != nranks_ || comm->rank() != rank_))
+    throw std::runtime_error("transport rank / size differ from the solver's");
+  FG_HIP_CHECK(hipSetDevice(device_));
+  comm_ = std::move(comm);
+  group_ = std::move(group);
+  if (comm_ && std::strcmp(comm_->name(), "rccl") == 0) {
+    // exchanges overlap the transforms of the next component: own stream, joined by events
+    FG_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+    owns_comm_stream_ = true;
+  }
+}
+
+SlabGroup& Solver::slab_group() {
+  if (!slab_layout_) throw std::runtime_error("not a slab solver");
+  if (!group_) {
+    if (nranks_ != 1) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
+    group_ = std::make_shared<SlabGroup>(std::vector<Solver*>{this});   // a lone slab is periodic in itself
+  }
+  return *group_;
+}
+
+void Solver::slab_alloc() {
+  if (su_[0]) return;
+  FG_HIP_CHECK(hipSetDevice(device_));
+  ucs_ = g_.n + 4 * g_.nyzp;
+  for (int k = 0; k < 2; ++k) {
+    FG_HIP_CHECK(hipMalloc(&su_[k], 3 * (size_t)ucs_ * sizeof(double)));
+    FG_HIP_CHECK(hipMemsetAsync(su_[k], 0, 3 * (size_t)ucs_ * sizeof(double), stream_));
+  }
+  FG_HIP_CHECK(hipMalloc(&smod_, 2 * (size_t)ucs_ * sizeof(double)));
+  FG_HIP_CHECK(hipMemsetAsync(smod_, 0, 2 * (size_t)ucs_ * sizeof(double), stream_));
+  smod_dirty_ = true;
+  gu_ = g_;
+  gu_.xw_lo = g_.nx + 4;   // plane -1 -> spare plane nx + 3
+  gu_.xw_hi = 0;           // planes nx, nx + 1, nx + 2 -> themselves (the last two are loaded by the march, never used)
+  fft_ys_.reset(new Fft3(make_grid(nxg_, nyl_, g_.nz, 1.0, 1.0, 1.0), stream_));
+  FG_HIP_CHECK(hipEventCreateWithFlags(&ev_c2x_, hipEventDisableTiming));
+  FG_HIP_CHECK(hipEventCreateWithFlags(&ev_norm_, hipEventDisableTiming));
+  for (int k = 0; k < kCommSlots; ++k) FG_HIP_CHECK(hipEventCreateWithFlags(&ev_x_[k], hipEventDisableTiming));
+}
+
+void Solver::comm_begin() {
+  if (comm_stream_ == stream_) return;
+  FG_HIP_CHECK(hipEventRecord(ev_c2x_, stream_));
+  FG_HIP_CHECK(hipStreamWaitEvent(comm_stream_, ev_c2x_, 0));
+}
+void Solver::comm_end(int slot) {
+  if (comm_stream_ == stream_) return;
+  FG_HIP_CHECK(hipEventRecord(ev_x_[slot], comm_stream_));
+  x_pending_[slot] = true;
+}
+void Solver::comm_wait(int slot) {
+  if (!x_pending_[slot]) return;
+  FG_HIP_CHECK(hipStreamWaitEvent(stream_, ev_x_[slot], 0));
+  x_pending_[slot] = false;
+}
+
+double* Solver::slab_buffer(int id) {
+  switch (id) {
+    case FG_BUF_SPECTRUM_X: return tau_;
+    case FG_BUF_SPECTRUM_Y: return nranks_ == 1 ? tau_ : tau_ + 3 * g_.n;   // one slab: the all-to-all is the identity
+    case FG_BUF_U: return su_[su_cur_ ^ 1];                                  // the displacement the chain is producing
+    case FG_BUF_MODULI: return smod_;
+    case FG_BUF_HALO_SEND_LO: return halo_[0];
+    case FG_BUF_HALO_SEND_HI: return halo_[1];
+    case FG_BUF_HALO_RECV_LO: return halo_[2];
+    case FG_BUF_HALO_RECV_HI: return halo_[3];
+  }
+  throw std::runtime_error("unknown slab buffer");
+}
+
+// One exchange of the plan.  A lone slab is periodic in itself: its halo planes are its own planes.
+void Solver::slab_exchange(int what, int comp, int done_slot) {
+  const SlabDims d = slab_dims(nxg_, g_.ny, g_.nz, nranks_, rank_);
+  const size_t pb = (size_t)d.plane * sizeof(double);
+  if (nranks_ == 1) {
+    if (what == FG_PLAN_HALO_U || what == FG_PLAN_HALO_MODULI) {
+      double* base = slab_buffer(what == FG_PLAN_HALO_U ? FG_BUF_U : FG_BUF_MODULI);
+      const int nc = what == FG_PLAN_HALO_U ? 3 : 2;
+      for (int c = 0; c < nc; ++c) {
+        double* b = base + c * d.ucs;
+        FG_HIP_CHECK(hipMemcpyAsync(b + slab_hi_plane(d) * d.plane, b, pb, hipMemcpyDeviceToDevice, stream_));
+        FG_HIP_CHECK(hipMemcpyAsync(b + slab_lo_plane(d) * d.plane, b + (long)(d.nxl - 1) * d.plane, pb, hipMemcpyDeviceToDevice,
+                                    stream_));
+      }
+    } else if (what == FG_PLAN_HALO_TAU) {
+      FG_HIP_CHECK(hipMemcpyAsync(halo_[2], halo_[1], pb, hipMemcpyDeviceToDevice, stream_));
+      FG_HIP_CHECK(hipMemcpyAsync(halo_[3], halo_[0], 2 * pb, hipMemcpyDeviceToDevice, stream_));
+    }
+    return;
+  }
+  if (!comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
+  const SlabPlan p = slab_plan(d, what, comp);
+  std::vector<XOp> ops(p.ops.size());
+  for (size_t i = 0; i < p.ops.size(); ++i) {
+    const fg_plan_op& o = p.ops[i];
+    ops[i] = XOp{o.send, o.peer, slab_buffer(o.buffer) + o.offset, (size_t)o.count * sizeof(double)};
+  }
+  comm_begin();
+  if (p.self_src.count)
+    FG_HIP_CHECK(hipMemcpyAsync(slab_buffer(p.self_dst.buffer) + p.self_dst.offset, slab_buffer(p.self_src.buffer) + p.self_src.offset,
+                                (size_t)p.self_src.count * sizeof(double), hipMemcpyDeviceToDevice, comm_stream_));
+  comm_->exchange(ops.data(), (int)ops.size(), comm_stream_);
+  comm_end(done_slot);
+}
+
+void Solver::slab_reduce(int slot, int n, bool min_op) {
+  if (nranks_ == 1) return;
+  if (!comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
+  comm_begin();
+  comm_->allreduce(dscal_ + slot, n, min_op, comm_stream_);
+  comm_end(kXSums);
+}
+
+void Solver::slab_fetch_norms(int n) {
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, n * sizeof(double), hipMemcpyDeviceToHost, comm_stream_));
+  FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, comm_stream_));
+  FG_HIP_CHECK(hipEventRecord(ev_norm_, comm_stream_));
+}
+
+bool Solver::slab_fast_ok(bool allow_mixed_bc) const {
+  if (!(opt_.u_loop >= 2 && opt_.u_tile && opt_.mode == 0 && opt_.gamma_scheme == 0 && opt_.mixing == kMixVoigt && pt_.n >= 1 &&
+        opt_.bc_relax == 1.0 && u_tile_supported(g_)))
+    return false;
+  return frobenius(BC_MQ_) < kEps || allow_mixed_bc;
+}
+
+void Solver::slab_moduli_step() {
+  if (!smod_dirty_) return;
+  FieldPtrs<2> mod;
+  mod.p[0] = smod_;
+  mod.p[1] = smod_ + ucs_;
+  launch_effective_moduli(g_, phase_table(), phase_ptrs(), mod, stream_);
+  slab_exchange(FG_PLAN_HALO_MODULI, 0, kXModuli);
+  smod_dirty_ = false;
+}
+
+// u_k (with the +-1 planes of the neighbours) -> all-reduced sums of squares of eps_k (, sums of tau), f_{k+1} in fu_
+void Solver::slab_front_fast(const double* E6, bool sum_tau) {
+  comm_wait(kXHaloU);
+  comm_wait(kXModuli);
+  comm_wait(kXSums);
+  Vec6 E;
+  for (int c = 0; c < 6; ++c) E.v[c] = E6[c];
+  FieldPtrs<2> mod;
+  mod.p[0] = smod_;
+  mod.p[1] = smod_ + ucs_;
+  launch_u_tile(gu_, opt_.mu_0, opt_.lambda_0, strided3(su_[su_cur_], ucs_), mod, ptrs3(fu_), E, partial_, dscal_ + kSlotSumSq,
+                opt_.u_tile, stream_, sum_tau);
+  slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
+}
+
+// The transform chain of one pass, cut into steps that each end in one exchange (k = 1..9):
+//   1..3  component c = k-1: z r2c, y c2c into the all-to-all layout          | all-to-all(c) forward
+//   4     x c2c + Green operator + x c2c^-1 on the y-slab, three components   | all-to-all(0) back
+//   5, 6                                                                      | all-to-all(1), (2) back
+//   7..9  component c = k-7: y c2c^-1 out of the all-to-all layout, z c2r     | (9:) halo planes of the new u
+// f is read from fu_, the new displacement lands in su_[next].
+void Solver::slab_chain_step(int k) {
+  const long n = g_.n;
+  double* S = slab_buffer(FG_BUF_SPECTRUM_X);
+  double* R = slab_buffer(FG_BUF_SPECTRUM_Y);
+  double* un = su_[su_cur_ ^ 1];
+  const bool blocked = fft_->can_block_y(nranks_);
+  if (k >= 1 && k <= 3) {
+    const int c = k - 1;
+    double* f = fu_ + c * n;
+    fft_->r2c_z(f, 1, n);
+    if (blocked) {
+      fft_->c2c_y_blocked(f, n, S + c * n, n, 1, -1, 1.0, nranks_);
+    } else {
+      fft_->c2c_y(f, 1, n, -1, 1.0);
+      launch_block_remap(f, S + c * n, g_, nyl_, true, stream_);
+    }
+    slab_exchange(FG_PLAN_A2A_FORWARD, c, kXA2AFwd + c);
+  } else if (k == 4) {
+    for (int c = 0; c < 3; ++c) comm_wait(kXA2AFwd + c);
+    const double alpha = -1.0;   // GammaOperator(..., -1)  F:20575
+    const double scale = 1 / (double)nglobal_;
+    G0Params gp;
+    gp.c10 = -alpha / (opt_.mu_0);
+    gp.c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    gp.inv_h0 = 2.0 * nxg_ / g_.dx;
+    G0Tables tb;
+    for (int a = 0; a < 3; ++a) {
+      tb.kpm[a] = gp.kpm[a] = g0_kpm_[a];
+      tb.kp[a] = gp.kp[a] = g0_kp_[a];
+    }
+    const int jj0 = rank_ * nyl_;   // this rank's ky rows
+    if (opt_.fuse_x && nxg_ > 1 && fft_ys_->can_fuse(0)) {
+      fft_ys_->fused_g0(R, n, 0, scale, gp, jj0);
+    } else {
+      if (nxg_ > 1) fft_ys_->c2c_x(R, 3, n, -1, scale);
+      else fft_ys_->scale(R, 3, n, scale);
+      Grid gy = make_grid(nxg_, nyl_, g_.nz, 1.0, 1.0, 1.0);
+      launch_g0(gy, ptrs3(R), tb, gp.c10, gp.c20, G0Layout{0, nyl_, jj0}, stream_);
+      if (nxg_ > 1) fft_ys_->c2c_x(R, 3, n, +1, 1.0);
+    }
+    slab_exchange(FG_PLAN_A2A_BACKWARD, 0, kXA2ABwd + 0);
+  } else if (k == 5 || k == 6) {
+    slab_exchange(FG_PLAN_A2A_BACKWARD, k - 4, kXA2ABwd + k - 4);
+  } else if (k >= 7 && k <= 9) {
+    const int c = k - 7;
+    comm_wait(kXA2ABwd + c);
+    double* u = un + c * ucs_;
+    if (blocked) {
+      fft_->c2c_y_blocked(S + c * n, n, u, ucs_, 1, +1, 1.0, nranks_);
+    } else {
+      launch_block_remap(S + c * n, u, g_, nyl_, false, stream_);
+      fft_->c2c_y(u, 1, ucs_, +1, 1.0);
+    }
+    fft_->c2r_z(u, 1, ucs_);
+    if (k == 9) slab_exchange(FG_PLAN_HALO_U, 0, kXHaloU);
+  } else {
+    throw std::runtime_error("slab_chain_step: k out of range");
+  }
+}
+
+// strain-state pipeline (laminate mixing, grids the tiled sweep does not fit, mixed BC with relaxation)
+void Solver::slab_front_exact(bool sum_tau) {
+  comm_wait(kXHaloU);
+  comm_wait(kXSums);
+  if (su_valid_ && eps_stale_) slab_materialise_eps();
+  if (opt_.mixing == kMixLaminate && !normals_) throw std::runtime_error("laminate mixing needs interface normals");
+  FieldPtrs<3> nrm;
+  for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+  launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phase_ptrs(), nrm, ptrs6(tau_), derr_, stream_);
+  if (sum_tau) launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);
+  const long plane = g_.nyzp, last = (long)(g_.nx - 1) * g_.nyzp;
+  launch_copy(tau_ + 0 * g_.n + last, halo_[1], plane, stream_);     // tau0, my last plane  -> right (x-1 there)
+  launch_copy(tau_ + 5 * g_.n, halo_[0], plane, stream_);            // tau5, my first plane -> left  (x+1 there)
+  launch_copy(tau_ + 4 * g_.n, halo_[0] + plane, plane, stream_);    // tau4
+  slab_exchange(FG_PLAN_HALO_TAU, 0, kXHaloTau);
+  if (sum_tau) slab_reduce(kSlotMean, 6, false);
+}
+
+void Solver::slab_div_exact() {
+  comm_wait(kXHaloTau);
+  const long plane = g_.nyzp;
+  XHalo h = {{halo_[2], nullptr}, {halo_[3], halo_[3] + plane}};
+  launch_div(g_, ptrs6(tau_), ptrs3(fu_), h, stream_);
+}
+
+void Solver::slab_back_exact(const double* E6, const double* R6) {
+  comm_wait(kXHaloU);
+  double* un = su_[su_cur_ ^ 1];
+  const SlabDims d = slab_dims(nxg_, g_.ny, g_.nz, nranks_, rank_);
+  const long lo = slab_lo_plane(d) * d.plane, hi = slab_hi_plane(d) * d.plane;
+  XHalo h = {{un + 1 * ucs_ + lo, un + 2 * ucs_ + lo}, {un + 0 * ucs_ + hi, nullptr}};
+  Vec6 E, R;
+  bool add_R = false;
+  for (int c = 0; c < 6; ++c) {
+    E.v[c] = E6[c];
+    R.v[c] = R6 ? R6[c] : 0.0;
+    if (R.v[c] != 0.0) add_R = true;
+  }
+  launch_eps_norm(g_, strided3(un, ucs_), ptrs6(eps_), E, R, add_R, partial_, dscal_ + kSlotSumSq, h, stream_);
+  slab_reduce(kSlotSumSq, 6, false);
+}
+
+void Solver::slab_materialise_eps() {
+  comm_wait(kXHaloU);
+  double* u = su_[su_cur_];
+  const SlabDims d = slab_dims(nxg_, g_.ny, g_.nz, nranks_, rank_);
+  const long lo = slab_lo_plane(d) * d.plane, hi = slab_hi_plane(d) * d.plane;
+  XHalo h = {{u + 1 * ucs_ + lo, u + 2 * ucs_ + lo}, {u + 0 * ucs_ + hi, nullptr}};
+  Vec6 E, R;
+  for (int c = 0; c < 6; ++c) E.v[c] = E_cur_[c], R.v[c] = 0.0;
+  launch_eps_norm(g_, strided3(u, ucs_), ptrs6(eps_), E, R, false, partial_, dscal_ + kSlotScratch, h, stream_);
+  eps_stale_ = false;
+}
+
+void Solver::slab_adopt(const double* E6, bool u_is_state) {
+  su_cur_ ^= 1;
+  su_valid_ = u_is_state;
+  for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
+}
+
+void Solver::slab_reset_state() {
+  solve_time_ = 0.0;
+  residuals_.clear();
+  iterations_ = 0;
+  cancel_ = false;
+  u_valid_ = false;
+  for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
+}
+
+// ===================================================================================================== group side
+void SlabGroup::check_members() const {
+  if (m_.empty()) throw std::runtime_error("empty slab group");
+  const Solver& a = *m_[0];
+  if (a.opt_.mode != 0 || a.opt_.gamma_scheme != 0 || a.opt_.method != 0)
+    throw std::runtime_error("slab-decomposed solvers run the basic scheme of the elasticity mode with the staggered Green operator");
+  if (a.pt_.n < 1) throw std::runtime_error("No materials specified");
+  for (Solver* s : m_) {
+    if (s->nranks_ > 1 && !s->comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
+    if (s->opt_.mixing != a.opt_.mixing || s->pt_.n != a.pt_.n || s->opt_.u_loop != a.opt_.u_loop || s->opt_.u_tile != a.opt_.u_tile)
+      throw std::runtime_error("the members of a slab group must carry the same options and materials");
+  }
+}
+
+void SlabGroup::synchronize() {
+  for (Solver* s : m_) {
+    FG_HIP_CHECK(hipSetDevice(s->device_));
+    FG_HIP_CHECK(hipStreamSynchronize(s->stream_));
+    if (s->comm_stream_ != s->stream_) FG_HIP_CHECK(hipStreamSynchronize(s->comm_stream_));
+  }
+}
+
+bool SlabGroup::fast_ok(bool allow_mixed_bc) const {
+  for (Solver* s : m_)
+    if (!s->slab_fast_ok(allow_mixed_bc)) return false;
+  return true;
+}
+
+void SlabGroup::prepare() {
+  for (Solver* s : m_) {
+    FG_HIP_CHECK(hipSetDevice(s->device_));
+    s->slab_alloc();
+  }
+  if (fast_ok(true))
+    for (Solver* s : m_) s->slab_moduli_step();
+}
+
+void SlabGroup::wait_norms() {
+  for (Solver* s : m_) FG_HIP_CHECK(hipEventSynchronize(s->ev_norm_));
+  for (Solver* s : m_)
+    if (*s->herr_ != 0) {
+      FG_HIP_CHECK(hipMemsetAsync(s->derr_, 0, sizeof(int), s->stream_));
+      if (s->opt_.mixing == kMixLaminate) throw std::runtime_error("The laminate mixing rule supports only two phase mixtures (stress)");
+      throw std::runtime_error("device kernel reported an error (stress)");
+    }
+}
+
+// all members have left their local contribution in dscal_[slot..slot+n): reduce over ranks, bring to every host
+void SlabGroup::reduce_and_fetch(int slot, int n, bool min_op) {
+  for (Solver* s : m_) s->slab_reduce(slot, n, min_op);
+  for (Solver* s : m_) {
+    FG_HIP_CHECK(hipMemcpyAsync(s->hscal_ + slot, s->dscal_ + slot, n * sizeof(double), hipMemcpyDeviceToHost, s->comm_stream_));
+    FG_HIP_CHECK(hipMemcpyAsync(s->herr_, s->derr_, sizeof(int), hipMemcpyDeviceToHost, s->comm_stream_));
+    FG_HIP_CHECK(hipEventRecord(s->ev_norm_, s->comm_stream_));
+  }
+  wait_norms();
+  for (Solver* s : m_) s->comm_wait(kXSums);   // later writes of dscal_ on the compute stream follow the reduction
+}
+
+void SlabGroup::mean_strain(double* out6) {
+  check_members();
+  prepare();
+  for (Solver* s : m_) {
+    if (s->su_valid_ && s->eps_stale_) s->slab_materialise_eps();
+    launch_sum6(s->g_, s->ptrs6(s->eps_), false, s->partial_, s->dscal_ + kSlotMean, s->stream_);
+  }
+  reduce_and_fetch(kSlotMean, 6, false);
+  for (int c = 0; c < 6; ++c) out6[c] = m_[0]->hscal_[kSlotMean + c] / (double)m_[0]->nglobal_;
+}
+
+void SlabGroup::mean_stress(double* out6) {
+  check_members();
+  prepare();
+  for (Solver* s : m_) {
+    if (s->su_valid_ && s->eps_stale_) s->slab_materialise_eps();
+    FieldPtrs<3> nrm;
+    for (int c = 0; c < 3; ++c) nrm.p[c] = s->normals_ ? s->normals_ + (long)c * s->g_.n : nullptr;
+    // meanPK1: alpha /= nxyz (global), accumulate  F:12318-12340
+    launch_stress_mean(s->g_, s->stress_params(0.0, 0.0, 1.0 / (double)s->nglobal_), s->ptrs6(s->eps_), s->phase_ptrs(), nrm,
+                       s->partial_, s->dscal_ + kSlotMean, s->derr_, s->stream_);
+  }
+  reduce_and_fetch(kSlotMean, 6, false);
+  for (int c = 0; c < 6; ++c) out6[c] = m_[0]->hscal_[kSlotMean + c];
+}
+
+double SlabGroup::volume_fraction(int p) {
+  check_members();
+  prepare();
+  for (Solver* s : m_) {
+    if (p < 0 || p >= s->pt_.n) throw std::runtime_error("phase index out of range");
+    launch_sum1(s->g_, s->phi_ + (long)p * s->g_.n, s->partial_, s->dscal_ + kSlotMisc, s->stream_);
+  }
+  reduce_and_fetch(kSlotMisc, 1, false);
+  return m_[0]->hscal_[kSlotMisc] / (double)m_[0]->nglobal_;
+}
+
+// calcRefMaterial  F:22283-22313 with the extreme tangent eigenvalues taken over all slabs
+void SlabGroup::calc_ref_material() {
+  check_members();
+  prepare();
+  for (Solver* s : m_)
+    launch_tangent_minmax(s->g_, s->phase_table(), s->opt_.mixing, s->phase_ptrs(), s->partial_, s->dscal_ + kSlotMinMax, s->derr_,
+                          s->stream_);
+  reduce_and_fetch(kSlotMinMax, 2, true);   // stored as (min, -max): one element-wise minimum serves both
+  double lambda_min = m_[0]->hscal_[kSlotMinMax], lambda_max = -m_[0]->hscal_[kSlotMinMax + 1];
+  if (lambda_min < 0) lambda_min = 0;   // F:12183-12223
+  double mu_0 = 0.5 * (lambda_min + lambda_max);
+  mu_0 *= 0.5 * m_[0]->opt_.ref_scale;
+  for (Solver* s : m_) {
+    s->opt_.mu_0 = mu_0;
+    s->recompute_bc();   // F:22312
+  }
+}
+
+// bc_error  F:21129-21161
+double SlabGroup::bc_error(const double* E_cur, const double* S_cur) {
+  Solver& a = *m_[0];
+  double Emean[6], Smean[6], PE[6], QS[6], PEc[6], d[6];
+  mean_strain(Emean);
+  mean_stress(Smean);
+  voigt_mv(a.BC_P_, Emean, PE);
+  voigt_mv(a.BC_Q_, Smean, QS);
+  voigt_mv(a.BC_P_, E_cur, PEc);
+  const double norm_E = voigt_norm2(PEc);
+  for (int i = 0; i < 6; ++i) d[i] = PE[i] - E_cur[i];
+  const double err_F = voigt_norm2(d) / ((norm_E < a.opt_.bc_tol) ? 1 : norm_E);
+  const double norm_S = voigt_norm2(S_cur);
+  for (int i = 0; i < 6; ++i) d[i] = QS[i] - S_cur[i];
+  const double err_S = voigt_norm2(d) / ((norm_S < a.opt_.bc_tol) ? 1 : norm_S);
+  return err_F > err_S ? err_F : err_S;
+}
+
+// one displacement pass on every member: the sweep (norms of eps_k), then -- speculatively, the host has not seen the
+// norms yet -- the whole transform chain to u_{k+1}; adopted by the caller if the loop goes on
+void SlabGroup::pass_fast(const double* E_cur, bool sum_tau) {
+  for (Solver* s : m_) s->slab_front_fast(E_cur, sum_tau);
+  for (Solver* s : m_) s->slab_fetch_norms(sum_tau ? 12 : 6);
+  for (int k = 1; k <= 9; ++k)
+    for (Solver* s : m_) s->slab_chain_step(k);
+}
+
+// one pass of the strain-state pipeline: eps_ -> eps_ (and the displacement it was built from in su_[next]); adopts
+void SlabGroup::pass_exact(const double* E6, bool mixed_bc) {
+  Solver& a = *m_[0];
+  const double alpha = -1.0;
+  double F00[6] = {0, 0, 0, 0, 0, 0};
+  if (a.opt_.bc_relax != 1.0) mean_strain(F00);   // F:20563-20565: mean of the operator's argument
+  for (Solver* s : m_) s->slab_front_exact(mixed_bc);
+  double F0[6] = {0, 0, 0, 0, 0, 0};
+  if (mixed_bc) {   // initBCProjector  F:20228-20239: <tau> over all slabs
+    for (Solver* s : m_) {
+      FG_HIP_CHECK(hipMemcpyAsync(s->hscal_ + kSlotMean, s->dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost,
+                                  s->comm_stream_));
+      FG_HIP_CHECK(hipEventRecord(s->ev_norm_, s->comm_stream_));
+    }
+  }
+  for (Solver* s : m_) s->slab_div_exact();
+  for (int k = 1; k <= 9; ++k)
+    for (Solver* s : m_) s->slab_chain_step(k);
+  if (mixed_bc) {
+    for (Solver* s : m_) FG_HIP_CHECK(hipEventSynchronize(s->ev_norm_));
+    for (int c = 0; c < 6; ++c) F0[c] = a.hscal_[kSlotMean + c] / (double)a.nglobal_;
+  }
+  // applyBCProjector  F:20247-20270: R = alpha*(bc_relax*MQ:F0 - (1-bc_relax)*M:(QC0:F00))
+  double R[6], t1[6], t2[6], t3[6];
+  voigt_mv(a.BC_MQ_, F0, t1);
+  voigt_mv(a.BC_QC0_, F00, t2);
+  voigt_mv(a.BC_M_, t2, t3);
+  bool add_R = false;
+  for (int c = 0; c < 6; ++c) {
+    R[c] = (!mixed_bc && a.opt_.bc_relax == 1.0) ? 0.0 : alpha * (a.opt_.bc_relax * t1[c] - (1 - a.opt_.bc_relax) * t3[c]);
+    if (R[c] != 0.0) add_R = true;
+  }
+  for (Solver* s : m_) s->slab_back_exact(E6, R);
+  for (Solver* s : m_) s->slab_fetch_norms(6);
+  for (Solver* s : m_) {
+    s->slab_adopt(E6, !add_R);
+    s->eps_stale_ = false;
+  }
+}
+
+void SlabGroup::iterate(const double* E6, int n) {
+  check_members();
+  prepare();
+  Solver& a = *m_[0];
+  const bool mixed_bc = !(frobenius(a.BC_MQ_) < kEps);
+  const bool fast = fast_ok(false);
+  int i = 0;
+  if (fast) {
+    bool have_u = true;
+    for (Solver* s : m_) have_u = have_u && s->su_valid_;
+    if (!have_u && n > 0) {   // no displacement yet: one strain-state pass leaves u (with its halo planes) and eps
+      pass_exact(E6, false);
+      ++i;
+    }
+    for (; i < n; ++i) {
+      pass_fast(m_[0]->E_cur_, false);
+      for (Solver* s : m_) {
+        s->slab_adopt(E6, true);
+        s->eps_stale_ = true;
+      }
+    }
+    return;
+  }
+  for (; i < n; ++i) pass_exact(E6, mixed_bc);
+}
+
+// LSSolver::run F:21247-21398 -> runLoadsteppingSolver (one load step) -> runBasic F:21716-21805, stop rule of
+// _converged F:21177-21244 -- the collective counterpart of Solver::run
+bool SlabGroup::run(const double* E6, const double* S6) {
+  check_members();
+  Solver& a = *m_[0];
+  double E0[6], S0[6];
+  for (int i = 0; i < 6; ++i) {
+    E0[i] = E6[i];
+    S0[i] = S6 ? S6[i] : 0.0;
+  }
+  for (Solver* s : m_) {
+    FG_HIP_CHECK(hipSetDevice(s->device_));
+    s->slab_reset_state();
+    s->recompute_bc();   // F:21354
+  }
+  {
+    const double se = std::sqrt(kEps);
+    double t[6];
+    voigt_mv(a.BC_P_, S0, t);
+    if (norm2(t, 6) > se * norm2(S0, 6)) throw std::runtime_error("Incompatible stress boundary condition specified");
+    voigt_mv(a.BC_Q_, E0, t);
+    if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
+  }
+  const double t_start = now_seconds();
+  prepare();
+  bool fast = fast_ok(true);
+  for (Solver* s : m_) {
+    FG_HIP_CHECK(hipMemsetAsync(s->eps_, 0, 6 * (size_t)s->g_.n * sizeof(double), s->stream_));   // F:21379
+    s->comm_wait(kXHaloU);
+    FG_HIP_CHECK(hipMemsetAsync(s->su_[s->su_cur_], 0, 3 * (size_t)s->ucs_ * sizeof(double), s->stream_));   // u_1 = 0 (eps_1 = E)
+    s->su_valid_ = fast;
+    s->eps_stale_ = fast;
+    s->in_run_ = true;
+    for (int i = 0; i < 6; ++i) s->E_cur_[i] = E0[i];
+  }
+
+  double prev = 0.0;   // EpsilonErrorEstimator  F:14591-14637: norms of the zero field at construction
+  long iter = 1;
+  bool update_ref = a.opt_.update_ref != 0;
+  double E[6], E_next[6];
+  for (int i = 0; i < 6; ++i) E[i] = E0[i];
+  bool failed = false;
+  const double small = std::numeric_limits<double>::min();
+  const double nglobal = (double)a.nglobal_;
+
+  for (;;) {
+    if (update_ref) {
+      calc_ref_material();
+      double t1[6], t2[6], t3[6];   // calcBCMean  F:20242-20245
+      voigt_mv(a.BC_QC0_, E0, t1);
+      for (int i = 0; i < 6; ++i) t2[i] = S0[i] - t1[i];
+      voigt_mv(a.BC_M_, t2, t3);
+      for (int i = 0; i < 6; ++i) E[i] = E0[i] + a.opt_.bc_relax * t3[i];
+      update_ref = false;
+      if (fast) prepare();   // effective moduli are independent of the reference material, but may not exist yet
+    }
+    const bool mixed_bc = !(frobenius(a.BC_MQ_) < kEps);
+    bool all_u = true;
+    for (Solver* s : m_) all_u = all_u && s->su_valid_;
+    bool pending = false;
+    if (fast && all_u) {
+      if (iter == 1)
+        for (Solver* s : m_)
+          for (int i = 0; i < 6; ++i) s->E_cur_[i] = E[i];   // eps_1 = E (u_1 = 0)
+      pass_fast(a.E_cur_, mixed_bc);
+      pending = true;
+    } else {
+      fast = false;
+      pass_exact(E, mixed_bc);
+    }
+    wait_norms();
+    for (int i = 0; i < 6; ++i) E_next[i] = E[i];
+    if (pending && mixed_bc) {
+      // applyBCProjector  F:20247-20270 with bc_relax = 1: eps_{k+1} = E + alpha MQ:<tau_k> + sym grad u_{k+1}
+      double F0[6], t1[6];
+      for (int c = 0; c < 6; ++c) F0[c] = a.hscal_[kSlotMean + c] / nglobal;
+      voigt_mv(a.BC_MQ_, F0, t1);
+      for (int c = 0; c < 6; ++c) E_next[c] = E[c] - t1[c];   // alpha = -1  (F:20575)
+    }
+
+    // component_norm + fix_dim + norm_2 over 9 mirrored entries  F:10127-10138, F:14600-14609, F:14627
+    double mm[6], s9 = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      const double ss = a.hscal_[kSlotSumSq + c];
+      for (Solver* s : m_) s->sumsq_[c] = ss;
+      mm[c] = std::sqrt(ss / nglobal);
+    }
+    for (int c = 0; c < 6; ++c) s9 += mm[c] * mm[c];
+    for (int c = 3; c < 6; ++c) s9 += mm[c] * mm[c];
+    const double cur = std::sqrt(s9);
+    const double abs_err = std::fabs(prev - cur);
+    const double rel_err = abs_err / (small + cur);
+    prev = cur;
+
+    // _converged  F:21177-21244
+    if (std::isnan(rel_err) || a.cancel_) {
+      failed = true;
+      break;
+    }
+    for (Solver* s : m_) s->residuals_.push_back(rel_err);
+    if (a.cb_ && a.cb_(a.cb_user_)) break;
+    if (a.cancel_) {
+      failed = true;
+      break;
+    }
+    if (iter >= a.opt_.maxiter) break;
+    if (rel_err <= a.opt_.tol || abs_err <= a.opt_.abs_tol) {
+      if (bc_error(E0, S0) <= a.opt_.bc_tol) break;
+    }
+    if (pending)
+      for (Solver* s : m_) {
+        s->slab_adopt(E_next, true);
+        s->eps_stale_ = true;
+      }
+    iter++;
+  }
+  for (Solver* s : m_) {
+    s->in_run_ = false;
+    s->iterations_ = iter;
+    if (s->su_valid_ && s->eps_stale_) s->slab_materialise_eps();
+  }
+  synchronize();
+  const double dt = now_seconds() - t_start;
+  for (Solver* s : m_) s->solve_time_ += dt;
+  return failed;
+}
+
+}  // namespace fg

@@ -13,11 +13,25 @@
 #include <string>
 #include <vector>
 
+#include "fg_comm.h"
 #include "fg_fft.h"
 #include "fg_hostmath.h"
 #include "fg_kernels.h"
 
 namespace fg {
+
+class SlabGroup;
+
+// device scalar slots (dscal_ / hscal_)
+namespace slots {
+constexpr int kSlotSumSq = 0;    // 6
+constexpr int kSlotMean = 6;     // 6
+constexpr int kSlotMinMax = 12;  // 2
+constexpr int kSlotMisc = 14;    // 2
+constexpr int kSlotScratch = 16; // 6: sums nobody reads (strain materialisation)
+constexpr int kSlotCg = 24;      // displacement CG: two blocks of 8 (norms of eps [6] + r:r, alternating per iteration), then p:(p-w) [8]
+constexpr int kNumSlots = 48;
+}  // namespace slots
 
 typedef int (*ConvergenceCallback)(void* user);
 
@@ -72,16 +86,20 @@ struct StageTimes {
 class Solver {
  public:
   // (nx, ny, nz) is the GLOBAL grid; with nranks > 1 this object holds x-slab `rank` of it.
-  Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device, int rank = 0, int nranks = 1);
+  // slab_layout: created through fg_create_slab / fg_slab_group_create (the loop then runs under the slab driver, also
+  // for nranks = 1); shared_stream: all members of an in-process group enqueue on one stream (not owned).
+  Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device, int rank = 0, int nranks = 1,
+         bool slab_layout = false, hipStream_t shared_stream = nullptr);
   ~Solver();
   Solver(const Solver&) = delete;
   Solver& operator=(const Solver&) = delete;
 
   const Grid& grid() const { return g_; }
   SolverOptions& options() { return opt_; }
-  void invalidate_moduli() { mod_dirty_ = true; }
+  void invalidate_moduli() { mod_dirty_ = smod_dirty_ = true; }
   void reference_material_changed() { recompute_bc(); }   // (mu_0, lambda_0) set from outside: M, MQ depend on C0
   hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
 
   void set_num_phases(int n);
   int num_phases() const { return pt_.n; }
@@ -123,6 +141,12 @@ class Solver {
   int nranks() const { return nranks_; }
   int nx_global() const { return nxg_; }
 
+  // slab driver below the ABI (fg_slab.hip): transport + the group of members this process drives
+  bool is_slab() const { return slab_layout_; }
+  void connect(std::unique_ptr<Comm> comm, std::shared_ptr<SlabGroup> group);
+  SlabGroup& slab_group();          // throws unless connected (a lone nranks = 1 slab connects to itself)
+  const char* transport() const { return comm_ ? comm_->name() : (slab_layout_ && nranks_ == 1 ? "self" : ""); }
+
   // single stages on the solver's own buffers (parity tests, profiling)
   void run_stage(int stage, const double* E6);
   void enable_stage_timing(bool on);
@@ -160,6 +184,47 @@ class Solver {
   void download_unpadded(const double* src, double* dst_unpadded);
   void time_begin(int stage);
   void time_end(int stage);
+
+  // ---- slab driver: per-member steps (fg_slab.hip); every comm call is the last dependent thing of its step
+  friend class SlabGroup;
+  void slab_alloc();
+  bool slab_fast_ok(bool allow_mixed_bc) const;
+  void slab_moduli_step();                               // effective moduli of the slab + exchange of their halo planes
+  void slab_front_fast(const double* E6, bool sum_tau);  // su_[cur] -> norms of eps_k (all-reduced), f_{k+1} in fu_
+  void slab_fetch_norms(int n);                          // D2H of the reduced sums (+ error flag), event for the host
+  void slab_chain_step(int k);                           // k = 1..9: transform chain fu_ -> su_[next], see fg_slab.hip
+  void slab_front_exact(bool sum_tau);                   // eps_ -> tau_, halo of tau (, sums of tau all-reduced)
+  void slab_div_exact();                                 // tau_ + halo -> fu_
+  void slab_back_exact(const double* E6, const double* R6);  // su_[next] + halo -> eps_, sums of squares all-reduced
+  void slab_adopt(const double* E6, bool u_is_state);
+  void slab_materialise_eps();                           // eps_ = E_cur + sym grad su_[cur]
+  void slab_reset_state();
+  void slab_reduce(int slot, int n, bool min_op);        // all-reduce of dscal_ slots on the comm stream
+  void slab_exchange(int what, int comp, int done_slot);
+  double* slab_buffer(int id);
+  void comm_begin();
+  void comm_end(int slot);
+  void comm_wait(int slot);
+
+  bool slab_layout_ = false;
+  bool owns_stream_ = true;
+  std::unique_ptr<Comm> comm_;
+  std::shared_ptr<SlabGroup> group_;
+  hipStream_t comm_stream_ = nullptr;   // exchanges (own stream with RCCL; the compute stream otherwise)
+  bool owns_comm_stream_ = false;
+  static constexpr int kCommSlots = 10; // 0-2 all-to-all forward, 3-5 backward, 6 halo of u, 7 halo of tau, 8 moduli, 9 sums
+  hipEvent_t ev_c2x_ = nullptr;         // compute -> comm
+  hipEvent_t ev_x_[kCommSlots] = {};    // comm -> compute
+  bool x_pending_[kCommSlots] = {};
+  hipEvent_t ev_norm_ = nullptr;        // the reduced sums have reached the host
+  double* su_[2] = {nullptr, nullptr};  // displacement of the slab, 3 components of ucs_ doubles (4 spare planes each)
+  int su_cur_ = 0;
+  bool su_valid_ = false;               // su_[su_cur_] (with valid halo planes) is the state: eps = E_cur_ + sym grad u
+  double* smod_ = nullptr;              // effective moduli, 2 components of ucs_ doubles
+  bool smod_dirty_ = true;
+  long ucs_ = 0;
+  Grid gu_;                             // g_ with the halo-plane mapping of the marching sweep
+  std::unique_ptr<Fft3> fft_ys_;        // x pass + Green operator on the y-slab [nxg][nyl][nzc]
 
   Grid g_;
   SolverOptions opt_;

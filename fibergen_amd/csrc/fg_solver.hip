@@ -9,21 +9,16 @@
 #include <stdexcept>
 
 #include "fg_hip_util.h"
+#include "fg_slab.h"
 
 namespace fg {
 
 using namespace hostmath;
 
+using namespace slots;
+
 namespace {
 constexpr double kEps = 2.220446049250313e-16;
-// device scalar slots
-constexpr int kSlotSumSq = 0;    // 6
-constexpr int kSlotMean = 6;     // 6
-constexpr int kSlotMinMax = 12;  // 2
-constexpr int kSlotMisc = 14;    // 2
-constexpr int kSlotScratch = 16; // 6: sums nobody reads (strain materialisation)
-constexpr int kSlotCg = 24;      // displacement CG: two blocks of 8 (norms of eps [6] + r:r, alternating per iteration), then p:(p-w) [8]
-constexpr int kNumSlots = 48;
 
 double now_seconds() {
   using clk = std::chrono::steady_clock;
@@ -31,8 +26,9 @@ double now_seconds() {
 }
 }  // namespace
 
-Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device, int rank, int nranks)
-    : device_(device), rank_(rank), nranks_(nranks), nxg_(nx) {
+Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int device, int rank, int nranks, bool slab_layout,
+               hipStream_t shared_stream)
+    : slab_layout_(slab_layout), device_(device), rank_(rank), nranks_(nranks), nxg_(nx) {
   if (nx < 1 || ny < 1 || nz < 1) throw std::runtime_error("grid dimensions must be >= 1");
   if (!(dx > 0) || !(dy > 0) || !(dz > 0)) throw std::runtime_error("RVE dimensions must be > 0");
   if (nranks < 1 || rank < 0 || rank >= nranks) throw std::runtime_error("invalid rank / number of ranks");
@@ -50,7 +46,13 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   if (ndev < 1) throw std::runtime_error("no HIP device available: fibergen_amd needs an AMD GPU (gfx950)");
   if (device < 0 || device >= ndev) throw std::runtime_error("invalid device index");
   FG_HIP_CHECK(hipSetDevice(device));
-  FG_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  if (shared_stream) {
+    stream_ = shared_stream;
+    owns_stream_ = false;
+  } else {
+    FG_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  }
+  comm_stream_ = stream_;
   FG_HIP_CHECK(hipEventCreate(&ev_[0]));
   FG_HIP_CHECK(hipEventCreate(&ev_[1]));
   FG_HIP_CHECK(hipEventCreateWithFlags(&ev_copy_, hipEventDisableTiming));
@@ -131,7 +133,9 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
 
 Solver::~Solver() {
   (void)hipSetDevice(device_);
+  if (group_) group_->invalidate();
   (void)hipStreamSynchronize(stream_);
+  if (comm_stream_ && comm_stream_ != stream_) (void)hipStreamSynchronize(comm_stream_);
   fft_.reset();
   fft_t_.reset();
   for (int k = 0; k < 4; ++k)
@@ -154,7 +158,16 @@ Solver::~Solver() {
   (void)hipEventDestroy(ev_[0]);
   (void)hipEventDestroy(ev_[1]);
   (void)hipEventDestroy(ev_copy_);
-  (void)hipStreamDestroy(stream_);
+  comm_.reset();
+  fft_ys_.reset();
+  for (double* b : {su_[0], su_[1], smod_})
+    if (b) (void)hipFree(b);
+  if (ev_c2x_) (void)hipEventDestroy(ev_c2x_);
+  if (ev_norm_) (void)hipEventDestroy(ev_norm_);
+  for (hipEvent_t e : ev_x_)
+    if (e) (void)hipEventDestroy(e);
+  if (owns_comm_stream_ && comm_stream_) (void)hipStreamDestroy(comm_stream_);
+  if (owns_stream_) (void)hipStreamDestroy(stream_);
 }
 
 // ------------------------------------------------------------------ configuration
@@ -167,12 +180,14 @@ void Solver::set_num_phases(int n) {
   FG_HIP_CHECK(hipMemsetAsync(phi_, 0, (size_t)n * g_.n * sizeof(double), stream_));
   pt_.n = n;
   mod_dirty_ = true;
+  smod_dirty_ = true;
   mixed_dirty_ = true;
 }
 
 void Solver::set_phase_material(int p, double mu, double lambda) {
   if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
   mod_dirty_ = true;
+  smod_dirty_ = true;
   mixed_dirty_ = true;
   pt_.mu[p] = mu;
   pt_.lambda[p] = lambda;
@@ -181,6 +196,7 @@ void Solver::set_phase_material(int p, double mu, double lambda) {
 void Solver::set_phase_field(int p, const double* phi_host) {
   if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
   mod_dirty_ = true;
+  smod_dirty_ = true;
   mixed_dirty_ = true;
   upload_padded(phi_ + (long)p * g_.n, phi_host);
 }
@@ -778,6 +794,10 @@ void Solver::u_pass_back() {
 }
 
 void Solver::ensure_eps() {
+  if (slab_layout_ && su_valid_ && eps_stale_) {   // slab driver: the state is su_[cur] with its halo planes
+    slab_materialise_eps();
+    return;
+  }
   if (!eps_stale_ || !u_valid_) return;
   Vec6 E, R;
   for (int c = 0; c < 6; ++c) E.v[c] = E_cur_[c], R.v[c] = 0.0;
@@ -1577,6 +1597,8 @@ void Solver::get_field(const std::string& name, double* out) {
   ensure_eps();
   // fu_ is overwritten by the displacement reconstruction (scalar modes: by an equivalent potential, still valid;
   // displacement-space CG: the reconstruction goes to the free buffer fu_alt_, fu_ is the iterate itself)
+  if (name == "u" && slab_layout_ && nranks_ > 1)
+    throw std::runtime_error("field 'u' (a global reconstruction) is not available on slab-decomposed solvers");
   if (name == "u" && opt_.mode != 1 && !cg_u_active_) u_valid_ = false;
   if (name == "sumsq") {  // the six sums of squares of the last norm sweep (device slot; the displacement loop keeps them there)
     FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -1666,6 +1688,7 @@ void Solver::set_field(const std::string& name, const double* in) {
   if (opt_.mode == 1) throw std::runtime_error("fields cannot be set in heat / porous mode");
   ensure_eps();
   u_valid_ = false;
+  su_valid_ = false;   // slab driver: the strain field is the state again
   if (name == "f_hat") {
     FG_HIP_CHECK(hipStreamSynchronize(stream_));
     FG_HIP_CHECK(hipMemcpy2D(fu_, g_.nzc * sizeof(cplx), in, g_.nzf * sizeof(cplx), g_.nzf * sizeof(cplx),

@@ -167,6 +167,72 @@ int fg_slab_phase(fg_solver* s, int phase, const double* E6, const double* R6);
 void* fg_exchange_buffer(fg_solver* s, const char* name, unsigned long* bytes);
 int fg_local_sums(fg_solver* s, const char* what, double* out);
 
+/* ---- slab decomposition, driver below the ABI (round 2) -----------------------------------
+ * The loop of a slab solver runs inside the library: the same entry points as for one GPU (fg_run_load_case,
+ * fg_iterate, fg_time_iterations, fg_mean_stress, fg_mean_strain, fg_volume_fraction, fg_calc_ref_material,
+ * fg_get_field with LOCAL shapes) become collective calls once the solver is connected to a transport.  Per pass
+ * (basicScheme F:20558-20578 with GammaOperatorStaggered F:20288-20300 cut along x):
+ *
+ *   displacement sweep on the x-slab (u with +-1 halo planes -> norms of eps_k, f_{k+1})   | all-reduce of 6..12 doubles
+ *   per component c: z r2c, y c2c writing the all-to-all layout                             | all-to-all(c)  (overlaps c+1)
+ *   x c2c + Green operator + x c2c^-1 on the y-slab (three components, one kernel)          | all-to-all(c) back
+ *   per component c: y c2c^-1 reading the all-to-all layout, z c2r                          | halo planes of u
+ *
+ * all stream-ordered: exchanges run on a second stream joined by events, the host waits only for the norms of the
+ * stop rule.  Laminate mixing and grids the tiled sweep does not fit take the strain-state pipeline (polarisation,
+ * halo of tau, divergence, the same transform chain, halo of u, strain + norms) under the same driver.
+ *
+ * Transports (exactly one per solver, before the first collective call):
+ *   fg_slab_connect_rccl      one process per GPU; RCCL (ncclSend / ncclRecv groups, ncclAllReduce) over xGMI.
+ *                             Rank 0 obtains the id with fg_comm_unique_id and hands it to all ranks out of band.
+ *   fg_slab_group_create      all nranks slabs in THIS process on ONE device and one stream (single-GPU tests,
+ *                             bench.py --force-slab); a collective call on any member drives all members.
+ *   fg_slab_connect_callback  the caller moves the bytes (multi-process tests over gloo). */
+#define FG_COMM_ID_BYTES 128
+int fg_comm_unique_id(char* id /* [FG_COMM_ID_BYTES] */);
+int fg_slab_connect_rccl(fg_solver* s, const char* id /* [FG_COMM_ID_BYTES] */);
+int fg_slab_group_create(int nx, int ny, int nz, double dx, double dy, double dz, int device, int nranks,
+                         fg_solver** out /* [nranks] */);
+typedef struct fg_xop {
+  int send;             /* 1 = send, 0 = receive */
+  int peer;
+  void* ptr;            /* device pointer */
+  unsigned long bytes;
+} fg_xop;
+/* exchange: the solver's streams are drained; sends / receives between two ranks match in list order.
+ * allreduce: in place on `n` host values (sum, or element-wise minimum when min_op != 0).  Return 0 on success. */
+typedef int (*fg_exchange_fn)(void* user, const fg_xop* ops, int nops);
+typedef int (*fg_allreduce_fn)(void* user, double* values, int n, int min_op);
+int fg_slab_connect_callback(fg_solver* s, fg_exchange_fn exchange, fg_allreduce_fn allreduce, void* user);
+/* name of the connected transport ("rccl", "local", "callback") or "" */
+const char* fg_slab_transport(const fg_solver* s);
+
+/* The exchange plan (pure index arithmetic, no GPU): ops of exchange `what` for `rank`, offsets / counts in doubles
+ * relative to the named buffer.  Returns the number of ops (<= capacity) or -1.  self_copy[2] (may be NULL) receives
+ * the rank's own all-to-all block as {source, destination}. */
+#define FG_PLAN_A2A_FORWARD 0   /* x-slabs -> y-slabs, component `comp` */
+#define FG_PLAN_A2A_BACKWARD 1
+#define FG_PLAN_HALO_U 2        /* +-1 planes of the three displacement components */
+#define FG_PLAN_HALO_MODULI 3   /* the same for the two effective-moduli arrays (once per geometry) */
+#define FG_PLAN_HALO_TAU 4      /* strain-state pipeline: tau0 | tau5, tau4 */
+#define FG_BUF_SPECTRUM_X 0     /* [3][P][nx/P][ny/P][nzp] blocked x-slab spectrum */
+#define FG_BUF_SPECTRUM_Y 1     /* [3][nx][ny/P][nzp] y-slab spectrum */
+#define FG_BUF_U 2              /* [3][nx/P + 4][ny][nzp] displacement with spare planes */
+#define FG_BUF_MODULI 3         /* [2][nx/P + 4][ny][nzp] */
+#define FG_BUF_HALO_SEND_LO 4
+#define FG_BUF_HALO_SEND_HI 5
+#define FG_BUF_HALO_RECV_LO 6
+#define FG_BUF_HALO_RECV_HI 7
+typedef struct fg_plan_op {
+  int send;
+  int peer;
+  int buffer;
+  long offset;
+  long count;
+} fg_plan_op;
+int fg_slab_plan(int nx, int ny, int nz, int nranks, int rank, int what, int comp, fg_plan_op* ops, int capacity,
+                 fg_plan_op* self_copy);
+
 /* ---- geometry pre-processing (host side, no GPU needed) ------------------------------
  * Analytic shapes placed with <place_fiber> (F:25788-25822) -> phase volume fractions and
  * interface normals: LSSolver::initPhi F:17489-17581 (adaptive sub-voxel integration,

@@ -18,10 +18,15 @@ def _P(a):
     return a.ctypes.data_as(_dp)
 
 
-def load(build=True):
-    so = os.path.join(_HERE, "c", "libfg_ref.so")
-    if not os.path.exists(so) and build:
-        subprocess.check_call(["make", "-C", os.path.join(_HERE, "c")], stdout=subprocess.DEVNULL)
+def load(build=True, native=False):
+    """native: the reference's release flags (-O3 -march=native), compiled on this very host (cpu_baseline only)."""
+    name = "libfg_ref_native.so" if native else "libfg_ref.so"
+    so = os.path.join(_HERE, "c", name)
+    if native or (not os.path.exists(so) and build):
+        # the native library is always rebuilt: one made on another machine may carry instructions this host lacks
+        if native and os.path.exists(so):
+            os.remove(so)
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "c"), name], stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(so)
     lib.ref_max_threads.restype = ctypes.c_int
     return lib
@@ -105,3 +110,57 @@ class CRef:
         e = self.eps_op(E, u)
         self.lib.ref_add(ctypes.c_size_t(self.N), _P(np.zeros(6)), _P(e))  # applyBCProjector's eps.add(R)  F:20269
         return e
+
+
+class CRefLoop:
+    """The loop of basicScheme as the reference runs it: ONE strain field that every routine works on in place
+    (tau aliases epsilon, F:15153-15155, F:20558-20578), buffers allocated once, `threads` OpenMP threads
+    (the reference's <num_threads>, default 1, F:25226).  cpu_baseline only; the checker is CRef."""
+
+    def __init__(self, n, dims, mats, phis, normals=None, mixing="voigt", threads=1, native=True):
+        self.lib = load(native=native)
+        self.nx, self.ny, self.nz = n
+        self.dims = tuple(float(d) for d in dims)
+        self.N = self.nx * self.ny * self.nz
+        self.mu = np.array([m[0] for m in mats], dtype=np.float64)
+        self.lam = np.array([m[1] for m in mats], dtype=np.float64)
+        self.phi = np.ascontiguousarray(np.stack(phis), dtype=np.float64)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+        self.mixing = {"voigt": 0, "laminate": 1}[mixing]
+        self.threads = int(threads)
+        self.eps = np.zeros((6,) + tuple(n))       # the one strain / polarisation field
+        self.f = np.zeros((3,) + tuple(n))         # divergence / displacement work field
+        self.zero6 = np.zeros(6)
+        self.norms = np.zeros(6)
+        self.eps_g = np.finfo(float).eps
+        self.eps_a = np.finfo(float).eps ** (2.0 / 3.0)
+        self.fft_seconds = 0.0
+
+    def one_pass(self, E, mu_0, lambda_0):
+        import time
+        d = ctypes.c_double
+        lib = self.lib
+        lib.ref_set_threads(self.threads)
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        nrm = _P(self.normals) if self.normals is not None else None
+        # calcStressDiff in place: tau over epsilon  F:18030-18033
+        if lib.ref_calc_stress(self.nx, self.ny, self.nz, _P(self.eps), _P(self.phi), nrm, len(self.mu), _P(self.mu),
+                               _P(self.lam), self.mixing, d(mu_0), d(lambda_0), d(1.0), d(self.eps_g), d(self.eps_a),
+                               _P(self.eps)):
+            raise RuntimeError("The laminate mixing rule supports only two phase mixtures")
+        lib.ref_div(self.nx, self.ny, self.nz, *map(d, self.dims), _P(self.eps), _P(self.f))
+        t = time.perf_counter()
+        fh = scipy.fft.rfftn(self.f, axes=(1, 2, 3), workers=self.threads)
+        self.fft_seconds += time.perf_counter() - t
+        v = fh.view(np.float64)
+        lib.ref_scale(ctypes.c_size_t(v.size), d(1 / float(self.N)), _P(v))
+        lib.ref_g0(self.nx, self.ny, self.nz, *map(d, self.dims), d(mu_0), d(lambda_0), d(-1.0), fh.ctypes.data_as(ctypes.c_void_p))
+        t = time.perf_counter()
+        u = scipy.fft.irfftn(fh, s=(self.nx, self.ny, self.nz), axes=(1, 2, 3), workers=self.threads, norm="forward",
+                             overwrite_x=True)
+        self.fft_seconds += time.perf_counter() - t
+        u = np.ascontiguousarray(u)
+        lib.ref_eps(self.nx, self.ny, self.nz, *map(d, self.dims), _P(E), _P(u), _P(self.eps))
+        lib.ref_add(ctypes.c_size_t(self.N), _P(self.zero6), _P(self.eps))          # applyBCProjector's eps.add(R)  F:20269
+        lib.ref_component_norm(ctypes.c_size_t(self.N), _P(self.eps), _P(self.norms))
+        return self.norms

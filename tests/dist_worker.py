@@ -1,8 +1,10 @@
-"""Worker for the multi-rank tests: run under torch.distributed.run with 2+ ranks.
-    --backend fake : NumPy slab backend over gloo (CPU suite)
-    --backend hip  : the HIP slab kernels; several ranks may share one GPU, bytes are then
-                     staged through the host by gloo (GPU suite on a 1-GPU box)
-Each rank writes its slab of the converged strain + scalars to --out.<rank>.npz."""
+"""Worker for the multi-rank tests: run under torch.distributed.run with 2+ ranks over gloo.
+    --backend plan : CPU suite.  Executes the library's exchange plan (fg_slab_plan: all-to-all blocks of the pencil
+                     transpose, halo planes) on NumPy buffers and checks every received value against the global array
+                     it must come from -- the offsets / peers RCCL will be handed on the GPUs.
+    --backend hip  : GPU suite on a 1-GPU box.  The slab driver of libfibergen_amd.so, one member per process, ranks
+                     share the GPU, exchanged bytes are staged through the host (callback transport).
+Each rank writes its results to --out.<rank>.npz."""
 import argparse
 import os
 import sys
@@ -14,9 +16,89 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def run_plan(a, dist, rank, P, grid):
+    import torch
+    from fibergen_amd.distributed import (PLAN_A2A_BACKWARD, PLAN_A2A_FORWARD, PLAN_HALO_MODULI, PLAN_HALO_TAU, PLAN_HALO_U,
+                                          slab_plan)
+    nx, ny, nz = grid
+    nxl, nyl = nx // P, ny // P
+    nzf = nz // 2 + 1
+    nzc = ((nzf + 7) // 8) * 8 if nz >= 64 else nzf
+    nzp = 2 * nzc
+    n = nxl * ny * nzp
+    plane = ny * nzp
+    ucs = n + 4 * plane
+    # global tagged array: value encodes (component, x, y, z') uniquely
+    c_, x_, y_, z_ = np.meshgrid(np.arange(3), np.arange(nx), np.arange(ny), np.arange(nzp), indexing="ij")
+    G = (((c_ * nx + x_) * ny + y_) * nzp + z_).astype(np.float64)
+
+    def execute(ops, selfc, bufs):
+        if selfc is not None:
+            s, d = selfc
+            bufs[d["buffer"]][d["offset"]:d["offset"] + d["count"]] = bufs[s["buffer"]][s["offset"]:s["offset"] + s["count"]]
+        reqs, staged = [], []
+        for o in ops:
+            view = bufs[o["buffer"]][o["offset"]:o["offset"] + o["count"]]
+            if o["send"]:
+                reqs.append(dist.P2POp(dist.isend, torch.from_numpy(view.copy()), o["peer"]))
+            else:
+                t = torch.empty(o["count"], dtype=torch.float64)
+                staged.append((view, t))
+                reqs.append(dist.P2POp(dist.irecv, t, o["peer"]))
+        if reqs:
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+        for view, t in staged:
+            view[:] = t.numpy()
+
+    errors = []
+    # ---- pencil transpose: blocked x-slab spectrum -> y-slab and back
+    Gs = G[:, rank * nxl:(rank + 1) * nxl]                               # my x-slab [3][nxl][ny][nzp]
+    S = Gs.reshape(3, nxl, P, nyl, nzp).transpose(0, 2, 1, 3, 4).copy()  # blocked layout [3][q][nxl][nyl][nzp]
+    bufs = {0: S.reshape(-1).copy(), 1: np.full(3 * n, -1.0)}
+    for c in range(3):
+        ops, selfc = slab_plan(nx, ny, nz, P, rank, PLAN_A2A_FORWARD, c)
+        execute(ops, selfc, bufs)
+    R = bufs[1].reshape(3, nx, nyl, nzp)                                  # y-slab [3][nx][nyl][nzp]
+    if not np.array_equal(R, G[:, :, rank * nyl:(rank + 1) * nyl]):
+        errors.append("forward all-to-all")
+    bufs[0][:] = -1.0
+    for c in range(3):
+        ops, selfc = slab_plan(nx, ny, nz, P, rank, PLAN_A2A_BACKWARD, c)
+        execute(ops, selfc, bufs)
+    if not np.array_equal(bufs[0], S.reshape(-1)):
+        errors.append("backward all-to-all")
+    # ---- halo planes of u (3 components) and of the moduli (2)
+    for what, nc, buf_id in ((PLAN_HALO_U, 3, 2), (PLAN_HALO_MODULI, 2, 3)):
+        U = np.full((nc, nxl + 4, ny, nzp), -1.0)
+        U[:, :nxl] = Gs[:nc]
+        bufs = {buf_id: U.reshape(-1)}
+        ops, selfc = slab_plan(nx, ny, nz, P, rank, what)
+        execute(ops, selfc, bufs)
+        U = bufs[buf_id].reshape(nc, nxl + 4, ny, nzp)
+        right0 = G[:nc, ((rank + 1) % P) * nxl]                           # first plane of the right neighbour
+        left_last = G[:nc, ((rank - 1) % P) * nxl + nxl - 1]              # last plane of the left neighbour
+        if not (np.array_equal(U[:, nxl], right0) and np.array_equal(U[:, nxl + 3], left_last)):
+            errors.append("halo planes %d" % what)
+        if not np.array_equal(U[:, :nxl], Gs[:nc]) or (U[:, nxl + 1:nxl + 3] != -1.0).any():
+            errors.append("halo exchange touched other planes %d" % what)
+    # ---- halo of tau: tau0 of plane -1 | tau5, tau4 of plane nxl (6 components tagged through G's first three twice)
+    T = np.concatenate([Gs, Gs + 0.5])                                     # tau0..tau5 of my slab
+    Tg = np.concatenate([G, G + 0.5])
+    bufs = {4: np.concatenate([T[5, 0].reshape(-1), T[4, 0].reshape(-1)]), 5: np.concatenate([T[0, nxl - 1].reshape(-1), np.zeros(plane)]),
+            6: np.full(2 * plane, -1.0), 7: np.full(2 * plane, -1.0)}
+    ops, selfc = slab_plan(nx, ny, nz, P, rank, PLAN_HALO_TAU)
+    execute(ops, selfc, bufs)
+    xl, xr = ((rank - 1) % P) * nxl + nxl - 1, ((rank + 1) % P) * nxl
+    if not (np.array_equal(bufs[6][:plane], Tg[0, xl].reshape(-1)) and np.array_equal(bufs[7][:plane], Tg[5, xr].reshape(-1))
+            and np.array_equal(bufs[7][plane:], Tg[4, xr].reshape(-1))):
+        errors.append("halo of tau")
+    np.savez(a.out + ".%d.npz" % rank, errors=np.array(errors))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--backend", default="fake")
+    ap.add_argument("--backend", default="plan")
     ap.add_argument("--grid", default="8,8,6")
     ap.add_argument("--dims", default="1,1,1")
     ap.add_argument("--mixing", default="voigt")
@@ -24,21 +106,21 @@ def main():
     ap.add_argument("--mixed-bc", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
-    import torch  # before the HIP library: one shared runtime
+    import torch  # noqa: F401  before the HIP library: one shared runtime
     import torch.distributed as dist
     dist.init_process_group("gloo")
     rank, P = dist.get_rank(), dist.get_world_size()
     grid = tuple(int(v) for v in a.grid.split(","))
     dims = tuple(float(v) for v in a.dims.split(","))
+    if a.backend == "plan":
+        run_plan(a, dist, rank, P, grid)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     from helpers import two_phase_setup
-    from fibergen_amd.distributed import DistributedLSSolver, HipSlabBackend
+    from fibergen_amd.distributed import DistributedLSSolver
     mats, phis, normals = two_phase_setup(grid, a.mixing)
-    if a.backend == "fake":
-        from fake_slab_backend import FakeSlabBackend
-        be = FakeSlabBackend(*grid, *dims, rank, P, a.mixing)
-    else:
-        be = HipSlabBackend(*grid, *dims, rank, P, device=0)
-    s = DistributedLSSolver(*grid, *dims, backend=be)
+    s = DistributedLSSolver(*grid, *dims, device=0)
     s.set_num_phases(2)
     for p in range(2):
         s.set_phase(p, mats[p][0], mats[p][1], s.slab(phis[p]))
@@ -56,7 +138,9 @@ def main():
     failed = s.run(E, S)
     np.savez(a.out + ".%d.npz" % rank, eps=s.get_field("epsilon"), sigma=s.get_field("sigma"),
              iterations=s.iterations, residuals=np.array(s.residuals), mean_stress=s.mean_stress(),
-             mean_strain=s.mean_strain(), mu_0=s.mu_0, failed=failed, vf=s.volume_fraction(1))
+             mean_strain=s.mean_strain(), mu_0=s.ref_material[0], failed=failed, vf=s.volume_fraction(1),
+             transport=s.transport)
+    s.close()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,15 +1,14 @@
-"""The N > 1 path on CPU: fibergen_amd.distributed.DistributedLSSolver driven with a NumPy
-slab backend over gloo, world_size 2 and 4, against the single-process oracle.  Checks the
-exchange pattern (halo planes, all-to-all blocks), the rank-ordered reductions, the stop rule
-and the mixed-BC mean correction across ranks."""
+"""The N > 1 path on CPU: the library's exchange plan (fg_slab_plan -- the peers, buffers, offsets and counts the slab
+driver hands to RCCL) executed over gloo, world_size 2 and 4, on NumPy buffers tagged with global indices: the pencil
+transpose must deliver exactly the y-slab of the global spectrum and return it, the halo exchanges exactly the
+neighbours' boundary planes (periodic).  The kernels themselves run in the GPU suite (tests/test_gpu_slab.py: all P
+members on one GPU; tests/test_gpu_distributed.py: one member per process over the same plan)."""
 import os
 import subprocess
 import sys
 
 import numpy as np
 import pytest
-
-from helpers import make_oracle, rel_err
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -24,30 +23,32 @@ def launch(nproc, out, *args, timeout=600):
     return [np.load(out + ".%d.npz" % r) for r in range(nproc)]
 
 
-@pytest.mark.parametrize("nproc,grid,mixing", [(2, "8,8,6", "voigt"), (2, "8,6,5", "laminate"), (4, "8,8,4", "voigt")])
-def test_slab_driver_matches_single_process_oracle(tmp_path, nproc, grid, mixing):
-    g = tuple(int(v) for v in grid.split(","))
-    res = launch(nproc, str(tmp_path / "r"), "--backend", "fake", "--grid", grid, "--mixing", mixing, "--dims", "1,2,1.5")
-    o = make_oracle(g, (1.0, 2.0, 1.5), mixing, tol=1e-8)
-    assert o.run([1.0, 0, 0, 0, 0, 0.5]) is False
-    eps = np.concatenate([r["eps"] for r in res], axis=1)
-    assert all(int(r["iterations"]) == o.iterations for r in res)
-    assert rel_err(eps, o.eps) < 1e-11
+@pytest.mark.parametrize("nproc,grid", [(2, "8,8,6"), (2, "6,4,64"), (4, "8,12,5")])
+def test_exchange_plan_over_gloo(tmp_path, nproc, grid):
+    res = launch(nproc, str(tmp_path / "p"), "--backend", "plan", "--grid", grid)
     for r in res:
-        assert np.array_equal(r["residuals"], res[0]["residuals"])      # identical decisions on every rank
-        assert np.abs(r["residuals"] - np.array(o.residuals)).max() < 1e-12
-        assert rel_err(r["mean_stress"], o.mean_stress()) < 1e-11
-        assert float(r["mu_0"]) == pytest.approx(o.mu_0, rel=1e-14)
-        assert float(r["vf"]) == pytest.approx(float(o.phis[1].mean()), rel=1e-13)
+        assert list(r["errors"]) == []
 
 
-def test_slab_driver_mixed_bc(tmp_path):
-    res = launch(2, str(tmp_path / "m"), "--backend", "fake", "--grid", "8,8,8", "--mixed-bc", "1", "--tol", "1e-9")
-    o = make_oracle((8, 8, 8), tol=1e-9, bc_tol=1e-8, maxiter=400)
-    P = np.zeros((6, 6))
-    P[0, 0] = 1
-    assert o.run([0.01, 0, 0, 0, 0, 0], S0=np.zeros(6), P=P) is False
-    eps = np.concatenate([r["eps"] for r in res], axis=1)
-    assert int(res[0]["iterations"]) == o.iterations
-    assert rel_err(eps, o.eps) < 1e-9
-    assert np.abs(res[0]["mean_stress"][1:]).max() < 1e-7
+def test_plan_is_consistent_across_ranks():
+    """Every send has exactly one matching receive of the same size on the peer, in the same per-pair order."""
+    from fibergen_amd.distributed import slab_plan
+    nx, ny, nz, P = 16, 8, 10, 4
+    for what in range(5):
+        plans = [slab_plan(nx, ny, nz, P, r, what, 1)[0] for r in range(P)]
+        for a in range(P):
+            for b in range(P):
+                if a == b:
+                    continue
+                sends = [o["count"] for o in plans[a] if o["send"] and o["peer"] == b]
+                recvs = [o["count"] for o in plans[b] if not o["send"] and o["peer"] == a]
+                assert sends == recvs, (what, a, b)
+        assert all(o["peer"] != r for r in range(P) for o in plans[r])
+
+
+def test_plan_rejects_bad_arguments():
+    from fibergen_amd import _lib
+    lib = _lib.load()
+    assert lib.fg_slab_plan(8, 8, 8, 3, 0, 0, 0, None, 0, None) == -1    # 8 not divisible by 3
+    assert lib.fg_slab_plan(8, 8, 8, 2, 2, 0, 0, None, 0, None) == -1    # rank out of range
+    assert lib.fg_slab_plan(8, 8, 8, 2, 0, 9, 0, None, 0, None) == -1    # unknown exchange

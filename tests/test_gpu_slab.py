@@ -1,0 +1,130 @@
+"""GPU tests of the slab driver below the C ABI (fg_slab_group_create: all P slabs of one problem on the one GPU of the
+test box, one stream; every step, buffer layout and exchange op is the one the multi-GPU RCCL run executes -- the
+exchanges are device copies here).  Checked against the NumPy oracle and against the single-GPU solver."""
+import numpy as np
+import pytest
+
+from helpers import make_gpu_solver, make_oracle, rel_err, two_phase_setup
+
+pytestmark = pytest.mark.gpu
+
+E_LOAD = np.array([1.0, 0, 0, 0, 0, 0.5])
+
+
+def make_group(P, grid, dims=(1.0, 1.0, 1.0), mixing="voigt", **kw):
+    from fibergen_amd.distributed import SlabGroup
+    mats, phis, normals = two_phase_setup(grid, mixing)
+    g = SlabGroup(*grid, *dims, nranks=P)
+    g.set_num_phases(2)
+    for p in range(2):
+        g.set_phase(p, mats[p][0], mats[p][1], phis[p])
+    g.set_normals(normals)
+    g.set_options(mixing_rule=mixing, **kw)
+    return g
+
+
+FAST = [   # grids the tiled displacement sweep fits (nz/2 >= 62, ny >= 14, local nx >= 4): the displacement loop
+    (1, (8, 16, 128), "voigt"),
+    (2, (8, 16, 128), "voigt"),
+    (4, (16, 16, 128), "voigt"),
+    (2, (16, 32, 256), "voigt"),     # nz/2 = 128: a z row is two waves of the tile
+    (2, (8, 16, 124), "voigt"),      # nz/2 = 62: tiles with halo lanes, generic z transform
+]
+EXACT = [  # strain-state pipeline: laminate mixing, small / odd / mixed-radix grids
+    (1, (16, 16, 16), "voigt"),
+    (2, (16, 16, 16), "voigt"),
+    (4, (16, 8, 16), "voigt"),
+    (2, (32, 16, 64), "laminate"),
+    (2, (12, 10, 6), "laminate"),    # generic (non power-of-two) FFT path in every direction, remapped all-to-all layout
+    (2, (8, 6, 5), "voigt"),         # odd nz
+    (2, (24, 48, 48), "voigt"),      # p * 2^k lengths
+    (2, (8, 16, 128), "laminate"),   # tile-sized grid, laminate => strain-state pipeline
+]
+
+
+@pytest.mark.parametrize("P,grid,mixing", FAST + EXACT)
+def test_group_run_matches_oracle(P, grid, mixing):
+    dims = (1.0, 2.0, 1.5)
+    g = make_group(P, grid, dims, mixing, tol=1e-8)
+    o = make_oracle(grid, dims, mixing, tol=1e-8)
+    assert o.run(E_LOAD) is False
+    assert g.run(E_LOAD) is False
+    assert g.iterations == o.iterations
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-11
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(g.get_field("sigma"), o.get_field("sigma")) < 1e-9
+    assert rel_err(g.mean_stress(), o.mean_stress()) < 1e-10
+    assert rel_err(g.mean_strain(), o.eps.mean(axis=(1, 2, 3))) < 1e-12
+    assert g.ref_material[0] == pytest.approx(o.mu_0, rel=1e-14)
+    assert g.volume_fraction(1) == pytest.approx(float(o.phis[1].mean()), rel=1e-13)
+    for m in g.members:   # every member carries the same history (identical stop decisions)
+        assert m.residuals == g.members[0].residuals and m.iterations == g.iterations
+    g.close()
+
+
+@pytest.mark.parametrize("P,grid", [(2, (8, 16, 128)), (2, (16, 16, 16))])
+def test_group_mixed_bc(P, grid):
+    Pm = np.zeros((6, 6))
+    Pm[0, 0] = 1.0
+    g = make_group(P, grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    g.set_bc_projector(Pm)
+    o = make_oracle(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    assert o.run([0.01, 0, 0, 0, 0, 0], S0=np.zeros(6), P=Pm) is False
+    assert g.run([0.01, 0, 0, 0, 0, 0], np.zeros(6)) is False
+    assert g.iterations == o.iterations
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8
+    assert np.abs(g.mean_stress()[1:]).max() < 1e-7
+    g.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_group_equals_single_gpu_solver(P):
+    """64 x 64 x 128: the slab loop against the single-GPU displacement loop (same kernels, cut along x)."""
+    grid = (64, 64, 128)
+    s = make_gpu_solver(grid, tol=1e-7)
+    g = make_group(P, grid, tol=1e-7)
+    assert s.run(E_LOAD) is False and g.run(E_LOAD) is False
+    assert g.iterations == s.iterations
+    assert np.abs(np.array(g.residuals) - np.array(s.residuals)).max() < 1e-12
+    assert rel_err(g.get_field("epsilon"), s.get_field("epsilon")) < 1e-11
+    assert rel_err(g.mean_stress(), s.mean_stress()) < 1e-12
+    # n passes without the stop rule, starting from the converged state
+    s.iterate(E_LOAD, 3)
+    g.iterate(E_LOAD, 3)
+    assert rel_err(g.get_field("epsilon"), s.get_field("epsilon")) < 1e-11
+    s.close()
+    g.close()
+
+
+def test_iterate_from_a_given_strain_field():
+    grid = (8, 16, 128)
+    rng = np.random.default_rng(3)
+    eps0 = rng.standard_normal((6,) + grid)
+    o = make_oracle(grid)
+    o.mu_0 = 1.7
+    eps = eps0.copy()
+    for _ in range(3):
+        eps = o.basic_scheme(E_LOAD, eps)
+    g = make_group(2, grid, mu_0=1.7, update_ref="never")
+    g.set_field("epsilon", eps0)
+    g.iterate(E_LOAD, 3)    # pass 1 through the strain-state pipeline, then the displacement loop
+    assert rel_err(g.get_field("epsilon"), eps) < 1e-11
+    g.close()
+
+
+def test_errors():
+    from fibergen_amd.distributed import SlabGroup, SlabMember
+    with pytest.raises(RuntimeError, match="divisible"):
+        SlabGroup(10, 8, 8, nranks=4)
+    m = SlabMember(16, 16, 16, rank=1, nranks=2)    # a member of a 2-slab problem without a transport
+    m.set_num_phases(1)
+    m.set_phase(0, 1.0, 1.0, np.ones(m.shape))
+    with pytest.raises(RuntimeError, match="not connected"):
+        m.run(E_LOAD)
+    assert m.transport == ""
+    m.close()
+    g = make_group(2, (16, 16, 16), method="cg")
+    with pytest.raises(RuntimeError, match="basic scheme"):
+        g.run(E_LOAD)
+    assert g.members[0].transport == "local"
+    g.close()
