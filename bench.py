@@ -3,168 +3,242 @@
 
     python bench.py --gpus N --steps K --warmup W [--n 256] [--mixing voigt|laminate]
 
-A "step" is one LS iteration (one basicScheme pass, F:20558-20578) on a synthetic fibre
-RVE resident in HBM.  With N > 1 (torchrun, one rank per GPU) every rank solves its own
-load case of the same RVE -- the six load cases of calc_effective_properties
-(F:26030-26114) are independent, so this shards without any data-path collective
-("scaling": "weak"); the value is the aggregate over ranks.
-Rank 0 prints one JSON line (metric of BASELINE.json: LS iterations/s, plus the HBM
-roofline of the dominant kernel and the CPU baseline).
+A "step" is one LS iteration (one basicScheme pass, F:20558-20578) on a synthetic fibre RVE resident in HBM
+(non-overlapping capsules from the build's seeded placer).
+
+  N = 1   the single-GPU displacement loop.  The K-step region is timed `--repeats` times, `ms_per_step` is the
+          median; `sustained_it_s` is a >= 2 s run; `run_load_case_it_s` times fg_run_load_case (stop rule included);
+          `also` carries the other BASELINE sizes (128^3 Voigt, 512^3 laminate = the north-star target config);
+          `slab_forced` the same problem through the slab driver as ONE slab; `cpu_baseline` the reference's loop in
+          C/OpenMP on the host cores (thread sweep + the reference's default of one thread).
+  N > 1   (torchrun, one rank per GPU) ONE problem, x-slab decomposed over the ranks, RCCL all-to-all between the FFT
+          axes: `value` is its it/s ("scaling": "strong"); `replicas` = every rank its own load case of the same RVE
+          (no collective, the six load cases of calc_effective_properties are independent).
+
+Rank 0 prints one JSON line (metric of BASELINE.json: LS iterations/s, plus the HBM roofline of the dominant kernel).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-
-
-def algorithmic_bytes(n, nphases, mixing):
-    """Algorithmic HBM bytes per launch of each kernel (DESIGN.md / SURVEY 8d): inputs read
-    once, outputs written once, float64."""
-    nx, ny, nz = n
-    N = nx * ny * nz
-    nzc = nz // 2 + 1
-    F = nx * ny * nzc  # complex frequencies (= padded pairs)
-    stress = (6 + 1 + 6) * 8 * N  # 6 eps + phi (second phase = 1 - phi) in, 6 tau out
-    if nphases != 2:
-        stress = (12 + nphases) * 8 * N
-    fft_pass = 3 * 2 * 16 * F     # 3 components, read + write, complex128
-    return {
-        "stress": stress,
-        "div": 9 * 8 * N,
-        "r2c_z": fft_pass, "c2c_y_fwd": fft_pass, "c2c_x_fwd": fft_pass,
-        "g0": 96 * F,
-        "c2c_x_inv": fft_pass, "c2c_y_inv": fft_pass, "c2r_z": fft_pass,
-        "eps_norm": 9 * 8 * N,
-    }
-
-
 A_MIN_BYTES_PER_VOXEL = 392   # SURVEY 8d: maximum legal fusion
 A_STAGE_BYTES_PER_VOXEL = 632
 
 
-def cpu_baseline(n, mixing, budget_s=20.0):
-    """The reference's per-iteration loop nests restated in C/OpenMP (oracle/c, pass structure of
-    BASELINE.md section 3) + pocketfft (scipy.fft, workers = cores) in place of threaded FFTW,
-    timed on all host cores on a bounded sample: passes of the same RVE until ~budget_s is used."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle.c_oracle import CRef
-    from fibergen_amd.rve import synthetic_fiber_rve
-    from helpers import INCLUSION, MATRIX, lame
-    scale = max(n[0], 128) / 128.0
-    K = int(round(40 * scale ** 3)) if n[0] >= 128 else 5
-    phi, normals = synthetic_fiber_rve(n, K=K, R=0.05 / scale, L=0.4 / scale, seed=0,
-                                       with_normals=(mixing == "laminate"))
-    c = CRef(n, (1.0, 1.0, 1.0), [lame(**MATRIX), lame(**INCLUSION)], [1 - phi, phi], normals, mixing)
-    E = np.array([1.0, 0, 0, 0, 0, 0])
-    eps = np.zeros((6,) + tuple(n))
-    mu_0 = 0.5 * (lame(**MATRIX)[0] + lame(**INCLUSION)[0])  # any positive reference medium: cost is identical
-    eps = c.basic_scheme(E, eps, mu_0, 0.0)   # warm-up (page faults, pocketfft plan cache)
-    c.fft_seconds = 0.0
-    t0 = time.perf_counter()
-    it = 0
-    while True:
-        eps = c.basic_scheme(E, eps, mu_0, 0.0)
-        c.component_norm(eps)
-        it += 1
-        if time.perf_counter() - t0 > budget_s or it >= 50:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": it / dt, "unit": "it/s", "cores": int(c.threads), "kind": "port",
-            "fft_share": c.fft_seconds / dt,
-            "sample": "%d passes of the same %dx%dx%d RVE; reference loop nests in C/OpenMP (oracle/c) + "
-                      "pocketfft rfftn/irfftn with %d workers standing in for threaded FFTW" % (it, *n, c.threads)}
+def algorithmic_bytes(n, nphases):
+    """Algorithmic HBM bytes per launch of each kernel (DESIGN.md / SURVEY 8d): inputs read once, outputs written
+    once, float64."""
+    nx, ny, nz = n
+    N = nx * ny * nz
+    F = nx * ny * (nz // 2 + 1)   # complex frequencies
+    stress = (6 + 1 + 6) * 8 * N if nphases == 2 else (12 + nphases) * 8 * N
+    fft_pass = 3 * 2 * 16 * F     # 3 components, read + write, complex128
+    return {"stress": stress, "div": 9 * 8 * N, "r2c_z": fft_pass, "c2c_y_fwd": fft_pass, "c2c_x_fwd": fft_pass,
+            "g0": 96 * F, "c2c_x_inv": fft_pass, "c2c_y_inv": fft_pass, "c2r_z": fft_pass, "eps_norm": 9 * 8 * N}
 
 
-def slab_section(args, n, K, rank, world, local_rank, dist, torch):
-    """The same RVE as ONE problem, x-slab decomposed over the ranks."""
-    from fibergen_amd.distributed import DistributedLSSolver
-    from fibergen_amd.rve import synthetic_fiber_rve
+def materials(mode):
     from helpers import INCLUSION, MATRIX, lame
-    if n[0] % world or n[1] % world:
-        return {"error": "grid not divisible by the number of ranks"}
-    scale = max(args.n, 128) / 128.0
-    phi, normals = synthetic_fiber_rve(n, K=K, R=0.05 / scale, L=0.4 / scale, seed=0,
-                                       with_normals=(args.mixing == "laminate"))
-    s = DistributedLSSolver(*n, device=local_rank)
+    if mode in ("porous", "heat"):
+        return [(1.0, 0.0), (10.0, 0.0)]
+    if mode == "viscosity":
+        return [(1.0, 0.0), (0.1, 0.0)]   # fluid with ten times more viscous particles (fluidity constants)
+    return [lame(**MATRIX), lame(**INCLUSION)]   # contrast 10
+
+
+def configure(s, phi, normals, mixing, mode, slab=None):
+    """materials, phases, normals, options on an LSSolver / SlabGroup / DistributedLSSolver"""
+    if mode != "elasticity":
+        s.set_options(mode=mode)
     s.set_num_phases(2)
-    mats = [lame(**MATRIX), lame(**INCLUSION)]
-    s.set_phase(0, mats[0][0], mats[0][1], s.slab(1.0 - phi))
-    s.set_phase(1, mats[1][0], mats[1][1], s.slab(phi))
+    mats = materials(mode)
+    cut = (lambda a: a) if slab is None else slab
+    s.set_phase(0, mats[0][0], mats[0][1], cut(1.0 - phi))
+    s.set_phase(1, mats[1][0], mats[1][1], cut(phi))
     if normals is not None:
-        s.set_normals(s.slab(normals))
-    s.set_options(mixing_rule=args.mixing)
-    if os.environ.get("FG_SLAB_FUSE_X"):
-        s.set_options(fuse_x=int(os.environ["FG_SLAB_FUSE_X"]))
-    del phi, normals
-    s.calc_ref_material()
-    E = np.array([1.0, 0, 0, 0, 0, 0])
-    s.iterate(E, max(2, args.warmup))
-    torch.cuda.synchronize()
-    dist.barrier()
-    s.comm_time = 0.0
-    t0 = time.perf_counter()
-    s.iterate(E, args.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt, s.comm_time], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt, comm = float(t[0].item()), float(t[1].item())
-    return {"value": args.steps / dt, "unit": "it/s", "ms_per_step": 1e3 * dt / args.steps, "scaling": "strong",
-            "exchange_ms_per_step": 1e3 * comm / args.steps,
-            "parallelism": "x-slabs x%d, 2 all-to-all + 2 halo exchanges per pass (RCCL p2p)" % world}
+        s.set_normals(cut(normals))
+    s.set_options(mixing_rule=mixing)
 
 
-def guarded_slab_section(args, n, K, rank, world, local_rank, dist, torch, out):
-    import threading
-
-    def give_up():
-        if rank == 0 and out is not None:
-            out["slab"] = {"error": "slab section exceeded %d s" % args.slab_timeout}
-            print(json.dumps(out), flush=True)
-        os._exit(0)
-    timer = threading.Timer(args.slab_timeout, give_up)
-    timer.daemon = True
-    timer.start()
-    try:
-        return slab_section(args, n, K, rank, world, local_rank, dist, torch)
-    except Exception as e:  # noqa: BLE001
-        return {"error": "%s: %s" % (type(e).__name__, e)}
-    finally:
-        timer.cancel()
+def timed_regions(iterate, sync, steps, warmup, repeats):
+    """W warm-up steps, then `repeats` regions of exactly `steps` steps, each bracketed by sync() on both sides."""
+    iterate(warmup)
+    sync()
+    out = []
+    for _ in range(repeats):
+        sync()
+        t0 = time.perf_counter()
+        iterate(steps)
+        sync()
+        out.append(time.perf_counter() - t0)
+    return out
 
 
-# HIP-event slot name -> kernel name in the rocprofv3 counter summaries under profiles/
-PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"), "u_eps_stress_div_r2cz": "k_u_fast_z", "stress_div": "k_stress_div_voigt", "xfft_g0_xifft": ("k_xfused_persistent", "k_xfused"),
-              "eps_norm": "k_eps_norm", "stress": "k_stress", "div": "k_div", "g0": "k_g0"}
+def kernel_table(s, E, n, steps, scalar):
+    """per-kernel durations, measured live with HIP events on the solver's stream -> {name: avg_ms, alg_GB, GBps}"""
+    s.enable_stage_timing(True)
+    s.iterate(E, steps)
+    times, cnt = s.stage_times()
+    s.enable_stage_timing(False)
+    N = n[0] * n[1] * n[2]
+    ab = algorithmic_bytes(n, 2)
+    if scalar:   # one component through the FFT chain; the sweep reads T and phi and writes f
+        F = n[0] * n[1] * (n[2] // 2 + 1)
+        ab = {k: 32 * F for k in ab}
+        ab["stress"] = 24 * N
+    kern = {}
+    for k, ms in times.items():
+        avg = ms / max(cnt, 1)
+        if avg <= 0:
+            continue   # stage absorbed by a fused kernel
+        name, alg = k, ab[k]
+        if scalar and k == "stress":
+            name = "T_grad_flux_div"
+        elif k == "stress" and times["div"] == 0 and times["eps_norm"] == 0:
+            # displacement sweep: strain operator + polarisation + divergence + norms, 3 u + phi in, 3 f out
+            name, alg = "u_eps_stress_div", 56 * N
+            if times["r2c_z"] == 0:
+                name, alg = "u_eps_stress_div_r2cz", (32 * n[2] + 48 * (n[2] // 2 + 1)) * n[0] * n[1]
+        elif k == "stress" and times["div"] == 0:
+            name, alg = "stress_div", 80 * N   # SURVEY 8d "S + div: 80"
+        if k == "g0" and times["c2c_x_fwd"] == 0:
+            name = "xfft_g0_xifft"             # x-FFT, Green operator, inverse x-FFT: 48 B/voxel
+        kern[name] = {"avg_ms": avg, "alg_GB": alg / 1e9, "GBps": (alg / 1e9) / (avg / 1e3)}
+    return kern, times, cnt
 
 
-def committed_traffic(n, slot):
-    """HBM bytes per launch of kernel `slot` from the committed PMC summary of this workload
-    (profiles/*pmc_hbm_traffic_<n>cubed*.csv: separate FETCH_SIZE / WRITE_SIZE passes of this same
-    bench command, FETCH_SIZE doubled for gfx950).  A counter pass cannot run inside the timed
-    process, so the figure is read back from the file; None when no pass exists for this grid."""
+# HIP-event slot name -> kernel names in the rocprofv3 counter summaries under profiles/
+PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"), "u_eps_stress_div_r2cz": ("k_u_fast_z",),
+              "stress_div": ("k_stress_div_voigt",), "xfft_g0_xifft": ("k_xfused",), "eps_norm": ("k_eps_norm",),
+              "stress": ("k_stress",), "div": ("k_div",), "g0": ("k_g0",), "r2c_z": ("k_zpass",), "c2r_z": ("k_zpass",),
+              "c2c_y_fwd": ("k_strided",), "c2c_y_inv": ("k_strided",)}
+
+
+def committed_traffic(n, mixing, slot, default_options):
+    """HBM bytes per launch of kernel `slot` from the newest committed PMC summary of this workload
+    (profiles/rNN_pmc_hbm_traffic_<n>cubed[_<mixing>]_vM.csv: separate FETCH_SIZE / WRITE_SIZE passes of this same bench
+    command, gfx950 corrections applied).  A counter pass cannot run inside the timed process, so the figure is read
+    back from the file (`traffic_source` says which); None when the run deviates from the default options or no pass
+    exists for this grid."""
     import csv
     import glob
-    want = PMC_KERNEL.get(slot)
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                          "*pmc_hbm_traffic_%dcubed*.csv" % n)))  # latest by name
-    if not want or not files:
+    import re
+    if not default_options or slot not in PMC_KERNEL:
         return None, None
-    rows = list(csv.DictReader(open(files[-1])))
-    for w in (want if isinstance(want, tuple) else (want,)):
+
+    def version(path):
+        m = re.match(r"r(\d+)_.*?_v(\d+)", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic_%dcubed*.csv" % n))
+             if ("laminate" in os.path.basename(f)) == (mixing == "laminate")]
+    if not files:
+        return None, None
+    newest = max(files, key=version)
+    rows = list(csv.DictReader(open(newest)))
+    for w in PMC_KERNEL[slot]:
         for row in rows:
             if row["kernel"].split("<")[0] == w:
-                return float(row["total_GB"]) * 1e9, "profiles/" + os.path.basename(files[-1])
+                return float(row["total_GB"]) * 1e9, "profiles/" + os.path.basename(newest)
     return None, None
+
+
+def cpu_baseline(n, mixing, phi, normals, budget_s=25.0):
+    """The reference's loop restated in C/OpenMP (oracle/c: one in-place strain field, buffers allocated once, the
+    reference's release flags -O3 -march=native built on this host) + pocketfft (scipy.fft, workers = threads) in place
+    of threaded FFTW, on the host cores: a sweep over thread counts (best = `value`) and the reference's default of ONE
+    thread (F:25226), each on a bounded number of passes of the same RVE."""
+    from oracle.c_oracle import CRefLoop
+    ncpu = os.cpu_count() or 1
+    mats = materials("elasticity")
+    E = np.array([1.0, 0, 0, 0, 0, 0])
+    mu_0 = 0.5 * (mats[0][0] + mats[1][0])   # any positive reference medium: the cost is identical
+    counts = sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu} | {ncpu})
+    c = CRefLoop(n, (1.0, 1.0, 1.0), mats, [1 - phi, phi], normals, mixing, threads=counts[-1])
+    c.one_pass(E, mu_0, 0.0)   # first touch of the buffers by the OpenMP threads, pocketfft plans
+    sweep = {}
+    t_start = time.perf_counter()
+    share = None
+    for th in reversed(counts):
+        c.threads = th
+        c.one_pass(E, mu_0, 0.0)
+        c.fft_seconds = 0.0
+        t0 = time.perf_counter()
+        it = 0
+        while it < 20 and (it < 2 or time.perf_counter() - t0 < min(3.0, budget_s / (2 * len(counts)))):
+            c.one_pass(E, mu_0, 0.0)
+            it += 1
+        dt = time.perf_counter() - t0
+        sweep[th] = it / dt
+        if share is None or sweep[th] >= max(sweep.values()):
+            share = c.fft_seconds / dt
+    best = max(sweep, key=sweep.get)
+    # the reference's default: one thread (one pass; the buffers are warm)
+    c.threads = 1
+    t0 = time.perf_counter()
+    c.one_pass(E, mu_0, 0.0)
+    one = 1.0 / (time.perf_counter() - t0)
+    return {"value": sweep[best], "unit": "it/s", "cores": int(best), "kind": "port",
+            "one_thread_it_s": one, "host_cpus": ncpu, "fft_share": share,
+            "thread_sweep_it_s": {str(k): v for k, v in sorted(sweep.items())},
+            "sample": "passes of the same %dx%dx%d RVE for <= 3 s per thread count (%s threads; value = best) + one "
+                      "pass with 1 thread; oracle/c loop nests (-O3 -march=native, in-place strain field, preallocated) "
+                      "+ pocketfft rfftn/irfftn workers = threads standing in for threaded FFTW; %.0f s in total"
+                      % (*n, "/".join(str(k) for k in counts), time.perf_counter() - t_start)}
+
+
+def measure_single(args, n_edge, mixing, mode, device, E, detail):
+    """One single-GPU workload: median-of-repeats it/s (+ kernels, sustained, run_load_case when detail)."""
+    from fibergen_amd import LSSolver
+    from fibergen_amd.rve import bench_rve
+    n = (n_edge,) * 3
+    phi, normals, par = bench_rve(n_edge, mixing)
+    s = LSSolver(*n, device=device)
+    configure(s, phi, normals, mixing, mode)
+    if args.u_tile is not None:
+        s.set_options(u_tile=args.u_tile)
+    if args.fuse_z is not None:
+        s.set_options(fuse_z=args.fuse_z)
+    s.calc_ref_material()
+    scalar = mode in ("porous", "heat")
+    dts = timed_regions(lambda k: s.iterate(E, k), s.synchronize, args.steps, args.warmup, args.repeats)
+    med = statistics.median(dts)
+    res = {"it_s": args.steps / med, "ms_per_step": 1e3 * med / args.steps,
+           "ms_per_step_min": 1e3 * min(dts) / args.steps, "ms_per_step_max": 1e3 * max(dts) / args.steps,
+           "repeats": len(dts), "rve": {"K": par["K"], "R": float(par["R"]), "L": float(par["L"]), "vf": float(phi.mean()),
+                                        "interface_voxel_fraction": float(((phi > 0) & (phi < 1)).mean())}}
+    kern, times, cnt = kernel_table(s, E, n, min(args.steps, 20), scalar)
+    dom = max(kern, key=lambda k: kern[k]["avg_ms"])
+    res["dominant_kernel"] = {"kernel": dom, **kern[dom], "frac_of_hbm_peak": kern[dom]["GBps"] / HBM_PEAK_GBS}
+    res["kernels"] = kern
+    if detail:
+        # sustained clocks: >= sustain_s of back-to-back passes
+        chunk = max(args.steps, int(0.25 / max(med / args.steps, 1e-6)))
+        s.synchronize()
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < args.sustain_s:
+            s.iterate(E, chunk)
+            s.synchronize()
+            done += chunk
+        res["sustained_it_s"] = done / (time.perf_counter() - t0)
+        res["sustained_s"] = time.perf_counter() - t0
+        # the reference's own entry point: LSSolver::run with the stop rule (norms fetched every pass), maxiter = K
+        s.set_options(tol=0.0, abs_tol=0.0, maxiter=args.steps)
+        s.run(E)
+        res["run_load_case_it_s"] = s.iterations / s.solve_time
+        s.set_options(tol=1e-4, abs_tol=np.finfo(float).eps, maxiter=10000)
+    return s, res, phi, normals
 
 
 def main():
@@ -172,172 +246,74 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=7, help="the K-step region is timed this many times; the median is reported")
+    ap.add_argument("--sustain-s", type=float, default=2.0)
     ap.add_argument("--n", type=int, default=256, help="grid size per axis (128, 256, 512 are the BASELINE sizes; any size runs)")
     ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
-    ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat", "viscosity"],
-                    help="porous / heat: scalar potential, 3-component gradient; viscosity: dual Stokes scheme "
-                         "(BASELINE config 5, 256^3)")
-    ap.add_argument("--u-tile", type=int, default=None, help="override the solver's u_tile option (0, 8, 16)")
-    ap.add_argument("--fuse-z", type=int, default=None, help="override the solver's fuse_z option (attach the z r2c to the sweep)")
+    ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat", "viscosity"])
+    ap.add_argument("--also", default="128:voigt,512:laminate",
+                    help="N = 1: further single-GPU workloads n:mixing reported under `also` ('' = none)")
+    ap.add_argument("--u-tile", type=int, default=None, help="override the solver's u_tile option (0, 8, 12, 16)")
+    ap.add_argument("--fuse-z", type=int, default=None, help="override the solver's fuse_z option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--no-slab", action="store_true", help="N > 1: skip the slab-decomposed measurement")
-    ap.add_argument("--slab-timeout", type=int, default=240)
-    ap.add_argument("--force-slab", action="store_true",
-                    help="also at N = 1: run the slab-decomposed driver (one slab, exchanges become local copies)")
+    ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--slab-members", type=int, default=1,
+                    help="N = 1: also run the slab driver with this many slabs on the one GPU (0 = skip)")
+    ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the load-case replica measurement")
+    ap.add_argument("--slab-timeout", type=int, default=300)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # torch is plumbing for the multi-rank barrier / max-reduction only.  It must be imported
-    # BEFORE libfibergen_amd.so is loaded so that both share one HIP runtime (same soname).
-    torch = None
-    dist = None
-    if world > 1 or args.force_slab:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from fibergen_amd import LSSolver
-    from fibergen_amd.rve import synthetic_fiber_rve
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import INCLUSION, MATRIX, lame
-
-    n = (args.n, args.n, args.n)
-    scale = max(args.n, 128) / 128.0
-    K = int(round(40 * scale ** 3)) if args.n >= 128 else 5
-    phi, normals = synthetic_fiber_rve(n, K=K, R=0.05 / scale, L=0.4 / scale, seed=0,
-                                       with_normals=(args.mixing == "laminate"))
+    default_options = args.u_tile is None and args.fuse_z is None and args.mode == "elasticity"
     scalar = args.mode in ("porous", "heat")
     stokes = args.mode == "viscosity"
-    s = LSSolver(*n, device=local_rank)
-    if scalar or stokes:
-        s.set_options(mode=args.mode)
-    s.set_num_phases(2)
-    mats = [(1.0, 0.0), (10.0, 0.0)] if scalar else [lame(**MATRIX), lame(**INCLUSION)]  # contrast 10
-    if stokes:
-        mats = [(1.0, 0.0), (0.1, 0.0)]   # fluid with ten times more viscous particles (fluidity constants)
-    s.set_phase(0, mats[0][0], mats[0][1], 1.0 - phi)
-    s.set_phase(1, mats[1][0], mats[1][1], phi)
-    if normals is not None:
-        s.set_normals(normals)
-    s.set_options(mixing_rule=args.mixing)
-    if args.u_tile is not None:
-        s.set_options(u_tile=args.u_tile)
-    if args.fuse_z is not None:
-        s.set_options(fuse_z=args.fuse_z)
-    vf = float(phi.mean())
-    del phi, normals
-    s.calc_ref_material()
-    # each rank its own load case (calc_effective_properties' unit strains / gradients)
-    E = np.zeros(3 if scalar else 6)
-    E[rank % E.size] = 1.0
-    if stokes:   # traceless prescribed stresses (F:26257-26261)
-        E = [np.array([1.0, -1, 0, 0, 0, 0]), np.array([0, 1.0, -1, 0, 0, 0]), np.array([0, 0, 0, 1.0, 0, 0]),
-             np.array([0, 0, 0, 0, 1.0, 0]), np.array([0, 0, 0, 0, 0, 1.0])][rank % 5]
+    n = (args.n,) * 3
+    N = args.n ** 3
+    metric = "LS iterations/sec (basic scheme, staggered grid, %s)" % (
+        args.mode + " scalar mode" if scalar else ("Stokes flow, dual scheme" if stokes else "linear elastic"))
 
-    def sync():
-        s.synchronize()  # the solver's own HIP stream carries all the work
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    s.iterate(E, args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    s.iterate(E, args.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = 1e3 * dt / args.steps
-    value = world * args.steps / dt
-
-    out = None
-    if rank == 0:
-        # per-kernel durations, measured live with HIP events on the solver's stream
-        s.enable_stage_timing(True)
-        s.iterate(E, min(args.steps, 20))
-        times, cnt = s.stage_times()
-        s.enable_stage_timing(False)
-        ab = algorithmic_bytes(n, 2, args.mixing)
-        if scalar:
-            # one component through the FFT chain; the sweep reads T and phi and writes f
-            F = n[0] * n[1] * (n[2] // 2 + 1)
-            ab = {k: 32 * F for k in ab}
-            ab["stress"] = 24 * n[0] * n[1] * n[2]
-        kern = {}
-        for k, ms in times.items():
-            avg = ms / max(cnt, 1)
-            if avg <= 0:
-                continue   # stage absorbed by a fused kernel
-            name, alg = k, ab[k]
-            if scalar and k == "stress":
-                name = "T_grad_flux_div"
-            elif k == "stress" and times["div"] == 0 and times["eps_norm"] == 0:
-                # displacement-based sweep: strain operator + polarisation + divergence + norms,
-                # 3 u + phi in, 3 f out
-                name, alg = "u_eps_stress_div", 56 * n[0] * n[1] * n[2]
-                if times["r2c_z"] == 0:
-                    # ... with the z r2c attached: the half spectrum of f goes out instead of f (3 x 16 B x nzf/nz)
-                    name = "u_eps_stress_div_r2cz"
-                    alg = (32 * n[2] + 48 * (n[2] // 2 + 1)) * n[0] * n[1]
-            elif k == "stress" and times["div"] == 0:
-                # polarisation + divergence in one sweep: 6 eps + phi in, 3 f out (SURVEY 8d "S + div: 80")
-                name, alg = "stress_div", 80 * n[0] * n[1] * n[2]
-            if k == "g0" and times["c2c_x_fwd"] == 0:
-                # x-FFT, Green operator, inverse x-FFT: 3 complex components in, 3 out (48 B/voxel)
-                name = "xfft_g0_xifft"
-            kern[name] = {"avg_ms": avg, "alg_GB": alg / 1e9, "GBps": (alg / 1e9) / (avg / 1e3)}
-        g0_alone = None
-        if not scalar and not stokes:
-            # north_star names the Green-operator apply on its own (">= 50 % of the HBM roofline in the
-            # Gamma0-apply kernel"): in the default pipeline it is fused into the x pass, so time the
-            # stand-alone kernel of the one-kernel-per-routine pipeline as well (96 B per frequency)
-            s.set_options(fuse_x=0)
-            s.enable_stage_timing(True)
-            s.iterate(E, 5)
-            t2, c2 = s.stage_times()   # accumulators continue from the measurement above
-            s.enable_stage_timing(False)
-            s.set_options(fuse_x=1)
-            if c2 > cnt and t2["g0"] > times["g0"]:
-                ms = (t2["g0"] - times["g0"]) / (c2 - cnt)
-                g0_alone = {"kernel": "k_g0 (fuse_x=0)", "avg_ms": ms, "alg_GB": ab["g0"] / 1e9,
-                            "GBps": ab["g0"] / 1e9 / (ms / 1e3), "frac_of_hbm_peak": ab["g0"] / 1e9 / (ms / 1e3) / HBM_PEAK_GBS}
-        dom = max(kern, key=lambda k: kern[k]["avg_ms"])
-        N = n[0] * n[1] * n[2]
-        traffic, traffic_src = committed_traffic(args.n, dom)
+    if world == 1:
+        # ------------------------------------------------------------------ one GPU
+        E = np.zeros(3 if scalar else 6)
+        E[0] = 1.0
+        if stokes:
+            E = np.array([1.0, -1, 0, 0, 0, 0])   # traceless prescribed stress (F:26257-26261)
+        s, res, phi, normals = measure_single(args, args.n, args.mixing, args.mode, local_rank, E, detail=True)
+        kern = res["kernels"]
+        dom = res["dominant_kernel"]["kernel"]
+        traffic, traffic_src = committed_traffic(args.n, args.mixing, dom, default_options)
         roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_from_committed_profile": traffic_src,
                 "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]}
+        it_s = res["it_s"]
+        per_voxel = (24 + 7 * 16) if scalar else A_MIN_BYTES_PER_VOXEL
         out = {
-            "metric": "LS iterations/sec (basic scheme, staggered grid, %s)" % (("linear elastic" if not stokes else "Stokes flow, dual scheme") if not scalar else
-                                                                               args.mode + " scalar mode"),
-            "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": metric, "value": it_s, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d^3 two-phase fibre RVE (K=%d capsules, vf=%.3f), contrast 10, mixing=%s, "
-                                   "one load case per GPU" % (args.n, K, vf, args.mixing),
-                       "grid": list(n), "mixing_rule": args.mixing, "mode": args.mode,
-                       "parallelism": "loadcase x%d" % world},
+            "config": {"workload": "%d^3 two-phase fibre RVE (K=%d non-overlapping capsules, R=%.4f, L=%.3f, vf=%.3f), contrast 10, "
+                                   "mixing=%s" % (args.n, res["rve"]["K"], res["rve"]["R"], res["rve"]["L"], res["rve"]["vf"], args.mixing),
+                       "grid": list(n), "mixing_rule": args.mixing, "mode": args.mode, "parallelism": "1 GPU"},
             "roofline": roof,
-            "loop_GBps_Amin": A_MIN_BYTES_PER_VOXEL * N * (args.steps / dt) / 1e9,
-            "loop_GBps_Astage": A_STAGE_BYTES_PER_VOXEL * N * (args.steps / dt) / 1e9,
-            "kernels": kern,
+            "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"], "repeats": res["repeats"],
+            "sustained_it_s": res.get("sustained_it_s"), "run_load_case_it_s": res.get("run_load_case_it_s"),
+            "loop_GBps_Amin": per_voxel * N * it_s / 1e9,
+            "loop_GBps_Astage": (per_voxel if scalar else A_STAGE_BYTES_PER_VOXEL) * N * it_s / 1e9,
+            "kernels": kern, "rve": res["rve"],
         }
-        if g0_alone is not None:
-            out["gamma0_apply_standalone"] = g0_alone
-        # the measured roofline: streaming copy / triad of the library on this GPU, 1 GiB arrays
-        try:
+        if not scalar and not stokes:
+            # north_star names the Green-operator apply on its own (">= 50 % of the HBM roofline in the Gamma0-apply
+            # kernel"): in the default pipeline it is fused into the x pass, so time the stand-alone kernel of the
+            # one-kernel-per-routine pipeline as well (96 B per frequency)
+            s.set_options(fuse_x=0)
+            k2, _, _ = kernel_table(s, E, n, 5, scalar)
+            s.set_options(fuse_x=1)
+            if "g0" in k2:
+                out["gamma0_apply_standalone"] = {"kernel": "k_g0 (fuse_x=0)", **k2["g0"],
+                                                  "frac_of_hbm_peak": k2["g0"]["GBps"] / HBM_PEAK_GBS}
+        try:   # the measured roofline: streaming copy / triad of the library on this GPU, 1 GiB arrays
             import ctypes
             from fibergen_amd import _lib
             cg, tg = ctypes.c_double(0.0), ctypes.c_double(0.0)
@@ -345,34 +321,150 @@ def main():
                 best = max(cg.value, tg.value)
                 out["hbm_stream"] = {"copy_GBps": cg.value, "triad_GBps": tg.value,
                                      "dominant_kernel_frac_of_measured": kern[dom]["GBps"] / best}
-                if g0_alone is not None:
-                    out["hbm_stream"]["gamma0_apply_frac_of_measured"] = g0_alone["GBps"] / best
+                if "gamma0_apply_standalone" in out:
+                    out["hbm_stream"]["gamma0_apply_frac_of_measured"] = out["gamma0_apply_standalone"]["GBps"] / best
         except Exception as e:  # noqa: BLE001
             out["hbm_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if scalar:
-            # the loop-level figures use the elasticity byte counts; per voxel the scalar loop moves
-            # 24 (sweep) + 7 x 16 (six 1-component FFT passes + Green operator) bytes
-            per = 24 + 7 * 16
-            out["loop_GBps_Amin"] = per * N * (args.steps / dt) / 1e9
-            out["loop_GBps_Astage"] = out["loop_GBps_Amin"]
-        if world == 1 and not args.no_cpu_baseline and not scalar and not stokes:
-            s.close()
-            out["cpu_baseline"] = cpu_baseline(n, args.mixing, args.cpu_budget)
-    if (world > 1 or args.force_slab) and not args.no_slab and not scalar and not stokes:
-        # Second measurement: ONE problem slab-decomposed over all ranks (x-slabs, two RCCL
-        # all-to-alls per pass).  Guarded: a failure or a stall here must not cost the line above.
         s.close()
-        slab = guarded_slab_section(args, n, K, rank, world, local_rank, dist, torch, out)
-        if out is not None:
-            out["slab"] = slab
-    if rank == 0:
+        if args.slab_members > 0 and not scalar and not stokes:
+            # the same problem through the slab driver on this one GPU (P = 1: a lone slab, halo = own planes, the
+            # all-to-all is the identity; P > 1: all slabs in this process, exchanges are device copies)
+            try:
+                from fibergen_amd.distributed import SlabGroup
+                g = SlabGroup(*n, nranks=args.slab_members, device=local_rank)
+                configure(g, phi, normals, args.mixing, args.mode)
+                g.calc_ref_material()
+                dts = timed_regions(lambda k: g.iterate(E, k), g.synchronize, args.steps, args.warmup, args.repeats)
+                med = statistics.median(dts)
+                out["slab_forced"] = {"members": args.slab_members, "it_s": args.steps / med, "ms_per_step": 1e3 * med / args.steps,
+                                      "ratio_to_single_gpu_loop": (args.steps / med) / it_s,
+                                      "transport": g.members[0].transport}
+                g.close()
+            except Exception as e:  # noqa: BLE001
+                out["slab_forced"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        also = {}
+        for item in [a for a in args.also.split(",") if a]:
+            ne, mix = item.split(":")
+            if (int(ne), mix) == (args.n, args.mixing) or scalar or stokes:
+                continue
+            try:
+                s2, r2, _, _ = measure_single(args, int(ne), mix, "elasticity", local_rank, E, detail=False)
+                s2.close()
+                r2["kernels"] = {k: {"avg_ms": v["avg_ms"], "GBps": v["GBps"]} for k, v in r2["kernels"].items()}
+                also["%s^3 %s" % (ne, mix)] = r2
+            except Exception as e:  # noqa: BLE001
+                also["%s^3 %s" % (ne, mix)] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if also:
+            out["also"] = also
+        if not args.no_cpu_baseline and not scalar and not stokes:
+            out["cpu_baseline"] = cpu_baseline(n, args.mixing, phi, normals, args.cpu_budget)
+            out["gpu_over_cpu"] = it_s / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        try:
-            dist.barrier()
-            dist.destroy_process_group()
-        except Exception:
-            pass
+        return
+
+    # ---------------------------------------------------------------------- N > 1: one rank per GPU
+    # torch is plumbing for rendez-vous, barrier and the max over ranks.  It must be imported BEFORE libfibergen_amd.so
+    # is loaded so that both share one HIP runtime (same soname).
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from fibergen_amd import LSSolver
+    from fibergen_amd.distributed import DistributedLSSolver
+    from fibergen_amd.rve import bench_rve
+    if scalar or stokes:
+        raise SystemExit("N > 1 measures the elasticity mode")
+    phi, normals, par = bench_rve(args.n, args.mixing)
+
+    def sync_all(obj):
+        obj.synchronize()
+        torch.cuda.synchronize(local_rank)
+        dist.barrier()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    replicas = None
+    if not args.no_replicas:
+        # every rank its own load case (calc_effective_properties' unit strains): no data-path collective
+        s = LSSolver(*n, device=local_rank)
+        configure(s, phi, normals, args.mixing, args.mode)
+        s.calc_ref_material()
+        E = np.zeros(6)
+        E[rank % 6] = 1.0
+        dts = timed_regions(lambda k: s.iterate(E, k), lambda: sync_all(s), args.steps, args.warmup, 3)
+        med = max_over_ranks(statistics.median(dts))
+        replicas = {"value": world * args.steps / med, "unit": "it/s", "ms_per_step": 1e3 * med / args.steps,
+                    "scaling": "weak", "parallelism": "one load case per GPU x%d, no collective" % world}
+        s.close()
+
+    line = {"metric": metric, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d^3 two-phase fibre RVE (K=%d non-overlapping capsules, R=%.4f, L=%.3f, vf=%.3f), contrast 10, "
+                                   "mixing=%s" % (args.n, par["K"], par["R"], par["L"], float(phi.mean()), args.mixing),
+                       "grid": list(n), "mixing_rule": args.mixing, "mode": args.mode}}
+
+    def emit(obj, code):
+        if rank == 0:
+            print(json.dumps(obj), flush=True)
+        sys.stdout.flush()
+        os._exit(code)
+
+    def watchdog():
+        # a stalled exchange must not cost the whole line: report the replicas with the error, exit non-zero
+        fb = dict(line)
+        fb.update({"value": replicas["value"] if replicas else None, "ms_per_step": replicas["ms_per_step"] if replicas else None,
+                   "scaling": "weak", "replicas": replicas,
+                   "slab": {"error": "slab-decomposed section exceeded %d s" % args.slab_timeout}})
+        fb["config"] = dict(line["config"], parallelism="load-case replicas (slab section stalled)")
+        emit(fb, 3)
+    timer = threading.Timer(args.slab_timeout, watchdog)
+    timer.daemon = True
+    timer.start()
+    try:
+        if args.n % world:
+            raise RuntimeError("grid not divisible by the number of ranks")
+        d = DistributedLSSolver(*n, device=local_rank)   # RCCL communicator from an id broadcast over the group
+        configure(d, phi, normals, args.mixing, args.mode, slab=d.slab)
+        del phi, normals
+        d.calc_ref_material()
+        E = np.array([1.0, 0, 0, 0, 0, 0])
+        dts = timed_regions(lambda k: d.iterate(E, k), lambda: sync_all(d), args.steps, args.warmup, args.repeats)
+        med = max_over_ranks(statistics.median(dts))
+        lo, hi = max_over_ranks(min(dts)), max_over_ranks(max(dts))
+        it_s = args.steps / med
+        local_n = (args.n // world, args.n, args.n)
+        kern, _, _ = kernel_table(d, E, local_n, min(args.steps, 10), False)   # this rank's slab, HIP events
+        dom = max(kern, key=lambda k: kern[k]["avg_ms"])
+        line.update({
+            "value": it_s, "ms_per_step": 1e3 * med / args.steps, "scaling": "strong",
+            "ms_per_step_min": 1e3 * lo / args.steps, "ms_per_step_max": 1e3 * hi / args.steps, "repeats": args.repeats,
+            "roofline": {"kernel": dom + " (rank 0's slab)", "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]},
+            "loop_GBps_Amin": A_MIN_BYTES_PER_VOXEL * N * it_s / 1e9,
+            "kernels": kern, "replicas": replicas, "transport": d.transport,
+            "alltoall_MB_per_gpu_per_pass": 2 * 3 * (world - 1) / world * (args.n // world) * args.n * (args.n // 2 + 1) * 16 / 1e6,
+        })
+        line["config"]["parallelism"] = ("x-slabs x%d: ONE problem, displacement loop per slab, per component one RCCL all-to-all "
+                                         "each way between the FFT axes, +-1 halo planes of u, norms all-reduced" % world)
+        d.close()
+    except Exception as e:  # noqa: BLE001
+        line.update({"value": replicas["value"] if replicas else None, "ms_per_step": replicas["ms_per_step"] if replicas else None,
+                     "scaling": "weak", "replicas": replicas, "slab": {"error": "%s: %s" % (type(e).__name__, e)}})
+        line["config"]["parallelism"] = "load-case replicas (slab section failed)"
+        timer.cancel()
+        emit(line, 4)
+    timer.cancel()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
 
 
 if __name__ == "__main__":

@@ -74,9 +74,6 @@ SIGNATURES = {
     "fg_hbm_stream": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p]),
     "fg_create_slab": (ctypes.c_void_p, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
-    "fg_slab_phase": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p]),
-    "fg_exchange_buffer": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulong)]),
-    "fg_local_sums": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_double_p]),
     "fg_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "fg_slab_connect_rccl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     "fg_slab_group_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,

@@ -174,28 +174,6 @@ int fg_slab_plan(int nx, int ny, int nz, int nranks, int rank, int what, int com
   return (int)p.ops.size();
 }
 
-int fg_slab_phase(fg_solver* s, int phase, const double* E6, const double* R6) {
-  return guarded(s, [&](fg::Solver& v) { v.slab_phase(phase, E6, R6); });
-}
-
-void* fg_exchange_buffer(fg_solver* s, const char* name, unsigned long* bytes) {
-  void* p = nullptr;
-  guarded(s, [&](fg::Solver& v) {
-    if (!name) throw std::runtime_error("NULL argument");
-    size_t b = 0;
-    p = v.exchange_buffer(name, &b);
-    if (bytes) *bytes = (unsigned long)b;
-  });
-  return p;
-}
-
-int fg_local_sums(fg_solver* s, const char* what, double* out) {
-  return guarded(s, [&](fg::Solver& v) {
-    if (!what || !out) throw std::runtime_error("NULL argument");
-    v.local_sums(what, out);
-  });
-}
-
 void fg_destroy(fg_solver* s) {
   if (!s) return;
   try {
@@ -263,6 +241,7 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       o.u_tile = (int)value;
     }
     else if (k == "fuse_x") o.fuse_x = value != 0;
+    else if (k == "slab_split") o.slab_split = value < 0 ? -1 : (value != 0);
     else if (k == "fuse_z") o.fuse_z = value < 0 ? -1 : (value != 0);
     else if (k == "u_loop") o.u_loop = (int)value;
     else if (k == "method") {

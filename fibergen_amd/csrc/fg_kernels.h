@@ -125,8 +125,6 @@ void launch_eps_delta_recompute(const Grid& g, const FieldPtrs<3>& u, const Fiel
                                 double coef, const FieldPtrs<6>& eps, double* partial, double* sumsq6, hipStream_t s);
 void launch_eps_delta(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& tau, const double* tau_sum, double nvox,
                       const Vec6& E, double coef, const FieldPtrs<6>& eps, double* partial, double* sumsq6, hipStream_t s);
-void launch_transpose_A(const double* src, double* dst, int nxl, int ny, int nyl, int nzc, bool to_blocks, hipStream_t s);
-void launch_transpose_B(const double* src, double* dst, int nx, int nxl, int nyl, int nzc, bool to_blocks, hipStream_t s);
 void launch_copy(const double* src, double* dst, long ndoubles, hipStream_t s);
 void launch_cg(int mode, const Grid& g, const FieldPtrs<6>& x, const FieldPtrs<6>& y, const FieldPtrs<6>& z, const Vec6& E,
                double a, double* partial, double* out6, hipStream_t s);

@@ -408,8 +408,8 @@ __global__ __launch_bounds__(kBlock, FG_K1_WAVES) void k_u_stress_div_voigt(Grid
 
 // ----------------------------------------------------------------------------- Green operator
 // G0OperatorFourierStaggeredGeneral  F:19834-19927, in place on 3 complex components.
-// layout.transposed == 0: [nx][ny][nzc] (g = full grid).  transposed == 1 (y-slab of the slab-decomposed
-// transform): [nyl][nx][nzc] with global ky = jj0 + jl; the zero mode lives on the slab with jj0 == 0.
+// Layout [nx][ny][nzc]; for the y-slab of the slab-decomposed transform g.ny is the slab thickness and the global
+// ky is jj0 + local row (the zero mode lives on the slab with jj0 == 0).
 __global__ __launch_bounds__(kBlock) void k_g0(Grid g, FieldPtrs<3> fh, G0Tables tb, double c10, double c20,
                                                G0Layout lay) {
   const long nfreq = lay.transposed ? (long)lay.nyl * g.nx * g.nzc : (long)g.nx * g.ny * g.nzc;
@@ -1207,43 +1207,6 @@ __global__ __launch_bounds__(kBlock) void k_tangent_minmax(Grid g, PhaseTable pt
   }
 }
 
-// Slab <-> pencil transposes of the 3 complex components, one complex per thread.
-// A: x-slab field [c][nxl][ny][nzc]  <->  blocks [q][c][nxl][nyl][nzc]   (q = owner of the y range)
-// B: blocks [p][c][nxl][nyl][nzc]    <->  y-slab field [c][nyl][nx][nzc]  (p = owner of the x range)
-__global__ __launch_bounds__(kBlock) void k_transpose_A(const cplx* src, cplx* dst, int nxl, int ny, int nyl, int nzc,
-                                                        int to_blocks) {
-  const long total = 3L * nxl * ny * nzc;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int kz = (int)(idx % nzc);
-    long r = idx / nzc;
-    const int y = (int)(r % ny);
-    r /= ny;
-    const int xl = (int)(r % nxl);
-    const int c = (int)(r / nxl);
-    const int q = y / nyl, yl = y - q * nyl;
-    const long blk = ((((long)q * 3 + c) * nxl + xl) * nyl + yl) * nzc + kz;
-    if (to_blocks) dst[blk] = src[idx];
-    else dst[idx] = src[blk];
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_transpose_B(const cplx* src, cplx* dst, int nx, int nxl, int nyl, int nzc,
-                                                        int to_blocks) {
-  const long total = 3L * nyl * nx * nzc;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int kz = (int)(idx % nzc);
-    long r = idx / nzc;
-    const int x = (int)(r % nx);
-    r /= nx;
-    const int yl = (int)(r % nyl);
-    const int c = (int)(r / nyl);
-    const int p = x / nxl, xl = x - p * nxl;
-    const long blk = ((((long)p * 3 + c) * nxl + xl) * nyl + yl) * nzc + kz;
-    if (to_blocks) dst[blk] = src[idx];
-    else dst[idx] = src[blk];
-  }
-}
-
 // copy one x-plane of a padded component (halo packing)
 __global__ __launch_bounds__(kBlock) void k_copy(const double* src, double* dst, long n2) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x)
@@ -1558,20 +1521,6 @@ void launch_eps_delta_recompute(const Grid& g, const FieldPtrs<3>& u, const Fiel
                        partial, sp, phi, chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
-  FG_HIP_CHECK(hipGetLastError());
-}
-
-void launch_transpose_A(const double* src, double* dst, int nxl, int ny, int nyl, int nzc, bool to_blocks, hipStream_t s) {
-  const long total = 3L * nxl * ny * nzc;
-  hipLaunchKernelGGL(k_transpose_A, dim3(grid_for(total, 1 << 20)), dim3(kBlock), 0, s, reinterpret_cast<const cplx*>(src),
-                     reinterpret_cast<cplx*>(dst), nxl, ny, nyl, nzc, to_blocks ? 1 : 0);
-  FG_HIP_CHECK(hipGetLastError());
-}
-
-void launch_transpose_B(const double* src, double* dst, int nx, int nxl, int nyl, int nzc, bool to_blocks, hipStream_t s) {
-  const long total = 3L * nyl * nx * nzc;
-  hipLaunchKernelGGL(k_transpose_B, dim3(grid_for(total, 1 << 20)), dim3(kBlock), 0, s, reinterpret_cast<const cplx*>(src),
-                     reinterpret_cast<cplx*>(dst), nx, nxl, nyl, nzc, to_blocks ? 1 : 0);
   FG_HIP_CHECK(hipGetLastError());
 }
 

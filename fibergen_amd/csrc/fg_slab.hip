@@ -4,6 +4,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -118,6 +119,15 @@ void Solver::comm_wait(int slot) {
   x_pending_[slot] = false;
 }
 
+// One slab has nothing to overlap; otherwise split when a component of the slab is >= 32 MB (512^3 on 8 GPUs: 135 MB,
+// 256^3 on 8: 17 MB).  Option slab_split / FG_SLAB_SPLIT = 0 / 1 override (tests, A/B runs).
+bool Solver::slab_split() const {
+  static const int env = getenv("FG_SLAB_SPLIT") ? atoi(getenv("FG_SLAB_SPLIT")) : -1;
+  if (env >= 0) return env != 0;
+  if (opt_.slab_split >= 0) return opt_.slab_split != 0;
+  return nranks_ > 1 && (double)g_.n * sizeof(double) >= 32.0 * 1024 * 1024;
+}
+
 double* Solver::slab_buffer(int id) {
   switch (id) {
     case FG_BUF_SPECTRUM_X: return tau_;
@@ -153,16 +163,18 @@ void Solver::slab_exchange(int what, int comp, int done_slot) {
     return;
   }
   if (!comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
-  const SlabPlan p = slab_plan(d, what, comp);
-  std::vector<XOp> ops(p.ops.size());
-  for (size_t i = 0; i < p.ops.size(); ++i) {
-    const fg_plan_op& o = p.ops[i];
-    ops[i] = XOp{o.send, o.peer, slab_buffer(o.buffer) + o.offset, (size_t)o.count * sizeof(double)};
-  }
+  // comp < 0: the three components of an all-to-all in ONE exchange (small slabs: fewer, larger messages)
+  std::vector<XOp> ops;
   comm_begin();
-  if (p.self_src.count)
-    FG_HIP_CHECK(hipMemcpyAsync(slab_buffer(p.self_dst.buffer) + p.self_dst.offset, slab_buffer(p.self_src.buffer) + p.self_src.offset,
-                                (size_t)p.self_src.count * sizeof(double), hipMemcpyDeviceToDevice, comm_stream_));
+  for (int c = comp < 0 ? 0 : comp; c <= (comp < 0 ? 2 : comp); ++c) {
+    const SlabPlan p = slab_plan(d, what, c);
+    for (const fg_plan_op& o : p.ops)
+      ops.push_back(XOp{o.send, o.peer, slab_buffer(o.buffer) + o.offset, (size_t)o.count * sizeof(double)});
+    if (p.self_src.count)
+      FG_HIP_CHECK(hipMemcpyAsync(slab_buffer(p.self_dst.buffer) + p.self_dst.offset,
+                                  slab_buffer(p.self_src.buffer) + p.self_src.offset, (size_t)p.self_src.count * sizeof(double),
+                                  hipMemcpyDeviceToDevice, comm_stream_));
+  }
   comm_->exchange(ops.data(), (int)ops.size(), comm_stream_);
   comm_end(done_slot);
 }
@@ -208,8 +220,10 @@ void Solver::slab_front_fast(const double* E6, bool sum_tau) {
   FieldPtrs<2> mod;
   mod.p[0] = smod_;
   mod.p[1] = smod_ + ucs_;
+  time_begin(0);
   launch_u_tile(gu_, opt_.mu_0, opt_.lambda_0, strided3(su_[su_cur_], ucs_), mod, ptrs3(fu_), E, partial_, dscal_ + kSlotSumSq,
                 opt_.u_tile, stream_, sum_tau);
+  time_end(0);
   slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
 }
 
@@ -225,17 +239,49 @@ void Solver::slab_chain_step(int k) {
   double* R = slab_buffer(FG_BUF_SPECTRUM_Y);
   double* un = su_[su_cur_ ^ 1];
   const bool blocked = fft_->can_block_y(nranks_);
-  if (k >= 1 && k <= 3) {
-    const int c = k - 1;
-    double* f = fu_ + c * n;
-    fft_->r2c_z(f, 1, n);
+  // Large slabs are bandwidth bound on the links: component c's all-to-all overlaps the transforms of c + 1.  Small
+  // slabs are latency bound (launches, RCCL start-up): the three components go through every stage together.
+  const bool split = slab_split();
+  auto forward = [&](int c0, int nc) {   // z r2c and y c2c (into the all-to-all layout) of components c0 .. c0 + nc - 1
+    double* f = fu_ + c0 * n;
+    time_begin(2);
+    fft_->r2c_z(f, nc, n);
+    time_end(2);
+    time_begin(3);
     if (blocked) {
-      fft_->c2c_y_blocked(f, n, S + c * n, n, 1, -1, 1.0, nranks_);
+      fft_->c2c_y_blocked(f, n, S + c0 * n, n, nc, -1, 1.0, nranks_);
     } else {
-      fft_->c2c_y(f, 1, n, -1, 1.0);
-      launch_block_remap(f, S + c * n, g_, nyl_, true, stream_);
+      fft_->c2c_y(f, nc, n, -1, 1.0);
+      for (int c = c0; c < c0 + nc; ++c) launch_block_remap(fu_ + c * n, S + c * n, g_, nyl_, true, stream_);
     }
-    slab_exchange(FG_PLAN_A2A_FORWARD, c, kXA2AFwd + c);
+    time_end(3);
+  };
+  auto backward = [&](int c0, int nc) {  // y c2c^-1 (out of the all-to-all layout) and z c2r
+    double* u = un + c0 * ucs_;
+    time_begin(7);
+    if (blocked) {
+      fft_->c2c_y_blocked(S + c0 * n, n, u, ucs_, nc, +1, 1.0, nranks_);
+    } else {
+      for (int c = c0; c < c0 + nc; ++c) launch_block_remap(S + c * n, un + c * ucs_, g_, nyl_, false, stream_);
+      fft_->c2c_y(u, nc, ucs_, +1, 1.0);
+    }
+    time_end(7);
+    time_begin(8);
+    fft_->c2r_z(u, nc, ucs_);
+    time_end(8);
+  };
+  auto finish = [&]() {
+    slab_exchange(FG_PLAN_HALO_U, 0, kXHaloU);
+    if (timing_) times_.count++;
+  };
+  if (k >= 1 && k <= 3) {
+    if (split) {
+      forward(k - 1, 1);
+      slab_exchange(FG_PLAN_A2A_FORWARD, k - 1, kXA2AFwd + k - 1);
+    } else if (k == 1) {
+      forward(0, 3);
+      slab_exchange(FG_PLAN_A2A_FORWARD, -1, kXA2AFwd);
+    }
   } else if (k == 4) {
     for (int c = 0; c < 3; ++c) comm_wait(kXA2AFwd + c);
     const double alpha = -1.0;   // GammaOperator(..., -1)  F:20575
@@ -250,6 +296,7 @@ void Solver::slab_chain_step(int k) {
       tb.kp[a] = gp.kp[a] = g0_kp_[a];
     }
     const int jj0 = rank_ * nyl_;   // this rank's ky rows
+    time_begin(5);
     if (opt_.fuse_x && nxg_ > 1 && fft_ys_->can_fuse(0)) {
       fft_ys_->fused_g0(R, n, 0, scale, gp, jj0);
     } else {
@@ -259,21 +306,20 @@ void Solver::slab_chain_step(int k) {
       launch_g0(gy, ptrs3(R), tb, gp.c10, gp.c20, G0Layout{0, nyl_, jj0}, stream_);
       if (nxg_ > 1) fft_ys_->c2c_x(R, 3, n, +1, 1.0);
     }
-    slab_exchange(FG_PLAN_A2A_BACKWARD, 0, kXA2ABwd + 0);
+    time_end(5);
+    slab_exchange(FG_PLAN_A2A_BACKWARD, split ? 0 : -1, kXA2ABwd + 0);
   } else if (k == 5 || k == 6) {
-    slab_exchange(FG_PLAN_A2A_BACKWARD, k - 4, kXA2ABwd + k - 4);
+    if (split) slab_exchange(FG_PLAN_A2A_BACKWARD, k - 4, kXA2ABwd + k - 4);
   } else if (k >= 7 && k <= 9) {
-    const int c = k - 7;
-    comm_wait(kXA2ABwd + c);
-    double* u = un + c * ucs_;
-    if (blocked) {
-      fft_->c2c_y_blocked(S + c * n, n, u, ucs_, 1, +1, 1.0, nranks_);
-    } else {
-      launch_block_remap(S + c * n, u, g_, nyl_, false, stream_);
-      fft_->c2c_y(u, 1, ucs_, +1, 1.0);
+    if (split) {
+      comm_wait(kXA2ABwd + k - 7);
+      backward(k - 7, 1);
+      if (k == 9) finish();
+    } else if (k == 7) {
+      comm_wait(kXA2ABwd);
+      backward(0, 3);
+      finish();
     }
-    fft_->c2r_z(u, 1, ucs_);
-    if (k == 9) slab_exchange(FG_PLAN_HALO_U, 0, kXHaloU);
   } else {
     throw std::runtime_error("slab_chain_step: k out of range");
   }
@@ -357,7 +403,8 @@ void SlabGroup::check_members() const {
   if (a.pt_.n < 1) throw std::runtime_error("No materials specified");
   for (Solver* s : m_) {
     if (s->nranks_ > 1 && !s->comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
-    if (s->opt_.mixing != a.opt_.mixing || s->pt_.n != a.pt_.n || s->opt_.u_loop != a.opt_.u_loop || s->opt_.u_tile != a.opt_.u_tile)
+    if (s->opt_.mixing != a.opt_.mixing || s->pt_.n != a.pt_.n || s->opt_.u_loop != a.opt_.u_loop || s->opt_.u_tile != a.opt_.u_tile ||
+        s->opt_.slab_split != a.opt_.slab_split)
       throw std::runtime_error("the members of a slab group must carry the same options and materials");
   }
 }

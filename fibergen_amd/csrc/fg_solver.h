@@ -60,6 +60,8 @@ struct SolverOptions {
   int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
   int u_tile = 8;               // fast displacement sweep (u_loop = 2) as the LDS-tiled marching kernel where the grid allows:
                                 // rows per workgroup (8, 12, 16), 0 = off.  512^3: 2.8 -> 1.95 ms per sweep
+  int slab_split = -1;          // slab driver: all-to-all per component, overlapping the next component's transforms (1), one
+                                // exchange for the three components (0), or by slab size (-1)
   int fuse_z = 0;               // attach the z r2c transform to the untiled fast sweep (u_tile = 0): 1 on, 0 off, -1 by size
                                 // (measured +3 % at 128^3, -1 % at 256^3, -5 % at 512^3 against the untiled sweep)
 };
@@ -133,10 +135,6 @@ class Solver {
   // device pointer of a padded component (for zero-copy wrapping by the caller)
   double* device_component(const std::string& name, int c);
 
-  // slab-decomposed pass: phases 0..4 with exchanges in between (see fg_solver.hip)
-  void slab_phase(int phase, const double* E6, const double* R6);
-  double* exchange_buffer(const std::string& name, size_t* bytes);
-  void local_sums(const std::string& what, double* out);
   int rank() const { return rank_; }
   int nranks() const { return nranks_; }
   int nx_global() const { return nxg_; }
@@ -202,6 +200,7 @@ class Solver {
   void slab_reduce(int slot, int n, bool min_op);        // all-reduce of dscal_ slots on the comm stream
   void slab_exchange(int what, int comp, int done_slot);
   double* slab_buffer(int id);
+  bool slab_split() const;                               // all-to-all per component (overlap) or once for all three
   void comm_begin();
   void comm_end(int slot);
   void comm_wait(int slot);
@@ -236,7 +235,6 @@ class Solver {
   int nyl_ = 0;        // ny / nranks: thickness of the y-slab after the transpose
   long nglobal_ = 0;   // global voxel count
   std::unique_ptr<Fft3> fft_;
-  std::unique_ptr<Fft3> fft_t_;  // x transform in the y-slab layout
   double* halo_[4] = {nullptr, nullptr, nullptr, nullptr};  // send_lo, send_hi, recv_lo, recv_hi (2 planes each)
 
   double* eps_ = nullptr;      // 6 padded components

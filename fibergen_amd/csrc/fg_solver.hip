@@ -81,10 +81,7 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   FG_HIP_CHECK(hipMemsetAsync(derr_, 0, sizeof(int), stream_));
 
   fft_.reset(new Fft3(g_, stream_));
-  {
-    // slab phases (also driven with nranks = 1 by the tests): x-lines in the y-slab layout [nyl][nx][nzc] are
-    // "y lines" of a (nyl, nx, nz) grid
-    fft_t_.reset(new Fft3(make_grid(nyl_, nxg_, nz, 1.0, 1.0, 1.0), stream_));
+  if (slab_layout_) {   // halo planes of the strain-state pipeline of the slab driver (tau going out, tau coming in)
     const size_t plane = (size_t)g_.nyzp * sizeof(double);
     for (int k = 0; k < 4; ++k) {
       FG_HIP_CHECK(hipMalloc(&halo_[k], 2 * plane));
@@ -137,7 +134,6 @@ Solver::~Solver() {
   (void)hipStreamSynchronize(stream_);
   if (comm_stream_ && comm_stream_ != stream_) (void)hipStreamSynchronize(comm_stream_);
   fft_.reset();
-  fft_t_.reset();
   for (int k = 0; k < 4; ++k)
     if (halo_[k]) (void)hipFree(halo_[k]);
   if (mixed_list_) (void)hipFree(mixed_list_);
@@ -355,7 +351,10 @@ void Solver::adopt_back() {
   if (timing_) times_.count++;
 }
 
-void Solver::enable_stage_timing(bool on) { timing_ = on; }
+void Solver::enable_stage_timing(bool on) {
+  if (on && !timing_) reset_stage_times();   // a new measurement starts from zero
+  timing_ = on;
+}
 void Solver::reset_stage_times() {
   for (int i = 0; i < kNumTimedKernels; ++i) times_.ms[i] = 0.0;
   times_.count = 0;
@@ -378,7 +377,7 @@ void Solver::time_end(int stage) {
 void Solver::basic_scheme(const double* E6, double* src, double* dst) {
   if (!src) src = eps_;
   if (!dst) dst = eps_;
-  if (nranks_ != 1) throw std::runtime_error("basic_scheme: slab solvers are driven phase by phase (fg_slab_phase)");
+  if (nranks_ != 1) throw std::runtime_error("basic_scheme: slab solvers run under the slab driver (fg_slab.hip)");
   if (pt_.n < 1) throw std::runtime_error("No materials specified");
   if (opt_.mixing == kMixLaminate && !normals_) throw std::runtime_error("laminate mixing needs interface normals");
   FieldPtrs<kMaxPhases> phi;
@@ -1341,162 +1340,6 @@ bool Solver::run_cg(const double* E0, const double* S0) {
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
   solve_time_ += now_seconds() - t_start;
   return failed;
-}
-
-// ------------------------------------------------------------------ slab-decomposed pass
-// One basicScheme pass of an x-slab, cut at the four exchange points.  Between the phases the
-// caller (fibergen_amd/distributed.py) moves the named buffers between ranks:
-//   after phase 0 and 3: halo planes   halo_send_hi -> right neighbour's halo_recv_lo,
-//                                       halo_send_lo -> left  neighbour's halo_recv_hi
-//   after phase 1 and 2: all-to-all    block q of a2a_send -> rank q's block <my rank> of a2a_recv
-// a2a_send / a2a_recv alias tau components 0-2 / 3-5 (tau is dead once the divergence is taken).
-void Solver::slab_phase(int phase, const double* E6, const double* R6) {
-  FG_HIP_CHECK(hipSetDevice(device_));
-  u_valid_ = false;
-  if (pt_.n < 1) throw std::runtime_error("No materials specified");
-  if (opt_.mixing == kMixLaminate && !normals_) throw std::runtime_error("laminate mixing needs interface normals");
-  const long plane = g_.nyzp;
-  const long last = (long)(g_.nx - 1) * g_.nyzp;
-  double* a2a_send = tau_;
-  double* a2a_recv = tau_ + 3 * g_.n;
-  double *send_lo = halo_[0], *send_hi = halo_[1], *recv_lo = halo_[2], *recv_hi = halo_[3];
-  const double alpha = -1.0;
-  switch (phase) {
-    case 0: {  // polarisation; halo of tau for the divergence
-      FieldPtrs<kMaxPhases> phi;
-      for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
-      FieldPtrs<3> nrm;
-      for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
-      launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
-      launch_copy(tau_ + 0 * g_.n + last, send_hi, plane, stream_);          // tau0, my last plane  -> right (x-1 there)
-      launch_copy(tau_ + 5 * g_.n, send_lo, plane, stream_);                 // tau5, my first plane -> left  (x+1 there)
-      launch_copy(tau_ + 4 * g_.n, send_lo + plane, plane, stream_);         // tau4
-      break;
-    }
-    case 1: {  // divergence, z and y transforms, pack for the slab -> pencil transpose
-      XHalo h = {{recv_lo, nullptr}, {recv_hi, recv_hi + plane}};
-      launch_div(g_, ptrs6(tau_), ptrs3(fu_), h, stream_);
-      fft_->r2c_z(fu_, 3, g_.n);
-      fft_->c2c_y(fu_, 3, g_.n, -1, 1.0);
-      launch_transpose_A(fu_, a2a_send, g_.nx, g_.ny, nyl_, g_.nzc, true, stream_);
-      break;
-    }
-    case 2: {  // x transform, Green operator and inverse x transform on the y-slab
-      launch_transpose_B(a2a_recv, fu_, nxg_, g_.nx, nyl_, g_.nzc, false, stream_);
-      const long cs = (long)nyl_ * nxg_ * g_.nzp;
-      const double scale = 1 / (double)nglobal_;
-      const double c10 = -alpha / (opt_.mu_0);
-      const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
-      if (opt_.fuse_x && nxg_ > 1 && fft_t_->can_fuse(1)) {
-        // the single-GPU loop's fused pass on the y-slab: x is the middle axis here, ky = rank*nyl + outer index
-        G0Params gp;
-        gp.c10 = c10;
-        gp.c20 = c20;
-        gp.inv_h0 = 2.0 * nxg_ / g_.dx;
-        for (int a = 0; a < 3; ++a) {
-          gp.kpm[a] = g0_kpm_[a];
-          gp.kp[a] = g0_kp_[a];
-        }
-        fft_t_->fused_g0(fu_, cs, 1, scale, gp, rank_ * nyl_);
-        launch_transpose_B(fu_, a2a_send, nxg_, g_.nx, nyl_, g_.nzc, true, stream_);
-        break;
-      }
-      if (nxg_ > 1) fft_t_->c2c_y(fu_, 3, cs, -1, scale);
-      else fft_t_->scale(fu_, 3, cs, scale);
-      G0Tables tb;
-      for (int a = 0; a < 3; ++a) {
-        tb.kpm[a] = g0_kpm_[a];
-        tb.kp[a] = g0_kp_[a];
-      }
-      Grid gg = g_;
-      gg.nx = nxg_;
-      FieldPtrs<3> f3;
-      for (int c = 0; c < 3; ++c) f3.p[c] = fu_ + c * cs;
-      launch_g0(gg, f3, tb, c10, c20, G0Layout{1, nyl_, rank_ * nyl_}, stream_);
-      if (nxg_ > 1) fft_t_->c2c_y(fu_, 3, cs, +1, 1.0);
-      launch_transpose_B(fu_, a2a_send, nxg_, g_.nx, nyl_, g_.nzc, true, stream_);
-      break;
-    }
-    case 3: {  // back on the x-slab: inverse y and z transforms; halo of u for the strain operator
-      launch_transpose_A(a2a_recv, fu_, g_.nx, g_.ny, nyl_, g_.nzc, false, stream_);
-      fft_->c2c_y(fu_, 3, g_.n, +1, 1.0);
-      fft_->c2r_z(fu_, 3, g_.n);
-      launch_copy(fu_ + 1 * g_.n + last, send_hi, plane, stream_);           // u1, my last plane  -> right
-      launch_copy(fu_ + 2 * g_.n + last, send_hi + plane, plane, stream_);   // u2
-      launch_copy(fu_ + 0 * g_.n, send_lo, plane, stream_);                  // u0, my first plane -> left
-      break;
-    }
-    case 4: {  // strain + local sums of squares
-      XHalo h = {{recv_lo, recv_lo + plane}, {recv_hi, nullptr}};
-      Vec6 E, R;
-      bool add_R = false;
-      for (int c = 0; c < 6; ++c) {
-        E.v[c] = E6 ? E6[c] : 0.0;
-        R.v[c] = R6 ? R6[c] : 0.0;
-        if (R.v[c] != 0.0) add_R = true;
-      }
-      launch_eps_norm(g_, ptrs3(fu_), ptrs6(eps_), E, R, add_R, partial_, dscal_ + kSlotSumSq, h, stream_);
-      FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-      check_device_error("stress");
-      for (int c = 0; c < 6; ++c) sumsq_[c] = hscal_[kSlotSumSq + c];
-      break;
-    }
-    default:
-      throw std::runtime_error("unknown slab phase");
-  }
-}
-
-double* Solver::exchange_buffer(const std::string& name, size_t* bytes) {
-  const size_t plane2 = 2 * (size_t)g_.nyzp * sizeof(double);
-  const size_t a2a = 3 * (size_t)g_.n * sizeof(double);
-  if (name == "halo_send_lo") { *bytes = plane2; return halo_[0]; }
-  if (name == "halo_send_hi") { *bytes = plane2; return halo_[1]; }
-  if (name == "halo_recv_lo") { *bytes = plane2; return halo_[2]; }
-  if (name == "halo_recv_hi") { *bytes = plane2; return halo_[3]; }
-  if (name == "a2a_send") { *bytes = a2a; return tau_; }
-  if (name == "a2a_recv") { *bytes = a2a; return tau_ + 3 * g_.n; }
-  throw std::runtime_error("unknown exchange buffer '" + name + "'");
-}
-
-// Local (this slab's) contributions to the global reductions of the loop; the caller adds / min-maxes
-// them over ranks in rank order.
-void Solver::local_sums(const std::string& what, double* out) {
-  FG_HIP_CHECK(hipSetDevice(device_));
-  ensure_eps();
-  FieldPtrs<kMaxPhases> phi;
-  for (int q = 0; q < kMaxPhases; ++q) phi.p[q] = q < pt_.n ? phi_ + (long)q * g_.n : nullptr;
-  FieldPtrs<3> nrm;
-  for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
-  int n = 6, slot = kSlotMean;
-  if (what == "sumsq") {
-    for (int c = 0; c < 6; ++c) out[c] = sumsq_[c];
-    return;
-  } else if (what == "epsilon") {
-    launch_sum6(g_, ptrs6(eps_), false, partial_, dscal_ + kSlotMean, stream_);
-  } else if (what == "tau") {
-    launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);
-  } else if (what == "stress") {  // sum of PK1(eps)/N_global over the slab  (meanPK1  F:12312-12351)
-    if (pt_.n < 1) throw std::runtime_error("No materials specified");
-    launch_stress_mean(g_, stress_params(0.0, 0.0, 1.0 / (double)nglobal_), ptrs6(eps_), phi, nrm, partial_,
-                       dscal_ + kSlotMean, derr_, stream_);
-  } else if (what == "tangent_minmax") {
-    if (pt_.n < 1) throw std::runtime_error("No materials specified");
-    launch_tangent_minmax(g_, phase_table(), opt_.mixing, phi, partial_, dscal_ + kSlotMinMax, derr_, stream_);
-    n = 2;
-    slot = kSlotMinMax;
-  } else if (what.rfind("phi:", 0) == 0) {
-    const int p = std::stoi(what.substr(4));
-    if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
-    launch_sum1(g_, phi_ + (long)p * g_.n, partial_, dscal_ + kSlotMisc, stream_);
-    n = 1;
-    slot = kSlotMisc;
-  } else {
-    throw std::runtime_error("unknown local sum '" + what + "'");
-  }
-  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + slot, dscal_ + slot, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
-  check_device_error(what.c_str());
-  for (int c = 0; c < n; ++c) out[c] = hscal_[slot + c];
-  if (what == "tangent_minmax") out[1] = -out[1];  // stored as (min, -max)
 }
 
 // ------------------------------------------------------------------ stages and fields

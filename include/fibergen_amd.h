@@ -81,7 +81,9 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * displacement, fast kernels; 1 = the same with the reference's operation order, iterates bit-identical to 0; 0 = the
  * strain field is the state, one kernel per reference routine where fuse_* are 0 too),
  * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (rows per workgroup of
- * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled), fuse_z (untiled sweep with the z transform attached). */
+ * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled), fuse_z (untiled sweep with the z transform attached),
+ * slab_split (slab driver: 1 = one all-to-all per component, overlapping the transforms of the next component; 0 = one
+ * exchange for the three components; -1 = by slab size, default). */
 int fg_set_option_d(fg_solver* s, const char* key, double value);
 int fg_set_option_i(fg_solver* s, const char* key, long value);
 
@@ -131,7 +133,8 @@ int fg_synchronize(fg_solver* s);
  * E6[0] carries alpha (default -1).  With timing enabled every kernel of a pass is bracketed
  * by HIP events on the solver stream; fg_get_stage_times reports the accumulated milliseconds
  * of the FG_NUM_TIMED_KERNELS kernels in launch order: stress, div, r2c_z, c2c_y_fwd,
- * c2c_x_fwd, g0, c2c_x_inv, c2c_y_inv, c2r_z, eps_norm, and the number of passes timed. */
+ * c2c_x_fwd, g0, c2c_x_inv, c2c_y_inv, c2r_z, eps_norm, and the number of passes timed.  Enabling (from disabled)
+ * resets the accumulators. */
 #define FG_NUM_TIMED_KERNELS 10
 int fg_run_stage(fg_solver* s, int stage, const double* E6);
 int fg_enable_stage_timing(fg_solver* s, int enable);
@@ -146,29 +149,10 @@ int fg_hbm_stream(int device, int megabytes, int reps, double* copy_GBps, double
  * The reference is single-process; this is the multi-GPU counterpart of one LSSolver.  Rank r
  * of nranks owns the x-planes [r*nx/nranks, (r+1)*nx/nranks) of every field (nx and ny must be
  * divisible by nranks); all arrays passed to / returned by the calls above then have the LOCAL
- * shape [ncomp][nx/nranks][ny][nz].  One pass of basicScheme is cut at its four exchange points:
- *
- *   fg_slab_phase(s,0)  polarisation                         -> halo exchange (tau)
- *   fg_slab_phase(s,1)  divergence, z- and y-FFT, pack       -> all-to-all
- *   fg_slab_phase(s,2)  x-FFT, Green operator, x-FFT^-1      -> all-to-all
- *   fg_slab_phase(s,3)  y- and z-FFT^-1                      -> halo exchange (u)
- *   fg_slab_phase(s,4)  strain operator (+E, +R), local sums of squares
- *
- * Halo exchange: "halo_send_hi" -> right neighbour's "halo_recv_lo", "halo_send_lo" -> left
- * neighbour's "halo_recv_hi" (periodic; 2 planes of [ny][2*(nz/2+1)] doubles each).
- * All-to-all: "a2a_send" holds nranks blocks [3][nx/P][ny/P][nz/2+1] complex, block q goes to
- * rank q; "a2a_recv" holds the blocks received, ordered by source rank.  The caller moves the
- * bytes (RCCL, driven by fibergen_amd/distributed.py); fg_exchange_buffer
- * returns device pointers.  fg_local_sums returns this slab's contribution to a global
- * reduction: "sumsq" (6, after phase 4), "epsilon" (6), "tau" (6), "stress" (6, already / N),
- * "tangent_minmax" (min, max), "phi:<p>" (1). */
+ * shape [ncomp][nx/nranks][ny][nz]. */
 fg_solver* fg_create_slab(int nx, int ny, int nz, double dx, double dy, double dz, int device, int rank, int nranks);
-int fg_slab_phase(fg_solver* s, int phase, const double* E6, const double* R6);
-void* fg_exchange_buffer(fg_solver* s, const char* name, unsigned long* bytes);
-int fg_local_sums(fg_solver* s, const char* what, double* out);
 
-/* ---- slab decomposition, driver below the ABI (round 2) -----------------------------------
- * The loop of a slab solver runs inside the library: the same entry points as for one GPU (fg_run_load_case,
+/* The loop of a slab solver runs inside the library: the same entry points as for one GPU (fg_run_load_case,
  * fg_iterate, fg_time_iterations, fg_mean_stress, fg_mean_strain, fg_volume_fraction, fg_calc_ref_material,
  * fg_get_field with LOCAL shapes) become collective calls once the solver is connected to a transport.  Per pass
  * (basicScheme F:20558-20578 with GammaOperatorStaggered F:20288-20300 cut along x):

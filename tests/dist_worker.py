@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--mixing", default="voigt")
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--mixed-bc", type=int, default=0)
+    ap.add_argument("--split", type=int, default=-1)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch  # noqa: F401  before the HIP library: one shared runtime
@@ -125,7 +126,7 @@ def main():
     for p in range(2):
         s.set_phase(p, mats[p][0], mats[p][1], s.slab(phis[p]))
     s.set_normals(s.slab(normals))
-    s.set_options(mixing_rule=a.mixing, tol=a.tol)
+    s.set_options(mixing_rule=a.mixing, tol=a.tol, slab_split=a.split)
     E = np.array([1.0, 0, 0, 0, 0, 0.5])
     S = None
     if a.mixed_bc:

@@ -11,16 +11,18 @@ from test_distributed_cpu import launch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("nproc,grid,mixing", [
-    (2, "8,16,128", "voigt"),        # displacement loop (tiled sweep with halo planes)
-    (2, "16,16,16", "voigt"),        # strain-state pipeline
-    (2, "32,16,64", "laminate"),
-    (4, "16,8,16", "voigt"),
-    (2, "12,10,6", "laminate"),
+@pytest.mark.parametrize("nproc,grid,mixing,split", [
+    (2, "8,16,128", "voigt", 1),     # displacement loop (tiled sweep with halo planes), all-to-all per component
+    (2, "8,16,128", "voigt", 0),     # ... one exchange for the three components
+    (2, "16,16,16", "voigt", 1),     # strain-state pipeline
+    (2, "32,16,64", "laminate", 0),
+    (4, "16,8,16", "voigt", 1),
+    (2, "12,10,6", "laminate", 1),
 ])
-def test_hip_slabs_match_oracle(tmp_path, nproc, grid, mixing):
+def test_hip_slabs_match_oracle(tmp_path, nproc, grid, mixing, split):
     g = tuple(int(v) for v in grid.split(","))
-    res = launch(nproc, str(tmp_path / "r"), "--backend", "hip", "--grid", grid, "--mixing", mixing, "--dims", "1,2,1.5")
+    res = launch(nproc, str(tmp_path / "r"), "--backend", "hip", "--grid", grid, "--mixing", mixing, "--dims", "1,2,1.5",
+                 "--split", str(split))
     o = make_oracle(g, (1.0, 2.0, 1.5), mixing, tol=1e-8)
     assert o.run([1.0, 0, 0, 0, 0, 0.5]) is False
     eps = np.concatenate([r["eps"] for r in res], axis=1)

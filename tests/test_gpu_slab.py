@@ -42,10 +42,11 @@ EXACT = [  # strain-state pipeline: laminate mixing, small / odd / mixed-radix g
 ]
 
 
+@pytest.mark.parametrize("split", [0, 1])   # one exchange for the three components / one per component (overlap)
 @pytest.mark.parametrize("P,grid,mixing", FAST + EXACT)
-def test_group_run_matches_oracle(P, grid, mixing):
+def test_group_run_matches_oracle(P, grid, mixing, split):
     dims = (1.0, 2.0, 1.5)
-    g = make_group(P, grid, dims, mixing, tol=1e-8)
+    g = make_group(P, grid, dims, mixing, tol=1e-8, slab_split=split)
     o = make_oracle(grid, dims, mixing, tol=1e-8)
     assert o.run(E_LOAD) is False
     assert g.run(E_LOAD) is False
