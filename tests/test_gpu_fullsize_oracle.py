@@ -1,0 +1,125 @@
+"""Oracle parity AT BASELINE.json's sizes on the benchmark workload itself (fibergen_amd.rve.bench_rve: the RVE
+bench.py times), through the C ABI.  The checker is oracle/c (CRef: the reference's loop nests in C/OpenMP + pocketfft,
+bit-identical per stage to the NumPy oracle, tests/test_c_oracle.py) because the NumPy oracle needs minutes per pass
+at these sizes.
+
+  256^3  Voigt and laminate: three passes from a non-trivial strain field -- pass 1 runs the strain-state pipeline,
+         passes 2-3 the default displacement loop (tiled sweep, fused x pass): eps <= 1e-11, sums of squares <= 1e-12
+  512^3  laminate (BASELINE config 3): two passes, the same bars (skipped when the host has too little memory)
+  128^3  (BASELINE config 2) converged runs at tol 1e-6, Voigt and laminate: iteration count equal, residual history,
+         the effective-stiffness column <S> <= 1e-9, strain field <= 1e-9
+"""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import INCLUSION, MATRIX, lame, rel_err
+
+pytestmark = pytest.mark.gpu
+
+E_LOAD = np.array([1.0, 0.0, 0.0, 0.0, 0.0, 0.5])
+DIMS = (1.0, 1.0, 1.0)
+
+
+def _workload(n, mixing):
+    from fibergen_amd.rve import bench_rve
+    phi, normals, _ = bench_rve(n, mixing)
+    return [lame(**MATRIX), lame(**INCLUSION)], [1.0 - phi, phi], normals
+
+
+def _gpu(n, mats, phis, normals, mixing, **kw):
+    from fibergen_amd import LSSolver
+    s = LSSolver(n, n, n)
+    s.set_num_phases(2)
+    for p in range(2):
+        s.set_phase(p, mats[p][0], mats[p][1], phis[p])
+    if normals is not None:
+        s.set_normals(normals)
+    s.set_options(mixing_rule=mixing, **kw)
+    return s
+
+
+def _cref(n, mats, phis, normals, mixing):
+    import os
+    from oracle.c_oracle import CRef
+    # 16 threads: the best point of the host's thread sweep (bench.py cpu_baseline); all 256 are 5x slower
+    return CRef((n, n, n), DIMS, mats, phis, normals, mixing, threads=min(16, os.cpu_count() or 1))
+
+
+def _start_field(n, phi):
+    """a deterministic, non-trivial strain field: the load plus phase- and position-dependent perturbations"""
+    x = (np.arange(n) + 0.5) / n
+    w = np.sin(2 * np.pi * x)[:, None, None] * np.cos(4 * np.pi * x)[None, :, None] + 0.5 * np.sin(6 * np.pi * x)[None, None, :]
+    eps = np.empty((6, n, n, n))
+    for c in range(6):
+        eps[c] = E_LOAD[c] + 0.05 * (c + 1) * phi + 0.02 * (6 - c) * w
+    return eps
+
+
+def _passes_against_cref(n, mixing, passes):
+    mats, phis, normals = _workload(n, mixing)
+    s = _gpu(n, mats, phis, normals, mixing)
+    mu_0, lam_0 = s.calc_ref_material()
+    # closed form of calcRefMaterial for isotropic phases with phi covering [0, 1]  (F:22283-22313, F:12763-12771):
+    # tangent eigenvalues {2 mu, 2 mu + 3 lambda} of the mixture, extremes at the pure phases
+    eig = [v for mu, lam in mats for v in (2 * mu, 2 * mu + 3 * lam)]
+    assert mu_0 == pytest.approx(0.25 * (min(eig) + max(eig)), rel=1e-14) and lam_0 == 0.0
+    eps0 = _start_field(n, phis[1])
+    s.set_field("epsilon", eps0)
+    s.iterate(E_LOAD, passes)            # pass 1: strain-state pipeline; then the displacement loop
+    got = s.get_field("epsilon")
+    sumsq = s.get_field("sumsq")          # norm sweep of the last displacement pass: belongs to eps_{passes-1}
+    s.close()
+    c = _cref(n, mats, phis, normals, mixing)
+    eps = eps0
+    prev = None
+    for _ in range(passes):
+        prev = eps
+        eps = c.basic_scheme(E_LOAD, eps, mu_0, lam_0)
+    assert rel_err(got, eps) < 1e-11
+    want_sumsq = (c.component_norm(prev) ** 2) * float(n) ** 3
+    assert np.abs(sumsq / want_sumsq - 1).max() < 1e-12
+
+
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_bench_workload_256_three_passes(mixing):
+    _passes_against_cref(256, mixing, 3)
+
+
+def test_bench_workload_512_laminate_two_passes():
+    psutil = pytest.importorskip("psutil")
+    if psutil.virtual_memory().available < 96 * 2 ** 30:
+        pytest.skip("needs ~64 GB of free host memory for the 512^3 checker")
+    _passes_against_cref(512, "laminate", 2)
+
+
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_config2_converged_run_128(mixing):
+    """BASELINE config 2: 128^3 fibre RVE, tol 1e-6 -- LSSolver::run on the GPU against the same loop on the checker
+    (runBasic F:21716-21805 with the stop rule of _converged F:21177-21244; pure strain BC, so bc_error = 0)."""
+    n = 128
+    mats, phis, normals = _workload(n, mixing)
+    s = _gpu(n, mats, phis, normals, mixing, tol=1e-6)
+    assert s.run(E_LOAD) is False
+    mu_0, lam_0 = s.ref_material
+    c = _cref(n, mats, phis, normals, mixing)
+    eps = np.zeros((6, n, n, n))
+    prev, it, residuals = 0.0, 1, []
+    tiny = np.finfo(float).tiny
+    while True:
+        eps = c.basic_scheme(E_LOAD, eps, mu_0, lam_0)
+        m = c.component_norm(eps)
+        cur = math.sqrt(float((m * m).sum() + (m[3:] * m[3:]).sum()))   # 9 mirrored entries  F:14600-14609
+        abs_err = abs(prev - cur)
+        rel = abs_err / (tiny + cur)
+        prev = cur
+        residuals.append(rel)
+        if rel <= 1e-6 or abs_err <= np.finfo(float).eps or it >= 10000:
+            break
+        it += 1
+    assert s.iterations == it
+    assert np.abs(np.array(s.residuals) - np.array(residuals)).max() < 1e-11
+    assert rel_err(s.get_field("epsilon"), eps) < 1e-9
+    assert rel_err(s.mean_stress(), c.mean_stress(eps)) < 1e-9       # the Ceff column of this load case
+    s.close()
