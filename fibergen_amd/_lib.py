@@ -85,7 +85,7 @@ SIGNATURES = {
     "fg_voxelize": (ctypes.c_int, [ctypes.POINTER(FgFiber), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_double, ctypes.c_double, ctypes.c_double, c_double_p, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p, c_double_p,
-                                   ctypes.c_char_p, ctypes.c_int]),
+                                   ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
 }
 
 _lib = None

@@ -1,6 +1,6 @@
 """Geometry pre-processing of the project layer: shapes placed with <place_fiber> ->
-phase volume fractions + interface normals, through the native voxeliser fg_voxelize
-(host C++/OpenMP, fibergen_amd/csrc/fg_geometry.cpp)."""
+phase volume fractions + interface normals, through the GPU voxeliser fg_voxelize
+(fibergen_amd/csrc/fg_voxelize.hip).  No CPU fallback: without a GPU it fails loudly."""
 from __future__ import annotations
 
 import ctypes
@@ -12,7 +12,8 @@ from . import _lib
 KINDS = {"capsule": 0, "halfspace": 1}
 
 
-def voxelize(fibers, shape, dims, x0, nphases, matrix_mat, want_normals=False, smooth_levels=-1, smooth_tol=1e-3):
+def voxelize(fibers, shape, dims, x0, nphases, matrix_mat, want_normals=False, smooth_levels=-1, smooth_tol=1e-3,
+             device=0):
     """Returns (phi[nphases,nx,ny,nz] before normalisation, normals[3,...] or None, {material: real volume fraction})."""
     lib = _lib.load()
     nx, ny, nz = shape
@@ -34,7 +35,7 @@ def voxelize(fibers, shape, dims, x0, nphases, matrix_mat, want_normals=False, s
                          x0a.ctypes.data_as(_lib.c_double_p), nphases, int(matrix_mat), int(smooth_levels),
                          float(smooth_tol), phi.ctypes.data_as(_lib.c_double_p),
                          normals.ctypes.data_as(_lib.c_double_p) if normals is not None else None,
-                         real.ctypes.data_as(_lib.c_double_p), err, 512)
+                         real.ctypes.data_as(_lib.c_double_p), int(device), err, 512)
     if rc != 0:
         raise RuntimeError(err.value.decode())
     vol = float(dims[0]) * float(dims[1]) * float(dims[2])

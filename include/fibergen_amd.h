@@ -217,7 +217,7 @@ typedef struct fg_plan_op {
 int fg_slab_plan(int nx, int ny, int nz, int nranks, int rank, int what, int comp, fg_plan_op* ops, int capacity,
                  fg_plan_op* self_copy);
 
-/* ---- geometry pre-processing (host side, no GPU needed) ------------------------------
+/* ---- geometry pre-processing (kernels on HIP device `device`) ------------------------
  * Analytic shapes placed with <place_fiber> (F:25788-25822) -> phase volume fractions and
  * interface normals: LSSolver::initPhi F:17489-17581 (adaptive sub-voxel integration,
  * integratePhiVoxel F:16622-16752, plane cuts F:1385-1577) and the NORMALS sampling
@@ -236,7 +236,7 @@ typedef struct fg_fiber {
 
 int fg_voxelize(const fg_fiber* fibers, int nfibers, int nx, int ny, int nz, double dx, double dy, double dz,
                 const double* x0, int nphases, int matrix_mat, int smooth_levels, double smooth_tol,
-                double* phi, double* normals, double* real_volume, char* err, int errlen);
+                double* phi, double* normals, double* real_volume, int device, char* err, int errlen);
 
 #ifdef __cplusplus
 }

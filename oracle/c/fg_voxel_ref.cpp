@@ -1,7 +1,6 @@
-// Host-side voxeliser: analytic shapes -> phase volume fractions and interface normals.
-//
-// Pre-processing that runs once per project (not part of the per-iteration hot path),
-// kept native like the reference's.  Restates, for the shapes the elasticity demos use
+// CHECKER of the voxeliser (test infrastructure only: nothing under fibergen_amd/ links or calls this; the product is
+// the GPU voxeliser fibergen_amd/csrc/fg_voxelize.hip).  Analytic shapes -> phase volume fractions and interface
+// normals, restating the reference's recursive algorithm routine by routine, for the shapes the elasticity demos use
 // (capsule / sphere and half space placed with <place_fiber>):
 //   LSSolver::initPhi               F:17489-17581   one closest-shape query per voxel centre
 //   LSSolver::integratePhiVoxel     F:16622-16752   adaptive octree refinement + plane cuts
@@ -18,7 +17,20 @@
 #include <string>
 #include <vector>
 
-#include "../../include/fibergen_amd.h"
+
+// the C ABI's fibre description (include/fibergen_amd.h), repeated so that the checker builds on its own
+extern "C" {
+typedef struct ref_fiber {
+  int kind;
+  int material;
+  double c[3];
+  double a[3];
+  double L;
+  double R;
+} ref_fiber;
+}
+#define FG_OK 0
+#define FG_ERROR 1
 
 namespace {
 
@@ -239,22 +251,22 @@ double integrate_voxel(int levels, double tol, double r_voxel0, V3 p, double dx,
 
 }  // namespace
 
-extern "C" int fg_voxelize(const fg_fiber* fibers, int nfibers, int nx, int ny, int nz, double dx, double dy, double dz,
+extern "C" int ref_voxelize(const ref_fiber* fibers, int nfibers, int nx, int ny, int nz, double dx, double dy, double dz,
                            const double* x0, int nphases, int matrix_mat, int smooth_levels, double smooth_tol,
                            double* phi, double* normals, double* real_volume, char* err, int errlen) {
   auto fail = [&](const std::string& m) {
     if (err && errlen > 0) std::snprintf(err, errlen, "%s", m.c_str());
     return FG_ERROR;
   };
-  if (nx < 1 || ny < 1 || nz < 1 || nphases < 1 || !phi || !x0) return fail("fg_voxelize: bad arguments");
-  if (nfibers > 0 && !fibers) return fail("fg_voxelize: fibers is NULL");
+  if (nx < 1 || ny < 1 || nz < 1 || nphases < 1 || !phi || !x0) return fail("ref_voxelize: bad arguments");
+  if (nfibers > 0 && !fibers) return fail("ref_voxelize: fibers is NULL");
   std::vector<Shape> shapes(nfibers);
   for (int i = 0; i < nfibers; ++i) {
-    const fg_fiber& f = fibers[i];
+    const ref_fiber& f = fibers[i];
     Shape& s = shapes[i];
     s.kind = f.kind;
     s.material = f.material;
-    if (f.material < 0 || f.material >= nphases) return fail("fg_voxelize: fiber material out of range");
+    if (f.material < 0 || f.material >= nphases) return fail("ref_voxelize: fiber material out of range");
     const V3 c = mk(f.c[0], f.c[1], f.c[2]);
     const V3 a = mk(f.a[0], f.a[1], f.a[2]);
     const double na = norm(a);

@@ -6,7 +6,7 @@ import math
 import numpy as np
 import pytest
 
-from fibergen_amd import geometry, materials
+from fibergen_amd import materials
 from fibergen_amd.fg import FG, _Fiber, _normalize_phi
 from fibergen_amd.xmlproject import XMLProject
 from oracle.ls_oracle import material_from_pair
@@ -114,41 +114,6 @@ def test_normalize_phi_last_material_wins():
     assert np.allclose(out[1], [0, 0.6, 0.5, 0.1])
     assert np.allclose(out[0], [1, 0.4, 0, 0])
     assert np.allclose(out.sum(axis=0), 1)
-
-
-def test_voxeliser_sphere_capsule_halfspace():
-    sph = [_Fiber("capsule", [.5, .5, .5], [1, 0, 0], 0.0, 0.3, 1)]
-    phi, nrm, real = geometry.voxelize(sph, (32, 32, 32), (1, 1, 1), (0, 0, 0), 2, 0, want_normals=True)
-    exact = 4 / 3 * math.pi * 0.3 ** 3
-    assert phi[0].min() == 1.0                      # matrix: all ones before normalisation
-    assert abs(phi[1].mean() - exact) / exact < 5e-4
-    assert real[1] == pytest.approx(exact, rel=1e-14)
-    assert ((phi[1] >= 0) & (phi[1] <= 1)).all()
-    # normals: unit, pointing out of the inclusion (F:5286-5294)
-    assert np.allclose((nrm * nrm).sum(axis=0), 1.0)
-    assert nrm[0, 31, 16, 16] > 0.99 and nrm[0, 0, 16, 16] < -0.99
-    # symmetric under the cube group
-    assert np.allclose(phi[1], phi[1][::-1]) and np.allclose(phi[1], phi[1].transpose(1, 0, 2))
-    # capsule: total length L, cylinder part L - 4/3 R (F:5256-5258): volume = pi R^2 L
-    cap = [_Fiber("capsule", [.5, .5, .5], [0, 0, 1], 0.6, 0.2, 1)]
-    phi, _, real = geometry.voxelize(cap, (32, 32, 32), (1, 1, 1), (0, 0, 0), 2, 0)
-    assert real[1] == pytest.approx(math.pi * 0.2 ** 2 * 0.6, rel=1e-13)
-    assert abs(phi[1].mean() - real[1]) / real[1] < 2e-3
-    # the three half spaces of demo/elasticity/laminate/project.xml:31-36
-    fib = [_Fiber("halfspace", [0.0, .5, .5], [1, 0, 0], 0, 0.25, 0),
-           _Fiber("halfspace", [0.2, .5, .5], [-1, 0, 0], 0, 0.25, 1),
-           _Fiber("halfspace", [0.5, .5, .5], [-1, 0, 0], 0, 0.25, 2)]
-    phi, _, _ = geometry.voxelize(fib, (10, 1, 1), (1, 1, 1), (0, 0, 0), 3, 0)
-    out = _normalize_phi(phi)[:, :, 0, 0]
-    assert np.allclose(out[0], [1, 1, 0, 0, 0, 0, 0, 0, 0, 0], atol=1e-15)
-    assert np.allclose(out[1], [0, 0, 1, 1, 1, 0, 0, 0, 0, 0], atol=1e-15)
-    assert np.allclose(out[2], [0, 0, 0, 0, 0, 1, 1, 1, 1, 1], atol=1e-15)
-    # a plane cutting voxels obliquely: exact volume fraction of the half space x+y < 1 is 1/2
-    obl = [_Fiber("halfspace", [.5, .5, .5], [1, 1, 0], 0, 0.25, 1)]
-    phi, _, _ = geometry.voxelize(obl, (8, 8, 2), (1, 1, 1), (0, 0, 0), 2, 0)
-    assert phi[1].mean() == pytest.approx(0.5, abs=1e-14)
-    with pytest.raises(RuntimeError, match="zero normal"):
-        geometry.voxelize([_Fiber("halfspace", [0, 0, 0], [0, 0, 0], 0, 0.1, 1)], (4, 4, 4), (1, 1, 1), (0, 0, 0), 2, 0)
 
 
 def test_unknown_settings_raise_like_reference(monkeypatch):
