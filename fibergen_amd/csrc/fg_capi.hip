@@ -239,8 +239,10 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
     else if (k == "u_tile") {
       if (value != 0 && value != 8 && value != 12 && value != 16) throw std::runtime_error("u_tile must be 0, 8, 12 or 16");
       o.u_tile = (int)value;
+      v.invalidate_interface_lists();
     }
     else if (k == "fuse_x") o.fuse_x = value != 0;
+    else if (k == "laminate_overlap") o.laminate_overlap = value != 0;
     else if (k == "slab_split") o.slab_split = value < 0 ? -1 : (value != 0);
     else if (k == "fuse_z") o.fuse_z = value < 0 ? -1 : (value != 0);
     else if (k == "u_loop") o.u_loop = (int)value;

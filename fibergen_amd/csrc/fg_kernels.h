@@ -104,6 +104,13 @@ unsigned launch_affected_list(const Grid& g, const unsigned* list, unsigned n, u
 void launch_laminate_delta(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
                            const FieldPtrs<3>& normals, const Vec6& E, const unsigned* list, unsigned n, double* dtau,
                            int* error_flag, hipStream_t s);
+// laminate correction in compact form (see k_interface_strain): static copies of the phase fractions [nph][n] and normals
+// [3][n] of the interface voxels (once per geometry), and per pass eps_j -> d_j (epsc: scratch [6][n], dtau: [n][6])
+void launch_interface_static(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& normals,
+                             const unsigned* list, unsigned n, double* phic, double* nrmc, hipStream_t s);
+void launch_interface_delta(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const Vec6& E, const unsigned* list,
+                            unsigned n, double* epsc, const double* phic, const double* nrmc, double* dtau, int* error_flag,
+                            hipStream_t s);
 void launch_sum_dtau(const double* dtau, unsigned n, double* partial, double* out6, hipStream_t s);
 void launch_delta_div(const Grid& g, const unsigned* aff, const int* slots, unsigned n, const double* dtau,
                       const FieldPtrs<3>& f, hipStream_t s);

@@ -963,6 +963,65 @@ __global__ __launch_bounds__(kBlock) void k_laminate_delta(Grid g, StressParams 
   }
 }
 
+// ---- laminate correction, compact form ---------------------------------------------------------------------------------
+// d_j = tau_laminate - tau_voigt of the interface voxels in two kernels instead of k_laminate_delta's one:
+//   k_interface_strain  eps_j from u by the strain stencil -- a light gather kernel at full occupancy (the scattered loads
+//                       are what costs), compact SoA [6][n] in list order;
+//   k_interface_solve   d_j from eps_j, the phase fractions and the normal, all compact and coalesced (static copies made
+//                       once per geometry by k_interface_static): the one-step Newton solve of laminate_split, 190 VGPRs,
+//                       no scattered loads.
+// 512^3, 3.3 M interface voxels: 0.60 ms -> 0.26 + 0.11 ms.  Measured and rejected: d added to the polarisation
+// inside the tiled sweep before its neighbour exchange (the dependent gather of d stalls the barrier-locked march: sweep
+// 1.85 -> 2.67 ms against 0.53 ms for k_delta_div), and the sweep emitting eps_j itself (mask load + scattered stores:
+// sweep 1.85 -> 2.41 ms against 0.26 ms for k_interface_strain).
+__global__ __launch_bounds__(kBlock) void k_interface_static(Grid g, int nph, FieldPtrs<kMaxPhases> phi, FieldPtrs<3> normals,
+                                                             const unsigned* list, unsigned n, double* phic, double* nrmc) {
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const long off = list[idx];
+    for (int q = 0; q < nph; ++q) phic[(long)q * n + idx] = phi.p[q][off];
+    for (int c = 0; c < 3; ++c) nrmc[(long)c * n + idx] = normals.p[c][off];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_interface_strain(Grid g, FieldPtrs<3> u, Vec6 E, const unsigned* list, unsigned n,
+                                                             double* epsc) {
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const long off = list[idx];
+    const long row = off / g.nzp;
+    const int k = (int)(off - row * g.nzp);
+    const int i = (int)(row / g.ny), j = (int)(row - (long)i * g.ny);
+    const VoxelNeighbours nb = voxel_neighbours(g, i, j, k);
+    const double u0 = u.p[0][off], u1 = u.p[1][off], u2 = u.p[2][off];
+    // epsOperatorStaggered  F:18632-18686 for one voxel
+    epsc[3L * n + idx] = E.v[3] + 0.5 * ((u2 - u.p[2][off + nb.yb]) * hy + (u1 - u.p[1][off + nb.zb]) * hz);
+    epsc[4L * n + idx] = E.v[4] + 0.5 * ((u2 - u.p[2][off + nb.xb]) * hx + (u0 - u.p[0][off + nb.zb]) * hz);
+    epsc[5L * n + idx] = E.v[5] + 0.5 * ((u1 - u.p[1][off + nb.xb]) * hx + (u0 - u.p[0][off + nb.yb]) * hy);
+    epsc[0L * n + idx] = E.v[0] + (u.p[0][off + nb.xf] - u0) * hx;
+    epsc[1L * n + idx] = E.v[1] + (u.p[1][off + nb.yf] - u1) * hy;
+    epsc[2L * n + idx] = E.v[2] + (u.p[2][off + nb.zf] - u2) * hz;
+  }
+}
+
+template <int NPH>
+__global__ __launch_bounds__(kBlock) void k_interface_solve(StressParams sp, const double* epsc, const double* phic,
+                                                            const double* nrmc, unsigned n, double* dtau, int* error_flag) {
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    double F[6], ph[NPH], nv[3], Pl[6], Pv[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) F[c] = epsc[(long)c * n + idx];
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) ph[q] = q < sp.pt.n ? phic[(long)q * n + idx] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nv[c] = nrmc[(long)c * n + idx];
+    // the reference-medium part of the polarisation is the same in both and cancels
+    if (pk1_laminate<NPH>(F, ph, nv, sp.pt, sp.alpha, false, sp.eps_g, sp.eps_a, Pl)) atomicOr(error_flag, 1);
+    pk1_voigt<NPH>(F, ph, sp.pt, sp.alpha, false, Pv);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) dtau[(long)idx * 6 + c] = Pl[c] - Pv[c];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_delta_div(Grid g, const unsigned* aff, const int* slots, unsigned n,
                                                       const double* dtau, FieldPtrs<3> f) {
   const double hx = g.hx, hy = g.hy, hz = g.hz;
@@ -1424,6 +1483,25 @@ unsigned launch_affected_list(const Grid& g, const unsigned* list, unsigned n, u
   FG_HIP_CHECK(hipFree(map));
   FG_HIP_CHECK(hipFree(counts));
   return m;
+}
+
+void launch_interface_static(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& normals,
+                             const unsigned* list, unsigned n, double* phic, double* nrmc, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_interface_static, dim3(grid_for((long)n, 1 << 16)), dim3(kBlock), 0, s, g, nph, phi, normals, list, n, phic,
+                     nrmc);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_interface_delta(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const Vec6& E, const unsigned* list,
+                            unsigned n, double* epsc, const double* phic, const double* nrmc, double* dtau, int* error_flag,
+                            hipStream_t s) {
+  if (n == 0) return;
+  const dim3 grid(grid_for((long)n, 1 << 16));
+  hipLaunchKernelGGL(k_interface_strain, grid, dim3(kBlock), 0, s, g, u, E, list, n, epsc);
+  if (sp.pt.n <= 2) hipLaunchKernelGGL((k_interface_solve<2>), grid, dim3(kBlock), 0, s, sp, epsc, phic, nrmc, n, dtau, error_flag);
+  else hipLaunchKernelGGL((k_interface_solve<kMaxPhases>), grid, dim3(kBlock), 0, s, sp, epsc, phic, nrmc, n, dtau, error_flag);
+  FG_HIP_CHECK(hipGetLastError());
 }
 
 void launch_laminate_delta(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,

@@ -60,6 +60,7 @@ struct SolverOptions {
   int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
   int u_tile = 8;               // fast displacement sweep (u_loop = 2) as the LDS-tiled marching kernel where the grid allows:
                                 // rows per workgroup (8, 12, 16), 0 = off.  512^3: 2.8 -> 1.95 ms per sweep
+  int laminate_overlap = 1;     // displacement loop with laminate mixing: interface kernels on a second stream beside the sweep
   int slab_split = -1;          // slab driver: all-to-all per component, overlapping the next component's transforms (1), one
                                 // exchange for the three components (0), or by slab size (-1)
   int fuse_z = 0;               // attach the z r2c transform to the untiled fast sweep (u_tile = 0): 1 on, 0 off, -1 by size
@@ -99,6 +100,7 @@ class Solver {
   const Grid& grid() const { return g_; }
   SolverOptions& options() { return opt_; }
   void invalidate_moduli() { mod_dirty_ = smod_dirty_ = true; }
+  void invalidate_interface_lists() { mixed_dirty_ = true; }   // which lists exist depends on u_tile
   void reference_material_changed() { recompute_bc(); }   // (mu_0, lambda_0) set from outside: M, MQ depend on C0
   hipStream_t stream() const { return stream_; }
   int device() const { return device_; }
@@ -248,6 +250,8 @@ class Solver {
   int* aff_slots_ = nullptr;        // 8 per entry: interface-list index of self, x-1, x+1, y-1, y+1, z-1, z+1 (or -1)
   unsigned aff_n_ = 0;
   double* dtau_ = nullptr;          // [mixed_n_][6] tau_laminate - tau_voigt of the current pass
+  // compact static copies for the interface solve (phase fractions [nph][n], normals [3][n]) and its strain scratch [6][n]
+  double *lam_phic_ = nullptr, *lam_nrmc_ = nullptr, *lam_epsc_ = nullptr;
   double* mod_ = nullptr;      // 2: per-voxel effective moduli (sum phi 2 mu, sum phi lambda) of the fast sweep
   bool mod_dirty_ = true;
   double* fu_alt_ = nullptr;   // 3: second f/u buffer of the displacement-based loop (swapped with fu_)
@@ -284,6 +288,8 @@ class Solver {
   StageTimes times_;
   hipEvent_t ev_[2];
   hipEvent_t ev_copy_;
+  hipStream_t aux_stream_ = nullptr;    // second stream of the laminate correction (created on first use) + fork / join events
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   bool pending_back_ = false;  // run(): the sweep of this pass is enqueued, its FFT chain not yet
   bool back_ready_ = false;    // the FFT chain is enqueued (fu_alt_ will hold u_{k+1}) but not adopted
 };

@@ -136,6 +136,8 @@ Solver::~Solver() {
   fft_.reset();
   for (int k = 0; k < 4; ++k)
     if (halo_[k]) (void)hipFree(halo_[k]);
+  for (void* p : {(void*)lam_phic_, (void*)lam_nrmc_, (void*)lam_epsc_})
+    if (p) (void)hipFree(p);
   if (mixed_list_) (void)hipFree(mixed_list_);
   if (aff_list_) (void)hipFree(aff_list_);
   if (aff_slots_) (void)hipFree(aff_slots_);
@@ -154,6 +156,12 @@ Solver::~Solver() {
   (void)hipEventDestroy(ev_[0]);
   (void)hipEventDestroy(ev_[1]);
   (void)hipEventDestroy(ev_copy_);
+  if (aux_stream_) {
+    (void)hipStreamSynchronize(aux_stream_);
+    (void)hipStreamDestroy(aux_stream_);
+    (void)hipEventDestroy(ev_fork_);
+    (void)hipEventDestroy(ev_join_);
+  }
   comm_.reset();
   fft_ys_.reset();
   for (double* b : {su_[0], su_[1], smod_})
@@ -199,6 +207,7 @@ void Solver::set_phase_field(int p, const double* phi_host) {
 
 void Solver::set_normals(const double* n_host) {
   FG_HIP_CHECK(hipSetDevice(device_));
+  mixed_dirty_ = true;   // the interface lists carry compact copies of the normals
   if (!normals_) {
     FG_HIP_CHECK(hipMalloc(&normals_, 3 * g_.n * sizeof(double)));
     FG_HIP_CHECK(hipMemsetAsync(normals_, 0, 3 * g_.n * sizeof(double), stream_));
@@ -710,9 +719,20 @@ void Solver::build_laminate_lists() {
   aff_slots_ = nullptr;
   dtau_ = nullptr;
   aff_n_ = 0;
+  for (void* p : {(void*)lam_phic_, (void*)lam_nrmc_, (void*)lam_epsc_})
+    if (p) FG_HIP_CHECK(hipFree(p));
+  lam_phic_ = lam_nrmc_ = lam_epsc_ = nullptr;
   mixed_n_ = launch_mixed_list(g_, pt_.n, phi, &mixed_list_, stream_);
   if (mixed_n_) {
     FG_HIP_CHECK(hipMalloc(&dtau_, (size_t)mixed_n_ * 6 * sizeof(double)));
+    // compact static copies for the interface solve (k_interface_solve) and its strain scratch
+    const size_t n = mixed_n_;
+    FG_HIP_CHECK(hipMalloc(&lam_phic_, n * pt_.n * sizeof(double)));
+    FG_HIP_CHECK(hipMalloc(&lam_nrmc_, n * 3 * sizeof(double)));
+    FG_HIP_CHECK(hipMalloc(&lam_epsc_, n * 6 * sizeof(double)));
+    FieldPtrs<3> nrm;
+    for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+    launch_interface_static(g_, pt_.n, phi, nrm, mixed_list_, mixed_n_, lam_phic_, lam_nrmc_, stream_);
     aff_n_ = launch_affected_list(g_, mixed_list_, mixed_n_, &aff_list_, &aff_slots_, stream_);
   }
   mixed_dirty_ = false;
@@ -754,12 +774,26 @@ void Solver::u_pass_front(const double* E6) {
     // fast variant: per-voxel effective moduli instead of the per-phase accumulation
     const FieldPtrs<2> mod = effective_moduli();
     const bool laminate = opt_.mixing != kMixVoigt;
+    if (laminate) {
+      build_laminate_lists();
+      if (opt_.laminate_overlap) {   // fork: u_k is complete, the previous pass is done with d
+        if (!aux_stream_) {
+          int lo = 0, hi = 0;
+          FG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = highest priority
+          FG_HIP_CHECK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, hi));
+          FG_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+          FG_HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        }
+        FG_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
+      }
+    }
     const bool want_z = !laminate && (opt_.fuse_z > 0 || (opt_.fuse_z < 0 && (long)g_.nx * g_.ny * g_.nz <= (1L << 22)));
     z_done_ = want_z && fft_->fast_z() && u_fast_z_supported(g_);
     if (opt_.u_tile && u_tile_supported(g_)) {
       z_done_ = false;
+      const bool sum_tau = !(frobenius(BC_MQ_) < kEps);   // mixed BC: sums of tau land in kSlotMean
       launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
-                    opt_.u_tile, stream_, !(frobenius(BC_MQ_) < kEps));   // mixed BC: sums of tau land in kSlotMean
+                    opt_.u_tile, stream_, sum_tau);
     } else if (z_done_)
       launch_u_fast_z(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
                       fft_->z_twiddles(), fft_->z_roots(), stream_);
@@ -768,11 +802,17 @@ void Solver::u_pass_front(const double* E6) {
     if (laminate) {
       // laminate mixing = the Voigt sweep over all voxels + the divergence of (tau_laminate - tau_voigt), which lives
       // on the interface voxels (lists built once per geometry, see k_laminate_delta)
-      build_laminate_lists();
       FieldPtrs<3> nrm;
       for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
-      launch_laminate_delta(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, E, mixed_list_, mixed_n_,
-                            dtau_, derr_, stream_);
+      // d depends on u only: its two kernels (a light gather, a short solve) run on a second stream beside the sweep
+      hipStream_t ds = opt_.laminate_overlap ? aux_stream_ : stream_;
+      if (ds != stream_) FG_HIP_CHECK(hipStreamWaitEvent(ds, ev_fork_, 0));
+      launch_interface_delta(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), E, mixed_list_, mixed_n_, lam_epsc_,
+                             lam_phic_, lam_nrmc_, dtau_, derr_, ds);
+      if (ds != stream_) {
+        FG_HIP_CHECK(hipEventRecord(ev_join_, ds));
+        FG_HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
+      }
       launch_delta_div(g_, aff_list_, aff_slots_, aff_n_, dtau_, ptrs3(fu_alt_), stream_);
       if (!(frobenius(BC_MQ_) < kEps))   // mixed BC: <tau_laminate> = <tau_voigt> (from the sweep) + sum of the differences / N
         launch_sum_dtau(dtau_, mixed_n_, partial_, dscal_ + kSlotScratch, stream_);

@@ -97,7 +97,7 @@ class LSSolver:
                     raise RuntimeError("mode '%s' is not available on the MI355X path" % v)
                 self.scalar = v in ("heat", "porous")
                 self._check(self._lib.fg_set_option_i(self._h, b"mode", {"elasticity": 0, "viscosity": 2}.get(v, 1)))
-            elif k in ("u_loop", "fuse_x", "fuse_z", "fuse_stress_div", "u_tile", "slab_split"):
+            elif k in ("u_loop", "fuse_x", "fuse_z", "fuse_stress_div", "u_tile", "slab_split", "laminate_overlap"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
             elif k in ("maxiter",):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))

@@ -82,7 +82,8 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * strain field is the state, one kernel per reference routine where fuse_* are 0 too),
  * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (rows per workgroup of
  * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled), fuse_z (untiled sweep with the z transform attached),
- * slab_split (slab driver: 1 = one all-to-all per component, overlapping the transforms of the next component; 0 = one
+ * laminate_overlap (1 = default: the interface kernels of the laminate correction run on a second stream beside the
+ * displacement sweep; 0 = one stream), slab_split (slab driver: 1 = one all-to-all per component, overlapping the transforms of the next component; 0 = one
  * exchange for the three components; -1 = by slab size, default). */
 int fg_set_option_d(fg_solver* s, const char* key, double value);
 int fg_set_option_i(fg_solver* s, const char* key, long value);
