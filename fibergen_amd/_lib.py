@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libfibergen_amd.so")
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 CALLBACK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+LOADSTEP_CALLBACK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
 
 
 
@@ -52,6 +53,8 @@ SIGNATURES = {
     "fg_set_convergence_callback": (ctypes.c_int, [ctypes.c_void_p, CALLBACK, ctypes.c_void_p]),
     "fg_cancel": (ctypes.c_int, [ctypes.c_void_p]),
     "fg_run_load_case": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, ctypes.POINTER(ctypes.c_int)]),
+    "fg_run_load_steps": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                         LOADSTEP_CALLBACK, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "fg_iterate": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int]),
     "fg_time_iterations": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p]),
     "fg_get_iterations": (ctypes.c_long, [ctypes.c_void_p]),

@@ -251,6 +251,10 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       o.method = (int)value;
     }
     else if (k == "fuse_stress_div") o.fuse_stress_div = value != 0;
+    else if (k == "error_estimator") {
+      if (value != 0 && value != 1) throw std::runtime_error("error_estimator must be 0 (epsilon) or 1 (residual)");
+      o.error_estimator = (int)value;
+    }
     else throw std::runtime_error("unknown option '" + k + "'");
   });
 }
@@ -274,6 +278,16 @@ int fg_run_load_case(fg_solver* s, const double* E6, const double* S6, int* fail
   return guarded(s, [&](fg::Solver& v) {
     if (!E6) throw std::runtime_error("strain pointer is NULL");
     const bool f = v.is_slab() ? v.slab_group().run(E6, S6) : v.run(E6, S6);   // slab solvers: collective call
+    if (failed) *failed = f ? 1 : 0;
+  });
+}
+
+int fg_run_load_steps(fg_solver* s, const double* E6, const double* S6, const double* params, int nparams, int first,
+                      fg_loadstep_callback cb, void* user, int* failed) {
+  return guarded(s, [&](fg::Solver& v) {
+    if (!E6 || !params) throw std::runtime_error("NULL argument");
+    if (v.is_slab()) throw std::runtime_error("load stepping is not available on slab-decomposed solvers");
+    const bool f = v.run_load_steps(E6, S6, params, nparams, first, cb, user);
     if (failed) *failed = f ? 1 : 0;
   });
 }

@@ -34,6 +34,7 @@ constexpr int kNumSlots = 48;
 }  // namespace slots
 
 typedef int (*ConvergenceCallback)(void* user);
+typedef int (*LoadstepCallback)(void* user, int istep);
 
 struct SolverOptions {
   // defaults of the LSSolver constructor  F:14800-14862
@@ -52,6 +53,8 @@ struct SolverOptions {
   int mode = 0;                 // 0 = elasticity, 1 = scalar (heat / porous: 3-component gradient, 1-component potential),
                                 // 2 = viscosity (dual Stokes scheme: DeltaOperatorStaggered F:20422-20460, 6 components)
   int gamma_scheme = 0;         // 0 = staggered (GammaOperatorStaggered F:20288), 1 = collocated (GammaOperatorCollocated F:20302)
+  int error_estimator = 0;      // 0 = epsilon (EpsilonErrorEstimator F:14591-14637), 1 = residual (ResidualErrorEstimator
+                                // F:14382-14405: abs = sqrt(gamma), rel = sqrt(gamma / gamma_0); method cg only)
   int method = 0;               // 0 = basic scheme (runBasic F:21716), 1 = conjugate gradients (runCGElasticity F:23153)
   int u_loop = 2;               // pure strain BC: displacement-based pass (0 off, 1 exact operation order: bit-identical
                                 // to 0, 2 precomputed effective moduli + FMA, agrees with 1 to rounding; with laminate
@@ -116,6 +119,10 @@ class Solver {
 
   // LSSolver::run  F:21247-21398.  Returns false on success, true on error like the reference.
   bool run(const double* E6, const double* S6);
+  // runLoadsteppingSolver  F:21584-21685: steps first .. nparams-1 with prescribed values params[i] * (E6, S6), each
+  // continuing from the one before; step_cb after every step (non-zero = stop, reported as failure like the reference)
+  bool run_load_steps(const double* E6, const double* S6, const double* params, int nparams, int first,
+                      LoadstepCallback step_cb, void* user);
   // timed iterations without convergence logic (bench / profiling): n passes of basicScheme
   void iterate(const double* E6, int n);
 
@@ -156,9 +163,11 @@ class Solver {
  private:
   // one pass  dst = E - Gamma0 : (C - C0) : src  (defaults: the solver's strain field, in place)
   void basic_scheme(const double* E6, double* src = nullptr, double* dst = nullptr);
-  bool run_cg(const double* E0, const double* S0);
-  bool run_cg_scalar(const double* E0);  // heat / porous: CG in potential space
-  bool run_cg_u(const double* E0);      // the same CG carried in displacement space (Voigt, prescribed mean strains)
+  bool run_one_step(const double* E0, const double* S0);
+  double current_norm9();
+  bool run_cg(const double* E0, const double* S0, double prev0);
+  bool run_cg_scalar(const double* E0, double prev0);  // heat / porous: CG in potential space
+  bool run_cg_u(const double* E0, double prev0);      // the same CG carried in displacement space (Voigt, prescribed mean strains)
   bool u_loop_eligible(bool allow_mixed_bc = false) const;
   FieldPtrs<2> effective_moduli();      // per-voxel sums of the phase moduli for the fast kernels (allocated on first use)
   void build_laminate_lists();          // interface / affected voxel lists of the laminate correction (once per geometry)
@@ -281,6 +290,7 @@ class Solver {
   bool z_done_ = false;     // the last displacement sweep wrote the z spectrum of f (not f)
   bool eps_stale_ = false;  // eps_ has not been written since fu_ changed
   bool in_run_ = false;
+  bool fresh_step_ = true;   // the load step being run starts from the zeroed field (not from a previous step)
   bool cg_u_active_ = false;  // displacement-space CG is iterating: fu_ is the iterate u_e, fu_alt_ is free between steps
   double E_cur_[6] = {0, 0, 0, 0, 0, 0};   // prescribed strain the current (u, eps) state was built with
   double E_next_[6] = {0, 0, 0, 0, 0, 0};

@@ -455,9 +455,8 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     return;
   }
   if (opt_.gamma_scheme == 1) {
-    // GammaOperatorCollocated  F:20302-20310: fftTensor, Gamma0_hat, fftInvTensor on the six components
-    if (frobenius(BC_MQ_) >= kEps || opt_.bc_relax != 1.0)
-      throw std::runtime_error("gamma_scheme=collocated supports prescribed mean strains only (projector = identity)");
+    // GammaOperatorCollocated  F:20302-20310: fftTensor, initBCProjector, Gamma0_hat, applyBCProjector, fftInvTensor on the
+    // six components
     time_begin(0);
     launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(src), phi, nrm, ptrs6(tau_), derr_, stream_);
     time_end(0);
@@ -468,6 +467,20 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     for (int a = 0; a < 3; ++a) xt.xi[a] = xi_[a];
     Vec6 Ev;
     for (int c = 0; c < 6; ++c) Ev.v[c] = E6[c];
+    if (!(frobenius(BC_MQ_) < kEps) || opt_.bc_relax != 1.0) {
+      // mixed boundary conditions: F0 = Re tau_hat(0) (initBCProjector(tau_hat) F:20219-20225; the forward transform is
+      // scaled, so this is the mean of tau), and the zero frequency of eta_hat becomes E + R (applyBCProjector(eta_hat,
+      // alpha) F:20272-20279) -- the Fourier kernel sets it to the value handed in
+      double F0[6], t1[6], t2[6], t3[6];
+      for (int c = 0; c < 6; ++c)
+        FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean + c, tau_ + (long)c * g_.n, sizeof(double), hipMemcpyDeviceToHost, stream_));
+      FG_HIP_CHECK(hipStreamSynchronize(stream_));
+      for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c];
+      voigt_mv(BC_MQ_, F0, t1);
+      voigt_mv(BC_QC0_, F00_, t2);
+      voigt_mv(BC_M_, t2, t3);
+      for (int c = 0; c < 6; ++c) Ev.v[c] += alpha * (opt_.bc_relax * t1[c] - (1 - opt_.bc_relax) * t3[c]);
+    }
     const double c10 = alpha / (4 * opt_.mu_0);
     const double c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
     time_begin(5);
@@ -959,43 +972,85 @@ double Solver::bc_error(const double* E_cur, const double* S_cur) {
 // run F:21247-21398 -> runLoadsteppingSolver (single load step, t = 1) F:21584-21685
 // -> runSolver -> runBasic F:21716-21805 with the stop rule of _converged F:21177-21244.
 bool Solver::run(const double* E6, const double* S6) {
+  const double one = 1.0;
+  return run_load_steps(E6, S6, &one, 1, 0, nullptr, nullptr);
+}
+
+// norm of the current strain field as EpsilonErrorEstimator's constructor takes it (F:14612-14618): a load step that
+// continues from the previous one starts its error estimate there, the first one at the zero field
+double Solver::current_norm9() {
+  ensure_eps();
+  launch_sum6(g_, ptrs6(eps_), true, partial_, dscal_ + kSlotScratch, stream_);
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotScratch, dscal_ + kSlotScratch, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  double s9 = 0.0;
+  const int nc = opt_.mode == 1 ? 3 : 6;
+  for (int c = 0; c < nc; ++c) {
+    const double m = std::sqrt(hscal_[kSlotScratch + c] / (double)nglobal_);
+    s9 += m * m * ((c >= 3) ? 2.0 : 1.0);   // shear norms mirrored to 9 entries (fix_dim)
+  }
+  return std::sqrt(s9);
+}
+
+// runLoadsteppingSolver  F:21584-21685: the prescribed values are scaled by the parameter of every load step, every
+// step continues from the strain field of the one before (the field is zeroed once, in run(), F:21379), and after each
+// step the load-step action runs (performLoadstepActions F:21435-21447: the caller's callback, non-zero = stop).
+// Load-step extrapolation (loadstep_extrapolation_order > 0) is not available.
+bool Solver::run_load_steps(const double* E6, const double* S6, const double* params, int nparams, int first,
+                            LoadstepCallback step_cb, void* user) {
   FG_HIP_CHECK(hipSetDevice(device_));
   if (pt_.n < 1) throw std::runtime_error("No materials specified");
+  if (nparams < 1 || first < 0 || !params) throw std::runtime_error("invalid load steps");
   solve_time_ = 0.0;
   cg_u_active_ = false;
   residuals_.clear();
   iterations_ = 0;
   cancel_ = false;
-  double E0[6], S0[6];
+  double Emax[6], Smax[6];
   for (int i = 0; i < 6; ++i) {
-    E0[i] = E6[i];
-    S0[i] = S6 ? S6[i] : 0.0;
+    Emax[i] = E6[i];
+    Smax[i] = S6 ? S6[i] : 0.0;
   }
   recompute_bc();  // F:21354
   {
     const double se = std::sqrt(kEps);
     double t[6];
-    voigt_mv(BC_P_, S0, t);
-    if (norm2(t, 6) > se * norm2(S0, 6)) throw std::runtime_error("Incompatible stress boundary condition specified");
-    voigt_mv(BC_Q_, E0, t);
-    if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
+    voigt_mv(BC_P_, Smax, t);
+    if (norm2(t, 6) > se * norm2(Smax, 6)) throw std::runtime_error("Incompatible stress boundary condition specified");
+    voigt_mv(BC_Q_, Emax, t);
+    if (norm2(t, 6) > se * norm2(Emax, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
   }
-  if (opt_.method == 1 && opt_.mode == 1) {
-    (void)u_loop_eligible();   // throws for configurations the scalar modes do not support
-    FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * (size_t)g_.n * sizeof(double), stream_));
-    return run_cg_scalar(E0);
-  }
-  if (opt_.method == 1) return run_cg(E0, S0);
-  const double t_start = now_seconds();
-  FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * g_.n * sizeof(double), stream_));  // F:21379
-  for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
+  FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * (size_t)g_.n * sizeof(double), stream_));  // F:21379
   u_valid_ = false;
   eps_stale_ = false;
+  for (int istep = first; istep < nparams; ++istep) {
+    double E[6], S[6];
+    for (int i = 0; i < 6; ++i) E[i] = params[istep] * Emax[i], S[i] = params[istep] * Smax[i];
+    fresh_step_ = istep == first;
+    if (run_one_step(E, S)) return true;
+    if (step_cb && step_cb(user, istep)) return true;   // "Loadstep callback break request."
+  }
+  return false;
+}
+
+// runSolver  F:21400-21433 for one load step
+bool Solver::run_one_step(const double* E0, const double* S0) {
+  // EpsilonErrorEstimator  F:14591-14637: constructed on the field the step starts from (zero for the first step)
+  const double prev0 = fresh_step_ ? 0.0 : current_norm9();
+  if (opt_.method == 1 && opt_.mode == 1) {
+    (void)u_loop_eligible();   // throws for configurations the scalar modes do not support
+    return run_cg_scalar(E0, prev0);
+  }
+  if (opt_.method == 1) return run_cg(E0, S0, prev0);
+  if (opt_.error_estimator != 0)   // ErrorEstimator::update  F:14359
+    throw std::runtime_error("Selected error estimator is not compatible with the selected solution method");
+  const double t_start = now_seconds();
+  for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
   // Displacement-based loop: eps_0 = 0 gives tau = 0, u_1 = 0 and eps_1 = E, so the loop starts from
   // u = 0 and every pass is [u_k -> norms of eps_k, f_{k+1}] + [f_{k+1} -> u_{k+1}] (see u_pass_front).
   bool uloop = u_loop_eligible(true);
   const bool mixed_bc = !(frobenius(BC_MQ_) < kEps);   // (NaN until calcRefMaterial ran: Q != 0)
-  if (uloop) {
+  if (uloop && fresh_step_) {
     FG_HIP_CHECK(hipMemsetAsync(fu_, 0, 3 * g_.n * sizeof(double), stream_));
     u_valid_ = true;
     eps_stale_ = true;
@@ -1003,9 +1058,12 @@ bool Solver::run(const double* E6, const double* S6) {
   }
   in_run_ = true;
 
-  // EpsilonErrorEstimator  F:14591-14637: norms of the zero field at construction
-  double prev = 0.0;
+  double prev = prev0;
   long iter = 1;
+  // a continuing load step in the displacement loop: the state is u of the previous step (eps = E_old + sym grad u); one
+  // unrecorded pass turns it into u' with eps' = E_new + sym grad u' -- the field the reference's first iteration of the
+  // step produces -- and the loop below then measures eps' in its first pass
+  bool carry = uloop && !fresh_step_ && u_valid_;
   bool update_ref = opt_.update_ref != 0;
   double E[6];
   for (int i = 0; i < 6; ++i) E[i] = E0[i];
@@ -1025,8 +1083,18 @@ bool Solver::run(const double* E6, const double* S6) {
     }
     bool pending_back = false;
     pending_back_ = back_ready_ = false;
+    if (carry) {
+      if (mixed_bc) {
+        carry = false;   // (the correction of the prescribed mean needs <tau> on the host: take the strain-state pass)
+        uloop = false;
+      } else {
+        u_pass_front(E);
+        u_pass_back();
+        carry = false;
+      }
+    }
     if (uloop && u_valid_) {
-      if (iter == 1)
+      if (iter == 1 && fresh_step_)
         for (int i = 0; i < 6; ++i) E_cur_[i] = E[i];  // eps_1 = E (u_1 = 0)
       u_pass_front(E);
       pending_back = true;
@@ -1099,7 +1167,7 @@ bool Solver::run(const double* E6, const double* S6) {
 //   u_r, u_p = the two halves of the 6-component buffer cg_r_.
 // Per iteration: one displacement sweep (the K1 of the basic scheme with E = 0) + FFT chain, one gradient dot product,
 // one point-wise update of u_e and u_r, one gradient norm sweep, one point-wise update of u_p.
-bool Solver::run_cg_u(const double* E0) {
+bool Solver::run_cg_u(const double* E0, double prev0) {
   const double t_start = now_seconds();
   const size_t f3 = 3 * (size_t)g_.n * sizeof(double);
   if (!cg_r_) FG_HIP_CHECK(hipMalloc(&cg_r_, 2 * f3));
@@ -1132,7 +1200,14 @@ bool Solver::run_cg_u(const double* E0) {
   FG_HIP_CHECK(hipMemcpyAsync(u_r, fu_alt_, f3, hipMemcpyDeviceToDevice, stream_));
   FG_HIP_CHECK(hipMemcpyAsync(u_p, fu_alt_, f3, hipMemcpyDeviceToDevice, stream_));   // p = r
   launch_cgu_dot(1, g_, ptrs3(fu_), ptrs3(u_r), E, partial_, dscal_ + blk[0], stream_);   // gamma_0 = r:r / N + tiny
-  double prev = 0.0;  // estimator constructed on the zero field
+  double prev = prev0;  // estimator constructed on the field the step started from
+  const bool residual_est = opt_.error_estimator == 1;
+  double gamma_cur = 0.0, gamma_0 = 0.0;   // r:r / N + tiny of the current iteration / of the start (residual estimator)
+  if (residual_est) {
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotCg + 6, dscal_ + blk[0] + 6, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    gamma_cur = gamma_0 = hscal_[kSlotCg + 6] / (double)nglobal_ + small;
+  }
   long iter = 0;
   bool failed = false;
   bool applied = false;   // u_w = operator(u_p) of the coming iteration is already enqueued
@@ -1168,9 +1243,14 @@ bool Solver::run_cg_u(const double* E0) {
     for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
     for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
     const double curn = std::sqrt(s9);
-    const double abs_err = std::fabs(prev - curn);
-    const double rel_err = abs_err / (small + curn);
+    double abs_err = std::fabs(prev - curn);
+    double rel_err = abs_err / (small + curn);
     prev = curn;
+    if (residual_est) {   // update_cg(gamma, gamma0)  F:14397-14401 with the gamma this iteration started from
+      abs_err = std::sqrt(gamma_cur);
+      rel_err = std::sqrt(gamma_cur / gamma_0);
+      gamma_cur = hscal_[kSlotCg + 6] / (double)nglobal_ + small;   // delta = r:r after the update: the next gamma
+    }
     if (std::isnan(rel_err) || cancel_) {  // _converged  F:21177-21244
       failed = true;
       break;
@@ -1205,7 +1285,7 @@ bool Solver::run_cg_u(const double* E0) {
 // Scalar modes: the same CG in potential space (g = E + grad T_e; r, p, w = grad T_r, T_p, T_w): runCG dispatches every
 // non-hyperelastic mode to runCGElasticity (F:22056-22066), whose inner product is the plain sum for 3 components
 // (F:20961-20980).  T_e = fu_[0], T_w = fu_alt_[0], T_r / T_p = components 1, 2 of fu_alt_'s buffer mate cg_r_.
-bool Solver::run_cg_scalar(const double* E0) {
+bool Solver::run_cg_scalar(const double* E0, double prev0) {
   const double t_start = now_seconds();
   const size_t f1 = (size_t)g_.n * sizeof(double);
   if (!cg_r_) FG_HIP_CHECK(hipMalloc(&cg_r_, 6 * f1));
@@ -1236,7 +1316,8 @@ bool Solver::run_cg_scalar(const double* E0) {
   launch_sc_cg_dot(1, g_, fu_, T_r, E, partial_, dscal_ + kSlotSumSq, stream_);
   fetch(kSlotSumSq, 7);
   double gamma = hscal_[kSlotSumSq + 6] / (double)nglobal_ + small;
-  double prev = 0.0;
+  const double gamma_0 = gamma;
+  double prev = prev0;
   long iter = 0;
   bool failed = false;
   for (;;) {
@@ -1259,9 +1340,13 @@ bool Solver::run_cg_scalar(const double* E0) {
       s3 += m * m;
     }
     const double cur = std::sqrt(s3);
-    const double abs_err = std::fabs(prev - cur);
-    const double rel_err = abs_err / (small + cur);
+    double abs_err = std::fabs(prev - cur);
+    double rel_err = abs_err / (small + cur);
     prev = cur;
+    if (opt_.error_estimator == 1) {   // update_cg(gamma, gamma0)  F:14397-14401
+      abs_err = std::sqrt(gamma);
+      rel_err = std::sqrt(gamma / gamma_0);
+    }
     if (std::isnan(rel_err) || cancel_) {
       failed = true;
       break;
@@ -1295,17 +1380,13 @@ bool Solver::run_cg_scalar(const double* E0) {
   return failed;
 }
 
-bool Solver::run_cg(const double* E0, const double* S0) {
+bool Solver::run_cg(const double* E0, const double* S0, double prev0) {
   if (nranks_ != 1) throw std::runtime_error("method=cg is not available on slab-decomposed solvers");
-  if (opt_.u_loop >= 2 && u_loop_eligible() && norm2(S0, 6) == 0.0) {
-    FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * (size_t)g_.n * sizeof(double), stream_));
-    return run_cg_u(E0);
-  }
+  if (opt_.u_loop >= 2 && u_loop_eligible() && norm2(S0, 6) == 0.0) return run_cg_u(E0, prev0);
   const double t_start = now_seconds();
   const size_t f6 = 6 * (size_t)g_.n * sizeof(double);
   for (double** b : {&cg_r_, &cg_p_, &cg_w_})
     if (!*b) FG_HIP_CHECK(hipMalloc(b, f6));
-  FG_HIP_CHECK(hipMemsetAsync(eps_, 0, f6, stream_));  // F:21379
   for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
   u_valid_ = false;
   eps_stale_ = false;
@@ -1320,7 +1401,7 @@ bool Solver::run_cg(const double* E0, const double* S0) {
     voigt_mv(BC_M_, t2, t3);
     for (int i = 0; i < 6; ++i) E.v[i] = E0[i] + opt_.bc_relax * t3[i], Z.v[i] = 0.0;
   }
-  double prev = 0.0;  // estimator constructed on the zero field
+  double prev = prev0;  // estimator constructed on the field the step started from
   auto fetch = [&](int slot, int n) {
     FG_HIP_CHECK(hipMemcpyAsync(hscal_ + slot, dscal_ + slot, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
     check_device_error("cg");
@@ -1331,6 +1412,7 @@ bool Solver::run_cg(const double* E0, const double* S0) {
   launch_cg(0, g_, r, e, e, E, 0.0, partial_, dscal_ + kSlotMean, stream_);        // r += E - eps ; r:r
   fetch(kSlotMean, 1);
   double gamma = hscal_[kSlotMean] / (double)nglobal_ + small;
+  const double gamma_0 = gamma;
   FG_HIP_CHECK(hipMemcpyAsync(cg_p_, cg_r_, f6, hipMemcpyDeviceToDevice, stream_));  // p = r
   long iter = 0;
   bool failed = false;
@@ -1350,9 +1432,13 @@ bool Solver::run_cg(const double* E0, const double* S0) {
     for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
     for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
     const double cur = std::sqrt(s9);
-    const double abs_err = std::fabs(prev - cur);
-    const double rel_err = abs_err / (small + cur);
+    double abs_err = std::fabs(prev - cur);
+    double rel_err = abs_err / (small + cur);
     prev = cur;
+    if (opt_.error_estimator == 1) {   // update_cg(gamma, gamma0)  F:14397-14401
+      abs_err = std::sqrt(gamma);
+      rel_err = std::sqrt(gamma / gamma_0);
+    }
     if (std::isnan(rel_err) || cancel_) {  // _converged  F:21177-21244
       failed = true;
       break;

@@ -246,8 +246,8 @@ class FG:
         if scheme not in ("staggered", "collocated") or (scheme == "collocated" and scalar):  # scalar: any non-elastic mode
             raise RuntimeError("Unknown gamma scheme '%s' (MI355X path: staggered, collocated for elasticity)" % scheme)
         est = self._child_value(solver, "error_estimator", "epsilon", str)
-        if est != "epsilon":
-            raise RuntimeError("error estimator '%s' is not available (epsilon only)" % est)
+        if est not in ("epsilon", "residual"):
+            raise RuntimeError("error estimator '%s' is not available (epsilon, residual)" % est)
         mixing = self._child_value(solver, "mixing_rule", "voigt", str)
         if mixing not in ("voigt", "laminate"):
             raise RuntimeError("Unknown mixing rule '%s'" % mixing)
@@ -255,7 +255,22 @@ class FG:
             raise RuntimeError("mixing rule '%s' is not available in %s mode (voigt only)" % (mixing, mode))
 
         lss = LSSolver(nx, ny, nz, dx, dy, dz, device=self._device)
-        opts = {"mode": mode, "mixing_rule": mixing, "method": method, "gamma_scheme": scheme}
+        opts = {"mode": mode, "mixing_rule": mixing, "method": method, "gamma_scheme": scheme, "error_estimator": est}
+        # <loadsteps>  F:15095-15119: a count (uniform steps i / n) or a list of <loadstep param=".."/>
+        self._loadsteps = [0.0, 1.0]
+        ls = solver.find("loadsteps") if solver is not None else None
+        if ls is not None:
+            entries = [c for c in ls if isinstance(c.tag, str)]
+            if entries:
+                self._loadsteps = [self._eval(c.attrib["param"]) for c in entries if c.tag == "loadstep"]
+            else:
+                n = self._eval(ls.text.strip(), int) if (ls.text and ls.text.strip()) else 1
+                self._loadsteps = [i / float(n) for i in range(n + 1)]
+        self._first_loadstep = self._child_value(solver, "first_loadstep", -1, int)
+        self._write_loadsteps = bool(self._child_value(solver, "write_loadsteps", 0, int))
+        self._loadstep_filename = self._child_value(solver, "loadstep_filename", "loadstep_%02d.vtk", str)
+        if self._child_value(solver, "loadstep_extrapolation_order", 0, int) > 0:
+            raise RuntimeError("loadstep_extrapolation_order > 0 is not available on the MI355X path")
         for k in _SOLVER_DOUBLE_KEYS:
             v = self._child_value(solver, k, None)
             if v is not None:
@@ -478,6 +493,21 @@ class FG:
         ix, iy, iz = rng(range_x, data.shape[1]), rng(range_y, data.shape[2]), rng(range_z, data.shape[3])
         return np.ascontiguousarray(data[np.ix_(ic, ix, iy, iz)])
 
+    def _run_lss(self, E, S=None):
+        """LSSolver::run with the project's load steps (runLoadsteppingSolver F:21584-21685); after every step the
+        load-step actions (performLoadstepActions F:21435-21447): VTK file if <write_loadsteps>, then the callback.
+        Returns the reference's run() value (True = error or stop request)."""
+        def step(istep):
+            if self._write_loadsteps and self._loadstep_filename:
+                self.write_vtk(self._loadstep_filename % istep)
+            return self._loadstep_callback is not None and bool(self._loadstep_callback())
+        first = self._first_loadstep if self._first_loadstep >= 0 else (0 if len(self._loadsteps) > 2 else 1)
+        return self._lss.run_load_steps(E, S, self._loadsteps, first, step)
+
+    def get_mean_cauchy_stress(self):
+        """FG::get_mean_cauchy_stress  F:27177 / F:25122: for the small-strain laws the Cauchy stress is the stress"""
+        return self.get_mean_stress()
+
     def _effective_viscosity(self, outdir):
         """calc_effective_properties, viscosity branch  F:26252-26347: five traceless stress experiments,
         Ceff55 = E55 S55^-1, completion to 6x6 by tracelessness, row shift of the first three columns,
@@ -488,9 +518,8 @@ class FG:
         E[3, 2] = E[4, 3] = E[5, 4] = 1
         S = np.zeros((6, 5))
         for i in range(5):
-            failed = self._lss.run(E[:, i])
-            stop = self._loadstep_callback is not None and self._loadstep_callback()
-            if failed or stop or self._error is not None:
+            failed = self._run_lss(E[:, i])
+            if failed or self._error is not None:
                 self._error = self._error or "NaN detected in solution. Aborting."
                 return EXIT_FAILURE
             S[:, i] = self._lss.mean_stress()
@@ -685,12 +714,20 @@ class FG:
                     raise RuntimeError("Prescibed fluid strain %s has not zero trace!" % S)
             self.init_phase()
             self._lss.set_bc_projector(P)
-            failed = self._lss.run(E, S)
-            if failed:
+            stopped = [False]
+            user_cb = self._loadstep_callback
+            if user_cb is not None:   # a stop request ends the run, but run()'s return value is ignored here (F:25938)
+                def wrapped():
+                    stopped[0] = bool(user_cb())
+                    return stopped[0]
+                self._loadstep_callback = wrapped
+            try:
+                failed = self._run_lss(E, S)
+            finally:
+                self._loadstep_callback = user_cb
+            if failed and not stopped[0]:
                 self._error = self._error or "NaN detected in solution. Aborting."
                 return EXIT_FAILURE
-            if self._loadstep_callback is not None and self._loadstep_callback():
-                pass  # the reference ignores run()'s return value here (F:25938)
             if self._error is not None:
                 return EXIT_FAILURE
             outfile = self._attr(act, "outfile", "", str)
@@ -753,9 +790,8 @@ class FG:
                 for i in range(3):
                     Ep = np.zeros(3)
                     Ep[i] = 1.0
-                    failed = self._lss.run(Ep)
-                    stop = self._loadstep_callback is not None and self._loadstep_callback()
-                    if failed or stop or self._error is not None:
+                    failed = self._run_lss(Ep)
+                    if failed or self._error is not None:
                         self._error = self._error or "NaN detected in solution. Aborting."
                         return EXIT_FAILURE
                     S[:, i] = self._lss.mean_stress()
@@ -769,9 +805,8 @@ class FG:
             for i in range(6):
                 Ep = np.zeros(6)
                 Ep[i] = 1.0
-                failed = self._lss.run(Ep)
-                stop = self._loadstep_callback is not None and self._loadstep_callback()
-                if failed or stop or self._error is not None:
+                failed = self._run_lss(Ep)
+                if failed or self._error is not None:
                     self._error = self._error or "NaN detected in solution. Aborting."
                     return EXIT_FAILURE
                 S[:, i] = self._lss.mean_stress()

@@ -97,6 +97,10 @@ class LSSolver:
                     raise RuntimeError("mode '%s' is not available on the MI355X path" % v)
                 self.scalar = v in ("heat", "porous")
                 self._check(self._lib.fg_set_option_i(self._h, b"mode", {"elasticity": 0, "viscosity": 2}.get(v, 1)))
+            elif k == "error_estimator":
+                if v not in ("epsilon", "residual"):
+                    raise RuntimeError("error estimator '%s' is not available (epsilon, residual)" % v)
+                self._check(self._lib.fg_set_option_i(self._h, b"error_estimator", 1 if v == "residual" else 0))
             elif k in ("u_loop", "fuse_x", "fuse_z", "fuse_stress_div", "u_tile", "slab_split", "laminate_overlap"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
             elif k in ("maxiter",):
@@ -144,6 +148,23 @@ class LSSolver:
             Sp = _dp(S)
         failed = ctypes.c_int(0)
         self._check(self._lib.fg_run_load_case(self._h, _dp(E), Sp, ctypes.byref(failed)))
+        return bool(failed.value)
+
+    def run_load_steps(self, E, S=None, params=(0.0, 1.0), first=None, step_callback=None):
+        """runLoadsteppingSolver: step i prescribes params[i] * (E, S), continuing from step i-1; step_callback(i) -> True
+        stops.  first defaults like the reference (1 for the standard list [0, 1], else 0).  True on error / stop."""
+        E = self._load6(E)
+        Sp = None
+        if S is not None:
+            S = self._load6(S)
+            Sp = _dp(S)
+        par = np.ascontiguousarray(params, dtype=np.float64)
+        if first is None:
+            first = 0 if par.size > 2 else 1
+        cb = _lib.LOADSTEP_CALLBACK(lambda _u, i: 1 if (step_callback is not None and step_callback(i)) else 0)
+        failed = ctypes.c_int(0)
+        self._check(self._lib.fg_run_load_steps(self._h, _dp(E), Sp, _dp(par), int(par.size), int(first), cb, None,
+                                                ctypes.byref(failed)))
         return bool(failed.value)
 
     def iterate(self, E, n):

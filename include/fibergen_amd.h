@@ -77,7 +77,8 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * fluidity constant of the XML, "epsilon" holds the fluid stress, "sigma" the shear rate; Voigt mixing, basic scheme),
  * gamma_scheme (0 = staggered, 1 = collocated: GammaOperatorCollocated F:20302-20310, Fourier-space 6x6 Gamma0),
  * method (0 = basic scheme, runBasic F:21716-21805; 1 = conjugate gradients, runCGElasticity
- * F:23153-23247, the reference's default), and the implementation switches u_loop (2 = default: the loop carries the
+ * F:23153-23247, the reference's default), error_estimator (0 = epsilon F:14591-14637; 1 = residual F:14382-14405, method
+ * cg only), and the implementation switches u_loop (2 = default: the loop carries the
  * displacement, fast kernels; 1 = the same with the reference's operation order, iterates bit-identical to 0; 0 = the
  * strain field is the state, one kernel per reference routine where fuse_* are 0 too),
  * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (rows per workgroup of
@@ -98,6 +99,15 @@ int fg_cancel(fg_solver* s);
  * gamma_scheme=staggered).  S may be NULL (= 0).  *failed receives the reference's
  * return value (1 = stopped on an error such as a NaN residual, F:21202-21208). */
 int fg_run_load_case(fg_solver* s, const double* E6, const double* S6, int* failed);
+
+/* runLoadsteppingSolver  F:21584-21685 with the <loadsteps> of the project (F:15095-15119): step i = first .. nparams-1
+ * prescribes params[i] * (E6, S6) and starts from the strain field of the step before (zeroed once, F:21379); after
+ * every step the load-step action runs (performLoadstepActions F:21435-21447): cb(user, i), non-zero stops the run,
+ * which then reports failure like the reference.  fg_run_load_case is the standard list {0, 1} with first = 1
+ * (F:21591).  loadstep_extrapolation_order > 0 is not available. */
+typedef int (*fg_loadstep_callback)(void* user, int istep);
+int fg_run_load_steps(fg_solver* s, const double* E6, const double* S6, const double* params, int nparams, int first,
+                      fg_loadstep_callback cb, void* user, int* failed);
 
 /* n passes of basicScheme without convergence logic, and the same bracketed by HIP
  * events on the solver stream (benchmarks). */

@@ -404,6 +404,7 @@ class LSOracle:
     lambda_0: float = 0.0
     update_ref: str = "loadstep"
     gamma_scheme: str = "staggered"               # or "collocated" (GammaOperatorCollocated F:20302-20310)
+    error_estimator: str = "epsilon"              # or "residual" (method cg only, F:14382-14405)
 
     def __post_init__(self):
         self.N = self.nx * self.ny * self.nz
@@ -685,10 +686,10 @@ class LSOracle:
 
     def gamma_collocated(self, E, mu_0, lambda_0, tau, alpha=-1.0, beta=0.0):
         """GammaOperatorCollocated  F:20302-20310 = fftTensor (1/N, F:18531-18560),
-        GammaOperatorFourierCollocated  F:19381-19608 (freq_hack off), fftInvTensor; pure strain BC."""
-        if np.linalg.norm(self.BC_MQ) >= EPS:
-            raise RuntimeError("collocated restatement: prescribed mean strains only")
+        GammaOperatorFourierCollocated  F:19381-19608 (freq_hack off), applyBCProjector on the zero frequency
+        (F:20272-20279), fftInvTensor."""
         th = np.fft.rfftn(tau, axes=(1, 2, 3)) * (1 / float(self.N))
+        F0 = th[:, 0, 0, 0].real.copy()   # initBCProjector(tau_hat)  F:20219-20225: the mean of tau, always
         xi = []
         for n, d in ((self.nx, self.dx), (self.ny, self.dy), (self.nz, self.dz)):
             half = (n // 2 - 1) if (n % 2 == 0) else n // 2
@@ -736,6 +737,9 @@ class LSOracle:
                     (th[3] * g(i, 3) + th[4] * g(i, 4) + th[5] * g(i, 5)) * 2.0
                 eh[i] = ey + beta * th[i]
         eh[:, 0, 0, 0] = np.asarray(E, dtype=np.float64)   # F:19605-19607
+        R = alpha * (self.bc_relax * voigt_dyad4_mv(self.BC_MQ, F0)
+                     - (1 - self.bc_relax) * voigt_dyad4_mv(self.BC_M, voigt_dyad4_mv(self.BC_QC0, self._F00)))
+        eh[:, 0, 0, 0] += R                                # applyBCProjector(eta_hat, alpha)  F:20272-20279
         return np.fft.irfftn(eh, s=(self.nx, self.ny, self.nz), axes=(1, 2, 3)) * float(self.N)
 
     def basic_scheme(self, E, eps):
@@ -773,6 +777,13 @@ class LSOracle:
         """LSSolver::run -> runLoadsteppingSolver (one step, t=1) -> runBasic
         F:21247-21398, F:21584-21685, F:21716-21805, stop rule _converged F:21177-21244.
         Returns True on error like the reference (F:21674-21677)."""
+        return self.run_load_steps(E0, S0, P, params=[0.0, 1.0])
+
+    def run_load_steps(self, E0, S0=None, P=None, params=(0.0, 1.0), first=None, method="basic", step_callback=None):
+        """run() with the <loadsteps> of the project  F:21247-21398 + runLoadsteppingSolver F:21584-21685: step i
+        prescribes params[i] * (E0, S0), starts from the strain field of step i-1 (zeroed once, F:21379) and is followed
+        by the load-step action (step_callback(i) -> True stops, F:21435-21447).  first_loadstep defaults to 1 for the
+        standard two-entry list [0, 1] and to 0 otherwise (F:21591)."""
         E0 = np.asarray(E0, dtype=np.float64)
         S0 = np.zeros(6) if S0 is None else np.asarray(S0, dtype=np.float64)
         self.E, self.S = E0, S0
@@ -788,7 +799,24 @@ class LSOracle:
             raise RuntimeError("Incompatible strain boundary condition specified")
         self.eps = np.zeros((6, self.nx, self.ny, self.nz))  # F:21379
         self._F00 = np.zeros(6)
-        # EpsilonErrorEstimator ctor: norms of the zero field  F:14612-14618
+        if first is None:
+            first = 0 if len(params) > 2 else 1
+        self.step_iterations = []
+        for istep in range(first, len(params)):
+            t = float(params[istep])
+            if method != "cg" and self.error_estimator == "residual":
+                raise RuntimeError("Selected error estimator is not compatible with the selected solution method")  # F:14359
+            failed = self._run_cg_step(t * E0, t * S0) if method == "cg" else self._run_basic_step(t * E0, t * S0)
+            self.step_iterations.append(self.iterations)
+            if failed:
+                return True
+            if step_callback is not None and step_callback(istep):
+                return True
+        return False
+
+    def _run_basic_step(self, E0, S0):
+        """runBasic  F:21716-21805 for one load step"""
+        # EpsilonErrorEstimator ctor: norms of the field the step starts from  F:14612-14618
         prev = self._norm9(self.component_norm(self.eps))
         it = 1
         update_ref = self.update_ref != "never"
@@ -830,25 +858,22 @@ class LSOracle:
     def run_cg(self, E0, S0=None, P=None):
         """LSSolver::run with method=cg: runCGElasticity  F:23153-23247 (l2 inner product,
         epsilon error estimator, no residual re-initialisation)."""
-        E0 = np.asarray(E0, dtype=np.float64)
-        S0 = np.zeros(6) if S0 is None else np.asarray(S0, dtype=np.float64)
-        self.residuals = []
-        self.error = None
-        if P is not None:
-            self.BC_P = np.asarray(P, dtype=np.float64)
-        self._set_bc_projector(self.BC_P)
-        self.eps = np.zeros((6, self.nx, self.ny, self.nz))
-        self._F00 = np.zeros(6)
+        return self.run_load_steps(E0, S0, P, params=[0.0, 1.0], method="cg")
+
+    def _run_cg_step(self, E0, S0):
+        """runCGElasticity  F:23153-23247 for one load step.  error_estimator 'epsilon' (F:14591-14637, via update_cg
+        F:14633) or 'residual' (ResidualErrorEstimator F:14382-14405: abs = sqrt(gamma), rel = sqrt(gamma / gamma0))."""
         if self.update_ref != "never":
             self.calc_ref_material()
         E = self.calc_bc_mean(E0, S0)
-        prev = self._norm9(self.component_norm(self.eps))   # estimator constructed on the zero field
+        prev = self._norm9(self.component_norm(self.eps))   # estimator constructed on the field the step starts from
         Z = np.zeros(6)
         eps = np.empty_like(self.eps)
-        eps[:] = E[:, None, None, None]
+        eps[:] = E[:, None, None, None]          # epsilon.setConstant(E)  F:23184
         r = self.basic_scheme(Z, eps)            # krylovOperator: -Gamma0 (C - C0) eps
         r = r + (E[:, None, None, None] - eps)   # adjustResidual  F:10012-10022
         gamma = self.inner_l2(r, r) + SMALLEST
+        gamma0 = gamma
         p = r.copy()
         it = 0
         while True:
@@ -857,10 +882,14 @@ class LSOracle:
             alpha = gamma / alpha
             eps = eps + alpha * p
             self.eps = eps
-            cur = self._norm9(self.component_norm(eps))
-            abs_err = abs(prev - cur)
-            rel_err = abs_err / (SMALLEST + cur)
-            prev = cur
+            if getattr(self, "error_estimator", "epsilon") == "residual":
+                abs_err = math.sqrt(gamma)
+                rel_err = math.sqrt(gamma / gamma0)
+            else:
+                cur = self._norm9(self.component_norm(eps))
+                abs_err = abs(prev - cur)
+                rel_err = abs_err / (SMALLEST + cur)
+                prev = cur
             if math.isnan(rel_err):
                 self.error = "NaN detected in solution. Aborting."
                 return True

@@ -1,0 +1,114 @@
+"""Load stepping (runLoadsteppingSolver F:21584-21685), the residual error estimator of the CG driver
+(ResidualErrorEstimator F:14382-14405) and the small boundary additions of round 2, against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_gpu_solver, make_oracle, rel_err
+
+pytestmark = pytest.mark.gpu
+
+E_LOAD = np.array([1.0, 0.2, 0, 0, 0, 0.5])
+PARAMS = [0.0, 0.25, 0.6, 1.0]
+
+
+@pytest.mark.parametrize("grid,mixing,method,opts", [
+    ((16, 16, 16), "voigt", "basic", {}),                       # untiled displacement loop
+    ((16, 16, 16), "laminate", "basic", {}),
+    ((16, 16, 16), "voigt", "basic", dict(u_loop=0)),           # strain-state pipeline
+    ((8, 16, 128), "voigt", "basic", {}),                       # tiled sweep
+    ((8, 16, 128), "laminate", "basic", {}),
+    ((16, 16, 16), "voigt", "cg", {}),                          # displacement-space CG
+    ((16, 16, 16), "laminate", "cg", dict(u_loop=0)),           # strain-space CG
+])
+def test_load_steps_match_oracle(grid, mixing, method, opts):
+    s = make_gpu_solver(grid, mixing=mixing, tol=1e-8, method=method, **opts)
+    o = make_oracle(grid, mixing=mixing, tol=1e-8)
+    steps, its = [], []
+    assert o.run_load_steps(E_LOAD, params=PARAMS, method=method) is False
+    assert s.run_load_steps(E_LOAD, params=PARAMS, step_callback=lambda i: (steps.append(i), its.append(s.iterations)) and False) is False
+    assert steps == [0, 1, 2, 3]                       # more than two entries: first_loadstep = 0  (F:21591)
+    assert its == o.step_iterations
+    assert np.abs(np.array(s.residuals) - np.array(o.residuals)).max() < 1e-10
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-10
+    # the same final state as one step (linear problem), and the standard list starts at step 1
+    steps.clear()
+    assert s.run_load_steps(E_LOAD, params=[0.0, 1.0], step_callback=lambda i: steps.append(i) and False) is False
+    assert steps == [1]
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-6
+    s.close()
+
+
+def test_load_steps_mixed_bc_and_stop_request():
+    grid = (8, 16, 128)
+    P = np.zeros((6, 6))
+    P[0, 0] = 1.0
+    s = make_gpu_solver(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    s.set_bc_projector(P)
+    o = make_oracle(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    assert o.run_load_steps([0.01, 0, 0, 0, 0, 0], np.zeros(6), P, params=[0.0, 0.5, 1.0]) is False
+    assert s.run_load_steps([0.01, 0, 0, 0, 0, 0], np.zeros(6), params=[0.0, 0.5, 1.0]) is False
+    assert s.iterations == o.iterations
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8
+    # a stop request from the load-step action ends the run and is reported like an error (F:21676-21678)
+    seen = []
+    assert s.run_load_steps([0.01, 0, 0, 0, 0, 0], np.zeros(6), params=[0.0, 0.5, 1.0],
+                            step_callback=lambda i: seen.append(i) or i == 1) is True
+    assert seen == [0, 1]
+    s.close()
+
+
+@pytest.mark.parametrize("mixing,opts", [("voigt", {}), ("laminate", dict(u_loop=0))])
+def test_cg_residual_estimator(mixing, opts):
+    grid = (16, 16, 16)
+    s = make_gpu_solver(grid, mixing=mixing, tol=1e-6, method="cg", error_estimator="residual", **opts)
+    o = make_oracle(grid, mixing=mixing, tol=1e-6)
+    o.error_estimator = "residual"
+    assert o.run_cg(E_LOAD) is False and s.run(E_LOAD) is False
+    assert s.iterations == o.iterations
+    assert s.residuals[0] == pytest.approx(1.0, abs=1e-15)       # sqrt(gamma_0 / gamma_0)
+    assert np.abs(np.array(s.residuals) / np.array(o.residuals) - 1).max() < 1e-8
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
+    # the epsilon estimator stops this problem at another iteration: the option is live
+    s.set_options(error_estimator="epsilon")
+    assert s.run(E_LOAD) is False and s.iterations != o.iterations
+    # ErrorEstimator::update  F:14359: not defined for the basic scheme
+    s.set_options(method="basic", error_estimator="residual")
+    with pytest.raises(RuntimeError, match="not compatible"):
+        s.run(E_LOAD)
+    s.close()
+
+
+XML = """<settings>
+  <solver n="16"><tol>1e-7</tol><method>basic</method><loadsteps>%s</loadsteps><write_loadsteps>%d</write_loadsteps>
+    <loadstep_filename>%s</loadstep_filename>
+    <materials><matrix E="1" nu="0.3" /><inclusion E="10" nu="0.2" /></materials></solver>
+  <actions><select_material name="inclusion" /><place_fiber R="0.3" /><run_load_case e11="1" e12="0.5" /></actions>
+</settings>"""
+
+
+def test_fg_loadsteps_callback_and_files(tmp_path):
+    from fibergen_amd.fg import FG
+    fg = FG()
+    fg.set_xml(XML % ("3", 1, str(tmp_path / "ls_%02d.vtk")))
+    calls = []
+    fg.set_loadstep_callback(lambda: calls.append(len(fg.get_residuals())) and False)
+    assert fg.run() == 0
+    assert len(calls) == 4 and calls == sorted(calls)       # steps 0..3, residual history grows over the steps
+    assert sorted(os.listdir(tmp_path)) == ["ls_00.vtk", "ls_01.vtk", "ls_02.vtk", "ls_03.vtk"]
+    full = np.array(fg.get_mean_stress())
+    assert fg.get_mean_cauchy_stress() == fg.get_mean_stress()   # F:27177: small strains
+    # explicit list, first_loadstep
+    fg2 = FG()
+    fg2.set_xml((XML % ("", 0, "x")).replace("<loadsteps></loadsteps>",
+                                              '<loadsteps><loadstep param="0.5"/><loadstep param="1"/></loadsteps><first_loadstep>0</first_loadstep>'))
+    n = []
+    fg2.set_loadstep_callback(lambda: n.append(1) and False)
+    assert fg2.run() == 0 and len(n) == 2
+    assert rel_err(np.array(fg2.get_mean_stress()), full) < 1e-6
+    fg3 = FG()
+    fg3.set_xml((XML % ("2", 0, "x")).replace("<tol>", "<loadstep_extrapolation_order>1</loadstep_extrapolation_order><tol>"))
+    with pytest.raises(RuntimeError, match="extrapolation"):
+        fg3.run()

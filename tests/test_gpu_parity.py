@@ -437,12 +437,25 @@ def test_collocated_cg_and_restrictions():
     assert s.run(E) is False and o.run_cg(E) is False
     assert s.iterations == o.iterations
     assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
-    # mixed boundary conditions are a staggered-scheme feature here
-    P = np.diag([1.0, 1.0, 0.0, 0.5, 0.5, 0.5])
-    s.set_options(method="basic")
+    s.close()
+
+
+@pytest.mark.parametrize("method", ["basic", "cg"])
+def test_collocated_mixed_boundary_conditions(method):
+    """initBCProjector(tau_hat) / applyBCProjector(eta_hat) of GammaOperatorCollocated  F:20302-20310, F:20219-20225,
+    F:20272-20279: uniaxial stress (strain 11 prescribed, the other stress components zero)."""
+    grid = (12, 10, 9)
+    P = np.zeros((6, 6))
+    P[0, 0] = 1.0
+    E, S = np.array([0.01, 0, 0, 0, 0, 0]), np.zeros(6)
+    s = make_gpu_solver(grid, tol=1e-9, bc_tol=1e-8, maxiter=600, gamma_scheme="collocated", method=method)
     s.set_bc_projector(P)
-    with pytest.raises(RuntimeError, match="collocated"):
-        s.run(np.array([1.0, 0, 0, 0, 0, 0]))
+    o = make_oracle(grid, tol=1e-9, bc_tol=1e-8, maxiter=600, gamma_scheme="collocated")
+    assert (o.run_cg(E, S, P) if method == "cg" else o.run(E, S, P)) is False
+    assert s.run(E, S) is False
+    assert s.iterations == o.iterations
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8
+    assert np.abs(s.mean_stress()[1:]).max() < 1e-7 and s.mean_strain()[0] == pytest.approx(0.01, rel=1e-10)
     s.close()
 
 
