@@ -818,8 +818,14 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   const int cus = device_cu_count();
   // march length: 32 planes (3 extra planes of loads per march), 16 when that leaves CUs without a workgroup
   // (128^3: 88 -> 176 workgroups, 0.053 -> 0.039 ms; 8 planes: 0.045 ms)
+  // thin x-slabs of a decomposed grid (nx = 32, 64) march 8 / 16 planes: 32 x 256 x 256: 44.7 -> 39.9 us, 64 x 512 x 512:
+  // 281 -> 240 us (more workgroups to balance over the CUs)
   int LX = lx_env > 0 ? lx_env : 32;
-  if (lx_env <= 0 && (long)nty * ntz * ((g.nx + 31) / 32) < cus) LX = 16;
+  if (lx_env <= 0) {
+    if (g.nx <= 32) LX = 8;
+    else if (g.nx <= 64) LX = 16;
+    else if ((long)nty * ntz * ((g.nx + 31) / 32) < cus) LX = 16;
+  }
   if (LX > g.nx) LX = g.nx;
   const int ntx = (g.nx + LX - 1) / LX;
   int nb = nty * ntz * ntx;
