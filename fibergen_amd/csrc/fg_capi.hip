@@ -107,6 +107,7 @@ int fg_slab_connect_rccl(fg_solver* s, const char* id) {
   return guarded(s, [&](fg::Solver& v) {
     if (!id) throw std::runtime_error("NULL argument");
     if (!v.is_slab()) throw std::runtime_error("not a slab solver (create it with fg_create_slab)");
+    if (v.has_group()) throw std::runtime_error("slab solver is already connected to a transport");
     auto comm = fg::make_rccl_comm(id, v.rank(), v.nranks(), v.device());
     v.connect(std::move(comm), std::make_shared<fg::SlabGroup>(std::vector<fg::Solver*>{&v}));
   });
@@ -243,6 +244,7 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
     }
     else if (k == "fuse_x") o.fuse_x = value != 0;
     else if (k == "laminate_overlap") o.laminate_overlap = value != 0;
+    else if (k == "slab_loopback") o.slab_loopback = value != 0;
     else if (k == "slab_split") o.slab_split = value < 0 ? -1 : (value != 0);
     else if (k == "fuse_z") o.fuse_z = value < 0 ? -1 : (value != 0);
     else if (k == "u_loop") o.u_loop = (int)value;

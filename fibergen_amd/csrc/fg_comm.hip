@@ -160,7 +160,7 @@ class LocalHub {
       for (const XOp& rv : cur[dst]) {
         if (rv.send) continue;
         const int src = rv.peer;
-        if (src < 0 || src >= n_ || src == dst) throw std::runtime_error("in-process exchange: bad peer");
+        if (src < 0 || src >= n_) throw std::runtime_error("in-process exchange: bad peer");
         size_t& k = next[src];
         while (k < cur[src].size() && !(cur[src][k].send && cur[src][k].peer == dst)) ++k;
         if (k == cur[src].size()) throw std::runtime_error("in-process exchange: receive without a matching send");

@@ -125,13 +125,18 @@ bool Solver::slab_split() const {
   static const int env = getenv("FG_SLAB_SPLIT") ? atoi(getenv("FG_SLAB_SPLIT")) : -1;
   if (env >= 0) return env != 0;
   if (opt_.slab_split >= 0) return opt_.slab_split != 0;
-  return nranks_ > 1 && (double)g_.n * sizeof(double) >= 32.0 * 1024 * 1024;
+  return (nranks_ > 1 || slab_loopback()) && (double)g_.n * sizeof(double) >= 32.0 * 1024 * 1024;
 }
+
+// Test mode for boxes with ONE GPU: a lone slab connected to a transport sends its all-to-all blocks and halo planes to
+// itself THROUGH the transport (RCCL: ncclSend / ncclRecv to the own rank inside a group, ncclAllReduce over one rank), on
+// the second stream with the event choreography of the multi-GPU run.
+bool Solver::slab_loopback() const { return nranks_ == 1 && comm_ && opt_.slab_loopback != 0; }
 
 double* Solver::slab_buffer(int id) {
   switch (id) {
     case FG_BUF_SPECTRUM_X: return tau_;
-    case FG_BUF_SPECTRUM_Y: return nranks_ == 1 ? tau_ : tau_ + 3 * g_.n;   // one slab: the all-to-all is the identity
+    case FG_BUF_SPECTRUM_Y: return (nranks_ == 1 && !slab_loopback()) ? tau_ : tau_ + 3 * g_.n;   // one slab: the identity
     case FG_BUF_U: return su_[su_cur_ ^ 1];                                  // the displacement the chain is producing
     case FG_BUF_MODULI: return smod_;
     case FG_BUF_HALO_SEND_LO: return halo_[0];
@@ -144,9 +149,10 @@ double* Solver::slab_buffer(int id) {
 
 // One exchange of the plan.  A lone slab is periodic in itself: its halo planes are its own planes.
 void Solver::slab_exchange(int what, int comp, int done_slot) {
-  const SlabDims d = slab_dims(nxg_, g_.ny, g_.nz, nranks_, rank_);
+  SlabDims d = slab_dims(nxg_, g_.ny, g_.nz, nranks_, rank_);
+  d.loopback = slab_loopback();
   const size_t pb = (size_t)d.plane * sizeof(double);
-  if (nranks_ == 1) {
+  if (nranks_ == 1 && !d.loopback) {
     if (what == FG_PLAN_HALO_U || what == FG_PLAN_HALO_MODULI) {
       double* base = slab_buffer(what == FG_PLAN_HALO_U ? FG_BUF_U : FG_BUF_MODULI);
       const int nc = what == FG_PLAN_HALO_U ? 3 : 2;
@@ -180,7 +186,7 @@ void Solver::slab_exchange(int what, int comp, int done_slot) {
 }
 
 void Solver::slab_reduce(int slot, int n, bool min_op) {
-  if (nranks_ == 1) return;
+  if (nranks_ == 1 && !slab_loopback()) return;
   if (!comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
   comm_begin();
   comm_->allreduce(dscal_ + slot, n, min_op, comm_stream_);

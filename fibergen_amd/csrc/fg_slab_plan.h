@@ -26,6 +26,7 @@ struct SlabDims {
   long n;            // doubles per component (without halo planes)
   long ucs;          // doubles per displacement / moduli component including its 4 spare planes
   long block;        // doubles per all-to-all block
+  bool loopback;     // test mode: a rank's own blocks / planes travel through the transport too (send / receive to itself)
 };
 
 inline SlabDims slab_dims(int nx, int ny, int nz, int nranks, int rank) {
@@ -39,6 +40,7 @@ inline SlabDims slab_dims(int nx, int ny, int nz, int nranks, int rank) {
   d.n = g.n;
   d.ucs = g.n + 4 * g.nyzp;
   d.block = (long)d.nxl * d.nyl * g.nzp;
+  d.loopback = false;
   return d;
 }
 
@@ -47,7 +49,7 @@ inline long slab_hi_plane(const SlabDims& d) { return (long)d.nxl; }        // c
 inline long slab_lo_plane(const SlabDims& d) { return (long)d.nxl + 3; }    // copy of the left neighbour's last plane
 
 // Ops of one exchange for `d.rank`, peers other than itself only (a rank's own all-to-all block is a local copy, see
-// `self`).  Offsets and counts in doubles relative to the start of the named buffer.
+// `self`; with d.loopback -- the single-GPU test of the RCCL transport -- the rank is its own peer instead).  Offsets and counts in doubles relative to the start of the named buffer.
 struct SlabPlan {
   std::vector<fg_plan_op> ops;
   fg_plan_op self_src, self_dst;   // count == 0: nothing to copy locally
@@ -76,22 +78,24 @@ inline SlabPlan slab_plan(const SlabDims& d, int what, int comp) {
       const int to = what == FG_PLAN_A2A_FORWARD ? FG_BUF_SPECTRUM_Y : FG_BUF_SPECTRUM_X;
       const long base = (long)comp * d.n;
       for (int q = 0; q < P; ++q) {
-        if (q == me) continue;
+        if (q == me && !d.loopback) continue;
         p.ops.push_back(plan_op(0, q, to, base + q * d.block, d.block));
       }
       for (int q = 0; q < P; ++q) {
-        if (q == me) continue;
+        if (q == me && !d.loopback) continue;
         p.ops.push_back(plan_op(1, q, from, base + q * d.block, d.block));
       }
-      p.self_src = plan_op(1, me, from, base + me * d.block, d.block);
-      p.self_dst = plan_op(0, me, to, base + me * d.block, d.block);
+      if (!d.loopback) {
+        p.self_src = plan_op(1, me, from, base + me * d.block, d.block);
+        p.self_dst = plan_op(0, me, to, base + me * d.block, d.block);
+      }
       break;
     }
     case FG_PLAN_HALO_U:      // three displacement components: plane 0 -> left's hi plane, last plane -> right's lo plane
     case FG_PLAN_HALO_MODULI: {
       const int buf = what == FG_PLAN_HALO_U ? FG_BUF_U : FG_BUF_MODULI;
       const int nc = what == FG_PLAN_HALO_U ? 3 : 2;
-      if (P == 1) break;   // periodic inside the slab: the driver copies its own planes
+      if (P == 1 && !d.loopback) break;   // periodic inside the slab: the driver copies its own planes
       for (int c = 0; c < nc; ++c) {
         const long b = (long)c * d.ucs;
         p.ops.push_back(plan_op(0, left, buf, b + slab_lo_plane(d) * d.plane, d.plane));
@@ -105,7 +109,7 @@ inline SlabPlan slab_plan(const SlabDims& d, int what, int comp) {
       break;
     }
     case FG_PLAN_HALO_TAU: {  // strain-state pipeline: tau0 last plane -> right, (tau5, tau4) first planes -> left
-      if (P == 1) break;
+      if (P == 1 && !d.loopback) break;
       p.ops.push_back(plan_op(0, left, FG_BUF_HALO_RECV_LO, 0, d.plane));         // tau0 of plane -1
       p.ops.push_back(plan_op(0, right, FG_BUF_HALO_RECV_HI, 0, 2 * d.plane));    // tau5, tau4 of plane nxl
       p.ops.push_back(plan_op(1, right, FG_BUF_HALO_SEND_HI, 0, d.plane));

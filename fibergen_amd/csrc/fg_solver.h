@@ -64,6 +64,7 @@ struct SolverOptions {
   int u_tile = 8;               // fast displacement sweep (u_loop = 2) as the LDS-tiled marching kernel where the grid allows:
                                 // rows per workgroup (8, 12, 16), 0 = off.  512^3: 2.8 -> 1.95 ms per sweep
   int laminate_overlap = 1;     // displacement loop with laminate mixing: interface kernels on a second stream beside the sweep
+  int slab_loopback = 0;        // test mode: a lone slab sends to itself through its transport (see Solver::slab_loopback)
   int slab_split = -1;          // slab driver: all-to-all per component, overlapping the next component's transforms (1), one
                                 // exchange for the three components (0), or by slab size (-1)
   int fuse_z = 0;               // attach the z r2c transform to the untiled fast sweep (u_tile = 0): 1 on, 0 off, -1 by size
@@ -151,6 +152,7 @@ class Solver {
   // slab driver below the ABI (fg_slab.hip): transport + the group of members this process drives
   bool is_slab() const { return slab_layout_; }
   void connect(std::unique_ptr<Comm> comm, std::shared_ptr<SlabGroup> group);
+  bool has_group() const { return (bool)group_; }
   SlabGroup& slab_group();          // throws unless connected (a lone nranks = 1 slab connects to itself)
   const char* transport() const { return comm_ ? comm_->name() : (slab_layout_ && nranks_ == 1 ? "self" : ""); }
 
@@ -211,6 +213,7 @@ class Solver {
   void slab_reduce(int slot, int n, bool min_op);        // all-reduce of dscal_ slots on the comm stream
   void slab_exchange(int what, int comp, int done_slot);
   double* slab_buffer(int id);
+  bool slab_loopback() const;
   bool slab_split() const;                               // all-to-all per component (overlap) or once for all three
   void comm_begin();
   void comm_end(int slot);

@@ -85,7 +85,8 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled), fuse_z (untiled sweep with the z transform attached),
  * laminate_overlap (1 = default: the interface kernels of the laminate correction run on a second stream beside the
  * displacement sweep; 0 = one stream), slab_split (slab driver: 1 = one all-to-all per component, overlapping the transforms of the next component; 0 = one
- * exchange for the three components; -1 = by slab size, default). */
+ * exchange for the three components; -1 = by slab size, default), slab_loopback (test mode on one GPU: a lone slab that is
+ * connected to a transport sends its all-to-all blocks and halo planes to itself through that transport). */
 int fg_set_option_d(fg_solver* s, const char* key, double value);
 int fg_set_option_i(fg_solver* s, const char* key, long value);
 

@@ -129,3 +129,44 @@ def test_errors():
         g.run(E_LOAD)
     assert g.members[0].transport == "local"
     g.close()
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("grid,mixing", [((8, 16, 128), "voigt"), ((16, 16, 16), "laminate")])
+def test_rccl_transport_loopback_on_one_gpu(grid, mixing, split):
+    """The RCCL transport itself, as far as ONE GPU allows: a lone slab with its own RCCL communicator (size 1) in loop-back
+    mode -- every all-to-all block and halo plane goes out through ncclSend and comes back through ncclRecv (same rank,
+    inside one group, built from the same exchange plan as for P ranks with the rank as its own peer), the norms through
+    ncclAllReduce, all on the second stream with the event choreography of the multi-GPU run.  Covers the library loading
+    (dlopen, symbols), the call signatures, counts and pointers, and the stream ordering; not covered: more than one rank."""
+    from fibergen_amd.distributed import SlabMember, rccl_unique_id
+    mats, phis, normals = two_phase_setup(grid, mixing)
+    m = SlabMember(*grid, 1.0, 2.0, 1.5, rank=0, nranks=1)
+    m.connect_rccl(rccl_unique_id())
+    assert m.transport == "rccl"
+    m.set_num_phases(2)
+    for p in range(2):
+        m.set_phase(p, mats[p][0], mats[p][1], phis[p])
+    m.set_normals(normals)
+    m.set_options(mixing_rule=mixing, tol=1e-8, slab_loopback=1, slab_split=split)
+    o = make_oracle(grid, (1.0, 2.0, 1.5), mixing, tol=1e-8)
+    assert o.run(E_LOAD) is False and m.run(E_LOAD) is False
+    assert m.iterations == o.iterations
+    assert np.abs(np.array(m.residuals) - np.array(o.residuals)).max() < 1e-11
+    assert rel_err(m.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(m.mean_stress(), o.mean_stress()) < 1e-10
+    assert m.ref_material[0] == pytest.approx(o.mu_0, rel=1e-14)
+    m.close()
+
+
+def test_rccl_loopback_beside_pytorch():
+    """the same with PyTorch loaded first (bench.py under torchrun): one RCCL in the process, the one already mapped"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_loopback_worker.py")], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("OK")][-1]
+    assert line.count("librccl") == 1, line     # exactly one RCCL mapped: shared with PyTorch, not a second copy
