@@ -53,6 +53,18 @@ def main():
             v = timeit(g)
             out["slab_groups"]["P=%d split=%d" % (P, split)] = {"it_s": v, "ratio": v / base}
             g.close()
+    # the RCCL transport in loop-back: one slab whose blocks / planes / norms go through ncclSend / ncclRecv / ncclAllReduce to
+    # itself on the second stream -- what the RCCL calls themselves cost per pass (on-device copies, no link)
+    from fibergen_amd.distributed import SlabMember, rccl_unique_id
+    out["rccl_loopback"] = {}
+    for split in (0, 1):
+        m = SlabMember(*n, rank=0, nranks=1)
+        m.connect_rccl(rccl_unique_id())
+        configure(m, phi, normals, a.mixing, "elasticity")
+        m.set_options(slab_loopback=1, slab_split=split)
+        v = timeit(m)
+        out["rccl_loopback"]["split=%d" % split] = {"it_s": v, "ratio": v / base}
+        m.close()
     print(json.dumps(out))
 
 
