@@ -97,13 +97,10 @@ void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const Field
 // interface voxels (some phase fraction strictly between 0 and 1): allocates and fills the list of their element
 // offsets in voxel order (*list, hipFree by the caller), returns the count
 unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned** list, hipStream_t s);
-// laminate mixing as a correction of the Voigt sweep (see k_laminate_delta): the voxels whose divergence stencil touches
+// laminate mixing as a correction of the Voigt sweep (see k_interface_strain): the voxels whose divergence stencil touches
 // an interface voxel, in voxel order, with 8 slots each (*aff, *slots allocated here); per pass the polarisation
 // difference at the interface voxels [n][6] and its divergence added to f
 unsigned launch_affected_list(const Grid& g, const unsigned* list, unsigned n, unsigned** aff, int** slots, hipStream_t s);
-void launch_laminate_delta(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
-                           const FieldPtrs<3>& normals, const Vec6& E, const unsigned* list, unsigned n, double* dtau,
-                           int* error_flag, hipStream_t s);
 // laminate correction in compact form (see k_interface_strain): static copies of the phase fractions [nph][n] and normals
 // [3][n] of the interface voxels (once per geometry), and per pass eps_j -> d_j (epsc: scratch [6][n], dtau: [n][6])
 void launch_interface_static(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& normals,

@@ -875,8 +875,8 @@ __global__ __launch_bounds__(kBlock) void k_mixed_list(Grid g, int nph, FieldPtr
 // Laminate mixing in the displacement loop (u_loop = 2).  The divergence is linear in the polarisation, so
 //   f = div tau_voigt + div (tau_laminate - tau_voigt),
 // and the second term lives on the interface voxels only: the tiled Voigt sweep runs unchanged over all voxels, then
-//   k_laminate_delta   d_j = P_laminate(eps_j) - P_voigt(eps_j) for every interface voxel j (eps from u by the strain
-//                      stencil, the one-step Newton solve of laminate_split), stored compactly [j][6];
+//   k_interface_*      d_j = P_laminate(eps_j) - P_voigt(eps_j) for every interface voxel j (eps from u by the strain
+//                      stencil, the one-step Newton solve of laminate_split), stored compactly [j][6] (see below);
 //   k_delta_div        every voxel whose divergence stencil touches an interface voxel adds div d to its f, gathering d
 //                      through seven precomputed slots (self, x-1, x+1, y-1, y+1, z-1, z+1; -1 = not an interface voxel).
 // One writer per voxel, fixed operation order: deterministic, no atomics.  The lists are built once per geometry.
@@ -931,40 +931,8 @@ __global__ __launch_bounds__(kBlock) void k_affected_list(Grid g, const int* map
   if (!aff && threadIdx.x == 0) counts[blockIdx.x] = base;
 }
 
-template <int NPH>
-__global__ __launch_bounds__(kBlock) void k_laminate_delta(Grid g, StressParams sp, FieldPtrs<3> u, FieldPtrs<kMaxPhases> phi,
-                                                           FieldPtrs<3> normals, Vec6 E, const unsigned* list, unsigned n,
-                                                           double* dtau, int* error_flag) {
-  const double hx = g.hx, hy = g.hy, hz = g.hz;
-  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-    const long off = list[idx];
-    const long row = off / g.nzp;
-    const int k = (int)(off - row * g.nzp);
-    const int i = (int)(row / g.ny), j = (int)(row - (long)i * g.ny);
-    const VoxelNeighbours nb = voxel_neighbours(g, i, j, k);
-    const double u0 = u.p[0][off], u1 = u.p[1][off], u2 = u.p[2][off];
-    double F[6];
-    // epsOperatorStaggered  F:18632-18686, the expressions of k_u_stress for one voxel
-    F[3] = E.v[3] + 0.5 * ((u2 - u.p[2][off + nb.yb]) * hy + (u1 - u.p[1][off + nb.zb]) * hz);
-    F[4] = E.v[4] + 0.5 * ((u2 - u.p[2][off + nb.xb]) * hx + (u0 - u.p[0][off + nb.zb]) * hz);
-    F[5] = E.v[5] + 0.5 * ((u1 - u.p[1][off + nb.xb]) * hx + (u0 - u.p[0][off + nb.yb]) * hy);
-    F[0] = E.v[0] + (u.p[0][off + nb.xf] - u0) * hx;
-    F[1] = E.v[1] + (u.p[1][off + nb.yf] - u1) * hy;
-    F[2] = E.v[2] + (u.p[2][off + nb.zf] - u2) * hz;
-    double ph[NPH], nv[3], Pl[6], Pv[6];
-#pragma unroll
-    for (int q = 0; q < NPH; ++q) ph[q] = q < sp.pt.n ? phi.p[q][off] : 0.0;
-    nv[0] = normals.p[0][off]; nv[1] = normals.p[1][off]; nv[2] = normals.p[2][off];
-    // the reference-medium part of the polarisation is the same in both and cancels
-    if (pk1_laminate<NPH>(F, ph, nv, sp.pt, sp.alpha, false, sp.eps_g, sp.eps_a, Pl)) atomicOr(error_flag, 1);
-    pk1_voigt<NPH>(F, ph, sp.pt, sp.alpha, false, Pv);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) dtau[(long)idx * 6 + c] = Pl[c] - Pv[c];
-  }
-}
-
 // ---- laminate correction, compact form ---------------------------------------------------------------------------------
-// d_j = tau_laminate - tau_voigt of the interface voxels in two kernels instead of k_laminate_delta's one:
+// d_j = tau_laminate - tau_voigt of the interface voxels in two kernels (round 1: one, k_laminate_delta):
 //   k_interface_strain  eps_j from u by the strain stencil -- a light gather kernel at full occupancy (the scattered loads
 //                       are what costs), compact SoA [6][n] in list order;
 //   k_interface_solve   d_j from eps_j, the phase fractions and the normal, all compact and coalesced (static copies made
@@ -1501,19 +1469,6 @@ void launch_interface_delta(const Grid& g, const StressParams& sp, const FieldPt
   hipLaunchKernelGGL(k_interface_strain, grid, dim3(kBlock), 0, s, g, u, E, list, n, epsc);
   if (sp.pt.n <= 2) hipLaunchKernelGGL((k_interface_solve<2>), grid, dim3(kBlock), 0, s, sp, epsc, phic, nrmc, n, dtau, error_flag);
   else hipLaunchKernelGGL((k_interface_solve<kMaxPhases>), grid, dim3(kBlock), 0, s, sp, epsc, phic, nrmc, n, dtau, error_flag);
-  FG_HIP_CHECK(hipGetLastError());
-}
-
-void launch_laminate_delta(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
-                           const FieldPtrs<3>& normals, const Vec6& E, const unsigned* list, unsigned n, double* dtau,
-                           int* error_flag, hipStream_t s) {
-  if (n == 0) return;
-  const dim3 grid(grid_for((long)n, 1 << 16));
-  if (sp.pt.n <= 2)
-    hipLaunchKernelGGL((k_laminate_delta<2>), grid, dim3(kBlock), 0, s, g, sp, u, phi, normals, E, list, n, dtau, error_flag);
-  else
-    hipLaunchKernelGGL((k_laminate_delta<kMaxPhases>), grid, dim3(kBlock), 0, s, g, sp, u, phi, normals, E, list, n, dtau,
-                       error_flag);
   FG_HIP_CHECK(hipGetLastError());
 }
 

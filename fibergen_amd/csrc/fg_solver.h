@@ -165,6 +165,7 @@ class Solver {
  private:
   // one pass  dst = E - Gamma0 : (C - C0) : src  (defaults: the solver's strain field, in place)
   void basic_scheme(const double* E6, double* src = nullptr, double* dst = nullptr);
+  void release();
   bool run_one_step(const double* E0, const double* S0);
   double current_norm9();
   bool run_cg(const double* E0, const double* S0, double prev0);
@@ -243,7 +244,7 @@ class Solver {
   SolverOptions opt_;
   PhaseTable pt_;
   int device_;
-  hipStream_t stream_;
+  hipStream_t stream_ = nullptr;
   int rank_ = 0, nranks_ = 1;
   int nxg_ = 0;        // global nx (g_.nx is the local slab thickness)
   int nyl_ = 0;        // ny / nranks: thickness of the y-slab after the transpose
@@ -299,8 +300,8 @@ class Solver {
   double E_next_[6] = {0, 0, 0, 0, 0, 0};
   bool timing_ = false;
   StageTimes times_;
-  hipEvent_t ev_[2];
-  hipEvent_t ev_copy_;
+  hipEvent_t ev_[2] = {nullptr, nullptr};
+  hipEvent_t ev_copy_ = nullptr;
   hipStream_t aux_stream_ = nullptr;    // second stream of the laminate correction (created on first use) + fork / join events
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   bool pending_back_ = false;  // run(): the sweep of this pass is enqueued, its FFT chain not yet

@@ -46,6 +46,7 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   if (ndev < 1) throw std::runtime_error("no HIP device available: fibergen_amd needs an AMD GPU (gfx950)");
   if (device < 0 || device >= ndev) throw std::runtime_error("invalid device index");
   FG_HIP_CHECK(hipSetDevice(device));
+  try {   // a failure half way (out of memory at 512^3, say) must give everything back: the destructor will not run
   if (shared_stream) {
     stream_ = shared_stream;
     owns_stream_ = false;
@@ -126,11 +127,21 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   recompute_bc();
   reset_stage_times();
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  } catch (...) {
+    release();
+    throw;
+  }
 }
 
 Solver::~Solver() {
   (void)hipSetDevice(device_);
   if (group_) group_->invalidate();
+  release();
+}
+
+// frees every device / host resource the object holds (idempotent; also the constructor's failure path)
+void Solver::release() {
+  if (!stream_) return;
   (void)hipStreamSynchronize(stream_);
   if (comm_stream_ && comm_stream_ != stream_) (void)hipStreamSynchronize(comm_stream_);
   fft_.reset();
@@ -153,9 +164,8 @@ Solver::~Solver() {
     if (g0_kp_[a]) (void)hipFree(g0_kp_[a]);
     if (xi_[a]) (void)hipFree(xi_[a]);
   }
-  (void)hipEventDestroy(ev_[0]);
-  (void)hipEventDestroy(ev_[1]);
-  (void)hipEventDestroy(ev_copy_);
+  for (hipEvent_t e : {ev_[0], ev_[1], ev_copy_})
+    if (e) (void)hipEventDestroy(e);
   if (aux_stream_) {
     (void)hipStreamSynchronize(aux_stream_);
     (void)hipStreamDestroy(aux_stream_);
@@ -172,6 +182,7 @@ Solver::~Solver() {
     if (e) (void)hipEventDestroy(e);
   if (owns_comm_stream_ && comm_stream_) (void)hipStreamDestroy(comm_stream_);
   if (owns_stream_) (void)hipStreamDestroy(stream_);
+  stream_ = comm_stream_ = nullptr;
 }
 
 // ------------------------------------------------------------------ configuration
@@ -814,7 +825,7 @@ void Solver::u_pass_front(const double* E6) {
       launch_u_fast(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, stream_);
     if (laminate) {
       // laminate mixing = the Voigt sweep over all voxels + the divergence of (tau_laminate - tau_voigt), which lives
-      // on the interface voxels (lists built once per geometry, see k_laminate_delta)
+      // on the interface voxels (lists built once per geometry, see k_interface_strain)
       FieldPtrs<3> nrm;
       for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
       // d depends on u only: its two kernels (a light gather, a short solve) run on a second stream beside the sweep

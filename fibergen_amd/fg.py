@@ -371,7 +371,8 @@ class FG:
             phi, normals, real_vf = geometry.voxelize(self._fibers, shape, self._dims, self._x0, nph, self._matrix_mat,
                                                       want_normals=(self._want_normals or self._mixing == "laminate"),
                                                       smooth_levels=self._solver_int("smooth_levels", -1),
-                                                      smooth_tol=self._solver_float("smooth_tol", 0.001))
+                                                      smooth_tol=self._solver_float("smooth_tol", 0.001),
+                                                      device=self._device)
             if normals is not None:
                 self._normals = normals
             self._real_vf = real_vf

@@ -415,6 +415,7 @@ class LSOracle:
         self.S = np.zeros(6)
         self.callback = None
         self.error = None
+        self._F00 = np.zeros(6)
         self._set_bc_projector(self.BC_P)
 
     # -- constitutive ----------------------------------------------------

@@ -1,14 +1,14 @@
 import sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from fibergen_amd import LSSolver
-from fibergen_amd.rve import synthetic_fiber_rve
+from fibergen_amd.rve import bench_rve
 from helpers import INCLUSION, MATRIX, lame
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 mixing = sys.argv[2] if len(sys.argv) > 2 else "voigt"
-scale = max(n, 128) / 128.0
-phi, normals = synthetic_fiber_rve((n, n, n), K=int(round(40 * scale ** 3)), R=0.05 / scale, L=0.4 / scale, seed=0,
-                                   with_normals=(mixing == "laminate"))
+phi, normals, _ = bench_rve(n, mixing)
 for method in ("cg", "basic"):
     s = LSSolver(n, n, n)
     s.set_num_phases(2)
