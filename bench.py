@@ -248,7 +248,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=7, help="the K-step region is timed this many times; the median is reported")
     ap.add_argument("--sustain-s", type=float, default=2.0)
-    ap.add_argument("--n", type=int, default=256, help="grid size per axis (128, 256, 512 are the BASELINE sizes; any size runs)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=256, help="grid size per axis (128, 256, 512 are the BASELINE sizes; any size runs)")
     ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
     ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat", "viscosity"])
     ap.add_argument("--also", default="128:voigt,512:laminate",
@@ -261,6 +261,9 @@ def main():
                     help="N = 1: also run the slab driver with this many slabs on the one GPU (0 = skip)")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the load-case replica measurement")
     ap.add_argument("--slab-timeout", type=int, default=300)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N > 1: torch.distributed backend.  gloo is the dry run of this script's multi-rank path on a box with "
+                         "ONE GPU: all ranks share device 0 and the slab exchanges are staged through the host")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -367,8 +370,13 @@ def main():
     # is loaded so that both share one HIP runtime (same soname).
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dry = args.dist_backend == "gloo"
+    if dry:
+        local_rank = 0
+        dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from fibergen_amd import LSSolver
     from fibergen_amd.distributed import DistributedLSSolver
     from fibergen_amd.rve import bench_rve
@@ -382,7 +390,7 @@ def main():
         dist.barrier()
 
     def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device="cuda:%d" % local_rank)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dry else "cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -450,6 +458,8 @@ def main():
         })
         line["config"]["parallelism"] = ("x-slabs x%d: ONE problem, displacement loop per slab, per component one RCCL all-to-all "
                                          "each way between the FFT axes, +-1 halo planes of u, norms all-reduced" % world)
+        if dry:
+            line["config"]["parallelism"] += " -- DRY RUN: all ranks on one GPU, exchanges staged through the host (gloo)"
         d.close()
     except Exception as e:  # noqa: BLE001
         line.update({"value": replicas["value"] if replicas else None, "ms_per_step": replicas["ms_per_step"] if replicas else None,
