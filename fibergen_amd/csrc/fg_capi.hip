@@ -243,6 +243,7 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       v.invalidate_interface_lists();
     }
     else if (k == "fuse_x") o.fuse_x = value != 0;
+    else if (k == "phi_sweep") o.phi_sweep = value != 0;
     else if (k == "laminate_overlap") o.laminate_overlap = value != 0;
     else if (k == "slab_loopback") o.slab_loopback = value != 0;
     else if (k == "slab_split") o.slab_split = value < 0 ? -1 : (value != 0);

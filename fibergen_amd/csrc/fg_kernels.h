@@ -78,8 +78,11 @@ bool u_tile_supported(const Grid& g);
 // f = div((C - C0) : eps) with the effective moduli of k_effective_moduli, sum6 = sums of the polarisation components
 void launch_eps_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<6>& eps, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& f, double* partial, double* sum6, hipStream_t s);
+// two_phase != nullptr: mod.p[0] is phi_1 of two complementary phases (launch_complement_check), the sweep forms the moduli
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
-                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s, bool sum_tau = false);
+                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s, bool sum_tau = false,
+                   const PhaseTable* two_phase = nullptr);
+void launch_complement_check(const Grid& g, const double* phi0, const double* phi1, int* flag, hipStream_t s);
 bool u_fast_z_supported(const Grid& g);
 void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, const cplx* tw_z,

@@ -310,10 +310,18 @@ __device__ unsigned long long g_k1_probe[kK1ProbeBlocks][kK1ProbeSlots];
 #define FG_K1_MARK(slot) do { } while (0)
 #endif
 
-template <int TYR, int ZS, bool SUMT>
+// PHI2: two complementary phases (phi_0 = 1 - phi_1 everywhere, checked by the caller): the sweep reads phi_1 (mod.p[0]) and
+// forms the effective moduli itself, A = 2 mu_0 + phi_1 (2 mu_1 - 2 mu_0), B likewise -- 8 bytes per voxel less than the two
+// precomputed arrays (64 -> 56 B/voxel, the algorithmic figure).  lin = {2 mu_0 + beta, 2 (mu_1 - mu_0), lambda_0 + gamma,
+// lambda_1 - lambda_0} of the two phases.
+struct PhaseLin {
+  double a0, da, b0, db;
+};
+
+template <int TYR, int ZS, bool SUMT, bool PHI2>
 __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, double beta, double gamma, FieldPtrs<3> u,
                                                                       FieldPtrs<2> mod, FieldPtrs<3> fo, Vec6 E, double* partial,
-                                                                      int nty, int ntz, int LX, int nt) {
+                                                                      int nty, int ntz, int LX, int nt, PhaseLin lin) {
   constexpr bool FULLROW = ZS > 0;
   constexpr int NZS = ZS ? ZS : 1;        // waves per row
   constexpr int TYU = TYR - 2;            // rows with output
@@ -401,7 +409,9 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
     const long o2 = plane(q + 2), oq = plane(q);
 #pragma unroll
     for (int c = 0; c < 3; ++c) u2[c] = ld2(u.p[c], o2);
-    const double2 Ac = ld2(mod.p[0], oq), Bc = ld2(mod.p[1], oq);
+    const double2 Ac = ld2(mod.p[0], oq);
+    double2 Bc = Ac;
+    if (!PHI2) Bc = ld2(mod.p[1], oq);
     // ---- y neighbours of u through LDS
 #pragma unroll
     for (int c = 0; c < 3; ++c) Ub[c][r][li] = uc[c];
@@ -432,7 +442,8 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
     e5.x = E.v[5] + 0.5 * (dx1.x * hx + (uc[0].x - U0yb.x) * hy);
     e5.y = E.v[5] + 0.5 * (dx1.y * hx + (uc[0].y - U0yb.y) * hy);
     // ---- polarisation  tau = (A - 2 mu0) eps + (B - lambda0) tr(eps) I
-    const double ax = Ac.x + beta, ay = Ac.y + beta, bx = Bc.x + gamma, by = Bc.y + gamma;
+    const double ax = PHI2 ? lin.a0 + Ac.x * lin.da : Ac.x + beta, ay = PHI2 ? lin.a0 + Ac.y * lin.da : Ac.y + beta;
+    const double bx = PHI2 ? lin.b0 + Bc.x * lin.db : Bc.x + gamma, by = PHI2 ? lin.b0 + Bc.y * lin.db : Bc.y + gamma;
     const double trx = e0.x + e1.x + e2.x, try_ = e0.y + e1.y + e2.y;
     double2 t0, t1, t2, t3, t4, t5;
     t0.x = e0.x * ax + bx * trx; t0.y = e0.y * ay + by * try_;
@@ -807,9 +818,10 @@ bool u_tile_supported(const Grid& g) {
   return g.nz % 2 == 0 && nzh >= 62 && g.ny >= 14 && g.nx >= 4;
 }
 
-template <int TYR, int ZS, bool SUMT>
+template <int TYR, int ZS, bool SUMT, bool PHI2 = false>
 void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
-                     const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s) {
+                     const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s,
+                     const PhaseLin& lin = PhaseLin{0, 0, 0, 0}) {
   constexpr int NZS = ZS ? ZS : 1;
   constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
   const int nzh = g.nz / 2;
@@ -833,12 +845,12 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
   static PerDeviceOnce configured;
   if (configured.first_use()) {
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, ZS, SUMT>),
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, ZS, SUMT, PHI2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   const int nt = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
-  hipLaunchKernelGGL((k_u_tile<TYR, ZS, SUMT>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E,
-                     partial, nty, ntz, LX, nt);
+  hipLaunchKernelGGL((k_u_tile<TYR, ZS, SUMT, PHI2>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E,
+                     partial, nty, ntz, LX, nt, lin);
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, SUMT ? 12 : 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
@@ -846,8 +858,22 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s,
-                   bool sum_tau) {
+                   bool sum_tau, const PhaseTable* two_phase) {
   const int nzh = g.nz / 2;
+  if (two_phase) {   // mod.p[0] is phi_1 of two complementary phases: the default tile shapes
+    const PhaseLin lin = {2 * two_phase->mu[0] - 2 * mu_0, 2 * (two_phase->mu[1] - two_phase->mu[0]),
+                          two_phase->lambda[0] - lambda_0, two_phase->lambda[1] - two_phase->lambda[0]};
+#define FG_PHI(R, Z)                                                                                                  \
+  do {                                                                                                                \
+    if (sum_tau) launch_u_tile_t<R, Z, true, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s, lin);        \
+    else launch_u_tile_t<R, Z, false, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s, lin);               \
+  } while (0)
+    if (nzh == 64) FG_PHI(8, 1);
+    else if (nzh == 128) FG_PHI(6, 2);
+    else FG_PHI(8, 0);
+#undef FG_PHI
+    return;
+  }
   if (sum_tau) {   // sumsq6[0..5] sums of squares of the strain, sumsq6[6..11] sums of the polarisation
     if (nzh == 64) launch_u_tile_t<8, 1, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
     else if (nzh == 128) launch_u_tile_t<6, 2, true>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s);
@@ -867,6 +893,29 @@ void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
     else FG_TILE(8, 0);
   }
 #undef FG_TILE
+}
+
+// *flag := 0 unless phi0 == 1 - phi1 bit for bit at every voxel (what normalizePhi F:17613-17626 produces for two phases);
+// the caller sets *flag = 1 beforehand
+__global__ __launch_bounds__(kBlock) void k_complement_check(Grid g, const double* phi0, const double* phi1, int* flag) {
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  bool bad = false;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / g.nzc;
+    const int k = 2 * (int)(i - row * g.nzc);
+    if (k >= g.nz) continue;
+    const double2 a = ld2(phi0, 2 * i), b = ld2(phi1, 2 * i);
+    bad = bad || (a.x != 1.0 - b.x) || (k + 1 < g.nz && a.y != 1.0 - b.y);
+  }
+  if (bad) *flag = 0;
+}
+
+void launch_complement_check(const Grid& g, const double* phi0, const double* phi1, int* flag, hipStream_t s) {
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  long nb = (npairs + kBlock - 1) / kBlock;
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(k_complement_check, dim3((unsigned)nb), dim3(kBlock), 0, s, g, phi0, phi1, flag);
+  FG_HIP_CHECK(hipGetLastError());
 }
 
 // Tiled marching form of the scalar sweep, the one-component sibling of k_u_tile: a workgroup of TYR rows (one or ZS

@@ -211,7 +211,11 @@ void Solver::slab_moduli_step() {
   FieldPtrs<2> mod;
   mod.p[0] = smod_;
   mod.p[1] = smod_ + ucs_;
-  launch_effective_moduli(g_, phase_table(), phase_ptrs(), mod, stream_);
+  // two complementary phases: the sweep reads phi_1 (with its halo planes) and forms the moduli itself.  The decision is
+  // local data; every rank of a run sees the same kind of phase fields (normalizePhi output or not)
+  slab_phi_ = two_phase_complementary();
+  if (slab_phi_) FG_HIP_CHECK(hipMemcpyAsync(smod_, phi_ + g_.n, (size_t)g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+  else launch_effective_moduli(g_, phase_table(), phase_ptrs(), mod, stream_);
   slab_exchange(FG_PLAN_HALO_MODULI, 0, kXModuli);
   smod_dirty_ = false;
 }
@@ -227,8 +231,9 @@ void Solver::slab_front_fast(const double* E6, bool sum_tau) {
   mod.p[0] = smod_;
   mod.p[1] = smod_ + ucs_;
   time_begin(0);
+  const PhaseTable pt2 = phase_table();
   launch_u_tile(gu_, opt_.mu_0, opt_.lambda_0, strided3(su_[su_cur_], ucs_), mod, ptrs3(fu_), E, partial_, dscal_ + kSlotSumSq,
-                opt_.u_tile, stream_, sum_tau);
+                opt_.u_tile, stream_, sum_tau, slab_phi_ ? &pt2 : nullptr);
   time_end(0);
   slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
 }

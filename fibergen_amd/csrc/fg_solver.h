@@ -63,6 +63,7 @@ struct SolverOptions {
   int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
   int u_tile = 8;               // fast displacement sweep (u_loop = 2) as the LDS-tiled marching kernel where the grid allows:
                                 // rows per workgroup (8, 12, 16), 0 = off.  512^3: 2.8 -> 1.95 ms per sweep
+  int phi_sweep = 1;            // two complementary phases: the tiled sweep reads phi_1 instead of the two moduli arrays
   int laminate_overlap = 1;     // displacement loop with laminate mixing: interface kernels on a second stream beside the sweep
   int slab_loopback = 0;        // test mode: a lone slab sends to itself through its transport (see Solver::slab_loopback)
   int slab_split = -1;          // slab driver: all-to-all per component, overlapping the next component's transforms (1), one
@@ -103,7 +104,7 @@ class Solver {
 
   const Grid& grid() const { return g_; }
   SolverOptions& options() { return opt_; }
-  void invalidate_moduli() { mod_dirty_ = smod_dirty_ = true; }
+  void invalidate_moduli() { mod_dirty_ = smod_dirty_ = complement_dirty_ = true; }
   void invalidate_interface_lists() { mixed_dirty_ = true; }   // which lists exist depends on u_tile
   void reference_material_changed() { recompute_bc(); }   // (mu_0, lambda_0) set from outside: M, MQ depend on C0
   hipStream_t stream() const { return stream_; }
@@ -172,6 +173,7 @@ class Solver {
   bool run_cg_scalar(const double* E0, double prev0);  // heat / porous: CG in potential space
   bool run_cg_u(const double* E0, double prev0);      // the same CG carried in displacement space (Voigt, prescribed mean strains)
   bool u_loop_eligible(bool allow_mixed_bc = false) const;
+  bool two_phase_complementary();       // phi_0 == 1 - phi_1 everywhere (checked once per geometry)
   FieldPtrs<2> effective_moduli();      // per-voxel sums of the phase moduli for the fast kernels (allocated on first use)
   void build_laminate_lists();          // interface / affected voxel lists of the laminate correction (once per geometry)
   void u_pass_front(const double* E6);  // u_k (fu_) -> sums of squares of eps_k, f_{k+1} (fu_alt_)
@@ -236,6 +238,7 @@ class Solver {
   bool su_valid_ = false;               // su_[su_cur_] (with valid halo planes) is the state: eps = E_cur_ + sym grad u
   double* smod_ = nullptr;              // effective moduli, 2 components of ucs_ doubles
   bool smod_dirty_ = true;
+  bool slab_phi_ = false;               // smod_ component 0 holds phi_1 (two complementary phases), not the moduli
   long ucs_ = 0;
   Grid gu_;                             // g_ with the halo-plane mapping of the marching sweep
   std::unique_ptr<Fft3> fft_ys_;        // x pass + Green operator on the y-slab [nxg][nyl][nzc]
@@ -267,6 +270,7 @@ class Solver {
   double *lam_phic_ = nullptr, *lam_nrmc_ = nullptr, *lam_epsc_ = nullptr;
   double* mod_ = nullptr;      // 2: per-voxel effective moduli (sum phi 2 mu, sum phi lambda) of the fast sweep
   bool mod_dirty_ = true;
+  bool complement_dirty_ = true, complementary_ = false;
   double* fu_alt_ = nullptr;   // 3: second f/u buffer of the displacement-based loop (swapped with fu_)
   double* phi_ = nullptr;      // nphase
   double* normals_ = nullptr;  // 3 (allocated on demand)

@@ -77,7 +77,7 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   }
   FG_HIP_CHECK(hipMalloc(&dscal_, kNumSlots * sizeof(double)));
   FG_HIP_CHECK(hipHostMalloc(&hscal_, kNumSlots * sizeof(double)));
-  FG_HIP_CHECK(hipMalloc(&derr_, sizeof(int)));
+  FG_HIP_CHECK(hipMalloc(&derr_, 2 * sizeof(int)));   // [0] kernel error flag, [1] scratch of two_phase_complementary
   FG_HIP_CHECK(hipHostMalloc(&herr_, sizeof(int)));
   FG_HIP_CHECK(hipMemsetAsync(derr_, 0, sizeof(int), stream_));
 
@@ -196,6 +196,7 @@ void Solver::set_num_phases(int n) {
   pt_.n = n;
   mod_dirty_ = true;
   smod_dirty_ = true;
+  complement_dirty_ = true;
   mixed_dirty_ = true;
 }
 
@@ -203,6 +204,7 @@ void Solver::set_phase_material(int p, double mu, double lambda) {
   if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
   mod_dirty_ = true;
   smod_dirty_ = true;
+  complement_dirty_ = true;
   mixed_dirty_ = true;
   pt_.mu[p] = mu;
   pt_.lambda[p] = lambda;
@@ -212,6 +214,7 @@ void Solver::set_phase_field(int p, const double* phi_host) {
   if (p < 0 || p >= pt_.n) throw std::runtime_error("phase index out of range");
   mod_dirty_ = true;
   smod_dirty_ = true;
+  complement_dirty_ = true;
   mixed_dirty_ = true;
   upload_padded(phi_ + (long)p * g_.n, phi_host);
 }
@@ -714,6 +717,23 @@ bool Solver::u_loop_eligible(bool allow_mixed_bc) const {
   return allow_mixed_bc && opt_.u_loop >= 2 && opt_.u_tile && u_tile_supported(g_);   // Voigt, or laminate as its correction
 }
 
+// Two phases whose fractions are complementary bit for bit (phi_0 == 1 - phi_1: what normalizePhi leaves for two
+// materials), checked once per geometry on the device.  Option phi_sweep = 0 switches the shortcut off (A/B runs).
+bool Solver::two_phase_complementary() {
+  if (pt_.n != 2 || opt_.mode != 0 || !opt_.phi_sweep) return false;
+  if (complement_dirty_) {
+    int one = 1;
+    FG_HIP_CHECK(hipMemcpyAsync(derr_ + 1, &one, sizeof(int), hipMemcpyHostToDevice, stream_));
+    launch_complement_check(g_, phi_, phi_ + g_.n, derr_ + 1, stream_);
+    int flag = 0;
+    FG_HIP_CHECK(hipMemcpyAsync(&flag, derr_ + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    complementary_ = flag != 0;
+    complement_dirty_ = false;
+  }
+  return complementary_;
+}
+
 // A = sum_p phi_p 2 mu_p, B = sum_p phi_p lambda_p per voxel (k_effective_moduli), computed once per geometry
 FieldPtrs<2> Solver::effective_moduli() {
   if (!mod_) {
@@ -795,8 +815,8 @@ void Solver::u_pass_front(const double* E6) {
     eps_stale_ = true;
     return;
   } else if (opt_.u_loop >= 2) {
-    // fast variant: per-voxel effective moduli instead of the per-phase accumulation
-    const FieldPtrs<2> mod = effective_moduli();
+    // fast variant: per-voxel effective moduli instead of the per-phase accumulation (computed once per geometry, on
+    // first use: the tiled sweep of two complementary phases does without them)
     const bool laminate = opt_.mixing != kMixVoigt;
     if (laminate) {
       build_laminate_lists();
@@ -816,13 +836,24 @@ void Solver::u_pass_front(const double* E6) {
     if (opt_.u_tile && u_tile_supported(g_)) {
       z_done_ = false;
       const bool sum_tau = !(frobenius(BC_MQ_) < kEps);   // mixed BC: sums of tau land in kSlotMean
-      launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
-                    opt_.u_tile, stream_, sum_tau);
+      if (two_phase_complementary()) {
+        // two phases with phi_0 = 1 - phi_1: the sweep reads phi_1 and forms the moduli itself (8 B per voxel less)
+        FieldPtrs<2> ph;
+        ph.p[0] = phi_ + g_.n;
+        ph.p[1] = nullptr;
+        const PhaseTable t = phase_table();
+        launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), ph, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, opt_.u_tile,
+                      stream_, sum_tau, &t);
+      } else {
+        launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_,
+                      dscal_ + kSlotSumSq, opt_.u_tile, stream_, sum_tau);
+      }
     } else if (z_done_)
-      launch_u_fast_z(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
+      launch_u_fast_z(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
                       fft_->z_twiddles(), fft_->z_roots(), stream_);
     else
-      launch_u_fast(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), mod, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, stream_);
+      launch_u_fast(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
+                    stream_);
     if (laminate) {
       // laminate mixing = the Voigt sweep over all voxels + the divergence of (tau_laminate - tau_voigt), which lives
       // on the interface voxels (lists built once per geometry, see k_interface_strain)
