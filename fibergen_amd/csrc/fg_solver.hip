@@ -704,8 +704,9 @@ bool Solver::u_loop_eligible(bool allow_mixed_bc) const {
     // the scalar modes only have the potential-based loop
     if (nranks_ != 1) throw std::runtime_error("heat / porous mode is not available on slab-decomposed solvers");
     if (opt_.mixing != kMixVoigt) throw std::runtime_error("heat / porous mode supports Voigt mixing only");
-    if (opt_.bc_relax != 1.0 || frobenius(BC_MQ_) >= kEps)
-      throw std::runtime_error("heat / porous mode supports prescribed mean gradients only (projector = identity)");
+    if (opt_.bc_relax != 1.0) throw std::runtime_error("heat / porous mode does not support bc_relax != 1");
+    if (frobenius(BC_MQ_) >= kEps && !allow_mixed_bc)
+      throw std::runtime_error("heat / porous mode: mixed boundary conditions run with method=basic (fg_run_load_case) only");
     return pt_.n >= 1;
   }
   if (!(opt_.u_loop && opt_.mode == 0 && opt_.gamma_scheme == 0 && nranks_ == 1 && pt_.n >= 1 &&
@@ -1139,6 +1140,15 @@ bool Solver::run_one_step(const double* E0, const double* S0) {
       if (iter == 1 && fresh_step_)
         for (int i = 0; i < 6; ++i) E_cur_[i] = E[i];  // eps_1 = E (u_1 = 0)
       u_pass_front(E);
+      if (opt_.mode == 1 && mixed_bc) {
+        // heat / porous with mixed boundary conditions (initBCProjector in GammaOperatorStaggeredHeat F:20342-20350): the
+        // sweeps of the scalar modes carry no sums of tau, so <tau> = <P(g) - 2 mu0 g> is taken from the gradient field
+        // (two extra sweeps per pass; a rarely used combination)
+        ensure_eps();
+        launch_sc_flux_mean(g_, scalar_params(opt_.mu_0, 1.0 / (double)nglobal_), ptrs3(eps_), phase_ptrs(), partial_,
+                            dscal_ + kSlotMean, stream_);
+        eps_stale_ = true;
+      }
       pending_back = true;
       pending_back_ = true;   // fetch_norms_and_errors enqueues the FFT chain behind the copies
     } else {
@@ -1150,6 +1160,8 @@ bool Solver::run_one_step(const double* E0, const double* S0) {
       // applyBCProjector  F:20247-20270 with bc_relax = 1: eps_{k+1} = E + alpha MQ:<tau_k> + sym grad u_{k+1}
       double F0[6], t1[6];
       for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)nglobal_;
+      if (opt_.mode == 1)   // the flux-mean sweep has divided by N already; components 3..5 do not exist
+        for (int c = 0; c < 6; ++c) F0[c] = c < 3 ? hscal_[kSlotMean + c] : 0.0;
       if (opt_.mixing != kMixVoigt)
         for (int c = 0; c < 6; ++c) F0[c] += hscal_[kSlotScratch + c] / (double)nglobal_;
       voigt_mv(BC_MQ_, F0, t1);

@@ -701,11 +701,12 @@ class FG:
                     if key in act.attrib:
                         P[i, j] = P[j, i] = self._eval(act.attrib[key])
             if scalar:
-                # heat / porous branch  F:26002-26024: 3-vectors e1..e3 (or e11, e22, e33), projector Id(3)
-                if np.abs(P[:3, :3] - np.eye(3)).max() > 0 or np.abs(S[:3]).max() > 0:
-                    raise RuntimeError("%s mode supports prescribed mean gradients only on the MI355X path" % self._mode)
-                E, S = E[:3], None
+                # heat / porous branch  F:26002-26024: 3-vectors e1..e3 / s1..s3 (or e11, ...), 3x3 projector p11..p33
+                # (Voigt::Id4(3) = Id); handed to the 6x6 interface with an inert shear block
+                P3 = P[:3, :3].copy()
                 P = np.diag([1.0, 1.0, 1.0, 0.5, 0.5, 0.5])
+                P[:3, :3] = P3
+                E, S = E[:3], (S[:3] if np.abs(S[:3]).max() > 0 or np.abs(P3 - np.eye(3)).max() > 0 else None)
             if self._mode == "viscosity":
                 # F:25975-25989: prescribed fluid stress and shear rate must be traceless
                 tol = 100.0 * np.finfo(np.float64).eps

@@ -39,6 +39,9 @@ class ScalarOracle:
         self.residuals = []
         self.callback = None
         self.error = None
+        self.bc_relax = 1.0
+        self.lambda_0 = 0.0
+        self.set_bc_projector(np.eye(3))
         # Green-operator tables are those of the elasticity path (same k+ / k- factors, F:19766-19815)
         self._tables = LSOracle(nx, ny, nz, dx, dy, dz).g0_axis_tables()
 
@@ -129,32 +132,80 @@ class ScalarOracle:
             lo = 0.0
         self.mu_0 = 0.5 * (lo + hi) * (0.5 * self.ref_scale)
 
+    # -- boundary-condition projector (dim 3: plain 3x3 algebra, Voigt::Id4(3) = Id, F:501-512) -------------------------
+    def set_bc_projector(self, P):
+        """setBCProjector  F:20599-20665 for dim = 3: Q = Id - P, Q C0, M = (Q C0 Q)^+ by SVD, M Q;
+        C0 = 2 mu0 Id + lambda0 II (F:20619)."""
+        P = np.asarray(P, dtype=np.float64)
+        se = math.sqrt(EPS)
+        if P.shape != (3, 3) or np.linalg.norm(P - P.T) > se:
+            raise RuntimeError("Projector is not symmetric")
+        if np.linalg.norm(P - P @ P) > se:
+            raise RuntimeError("Specified Projector is not a projector")
+        self.BC_P = P
+        self.BC_Q = np.eye(3) - P
+        self._bc_matrices()
+
+    def _bc_matrices(self):
+        Q = self.BC_Q
+        if not np.any(Q) or math.isnan(self.mu_0):
+            self.BC_QC0 = np.zeros((3, 3)) if not np.any(Q) else Q * float("nan")
+            self.BC_M = np.zeros((3, 3)) if not np.any(Q) else np.full((3, 3), float("nan"))
+            self.BC_MQ = self.BC_M.copy()
+            return
+        C0 = 2 * self.mu_0 * np.eye(3) + self.lambda_0 * np.ones((3, 3))
+        self.BC_QC0 = Q @ C0
+        U, sv, VT = np.linalg.svd(self.BC_QC0 @ Q)
+        thr = math.sqrt(EPS) * float(np.linalg.norm(sv))
+        sinv = np.array([1.0 / x if abs(x) > thr else 0.0 for x in sv])
+        self.BC_M = (VT.T * sinv) @ U.T
+        self.BC_MQ = self.BC_M @ Q
+
+    def calc_bc_mean(self, E, S):
+        """calcBCMean  F:20242-20245"""
+        return E + self.bc_relax * (self.BC_M @ (S - self.BC_QC0 @ E))
+
     # -- iteration ---------------------------------------------------------------------------------------
     def basic_scheme(self, E, g):
         """basicScheme  F:20558-20578 -> GammaOperatorStaggeredHeat  F:20342-20351 (alpha = -1):
-        g <- E + grad G0(div((C - C0) g)); pure gradient loading (P = Id: Q = 0, no projector term)."""
+        g <- E + grad G0(div((C - C0) g)) + R with initBCProjector / applyBCProjector  F:20228-20270."""
+        F00 = g.reshape(3, -1).sum(axis=1) / self.N if self.bc_relax != 1.0 else np.zeros(3)
         tau = self.calc_stress(self.mu_0, g)
+        F0 = np.zeros(3) if np.linalg.norm(self.BC_MQ) < EPS else tau.reshape(3, -1).sum(axis=1) / self.N
         T = self.g0_heat(self.mu_0, self.div_heat(tau), -1.0)
-        return self.eps_heat(E, T)
+        R = -1.0 * (self.bc_relax * (self.BC_MQ @ F0) - (1 - self.bc_relax) * (self.BC_M @ (self.BC_QC0 @ F00)))
+        return self.eps_heat(E, T) + R[:, None, None, None]
 
     def component_norm(self, g):
         return np.sqrt((g.reshape(3, -1) ** 2).sum(axis=1) / self.N)
 
-    def run(self, E0):
+    def run(self, E0, S0=None, P=None):
         """LSSolver::run -> runBasic  F:21247-21398, F:21716-21805 with the stop rule _converged  F:21177-21244
         and EpsilonErrorEstimator  F:14591-14637 (fix_dim zeroes entries 3..8 for dim 3, F:12122-12124)."""
         E0 = np.asarray(E0, dtype=np.float64)
+        S0 = np.zeros(3) if S0 is None else np.asarray(S0, dtype=np.float64)
+        if P is not None:
+            self.set_bc_projector(P)
+        self._bc_matrices()
+        se = math.sqrt(EPS)
+        if np.linalg.norm(self.BC_P @ S0) > se * np.linalg.norm(S0):
+            raise RuntimeError("Incompatible stress boundary condition specified")
+        if np.linalg.norm(self.BC_Q @ E0) > se * np.linalg.norm(E0):
+            raise RuntimeError("Incompatible strain boundary condition specified")
         self.residuals = []
         self.error = None
         self.eps = np.zeros((3, self.nx, self.ny, self.nz))
         prev = float(np.linalg.norm(self.component_norm(self.eps)))
         it = 1
         update_ref = self.update_ref != "never"
+        E = E0
         while True:
             if update_ref:
                 self.calc_ref_material()
+                self._bc_matrices()
+                E = self.calc_bc_mean(E0, S0)
                 update_ref = False
-            self.eps = self.basic_scheme(E0, self.eps)
+            self.eps = self.basic_scheme(E, self.eps)
             cur = float(np.linalg.norm(self.component_norm(self.eps)))
             abs_err = abs(prev - cur)
             rel_err = abs_err / (SMALLEST + cur)
@@ -168,7 +219,7 @@ class ScalarOracle:
             if it >= self.maxiter:
                 break
             if rel_err <= self.tol or abs_err <= self.abs_tol:
-                if self.bc_error(E0) <= self.bc_tol:
+                if self.bc_error(E0, S0) <= self.bc_tol:
                     break
             it += 1
         self.iterations = it
@@ -227,11 +278,15 @@ class ScalarOracle:
         self.iterations = it
         return False
 
-    def bc_error(self, E_cur):
-        """bc_error  F:21129-21161 with P = Id, S = 0: only the gradient part can be non-zero."""
-        Emean = self.mean_strain()
-        nE = float(np.linalg.norm(E_cur))
-        return float(np.linalg.norm(Emean - E_cur)) / (1 if nE < self.bc_tol else nE)
+    def bc_error(self, E_cur, S_cur=None):
+        """bc_error  F:21129-21161 (dim 3: plain norms)"""
+        S_cur = np.zeros(3) if S_cur is None else np.asarray(S_cur, dtype=np.float64)
+        Emean, Smean = self.mean_strain(), self.mean_stress()
+        nE = float(np.linalg.norm(self.BC_P @ E_cur))
+        err_F = float(np.linalg.norm(self.BC_P @ Emean - E_cur)) / (1 if nE < self.bc_tol else nE)
+        nS = float(np.linalg.norm(S_cur))
+        err_S = float(np.linalg.norm(self.BC_Q @ Smean - S_cur)) / (1 if nS < self.bc_tol else nS)
+        return max(err_F, err_S)
 
     def calc_effective_properties(self):
         """calc_effective_properties, heat / porous branch  F:26115-26165: three unit gradients,

@@ -189,3 +189,26 @@ def test_scalar_cg_matches_oracle(grid, dims):
     assert rel_err(s.mean_stress(), b.mean_stress()) < 1e-6
     s.close()
     b.close()
+
+
+@pytest.mark.parametrize("grid,u_loop", [((16, 16, 16), 1), ((12, 10, 6), 2), ((8, 16, 128), 2)])
+def test_scalar_mixed_boundary_conditions(grid, u_loop):
+    """initBCProjector / applyBCProjector of GammaOperatorStaggeredHeat  F:20342-20350 with setBCProjector for dim 3
+    (F:20599-20665): a flux prescribed in x, gradients prescribed in y and z."""
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 12.0], [1 - phi1, phi1]
+    P3 = np.diag([0.0, 1.0, 1.0])
+    P6 = np.diag([0.0, 1.0, 1.0, 0.5, 0.5, 0.5])
+    E, S = np.array([0.0, 0.3, -0.2]), np.array([1.5, 0.0, 0.0])
+    s = _solver(grid, mus, phis, tol=1e-10, bc_tol=1e-9, maxiter=500, u_loop=u_loop)
+    s.set_bc_projector(P6)
+    o = _oracle(grid, mus, phis, tol=1e-10, bc_tol=1e-9, maxiter=500)
+    assert o.run(E, S, P3) is False and s.run(E, S) is False
+    assert s.iterations == o.iterations
+    assert np.abs(np.array(s.residuals) - np.array(o.residuals)).max() < 1e-10
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
+    assert s.mean_stress()[0] == pytest.approx(1.5, rel=1e-8) and np.abs(s.mean_strain()[1:] - E[1:]).max() < 1e-12
+    s.set_options(method="cg")
+    with pytest.raises(RuntimeError, match="method=basic"):
+        s.run(E, S)
+    s.close()

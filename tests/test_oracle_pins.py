@@ -423,3 +423,19 @@ def test_viscosity_homogeneous_fluid_and_velocity_is_divergence_free():
     hx, hy, hz = shape[0] / o.dx, shape[1] / o.dy, shape[2] / o.dz
     div = (np.roll(u[0], -1, 0) - u[0]) * hx + (np.roll(u[1], -1, 1) - u[1]) * hy + (np.roll(u[2], -1, 2) - u[2]) * hz
     assert np.abs(div).max() < 1e-10 * max(1.0, np.abs(u).max() * hx)
+
+
+def test_scalar_mixed_bc_prescribed_flux_through_layers():
+    """Mixed boundary conditions of the scalar modes (setBCProjector for dim 3 F:20599-20665, initBCProjector /
+    applyBCProjector inside GammaOperatorStaggeredHeat F:20342-20350): a flux prescribed ACROSS layers must produce the
+    mean gradient flux / harmonic mean -- the series closed form the discretisation reproduces exactly."""
+    from oracle.scalar_oracle import ScalarOracle
+    n = (8, 1, 1)
+    phi = np.zeros(n)
+    phi[:3] = 1.0
+    o = ScalarOracle(*n, mus=[1.0, 10.0], phis=[1 - phi, phi], tol=1e-12, bc_tol=1e-10, maxiter=2000)
+    P = np.diag([0.0, 1.0, 1.0])          # flux prescribed in x, gradients prescribed in y and z
+    assert o.run(np.zeros(3), np.array([2.0, 0, 0]), P) is False
+    k_series = 1 / ((5 / 8) / 1.0 + (3 / 8) / 10.0)
+    assert o.mean_strain()[0] == pytest.approx(2.0 / k_series, rel=1e-9)
+    assert np.abs(o.mean_stress() - np.array([2.0, 0, 0])).max() < 1e-9
