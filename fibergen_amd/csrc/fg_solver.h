@@ -279,6 +279,8 @@ class Solver {
   double* hscal_ = nullptr;    // pinned host mirror
   int* derr_ = nullptr;        // device error flag
   int* herr_ = nullptr;
+  unsigned* hseq_ = nullptr;   // pinned: sequence number the stop rule's publish kernel writes last
+  unsigned publish_seq_ = 0;
   double* g0_kpm_[3] = {nullptr, nullptr, nullptr};
   cplx* g0_kp_[3] = {nullptr, nullptr, nullptr};
   double* xi_[3] = {nullptr, nullptr, nullptr};  // collocated scheme: signed frequency / cell size per axis
