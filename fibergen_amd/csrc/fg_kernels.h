@@ -114,6 +114,11 @@ void launch_interface_delta(const Grid& g, const StressParams& sp, const FieldPt
 void launch_sum_dtau(const double* dtau, unsigned n, double* partial, double* out6, hipStream_t s);
 void launch_delta_div(const Grid& g, const unsigned* aff, const int* slots, unsigned n, const double* dtau,
                       const FieldPtrs<3>& f, hipStream_t s);
+// x-slabs: the difference field of the boundary planes as dense planes for the neighbours (lo2: d5, d4 of the first plane;
+// hi1: d0 of the last plane) and the neighbours' planes applied to f (from_lo1: d0 of plane -1; from_hi2: d5, d4 of plane nx)
+void launch_delta_pack(const Grid& g, const unsigned* list, unsigned n, const double* dtau, double* lo2, double* hi1, hipStream_t s);
+void launch_delta_div_halo(const Grid& g, const double* from_lo1, const double* from_hi2, const FieldPtrs<3>& f, hipStream_t s);
+void launch_add_small(double* out, const double* in, int n, hipStream_t s);
 void launch_div(const Grid& g, const FieldPtrs<6>& tau, const FieldPtrs<3>& f, const XHalo& h, hipStream_t s);
 void launch_g0(const Grid& g, const FieldPtrs<3>& fh, const G0Tables& tb, double c10, double c20, const G0Layout& lay,
                hipStream_t s);

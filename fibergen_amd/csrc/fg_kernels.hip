@@ -891,10 +891,11 @@ __global__ __launch_bounds__(kBlock) void k_mixed_map(const unsigned* list, unsi
 struct VoxelNeighbours {
   long xf, xb, yf, yb, zf, zb;
 };
+// x neighbours through Grid::xw_lo / xw_hi: periodic in a whole grid, the spare planes of the neighbours in an x-slab
 __device__ __forceinline__ VoxelNeighbours voxel_neighbours(const Grid& g, int i, int j, int k) {
   VoxelNeighbours n;
-  n.xf = (i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
-  n.xb = (i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+  n.xf = (i + 1 == g.nx ? (long)(g.nx - g.xw_hi) - i : 1L) * g.nyzp;
+  n.xb = (i == 0 ? (long)(g.xw_lo - 1) : -1L) * g.nyzp;
   n.yf = (j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
   n.yb = (j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
   n.zf = (k + 1 == g.nz ? -(long)(g.nz - 1) : 1L);
@@ -918,7 +919,13 @@ __global__ __launch_bounds__(kBlock) void k_affected_list(Grid g, const int* map
       const int i = (int)(row / g.ny), j = (int)(row - (long)i * g.ny);
       off = row * g.nzp + k;
       const VoxelNeighbours nb = voxel_neighbours(g, i, j, k);
-      sl[0] = map[off]; sl[1] = map[off + nb.xb]; sl[2] = map[off + nb.xf]; sl[3] = map[off + nb.yb];
+      // x-slab (xw_hi != nx): the x neighbours of the two boundary planes live on other ranks; their part of the
+      // divergence arrives as dense planes (k_delta_div_halo)
+      const bool slab = g.xw_hi != g.nx;
+      sl[0] = map[off];
+      sl[1] = (slab && i == 0) ? -1 : map[off + nb.xb];
+      sl[2] = (slab && i + 1 == g.nx) ? -1 : map[off + nb.xf];
+      sl[3] = map[off + nb.yb];
       sl[4] = map[off + nb.yf]; sl[5] = map[off + nb.zb]; sl[6] = map[off + nb.zf];
       for (int t = 0; t < 7; ++t) any = any || sl[t] >= 0;
     }
@@ -1006,6 +1013,41 @@ __global__ __launch_bounds__(kBlock) void k_delta_div(Grid g, const unsigned* af
     f.p[1][off] += d1;
     f.p[2][off] += d2;
   }
+}
+
+// x-slabs: the difference field of the two boundary planes as dense planes for the neighbours (the shape of the
+// polarisation halo of the strain-state pipeline): lo = (d5, d4) of the first plane -> left neighbour (its x+1 terms),
+// hi = d0 of the last plane -> right neighbour (its x-1 term).  The planes are zeroed before; the interface voxels of a
+// boundary plane are few, every list entry looks at its plane only.
+__global__ __launch_bounds__(kBlock) void k_delta_pack(Grid g, const unsigned* list, unsigned n, const double* dtau, double* lo,
+                                                       double* hi) {
+  const long last = (long)(g.nx - 1) * g.nyzp;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const long off = list[idx];
+    if (off < g.nyzp) {
+      lo[off] = dtau[(long)idx * 6 + 5];
+      lo[g.nyzp + off] = dtau[(long)idx * 6 + 4];
+    }
+    if (off >= last) hi[off - last] = dtau[(long)idx * 6 + 0];
+  }
+}
+
+// ... and their terms of divOperatorStaggered F:18853-18908 on the receiving side: f0(0,j,k) -= d0(-1,j,k) hx,
+// f1(nx-1,j,k) += d5(nx,j,k) hx, f2(nx-1,j,k) += d4(nx,j,k) hx
+__global__ __launch_bounds__(kBlock) void k_delta_div_halo(Grid g, const double* from_lo, const double* from_hi, FieldPtrs<3> f) {
+  const long last = (long)(g.nx - 1) * g.nyzp;
+  const double hx = g.hx;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < g.nyzp; idx += (long)gridDim.x * blockDim.x) {
+    const double a = from_lo[idx], b = from_hi[idx], c = from_hi[g.nyzp + idx];
+    if (a != 0.0) f.p[0][idx] -= a * hx;
+    if (b != 0.0) f.p[1][last + idx] += b * hx;
+    if (c != 0.0) f.p[2][last + idx] += c * hx;
+  }
+}
+
+// out[c] += in[c], c < n (a handful of device scalars)
+__global__ void k_add_small(double* out, const double* in, int n) {
+  if ((int)threadIdx.x < n) out[threadIdx.x] += in[threadIdx.x];
 }
 
 // ----------------------------------------------------------------------------- viscosity: strain + Delta-operator tail
@@ -1492,6 +1534,25 @@ void launch_sum_dtau(const double* dtau, unsigned n, double* partial, double* ou
   hipLaunchKernelGGL(k_sum_dtau, dim3(nb), dim3(kBlock), 0, s, dtau, n, partial);
   FG_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, out6);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_delta_pack(const Grid& g, const unsigned* list, unsigned n, const double* dtau, double* lo2, double* hi1,
+                       hipStream_t s) {
+  FG_HIP_CHECK(hipMemsetAsync(lo2, 0, 2 * (size_t)g.nyzp * sizeof(double), s));
+  FG_HIP_CHECK(hipMemsetAsync(hi1, 0, (size_t)g.nyzp * sizeof(double), s));
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_delta_pack, dim3(grid_for((long)n, 1 << 16)), dim3(kBlock), 0, s, g, list, n, dtau, lo2, hi1);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_delta_div_halo(const Grid& g, const double* from_lo1, const double* from_hi2, const FieldPtrs<3>& f, hipStream_t s) {
+  hipLaunchKernelGGL(k_delta_div_halo, dim3(grid_for(g.nyzp, 1 << 16)), dim3(kBlock), 0, s, g, from_lo1, from_hi2, f);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_add_small(double* out, const double* in, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_add_small, dim3(1), dim3(64), 0, s, out, in, n);
   FG_HIP_CHECK(hipGetLastError());
 }
 

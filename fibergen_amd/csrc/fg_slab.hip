@@ -200,8 +200,8 @@ void Solver::slab_fetch_norms(int n) {
 }
 
 bool Solver::slab_fast_ok(bool allow_mixed_bc) const {
-  if (!(opt_.u_loop >= 2 && opt_.u_tile && opt_.mode == 0 && opt_.gamma_scheme == 0 && opt_.mixing == kMixVoigt && pt_.n >= 1 &&
-        opt_.bc_relax == 1.0 && u_tile_supported(g_)))
+  if (!(opt_.u_loop >= 2 && opt_.u_tile && opt_.mode == 0 && opt_.gamma_scheme == 0 && pt_.n >= 1 &&
+        (opt_.mixing == kMixVoigt || (opt_.mixing == kMixLaminate && normals_)) && opt_.bc_relax == 1.0 && u_tile_supported(g_)))
     return false;
   return frobenius(BC_MQ_) < kEps || allow_mixed_bc;
 }
@@ -231,9 +231,35 @@ void Solver::slab_front_fast(const double* E6, bool sum_tau) {
   mod.p[0] = smod_;
   mod.p[1] = smod_ + ucs_;
   time_begin(0);
+  const bool laminate = opt_.mixing == kMixLaminate;
+  if (laminate) {
+    // laminate mixing = the Voigt sweep + the divergence of d = tau_laminate - tau_voigt on the interface voxels (see
+    // k_interface_strain).  d of the slab's two boundary planes also enters the divergence on the neighbouring slabs: it
+    // travels as dense planes (the polarisation halo of the strain-state pipeline) while the sweep runs.
+    build_laminate_lists();
+    launch_interface_delta(gu_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), strided3(su_[su_cur_], ucs_), E, mixed_list_, mixed_n_,
+                           lam_epsc_, lam_phic_, lam_nrmc_, dtau_, derr_, stream_);
+    launch_delta_pack(g_, mixed_list_, mixed_n_, dtau_, halo_[0], halo_[1], stream_);
+    slab_exchange(FG_PLAN_HALO_TAU, 0, kXHaloTau);
+  }
   const PhaseTable pt2 = phase_table();
   launch_u_tile(gu_, opt_.mu_0, opt_.lambda_0, strided3(su_[su_cur_], ucs_), mod, ptrs3(fu_), E, partial_, dscal_ + kSlotSumSq,
                 opt_.u_tile, stream_, sum_tau, slab_phi_ ? &pt2 : nullptr);
+  if (laminate) return;   // slab_front_laminate (next step: the planes of the neighbours have to be posted first)
+  time_end(0);
+  slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
+}
+
+// second step of the sweep with laminate mixing: div d of the own interface voxels and of the neighbours' boundary planes
+void Solver::slab_front_laminate(bool sum_tau) {
+  if (opt_.mixing != kMixLaminate) return;
+  launch_delta_div(g_, aff_list_, aff_slots_, aff_n_, dtau_, ptrs3(fu_), stream_);
+  comm_wait(kXHaloTau);
+  launch_delta_div_halo(g_, halo_[2], halo_[3], ptrs3(fu_), stream_);
+  if (sum_tau) {   // mixed BC: <tau_laminate> = <tau_voigt> (from the sweep) + sum of the differences / N
+    launch_sum_dtau(dtau_, mixed_n_, partial_, dscal_ + kSlotScratch, stream_);
+    launch_add_small(dscal_ + kSlotMean, dscal_ + kSlotScratch, 6, stream_);
+  }
   time_end(0);
   slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
 }
@@ -440,7 +466,10 @@ void SlabGroup::prepare() {
     s->slab_alloc();
   }
   if (fast_ok(true))
-    for (Solver* s : m_) s->slab_moduli_step();
+    for (Solver* s : m_) {
+      s->slab_moduli_step();
+      if (s->opt_.mixing == kMixLaminate) s->build_laminate_lists();   // allocates and synchronises: not inside a pass
+    }
 }
 
 void SlabGroup::wait_norms() {
@@ -542,6 +571,7 @@ double SlabGroup::bc_error(const double* E_cur, const double* S_cur) {
 // norms yet -- the whole transform chain to u_{k+1}; adopted by the caller if the loop goes on
 void SlabGroup::pass_fast(const double* E_cur, bool sum_tau) {
   for (Solver* s : m_) s->slab_front_fast(E_cur, sum_tau);
+  for (Solver* s : m_) s->slab_front_laminate(sum_tau);
   for (Solver* s : m_) s->slab_fetch_norms(sum_tau ? 12 : 6);
   for (int k = 1; k <= 9; ++k)
     for (Solver* s : m_) s->slab_chain_step(k);

@@ -205,6 +205,7 @@ class Solver {
   bool slab_fast_ok(bool allow_mixed_bc) const;
   void slab_moduli_step();                               // effective moduli of the slab + exchange of their halo planes
   void slab_front_fast(const double* E6, bool sum_tau);  // su_[cur] -> norms of eps_k (all-reduced), f_{k+1} in fu_
+  void slab_front_laminate(bool sum_tau);
   void slab_fetch_norms(int n);                          // D2H of the reduced sums (+ error flag), event for the host
   void slab_chain_step(int k);                           // k = 1..9: transform chain fu_ -> su_[next], see fg_slab.hip
   void slab_front_exact(bool sum_tau);                   // eps_ -> tau_, halo of tau (, sums of tau all-reduced)

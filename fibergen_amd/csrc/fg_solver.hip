@@ -815,7 +815,8 @@ void Solver::build_laminate_lists() {
     FieldPtrs<3> nrm;
     for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
     launch_interface_static(g_, pt_.n, phi, nrm, mixed_list_, mixed_n_, lam_phic_, lam_nrmc_, stream_);
-    aff_n_ = launch_affected_list(g_, mixed_list_, mixed_n_, &aff_list_, &aff_slots_, stream_);
+    // x-slab: no x neighbours across the slab faces in the slots (gu_: the grid with the slab's plane mapping)
+    aff_n_ = launch_affected_list(slab_layout_ ? gu_ : g_, mixed_list_, mixed_n_, &aff_list_, &aff_slots_, stream_);
   }
   mixed_dirty_ = false;
 }

@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("nproc,grid,mixing,split", [
     (2, "8,16,128", "voigt", 1),     # displacement loop (tiled sweep with halo planes), all-to-all per component
     (2, "8,16,128", "voigt", 0),     # ... one exchange for the three components
+    (2, "8,16,128", "laminate", 1),  # displacement loop with the interface correction (dense planes to the neighbours)
+    (4, "16,16,128", "laminate", 0),
     (2, "16,16,16", "voigt", 1),     # strain-state pipeline
     (2, "32,16,64", "laminate", 0),
     (4, "16,8,16", "voigt", 1),

@@ -29,6 +29,12 @@ FAST = [   # grids the tiled displacement sweep fits (nz/2 >= 62, ny >= 14, loca
     (4, (16, 16, 128), "voigt"),
     (2, (16, 32, 256), "voigt"),     # nz/2 = 128: a z row is two waves of the tile
     (2, (8, 16, 124), "voigt"),      # nz/2 = 62: tiles with halo lanes, generic z transform
+    # laminate mixing in the displacement loop: Voigt sweep + interface correction, the difference field of the slab faces
+    # travels to the neighbours as dense planes
+    (1, (8, 16, 128), "laminate"),
+    (2, (8, 16, 128), "laminate"),
+    (4, (16, 16, 128), "laminate"),
+    (2, (16, 32, 256), "laminate"),
 ]
 EXACT = [  # strain-state pipeline: laminate mixing, small / odd / mixed-radix grids
     (1, (16, 16, 16), "voigt"),
@@ -38,7 +44,6 @@ EXACT = [  # strain-state pipeline: laminate mixing, small / odd / mixed-radix g
     (2, (12, 10, 6), "laminate"),    # generic (non power-of-two) FFT path in every direction, remapped all-to-all layout
     (2, (8, 6, 5), "voigt"),         # odd nz
     (2, (24, 48, 48), "voigt"),      # p * 2^k lengths
-    (2, (8, 16, 128), "laminate"),   # tile-sized grid, laminate => strain-state pipeline
 ]
 
 
@@ -63,13 +68,14 @@ def test_group_run_matches_oracle(P, grid, mixing, split):
     g.close()
 
 
-@pytest.mark.parametrize("P,grid", [(2, (8, 16, 128)), (2, (16, 16, 16))])
-def test_group_mixed_bc(P, grid):
+@pytest.mark.parametrize("P,grid,mixing", [(2, (8, 16, 128), "voigt"), (2, (16, 16, 16), "voigt"), (2, (8, 16, 128), "laminate"),
+                                           (4, (16, 16, 128), "laminate")])
+def test_group_mixed_bc(P, grid, mixing):
     Pm = np.zeros((6, 6))
     Pm[0, 0] = 1.0
-    g = make_group(P, grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    g = make_group(P, grid, mixing=mixing, tol=1e-9, bc_tol=1e-8, maxiter=400)
     g.set_bc_projector(Pm)
-    o = make_oracle(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    o = make_oracle(grid, mixing=mixing, tol=1e-9, bc_tol=1e-8, maxiter=400)
     assert o.run([0.01, 0, 0, 0, 0, 0], S0=np.zeros(6), P=Pm) is False
     assert g.run([0.01, 0, 0, 0, 0, 0], np.zeros(6)) is False
     assert g.iterations == o.iterations
@@ -90,6 +96,35 @@ def test_group_equals_single_gpu_solver(P):
     assert rel_err(g.get_field("epsilon"), s.get_field("epsilon")) < 1e-11
     assert rel_err(g.mean_stress(), s.mean_stress()) < 1e-12
     # n passes without the stop rule, starting from the converged state
+    s.iterate(E_LOAD, 3)
+    g.iterate(E_LOAD, 3)
+    assert rel_err(g.get_field("epsilon"), s.get_field("epsilon")) < 1e-11
+    s.close()
+    g.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_laminate_group_equals_single_gpu_solver_with_interfaces_on_every_slab_face(P):
+    """The sphere is shifted by half a period along x, so that its surface also crosses the periodic face between the
+    last and the first slab: every dense-plane hand-over of the interface correction carries values."""
+    from fibergen_amd import LSSolver
+    from fibergen_amd.distributed import SlabGroup
+    grid = (32, 32, 128)
+    mats, phis, normals = two_phase_setup(grid, "laminate")
+    phis = [np.roll(p, 13, axis=0) for p in phis]
+    normals = np.roll(normals, 13, axis=1)
+    s, g = LSSolver(*grid), SlabGroup(*grid, nranks=P)
+    for x in (s, g):
+        x.set_num_phases(2)
+        for p in range(2):
+            x.set_phase(p, mats[p][0], mats[p][1], phis[p])
+        x.set_normals(normals)
+        x.set_options(mixing_rule="laminate", tol=1e-7)
+    assert s.run(E_LOAD) is False and g.run(E_LOAD) is False
+    assert g.iterations == s.iterations
+    assert np.abs(np.array(g.residuals) - np.array(s.residuals)).max() < 1e-12
+    assert rel_err(g.get_field("epsilon"), s.get_field("epsilon")) < 1e-11
+    assert rel_err(g.mean_stress(), s.mean_stress()) < 1e-12
     s.iterate(E_LOAD, 3)
     g.iterate(E_LOAD, 3)
     assert rel_err(g.get_field("epsilon"), s.get_field("epsilon")) < 1e-11
@@ -132,7 +167,7 @@ def test_errors():
 
 
 @pytest.mark.parametrize("split", [0, 1])
-@pytest.mark.parametrize("grid,mixing", [((8, 16, 128), "voigt"), ((16, 16, 16), "laminate")])
+@pytest.mark.parametrize("grid,mixing", [((8, 16, 128), "voigt"), ((16, 16, 16), "laminate"), ((8, 16, 128), "laminate")])
 def test_rccl_transport_loopback_on_one_gpu(grid, mixing, split):
     """The RCCL transport itself, as far as ONE GPU allows: a lone slab with its own RCCL communicator (size 1) in loop-back
     mode -- every all-to-all block and halo plane goes out through ncclSend and comes back through ncclRecv (same rank,
