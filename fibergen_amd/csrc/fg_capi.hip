@@ -254,6 +254,10 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       o.method = (int)value;
     }
     else if (k == "fuse_stress_div") o.fuse_stress_div = value != 0;
+    else if (k == "loadstep_extrapolation_order") {
+      if (value < 0 || value > 7) throw std::runtime_error("loadstep_extrapolation_order must be 0..7");
+      o.loadstep_extrapolation_order = (int)value;
+    }
     else if (k == "error_estimator") {
       if (value != 0 && value != 1) throw std::runtime_error("error_estimator must be 0 (epsilon) or 1 (residual)");
       o.error_estimator = (int)value;

@@ -138,6 +138,8 @@ void launch_eps_delta_recompute(const Grid& g, const FieldPtrs<3>& u, const Fiel
 void launch_eps_delta(const Grid& g, const FieldPtrs<3>& u, const FieldPtrs<6>& tau, const double* tau_sum, double nvox,
                       const Vec6& E, double coef, const FieldPtrs<6>& eps, double* partial, double* sumsq6, hipStream_t s);
 void launch_copy(const double* src, double* dst, long ndoubles, hipStream_t s);
+// out = sum_{i<n} w[i] in[i] (n <= 8)
+void launch_lincomb(int n, const double* const* in, const double* w, double* out, long ndoubles, hipStream_t s);
 void launch_cg(int mode, const Grid& g, const FieldPtrs<6>& x, const FieldPtrs<6>& y, const FieldPtrs<6>& z, const Vec6& E,
                double a, double* partial, double* out6, hipStream_t s);
 void launch_set_const6(const Grid& g, const FieldPtrs<6>& x, const Vec6& E, hipStream_t s);

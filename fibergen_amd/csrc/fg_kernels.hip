@@ -1537,6 +1537,30 @@ void launch_sum_dtau(const double* dtau, unsigned n, double* partial, double* ou
   FG_HIP_CHECK(hipGetLastError());
 }
 
+// out = sum_i w[i] in[i], i < n <= 8, over ndoubles values (load-step extrapolation: the polynomial through the fields of
+// the last steps evaluated at the new parameter, extrapolateLoadstepPolynomial F:21468-21514 -- the reference forms the
+// coefficients per voxel, p = V^-1 f, and then sum_i t^i p_i; with w = V^-T tpowers that is the same linear combination)
+struct Lincomb {
+  const double* in[8];
+  double w[8];
+  int n;
+};
+__global__ __launch_bounds__(kBlock) void k_lincomb(Lincomb a, double* out, long ndoubles) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ndoubles; i += (long)gridDim.x * blockDim.x) {
+    double v = 0.0;
+    for (int q = 0; q < a.n; ++q) v += a.w[q] * a.in[q][i];
+    out[i] = v;
+  }
+}
+void launch_lincomb(int n, const double* const* in, const double* w, double* out, long ndoubles, hipStream_t s) {
+  if (n < 1 || n > 8) throw std::runtime_error("launch_lincomb: 1..8 terms");
+  Lincomb a;
+  a.n = n;
+  for (int q = 0; q < 8; ++q) a.in[q] = q < n ? in[q] : nullptr, a.w[q] = q < n ? w[q] : 0.0;
+  hipLaunchKernelGGL(k_lincomb, dim3(grid_for(ndoubles, 1 << 16)), dim3(kBlock), 0, s, a, out, ndoubles);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
 void launch_delta_pack(const Grid& g, const unsigned* list, unsigned n, const double* dtau, double* lo2, double* hi1,
                        hipStream_t s) {
   FG_HIP_CHECK(hipMemsetAsync(lo2, 0, 2 * (size_t)g.nyzp * sizeof(double), s));

@@ -53,6 +53,7 @@ struct SolverOptions {
   int mode = 0;                 // 0 = elasticity, 1 = scalar (heat / porous: 3-component gradient, 1-component potential),
                                 // 2 = viscosity (dual Stokes scheme: DeltaOperatorStaggered F:20422-20460, 6 components)
   int gamma_scheme = 0;         // 0 = staggered (GammaOperatorStaggered F:20288), 1 = collocated (GammaOperatorCollocated F:20302)
+  int loadstep_extrapolation_order = 0;   // 0 = none, 1 = linear, ... (F:14696; method "polynomial" F:21468-21514)
   int error_estimator = 0;      // 0 = epsilon (EpsilonErrorEstimator F:14591-14637), 1 = residual (ResidualErrorEstimator
                                 // F:14382-14405: abs = sqrt(gamma), rel = sqrt(gamma / gamma_0); method cg only)
   int method = 0;               // 0 = basic scheme (runBasic F:21716), 1 = conjugate gradients (runCGElasticity F:23153)

@@ -1076,7 +1076,8 @@ double Solver::current_norm9() {
 // runLoadsteppingSolver  F:21584-21685: the prescribed values are scaled by the parameter of every load step, every
 // step continues from the strain field of the one before (the field is zeroed once, in run(), F:21379), and after each
 // step the load-step action runs (performLoadstepActions F:21435-21447: the caller's callback, non-zero = stop).
-// Load-step extrapolation (loadstep_extrapolation_order > 0) is not available.
+// Load-step extrapolation (loadstep_extrapolation_order > 0, polynomial method F:21468-21514): from the second step on the
+// step starts from the polynomial through the converged strain fields of the last order + 1 steps evaluated at its parameter.
 bool Solver::run_load_steps(const double* E6, const double* S6, const double* params, int nparams, int first,
                             LoadstepCallback step_cb, void* user) {
   FG_HIP_CHECK(hipSetDevice(device_));
@@ -1104,10 +1105,67 @@ bool Solver::run_load_steps(const double* E6, const double* S6, const double* pa
   FG_HIP_CHECK(hipMemsetAsync(eps_, 0, 6 * (size_t)g_.n * sizeof(double), stream_));  // F:21379
   u_valid_ = false;
   eps_stale_ = false;
+  // converged strain fields of the last steps (device copies, oldest first)  F:21586
+  struct Kept {
+    double t;
+    double* eps;
+  };
+  std::vector<Kept> last;
+  struct Release {
+    std::vector<Kept>& v;
+    ~Release() {
+      for (Kept& k : v) (void)hipFree(k.eps);
+    }
+  } release{last};
+  const size_t f6 = 6 * (size_t)g_.n * sizeof(double);
   for (int istep = first; istep < nparams; ++istep) {
     double E[6], S[6];
     for (int i = 0; i < 6; ++i) E[i] = params[istep] * Emax[i], S[i] = params[istep] * Smax[i];
     fresh_step_ = istep == first;
+    const int order = opt_.loadstep_extrapolation_order;
+    if (order > 0 && istep > first) {   // F:21634-21650
+      if (slab_layout_) throw std::runtime_error("load-step extrapolation is not available on slab-decomposed solvers");
+      double* buf = nullptr;
+      while ((int)last.size() > order) {   // the oldest buffer is reused for the new copy
+        if (buf) FG_HIP_CHECK(hipFree(buf));
+        buf = last.front().eps;
+        last.erase(last.begin());
+      }
+      if (!buf) FG_HIP_CHECK(hipMalloc(&buf, f6));
+      ensure_eps();
+      FG_HIP_CHECK(hipMemcpyAsync(buf, eps_, f6, hipMemcpyDeviceToDevice, stream_));
+      last.push_back(Kept{params[istep - 1], buf});
+      const int n = (int)last.size();
+      if (n >= 2) {
+        // w = V^-T tpowers with V_ij = t_i^j: solve V^T w = tpowers (Gauss elimination with partial pivoting, n <= 8)
+        double A[8][9], w[8];
+        for (int i = 0; i < n; ++i) {
+          for (int j = 0; j < n; ++j) A[i][j] = std::pow(last[j].t, i);   // (V^T)_ij = t_j^i
+          A[i][n] = std::pow(params[istep], i);
+        }
+        for (int c = 0; c < n; ++c) {
+          int piv = c;
+          for (int r = c + 1; r < n; ++r)
+            if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+          if (A[piv][c] == 0.0) throw std::runtime_error("Error inverting Vandermonde matrix");   // F:21490-21492
+          for (int j = 0; j <= n; ++j) std::swap(A[c][j], A[piv][j]);
+          for (int r = c + 1; r < n; ++r) {
+            const double m = A[r][c] / A[c][c];
+            for (int j = c; j <= n; ++j) A[r][j] -= m * A[c][j];
+          }
+        }
+        for (int r = n - 1; r >= 0; --r) {
+          double v = A[r][n];
+          for (int j = r + 1; j < n; ++j) v -= A[r][j] * w[j];
+          w[r] = v / A[r][r];
+        }
+        const double* in[8];
+        for (int i = 0; i < n; ++i) in[i] = last[i].eps;
+        launch_lincomb(n, in, w, eps_, 6 * g_.n, stream_);
+        u_valid_ = false;      // the state is the extrapolated strain field: one strain-state pass, then the displacement loop
+        eps_stale_ = false;
+      }
+    }
     if (run_one_step(E, S)) return true;
     if (step_cb && step_cb(user, istep)) return true;   // "Loadstep callback break request."
   }
@@ -1190,11 +1248,15 @@ bool Solver::run_one_step(const double* E0, const double* S0) {
       pending_back = true;
       pending_back_ = true;   // fetch_norms_and_errors enqueues the FFT chain behind the copies
     } else {
-      uloop = false;
+      // no displacement behind the strain field (a step that starts from a given / extrapolated field, mixed boundary
+      // conditions with their correction term in the strain): strain-state pass.  If it leaves a displacement, the loop
+      // goes on in displacement space after the unrecorded pass of a continuing step (carry).
       basic_scheme(E);
+      if (uloop && u_valid_ && !mixed_bc) carry = true;
+      else uloop = false;
     }
     fetch_norms_and_errors("stress");
-    if (uloop && mixed_bc) {
+    if (pending_back && mixed_bc) {
       // applyBCProjector  F:20247-20270 with bc_relax = 1: eps_{k+1} = E + alpha MQ:<tau_k> + sym grad u_{k+1}
       double F0[6], t1[6];
       for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)nglobal_;

@@ -269,8 +269,11 @@ class FG:
         self._first_loadstep = self._child_value(solver, "first_loadstep", -1, int)
         self._write_loadsteps = bool(self._child_value(solver, "write_loadsteps", 0, int))
         self._loadstep_filename = self._child_value(solver, "loadstep_filename", "loadstep_%02d.vtk", str)
-        if self._child_value(solver, "loadstep_extrapolation_order", 0, int) > 0:
-            raise RuntimeError("loadstep_extrapolation_order > 0 is not available on the MI355X path")
+        # F:15090-15091; "transformation" (F:21516-21580) belongs to hyperelasticity, which is out of scope
+        self._extrapolation_order = self._child_value(solver, "loadstep_extrapolation_order", 0, int)
+        if self._child_value(solver, "loadstep_extrapolation_method", "polynomial", str) != "polynomial" and self._extrapolation_order > 0:
+            raise RuntimeError("loadstep_extrapolation_method: only 'polynomial' is available on the MI355X path")
+        opts["loadstep_extrapolation_order"] = self._extrapolation_order
         for k in _SOLVER_DOUBLE_KEYS:
             v = self._child_value(solver, k, None)
             if v is not None:

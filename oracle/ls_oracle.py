@@ -405,6 +405,7 @@ class LSOracle:
     update_ref: str = "loadstep"
     gamma_scheme: str = "staggered"               # or "collocated" (GammaOperatorCollocated F:20302-20310)
     error_estimator: str = "epsilon"              # or "residual" (method cg only, F:14382-14405)
+    loadstep_extrapolation_order: int = 0         # 0 = none, 1 = linear, ...  (F:14696, F:14830; method "polynomial")
 
     def __post_init__(self):
         self.N = self.nx * self.ny * self.nz
@@ -803,8 +804,16 @@ class LSOracle:
         if first is None:
             first = 0 if len(params) > 2 else 1
         self.step_iterations = []
+        last = []   # (parameter, converged strain field) of the previous steps  F:21586
         for istep in range(first, len(params)):
             t = float(params[istep])
+            order = int(self.loadstep_extrapolation_order)
+            if order > 0 and istep > first:   # F:21634-21650
+                while len(last) > order:
+                    last.pop(0)
+                last.append((float(params[istep - 1]), self.eps.copy()))
+                if len(last) >= 2:
+                    self.eps = self.extrapolate_loadstep_polynomial(last, t)
             if method != "cg" and self.error_estimator == "residual":
                 raise RuntimeError("Selected error estimator is not compatible with the selected solution method")  # F:14359
             failed = self._run_cg_step(t * E0, t * S0) if method == "cg" else self._run_basic_step(t * E0, t * S0)
@@ -814,6 +823,18 @@ class LSOracle:
             if step_callback is not None and step_callback(istep):
                 return True
         return False
+
+    @staticmethod
+    def extrapolate_loadstep_polynomial(last, t):
+        """extrapolateLoadstepPolynomial  F:21468-21514: per voxel and component the polynomial through the values of the
+        last steps, p = V^-1 f with the Vandermonde matrix V_ij = t_i^j, evaluated at t (sum_i t^i p_i)."""
+        n = len(last)
+        V = np.array([[lt ** j for j in range(n)] for lt, _ in last], dtype=np.float64)
+        tpowers = np.array([t ** i for i in range(n)], dtype=np.float64)
+        Vinv = np.linalg.solve(V, np.eye(n))   # lapack gesv on the identity  F:21485-21489
+        f = np.stack([e for _, e in last])      # [n, 6, nx, ny, nz]
+        p = np.tensordot(Vinv, f, axes=(1, 0))
+        return np.tensordot(tpowers, p, axes=(0, 0))
 
     def _run_basic_step(self, E0, S0):
         """runBasic  F:21716-21805 for one load step"""

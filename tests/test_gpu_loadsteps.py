@@ -109,6 +109,38 @@ def test_fg_loadsteps_callback_and_files(tmp_path):
     assert fg2.run() == 0 and len(n) == 2
     assert rel_err(np.array(fg2.get_mean_stress()), full) < 1e-6
     fg3 = FG()
-    fg3.set_xml((XML % ("2", 0, "x")).replace("<tol>", "<loadstep_extrapolation_order>1</loadstep_extrapolation_order><tol>"))
+    fg3.set_xml((XML % ("4", 0, "x")).replace("<tol>", "<loadstep_extrapolation_order>1</loadstep_extrapolation_order><tol>"))
+    lens = []
+    fg3.set_loadstep_callback(lambda: lens.append(len(fg3.get_residuals())) and False)
+    assert fg3.run() == 0
+    its = np.diff([0] + lens)                       # iterations per step 0..4
+    assert its[1] > 5 and its[2:].max() <= 3        # from the third step on the linear extrapolation is the solution
+    assert rel_err(np.array(fg3.get_mean_stress()), full) < 1e-6
+    fg4 = FG()
+    fg4.set_xml((XML % ("2", 0, "x")).replace("<tol>", "<loadstep_extrapolation_order>1</loadstep_extrapolation_order>"
+                                                       "<loadstep_extrapolation_method>transformation</loadstep_extrapolation_method><tol>"))
     with pytest.raises(RuntimeError, match="extrapolation"):
-        fg3.run()
+        fg4.run()
+
+
+@pytest.mark.parametrize("grid,mixing,order,opts", [
+    ((16, 16, 16), "voigt", 1, {}),
+    ((8, 16, 128), "laminate", 2, {}),                 # tiled sweep: strain-state pass on the extrapolated field, then u loop
+    ((16, 16, 16), "laminate", 2, dict(u_loop=0)),
+])
+def test_load_step_extrapolation_matches_oracle(grid, mixing, order, opts):
+    """loadstep_extrapolation_order > 0 (extrapolateLoadstepPolynomial F:21468-21514): a step starts from the polynomial
+    through the converged fields of the previous steps.  The problem is linear in the load parameter, so the linear
+    extrapolation lands on the solution and the later steps need (almost) no iterations."""
+    params = [0.0, 0.25, 0.6, 0.8, 1.0]
+    s = make_gpu_solver(grid, mixing=mixing, tol=1e-8, loadstep_extrapolation_order=order, **opts)
+    o = make_oracle(grid, mixing=mixing, tol=1e-8, loadstep_extrapolation_order=order)
+    its = []
+    assert o.run_load_steps(E_LOAD, params=params) is False
+    assert s.run_load_steps(E_LOAD, params=params, step_callback=lambda i: its.append(s.iterations) and False) is False
+    assert its == o.step_iterations
+    assert max(its[2:]) <= 3 < its[1]
+    assert np.abs(np.array(s.residuals) - np.array(o.residuals)).max() < 1e-10
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-10
+    s.close()

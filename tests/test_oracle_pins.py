@@ -439,3 +439,25 @@ def test_scalar_mixed_bc_prescribed_flux_through_layers():
     k_series = 1 / ((5 / 8) / 1.0 + (3 / 8) / 10.0)
     assert o.mean_strain()[0] == pytest.approx(2.0 / k_series, rel=1e-9)
     assert np.abs(o.mean_stress() - np.array([2.0, 0, 0])).max() < 1e-9
+
+
+def test_load_step_extrapolation_is_exact_for_polynomial_histories_and_cuts_iterations():
+    """extrapolateLoadstepPolynomial  F:21468-21514: the polynomial through the last fields evaluated at the new parameter
+    (exact for fields that ARE polynomials of that degree in t), and in runLoadsteppingSolver F:21634-21650 the linear
+    problem's later steps start on the solution."""
+    from helpers import make_oracle
+    rng = np.random.default_rng(5)
+    a, b, c = (rng.standard_normal((6, 3, 4, 5)) for _ in range(3))
+    f = lambda t: a + b * t + c * t * t
+    last = [(t, f(t)) for t in (0.1, 0.4, 0.55)]
+    assert np.abs(LSOracle.extrapolate_loadstep_polynomial(last, 0.9) - f(0.9)).max() < 1e-12
+    assert np.abs(LSOracle.extrapolate_loadstep_polynomial(last[1:], 0.9) - (f(0.55) + (f(0.55) - f(0.4)) * (0.35 / 0.15))).max() < 1e-12
+    n = (8, 8, 8)
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    params = [0.0, 0.3, 0.7, 1.0]
+    o0 = make_oracle(n, tol=1e-8)
+    o1 = make_oracle(n, tol=1e-8, loadstep_extrapolation_order=1)
+    assert o0.run_load_steps(E, params=params) is False and o1.run_load_steps(E, params=params) is False
+    assert o1.step_iterations[:2] == o0.step_iterations[:2]      # nothing to extrapolate from before the third step
+    assert max(o1.step_iterations[2:]) <= 3 < min(o0.step_iterations[1:])
+    assert np.abs(o1.eps - o0.eps).max() < 1e-6
