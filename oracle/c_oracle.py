@@ -15,6 +15,10 @@ _dp = ctypes.POINTER(ctypes.c_double)
 
 
 def _P(a):
+    # the C side indexes [c][x][y][z] with z fastest: a Fortran-ordered or strided array (np.stack of transposed views
+    # keeps the inputs' order) must not reach it silently
+    if not (a.flags["C_CONTIGUOUS"] and a.dtype == np.float64):
+        raise ValueError("oracle/c expects C-contiguous float64 arrays")
     return a.ctypes.data_as(_dp)
 
 
@@ -55,6 +59,7 @@ class CRef:
         return ctypes.c_double(float(v))
 
     def calc_stress(self, mu_0, lambda_0, eps, alpha=1.0):
+        eps = np.ascontiguousarray(eps, dtype=np.float64)
         tau = np.empty_like(eps)
         err = self.lib.ref_calc_stress(self.nx, self.ny, self.nz, _P(eps), _P(self.phi),
                                        _P(self.normals) if self.normals is not None else None, len(self.mu),
@@ -65,6 +70,7 @@ class CRef:
         return tau
 
     def mean_stress(self, eps):
+        eps = np.ascontiguousarray(eps, dtype=np.float64)
         out = np.zeros(6)
         self.lib.ref_mean_stress(self.nx, self.ny, self.nz, _P(eps), _P(self.phi),
                                  _P(self.normals) if self.normals is not None else None, len(self.mu), _P(self.mu),
@@ -72,6 +78,7 @@ class CRef:
         return out
 
     def div(self, tau):
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
         f = np.empty((3,) + tau.shape[1:])
         self.lib.ref_div(self.nx, self.ny, self.nz, *map(self._d, self.dims), _P(tau), _P(f))
         return f
@@ -84,11 +91,13 @@ class CRef:
 
     def eps_op(self, E, u):
         E = np.ascontiguousarray(E, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
         y = np.empty((6,) + u.shape[1:])
         self.lib.ref_eps(self.nx, self.ny, self.nz, *map(self._d, self.dims), _P(E), _P(u), _P(y))
         return y
 
     def component_norm(self, eps):
+        eps = np.ascontiguousarray(eps, dtype=np.float64)
         m = np.zeros(6)
         self.lib.ref_component_norm(ctypes.c_size_t(self.N), _P(eps), _P(m))
         return m

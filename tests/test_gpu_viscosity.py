@@ -119,3 +119,29 @@ def test_fg_viscosity_project():
       <actions><run_load_case e11="1" /></actions></settings>""")
     with pytest.raises(RuntimeError, match="zero trace"):
         fg2.run()
+
+
+@pytest.mark.parametrize("V,n", [(0.20, 32), (0.08, 32), (0.28, 48)])
+def test_fg_nunan_keller_demo_project(V, n):
+    """demo/viscosity/nunan_keller/project.xml (and its python twin) on the product path: the project as written except
+    for gamma_scheme (full_staggered there, staggered here) and the grid; alpha and beta evaluated like the demo does
+    (demo/python/nunan_keller/project.xml:38-40) against the table of Nunan & Keller it carries."""
+    from fibergen_amd import FG
+    from test_oracle_pins import NUNAN_KELLER
+    fg = FG()
+    fg.set_xml("""
+    <settings><print_precision>6</print_precision>
+      <solver n="%d">
+        <materials><matrix mu="1" /><fiber mu="0" /></materials>
+        <mode>viscosity</mode><gamma_scheme>staggered</gamma_scheme><method>cg</method>
+        <tol>1e-5</tol><smooth_tol>1e-5</smooth_tol></solver>
+      <actions><select_material name="fiber" /><place_fiber V="%g" /><calc_effective_properties /></actions>
+    </settings>""" % (n, V))
+    assert fg.run() == 0
+    mu_eff = fg.get_effective_property()
+    alpha = 0.5 * (mu_eff[0][0] - mu_eff[0][1]) - 1
+    beta = mu_eff[3][3] - 1
+    assert fg.get_volume_fraction("fiber") == pytest.approx(V, rel=2e-3)
+    assert alpha == pytest.approx(NUNAN_KELLER[V][0], rel=0.03)
+    assert beta == pytest.approx(NUNAN_KELLER[V][1], rel=0.025)
+    assert mu_eff[3][3] == pytest.approx(mu_eff[4][4], rel=1e-4) and mu_eff[3][3] == pytest.approx(mu_eff[5][5], rel=1e-4)

@@ -461,3 +461,30 @@ def test_load_step_extrapolation_is_exact_for_polynomial_histories_and_cuts_iter
     assert o1.step_iterations[:2] == o0.step_iterations[:2]      # nothing to extrapolate from before the third step
     assert max(o1.step_iterations[2:]) <= 3 < min(o0.step_iterations[1:])
     assert np.abs(o1.eps - o0.eps).max() < 1e-6
+
+
+# Nunan & Keller (1984), "Effective viscosity of a periodic suspension": coefficients (alpha, beta) of the effective
+# viscosity tensor of a simple cubic lattice of rigid spheres at volume fraction V -- the table the reference carries in
+# demo/viscosity/nunan_keller/project.xml:21-32 (and demo/python/nunan_keller/project.xml:21-31 with the evaluation
+# alpha = (mu_eff[0][0] - mu_eff[0][1]) / 2 - 1, beta = mu_eff[3][3] - 1).
+NUNAN_KELLER = {0.01: (0.025941, 0.024813), 0.02: (0.053804, 0.049320), 0.04: (0.11567, 0.097696), 0.08: (0.26755, 0.19337),
+                0.12: (0.46580, 0.28995), 0.16: (0.72502, 0.39009), 0.20: (1.0666, 0.49665), 0.24: (1.5228, 0.61306),
+                0.28: (2.1459, 0.74379)}
+
+
+@pytest.mark.parametrize("V,n", [(0.20, 16), (0.08, 16)])
+def test_viscosity_nunan_keller_lattice_of_rigid_spheres(V, n):
+    """The reference-held table of the viscosity mode.  The demo runs gamma_scheme full_staggered at n = 64; the staggered
+    scheme of this path on a 16^3 grid lands within a few per cent (alpha: extension along the lattice axes, beta: shear)."""
+    from oracle.viscosity_oracle import ViscosityOracle
+    from helpers import sphere_phi
+    R = (3 * V / (4 * math.pi)) ** (1 / 3)
+    phi = sphere_phi((n, n, n), R, sub=8)
+    o = ViscosityOracle(n, n, n, mats=[(1.0, 0.0), (0.0, 0.0)], phis=[1 - phi, phi], tol=1e-5)   # fluidity 0: rigid
+    assert o.run_cg(np.array([1.0, -1.0, 0, 0, 0, 0])) is False
+    rate_axial = o.mean_stress()[0]          # mean shear rate = stress / (2 eta): 1 / (2 (1 + alpha)) for the unit fluid
+    assert o.run_cg(np.array([0, 0, 0, 1.0, 0, 0])) is False
+    rate_shear = o.mean_stress()[3]
+    alpha, beta = 1 / (2 * rate_axial) - 1, 1 / (2 * rate_shear) - 1
+    assert alpha == pytest.approx(NUNAN_KELLER[V][0], rel=0.04)
+    assert beta == pytest.approx(NUNAN_KELLER[V][1], rel=0.02)
