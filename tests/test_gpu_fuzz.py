@@ -1,0 +1,189 @@
+"""Randomised combinations through the C ABI against the NumPy oracle: every seed draws a grid (powers of two, odd,
+prime, p * 2^k lengths, tile-sized rows), a cell, one to three phases with smooth random fraction fields and random
+isotropic moduli, the mixing rule, the Green operator, the solution method, the loop variant (u_loop / u_tile / fuse_x),
+optionally mixed boundary conditions and load steps -- the combinations the hand-written cases of the other files do not
+enumerate.  The draw is deterministic per seed; a failing seed is a bug report.
+
+Bars: iteration counts equal, residual histories 1e-9, strain fields 1e-8, mean stress 1e-9 (runs to tol 1e-7)."""
+import numpy as np
+import pytest
+
+from helpers import lame, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LENGTHS_XY = [1, 2, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24]
+LENGTHS_Z = [1, 4, 5, 6, 8, 9, 12, 16, 24, 124, 128]
+PROJECTORS = {   # diagonal of the Voigt projector onto the prescribed-strain components (shear entries carry 1/2); the rest: stress
+    "uniaxial_stress_x": [1, 0, 0, 0, 0, 0],
+    "plane_strain_free_z": [1, 1, 0, 0.5, 0.5, 0.5],
+    "shear_only": [0, 0, 0, 0, 0, 0.5],
+}
+
+
+def smooth_field(rng, shape):
+    """a smooth periodic field in [0, 1] with flat parts at both ends (pure voxels and mixtures)"""
+    x = [np.arange(m) / m for m in shape]
+    f = np.zeros(shape)
+    for _ in range(3):
+        k = rng.integers(0, 3, size=3)
+        ph = rng.uniform(0, 2 * np.pi, size=3)
+        f += rng.uniform(0.5, 1.0) * (np.cos(2 * np.pi * k[0] * x[0] + ph[0])[:, None, None] *
+                                      np.cos(2 * np.pi * k[1] * x[1] + ph[1])[None, :, None] *
+                                      np.cos(2 * np.pi * k[2] * x[2] + ph[2])[None, None, :])
+    f = (f - f.min()) / max(f.max() - f.min(), 1e-300)
+    return np.clip(1.6 * f - 0.3, 0.0, 1.0)
+
+
+def draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    while True:
+        shape = (int(rng.choice(LENGTHS_XY)), int(rng.choice(LENGTHS_XY)), int(rng.choice(LENGTHS_Z)))
+        if 8 <= shape[0] * shape[1] * shape[2] <= 40000:
+            break
+    dims = tuple(float(v) for v in rng.uniform(0.5, 2.0, size=3))
+    nph = int(rng.integers(1, 4))
+    mixing = "laminate" if (nph == 2 and rng.random() < 0.5) else "voigt"
+    mats = [lame(E=float(rng.uniform(0.5, 20.0)), nu=float(rng.uniform(0.05, 0.4))) for _ in range(nph)]
+    if nph == 1:
+        phis = [np.ones(shape)]
+    elif nph == 2:
+        p1 = smooth_field(rng, shape)
+        phis = [1.0 - p1, p1]
+    else:
+        p1, p2 = smooth_field(rng, shape), smooth_field(rng, shape)
+        p2 = np.minimum(p2, 1.0 - p1)
+        phis = [1.0 - p1 - p2, p1, p2]
+    normals = None
+    if mixing == "laminate":
+        v = rng.standard_normal((3,) + shape)
+        normals = v / np.sqrt((v * v).sum(axis=0))
+    scheme = "collocated" if rng.random() < 0.2 else "staggered"
+    method = "cg" if rng.random() < 0.35 else "basic"
+    opts = {}
+    if rng.random() < 0.5:
+        opts["u_loop"] = int(rng.integers(0, 3))
+    if rng.random() < 0.3:
+        opts["fuse_x"] = int(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        opts["u_tile"] = int(rng.choice([0, 8, 12, 16]))
+    if rng.random() < 0.3:
+        opts["fuse_stress_div"] = int(rng.integers(0, 2))
+    bc = None
+    if rng.random() < 0.3:
+        bc = str(rng.choice(list(PROJECTORS)))
+    steps = None
+    if rng.random() < 0.25:
+        steps = [0.0, 0.4, 1.0]
+    E = rng.uniform(-1.0, 1.0, size=6)
+    return dict(shape=shape, dims=dims, mats=mats, phis=phis, normals=normals, mixing=mixing, scheme=scheme, method=method,
+                opts=opts, bc=bc, steps=steps, E=E)
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_combination_matches_oracle(seed):
+    from fibergen_amd import LSSolver
+    from oracle.ls_oracle import LSOracle
+    c = draw(seed)
+    shape, dims = c["shape"], c["dims"]
+    common = dict(tol=1e-7, maxiter=400)
+    o = LSOracle(*shape, *dims, mats=c["mats"], phis=c["phis"], normals=c["normals"], mixing_rule=c["mixing"],
+                 gamma_scheme=c["scheme"], **common)
+    s = LSSolver(*shape, *dims)
+    s.set_num_phases(len(c["mats"]))
+    for p, (m, phi) in enumerate(zip(c["mats"], c["phis"])):
+        s.set_phase(p, m[0], m[1], phi)
+    if c["normals"] is not None:
+        s.set_normals(c["normals"])
+    s.set_options(mixing_rule=c["mixing"], gamma_scheme=c["scheme"], method=c["method"], **common, **c["opts"])
+    E, S0, P = c["E"].copy(), np.zeros(6), None
+    if c["bc"] is not None:
+        keep = np.array(PROJECTORS[c["bc"]], dtype=float)
+        P = np.diag(keep)
+        E = E * (keep > 0)                 # prescribed strain lives in the range of P, the stress (zero) in its complement
+        s.set_bc_projector(P)
+    params = c["steps"] or [0.0, 1.0]
+    tag = "seed %d: %s" % (seed, {k: c[k] for k in ("shape", "mixing", "scheme", "method", "opts", "bc", "steps")})
+    try:
+        ref_failed = o.run_load_steps(E, S0, P, params=params, method=c["method"])
+    except RuntimeError as e:
+        # a combination the reference rejects must be rejected by the product with the same message
+        with pytest.raises(RuntimeError) as got:
+            s.run_load_steps(E, S0, params=params)
+        assert str(e).split(":")[0][:24] in str(got.value), tag
+        s.close()
+        return
+    failed = s.run_load_steps(E, S0, params=params)
+    assert failed == ref_failed, tag
+    assert s.iterations == o.iterations, tag
+    r, rr = np.array(s.residuals), np.array(o.residuals)
+    assert r.shape == rr.shape and np.abs(r - rr).max() < 1e-9, tag
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8, tag
+    assert np.abs(s.mean_stress() - o.mean_stress()).max() < 1e-9 * max(1.0, np.abs(o.mean_stress()).max()), tag
+    s.close()
+
+
+def draw_slab(seed):
+    rng = np.random.default_rng(5000 + seed)
+    P = int(rng.choice([1, 2, 4]))
+    fast = rng.random() < 0.5               # grids the tiled sweep fits (displacement loop per slab) or small / odd ones
+    if fast:
+        shape = (P * int(rng.choice([4, 8])), int(rng.choice([16, 32])) if P < 4 else 16, int(rng.choice([124, 128])))
+    else:
+        while True:
+            shape = (P * int(rng.choice([1, 2, 3, 4, 6])), P * int(rng.choice([1, 2, 3, 4, 5])), int(rng.choice(LENGTHS_Z[:9])))
+            if 8 <= shape[0] * shape[1] * shape[2] <= 20000:
+                break
+    dims = tuple(float(v) for v in rng.uniform(0.5, 2.0, size=3))
+    nph = int(rng.integers(1, 4))
+    mixing = "laminate" if (nph == 2 and rng.random() < 0.6) else "voigt"
+    mats = [lame(E=float(rng.uniform(0.5, 20.0)), nu=float(rng.uniform(0.05, 0.4))) for _ in range(nph)]
+    if nph == 1:
+        phis = [np.ones(shape)]
+    elif nph == 2:
+        p1 = smooth_field(rng, shape)
+        phis = [1.0 - p1, p1]
+    else:
+        p1, p2 = smooth_field(rng, shape), smooth_field(rng, shape)
+        p2 = np.minimum(p2, 1.0 - p1)
+        phis = [1.0 - p1 - p2, p1, p2]
+    v = rng.standard_normal((3,) + shape)
+    normals = v / np.sqrt((v * v).sum(axis=0))
+    bc = str(rng.choice(list(PROJECTORS))) if rng.random() < 0.3 else None
+    opts = {"slab_split": int(rng.integers(0, 2))}
+    if rng.random() < 0.3:
+        opts["fuse_x"] = int(rng.integers(0, 2))
+    if rng.random() < 0.2:
+        opts["phi_sweep"] = 0
+    return dict(P=P, shape=shape, dims=dims, mats=mats, phis=phis, normals=normals, mixing=mixing, bc=bc, opts=opts,
+                E=rng.uniform(-1.0, 1.0, size=6))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_slab_group_matches_oracle(seed):
+    """The slab driver (all P slabs in this process, exchanges as device copies) on random problems."""
+    from fibergen_amd.distributed import SlabGroup
+    from oracle.ls_oracle import LSOracle
+    c = draw_slab(seed)
+    shape, dims = c["shape"], c["dims"]
+    common = dict(tol=1e-7, maxiter=400)
+    o = LSOracle(*shape, *dims, mats=c["mats"], phis=c["phis"], normals=c["normals"], mixing_rule=c["mixing"], **common)
+    g = SlabGroup(*shape, *dims, nranks=c["P"])
+    g.set_num_phases(len(c["mats"]))
+    for p, (m, phi) in enumerate(zip(c["mats"], c["phis"])):
+        g.set_phase(p, m[0], m[1], phi)
+    g.set_normals(c["normals"])
+    g.set_options(mixing_rule=c["mixing"], **common, **c["opts"])
+    E, S0, P = c["E"].copy(), np.zeros(6), None
+    if c["bc"] is not None:
+        keep = np.array(PROJECTORS[c["bc"]], dtype=float)
+        P = np.diag(keep)
+        E = E * (keep > 0)
+        g.set_bc_projector(P)
+    tag = "seed %d: %s" % (seed, {k: c[k] for k in ("P", "shape", "mixing", "opts", "bc")})
+    assert o.run(E, S0, P) is False and g.run(E, S0) is False, tag
+    assert g.iterations == o.iterations, tag
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-9, tag
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8, tag
+    assert np.abs(g.mean_stress() - o.mean_stress()).max() < 1e-9 * max(1.0, np.abs(o.mean_stress()).max()), tag
+    g.close()
