@@ -48,6 +48,8 @@ class FG:
 
     def __init__(self, device=0):
         self._device = device
+        self._shard = False
+        self._shard_group = None
         self._project = XMLProject()
         self._variables = {}
         self._py_enabled = True
@@ -186,6 +188,23 @@ class FG:
     # ------------------------------------------------------------------ callbacks / misc API
     def set_convergence_callback(self, func):
         self._convergence_callback = func
+
+    def shard_load_cases(self, enable=True, group=None):
+        """Extension of the reference API for multi-GPU jobs (one process per GPU, torch.distributed initialised, this FG
+        created with device = LOCAL_RANK): calc_effective_properties gives each rank every world_size-th of its six unit
+        experiments and gathers the mean stresses -- the load cases are independent, no field ever crosses a link.  Every
+        rank ends with the same effective stiffness.  (The slab decomposition of ONE load case is
+        fibergen_amd.distributed.DistributedLSSolver.)"""
+        self._shard = bool(enable)
+        self._shard_group = group
+
+    def _load_case_shard(self):
+        if not getattr(self, "_shard", False):
+            return 0, 1
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0, 1
+        return dist.get_rank(self._shard_group), dist.get_world_size(self._shard_group)
 
     def set_loadstep_callback(self, func):
         self._loadstep_callback = func
@@ -807,16 +826,27 @@ class FG:
                          self._Ceff_voigt)
                 return None
             S = np.zeros((6, 6))
-            for i in range(6):
+            rank, world = self._load_case_shard()
+            bad = False
+            for i in range(rank, 6, world):   # the six unit experiments are independent: one rank each (no data-path collective)
                 Ep = np.zeros(6)
                 Ep[i] = 1.0
                 failed = self._run_lss(Ep)
                 if failed or self._error is not None:
-                    self._error = self._error or "NaN detected in solution. Aborting."
-                    return EXIT_FAILURE
+                    bad = True
+                    break
                 S[:, i] = self._lss.mean_stress()
                 if outdir:
                     self.write_vtk("%s/results_%d.vtk" % (outdir, i + 1))  # F:26056-26062
+            if world > 1:
+                import torch.distributed as dist
+                parts = [None] * world
+                dist.all_gather_object(parts, (bad, S), group=self._shard_group)
+                bad = any(b for b, _ in parts)
+                S = sum(Sp for _, Sp in parts)
+            if bad:
+                self._error = self._error or "NaN detected in solution. Aborting."
+                return EXIT_FAILURE
             Ceff = S @ np.linalg.inv(np.eye(6))  # Ceff = S E^-1 with unit experiments  F:26072-26075
             Cv = Ceff.copy()
             Cv[:, 3:6] *= 0.5                     # F:26083-26088

@@ -118,6 +118,20 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if a.backend == "fg-shard":
+        # calc_effective_properties with the six load cases dealt to the ranks (FG.shard_load_cases)
+        from fibergen_amd import FG
+        fg = FG(device=0)
+        fg.set_xml("""<settings><solver nx="%d" ny="%d" nz="%d"><tol>%g</tol><method>basic</method><mixing_rule>%s</mixing_rule>
+          <materials><matrix E="1" nu="0.3" /><inclusion E="10" nu="0.2" /></materials></solver>
+          <actions><select_material name="inclusion" /><place_fiber R="0.3" /><calc_effective_properties /></actions>
+        </settings>""" % (grid + (a.tol, a.mixing)))
+        fg.shard_load_cases(True)
+        rc = fg.run()
+        np.savez(a.out + ".%d.npz" % rank, rc=rc, C=np.array(fg.get_effective_property()))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     from helpers import two_phase_setup
     from fibergen_amd.distributed import DistributedLSSolver
     mats, phis, normals = two_phase_setup(grid, a.mixing)

@@ -50,3 +50,22 @@ def test_hip_slabs_mixed_bc(tmp_path):
     eps = np.concatenate([r["eps"] for r in res], axis=1)
     assert int(res[0]["iterations"]) == o.iterations
     assert rel_err(eps, o.eps) < 1e-8
+
+
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_fg_load_cases_sharded_over_ranks(tmp_path, nproc):
+    """FG.shard_load_cases: the six unit experiments of calc_effective_properties dealt to the ranks (no data-path
+    collective, only the 6 x 6 means are gathered); every rank ends with the stiffness one process computes alone."""
+    from fibergen_amd import FG
+    res = launch(nproc, str(tmp_path / "s"), "--backend", "fg-shard", "--grid", "16,16,16", "--tol", "1e-8")
+    fg = FG()
+    fg.set_xml("""<settings><solver n="16"><tol>1e-8</tol><method>basic</method><mixing_rule>voigt</mixing_rule>
+      <materials><matrix E="1" nu="0.3" /><inclusion E="10" nu="0.2" /></materials></solver>
+      <actions><select_material name="inclusion" /><place_fiber R="0.3" /><calc_effective_properties /></actions>
+    </settings>""")
+    assert fg.run() == 0
+    C = np.array(fg.get_effective_property())
+    for r in res:
+        assert int(r["rc"]) == 0
+        assert np.array_equal(r["C"], res[0]["C"])
+        assert rel_err(r["C"], C) < 1e-12
