@@ -5,10 +5,16 @@ optionally mixed boundary conditions and load steps -- the combinations the hand
 enumerate.  The draw is deterministic per seed; a failing seed is a bug report.
 
 Bars: iteration counts equal, residual histories 1e-9, strain fields 1e-8, mean stress 1e-9 (runs to tol 1e-7)."""
+import os
+
 import numpy as np
 import pytest
 
 from helpers import lame, rel_err
+
+# FG_FUZZ_SEEDS=n widens both sweeps to n seeds (a soak run; the suite keeps the first 150 / 60)
+N_SINGLE = int(os.environ.get("FG_FUZZ_SEEDS", "150"))
+N_SLAB = int(os.environ.get("FG_FUZZ_SEEDS", "60"))
 
 pytestmark = pytest.mark.gpu
 
@@ -80,7 +86,7 @@ def draw(seed):
                 opts=opts, bc=bc, steps=steps, E=E)
 
 
-@pytest.mark.parametrize("seed", range(150))
+@pytest.mark.parametrize("seed", range(N_SINGLE))
 def test_random_combination_matches_oracle(seed):
     from fibergen_amd import LSSolver
     from oracle.ls_oracle import LSOracle
@@ -159,7 +165,7 @@ def draw_slab(seed):
                 E=rng.uniform(-1.0, 1.0, size=6))
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(N_SLAB))
 def test_random_slab_group_matches_oracle(seed):
     """The slab driver (all P slabs in this process, exchanges as device copies) on random problems."""
     from fibergen_amd.distributed import SlabGroup
