@@ -193,3 +193,74 @@ def test_random_slab_group_matches_oracle(seed):
     assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8, tag
     assert np.abs(g.mean_stress() - o.mean_stress()).max() < 1e-9 * max(1.0, np.abs(o.mean_stress()).max()), tag
     g.close()
+
+
+def draw_scalar(seed):
+    rng = np.random.default_rng(9000 + seed)
+    while True:
+        shape = (int(rng.choice(LENGTHS_XY)), int(rng.choice(LENGTHS_XY)), int(rng.choice(LENGTHS_Z)))
+        if 8 <= shape[0] * shape[1] * shape[2] <= 40000:
+            break
+    dims = tuple(float(v) for v in rng.uniform(0.5, 2.0, size=3))
+    nph = int(rng.integers(1, 4))
+    mus = [float(rng.uniform(0.05, 20.0)) for _ in range(nph)]
+    if nph == 1:
+        phis = [np.ones(shape)]
+    elif nph == 2:
+        p1 = smooth_field(rng, shape)
+        phis = [1.0 - p1, p1]
+    else:
+        p1, p2 = smooth_field(rng, shape), smooth_field(rng, shape)
+        p2 = np.minimum(p2, 1.0 - p1)
+        phis = [1.0 - p1 - p2, p1, p2]
+    return dict(shape=shape, dims=dims, mus=mus, phis=phis, mode=str(rng.choice(["heat", "porous", "viscosity"])),
+                method="cg" if rng.random() < 0.35 else "basic", u_loop=int(rng.choice([1, 2])),
+                bc=rng.random() < 0.25, E=rng.uniform(-1.0, 1.0, size=6))
+
+
+@pytest.mark.parametrize("seed", range(N_SLAB))
+def test_random_scalar_and_viscosity_problems_match_their_oracles(seed):
+    """mode = heat / porous (potential-based loop, ScalarOracle) and viscosity (dual Stokes scheme, ViscosityOracle)."""
+    from fibergen_amd import LSSolver
+    c = draw_scalar(seed)
+    shape, dims, mode = c["shape"], c["dims"], c["mode"]
+    common = dict(tol=1e-7, maxiter=300)
+    s = LSSolver(*shape, *dims)
+    s.set_options(mode=mode)
+    s.set_num_phases(len(c["mus"]))
+    for p, (mu, phi) in enumerate(zip(c["mus"], c["phis"])):
+        s.set_phase(p, mu, 0.0, phi)
+    tag = "seed %d: %s" % (seed, {k: c[k] for k in ("shape", "mode", "method", "u_loop", "bc")})
+    if mode == "viscosity":
+        from oracle.viscosity_oracle import ViscosityOracle
+        o = ViscosityOracle(*shape, *dims, mats=[(m, 0.0) for m in c["mus"]], phis=c["phis"], **common)
+        E = c["E"].copy()
+        E[:3] -= E[:3].mean()               # the prescribed fluid stress is traceless
+        s.set_options(method=c["method"], **common)
+        ref_failed = o.run_cg(E) if c["method"] == "cg" else o.run(E)
+        failed = s.run(E)
+    else:
+        from oracle.scalar_oracle import ScalarOracle
+        o = ScalarOracle(*shape, mus=c["mus"], phis=c["phis"], dx=dims[0], dy=dims[1], dz=dims[2], **common)
+        E = c["E"][:3].copy()
+        s.set_options(method=c["method"], u_loop=c["u_loop"], **common)
+        if c["bc"] and c["method"] == "basic":
+            P3 = np.diag([1.0, 0.0, 1.0])   # gradient prescribed along x and z, zero mean flux along y
+            P6 = np.zeros((6, 6))
+            P6[:3, :3] = P3
+            E = E * np.array([1.0, 0.0, 1.0])
+            s.set_bc_projector(P6)
+            s.set_options(bc_tol=1e-8)
+            o.bc_tol = 1e-8
+            ref_failed = o.run(E, np.zeros(3), P3)
+            failed = s.run(E, np.zeros(6))
+        else:
+            ref_failed = o.run_cg(E) if c["method"] == "cg" else o.run(E)
+            failed = s.run(E)
+    assert failed == ref_failed, tag
+    assert s.iterations == o.iterations, tag
+    assert np.abs(np.array(s.residuals) - np.array(o.residuals)).max() < 1e-9, tag
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8, tag
+    ms = np.asarray(s.mean_stress())[:len(np.atleast_1d(o.mean_stress()))]
+    assert np.abs(ms - o.mean_stress()).max() < 1e-9 * max(1.0, np.abs(o.mean_stress()).max()), tag
+    s.close()
