@@ -112,3 +112,31 @@ def test_bench_scale_geometry():
     assert dt < 60
     assert phi[1].max() == 1.0 and 0.02 < ((phi[1] > 0) & (phi[1] < 1)).mean() < 0.05
     assert len(inside) > 5 and phi[1].mean() < real[1] + 1e-3
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_equal_checker(seed):
+    """Seeded random scenes: grid and cell shape, origin, a mix of spheres, capsules and half spaces of up to three
+    materials, overlapping, any smoothing depth / tolerance."""
+    rng = np.random.default_rng(300 + seed)
+    shape = tuple(int(v) for v in rng.choice([1, 2, 5, 8, 12, 16, 24, 33], size=3))
+    dims = tuple(float(v) for v in rng.uniform(0.5, 2.0, size=3))
+    x0 = tuple(float(v) for v in rng.uniform(-1.0, 1.0, size=3))
+    nmat = int(rng.integers(1, 4))
+    fibers = []
+    for _ in range(int(rng.integers(1, 16))):
+        c = [x0[k] + rng.random() * dims[k] for k in range(3)]
+        a = rng.standard_normal(3).tolist()
+        m = int(rng.integers(1, nmat + 1))
+        kind = rng.random()
+        if kind < 0.15:
+            fibers.append(Fiber("halfspace", c, a, 0, 0.25, m))
+        elif kind < 0.4:
+            fibers.append(Fiber("capsule", c, a, 0.0, float(rng.uniform(0.02, 0.4)), m))
+        else:
+            fibers.append(Fiber("capsule", c, a, float(rng.uniform(0.0, 0.8)), float(rng.uniform(0.02, 0.2)), m))
+    kw = dict(smooth_levels=int(rng.choice([-1, 0, 1, 2])), smooth_tol=float(10.0 ** rng.uniform(-4, -1)))   # (24 seeds with levels 3 / tol 1e-5 passed too: 2 min of checker time)
+    (phi, nrm, real), (phi_c, nrm_c, real_c) = both(fibers, shape, dims, x0, nph=nmat + 1, **kw)
+    assert np.abs(phi - phi_c).max() <= TOL, (seed, shape, kw)
+    assert np.abs(nrm - nrm_c).max() <= 1e-13, (seed, shape, kw)
+    assert real == real_c
