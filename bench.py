@@ -264,6 +264,10 @@ def main():
                     help="N = 1: also run the slab driver with this many slabs on the one GPU (0 = skip)")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the load-case replica measurement")
     ap.add_argument("--slab-timeout", type=int, default=300)
+    ap.add_argument("--also-slab", default="512:laminate",
+                    help="N > 1: one more slab-decomposed workload n:mixing after the headline one, reported under `also_slab` "
+                         "(default: BASELINE's north-star target configuration; '' = none).  Its failure or timeout leaves "
+                         "the headline line untouched")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="N > 1: torch.distributed backend.  gloo is the dry run of this script's multi-rank path on a box with "
                          "ONE GPU: all ranks share device 0 and the slab exchanges are staged through the host")
@@ -464,6 +468,37 @@ def main():
         if dry:
             line["config"]["parallelism"] += " -- DRY RUN: all ranks on one GPU, exchanges staged through the host (gloo)"
         d.close()
+        timer.cancel()
+        if args.also_slab:
+            # the north-star target configuration through the same driver; whatever happens here, the headline line stands
+            def give_up():
+                line["also_slab"] = {args.also_slab: {"error": "exceeded %d s" % args.slab_timeout}}
+                emit(line, 0)
+            timer = threading.Timer(args.slab_timeout, give_up)
+            timer.daemon = True
+            timer.start()
+            try:
+                ne, mix = args.also_slab.split(":")
+                ne = int(ne)
+                if ne % world:
+                    raise RuntimeError("grid not divisible by the number of ranks")
+                phi2, normals2, par2 = bench_rve(ne, mix)
+                d2 = DistributedLSSolver(ne, ne, ne, device=local_rank)
+                configure(d2, phi2, normals2, mix, "elasticity", slab=d2.slab)
+                del phi2, normals2
+                d2.calc_ref_material()
+                steps2 = max(5, args.steps // 2) if ne >= 512 else args.steps
+                dts2 = timed_regions(lambda k: d2.iterate(E, k), lambda: sync_all(d2), steps2, min(args.warmup, 3), 3)
+                med2 = max_over_ranks(statistics.median(dts2))
+                kern2, _, _ = kernel_table(d2, E, (ne // world, ne, ne), min(steps2, 10), False)
+                line["also_slab"] = {"%d^3 %s" % (ne, mix): {
+                    "it_s": steps2 / med2, "ms_per_step": 1e3 * med2 / steps2, "steps": steps2, "repeats": 3,
+                    "rve": {"K": par2["K"], "R": par2["R"], "L": par2["L"]}, "transport": d2.transport,
+                    "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern2.items()},
+                    "alltoall_MB_per_gpu_per_pass": 2 * 3 * (world - 1) / world * (ne // world) * ne * (ne // 2 + 1) * 16 / 1e6}}
+                d2.close()
+            except Exception as e:  # noqa: BLE001
+                line["also_slab"] = {args.also_slab: {"error": "%s: %s" % (type(e).__name__, e)}}
     except Exception as e:  # noqa: BLE001
         line.update({"value": replicas["value"] if replicas else None, "ms_per_step": replicas["ms_per_step"] if replicas else None,
                      "scaling": "weak", "replicas": replicas, "slab": {"error": "%s: %s" % (type(e).__name__, e)}})
