@@ -124,7 +124,7 @@ int emu_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, doub
   a.kp[2] = reinterpret_cast<const cplx*>(kp2);
 #define CASE(n)                                                               \
   if (N == n) {                                                               \
-    constexpr int C = XTileCols<n>::value;                                    \
+    constexpr int C = 8; /* the product's tile width for three components */     \
     a.tiles_per_outer = (a.ncols + C - 1) / C;                                \
     for (int q = 0; q < 8; ++q) {                                             \
       const double th = 3.14159265358979323846 * fft::Line<n>::last_index(0, q) / n;      \
