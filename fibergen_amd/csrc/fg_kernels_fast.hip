@@ -818,6 +818,24 @@ bool u_tile_supported(const Grid& g) {
   return g.nz % 2 == 0 && nzh >= 62 && g.ny >= 14 && g.nx >= 4;
 }
 
+// Planes per march of the tiled sweep.  A march of LX planes costs LX + 3 steps (pipeline fill), the workgroups are dealt
+// to the CUs in rounds, and a CU with two workgroups runs each at half speed, so the sweep takes about
+// ceil(tiles * ceil(nx / LX) / CUs) * (LX + 3) steps: the LX with the smallest product wins, the longer march on a tie.
+// Measured against the fixed 32 / 16 of round 1: 128^3 16 -> 12 planes (242 workgroups on 256 CUs) 0.0366 -> 0.0347 ms,
+// 11 planes (264: a second round) 0.049 ms; 256^3 32 -> 64 (exactly 256 workgroups) 0.210 -> 0.203 ms, 48 (384) 0.265 ms;
+// 512^3 32 -> 64: -1 %; thin x-slabs 32 x 256 x 256 -> 8, 64 x 512 x 512 -> 16 as measured before (44.7 -> 39.9 us,
+// 281 -> 240 us).
+inline int march_length(int nx, long tiles, int cus) {
+  int best = nx < 4 ? nx : 4;
+  long best_cost = -1;
+  for (int lx = 4; lx <= nx && lx <= 64; ++lx) {   // (128-plane marches: 384^3 0.727 -> 0.766 ms, 512^3 no gain: neighbouring tiles drift apart)
+    const long groups = tiles * ((nx + lx - 1) / lx);
+    const long cost = ((groups + cus - 1) / cus) * (lx + 3);
+    if (best_cost < 0 || cost <= best_cost) best = lx, best_cost = cost;
+  }
+  return best;
+}
+
 template <int TYR, int ZS, bool SUMT, bool PHI2 = false>
 void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s,
@@ -828,16 +846,7 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
   static const int lx_env = getenv("FG_TILE_LX") ? atoi(getenv("FG_TILE_LX")) : 0;  // tuning knob (0 = by size)
   const int cus = device_cu_count();
-  // march length: 32 planes (3 extra planes of loads per march), 16 when that leaves CUs without a workgroup
-  // (128^3: 88 -> 176 workgroups, 0.053 -> 0.039 ms; 8 planes: 0.045 ms)
-  // thin x-slabs of a decomposed grid (nx = 32, 64) march 8 / 16 planes: 32 x 256 x 256: 44.7 -> 39.9 us, 64 x 512 x 512:
-  // 281 -> 240 us (more workgroups to balance over the CUs)
-  int LX = lx_env > 0 ? lx_env : 32;
-  if (lx_env <= 0) {
-    if (g.nx <= 32) LX = 8;
-    else if (g.nx <= 64) LX = 16;
-    else if ((long)nty * ntz * ((g.nx + 31) / 32) < cus) LX = 16;
-  }
+  int LX = lx_env > 0 ? lx_env : march_length(g.nx, (long)nty * ntz, cus);
   if (LX > g.nx) LX = g.nx;
   const int ntx = (g.nx + LX - 1) / LX;
   int nb = nty * ntz * ntx;
