@@ -1065,8 +1065,9 @@ void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double*
   const int nzh = g.nz / 2;
   const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
   const int cus = device_cu_count();
-  int LX = 32;
-  if ((long)nty * ntz * ((g.nx + 31) / 32) < 2L * cus) LX = 16;
+  static const int lx_env = getenv("FG_SC_TILE_LX") ? atoi(getenv("FG_SC_TILE_LX")) : 0;   // -1: the rule of round 1
+  int LX = lx_env > 0 ? lx_env : march_length(g.nx, (long)nty * ntz, 2 * cus);   // the light scalar sweep runs two workgroups per CU at full speed
+  if (lx_env < 0) LX = ((long)nty * ntz * ((g.nx + 31) / 32) < 2L * cus) ? 16 : 32;
   if (LX > g.nx) LX = g.nx;
   const int ntx = (g.nx + LX - 1) / LX;
   int nb = nty * ntz * ntx;
