@@ -160,7 +160,9 @@ struct R2CKernel {
 };
 
 // ------------------------------------------------------------------ z pass, c2r
-template <int M, int LINES>
+// MIRROR: the mirrored coefficient X[M - m] of the merge comes from the lane that loaded it as ITS X[m] (wave shuffle
+// inside the T lanes of the line) instead of a second global load: every coefficient is read once.
+template <int M, int LINES, bool MIRROR = false>
 struct C2RKernel {
   static constexpr int T = M / 8;
   static constexpr int THREADS = T * LINES;
@@ -183,6 +185,27 @@ struct C2RKernel {
       r.valid = row < a.nrows;
       r.row = a.data + row * a.nzp;
       const cplx* in = reinterpret_cast<const cplx*>(r.row);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (MIRROR && T <= 64 && T >= 2 && pass_radix(M, 0) == 8) {
+        // first_index(jt, q) = jt + q T, so X[M - m] = X[(T - jt) + (7 - q) T]: slot 7 - q of lane T - jt of this line
+        // (jt = 0: the own slots 8 - q, and the Nyquist bin for q = 0)
+        cplx x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = r.valid ? cload_stream(&in[r.jt + q * T], a.nt) : cmake(0.0, 0.0);
+        cplx ny = (r.valid && r.jt == 0) ? cload_stream(&in[M], a.nt) : cmake(0.0, 0.0);
+        const int lane = threadIdx.x & 63;
+        const int src = (lane & ~(T - 1)) | ((T - r.jt) & (T - 1));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          cplx xm = cmake(__shfl(x[7 - q].re, src), __shfl(x[7 - q].im, src));
+          if (r.jt == 0) xm = q == 0 ? ny : x[8 - (q ? q : 8)];
+          cplx xk = x[q];
+          if (r.jt == 0 && q == 0) { xk.im = 0.0; xm.im = 0.0; }   // FFTW's c2r ignores the imaginary parts of DC and Nyquist
+          r.v[q] = c2r_merge(xk, xm, a.wz[r.jt + q * T]);
+        }
+      } else
+#endif
+      {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         int m = Line<M>::first_index(r.jt, q);
@@ -194,6 +217,7 @@ struct C2RKernel {
           if (m == 0) { xk.im = 0.0; xm.im = 0.0; }
         }
         r.v[q] = c2r_merge(xk, xm, a.wz[m]);
+      }
       }
     }
     Line<M>::template phase<+1, PH>(r.v, r.jt, lds, L, r.l, a.tw);
