@@ -108,13 +108,16 @@ struct ZArgs {
   int nt;           // streaming stores
 };
 
-template <int M, int LINES>
+// MIRROR: the split X[k] from Z[k] and Z[M - k] takes the mirrored value from the lane that holds it (wave shuffle inside
+// the T lanes of the line) right after the last pass, instead of a round trip of the whole spectrum through LDS.
+template <int M, int LINES, bool MIRROR = false>
 struct R2CKernel {
   static constexpr int T = M / 8;
   static constexpr int THREADS = T * LINES;
   static constexpr int LS = M + M / 8 + 2;       // line stride (doubles)
   static constexpr int LDS_DOUBLES = 2 * LS * LINES;
-  static constexpr int NPHASE = Line<M>::NPHASE + 1;
+  static constexpr bool SHUFFLE = MIRROR && T <= 64 && T >= 2;
+  static constexpr int NPHASE = Line<M>::NPHASE + (SHUFFLE ? 0 : 1);
   struct Regs {
     cplx v[8];
     double* row;
@@ -136,6 +139,33 @@ struct R2CKernel {
         r.v[q] = r.valid ? cload_stream(&reinterpret_cast<const cplx*>(r.row)[m], a.nt) : cmake(0.0, 0.0);
       }
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (SHUFFLE) {
+      Line<M>::template phase<-1, PH>(r.v, r.jt, lds, L, r.l, a.tw);
+      if (PH == NPHASE - 1) {
+        // slot q = (b, rr) of the last pass (radix RL) holds Z[jt + s T], s = b + rr (8 / RL); Z[M - k] is slot s' = 7 - s of
+        // lane T - jt of this line (jt = 0: the own slot 8 - s, Z[M] := Z[0])
+        constexpr int RL = pass_radix(M, num_passes(M) - 1), G = 8 / RL;
+        const int lane = threadIdx.x & 63;
+        const int src = (lane & ~(T - 1)) | ((T - r.jt) & (T - 1));
+        cplx* out = reinterpret_cast<cplx*>(r.row);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int s = q / RL + (q % RL) * G;
+          const int sm = 7 - s, qm = (sm % G) * RL + sm / G;
+          const int s0 = (8 - s) % 8, q0 = (s0 % G) * RL + s0 / G;
+          cplx zm = cmake(__shfl(r.v[qm].re, src), __shfl(r.v[qm].im, src));
+          if (r.jt == 0) zm = r.v[q0];
+          const int k = r.jt + s * T;
+          if (r.valid) cstore_stream(&out[k], r2c_split(r.v[q], zm, a.wz[k]), a.nt);
+        }
+        if (r.valid && r.jt == 0) cstore_stream(&out[M], r2c_split(r.v[0], r.v[0], a.wz[M]), a.nt);   // k = M (Nyquist): Z[M] := Z[0]
+      }
+      return;
+    }
+#endif
     if (PH < NPHASE - 1) {
       Line<M>::template phase<-1, (PH < NPHASE - 1 ? PH : 0)>(r.v, r.jt, lds, L, r.l, a.tw);
       if (PH == NPHASE - 2) {  // natural-order spectrum of the packed line -> LDS
