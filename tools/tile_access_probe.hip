@@ -14,13 +14,13 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 // N rows, T = N / 8 threads per column, 8 columns per tile; MODE 0: tid = jt * 8 + t (rows x columns: coalesced segments),
 // MODE 1: tid = t * T + jt (a column's T threads are consecutive lanes)
-template <int N, int MODE>
-__global__ __launch_bounds__(N) void k_tile(const v2d* in, v2d* out, long ls, int tiles_per_outer, long os) {
+template <int N, int MODE, int C = 8>
+__global__ __launch_bounds__(N / 8 * C) void k_tile(const v2d* in, v2d* out, long ls, int tiles_per_outer, long os) {
   constexpr int T = N / 8;
   const int tid = threadIdx.x;
-  const int t = MODE == 0 ? tid % 8 : tid / T;
-  const int jt = MODE == 0 ? tid / 8 : tid % T;
-  const long base = (long)(blockIdx.x / tiles_per_outer) * os + (long)(blockIdx.x % tiles_per_outer) * 8 + t;
+  const int t = MODE == 0 ? tid % C : tid / T;
+  const int jt = MODE == 0 ? tid / C : tid % T;
+  const long base = (long)(blockIdx.x / tiles_per_outer) * os + (long)(blockIdx.x % tiles_per_outer) * C + t;
   v2d v[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load(&in[base + (long)(jt + q * T) * ls]);
@@ -64,6 +64,19 @@ void run(int n) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("n %d x-pass tiles, %s: %.3f ms, %.0f GB/s\n", n, mode == 0 ? "lanes = columns (128-byte segments)" : "a wave owns lines                   ",
            ms / 10, 2.0 * total * 16 / (ms / 10) / 1e6);
+  }
+  // the x pass with 16-column (256-byte) and 4-column (64-byte) segments
+  for (int c = 0; c < 2; ++c) {
+    const int C = c == 0 ? 16 : 4;
+    const int tp = (int)(ls / C);
+    CK(hipEventRecord(e0));
+    for (int it = 0; it < 10; ++it) {
+      if (c == 0) hipLaunchKernelGGL((k_tile<N, 0, 16>), dim3(tp), dim3(N / 8 * 16), 0, 0, a, b, ls, tp, 0L);
+      else hipLaunchKernelGGL((k_tile<N, 0, 4>), dim3(tp), dim3(N / 8 * 4), 0, 0, a, b, ls, tp, 0L);
+    }
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("n %d x-pass tiles of %d columns (%d-byte segments): %.3f ms, %.0f GB/s\n", n, C, C * 16, ms / 10, 2.0 * total * 16 / (ms / 10) / 1e6);
   }
   CK(hipFree(a)); CK(hipFree(b));
 }
