@@ -91,7 +91,12 @@ def test_div_and_eps_stages(grid, dims):
     assert rel_err(s.get_field("sumsq"), (ref.reshape(6, -1) ** 2).sum(axis=1)) < 1e-12
 
 
-@pytest.mark.parametrize("grid,dims", GRIDS + [((64, 64, 64), (1.0, 1.0, 1.0)), ((128, 8, 256), (1.0, 1.0, 1.0))])
+@pytest.mark.parametrize("grid,dims", GRIDS + [((64, 64, 64), (1.0, 1.0, 1.0)), ((128, 8, 256), (1.0, 1.0, 1.0)),
+                                       # every line length of the z passes with the wave-shuffle mirror: nz/2 = 64 ... 512
+                                       # (T = 8, 16, 32, 64 lanes per line), and nz/2 = 1024 (two loads / LDS split)
+                                       ((8, 8, 128), (1.0, 1.0, 1.0)), ((8, 16, 512), (1.0, 1.0, 1.0)),
+                                       ((8, 8, 1024), (1.0, 1.0, 1.0)), ((4, 8, 2048), (1.0, 1.0, 1.0)),
+                                       ((512, 8, 16), (1.0, 1.0, 1.0)), ((8, 1024, 16), (1.0, 1.0, 1.0))])
 def test_fft_forward_inverse(grid, dims):
     rng = np.random.default_rng(12)
     o = make_oracle(grid, dims) if max(grid) <= 64 else None
