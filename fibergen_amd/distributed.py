@@ -126,7 +126,7 @@ class DistributedLSSolver(SlabMember):
     backend gloo  -> callback transport: exchanged bytes are staged through the host (ranks may share a GPU).
     Without an initialised process group this is a lone slab (P = 1)."""
 
-    def __init__(self, nx, ny, nz, dx=1.0, dy=1.0, dz=1.0, group=None, device=None):
+    def __init__(self, nx, ny, nz, dx=1.0, dy=1.0, dz=1.0, group=None, device=None, transport=None):
         import os
         dist = None
         try:
@@ -144,9 +144,13 @@ class DistributedLSSolver(SlabMember):
         self._dist, self.group = dist, group
         if nranks == 1:
             return
-        if backend == "nccl":
+        # transport = "rccl" (or FG_SLAB_TRANSPORT=rccl) uses the library's RCCL transport whatever torch's backend is: the
+        # unique id then travels over gloo (tests: several RCCL ranks on ONE GPU, see tests/test_gpu_distributed.py)
+        transport = transport or os.environ.get("FG_SLAB_TRANSPORT")
+        if backend == "nccl" or transport == "rccl":
             import torch
-            torch.cuda.set_device(self.device)   # torch-side collectives of this process use the same GPU
+            if backend == "nccl":
+                torch.cuda.set_device(self.device)   # torch-side collectives of this process use the same GPU
             box = [rccl_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             self.connect_rccl(box[0])

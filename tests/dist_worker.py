@@ -106,7 +106,17 @@ def main():
     ap.add_argument("--mixed-bc", type=int, default=0)
     ap.add_argument("--split", type=int, default=-1)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--transport", default="",
+                    help="rccl: the library's RCCL transport between the ranks although they share ONE GPU -- every rank poses "
+                         "as a host of its own (NCCL_HOSTID), so that RCCL connects them through its socket transport on the "
+                         "loop-back interface instead of refusing the duplicate device")
     a = ap.parse_args()
+    if a.transport == "rccl":
+        import os
+        os.environ["NCCL_HOSTID"] = "fibergen-test-rank-%s" % os.environ.get("RANK", "0")
+        os.environ["NCCL_SOCKET_IFNAME"] = "lo"
+        os.environ["NCCL_IB_DISABLE"] = "1"
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
     import torch  # noqa: F401  before the HIP library: one shared runtime
     import torch.distributed as dist
     dist.init_process_group("gloo")
@@ -135,7 +145,7 @@ def main():
     from helpers import two_phase_setup
     from fibergen_amd.distributed import DistributedLSSolver
     mats, phis, normals = two_phase_setup(grid, a.mixing)
-    s = DistributedLSSolver(*grid, *dims, device=0)
+    s = DistributedLSSolver(*grid, *dims, device=0, transport=a.transport or None)
     s.set_num_phases(2)
     for p in range(2):
         s.set_phase(p, mats[p][0], mats[p][1], s.slab(phis[p]))

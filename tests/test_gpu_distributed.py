@@ -69,3 +69,43 @@ def test_fg_load_cases_sharded_over_ranks(tmp_path, nproc):
         assert int(r["rc"]) == 0
         assert np.array_equal(r["C"], res[0]["C"])
         assert rel_err(r["C"], C) < 1e-12
+
+
+@pytest.mark.parametrize("nproc,grid,mixing,split", [
+    (2, "8,16,128", "voigt", 1),      # displacement loop, one all-to-all per component on the second stream
+    (2, "8,16,128", "laminate", 0),   # + the interface correction's dense planes, three components in one exchange
+    (4, "16,16,128", "voigt", 1),     # four ranks: every rank sends to three peers per all-to-all
+    (4, "16,16,128", "laminate", 1),
+    (2, "12,10,6", "laminate", 1),    # strain-state pipeline, remapped all-to-all layout
+])
+def test_rccl_transport_between_ranks_on_one_gpu(tmp_path, nproc, grid, mixing, split):
+    """The RCCL transport with MORE THAN ONE RANK on the one GPU of the test box: every process poses as a host of its own
+    (NCCL_HOSTID), so RCCL connects the ranks through its socket transport on the loop-back interface instead of refusing the
+    duplicate device.  ncclCommInitRank over 2 / 4 ranks, grouped ncclSend / ncclRecv between DIFFERENT ranks (all-to-all
+    blocks, halo planes to the left and right neighbour), ncclAllReduce of the norms -- the calls, counts, peers, ordering
+    and stream choreography of the multi-GPU run; only the wire differs (sockets instead of xGMI)."""
+    g = tuple(int(v) for v in grid.split(","))
+    res = launch(nproc, str(tmp_path / "q"), "--backend", "hip", "--grid", grid, "--mixing", mixing, "--dims", "1,2,1.5",
+                 "--split", str(split), "--transport", "rccl")
+    o = make_oracle(g, (1.0, 2.0, 1.5), mixing, tol=1e-8)
+    assert o.run([1.0, 0, 0, 0, 0, 0.5]) is False
+    eps = np.concatenate([r["eps"] for r in res], axis=1)
+    assert all(str(r["transport"]) == "rccl" for r in res)
+    assert all(int(r["iterations"]) == o.iterations for r in res)
+    assert rel_err(eps, o.eps) < 1e-9
+    for r in res:
+        assert np.array_equal(r["residuals"], res[0]["residuals"])      # all-reduced norms: identical on every rank
+        assert np.abs(r["residuals"] - np.array(o.residuals)).max() < 1e-11
+        assert rel_err(r["mean_stress"], o.mean_stress()) < 1e-10
+
+
+def test_rccl_ranks_mixed_bc(tmp_path):
+    res = launch(2, str(tmp_path / "qm"), "--backend", "hip", "--grid", "8,16,128", "--mixed-bc", "1", "--tol", "1e-9",
+                 "--transport", "rccl")
+    o = make_oracle((8, 16, 128), tol=1e-9, bc_tol=1e-8, maxiter=400)
+    P = np.zeros((6, 6))
+    P[0, 0] = 1
+    assert o.run([0.01, 0, 0, 0, 0, 0], S0=np.zeros(6), P=P) is False
+    eps = np.concatenate([r["eps"] for r in res], axis=1)
+    assert str(res[0]["transport"]) == "rccl" and int(res[0]["iterations"]) == o.iterations
+    assert rel_err(eps, o.eps) < 1e-8
