@@ -268,9 +268,11 @@ def main():
                     help="N > 1: one more slab-decomposed workload n:mixing after the headline one, reported under `also_slab` "
                          "(default: BASELINE's north-star target configuration; '' = none).  Its failure or timeout leaves "
                          "the headline line untouched")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo", "nccl-one-gpu"],
                     help="N > 1: torch.distributed backend.  gloo is the dry run of this script's multi-rank path on a box with "
-                         "ONE GPU: all ranks share device 0 and the slab exchanges are staged through the host")
+                         "ONE GPU: all ranks share device 0 and the slab exchanges are staged through the host.  nccl-one-gpu: "
+                         "the real RCCL path (torch's process group AND the library's transport) with all ranks on device 0 -- "
+                         "every rank poses as a host of its own (NCCL_HOSTID), RCCL connects them over loop-back sockets")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -377,10 +379,17 @@ def main():
     # is loaded so that both share one HIP runtime (same soname).
     import torch
     import torch.distributed as dist
-    dry = args.dist_backend == "gloo"
-    if dry:
+    dry = args.dist_backend != "nccl"
+    if args.dist_backend == "gloo":
         local_rank = 0
         dist.init_process_group("gloo")
+    elif args.dist_backend == "nccl-one-gpu":
+        local_rank = 0
+        os.environ["NCCL_HOSTID"] = "fibergen-bench-rank-%d" % rank
+        os.environ["NCCL_SOCKET_IFNAME"] = "lo"
+        os.environ["NCCL_IB_DISABLE"] = "1"
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     else:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -397,7 +406,7 @@ def main():
         dist.barrier()
 
     def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dry else "cuda:%d" % local_rank)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.dist_backend == "gloo" else "cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -466,7 +475,9 @@ def main():
         line["config"]["parallelism"] = ("x-slabs x%d: ONE problem, displacement loop per slab, per component one RCCL all-to-all "
                                          "each way between the FFT axes, +-1 halo planes of u, norms all-reduced" % world)
         if dry:
-            line["config"]["parallelism"] += " -- DRY RUN: all ranks on one GPU, exchanges staged through the host (gloo)"
+            line["config"]["parallelism"] += (" -- DRY RUN: all ranks on one GPU, " +
+                                              ("exchanges staged through the host (gloo)" if args.dist_backend == "gloo"
+                                               else "RCCL between them over loop-back sockets"))
         d.close()
         timer.cancel()
         if args.also_slab:
