@@ -89,6 +89,7 @@ def launch_rccl(nproc, out, *args):
     (2, "8,16,128", "laminate", 0),   # + the interface correction's dense planes, three components in one exchange
     (4, "16,16,128", "voigt", 1),     # four ranks: every rank sends to three peers per all-to-all
     (4, "16,16,128", "laminate", 1),
+    (8, "32,16,128", "laminate", 0),  # eight ranks as on a full node: 7 peers per all-to-all, slabs of 4 planes
     (2, "12,10,6", "laminate", 1),    # strain-state pipeline, remapped all-to-all layout
 ])
 def test_rccl_transport_between_ranks_on_one_gpu(tmp_path, nproc, grid, mixing, split):
