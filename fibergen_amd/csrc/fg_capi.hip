@@ -163,7 +163,7 @@ int fg_slab_group_create(int nx, int ny, int nz, double dx, double dy, double dz
 int fg_slab_plan(int nx, int ny, int nz, int nranks, int rank, int what, int comp, fg_plan_op* ops, int capacity,
                  fg_plan_op* self_copy) {
   if (nx < 1 || ny < 1 || nz < 1 || nranks < 1 || rank < 0 || rank >= nranks || nx % nranks || ny % nranks) return -1;
-  if (what < FG_PLAN_A2A_FORWARD || what > FG_PLAN_HALO_TAU || comp < 0 || comp > 2) return -1;
+  if (what < FG_PLAN_A2A_FORWARD || what > FG_PLAN_HALO_TAU || comp < -1 || comp > 2) return -1;
   const fg::SlabPlan p = fg::slab_plan(fg::slab_dims(nx, ny, nz, nranks, rank), what, comp);
   if ((int)p.ops.size() > capacity && ops) return -1;
   if (ops)
@@ -247,6 +247,7 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
     else if (k == "laminate_overlap") o.laminate_overlap = value != 0;
     else if (k == "slab_loopback") o.slab_loopback = value != 0;
     else if (k == "slab_split") o.slab_split = value < 0 ? -1 : (value != 0);
+    else if (k == "slab_interleave") o.slab_interleave = value < 0 ? -1 : (value != 0);
     else if (k == "fuse_z") o.fuse_z = value < 0 ? -1 : (value != 0);
     else if (k == "u_loop") o.u_loop = (int)value;
     else if (k == "method") {

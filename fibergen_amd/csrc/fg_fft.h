@@ -42,10 +42,13 @@ class Fft3 {
   // [nx][ny][nzc]; blocked layout [q][nx][ny/P][nzc] (block q = what peer q receives / sent), see StridedArgs.
   // dir = -1: in plain -> out blocked (forward); dir = +1: in blocked -> out plain (inverse).  Component strides in doubles.
   bool can_block_y(int nranks) const;
-  void c2c_y_blocked(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale, int nranks);
+  void c2c_y_blocked(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale, int nranks,
+                     int interleave = 1);
   bool can_fuse(int axis, int ncomp = 3) const;
   // ncomp = 3: elastic Green operator on three components; ncomp = 1: scalar (heat / porous) operator c10 / |k|^2
-  void fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp = 3);
+  // xjump != 0 (doubles): line point j of the x pass sits at j * ls + (j >> xsplit) * xjump (interleaved slab layout)
+  void fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp = 3, int xsplit = 31,
+                long xjump = 0);
 
   bool fast_x() const { return fast_[0]; }
   bool fast_y() const { return fast_[1]; }

@@ -832,7 +832,7 @@ void launch_z(const ZArgs& a, int ncomp, long comp_stride, int lines, hipStream_
   FG_HIP_CHECK(hipGetLastError());
 }
 
-template <int N, int C, int NC>
+template <int N, int C, int NC, bool XSPLIT = false>
 void xfused_nc(XFusedArgs a, int nouter, hipStream_t s);
 
 template <int N>
@@ -841,12 +841,13 @@ void xfused_n(XFusedArgs a, int nouter, int ncomp, hipStream_t s) {
   // three components: 8-column (128-byte) tiles whatever the length -- more, smaller workgroups balance better over the
   // 256 CUs than 256-thread tiles of short lines (128^3: 0.037 -> 0.035 ms, 6 220 -> 6 315 it/s; 64^3: +1 %)
   if (ncomp == 1) xfused_nc<N, XTileCols<N>::value, 1>(a, nouter, s);
+  else if (a.xjump != 0) xfused_nc<N, 8, 3, true>(a, nouter, s);   // slab decomposition, components interleaved per peer
   else xfused_nc<N, 8, 3>(a, nouter, s);
 }
 
-template <int N, int C, int NC>
+template <int N, int C, int NC, bool XSPLIT>
 void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
-  using K = XFusedKernel<N, C, NC>;
+  using K = XFusedKernel<N, C, NC, XSPLIT>;
   static PerDeviceOnce configured;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
   if (configured.first_use()) {
@@ -1122,7 +1123,8 @@ bool Fft3::can_fuse(int axis, int ncomp) const {
   return odd_[axis] == 3 ? xfused_mixed_p<3>(n / 3, a, 0, nullptr, stream_, true) : xfused_mixed_p<5>(n / 5, a, 0, nullptr, stream_, true);
 }
 
-void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp) {
+void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp, int xsplit,
+                    long xjump) {
   if (ncomp != 1 && ncomp != 3) throw std::runtime_error("fft: fused Green-operator pass takes 1 or 3 components");
   if (!can_fuse(axis, ncomp)) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
   const int n = axis == 0 ? g_.nx : g_.ny;
@@ -1147,6 +1149,11 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
   for (int k = 0; k < 3; ++k) {
     a.kpm[k] = gp.kpm[k];
     a.kp[k] = gp.kp[k];
+  }
+  if (xjump != 0) {
+    if (!fast_[axis] || axis != 0 || ncomp != 3) throw std::runtime_error("fft: interleaved layout needs the radix x pass");
+    a.xsplit = xsplit;
+    a.xjump = xjump / 2;
   }
   const int nouter = axis == 0 ? 1 : g_.nx;
   if (!fast_[axis]) {
@@ -1174,13 +1181,16 @@ bool Fft3::can_block_y(int nranks) const {
   return fast_[1] && is_pow2(nyl);
 }
 
-void Fft3::c2c_y_blocked(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale, int nranks) {
+void Fft3::c2c_y_blocked(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale, int nranks,
+                         int interleave) {
   if (!can_block_y(nranks)) throw std::runtime_error("fft: blocked y pass not available for this length");
   const int nyl = g_.ny / nranks;
   int sh = 0;
   while ((1 << sh) < nyl) ++sh;
   const long plain_os = (long)g_.ny * g_.nzc, blocked_os = (long)nyl * g_.nzc;
-  const long jump = (long)g_.nx * nyl * g_.nzc - (long)nyl * g_.nzc;
+  // interleave = 3: a peer's block holds its three components one after the other ([q][c][nx][ny/P][nzc]; the component
+  // stride of the blocked side is then ONE block) -- one message per peer
+  const long jump = (long)interleave * g_.nx * nyl * g_.nzc - (long)nyl * g_.nzc;
   StridedArgs a;
   a.data = reinterpret_cast<cplx*>(in);
   a.out = reinterpret_cast<cplx*>(out);

@@ -338,11 +338,15 @@ struct XFusedArgs {
   cplx xq[8];              // e^{+i pi off(q) / N}, off(q) = last_index(0, q)
   double inv_h;            // 1/h = 2 N / d of the transformed axis
   int xcd_order;           // 1: blockIdx is remapped so that each XCD works on a contiguous run of tiles
+  // Slab decomposition with the three components of a peer's block interleaved (y-slab [p][c][nx/P][ny/P][nzc], what one
+  // message per peer delivers): line point j sits at  j*ls + (j >> xsplit) * xjump  (XFusedKernel<.., XSPLIT = true> only)
+  int xsplit = 31;
+  long xjump = 0;
 };
 
 // NC = 3: the three components of the elastic problem and G0OperatorFourierStaggeredGeneral; NC = 1: the scalar modes
 // (one potential, G0OperatorFourierStaggeredGeneralHeat  F:19779-19823: c1 = c10 / |k|^2).
-template <int N, int C, int NC = 3>
+template <int N, int C, int NC = 3, bool XSPLIT = false>
 struct XFusedKernel {
   static constexpr int T = N / 8;
   static constexpr int THREADS = T * C;
@@ -406,8 +410,11 @@ struct XFusedKernel {
       for (int c = 0; c < NC; ++c) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          r.v[c][q] = r.valid ? cload_stream(&a.data[c * a.comp_stride + r.base + (long)Line<N>::first_index(r.jt, q) * a.ls], a.nt)
-                              : cmake(0.0, 0.0);
+        {
+          const int j = Line<N>::first_index(r.jt, q);
+          const long off = (long)j * a.ls + (XSPLIT ? (long)(j >> a.xsplit) * a.xjump : 0L);
+          r.v[c][q] = r.valid ? cload_stream(&a.data[c * a.comp_stride + r.base + off], a.nt) : cmake(0.0, 0.0);
+        }
       }
     }
     if (TR < NC) {
@@ -473,8 +480,11 @@ struct XFusedKernel {
       Line<N>::template phase<+1, LP>(r.v[comp], r.jt, lds, L, r.t, tw);
       if (LP == NPL - 1 && r.valid) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-          cstore_stream(&a.data[comp * a.comp_stride + r.base + (long)Line<N>::last_index(r.jt, q) * a.ls], r.v[comp][q], a.nt);
+        for (int q = 0; q < 8; ++q) {
+          const int j = Line<N>::last_index(r.jt, q);
+          const long off = (long)j * a.ls + (XSPLIT ? (long)(j >> a.xsplit) * a.xjump : 0L);
+          cstore_stream(&a.data[comp * a.comp_stride + r.base + off], r.v[comp][q], a.nt);
+        }
       }
     }
   }

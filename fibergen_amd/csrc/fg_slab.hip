@@ -128,6 +128,18 @@ bool Solver::slab_split() const {
   return (nranks_ > 1 || slab_loopback()) && (double)g_.n * sizeof(double) >= 32.0 * 1024 * 1024;
 }
 
+// Batched exchanges (no split) with the three components of a peer in one message: needs the y pass that writes / reads the
+// blocked layout and the radix fused x pass (powers of two all round).  Option slab_interleave / FG_SLAB_INTERLEAVE = 0 keeps
+// one message per peer and component.
+bool Solver::slab_interleave() const {
+  static const int env = getenv("FG_SLAB_INTERLEAVE") ? atoi(getenv("FG_SLAB_INTERLEAVE")) : -1;
+  if (env == 0 || opt_.slab_interleave == 0) return false;
+  if (slab_split() || !(nranks_ > 1 || slab_loopback())) return false;
+  const int nxl = g_.nx;
+  return fft_ && fft_ys_ && fft_->can_block_y(nranks_) && opt_.fuse_x && nxg_ > 1 && fft_ys_->fast_x() && fft_ys_->can_fuse(0) &&
+         nxl > 0 && (nxl & (nxl - 1)) == 0;
+}
+
 // Test mode for boxes with ONE GPU: a lone slab connected to a transport sends its all-to-all blocks and halo planes to
 // itself THROUGH the transport (RCCL: ncclSend / ncclRecv to the own rank inside a group, ncclAllReduce over one rank), on
 // the second stream with the event choreography of the multi-GPU run.
@@ -169,10 +181,12 @@ void Solver::slab_exchange(int what, int comp, int done_slot) {
     return;
   }
   if (!comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
-  // comp < 0: the three components of an all-to-all in ONE exchange (small slabs: fewer, larger messages)
+  // comp < 0: the three components of an all-to-all in ONE exchange (small slabs: fewer, larger messages) -- one message
+  // per peer where the interleaved layout is available, else one per peer and component
   std::vector<XOp> ops;
   comm_begin();
-  for (int c = comp < 0 ? 0 : comp; c <= (comp < 0 ? 2 : comp); ++c) {
+  const bool one_msg = comp < 0 && slab_interleave() && (what == FG_PLAN_A2A_FORWARD || what == FG_PLAN_A2A_BACKWARD);
+  for (int c = comp < 0 ? (one_msg ? -1 : 0) : comp; c <= (comp < 0 ? (one_msg ? -1 : 2) : comp); ++c) {
     const SlabPlan p = slab_plan(d, what, c);
     for (const fg_plan_op& o : p.ops)
       ops.push_back(XOp{o.send, o.peer, slab_buffer(o.buffer) + o.offset, (size_t)o.count * sizeof(double)});
@@ -279,13 +293,17 @@ void Solver::slab_chain_step(int k) {
   // Large slabs are bandwidth bound on the links: component c's all-to-all overlaps the transforms of c + 1.  Small
   // slabs are latency bound (launches, RCCL start-up): the three components go through every stage together.
   const bool split = slab_split();
+  const bool inter = slab_interleave();   // batched mode, one message per peer: blocks of three components
+  const SlabDims sd = slab_dims(nxg_, g_.ny, g_.nz, nranks_, rank_);
   auto forward = [&](int c0, int nc) {   // z r2c and y c2c (into the all-to-all layout) of components c0 .. c0 + nc - 1
     double* f = fu_ + c0 * n;
     time_begin(2);
     fft_->r2c_z(f, nc, n);
     time_end(2);
     time_begin(3);
-    if (blocked) {
+    if (inter) {
+      fft_->c2c_y_blocked(f, n, S, sd.block, nc, -1, 1.0, nranks_, 3);
+    } else if (blocked) {
       fft_->c2c_y_blocked(f, n, S + c0 * n, n, nc, -1, 1.0, nranks_);
     } else {
       fft_->c2c_y(f, nc, n, -1, 1.0);
@@ -296,7 +314,9 @@ void Solver::slab_chain_step(int k) {
   auto backward = [&](int c0, int nc) {  // y c2c^-1 (out of the all-to-all layout) and z c2r
     double* u = un + c0 * ucs_;
     time_begin(7);
-    if (blocked) {
+    if (inter) {
+      fft_->c2c_y_blocked(S, sd.block, u, ucs_, nc, +1, 1.0, nranks_, 3);
+    } else if (blocked) {
       fft_->c2c_y_blocked(S + c0 * n, n, u, ucs_, nc, +1, 1.0, nranks_);
     } else {
       for (int c = c0; c < c0 + nc; ++c) launch_block_remap(S + c * n, un + c * ucs_, g_, nyl_, false, stream_);
@@ -334,7 +354,12 @@ void Solver::slab_chain_step(int k) {
     }
     const int jj0 = rank_ * nyl_;   // this rank's ky rows
     time_begin(5);
-    if (opt_.fuse_x && nxg_ > 1 && fft_ys_->can_fuse(0)) {
+    if (inter) {
+      // y-slab [p][c][nxl][nyl][nzc]: component stride one block, x plane j at j * ls + (j / nxl) * 2 blocks
+      int sh = 0;
+      while ((1 << sh) < g_.nx) ++sh;
+      fft_ys_->fused_g0(R, sd.block, 0, scale, gp, jj0, 3, sh, 2 * sd.block);
+    } else if (opt_.fuse_x && nxg_ > 1 && fft_ys_->can_fuse(0)) {
       fft_ys_->fused_g0(R, n, 0, scale, gp, jj0);
     } else {
       if (nxg_ > 1) fft_ys_->c2c_x(R, 3, n, -1, scale);
@@ -441,7 +466,7 @@ void SlabGroup::check_members() const {
   for (Solver* s : m_) {
     if (s->nranks_ > 1 && !s->comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
     if (s->opt_.mixing != a.opt_.mixing || s->pt_.n != a.pt_.n || s->opt_.u_loop != a.opt_.u_loop || s->opt_.u_tile != a.opt_.u_tile ||
-        s->opt_.slab_split != a.opt_.slab_split)
+        s->opt_.slab_split != a.opt_.slab_split || s->opt_.slab_interleave != a.opt_.slab_interleave)
       throw std::runtime_error("the members of a slab group must carry the same options and materials");
   }
 }

@@ -29,6 +29,11 @@ struct SlabDims {
   bool loopback;     // test mode: a rank's own blocks / planes travel through the transport too (send / receive to itself)
 };
 
+// All-to-all of the three components in ONE message per peer (comp = -1): a peer's block holds its three components one
+// after the other, x-slab side [q][c][nxl][nyl][nzc], y-slab side [p][c][nxl][nyl][nzc] (the y pass writes / reads that
+// layout, the fused x pass walks it with its (j >> split) * jump term).
+inline long slab_peer_block(const SlabDims& d) { return 3 * d.block; }
+
 inline SlabDims slab_dims(int nx, int ny, int nz, int nranks, int rank) {
   SlabDims d;
   d.nx = nx; d.ny = ny; d.nz = nz; d.nranks = nranks; d.rank = rank;
@@ -65,7 +70,8 @@ inline fg_plan_op plan_op(int send, int peer, int buffer, long offset, long coun
   return o;
 }
 
-// what: FG_PLAN_*; comp: component (all-to-all: 0..2; halos: ignored, all components of the exchange are listed)
+// what: FG_PLAN_*; comp: component (all-to-all: 0..2, or -1 = the three components interleaved per peer; halos: ignored,
+// all components of the exchange are listed)
 inline SlabPlan slab_plan(const SlabDims& d, int what, int comp) {
   SlabPlan p;
   p.self_src = p.self_dst = plan_op(0, d.rank, 0, 0, 0);
@@ -76,18 +82,21 @@ inline SlabPlan slab_plan(const SlabDims& d, int what, int comp) {
     case FG_PLAN_A2A_BACKWARD: { // y-slab (R) -> blocked x-slab (S)
       const int from = what == FG_PLAN_A2A_FORWARD ? FG_BUF_SPECTRUM_X : FG_BUF_SPECTRUM_Y;
       const int to = what == FG_PLAN_A2A_FORWARD ? FG_BUF_SPECTRUM_Y : FG_BUF_SPECTRUM_X;
-      const long base = (long)comp * d.n;
+      // comp >= 0: one component, blocks of d.block at comp * n + q * block; comp < 0: the three components of a peer in
+      // one block of 3 * d.block at q * 3 * block
+      const long base = comp < 0 ? 0 : (long)comp * d.n;
+      const long blk = comp < 0 ? slab_peer_block(d) : d.block;
       for (int q = 0; q < P; ++q) {
         if (q == me && !d.loopback) continue;
-        p.ops.push_back(plan_op(0, q, to, base + q * d.block, d.block));
+        p.ops.push_back(plan_op(0, q, to, base + q * blk, blk));
       }
       for (int q = 0; q < P; ++q) {
         if (q == me && !d.loopback) continue;
-        p.ops.push_back(plan_op(1, q, from, base + q * d.block, d.block));
+        p.ops.push_back(plan_op(1, q, from, base + q * blk, blk));
       }
       if (!d.loopback) {
-        p.self_src = plan_op(1, me, from, base + me * d.block, d.block);
-        p.self_dst = plan_op(0, me, to, base + me * d.block, d.block);
+        p.self_src = plan_op(1, me, from, base + me * blk, blk);
+        p.self_dst = plan_op(0, me, to, base + me * blk, blk);
       }
       break;
     }

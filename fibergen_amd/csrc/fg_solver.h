@@ -54,6 +54,7 @@ struct SolverOptions {
                                 // 2 = viscosity (dual Stokes scheme: DeltaOperatorStaggered F:20422-20460, 6 components)
   int gamma_scheme = 0;         // 0 = staggered (GammaOperatorStaggered F:20288), 1 = collocated (GammaOperatorCollocated F:20302)
   int loadstep_extrapolation_order = 0;   // 0 = none, 1 = linear, ... (F:14696; method "polynomial" F:21468-21514)
+  int slab_interleave = -1;     // -1: where available; 0: one message per peer and component
   int error_estimator = 0;      // 0 = epsilon (EpsilonErrorEstimator F:14591-14637), 1 = residual (ResidualErrorEstimator
                                 // F:14382-14405: abs = sqrt(gamma), rel = sqrt(gamma / gamma_0); method cg only)
   int method = 0;               // 0 = basic scheme (runBasic F:21716), 1 = conjugate gradients (runCGElasticity F:23153)
@@ -219,6 +220,7 @@ class Solver {
   void slab_exchange(int what, int comp, int done_slot);
   double* slab_buffer(int id);
   bool slab_loopback() const;
+  bool slab_interleave() const;                          // batched exchanges: one message per peer (three components per block)
   bool slab_split() const;                               // all-to-all per component (overlap) or once for all three
   void comm_begin();
   void comm_end(int slot);

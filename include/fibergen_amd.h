@@ -209,7 +209,8 @@ const char* fg_slab_transport(const fg_solver* s);
 /* The exchange plan (pure index arithmetic, no GPU): ops of exchange `what` for `rank`, offsets / counts in doubles
  * relative to the named buffer.  Returns the number of ops (<= capacity) or -1.  self_copy[2] (may be NULL) receives
  * the rank's own all-to-all block as {source, destination}. */
-#define FG_PLAN_A2A_FORWARD 0   /* x-slabs -> y-slabs, component `comp` */
+#define FG_PLAN_A2A_FORWARD 0   /* x-slabs -> y-slabs: component `comp` = 0..2 (blocks of one component), or comp = -1: ONE
+                                 * message per peer holding its three components ([P][3][nx/P][ny/P][nzp] on both sides) */
 #define FG_PLAN_A2A_BACKWARD 1
 #define FG_PLAN_HALO_U 2        /* +-1 planes of the three displacement components */
 #define FG_PLAN_HALO_MODULI 3   /* the same for the two effective-moduli arrays (once per geometry) */

@@ -68,6 +68,23 @@ def run_plan(a, dist, rank, P, grid):
         execute(ops, selfc, bufs)
     if not np.array_equal(bufs[0], S.reshape(-1)):
         errors.append("backward all-to-all")
+    # ---- the same with the three components of a peer in ONE message (comp = -1): x-slab side [q][c][nxl][nyl][nzp],
+    #      y-slab side [p][c][nxl][nyl][nzp]
+    Si = Gs.reshape(3, nxl, P, nyl, nzp).transpose(2, 0, 1, 3, 4).copy()   # [q][c][nxl][nyl][nzp]
+    bufs = {0: Si.reshape(-1).copy(), 1: np.full(3 * n, -1.0)}
+    ops, selfc = slab_plan(nx, ny, nz, P, rank, PLAN_A2A_FORWARD, -1)
+    if len(ops) != 2 * (P - 1):
+        errors.append("one message per peer")
+    execute(ops, selfc, bufs)
+    Ri = bufs[1].reshape(P, 3, nxl, nyl, nzp)                               # block p = planes [p nxl, (p+1) nxl) of my ky rows
+    want = G[:, :, rank * nyl:(rank + 1) * nyl].reshape(3, P, nxl, nyl, nzp).transpose(1, 0, 2, 3, 4)
+    if not np.array_equal(Ri, want):
+        errors.append("forward all-to-all, interleaved")
+    bufs[0][:] = -1.0
+    ops, selfc = slab_plan(nx, ny, nz, P, rank, PLAN_A2A_BACKWARD, -1)
+    execute(ops, selfc, bufs)
+    if not np.array_equal(bufs[0], Si.reshape(-1)):
+        errors.append("backward all-to-all, interleaved")
     # ---- halo planes of u (3 components) and of the moduli (2)
     for what, nc, buf_id in ((PLAN_HALO_U, 3, 2), (PLAN_HALO_MODULI, 2, 3)):
         U = np.full((nc, nxl + 4, ny, nzp), -1.0)
