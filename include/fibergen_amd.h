@@ -86,7 +86,9 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * phi_sweep (1 = default: with two phases whose fractions are complementary bit for bit the tiled sweep reads phi_1 and
  * forms the effective moduli itself; 0 = always the two precomputed moduli arrays), laminate_overlap (1 = default: the interface kernels of the laminate correction run on a second stream beside the
  * displacement sweep; 0 = one stream), slab_split (slab driver: 1 = one all-to-all per component, overlapping the transforms of the next component; 0 = one
- * exchange for the three components; -1 = by slab size, default), slab_loopback (test mode on one GPU: a lone slab that is
+ * exchange for the three components; -1 = by slab size, default), slab_interleave (-1 = default: in the one-exchange mode a
+ * peer's three components travel as ONE message where the sizes allow; 0 = one message per peer and component),
+ * slab_loopback (test mode on one GPU: a lone slab that is
  * connected to a transport sends its all-to-all blocks and halo planes to itself through that transport). */
 int fg_set_option_d(fg_solver* s, const char* key, double value);
 int fg_set_option_i(fg_solver* s, const char* key, long value);
