@@ -11,16 +11,21 @@ A "step" is one LS iteration (one basicScheme pass, F:20558-20578) on a syntheti
           `also` carries the other BASELINE sizes (128^3 Voigt, 512^3 laminate = the north-star target config);
           `slab_forced` the same problem through the slab driver as ONE slab; `cpu_baseline` the reference's loop in
           C/OpenMP on the host cores (thread sweep + the reference's default of one thread).
-  N > 1   (torchrun, one rank per GPU) ONE problem, x-slab decomposed over the ranks, RCCL all-to-all between the FFT
-          axes: `value` is its it/s ("scaling": "strong"); `replicas` = every rank its own load case of the same RVE
-          (no collective, the six load cases of calc_effective_properties are independent).
+  N > 1   one rank per GPU: ONE problem, x-slab decomposed over the ranks, RCCL all-to-all between the FFT axes: `value`
+          is its it/s ("scaling": "strong"); `replicas` = every rank its own load case of the same RVE (no collective,
+          the six load cases of calc_effective_properties are independent).  Started under torchrun (WORLD_SIZE set) the
+          process is one rank; started plainly (`python bench.py --gpus 8`) it launches the N ranks itself -- before it
+          has touched the GPU -- relays rank 0's line and exits with the ranks' code.  The line names the ranks' devices
+          (PCI bus ids), the transport and the time the exchanges take (`alltoall_ms`).
 
 Rank 0 prints one JSON line (metric of BASELINE.json: LS iterations/s, plus the HBM roofline of the dominant kernel).
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import threading
 import time
@@ -32,8 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-A_MIN_BYTES_PER_VOXEL = 392   # maximum legal fusion
-A_STAGE_BYTES_PER_VOXEL = 632
+A_MIN_BYTES_PER_VOXEL = 392   # maximum legal fusion with the strain as the state (kept so that rounds compare)
 
 
 def algorithmic_bytes(n, nphases):
@@ -91,6 +95,8 @@ def kernel_table(s, E, n, steps, scalar):
     s.iterate(E, steps)
     times, cnt = s.stage_times()
     s.enable_stage_timing(False)
+    kernel_table.last_sum_ms = sum(times.values()) / max(cnt, 1)
+    kernel_table.last_bias_ms = s.stage_timing_bias()
     N = n[0] * n[1] * n[2]
     ab = algorithmic_bytes(n, 2)
     if scalar:   # one component through the FFT chain; the sweep reads T and phi and writes f
@@ -153,48 +159,87 @@ def committed_traffic(n, mixing, slot, default_options):
     return None, None
 
 
-def cpu_baseline(n, mixing, phi, normals, budget_s=25.0):
-    """The reference's loop restated in C/OpenMP (oracle/c: one in-place strain field, buffers allocated once, the
-    reference's release flags -O3 -march=native built on this host) + pocketfft (scipy.fft, workers = threads) in place
-    of threaded FFTW, on the host cores: a sweep over thread counts (best = `value`) and the reference's default of ONE
-    thread (F:25226), each on a bounded number of passes of the same RVE."""
+def physical_cores():
+    """(physical cores, sockets) of this host from /proc/cpuinfo; (None, None) when it cannot be read"""
+    try:
+        cores, phys = set(), set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    cores.add((pid, cid))
+                    phys.add(pid)
+                pid = cid = None
+        return (len(cores) or None), (len(phys) or None)
+    except OSError:
+        return None, None
+
+
+def cpu_passes(n, mixing, phi, normals, threads, max_passes, max_seconds):
+    """`threads` OpenMP threads on a FRESH set of buffers: the arrays are allocated here and first touched by the very
+    threads that are timed (a first pass, untimed), so their pages sit on the NUMA nodes of those threads -- the thread
+    sweep of round 2 first-touched with all hardware threads and then timed fewer, which put the pages on the wrong nodes.
+    -> (it/s, fft share of the time, passes timed)"""
     from oracle.c_oracle import CRefLoop
-    ncpu = os.cpu_count() or 1
     mats = materials("elasticity")
     E = np.array([1.0, 0, 0, 0, 0, 0])
     mu_0 = 0.5 * (mats[0][0] + mats[1][0])   # any positive reference medium: the cost is identical
-    counts = sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu} | {ncpu})
-    c = CRefLoop(n, (1.0, 1.0, 1.0), mats, [1 - phi, phi], normals, mixing, threads=counts[-1])
-    c.one_pass(E, mu_0, 0.0)   # first touch of the buffers by the OpenMP threads, pocketfft plans
-    sweep = {}
-    t_start = time.perf_counter()
-    share = None
-    for th in reversed(counts):
-        c.threads = th
-        c.one_pass(E, mu_0, 0.0)
-        c.fft_seconds = 0.0
-        t0 = time.perf_counter()
-        it = 0
-        while it < 20 and (it < 2 or time.perf_counter() - t0 < min(3.0, budget_s / (2 * len(counts)))):
-            c.one_pass(E, mu_0, 0.0)
-            it += 1
-        dt = time.perf_counter() - t0
-        sweep[th] = it / dt
-        if share is None or sweep[th] >= max(sweep.values()):
-            share = c.fft_seconds / dt
-    best = max(sweep, key=sweep.get)
-    # the reference's default: one thread (one pass; the buffers are warm)
-    c.threads = 1
+    c = CRefLoop(n, (1.0, 1.0, 1.0), mats, [1 - phi, phi], normals, mixing, threads=threads)
+    c.one_pass(E, mu_0, 0.0)   # first touch, pocketfft plans
+    c.fft_seconds = 0.0
     t0 = time.perf_counter()
-    c.one_pass(E, mu_0, 0.0)
-    one = 1.0 / (time.perf_counter() - t0)
+    it = 0
+    while it < max_passes and (it < 2 or time.perf_counter() - t0 < max_seconds):
+        c.one_pass(E, mu_0, 0.0)
+        it += 1
+    dt = time.perf_counter() - t0
+    return it / dt, c.fft_seconds / dt, it
+
+
+def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
+    """The reference's loop restated in C/OpenMP (oracle/c: one in-place strain field, buffers allocated once, the
+    reference's release flags -O3 -march=native built on this host) + pocketfft (scipy.fft, workers = threads) in place
+    of threaded FFTW, on the host cores, threads spread over the cores (OMP_PROC_BIND=spread, OMP_PLACES=cores): a sweep
+    over thread counts on the headline grid (best = `value`), the reference's default of ONE thread (F:25226), and the
+    other BASELINE grids `others` = [(n_edge, mixing, phi, normals)] at the best thread count (`per_grid`)."""
+    os.environ.setdefault("OMP_PROC_BIND", "spread")   # read by libgomp when the oracle library is loaded (below)
+    os.environ.setdefault("OMP_PLACES", "cores")
+    ncpu = os.cpu_count() or 1
+    cores, sockets = physical_cores()
+    counts = sorted({t for t in (16, 32, 64, cores or ncpu) if t <= ncpu})
+    t_start = time.perf_counter()
+    sweep, shares = {}, {}
+    for th in counts:
+        sweep[th], shares[th], _ = cpu_passes(n, mixing, phi, normals, th, 20, min(3.0, budget_s / (2 * len(counts))))
+    best = max(sweep, key=sweep.get)
+    one, _, _ = cpu_passes(n, mixing, phi, normals, 1, 1, 0.0) if n[0] <= 256 else (None, None, None)
+    per_grid = {"%d^3 %s" % (n[0], mixing): {"it_s": sweep[best], "threads": int(best), "fft_share": shares[best]}}
+    for ne, mix, ph, nr in others:
+        key = "%d^3 %s" % (ne, mix)
+        try:
+            need = 30 * ne ** 3 * 8 * 1.1   # strain 6 + work 3 + spectrum 3 + inverse 3 + phases 2 + normals 3 + slack, float64
+            avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+            if need > 0.8 * avail:
+                per_grid[key] = {"skipped": "needs %.0f GB of host memory, %.0f GB available" % (need / 1e9, avail / 1e9)}
+                continue
+            v, sh, it = cpu_passes((ne,) * 3, mix, ph, nr, best, 20 if ne < 256 else 2, 3.0)
+            per_grid[key] = {"it_s": v, "threads": int(best), "fft_share": sh, "passes": it}
+        except Exception as e:  # noqa: BLE001
+            per_grid[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     return {"value": sweep[best], "unit": "it/s", "cores": int(best), "kind": "port",
-            "one_thread_it_s": one, "host_cpus": ncpu, "fft_share": share,
-            "thread_sweep_it_s": {str(k): v for k, v in sorted(sweep.items())},
-            "sample": "passes of the same %dx%dx%d RVE for <= 3 s per thread count (%s threads; value = best) + one "
-                      "pass with 1 thread; oracle/c loop nests (-O3 -march=native, in-place strain field, preallocated) "
-                      "+ pocketfft rfftn/irfftn workers = threads standing in for threaded FFTW; %.0f s in total"
-                      % (*n, "/".join(str(k) for k in counts), time.perf_counter() - t_start)}
+            "one_thread_it_s": one, "host_cpus": ncpu, "physical_cores": cores, "sockets": sockets, "fft_share": shares[best],
+            "thread_sweep_it_s": {str(k): v for k, v in sorted(sweep.items())}, "per_grid": per_grid,
+            "sample": "passes of the same %dx%dx%d RVE for <= 3 s per thread count (%s threads; value = best; every count on "
+                      "freshly allocated buffers first touched by its own threads, OMP_PROC_BIND=%s OMP_PLACES=%s) + one pass "
+                      "with 1 thread; per_grid: the other BASELINE grids at the best count (512^3: 2 passes); oracle/c loop "
+                      "nests (-O3 -march=native, in-place strain field, preallocated) + pocketfft rfftn/irfftn workers = "
+                      "threads standing in for threaded FFTW; %.0f s in total"
+                      % (*n, "/".join(str(k) for k in counts), os.environ["OMP_PROC_BIND"], os.environ["OMP_PLACES"],
+                         time.perf_counter() - t_start)}
 
 
 def measure_single(args, n_edge, mixing, mode, device, E, detail):
@@ -221,6 +266,10 @@ def measure_single(args, n_edge, mixing, mode, device, E, detail):
     dom = max(kern, key=lambda k: kern[k]["avg_ms"])
     res["dominant_kernel"] = {"kernel": dom, **kern[dom], "frac_of_hbm_peak": kern[dom]["GBps"] / HBM_PEAK_GBS}
     res["kernels"] = kern
+    # the per-kernel HIP-event figures (an empty event pair's reading subtracted) against the step they make up
+    res["kernel_sum_ms"] = kernel_table.last_sum_ms
+    res["hip_event_bias_ms_subtracted"] = kernel_table.last_bias_ms
+    res["loop_alg_GBps"] = sum(v["alg_GB"] for v in kern.values()) / (res["ms_per_step"] / 1e3)
     if detail:
         # sustained clocks: >= sustain_s of back-to-back passes
         chunk = max(args.steps, int(0.25 / max(med / args.steps, 1e-6)))
@@ -250,12 +299,13 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=7, help="the K-step region is timed this many times; the median is reported")
-    ap.add_argument("--sustain-s", type=float, default=2.0)
+    ap.add_argument("--sustain-s", type=float, default=10.0)
     ap.add_argument("--n", "--size", dest="n", type=int, default=256, help="grid size per axis (128, 256, 512 are the BASELINE sizes; any size runs)")
     ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
     ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat", "viscosity"])
-    ap.add_argument("--also", default="128:voigt,512:laminate",
-                    help="N = 1: further single-GPU workloads n:mixing reported under `also` ('' = none)")
+    ap.add_argument("--also", default="128:voigt,512:laminate,256:voigt:porous,256:voigt:viscosity",
+                    help="N = 1: further single-GPU workloads n:mixing[:mode] reported under `also` ('' = none): the other "
+                         "BASELINE sizes and config 5 (porous / Stokes)")
     ap.add_argument("--u-tile", type=int, default=None, help="override the solver's u_tile option (0, 8, 12, 16)")
     ap.add_argument("--fuse-z", type=int, default=None, help="override the solver's fuse_z option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -275,9 +325,32 @@ def main():
                          "every rank poses as a host of its own (NCCL_HOSTID), RCCL connects them over loop-back sockets")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started plainly: launch the N ranks as fresh processes (torch.distributed.run, one rank per GPU) and relay
+        # rank 0's line.  Nothing in this process has touched the GPU (numpy only so far), and nothing is exec'ed.
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        for ln in proc.stdout.splitlines():
+            if not ln.startswith("{"):
+                print(ln, file=sys.stderr)
+        if lines:
+            print(lines[-1], flush=True)
+        elif proc.returncode == 0:
+            proc.returncode = 6
+        sys.exit(proc.returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE = %d: the launcher's rank count is used" % (args.gpus, world), file=sys.stderr)
     default_options = args.u_tile is None and args.fuse_z is None and args.mode == "elasticity"
     scalar = args.mode in ("porous", "heat")
     stokes = args.mode == "viscosity"
@@ -311,8 +384,11 @@ def main():
             "roofline": roof,
             "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"], "repeats": res["repeats"],
             "sustained_it_s": res.get("sustained_it_s"), "run_load_case_it_s": res.get("run_load_case_it_s"),
-            "loop_GBps_Amin": per_voxel * N * it_s / 1e9,
-            "loop_GBps_Astage": (per_voxel if scalar else A_STAGE_BYTES_PER_VOXEL) * N * it_s / 1e9,
+            # bytes the loop moves as it runs (sum of its kernels' algorithmic bytes) per second of step time -- a rate;
+            # loop_GBps_Amin prices the same steps at SURVEY 8d's A_min = 392 B/voxel (strain as the state) so that rounds
+            # compare -- an as-if figure, not a rate
+            "loop_alg_GBps": res["loop_alg_GBps"], "loop_GBps_Amin": per_voxel * N * it_s / 1e9,
+            "kernel_sum_ms": res["kernel_sum_ms"], "hip_event_bias_ms_subtracted": res["hip_event_bias_ms_subtracted"],
             "kernels": kern, "rve": res["rve"],
         }
         if not scalar and not stokes:
@@ -350,27 +426,49 @@ def main():
                 med = statistics.median(dts)
                 out["slab_forced"] = {"members": args.slab_members, "it_s": args.steps / med, "ms_per_step": 1e3 * med / args.steps,
                                       "ratio_to_single_gpu_loop": (args.steps / med) / it_s,
-                                      "transport": g.members[0].transport}
+                                      "transport": g.members[0].transport,
+                                      "note": "the N > 1 path of this script with one slab: what `--gpus N` runs per rank, "
+                                              "against the single-GPU loop that is `value`"}
                 g.close()
             except Exception as e:  # noqa: BLE001
                 out["slab_forced"] = {"error": "%s: %s" % (type(e).__name__, e)}
         also = {}
+        cpu_others = []
         for item in [a for a in args.also.split(",") if a]:
-            ne, mix = item.split(":")
-            if (int(ne), mix) == (args.n, args.mixing) or scalar or stokes:
+            parts = item.split(":")
+            ne, mix, mode2 = int(parts[0]), parts[1], (parts[2] if len(parts) > 2 else "elasticity")
+            if (ne, mix, mode2) == (args.n, args.mixing, args.mode) or scalar or stokes:
                 continue
+            key = "%d^3 %s" % (ne, mix) + ("" if mode2 == "elasticity" else " " + mode2)
             try:
-                s2, r2, _, _ = measure_single(args, int(ne), mix, "elasticity", local_rank, E, detail=False)
+                E2 = E
+                if mode2 in ("porous", "heat"):
+                    E2 = np.array([1.0, 0, 0])
+                elif mode2 == "viscosity":
+                    E2 = np.array([1.0, -1, 0, 0, 0, 0])
+                s2, r2, phi2, nrm2 = measure_single(args, ne, mix, mode2, local_rank, E2, detail=False)
                 s2.close()
                 r2["kernels"] = {k: {"avg_ms": v["avg_ms"], "GBps": v["GBps"]} for k, v in r2["kernels"].items()}
-                also["%s^3 %s" % (ne, mix)] = r2
+                also[key] = r2
+                if mode2 == "elasticity":
+                    cpu_others.append((ne, mix, phi2, nrm2))
             except Exception as e:  # noqa: BLE001
-                also["%s^3 %s" % (ne, mix)] = {"error": "%s: %s" % (type(e).__name__, e)}
+                also[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         if also:
             out["also"] = also
         if not args.no_cpu_baseline and not scalar and not stokes:
-            out["cpu_baseline"] = cpu_baseline(n, args.mixing, phi, normals, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(n, args.mixing, phi, normals, args.cpu_budget, cpu_others)
             out["gpu_over_cpu"] = it_s / out["cpu_baseline"]["value"]
+            # north_star's table: it/s per grid on the GPU beside the CPU path timed in this same run
+            tab = {"%d^3 %s" % (args.n, args.mixing): {"gpu_it_s": it_s}}
+            for k, v in also.items():
+                if "it_s" in v:
+                    tab[k] = {"gpu_it_s": v["it_s"]}
+            for k, v in out["cpu_baseline"]["per_grid"].items():
+                if k in tab and "it_s" in v:
+                    tab[k].update({"cpu_it_s": v["it_s"], "cpu_threads": v["threads"], "cpu_fft_share": v["fft_share"],
+                                   "gpu_over_cpu": tab[k]["gpu_it_s"] / v["it_s"]})
+            out["per_grid"] = tab
         print(json.dumps(out), flush=True)
         return
 
@@ -391,6 +489,12 @@ def main():
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     else:
+        if torch.cuda.device_count() < world:   # (counting devices does not initialise the GPU)
+            if rank == 0:
+                print(json.dumps({"metric": metric, "value": None, "unit": "it/s", "n_gpus": world,
+                                  "error": "%d ranks but %d GPUs visible; --dist-backend nccl-one-gpu runs the RCCL path with all "
+                                           "ranks on one GPU" % (world, torch.cuda.device_count())}), flush=True)
+            sys.exit(5)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from fibergen_amd import LSSolver
@@ -409,6 +513,21 @@ def main():
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.dist_backend == "gloo" else "cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def pci_bus_id(dev):
+        import ctypes
+        from fibergen_amd import _lib
+        buf = ctypes.create_string_buffer(64)
+        return buf.value.decode() if _lib.load().fg_device_pci_bus_id(int(dev), buf, 64) == 0 else "?"
+
+    def exchange_times(solver, passes):
+        """per pass, max over ranks: ms of the exchanges measured by HIP events on the exchange stream while stage timing
+        was on (kernel_table): every exchange waited for, nothing overlapped -- what the links (and the slowest peer) cost"""
+        ct = solver.comm_times()
+        return {k: max_over_ranks(v / max(passes, 1)) for k, v in ct.items()}
+
+    devices = [None] * world
+    dist.all_gather_object(devices, "%s rank %d: %s" % (socket.gethostname(), rank, pci_bus_id(local_rank)))
 
     replicas = None
     if not args.no_replicas:
@@ -460,7 +579,8 @@ def main():
         lo, hi = max_over_ranks(min(dts)), max_over_ranks(max(dts))
         it_s = args.steps / med
         local_n = (args.n // world, args.n, args.n)
-        kern, _, _ = kernel_table(d, E, local_n, min(args.steps, 10), False)   # this rank's slab, HIP events
+        kern, _, cnt = kernel_table(d, E, local_n, min(args.steps, 10), False)   # this rank's slab, HIP events
+        xt = exchange_times(d, cnt)
         dom = max(kern, key=lambda k: kern[k]["avg_ms"])
         line.update({
             "value": it_s, "ms_per_step": 1e3 * med / args.steps, "scaling": "strong",
@@ -469,7 +589,10 @@ def main():
                          "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
                          "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]},
             "loop_GBps_Amin": A_MIN_BYTES_PER_VOXEL * N * it_s / 1e9,
-            "kernels": kern, "replicas": replicas, "transport": d.transport,
+            "kernels": kern, "kernel_sum_ms": kernel_table.last_sum_ms, "replicas": replicas,
+            "transport": d.transport, "rccl_ranks": world if d.transport == "rccl" else 0,
+            "devices": devices, "distinct_devices": len({x.split(": ")[1] for x in devices}),
+            "alltoall_ms": xt["alltoall_fwd"] + xt["alltoall_bwd"], "exchange_ms_per_pass": xt,
             "alltoall_MB_per_gpu_per_pass": 2 * 3 * (world - 1) / world * (args.n // world) * args.n * (args.n // 2 + 1) * 16 / 1e6,
         })
         line["config"]["parallelism"] = ("x-slabs x%d: ONE problem, displacement loop per slab, per component one RCCL all-to-all "
@@ -501,11 +624,13 @@ def main():
                 steps2 = max(5, args.steps // 2) if ne >= 512 else args.steps
                 dts2 = timed_regions(lambda k: d2.iterate(E, k), lambda: sync_all(d2), steps2, min(args.warmup, 3), 3)
                 med2 = max_over_ranks(statistics.median(dts2))
-                kern2, _, _ = kernel_table(d2, E, (ne // world, ne, ne), min(steps2, 10), False)
+                kern2, _, cnt2 = kernel_table(d2, E, (ne // world, ne, ne), min(steps2, 10), False)
+                xt2 = exchange_times(d2, cnt2)
                 line["also_slab"] = {"%d^3 %s" % (ne, mix): {
                     "it_s": steps2 / med2, "ms_per_step": 1e3 * med2 / steps2, "steps": steps2, "repeats": 3,
                     "rve": {"K": par2["K"], "R": par2["R"], "L": par2["L"]}, "transport": d2.transport,
                     "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern2.items()},
+                    "alltoall_ms": xt2["alltoall_fwd"] + xt2["alltoall_bwd"], "exchange_ms_per_pass": xt2,
                     "alltoall_MB_per_gpu_per_pass": 2 * 3 * (world - 1) / world * (ne // world) * ne * (ne // 2 + 1) * 16 / 1e6}}
                 d2.close()
             except Exception as e:  # noqa: BLE001

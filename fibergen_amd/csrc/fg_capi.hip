@@ -124,6 +124,7 @@ const char* fg_slab_transport(const fg_solver* s) { return (s && s->impl) ? s->i
 
 int fg_slab_group_create(int nx, int ny, int nz, double dx, double dy, double dz, int device, int nranks, fg_solver** out) {
   std::vector<fg_solver*> made;
+  std::shared_ptr<fg::SlabGroup> group;   // outlives the members on the failure path: it owns their stream
   try {
     if (!out) throw std::runtime_error("NULL argument");
     if (nranks < 1 || nranks > 16) throw std::runtime_error("in-process slab group: 1..16 members");
@@ -134,7 +135,7 @@ int fg_slab_group_create(int nx, int ny, int nz, double dx, double dy, double dz
     FG_HIP_CHECK(hipSetDevice(device));
     hipStream_t stream = nullptr;
     FG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    auto group = std::make_shared<fg::SlabGroup>(std::vector<fg::Solver*>{}, stream);   // owns the stream
+    group = std::make_shared<fg::SlabGroup>(std::vector<fg::Solver*>{}, stream);   // owns the stream
     auto hub = fg::make_local_hub(nranks);
     std::vector<fg::Solver*> members;
     for (int r = 0; r < nranks; ++r) {
@@ -154,9 +155,13 @@ int fg_slab_group_create(int nx, int ny, int nz, double dx, double dy, double dz
     g_create_error = "unknown error";
   }
   for (fg_solver* h : made) {
-    delete h->impl;
+    try {
+      delete h->impl;
+    } catch (...) {
+    }
     delete h;
   }
+  group.reset();   // destroys the shared stream, after the members that synchronise on it
   return FG_ERROR;
 }
 
@@ -420,6 +425,29 @@ int fg_get_stage_times(const fg_solver* s, double* ms, long* count) {
     for (int i = 0; i < fg::kNumTimedKernels; ++i) ms[i] = t.ms[i];
   if (count) *count = t.count;
   return FG_OK;
+}
+
+int fg_get_stage_timing_bias(const fg_solver* s, double* ms) {
+  if (!s || !s->impl || !ms) return FG_ERROR;
+  *ms = s->impl->event_bias_ms();
+  return FG_OK;
+}
+
+int fg_get_comm_times(const fg_solver* s, double* ms) {
+  if (!s || !s->impl || !ms) return FG_ERROR;
+  s->impl->comm_times(ms);
+  return FG_OK;
+}
+
+int fg_device_pci_bus_id(int device, char* out, int capacity) {
+  try {
+    if (!out || capacity < 16) throw std::runtime_error("fg_device_pci_bus_id: buffer of at least 16 bytes needed");
+    FG_HIP_CHECK(hipDeviceGetPCIBusId(out, capacity, device));
+    return FG_OK;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    return FG_ERROR;
+  }
 }
 
 int fg_hbm_stream(int device, int megabytes, int reps, double* copy_GBps, double* triad_GBps) {

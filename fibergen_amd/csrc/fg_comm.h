@@ -41,6 +41,9 @@ class Comm {
   virtual void exchange(const XOp* ops, int n, hipStream_t stream) = 0;
   // in place on a device buffer; min_op: element-wise minimum instead of the sum
   virtual void allreduce(double* buf, int n, bool min_op, hipStream_t stream) = 0;
+  // collectives issued between the two calls may be fused into one launch (RCCL group); no-ops elsewhere
+  virtual void group_begin() {}
+  virtual void group_end() {}
   virtual const char* name() const = 0;
 };
 

@@ -99,6 +99,8 @@ class RcclComm : public Comm {
   void allreduce(double* buf, int n, bool min_op, hipStream_t stream) override {
     FG_NCCL_CHECK(rccl().AllReduce(buf, buf, (size_t)n, ncclDouble, min_op ? ncclMin : ncclSum, comm_, stream));
   }
+  void group_begin() override { FG_NCCL_CHECK(rccl().GroupStart()); }
+  void group_end() override { FG_NCCL_CHECK(rccl().GroupEnd()); }
 
  private:
   int rank_, size_;

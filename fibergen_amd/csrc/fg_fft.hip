@@ -383,7 +383,7 @@ bool launch_strided_mixed(const StridedArgs& a0, int nouter, int dir, int ncomp,
     a.tiles_per_outer = (a.ncols + 7) / 8;
     const dim3 grid((unsigned)((long)a.tiles_per_outer * nouter), ncomp);
     static PerDeviceOnce configured;
-    if (configured.first_use()) {
+    if (auto once = configured.first_use()) {
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strided_mixed<M, P, -1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strided_mixed<M, P, +1>),
@@ -500,7 +500,7 @@ bool launch_z_mixed(double* data, long nrows, int nzp, int ncomp, long comp_stri
   } else {
     const dim3 grid((unsigned)((nrows + LINES - 1) / LINES), ncomp);
     static PerDeviceOnce configured;
-    if (configured.first_use()) {
+    if (auto once = configured.first_use()) {
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_z_mixed<MP, P, LINES, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_z_mixed<MP, P, LINES, false>),
@@ -670,7 +670,7 @@ bool launch_xfused_mixed(XFusedArgs a, int nouter, const cplx* wN, hipStream_t s
     if (probe_only) return true;
     a.tiles_per_outer = (a.ncols + 7) / 8;
     static PerDeviceOnce configured;
-    if (configured.first_use()) {
+    if (auto once = configured.first_use()) {
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused_mixed<M, P>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -811,7 +811,7 @@ template <class K>
 void launch_strided(const StridedArgs& a, long nblocks, int ncomp, long comp_stride, hipStream_t s) {
   static PerDeviceOnce configured;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
-  if (configured.first_use()) {
+  if (auto once = configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strided<K>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
@@ -823,7 +823,7 @@ template <class K>
 void launch_z(const ZArgs& a, int ncomp, long comp_stride, int lines, hipStream_t s) {
   static PerDeviceOnce configured;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
-  if (configured.first_use()) {
+  if (auto once = configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zpass<K>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
@@ -850,7 +850,7 @@ void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
   using K = XFusedKernel<N, C, NC, XSPLIT>;
   static PerDeviceOnce configured;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
-  if (configured.first_use()) {
+  if (auto once = configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xfused<K>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
@@ -1037,7 +1037,7 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
 #define FG_TILE_COMBINE(D, PP)                                                                                         \
   do {                                                                                                                 \
     static PerDeviceOnce configured;                                                                                    \
-    if (configured.first_use()) {                                                                                                 \
+    if (auto once = configured.first_use()) {                                                                                                 \
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixed_combine_tile<D, PP>),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
     }                                                                                                                  \
@@ -1276,7 +1276,7 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
 #define FG_FINISH(PP)                                                                                             \
   do {                                                                                                            \
     static PerDeviceOnce configured;                                                                               \
-    if (configured.first_use()) {                                                                                            \
+    if (auto once = configured.first_use()) {                                                                                            \
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixed_r2c_finish<PP>),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
     }                                                                                                             \
@@ -1345,7 +1345,7 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
 #define FG_START(PP)                                                                                             \
   do {                                                                                                           \
     static PerDeviceOnce configured;                                                                              \
-    if (configured.first_use()) {                                                                                           \
+    if (auto once = configured.first_use()) {                                                                                           \
       FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixed_c2r_start<PP>),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
     }                                                                                                            \

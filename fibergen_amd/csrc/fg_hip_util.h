@@ -16,6 +16,8 @@
   } while (0)
 
 #include <atomic>
+#include <exception>
+#include <mutex>
 
 namespace fg {
 
@@ -30,9 +32,30 @@ inline int current_device() {
   return d < 0 || d >= kMaxDevices ? 0 : d;
 }
 
+// first_use() hands the first caller on a device a guard that keeps the other callers of that device waiting until the
+// guarded block (hipFuncSetAttribute ...) has run; the flag is set only when the block left without an exception:
+//     static PerDeviceOnce configured;
+//     if (auto once = configured.first_use()) { FG_HIP_CHECK(hipFuncSetAttribute(...)); }
 struct PerDeviceOnce {
   std::atomic<bool> done[kMaxDevices] = {};
-  bool first_use() { return !done[current_device()].exchange(true); }
+  std::mutex mu;
+  struct Guard {
+    PerDeviceOnce* owner;
+    int device;
+    int exceptions;
+    std::unique_lock<std::mutex> lock;
+    explicit operator bool() const { return owner != nullptr; }
+    ~Guard() {
+      if (owner && std::uncaught_exceptions() == exceptions) owner->done[device].store(true, std::memory_order_release);
+    }
+  };
+  Guard first_use() {
+    const int d = current_device();
+    if (done[d].load(std::memory_order_acquire)) return Guard{nullptr, d, 0, {}};
+    std::unique_lock<std::mutex> lk(mu);
+    if (done[d].load(std::memory_order_acquire)) return Guard{nullptr, d, 0, {}};
+    return Guard{this, d, std::uncaught_exceptions(), std::move(lk)};
+  }
 };
 
 inline int device_cu_count() {

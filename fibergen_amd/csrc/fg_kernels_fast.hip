@@ -853,7 +853,7 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   if (nb >= 8) nb = ((nb + 7) / 8) * 8;
   const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
   static PerDeviceOnce configured;
-  if (configured.first_use()) {
+  if (auto once = configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, ZS, SUMT, PHI2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
@@ -1113,7 +1113,7 @@ void launch_eps_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldP
   if (nb >= 8) nb = ((nb + 7) / 8) * 8;
   const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
   static PerDeviceOnce configured;
-  if (configured.first_use()) {
+  if (auto once = configured.first_use()) {
     FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eps_tile<TYR, ZS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }

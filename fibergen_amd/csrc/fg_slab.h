@@ -37,7 +37,10 @@ class SlabGroup {
  private:
   void prepare();                                   // buffers, effective moduli + their halo planes
   bool fast_ok(bool allow_mixed_bc) const;
-  void pass_fast(const double* E_cur, bool sum_tau);                   // steps 0..9, speculative chain included
+  void pass_fast(const double* E_cur, bool sum_tau, bool chain);       // steps 0..9 (chain: the speculative chain included)
+  void pass_fast_chain();                                              // steps 1..9
+  bool stop_requested() const;                                         // reduced flag word: some rank was cancelled
+  void vote(double* v2);                                               // sums of two host values over the ranks
   void pass_exact(const double* E6, bool mixed_bc);                    // strain-state pipeline, adopts
   void wait_norms();
   void reduce_and_fetch(int slot, int n, bool min_op);                 // members' dscal_ slots -> reduced hscal_

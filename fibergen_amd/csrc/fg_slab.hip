@@ -51,6 +51,14 @@ void launch_block_remap(const double* in, double* out, const Grid& g, int nyl, b
   FG_HIP_CHECK(hipGetLastError());
 }
 
+// The flag word every reduction of the driver carries (summed over the ranks): whether a kernel of this rank raised the
+// device error flag, and whether this rank was asked to stop.  Stop and error decisions are taken on the reduced word, so
+// every rank takes the same one.
+__global__ void k_flag_word(const int* derr, double stop, double* flag) {
+  flag[0] = *derr != 0 ? 1.0 : 0.0;
+  flag[1] = stop;
+}
+
 FieldPtrs<3> strided3(double* base, long stride) {
   FieldPtrs<3> f;
   for (int c = 0; c < 3; ++c) f.p[c] = base + c * stride;
@@ -101,6 +109,7 @@ void Solver::slab_alloc() {
   FG_HIP_CHECK(hipEventCreateWithFlags(&ev_c2x_, hipEventDisableTiming));
   FG_HIP_CHECK(hipEventCreateWithFlags(&ev_norm_, hipEventDisableTiming));
   for (int k = 0; k < kCommSlots; ++k) FG_HIP_CHECK(hipEventCreateWithFlags(&ev_x_[k], hipEventDisableTiming));
+  for (int k = 0; k < 2; ++k) FG_HIP_CHECK(hipEventCreate(&ev_ct_[k]));
 }
 
 void Solver::comm_begin() {
@@ -117,6 +126,20 @@ void Solver::comm_wait(int slot) {
   if (!x_pending_[slot]) return;
   FG_HIP_CHECK(hipStreamWaitEvent(stream_, ev_x_[slot], 0));
   x_pending_[slot] = false;
+}
+
+// stage timing: HIP events on the exchange stream around one exchange; the host waits for it (every rank does, in the same
+// order), so the figure is the exchange alone -- transfer plus the wait for the slowest peer -- with nothing overlapped
+void Solver::comm_time_begin() {
+  if (timing_) FG_HIP_CHECK(hipEventRecord(ev_ct_[0], comm_stream_));
+}
+void Solver::comm_time_end(int category) {
+  if (!timing_) return;
+  FG_HIP_CHECK(hipEventRecord(ev_ct_[1], comm_stream_));
+  FG_HIP_CHECK(hipEventSynchronize(ev_ct_[1]));
+  float ms = 0.f;
+  FG_HIP_CHECK(hipEventElapsedTime(&ms, ev_ct_[0], ev_ct_[1]));
+  comm_ms_[category] += ms;
 }
 
 // One slab has nothing to overlap; otherwise split when a component of the slab is >= 32 MB (512^3 on 8 GPUs: 135 MB,
@@ -195,20 +218,34 @@ void Solver::slab_exchange(int what, int comp, int done_slot) {
                                   slab_buffer(p.self_src.buffer) + p.self_src.offset, (size_t)p.self_src.count * sizeof(double),
                                   hipMemcpyDeviceToDevice, comm_stream_));
   }
+  comm_time_begin();
   comm_->exchange(ops.data(), (int)ops.size(), comm_stream_);
+  comm_time_end(what == FG_PLAN_A2A_FORWARD ? 0 : what == FG_PLAN_A2A_BACKWARD ? 1 : 2);
   comm_end(done_slot);
 }
 
+// All-reduce of dscal_[slot .. slot + n) together with the flag word.  The exchange stream is ordered behind the compute
+// stream here in every configuration (also for a lone slab, whose sums need no reduction): the copies to the host that
+// follow are issued on the exchange stream.
 void Solver::slab_reduce(int slot, int n, bool min_op) {
-  if (nranks_ == 1 && !slab_loopback()) return;
-  if (!comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
+  hipLaunchKernelGGL(k_flag_word, dim3(1), dim3(1), 0, stream_, derr_, cancel_ ? 1.0 : 0.0, dscal_ + kSlotFlag);
+  FG_HIP_CHECK(hipGetLastError());
   comm_begin();
-  comm_->allreduce(dscal_ + slot, n, min_op, comm_stream_);
+  if (nranks_ > 1 || slab_loopback()) {
+    if (!comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
+    comm_time_begin();
+    comm_->group_begin();
+    comm_->allreduce(dscal_ + slot, n, min_op, comm_stream_);
+    comm_->allreduce(dscal_ + kSlotFlag, 2, false, comm_stream_);
+    comm_->group_end();
+    comm_time_end(3);
+  }
   comm_end(kXSums);
 }
 
 void Solver::slab_fetch_norms(int n) {
   FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, n * sizeof(double), hipMemcpyDeviceToHost, comm_stream_));
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotFlag, dscal_ + kSlotFlag, 2 * sizeof(double), hipMemcpyDeviceToHost, comm_stream_));
   FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, comm_stream_));
   FG_HIP_CHECK(hipEventRecord(ev_norm_, comm_stream_));
 }
@@ -497,26 +534,50 @@ void SlabGroup::prepare() {
     }
 }
 
+// Waits for the sums (and the flag word) of the last reduction.  The error decision is taken on the REDUCED flag: when a
+// kernel of any rank raised its error flag (a laminate voxel with more than two phases that only one slab contains, say),
+// every rank throws here, in the same pass.
 void SlabGroup::wait_norms() {
   for (Solver* s : m_) FG_HIP_CHECK(hipEventSynchronize(s->ev_norm_));
-  for (Solver* s : m_)
-    if (*s->herr_ != 0) {
-      FG_HIP_CHECK(hipMemsetAsync(s->derr_, 0, sizeof(int), s->stream_));
-      if (s->opt_.mixing == kMixLaminate) throw std::runtime_error("The laminate mixing rule supports only two phase mixtures (stress)");
-      throw std::runtime_error("device kernel reported an error (stress)");
-    }
+  bool any = false, mine = false;
+  for (Solver* s : m_) {
+    any = any || s->hscal_[kSlotFlag] != 0.0;
+    mine = mine || *s->herr_ != 0;
+  }
+  if (!any) return;
+  for (Solver* s : m_) FG_HIP_CHECK(hipMemsetAsync(s->derr_, 0, sizeof(int), s->stream_));
+  const char* where = mine ? "(stress)" : "(stress, on another rank)";
+  if (m_[0]->opt_.mixing == kMixLaminate)
+    throw std::runtime_error(std::string("The laminate mixing rule supports only two phase mixtures ") + where);
+  throw std::runtime_error(std::string("device kernel reported an error ") + where);
 }
+
+bool SlabGroup::stop_requested() const { return m_[0]->hscal_[kSlotFlag + 1] != 0.0; }
 
 // all members have left their local contribution in dscal_[slot..slot+n): reduce over ranks, bring to every host
 void SlabGroup::reduce_and_fetch(int slot, int n, bool min_op) {
   for (Solver* s : m_) s->slab_reduce(slot, n, min_op);
   for (Solver* s : m_) {
     FG_HIP_CHECK(hipMemcpyAsync(s->hscal_ + slot, s->dscal_ + slot, n * sizeof(double), hipMemcpyDeviceToHost, s->comm_stream_));
+    FG_HIP_CHECK(hipMemcpyAsync(s->hscal_ + kSlotFlag, s->dscal_ + kSlotFlag, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                                s->comm_stream_));
     FG_HIP_CHECK(hipMemcpyAsync(s->herr_, s->derr_, sizeof(int), hipMemcpyDeviceToHost, s->comm_stream_));
     FG_HIP_CHECK(hipEventRecord(s->ev_norm_, s->comm_stream_));
   }
   wait_norms();
   for (Solver* s : m_) s->comm_wait(kXSums);   // later writes of dscal_ on the compute stream follow the reduction
+}
+
+// Sum over all ranks of two small host values (votes: a callback asked to stop, a rank was cancelled).
+void SlabGroup::vote(double* v2) {
+  for (Solver* s : m_) {
+    s->hscal_[kSlotMisc] = s == m_[0] ? v2[0] : 0.0;
+    s->hscal_[kSlotMisc + 1] = s == m_[0] ? v2[1] : 0.0;
+    FG_HIP_CHECK(hipMemcpyAsync(s->dscal_ + kSlotMisc, s->hscal_ + kSlotMisc, 2 * sizeof(double), hipMemcpyHostToDevice, s->stream_));
+  }
+  reduce_and_fetch(kSlotMisc, 2, false);
+  v2[0] = m_[0]->hscal_[kSlotMisc];
+  v2[1] = m_[0]->hscal_[kSlotMisc + 1];
 }
 
 void SlabGroup::mean_strain(double* out6) {
@@ -593,11 +654,16 @@ double SlabGroup::bc_error(const double* E_cur, const double* S_cur) {
 }
 
 // one displacement pass on every member: the sweep (norms of eps_k), then -- speculatively, the host has not seen the
-// norms yet -- the whole transform chain to u_{k+1}; adopted by the caller if the loop goes on
-void SlabGroup::pass_fast(const double* E_cur, bool sum_tau) {
+// norms yet -- the whole transform chain to u_{k+1}; adopted by the caller if the loop goes on.  chain = false leaves the
+// chain to a later pass_fast_chain() (a run with convergence callbacks decides first, see SlabGroup::run)
+void SlabGroup::pass_fast(const double* E_cur, bool sum_tau, bool chain) {
   for (Solver* s : m_) s->slab_front_fast(E_cur, sum_tau);
   for (Solver* s : m_) s->slab_front_laminate(sum_tau);
   for (Solver* s : m_) s->slab_fetch_norms(sum_tau ? 12 : 6);
+  if (chain) pass_fast_chain();
+}
+
+void SlabGroup::pass_fast_chain() {
   for (int k = 1; k <= 9; ++k)
     for (Solver* s : m_) s->slab_chain_step(k);
 }
@@ -657,7 +723,7 @@ void SlabGroup::iterate(const double* E6, int n) {
       ++i;
     }
     for (; i < n; ++i) {
-      pass_fast(m_[0]->E_cur_, false);
+      pass_fast(m_[0]->E_cur_, false, true);
       for (Solver* s : m_) {
         s->slab_adopt(E6, true);
         s->eps_stale_ = true;
@@ -704,6 +770,20 @@ bool SlabGroup::run(const double* E6, const double* S6) {
     for (int i = 0; i < 6; ++i) s->E_cur_[i] = E0[i];
   }
 
+  // Stop decisions are collective.  Callbacks may be installed on some ranks only (rank 0 printing its progress) and may
+  // answer differently; whether any rank has one is agreed once per run, and if so every pass ends with a vote on the
+  // callbacks' answers before the transform chain of the next pass is enqueued (no speculation: a vote behind the
+  // speculative exchanges would wait for them).  Without callbacks only fg_cancel can ask for a stop from outside; it
+  // travels with the flag word of the next pass's reduction.
+  bool voting = false;
+  if (a.nranks_ > 1) {
+    double v[2] = {0.0, 0.0};
+    for (Solver* s : m_)
+      if (s->cb_) v[0] = 1.0;
+    vote(v);
+    voting = v[0] != 0.0;
+  }
+
   double prev = 0.0;   // EpsilonErrorEstimator  F:14591-14637: norms of the zero field at construction
   long iter = 1;
   bool update_ref = a.opt_.update_ref != 0;
@@ -732,7 +812,7 @@ bool SlabGroup::run(const double* E6, const double* S6) {
       if (iter == 1)
         for (Solver* s : m_)
           for (int i = 0; i < 6; ++i) s->E_cur_[i] = E[i];   // eps_1 = E (u_1 = 0)
-      pass_fast(a.E_cur_, mixed_bc);
+      pass_fast(a.E_cur_, mixed_bc, !voting);
       pending = true;
     } else {
       fast = false;
@@ -762,14 +842,26 @@ bool SlabGroup::run(const double* E6, const double* S6) {
     const double rel_err = abs_err / (small + cur);
     prev = cur;
 
-    // _converged  F:21177-21244
-    if (std::isnan(rel_err) || a.cancel_) {
+    // _converged  F:21177-21244.  rel_err comes from all-reduced sums and is the same on every rank; so is the stop word.
+    if (std::isnan(rel_err) || stop_requested()) {
       failed = true;
       break;
     }
     for (Solver* s : m_) s->residuals_.push_back(rel_err);
-    if (a.cb_ && a.cb_(a.cb_user_)) break;
-    if (a.cancel_) {
+    bool stop = false, cancelled = false;
+    for (Solver* s : m_) {
+      if (s->cb_ && s->cb_(s->cb_user_)) stop = true;
+      if (s->cancel_) cancelled = true;   // cancelled from inside the callback
+    }
+    if (voting) {
+      double v[2] = {stop ? 1.0 : 0.0, cancelled ? 1.0 : 0.0};
+      vote(v);
+      stop = v[0] != 0.0;
+      cancelled = v[1] != 0.0;
+    }
+    if (a.nranks_ > 1 && !voting) cancelled = false;   // an asynchronous fg_cancel: acted upon through the next flag word
+    if (stop) break;
+    if (cancelled) {
       failed = true;
       break;
     }
@@ -777,11 +869,13 @@ bool SlabGroup::run(const double* E6, const double* S6) {
     if (rel_err <= a.opt_.tol || abs_err <= a.opt_.abs_tol) {
       if (bc_error(E0, S0) <= a.opt_.bc_tol) break;
     }
-    if (pending)
+    if (pending) {
+      if (voting) pass_fast_chain();
       for (Solver* s : m_) {
         s->slab_adopt(E_next, true);
         s->eps_stale_ = true;
       }
+    }
     iter++;
   }
   for (Solver* s : m_) {

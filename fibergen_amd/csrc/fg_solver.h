@@ -29,6 +29,8 @@ constexpr int kSlotMean = 6;     // 6
 constexpr int kSlotMinMax = 12;  // 2
 constexpr int kSlotMisc = 14;    // 2
 constexpr int kSlotScratch = 16; // 6: sums nobody reads (strain materialisation)
+constexpr int kSlotFlag = 22;    // 2: slab driver, summed over the ranks with every reduction: [0] ranks whose device error flag
+                                 // is raised, [1] ranks that were asked to stop (fg_cancel)
 constexpr int kSlotCg = 24;      // displacement CG: two blocks of 8 (norms of eps [6] + r:r, alternating per iteration), then p:(p-w) [8]
 constexpr int kNumSlots = 48;
 }  // namespace slots
@@ -163,7 +165,14 @@ class Solver {
   void run_stage(int stage, const double* E6);
   void enable_stage_timing(bool on);
   StageTimes stage_times() const { return times_; }
+  // slab driver, while stage timing is on: milliseconds spent in the exchanges on the exchange stream (HIP events around
+  // each one; the host waits for every exchange, so nothing overlaps while this is measured):
+  // [0] all-to-all forward, [1] all-to-all backward, [2] halo planes, [3] all-reduces; same pass count as stage_times()
+  void comm_times(double* ms4) const {
+    for (int i = 0; i < 4; ++i) ms4[i] = comm_ms_[i];
+  }
   void reset_stage_times();
+  double event_bias_ms() const { return event_bias_ms_; }
 
  private:
   // one pass  dst = E - Gamma0 : (C - C0) : src  (defaults: the solver's strain field, in place)
@@ -208,7 +217,9 @@ class Solver {
   void slab_moduli_step();                               // effective moduli of the slab + exchange of their halo planes
   void slab_front_fast(const double* E6, bool sum_tau);  // su_[cur] -> norms of eps_k (all-reduced), f_{k+1} in fu_
   void slab_front_laminate(bool sum_tau);
-  void slab_fetch_norms(int n);                          // D2H of the reduced sums (+ error flag), event for the host
+  void slab_fetch_norms(int n);                          // D2H of the reduced sums (+ flag word), event for the host
+  void comm_time_begin();
+  void comm_time_end(int category);
   void slab_chain_step(int k);                           // k = 1..9: transform chain fu_ -> su_[next], see fg_slab.hip
   void slab_front_exact(bool sum_tau);                   // eps_ -> tau_, halo of tau (, sums of tau all-reduced)
   void slab_div_exact();                                 // tau_ + halo -> fu_
@@ -237,6 +248,8 @@ class Solver {
   hipEvent_t ev_x_[kCommSlots] = {};    // comm -> compute
   bool x_pending_[kCommSlots] = {};
   hipEvent_t ev_norm_ = nullptr;        // the reduced sums have reached the host
+  hipEvent_t ev_ct_[2] = {nullptr, nullptr};   // exchange timing (stage timing on)
+  double comm_ms_[4] = {0, 0, 0, 0};
   double* su_[2] = {nullptr, nullptr};  // displacement of the slab, 3 components of ucs_ doubles (4 spare planes each)
   int su_cur_ = 0;
   bool su_valid_ = false;               // su_[su_cur_] (with valid halo planes) is the state: eps = E_cur_ + sym grad u
@@ -309,6 +322,7 @@ class Solver {
   double E_cur_[6] = {0, 0, 0, 0, 0, 0};   // prescribed strain the current (u, eps) state was built with
   double E_next_[6] = {0, 0, 0, 0, 0, 0};
   bool timing_ = false;
+  double event_bias_ms_ = 0.0;   // reading of an empty event pair, subtracted from every timed kernel
   StageTimes times_;
   hipEvent_t ev_[2] = {nullptr, nullptr};
   hipEvent_t ev_copy_ = nullptr;

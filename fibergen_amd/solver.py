@@ -269,5 +269,17 @@ class LSSolver:
         self._lib.fg_get_stage_times(self._h, _dp(ms), ctypes.byref(cnt))
         return dict(zip(KERNELS, ms.tolist())), cnt.value
 
+    def stage_timing_bias(self):
+        """ms an empty HIP-event pair reads on the solver's stream (already subtracted from stage_times)"""
+        v = ctypes.c_double(0.0)
+        self._lib.fg_get_stage_timing_bias(self._h, ctypes.byref(v))
+        return v.value
+
+    def comm_times(self):
+        """slab solvers, stage timing on: accumulated ms of the exchanges (fg_get_comm_times)"""
+        ms = np.zeros(4)
+        self._lib.fg_get_comm_times(self._h, _dp(ms))
+        return dict(zip(("alltoall_fwd", "alltoall_bwd", "halo", "allreduce"), ms.tolist()))
+
     def device_pointer(self, name, comp):
         return self._lib.fg_device_pointer(self._h, name.encode(), int(comp))

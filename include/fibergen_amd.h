@@ -156,6 +156,9 @@ int fg_synchronize(fg_solver* s);
 int fg_run_stage(fg_solver* s, int stage, const double* E6);
 int fg_enable_stage_timing(fg_solver* s, int enable);
 int fg_get_stage_times(const fg_solver* s, double* ms /* [FG_NUM_TIMED_KERNELS] */, long* count);
+/* What a pair of HIP events reads with nothing between them on this solver's stream (measured when timing is switched
+ * on, milliseconds); it has been subtracted from every figure fg_get_stage_times reports. */
+int fg_get_stage_timing_bias(const fg_solver* s, double* ms);
 
 /* Measurement helper (no counterpart in the reference): achieved HBM bandwidth of a streaming copy a = b and of the
  * triad a = b + s*c on `device`, arrays of `megabytes` MB each, best of `reps` launches, in GB/s of bytes moved
@@ -207,6 +210,20 @@ typedef int (*fg_allreduce_fn)(void* user, double* values, int n, int min_op);
 int fg_slab_connect_callback(fg_solver* s, fg_exchange_fn exchange, fg_allreduce_fn allreduce, void* user);
 /* name of the connected transport ("rccl", "local", "callback") or "" */
 const char* fg_slab_transport(const fg_solver* s);
+
+/* Stop and error decisions of a collective run are themselves collective: every reduction of the loop carries a flag word
+ * (device error flag of any rank, fg_cancel on any rank), and fg_run_load_case returns / fails on every rank in the same
+ * pass.  fg_cancel from another thread takes effect with the next pass's reduction.  Convergence callbacks (F:21215) may be
+ * installed on some ranks only and may answer differently: when any rank has one, every pass ends with a vote and the
+ * run stops everywhere as soon as one callback asks for it (the transform chain of the next pass is then no longer
+ * enqueued speculatively, which costs the overlap of the host with the device). */
+
+/* Measurement: with stage timing on (fg_enable_stage_timing) the exchanges of a slab solver are bracketed by HIP events on
+ * the exchange stream and waited for one by one; ms[0] all-to-all forward, ms[1] all-to-all backward, ms[2] halo planes,
+ * ms[3] all-reduces, accumulated over the passes fg_get_stage_times counts. */
+int fg_get_comm_times(const fg_solver* s, double* ms /* [4] */);
+/* PCI bus id ("0000:05:00.0") of HIP device `device`: lets a launcher show that N ranks sit on N different GPUs. */
+int fg_device_pci_bus_id(int device, char* out, int capacity);
 
 /* The exchange plan (pure index arithmetic, no GPU): ops of exchange `what` for `rank`, offsets / counts in doubles
  * relative to the named buffer.  Returns the number of ops (<= capacity) or -1.  self_copy[2] (may be NULL) receives

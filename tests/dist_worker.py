@@ -123,6 +123,11 @@ def main():
     ap.add_argument("--mixed-bc", type=int, default=0)
     ap.add_argument("--split", type=int, default=-1)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--stop-rank", type=int, default=-1, help="only this rank installs a convergence callback ...")
+    ap.add_argument("--stop-iter", type=int, default=0, help="... which asks to stop in this iteration")
+    ap.add_argument("--bad-rank", type=int, default=-1,
+                    help="laminate mixing: this rank's slab gets one voxel with THREE phases (a device-side error that only "
+                         "this rank sees locally)")
     ap.add_argument("--transport", default="",
                     help="rccl: the library's RCCL transport between the ranks although they share ONE GPU -- every rank poses "
                          "as a host of its own (NCCL_HOSTID), so that RCCL connects them through its socket transport on the "
@@ -162,9 +167,27 @@ def main():
     from helpers import two_phase_setup
     from fibergen_amd.distributed import DistributedLSSolver
     mats, phis, normals = two_phase_setup(grid, a.mixing)
-    s = DistributedLSSolver(*grid, *dims, device=0, transport=a.transport or None)
-    s.set_num_phases(2)
-    for p in range(2):
+    try:
+        s = DistributedLSSolver(*grid, *dims, device=0, transport=a.transport or None)
+    except RuntimeError as e:
+        if a.transport == "rccl" and ("ncclCommInitRank" in str(e) or "ncclGetUniqueId" in str(e) or "cannot load librccl" in str(e)):
+            # the one failure the GPU suite may skip on: RCCL cannot connect the ranks on this box at all
+            print("FG_RCCL_INIT_FAILED: %s" % e, file=sys.stderr, flush=True)
+        raise
+    nph = 2
+    if a.bad_rank >= 0:
+        nph = 3
+        mats = list(mats) + [mats[1]]
+        third = np.zeros_like(phis[0])
+        lo = a.bad_rank * (grid[0] // P)
+        sl = phis[1][lo:lo + grid[0] // P]
+        idx = np.argwhere((sl > 0.2) & (sl < 0.8))[0]
+        v = (lo + idx[0], idx[1], idx[2])
+        third[v] = 0.1
+        phis = [phis[0].copy(), phis[1].copy(), third]
+        phis[0][v] -= 0.1
+    s.set_num_phases(nph)
+    for p in range(nph):
         s.set_phase(p, mats[p][0], mats[p][1], s.slab(phis[p]))
     s.set_normals(s.slab(normals))
     s.set_options(mixing_rule=a.mixing, tol=a.tol, slab_split=a.split)
@@ -177,11 +200,25 @@ def main():
         s.set_options(bc_tol=1e-8, maxiter=400)
         E = np.array([0.01, 0, 0, 0, 0, 0])
         S = np.zeros(6)
-    failed = s.run(E, S)
-    np.savez(a.out + ".%d.npz" % rank, eps=s.get_field("epsilon"), sigma=s.get_field("sigma"),
-             iterations=s.iterations, residuals=np.array(s.residuals), mean_stress=s.mean_stress(),
-             mean_strain=s.mean_strain(), mu_0=s.ref_material[0], failed=failed, vf=s.volume_fraction(1),
-             transport=s.transport)
+    calls = []
+    if a.stop_rank == rank:
+        def cb():
+            calls.append(1)
+            return len(calls) >= a.stop_iter
+        s.set_convergence_callback(cb)
+    error = ""
+    failed = None
+    try:
+        failed = s.run(E, S)
+    except RuntimeError as e:
+        error = str(e)
+    if error:
+        np.savez(a.out + ".%d.npz" % rank, error=error, transport=s.transport)
+    else:
+        np.savez(a.out + ".%d.npz" % rank, eps=s.get_field("epsilon"), sigma=s.get_field("sigma"),
+                 iterations=s.iterations, residuals=np.array(s.residuals), mean_stress=s.mean_stress(),
+                 mean_strain=s.mean_strain(), mu_0=s.ref_material[0], failed=failed, vf=s.volume_fraction(1),
+                 transport=s.transport, callback_calls=len(calls), error="")
     s.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -205,3 +205,55 @@ def test_rccl_loopback_beside_pytorch():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("OK")][-1]
     assert line.count("librccl") == 1, line     # exactly one RCCL mapped: shared with PyTorch, not a second copy
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4's sizes through the slab driver: 8 slabs of the benchmark RVE in one process on the one GPU of the
+# test box (the exchanges are device copies; every offset of the blocked all-to-all layouts, every halo plane and the
+# interface correction across slab faces are the ones an 8-GPU run uses) against the single-GPU solver, which
+# tests/test_gpu_fullsize_oracle.py checks against oracle/c at these very sizes.
+def _bench_problem(n, mixing):
+    from helpers import INCLUSION, MATRIX, lame
+    from fibergen_amd.rve import bench_rve
+    phi, normals, _ = bench_rve(n, mixing)
+    return [lame(**MATRIX), lame(**INCLUSION)], [1.0 - phi, phi], normals
+
+
+def _start_field(n, phi):
+    x = (np.arange(n) + 0.5) / n
+    w = np.sin(2 * np.pi * x)[:, None, None] * np.cos(4 * np.pi * x)[None, :, None] + 0.5 * np.sin(6 * np.pi * x)[None, None, :]
+    eps = np.empty((6, n, n, n))
+    for c in range(6):
+        eps[c] = E_LOAD[c] + 0.05 * (c + 1) * phi + 0.02 * (6 - c) * w
+    return eps
+
+
+@pytest.mark.parametrize("n,mixing,passes,split", [(256, "voigt", 3, -1), (256, "laminate", 3, -1), (512, "laminate", 2, -1),
+                                                   (256, "voigt", 3, 1)])
+def test_eight_slabs_at_baseline_size_equal_single_gpu_solver(n, mixing, passes, split):
+    import gc
+    from fibergen_amd import LSSolver
+    from fibergen_amd.distributed import SlabGroup
+    mats, phis, normals = _bench_problem(n, mixing)
+    eps0 = _start_field(n, phis[1])
+    got = {}
+    for kind in ("single", "slabs"):
+        x = LSSolver(n, n, n) if kind == "single" else SlabGroup(n, n, n, nranks=8)
+        x.set_num_phases(2)
+        for p in range(2):
+            x.set_phase(p, mats[p][0], mats[p][1], phis[p])
+        if normals is not None:
+            x.set_normals(normals)
+        x.set_options(mixing_rule=mixing)
+        if kind == "slabs":
+            x.set_options(slab_split=split)
+        x.calc_ref_material()
+        x.set_field("epsilon", eps0)
+        x.iterate(E_LOAD, passes)     # pass 1: strain-state pipeline (no displacement yet), then the displacement loop
+        got[kind] = (x.get_field("epsilon"), x.mean_stress(), x.ref_material)
+        x.close()
+        del x
+        gc.collect()
+    assert got["slabs"][2] == got["single"][2]
+    assert rel_err(got["slabs"][0], got["single"][0]) < 1e-11
+    assert rel_err(got["slabs"][1], got["single"][1]) < 1e-12
