@@ -203,11 +203,10 @@ def cpu_passes(n, mixing, phi, normals, threads, max_passes, max_seconds):
 def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
     """The reference's loop restated in C/OpenMP (oracle/c: one in-place strain field, buffers allocated once, the
     reference's release flags -O3 -march=native built on this host) + pocketfft (scipy.fft, workers = threads) in place
-    of threaded FFTW, on the host cores, threads spread over the cores (OMP_PROC_BIND=spread, OMP_PLACES=cores): a sweep
-    over thread counts on the headline grid (best = `value`), the reference's default of ONE thread (F:25226), and the
-    other BASELINE grids `others` = [(n_edge, mixing, phi, normals)] at the best thread count (`per_grid`)."""
-    os.environ.setdefault("OMP_PROC_BIND", "spread")   # read by libgomp when the oracle library is loaded (below)
-    os.environ.setdefault("OMP_PLACES", "cores")
+    of threaded FFTW, on the host cores: a sweep over thread counts on the headline grid (best = `value`), the reference's
+    default of ONE thread (F:25226), and the other BASELINE grids `others` = [(n_edge, mixing, phi, normals)] at the best
+    thread count (`per_grid`).  No thread pinning: OMP_PROC_BIND binds the calling thread too, and pocketfft's worker
+    threads inherit its one-core mask (measured: 70 % of the pass in the FFT, 1.3 instead of 2.7 it/s at 256^3)."""
     ncpu = os.cpu_count() or 1
     cores, sockets = physical_cores()
     counts = sorted({t for t in (16, 32, 64, cores or ncpu) if t <= ncpu})
@@ -234,12 +233,25 @@ def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
             "one_thread_it_s": one, "host_cpus": ncpu, "physical_cores": cores, "sockets": sockets, "fft_share": shares[best],
             "thread_sweep_it_s": {str(k): v for k, v in sorted(sweep.items())}, "per_grid": per_grid,
             "sample": "passes of the same %dx%dx%d RVE for <= 3 s per thread count (%s threads; value = best; every count on "
-                      "freshly allocated buffers first touched by its own threads, OMP_PROC_BIND=%s OMP_PLACES=%s) + one pass "
+                      "freshly allocated buffers first touched by its own threads) + one pass "
                       "with 1 thread; per_grid: the other BASELINE grids at the best count (512^3: 2 passes); oracle/c loop "
                       "nests (-O3 -march=native, in-place strain field, preallocated) + pocketfft rfftn/irfftn workers = "
                       "threads standing in for threaded FFTW; %.0f s in total"
-                      % (*n, "/".join(str(k) for k in counts), os.environ["OMP_PROC_BIND"], os.environ["OMP_PLACES"],
-                         time.perf_counter() - t_start)}
+                      % (*n, "/".join(str(k) for k in counts), time.perf_counter() - t_start)}
+
+
+def cg_rate(s, E, steps, repeats, sync):
+    """CG iterations per second through the solver's run entry point (stop rule every iteration, maxiter = steps)"""
+    s.set_options(method="cg", tol=0.0, abs_tol=0.0, maxiter=steps)
+    rates = []
+    for _ in range(repeats + 1):
+        sync()
+        t0 = time.perf_counter()
+        s.run(E)
+        sync()
+        rates.append((s.iterations + 1) / (time.perf_counter() - t0))   # iterations 0 .. maxiter
+    s.set_options(method="basic", tol=1e-4, abs_tol=np.finfo(float).eps, maxiter=10000)
+    return statistics.median(rates[1:]), min(rates[1:]), max(rates[1:])
 
 
 def measure_single(args, n_edge, mixing, mode, device, E, detail):
@@ -290,6 +302,9 @@ def measure_single(args, n_edge, mixing, mode, device, E, detail):
         res["run_load_case_it_s"] = s.iterations / s.solve_time
         res["run_load_case_iterations"] = s.iterations
         s.set_options(tol=1e-4, abs_tol=np.finfo(float).eps, maxiter=10000)
+        if args.method == "cg":
+            med_cg, lo_cg, hi_cg = cg_rate(s, E, args.steps, 5, s.synchronize)
+            res["cg"] = {"it_s": med_cg, "it_s_min": lo_cg, "it_s_max": hi_cg, "iterations_per_run": args.steps + 1}
     return s, res, phi, normals
 
 
@@ -303,6 +318,10 @@ def main():
     ap.add_argument("--n", "--size", dest="n", type=int, default=256, help="grid size per axis (128, 256, 512 are the BASELINE sizes; any size runs)")
     ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
     ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat", "viscosity"])
+    ap.add_argument("--method", default="basic", choices=["basic", "cg"],
+                    help="cg: `value` is the rate of runCGElasticity iterations (F:23153-23247, the reference's default method; one "
+                         "operator application + two inner-product sweeps + two vector updates each) through fg_run_load_case "
+                         "with maxiter = steps; the kernel table stays the basic scheme's (the operator is the same kernels)")
     ap.add_argument("--also", default="128:voigt,512:laminate,256:voigt:porous,256:voigt:viscosity",
                     help="N = 1: further single-GPU workloads n:mixing[:mode] reported under `also` ('' = none): the other "
                          "BASELINE sizes and config 5 (porous / Stokes)")
@@ -373,6 +392,8 @@ def main():
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_from_committed_profile": traffic_src,
                 "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]}
         it_s = res["it_s"]
+        if args.method == "cg":
+            metric = metric.replace("LS iterations/sec (basic scheme", "CG iterations/sec (runCGElasticity")
         per_voxel = (24 + 7 * 16) if scalar else A_MIN_BYTES_PER_VOXEL
         out = {
             "metric": metric, "value": it_s, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -391,6 +412,9 @@ def main():
             "kernel_sum_ms": res["kernel_sum_ms"], "hip_event_bias_ms_subtracted": res["hip_event_bias_ms_subtracted"],
             "kernels": kern, "rve": res["rve"],
         }
+        if args.method == "cg":
+            out.update({"value": res["cg"]["it_s"], "ms_per_step": 1e3 / res["cg"]["it_s"], "cg": res["cg"],
+                        "basic_scheme_it_s": it_s})
         if not scalar and not stokes:
             # north_star names the Green-operator apply on its own (">= 50 % of the HBM roofline in the Gamma0-apply
             # kernel"): in the default pipeline it is fused into the x pass, so time the stand-alone kernel of the
@@ -424,6 +448,10 @@ def main():
                 g.calc_ref_material()
                 dts = timed_regions(lambda k: g.iterate(E, k), g.synchronize, args.steps, args.warmup, args.repeats)
                 med = statistics.median(dts)
+                if args.method == "cg":
+                    med_cg, _, _ = cg_rate(g, E, args.steps, 5, g.synchronize)
+                    out["slab_forced_cg"] = {"members": args.slab_members, "it_s": med_cg,
+                                             "ratio_to_single_gpu_cg": med_cg / res["cg"]["it_s"]}
                 out["slab_forced"] = {"members": args.slab_members, "it_s": args.steps / med, "ms_per_step": 1e3 * med / args.steps,
                                       "ratio_to_single_gpu_loop": (args.steps / med) / it_s,
                                       "transport": g.members[0].transport,
@@ -601,6 +629,11 @@ def main():
             line["config"]["parallelism"] += (" -- DRY RUN: all ranks on one GPU, " +
                                               ("exchanges staged through the host (gloo)" if args.dist_backend == "gloo"
                                                else "RCCL between them over loop-back sockets"))
+        if args.method == "cg":
+            med_cg, lo_cg, hi_cg = cg_rate(d, E, args.steps, 3, lambda: sync_all(d))
+            med_cg = 1.0 / max_over_ranks(1.0 / med_cg)
+            line.update({"metric": metric.replace("LS iterations/sec (basic scheme", "CG iterations/sec (runCGElasticity"),
+                         "basic_scheme_it_s": it_s, "value": med_cg, "ms_per_step": 1e3 / med_cg})
         d.close()
         timer.cancel()
         if args.also_slab:

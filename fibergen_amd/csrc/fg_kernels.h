@@ -96,7 +96,8 @@ void launch_u_stress(const Grid& g, const StressParams& sp, const FieldPtrs<3>& 
 void launch_cgu_dot(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldPtrs<3>& b, const Vec6& E, double* partial,
                     double* out7, hipStream_t s);
 void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r,
-                     const FieldPtrs<3>& w, const double* sc, int i_num, int i_den, double nvox, double small, hipStream_t s);
+                     const FieldPtrs<3>& w, const double* sc, int i_num, int i_den, double nvox, double small, hipStream_t s,
+                     long count = 0 /* doubles per component to update; 0 = g.n (x-slabs: + the spare planes) */);
 // interface voxels (some phase fraction strictly between 0 and 1): allocates and fills the list of their element
 // offsets in voxel order (*list, hipFree by the caller), returns the count
 unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned** list, hipStream_t s);

@@ -690,8 +690,9 @@ struct StrainPair {
 // staggered symmetric gradient of u at the pair p (epsOperatorStaggered  F:18632-18686 without E)
 __device__ __forceinline__ StrainPair grad_s_pair(const Grid& g, const FieldPtrs<3>& u, const PairPos& p, bool second) {
   const double hx = g.hx, hy = g.hy, hz = g.hz;
-  const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
-  const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+  // x neighbours through Grid::xw_lo / xw_hi: periodic in a whole grid, the spare planes of the neighbours in an x-slab
+  const long xf = (p.i + 1 == g.nx ? (long)(g.nx - g.xw_hi) - p.i : 1L) * g.nyzp;
+  const long xb = (p.i == 0 ? (long)(g.xw_lo - 1) : -1L) * g.nyzp;
   const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
   const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
   const long rowoff = p.off - p.k;
@@ -1432,8 +1433,9 @@ void launch_cgu_dot(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldP
 }
 
 void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r,
-                     const FieldPtrs<3>& w, const double* sc, int i_num, int i_den, double nvox, double small, hipStream_t s) {
-  const long n2 = g.n / 2;
+                     const FieldPtrs<3>& w, const double* sc, int i_num, int i_den, double nvox, double small, hipStream_t s,
+                     long count) {
+  const long n2 = (count > 0 ? count : g.n) / 2;
   const dim3 grid(grid_for(n2, 1 << 16));
   if (mode == 0) hipLaunchKernelGGL((k_cgu_axpy<0>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, sc, i_num, i_den, nvox, small);
   else hipLaunchKernelGGL((k_cgu_axpy<1>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, sc, i_num, i_den, nvox, small);

@@ -272,7 +272,8 @@ void Solver::slab_moduli_step() {
 }
 
 // u_k (with the +-1 planes of the neighbours) -> all-reduced sums of squares of eps_k (, sums of tau), f_{k+1} in fu_
-void Solver::slab_front_fast(const double* E6, bool sum_tau) {
+void Solver::slab_front_fast(const double* E6, bool sum_tau, const double* u_src, bool reduce) {
+  double* u_in = u_src ? const_cast<double*>(u_src) : su_[su_cur_];
   comm_wait(kXHaloU);
   comm_wait(kXModuli);
   comm_wait(kXSums);
@@ -288,21 +289,21 @@ void Solver::slab_front_fast(const double* E6, bool sum_tau) {
     // k_interface_strain).  d of the slab's two boundary planes also enters the divergence on the neighbouring slabs: it
     // travels as dense planes (the polarisation halo of the strain-state pipeline) while the sweep runs.
     build_laminate_lists();
-    launch_interface_delta(gu_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), strided3(su_[su_cur_], ucs_), E, mixed_list_, mixed_n_,
+    launch_interface_delta(gu_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), strided3(u_in, ucs_), E, mixed_list_, mixed_n_,
                            lam_epsc_, lam_phic_, lam_nrmc_, dtau_, derr_, stream_);
     launch_delta_pack(g_, mixed_list_, mixed_n_, dtau_, halo_[0], halo_[1], stream_);
     slab_exchange(FG_PLAN_HALO_TAU, 0, kXHaloTau);
   }
   const PhaseTable pt2 = phase_table();
-  launch_u_tile(gu_, opt_.mu_0, opt_.lambda_0, strided3(su_[su_cur_], ucs_), mod, ptrs3(fu_), E, partial_, dscal_ + kSlotSumSq,
+  launch_u_tile(gu_, opt_.mu_0, opt_.lambda_0, strided3(u_in, ucs_), mod, ptrs3(fu_), E, partial_, dscal_ + kSlotSumSq,
                 opt_.u_tile, stream_, sum_tau, slab_phi_ ? &pt2 : nullptr);
   if (laminate) return;   // slab_front_laminate (next step: the planes of the neighbours have to be posted first)
   time_end(0);
-  slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
+  if (reduce) slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
 }
 
 // second step of the sweep with laminate mixing: div d of the own interface voxels and of the neighbours' boundary planes
-void Solver::slab_front_laminate(bool sum_tau) {
+void Solver::slab_front_laminate(bool sum_tau, bool reduce) {
   if (opt_.mixing != kMixLaminate) return;
   launch_delta_div(g_, aff_list_, aff_slots_, aff_n_, dtau_, ptrs3(fu_), stream_);
   comm_wait(kXHaloTau);
@@ -312,7 +313,14 @@ void Solver::slab_front_laminate(bool sum_tau) {
     launch_add_small(dscal_ + kSlotMean, dscal_ + kSlotScratch, 6, stream_);
   }
   time_end(0);
-  slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
+  if (reduce) slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
+}
+
+void Solver::slab_cg_alloc() {
+  if (scg_) return;
+  FG_HIP_CHECK(hipSetDevice(device_));
+  FG_HIP_CHECK(hipMalloc(&scg_, 6 * (size_t)ucs_ * sizeof(double)));
+  FG_HIP_CHECK(hipMemsetAsync(scg_, 0, 6 * (size_t)ucs_ * sizeof(double), stream_));
 }
 
 // The transform chain of one pass, cut into steps that each end in one exchange (k = 1..9):
@@ -497,13 +505,13 @@ void Solver::slab_reset_state() {
 void SlabGroup::check_members() const {
   if (m_.empty()) throw std::runtime_error("empty slab group");
   const Solver& a = *m_[0];
-  if (a.opt_.mode != 0 || a.opt_.gamma_scheme != 0 || a.opt_.method != 0)
-    throw std::runtime_error("slab-decomposed solvers run the basic scheme of the elasticity mode with the staggered Green operator");
+  if (a.opt_.mode != 0 || a.opt_.gamma_scheme != 0)
+    throw std::runtime_error("slab-decomposed solvers run the elasticity mode with the staggered Green operator");
   if (a.pt_.n < 1) throw std::runtime_error("No materials specified");
   for (Solver* s : m_) {
     if (s->nranks_ > 1 && !s->comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
     if (s->opt_.mixing != a.opt_.mixing || s->pt_.n != a.pt_.n || s->opt_.u_loop != a.opt_.u_loop || s->opt_.u_tile != a.opt_.u_tile ||
-        s->opt_.slab_split != a.opt_.slab_split || s->opt_.slab_interleave != a.opt_.slab_interleave)
+        s->opt_.slab_split != a.opt_.slab_split || s->opt_.slab_interleave != a.opt_.slab_interleave || s->opt_.method != a.opt_.method)
       throw std::runtime_error("the members of a slab group must carry the same options and materials");
   }
 }
@@ -566,6 +574,15 @@ void SlabGroup::reduce_and_fetch(int slot, int n, bool min_op) {
   }
   wait_norms();
   for (Solver* s : m_) s->comm_wait(kXSums);   // later writes of dscal_ on the compute stream follow the reduction
+}
+
+bool SlabGroup::agree_on_voting() {
+  if (m_[0]->nranks_ == 1) return false;
+  double v[2] = {0.0, 0.0};
+  for (Solver* s : m_)
+    if (s->cb_) v[0] = 1.0;
+  vote(v);
+  return v[0] != 0.0;
 }
 
 // Sum over all ranks of two small host values (votes: a callback asked to stop, a rank was cancelled).
@@ -739,6 +756,7 @@ void SlabGroup::iterate(const double* E6, int n) {
 bool SlabGroup::run(const double* E6, const double* S6) {
   check_members();
   Solver& a = *m_[0];
+  if (a.opt_.method == 1) return run_cg(E6, S6);
   double E0[6], S0[6];
   for (int i = 0; i < 6; ++i) {
     E0[i] = E6[i];
@@ -775,14 +793,7 @@ bool SlabGroup::run(const double* E6, const double* S6) {
   // callbacks' answers before the transform chain of the next pass is enqueued (no speculation: a vote behind the
   // speculative exchanges would wait for them).  Without callbacks only fg_cancel can ask for a stop from outside; it
   // travels with the flag word of the next pass's reduction.
-  bool voting = false;
-  if (a.nranks_ > 1) {
-    double v[2] = {0.0, 0.0};
-    for (Solver* s : m_)
-      if (s->cb_) v[0] = 1.0;
-    vote(v);
-    voting = v[0] != 0.0;
-  }
+  const bool voting = agree_on_voting();
 
   double prev = 0.0;   // EpsilonErrorEstimator  F:14591-14637: norms of the zero field at construction
   long iter = 1;
@@ -882,6 +893,186 @@ bool SlabGroup::run(const double* E6, const double* S6) {
     s->in_run_ = false;
     s->iterations_ = iter;
     if (s->su_valid_ && s->eps_stale_) s->slab_materialise_eps();
+  }
+  synchronize();
+  const double dt = now_seconds() - t_start;
+  for (Solver* s : m_) s->solve_time_ += dt;
+  return failed;
+}
+
+// runCGElasticity  F:23153-23247 on the slabs, carried in displacement space like Solver::run_cg_u (eps = E + grad_s u_e;
+// r, p, w = grad_s u_r, u_p, u_w).  u_e = su_[cur], u_w = su_[cur ^ 1] (where the transform chain leaves its result, halo
+// planes exchanged), u_r / u_p = scg_.  The vector updates are point-wise and linear with coefficients every rank forms
+// from the same all-reduced sums, so applying them to the spare planes as well keeps the halo planes of u_e, u_r and u_p
+// valid without any further exchange: per iteration the only traffic beyond the operator's own (two all-to-alls, halo of
+// u_w) are two all-reduces, p:(p - w) and the seven sums of the stop rule (norms of eps, r:r) -- innerProductL2
+// F:20955-21038 with the partial sums of the slabs added in rank order by the transport.
+bool SlabGroup::run_cg(const double* E6, const double* S6) {
+  Solver& a = *m_[0];
+  double E0[6], S0[6];
+  for (int i = 0; i < 6; ++i) {
+    E0[i] = E6[i];
+    S0[i] = S6 ? S6[i] : 0.0;
+  }
+  for (Solver* s : m_) {
+    FG_HIP_CHECK(hipSetDevice(s->device_));
+    s->slab_reset_state();
+    s->recompute_bc();
+  }
+  if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_MQ_) < kEps) || !fast_ok(false))
+    throw std::runtime_error("method=cg on slab-decomposed solvers runs in displacement space: prescribed mean strains, Voigt or "
+                             "laminate mixing, u_loop=2 and a grid the tiled sweep fits");
+  const double t_start = now_seconds();
+  prepare();
+  if (a.opt_.update_ref) {
+    calc_ref_material();
+    prepare();
+  }
+  const bool voting = agree_on_voting();
+  const bool residual_est = a.opt_.error_estimator == 1;
+  const double small = std::numeric_limits<double>::min();
+  const double nglobal = (double)a.nglobal_;
+  const int blk[2] = {kSlotCg, kSlotCg + 8}, s0 = kSlotCg + 16;
+  Vec6 E, Z;
+  for (int i = 0; i < 6; ++i) E.v[i] = E0[i], Z.v[i] = 0.0;
+
+  auto u_e = [](Solver* s) { return s->su_[s->su_cur_]; };
+  auto u_w = [](Solver* s) { return s->su_[s->su_cur_ ^ 1]; };
+  auto u_r = [](Solver* s) { return s->scg_; };
+  auto u_p = [](Solver* s) { return s->scg_ + 3 * s->ucs_; };
+  // u_w = operator(u_in) with prescribed mean Eadd: sweep + transform chain; the halo planes of u_w are on their way
+  auto apply = [&](bool from_p, const double* Eadd) {
+    for (Solver* s : m_) s->slab_front_fast(Eadd, false, from_p ? u_p(s) : u_e(s), false);
+    for (Solver* s : m_) s->slab_front_laminate(false, false);
+    pass_fast_chain();
+  };
+  auto fetch7 = [&](int slot) {
+    for (Solver* s : m_) {
+      FG_HIP_CHECK(hipMemcpyAsync(s->hscal_ + kSlotCg, s->dscal_ + slot, 7 * sizeof(double), hipMemcpyDeviceToHost, s->comm_stream_));
+      FG_HIP_CHECK(hipMemcpyAsync(s->hscal_ + kSlotFlag, s->dscal_ + kSlotFlag, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                                  s->comm_stream_));
+      FG_HIP_CHECK(hipMemcpyAsync(s->herr_, s->derr_, sizeof(int), hipMemcpyDeviceToHost, s->comm_stream_));
+      FG_HIP_CHECK(hipEventRecord(s->ev_norm_, s->comm_stream_));
+    }
+  };
+  auto direction_update = [&](int cur, int nxt) {   // p = r + beta p, beta = delta / gamma
+    for (Solver* s : m_) {
+      s->comm_wait(kXSums);
+      launch_cgu_axpy(1, s->gu_, strided3(u_e(s), s->ucs_), strided3(u_p(s), s->ucs_), strided3(u_r(s), s->ucs_),
+                      strided3(u_w(s), s->ucs_), s->dscal_, blk[nxt] + 6, blk[cur] + 6, nglobal, small, s->stream_, s->ucs_);
+    }
+  };
+
+  for (Solver* s : m_) {
+    s->slab_cg_alloc();
+    s->comm_wait(kXHaloU);
+    FG_HIP_CHECK(hipMemsetAsync(u_e(s), 0, 3 * (size_t)s->ucs_ * sizeof(double), s->stream_));   // eps_0 = E
+    s->su_valid_ = true;
+    s->eps_stale_ = true;
+    s->in_run_ = true;
+    for (int i = 0; i < 6; ++i) s->E_cur_[i] = E0[i];
+  }
+  apply(false, E.v);   // r = -Gamma0 (C - C0) E  (+ E - eps_0 = 0, adjustResidual F:10012-10022)
+  for (Solver* s : m_) {
+    s->comm_wait(kXHaloU);
+    const size_t f3 = 3 * (size_t)s->ucs_ * sizeof(double);
+    FG_HIP_CHECK(hipMemcpyAsync(u_r(s), u_w(s), f3, hipMemcpyDeviceToDevice, s->stream_));
+    FG_HIP_CHECK(hipMemcpyAsync(u_p(s), u_w(s), f3, hipMemcpyDeviceToDevice, s->stream_));   // p = r
+    launch_cgu_dot(1, s->gu_, strided3(u_e(s), s->ucs_), strided3(u_r(s), s->ucs_), E, s->partial_, s->dscal_ + blk[0], s->stream_);
+    s->slab_reduce(blk[0], 7, false);   // gamma_0 = r:r / N + tiny
+  }
+  double gamma_cur = 0.0, gamma_0 = 0.0;
+  if (residual_est) {
+    fetch7(blk[0]);
+    wait_norms();
+    gamma_cur = gamma_0 = a.hscal_[kSlotCg + 6] / nglobal + small;
+  }
+  double prev = 0.0;   // estimator constructed on the zeroed field the run starts from
+  long iter = 0;
+  bool failed = false, applied = false;
+  for (;;) {
+    const int cur = (int)(iter & 1), nxt = cur ^ 1;
+    if (!applied) apply(true, Z.v);   // u_w = operator(u_p)
+    applied = false;
+    for (Solver* s : m_) {
+      s->comm_wait(kXHaloU);
+      s->comm_wait(kXSums);
+      launch_cgu_dot(0, s->gu_, strided3(u_p(s), s->ucs_), strided3(u_w(s), s->ucs_), Z, s->partial_, s->dscal_ + s0, s->stream_);
+      s->slab_reduce(s0, 1, false);   // p : (p - w)
+    }
+    for (Solver* s : m_) {
+      s->comm_wait(kXSums);
+      // eps += alpha p ; r -= alpha (p - w),  alpha = gamma / (p:(p - w) / N + tiny); spare planes included
+      launch_cgu_axpy(0, s->gu_, strided3(u_e(s), s->ucs_), strided3(u_p(s), s->ucs_), strided3(u_r(s), s->ucs_),
+                      strided3(u_w(s), s->ucs_), s->dscal_, blk[cur] + 6, s0, nglobal, small, s->stream_, s->ucs_);
+      launch_cgu_dot(1, s->gu_, strided3(u_e(s), s->ucs_), strided3(u_r(s), s->ucs_), E, s->partial_, s->dscal_ + blk[nxt], s->stream_);
+      s->slab_reduce(blk[nxt], 7, false);   // norms of eps ; r : r
+    }
+    fetch7(blk[nxt]);
+    if (!voting && iter < a.opt_.maxiter) {   // the next direction and operator application, enqueued behind the copies
+      direction_update(cur, nxt);
+      apply(true, Z.v);
+      applied = true;
+    }
+    wait_norms();
+    for (Solver* s : m_) {   // state for accessors called from the callback / bc_error: eps = E + grad_s u_e
+      s->su_valid_ = true;
+      s->eps_stale_ = true;
+      for (int c = 0; c < 6; ++c) s->E_cur_[c] = E.v[c];
+    }
+    double m[6], s9 = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      const double ss = a.hscal_[kSlotCg + c];
+      for (Solver* s : m_) s->sumsq_[c] = ss;
+      m[c] = std::sqrt(ss / nglobal);
+    }
+    for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
+    for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
+    const double curn = std::sqrt(s9);
+    double abs_err = std::fabs(prev - curn);
+    double rel_err = abs_err / (small + curn);
+    prev = curn;
+    if (residual_est) {   // update_cg(gamma, gamma0)  F:14397-14401 with the gamma this iteration started from
+      abs_err = std::sqrt(gamma_cur);
+      rel_err = std::sqrt(gamma_cur / gamma_0);
+      gamma_cur = a.hscal_[kSlotCg + 6] / nglobal + small;
+    }
+    if (std::isnan(rel_err) || stop_requested()) {   // _converged  F:21177-21244, decisions on reduced values only
+      failed = true;
+      break;
+    }
+    for (Solver* s : m_) s->residuals_.push_back(rel_err);
+    bool stop = false, cancelled = false;
+    for (Solver* s : m_) {
+      if (s->cb_ && s->cb_(s->cb_user_)) stop = true;
+      if (s->cancel_) cancelled = true;
+    }
+    if (voting) {
+      double v[2] = {stop ? 1.0 : 0.0, cancelled ? 1.0 : 0.0};
+      vote(v);
+      stop = v[0] != 0.0;
+      cancelled = v[1] != 0.0;
+    }
+    if (a.nranks_ > 1 && !voting) cancelled = false;
+    if (stop) break;
+    if (cancelled) {
+      failed = true;
+      break;
+    }
+    if (iter >= a.opt_.maxiter) break;
+    if (rel_err <= a.opt_.tol || abs_err <= a.opt_.abs_tol) {
+      if (bc_error(E0, S0) <= a.opt_.bc_tol) break;
+    }
+    iter++;
+    if (!applied) direction_update(cur, nxt);
+  }
+  for (Solver* s : m_) {
+    s->in_run_ = false;
+    s->iterations_ = iter;
+    s->su_valid_ = true;
+    s->eps_stale_ = true;
+    for (int c = 0; c < 6; ++c) s->E_cur_[c] = E.v[c];
+    s->slab_materialise_eps();
   }
   synchronize();
   const double dt = now_seconds() - t_start;

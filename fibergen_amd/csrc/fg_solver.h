@@ -215,8 +215,10 @@ class Solver {
   void slab_alloc();
   bool slab_fast_ok(bool allow_mixed_bc) const;
   void slab_moduli_step();                               // effective moduli of the slab + exchange of their halo planes
-  void slab_front_fast(const double* E6, bool sum_tau);  // su_[cur] -> norms of eps_k (all-reduced), f_{k+1} in fu_
-  void slab_front_laminate(bool sum_tau);
+  // su_[cur] (or u_src) -> norms of eps_k (all-reduced unless !reduce), f_{k+1} in fu_
+  void slab_front_fast(const double* E6, bool sum_tau, const double* u_src = nullptr, bool reduce = true);
+  void slab_front_laminate(bool sum_tau, bool reduce = true);
+  void slab_cg_alloc();                                  // u_r, u_p of the displacement-space CG (with spare planes)
   void slab_fetch_norms(int n);                          // D2H of the reduced sums (+ flag word), event for the host
   void comm_time_begin();
   void comm_time_end(int category);
@@ -253,6 +255,7 @@ class Solver {
   double* su_[2] = {nullptr, nullptr};  // displacement of the slab, 3 components of ucs_ doubles (4 spare planes each)
   int su_cur_ = 0;
   bool su_valid_ = false;               // su_[su_cur_] (with valid halo planes) is the state: eps = E_cur_ + sym grad u
+  double* scg_ = nullptr;               // displacement-space CG on slabs: u_r, u_p (3 components of ucs_ doubles each)
   double* smod_ = nullptr;              // effective moduli, 2 components of ucs_ doubles
   bool smod_dirty_ = true;
   bool slab_phi_ = false;               // smod_ component 0 holds phi_1 (two complementary phases), not the moduli

@@ -190,7 +190,7 @@ void Solver::release() {
   }
   comm_.reset();
   fft_ys_.reset();
-  for (double* b : {su_[0], su_[1], smod_})
+  for (double* b : {su_[0], su_[1], smod_, scg_})
     if (b) (void)hipFree(b);
   if (ev_c2x_) (void)hipEventDestroy(ev_c2x_);
   if (ev_norm_) (void)hipEventDestroy(ev_norm_);
@@ -1553,7 +1553,7 @@ bool Solver::run_cg_scalar(const double* E0, double prev0) {
 }
 
 bool Solver::run_cg(const double* E0, const double* S0, double prev0) {
-  if (nranks_ != 1) throw std::runtime_error("method=cg is not available on slab-decomposed solvers");
+  if (nranks_ != 1) throw std::runtime_error("slab-decomposed solvers run method=cg under the slab driver (fg_slab.hip)");
   if (opt_.u_loop >= 2 && u_loop_eligible() && norm2(S0, 6) == 0.0) return run_cg_u(E0, prev0);
   const double t_start = now_seconds();
   const size_t f6 = 6 * (size_t)g_.n * sizeof(double);

@@ -367,6 +367,156 @@ void ref_component_norm(size_t N, const double* eps, double* m6) {
   for (int c = 0; c < 6; c++) m6[c] = sqrt(a[c] / (double)N);
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Scalar modes (mode = heat / porous, BASELINE config 5): 3-component gradient field g = E + grad T, one potential T.
+ * Same conventions as above; the loop nests follow the reference's traversal orders. */
+
+/* calcStress F:18134-18184 for dim 3 over VoigtMixedMaterialLaw::PK1 F:12752-12761 and
+ * ScalarLinearIsotropicMaterialLaw::PK1 F:11182-11198: S_m (+)= E_m * ((phi * alpha) * mu), phases with phi <= 10 eps
+ * skipped (F:12736); then tau += beta g, beta = -alpha 2 mu_0 (lambda_0 = 0 in these modes). */
+void ref_calc_stress_scalar(int nx, int ny, int nz, const double* g, const double* phi, int nph, const double* mu, double mu_0,
+                            double alpha, double* tau) {
+  const size_t N = (size_t)nx * ny * nz;
+  const double beta = -alpha * 2 * mu_0;
+  const double thr = 10 * 2.220446049250313e-16;
+#pragma omp parallel for schedule(dynamic) collapse(2)
+  for (int i = 0; i < nx; i++)
+    for (int j = 0; j < ny; j++)
+      for (int k = 0; k < nz; k++) {
+        const size_t o = IDX(i, j, k);
+        double F[3], P[3] = {0, 0, 0};
+        int first = 1;
+        for (int c = 0; c < 3; c++) F[c] = g[c * N + o];
+        for (int p = 0; p < nph; p++) {
+          const double ph = phi[p * N + o];
+          if (ph <= thr) continue;
+          const double am = (ph * alpha) * mu[p];
+          for (int c = 0; c < 3; c++) P[c] = first ? F[c] * am : P[c] + F[c] * am;
+          first = 0;
+        }
+        if (beta != 0)
+          for (int c = 0; c < 3; c++) P[c] += beta * F[c];
+        for (int c = 0; c < 3; c++) tau[c * N + o] = P[c];
+      }
+}
+
+/* divOperatorStaggeredHeat  F:18914-18975: backward differences accumulated into y[0] along x, then y, then z */
+void ref_div_heat(int nx, int ny, int nz, double dx, double dy, double dz, const double* x, double* y) {
+  const size_t N = (size_t)nx * ny * nz;
+  const double hx = nx / dx, hy = ny / dy, hz = nz / dz;
+  const double *x0p = x, *x1p = x + N, *x2p = x + 2 * N;
+#pragma omp parallel
+  {
+#pragma omp for schedule(static) collapse(2)
+    for (int kk = 0; kk < nz; kk++)
+      for (int jj = 0; jj < ny; jj++) {
+        double a0 = x0p[IDX(nx - 1, jj, kk)];
+        for (int ii = 0; ii < nx; ii++) {
+          const size_t k = IDX(ii, jj, kk);
+          const double a1 = x0p[k];
+          y[k] = (a1 - a0) * hx;
+          a0 = a1;
+        }
+      }
+#pragma omp for schedule(static) collapse(2)
+    for (int kk = 0; kk < nz; kk++)
+      for (int ii = 0; ii < nx; ii++) {
+        double a0 = x1p[IDX(ii, ny - 1, kk)];
+        for (int jj = 0; jj < ny; jj++) {
+          const size_t k = IDX(ii, jj, kk);
+          const double a1 = x1p[k];
+          y[k] += (a1 - a0) * hy;
+          a0 = a1;
+        }
+      }
+#pragma omp for schedule(static) collapse(2)
+    for (int jj = 0; jj < ny; jj++)
+      for (int ii = 0; ii < nx; ii++) {
+        double a0 = x2p[IDX(ii, jj, nz - 1)];
+        for (int kk = 0; kk < nz; kk++) {
+          const size_t k = IDX(ii, jj, kk);
+          const double a1 = x2p[k];
+          y[k] += (a1 - a0) * hz;
+          a0 = a1;
+        }
+      }
+  }
+}
+
+/* epsOperatorStaggeredHeat  F:18697-18760: forward differences of the potential plus E, lines walked backwards */
+void ref_eps_heat(int nx, int ny, int nz, double dx, double dy, double dz, const double* E, const double* T, double* y) {
+  const size_t N = (size_t)nx * ny * nz;
+  const double hx = nx / dx, hy = ny / dy, hz = nz / dz;
+#pragma omp parallel
+  {
+#pragma omp for nowait schedule(static) collapse(2)
+    for (int jj = 0; jj < ny; jj++)
+      for (int ii = 0; ii < nx; ii++) {
+        double a0 = T[IDX(ii, jj, 0)];
+        for (int kk = nz - 1; kk >= 0; kk--) {
+          const size_t k = IDX(ii, jj, kk);
+          const double a1 = T[k];
+          y[2 * N + k] = E[2] + (a0 - a1) * hz;
+          a0 = a1;
+        }
+      }
+#pragma omp for nowait schedule(static) collapse(2)
+    for (int kk = 0; kk < nz; kk++)
+      for (int ii = 0; ii < nx; ii++) {
+        double a0 = T[IDX(ii, 0, kk)];
+        for (int jj = ny - 1; jj >= 0; jj--) {
+          const size_t k = IDX(ii, jj, kk);
+          const double a1 = T[k];
+          y[N + k] = E[1] + (a0 - a1) * hy;
+          a0 = a1;
+        }
+      }
+#pragma omp barrier
+#pragma omp for nowait schedule(static) collapse(2)
+    for (int kk = 0; kk < nz; kk++)
+      for (int jj = 0; jj < ny; jj++) {
+        double a0 = T[IDX(0, jj, kk)];
+        for (int ii = nx - 1; ii >= 0; ii--) {
+          const size_t k = IDX(ii, jj, kk);
+          const double a1 = T[k];
+          y[k] = E[0] + (a0 - a1) * hx;
+          a0 = a1;
+        }
+      }
+  }
+}
+
+/* G0OperatorFourierStaggeredHeat + GeneralHeat  F:19758-19823: c1 = c10 / |k|^2, c10 = -alpha / (2 mu_0); th = [nx][ny][nzc]
+ * complex, in place; zero mode := 0 */
+void ref_g0_heat(int nx, int ny, int nz, double dx, double dy, double dz, double mu_0, double alpha, double _Complex* th) {
+  const int nzc = nz / 2 + 1;
+  const double c10 = -alpha / (2 * mu_0);
+  const double h0 = dx / (2 * nx), h1 = dy / (2 * ny), h2 = dz / (2 * nz);
+  const double xi0_0 = 2 * M_PI * h0 / (dx), xi1_0 = 2 * M_PI * h1 / (dy), xi2_0 = 2 * M_PI * h2 / (dz);
+  const size_t ii_half = (nx & 1) == 0 ? (size_t)(nx / 2 - 1) : (size_t)(nx / 2);
+  const size_t jj_half = (ny & 1) == 0 ? (size_t)(ny / 2 - 1) : (size_t)(ny / 2);
+  const size_t kk_half = (nz & 1) == 0 ? (size_t)(nz / 2 - 1) : (size_t)(nz / 2);
+#pragma omp parallel for schedule(static)
+  for (size_t ii = 0; ii < (size_t)nx; ii++) {
+    const double xi0 = xi0_0 * ((ii <= ii_half) ? (double)ii : ((double)ii - (double)nx));
+    const double kpm0 = sin(xi0) / h0;
+    for (size_t jj = 0; jj < (size_t)ny; jj++) {
+      const double xi1 = xi1_0 * ((jj <= jj_half) ? (double)jj : ((double)jj - (double)ny));
+      const double kpm1 = sin(xi1) / h1;
+      size_t k = (ii * ny + jj) * nzc;
+      for (size_t kk = 0; kk < (size_t)nzc; kk++) {
+        const double xi2 = xi2_0 * ((kk <= kk_half) ? (double)kk : ((double)kk - (double)nz));
+        const double kpm2 = sin(xi2) / h2;
+        const double norm_kp2 = kpm0 * kpm0 + kpm1 * kpm1 + kpm2 * kpm2;
+        const double c1 = c10 / (norm_kp2);
+        th[k] = c1 * th[k];
+        k++;
+      }
+    }
+  }
+  th[0] = 0;
+}
+
 int ref_max_threads(void);
 #ifdef _OPENMP
 #include <omp.h>

@@ -121,6 +121,66 @@ class CRef:
         return e
 
 
+class CRefScalar:
+    """One pass of basicScheme in the scalar modes (heat / porous, BASELINE config 5): GammaOperatorStaggeredHeat
+    F:20342-20351 with prescribed mean gradients -- polarisation, divOperatorStaggeredHeat, r2c + 1/N, the heat Green
+    operator, c2r, epsOperatorStaggeredHeat -- on the C loop nests (checker at 256^3, where the NumPy oracle is slow)."""
+
+    def __init__(self, n, dims, mus, phis, threads=None):
+        self.lib = load()
+        self.nx, self.ny, self.nz = n
+        self.dims = tuple(float(d) for d in dims)
+        self.N = self.nx * self.ny * self.nz
+        self.mu = np.ascontiguousarray(mus, dtype=np.float64)
+        self.phi = np.ascontiguousarray(np.stack(phis), dtype=np.float64)
+        self.threads = threads or self.lib.ref_max_threads()
+        self.lib.ref_set_threads(int(self.threads))
+
+    def basic_scheme(self, E, g, mu_0):
+        d = ctypes.c_double
+        lib = self.lib
+        n3 = (self.nx, self.ny, self.nz)
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        tau = np.empty_like(g)
+        lib.ref_calc_stress_scalar(*n3, _P(g), _P(self.phi), len(self.mu), _P(self.mu), d(mu_0), d(1.0), _P(tau))
+        f = np.empty(n3)
+        lib.ref_div_heat(*n3, *map(d, self.dims), _P(tau), _P(f))
+        th = scipy.fft.rfftn(f, workers=self.threads)                      # fftVector(., 1)  F:18481-18510
+        v = th.view(np.float64)
+        lib.ref_scale(ctypes.c_size_t(v.size), d(1 / float(self.N)), _P(v))
+        lib.ref_g0_heat(*n3, *map(d, self.dims), d(mu_0), d(-1.0), th.ctypes.data_as(ctypes.c_void_p))
+        T = np.ascontiguousarray(scipy.fft.irfftn(th, s=n3, workers=self.threads, norm="forward"))
+        out = np.empty_like(g)
+        lib.ref_eps_heat(*n3, *map(d, self.dims), _P(E), _P(T), _P(out))
+        return out
+
+
+class CRefViscosity(CRef):
+    """One pass of basicScheme in mode = viscosity on the C loop nests: DeltaOperatorStaggered F:20422-20460 composed of
+    the elasticity routines (the law ScalarLinearIsotropicMaterialLaw(6) with mu / 2, F:15234-15239, is S = E * (alpha mu / 2):
+    Hooke with (mu / 4, 0) performs the same multiplications, scalings by powers of two being exact)."""
+
+    def __init__(self, n, dims, mus, phis, threads=None):
+        super().__init__(n, dims, [(0.25 * m, 0.0) for m in mus], phis, None, "voigt", threads)
+
+    def basic_scheme(self, E, eps, mu_0, lambda_0=0.0):
+        alpha = -1.0
+        m = 1 / (4 * mu_0)
+        tau = self.calc_stress(mu_0, lambda_0, eps)
+        adj = np.asarray(E, dtype=np.float64) - 2 * alpha * m * (tau.reshape(6, -1).sum(axis=1) / self.N)
+        f = self.div(tau)
+        fh = scipy.fft.rfftn(f, axes=(1, 2, 3), workers=self.threads)
+        v = fh.view(np.float64)
+        self.lib.ref_scale(ctypes.c_size_t(v.size), self._d(1 / float(self.N)), _P(v))
+        fh = self.g0(-1.0 / (4 * m), float("inf"), fh, alpha)               # lambda_0 = inf: c20 = c10  F:19749-19755
+        u = np.ascontiguousarray(scipy.fft.irfftn(fh, s=(self.nx, self.ny, self.nz), axes=(1, 2, 3), workers=self.threads,
+                                                  norm="forward"))
+        eta = self.eps_op(adj, u)
+        eta += (2 * alpha * m) * tau                                         # eta.xpay(eta, 2 alpha m, tau_copy)
+        return eta
+
+
 class CRefLoop:
     """The loop of basicScheme as the reference runs it: ONE strain field that every routine works on in place
     (tau aliases epsilon, F:15153-15155, F:20558-20578), buffers allocated once, `threads` OpenMP threads

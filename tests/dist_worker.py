@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--mixed-bc", type=int, default=0)
     ap.add_argument("--split", type=int, default=-1)
+    ap.add_argument("--method", default="basic")
     ap.add_argument("--out", required=True)
     ap.add_argument("--stop-rank", type=int, default=-1, help="only this rank installs a convergence callback ...")
     ap.add_argument("--stop-iter", type=int, default=0, help="... which asks to stop in this iteration")
@@ -190,7 +191,7 @@ def main():
     for p in range(nph):
         s.set_phase(p, mats[p][0], mats[p][1], s.slab(phis[p]))
     s.set_normals(s.slab(normals))
-    s.set_options(mixing_rule=a.mixing, tol=a.tol, slab_split=a.split)
+    s.set_options(mixing_rule=a.mixing, tol=a.tol, slab_split=a.split, method=a.method)
     E = np.array([1.0, 0, 0, 0, 0, 0.5])
     S = None
     if a.mixed_bc:

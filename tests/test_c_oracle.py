@@ -35,3 +35,42 @@ def test_c_stages_equal_numpy_oracle(grid, dims, mixing):
     e1 = c.basic_scheme(E, eps, o.mu_0, o.lambda_0)
     e2 = o.basic_scheme(E, eps)
     assert rel_err(e1, e2) < 1e-12
+
+
+@pytest.mark.parametrize("grid,dims", GRIDS[:3])
+def test_c_scalar_and_viscosity_passes_equal_numpy_oracles(grid, dims):
+    """config 5's checkers at 256^3 (tests/test_gpu_fullsize_oracle.py) are the C loop nests; here they are held against
+    the NumPy restatements of the same routines (oracle/scalar_oracle.py, oracle/viscosity_oracle.py)."""
+    from oracle.c_oracle import CRefScalar, CRefViscosity
+    from oracle.scalar_oracle import ScalarOracle
+    from oracle.viscosity_oracle import ViscosityOracle
+    rng = np.random.default_rng(11)
+    _, phis, _ = two_phase_setup(grid)
+    mus = [1.0, 10.0]
+    so = ScalarOracle(*grid, mus=mus, phis=phis, dx=dims[0], dy=dims[1], dz=dims[2])
+    so.calc_ref_material()
+    cs = CRefScalar(grid, dims, mus, phis, threads=2)
+    g = rng.standard_normal((3,) + grid)
+    E3 = np.array([0.3, -0.2, 0.1])
+    assert rel_err(cs.basic_scheme(E3, g, so.mu_0), so.basic_scheme(E3, g)) < 1e-12
+    tau = np.empty_like(g)
+    import ctypes
+    from oracle.c_oracle import _P
+    cs.lib.ref_calc_stress_scalar(*grid, _P(g), _P(cs.phi), 2, _P(cs.mu), ctypes.c_double(0.7), ctypes.c_double(1.0), _P(tau))
+    assert np.array_equal(tau, so.calc_stress(0.7, g))
+    f = np.empty(grid)
+    cs.lib.ref_div_heat(*grid, *map(ctypes.c_double, dims), _P(tau), _P(f))
+    assert np.array_equal(f, so.div_heat(tau))
+    out = np.empty_like(g)
+    T = rng.standard_normal(grid)
+    cs.lib.ref_eps_heat(*grid, *map(ctypes.c_double, dims), _P(E3), _P(T), _P(out))
+    assert np.array_equal(out, so.eps_heat(E3, T))
+
+    vmus = [1.0, 0.1]
+    vo = ViscosityOracle(*grid, *dims, mats=[(m, 0.0) for m in vmus], phis=phis)
+    vo.calc_ref_material()
+    cv = CRefViscosity(grid, dims, vmus, phis, threads=2)
+    eps = rng.standard_normal((6,) + grid)
+    E6 = np.array([1.0, -1.0, 0.0, 0.2, -0.1, 0.3])
+    assert np.array_equal(cv.calc_stress(vo.mu_0, 0.0, eps), vo.calc_stress(vo.mu_0, vo.lambda_0, eps))
+    assert rel_err(cv.basic_scheme(E6, eps, vo.mu_0), vo.basic_scheme(E6, eps)) < 1e-12

@@ -169,3 +169,24 @@ def test_lone_slab_on_rccl_transport(loopback):
     if p.returncode != 0 and "FG_RCCL_INIT_FAILED" in p.stderr:
         pytest.skip("RCCL cannot be initialised here: " + p.stderr.strip().splitlines()[-1][:200])
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.parametrize("transport", ["callback", "rccl"])
+@pytest.mark.parametrize("nproc,grid,mixing,split", [(2, "8,16,128", "voigt", 0), (2, "8,16,128", "laminate", 1),
+                                                     (4, "16,16,128", "laminate", 0)])
+def test_cg_on_slabs_one_rank_per_process(tmp_path, transport, nproc, grid, mixing, split):
+    """method = cg over the ranks: the inner products are all-reduced on the device, iteration counts and residual
+    histories equal the oracle's CG on every rank"""
+    g = tuple(int(v) for v in grid.split(","))
+    args = ("--backend", "hip", "--grid", grid, "--mixing", mixing, "--dims", "1,2,1.5", "--split", str(split), "--method", "cg",
+            "--tol", "1e-9")
+    res = launch_rccl(nproc, str(tmp_path / "g"), *args) if transport == "rccl" else launch(nproc, str(tmp_path / "g"), *args)
+    o = make_oracle(g, (1.0, 2.0, 1.5), mixing, tol=1e-9)
+    assert o.run_cg([1.0, 0, 0, 0, 0, 0.5]) is False
+    eps = np.concatenate([r["eps"] for r in res], axis=1)
+    assert all(int(r["iterations"]) == o.iterations for r in res)
+    assert rel_err(eps, o.eps) < 1e-8
+    for r in res:
+        assert np.array_equal(r["residuals"], res[0]["residuals"])
+        assert np.abs(r["residuals"] - np.array(o.residuals)).max() < 1e-9
+        assert rel_err(r["mean_stress"], o.mean_stress()) < 1e-9

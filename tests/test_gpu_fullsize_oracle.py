@@ -123,3 +123,63 @@ def test_config2_converged_run_128(mixing):
     assert rel_err(s.get_field("epsilon"), eps) < 1e-9
     assert rel_err(s.mean_stress(), c.mean_stress(eps)) < 1e-9       # the Ceff column of this load case
     s.close()
+
+
+# ---- BASELINE config 5 at its size: 256^3 porous (scalar mode) and viscosity (dual Stokes scheme) on the benchmark RVE,
+#      three passes from a non-trivial field against the C loop nests (oracle/c: CRefScalar, CRefViscosity)
+def _threads():
+    import os
+    return min(16, os.cpu_count() or 1)
+
+
+def test_config5_porous_256_three_passes():
+    from fibergen_amd import LSSolver
+    from fibergen_amd.rve import bench_rve
+    from oracle.c_oracle import CRefScalar
+    n = 256
+    phi, _, _ = bench_rve(n, "voigt")
+    mus, phis = [1.0, 10.0], [1.0 - phi, phi]      # bench.py's porous materials
+    E = np.array([1.0, 0.0, 0.0])
+    s = LSSolver(n, n, n)
+    s.set_options(mode="porous")
+    s.set_num_phases(2)
+    for p in range(2):
+        s.set_phase(p, mus[p], 0.0, phis[p])
+    mu_0, _ = s.calc_ref_material()
+    g0 = _start_field(n, phi)[:3].copy()
+    s.set_field("epsilon", g0)
+    s.iterate(E, 3)
+    got = s.get_field("epsilon")
+    s.close()
+    c = CRefScalar((n, n, n), DIMS, mus, phis, threads=_threads())
+    g = g0
+    for _ in range(3):
+        g = c.basic_scheme(E, g, mu_0)
+    assert rel_err(got, g) < 1e-11
+
+
+def test_config5_viscosity_256_three_passes():
+    from fibergen_amd import LSSolver
+    from fibergen_amd.rve import bench_rve
+    from oracle.c_oracle import CRefViscosity
+    n = 256
+    phi, _, _ = bench_rve(n, "voigt")
+    mus, phis = [1.0, 0.1], [1.0 - phi, phi]       # bench.py's fluid with ten times more viscous particles
+    E = np.array([1.0, -1.0, 0.0, 0.0, 0.0, 0.0])   # traceless prescribed stress (F:26257-26261)
+    s = LSSolver(n, n, n)
+    s.set_options(mode="viscosity")
+    s.set_num_phases(2)
+    for p in range(2):
+        s.set_phase(p, mus[p], 0.0, phis[p])
+    mu_0, lam_0 = s.calc_ref_material()
+    e0 = _start_field(n, phi)
+    e0[:3] -= e0[:3].mean(axis=0)                  # the field of this mode is a traceless stress
+    s.set_field("epsilon", e0)
+    s.iterate(E, 3)
+    got = s.get_field("epsilon")
+    s.close()
+    c = CRefViscosity((n, n, n), DIMS, mus, phis, threads=_threads())
+    eps = e0
+    for _ in range(3):
+        eps = c.basic_scheme(E, eps, mu_0, lam_0)
+    assert rel_err(got, eps) < 1e-11

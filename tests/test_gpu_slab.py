@@ -257,3 +257,48 @@ def test_eight_slabs_at_baseline_size_equal_single_gpu_solver(n, mixing, passes,
     assert got["slabs"][2] == got["single"][2]
     assert rel_err(got["slabs"][0], got["single"][0]) < 1e-11
     assert rel_err(got["slabs"][1], got["single"][1]) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# method = cg (runCGElasticity F:23153-23247, the reference's default) on the slabs, in displacement space
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("P,grid,mixing", [c for c in FAST if c[1] != (8, 16, 124)])
+def test_group_cg_matches_oracle(P, grid, mixing, residual):
+    dims = (1.0, 2.0, 1.5)
+    kw = dict(error_estimator="residual") if residual else {}
+    g = make_group(P, grid, dims, mixing, tol=1e-9, method="cg", **kw)
+    o = make_oracle(grid, dims, mixing, tol=1e-9, **kw)
+    assert o.run_cg(E_LOAD) is False
+    assert g.run(E_LOAD) is False
+    assert g.iterations == o.iterations and len(g.residuals) == len(o.residuals)
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-9
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8
+    assert rel_err(g.mean_stress(), o.mean_stress()) < 1e-9
+    assert rel_err(g.mean_strain(), E_LOAD) < 1e-12
+    for m in g.members:
+        assert m.residuals == g.members[0].residuals and m.iterations == g.iterations
+    g.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_group_cg_equals_single_gpu_cg(P, mixing):
+    grid = (64, 64, 128)
+    s = make_gpu_solver(grid, mixing=mixing, tol=1e-8, method="cg")
+    g = make_group(P, grid, mixing=mixing, tol=1e-8, method="cg")
+    seen = []
+    g.set_convergence_callback(lambda: seen.append(g.mean_stress().copy()) and False)   # accessors inside the callback: current iterate
+    assert s.run(E_LOAD) is False and g.run(E_LOAD) is False
+    assert g.iterations == s.iterations and len(seen) == len(g.residuals)
+    assert np.abs(np.array(g.residuals) - np.array(s.residuals)).max() < 1e-11
+    assert rel_err(g.get_field("epsilon"), s.get_field("epsilon")) < 1e-10
+    assert rel_err(g.mean_stress(), s.mean_stress()) < 1e-11 and rel_err(seen[-1], s.mean_stress()) < 1e-11
+    s.close()
+    g.close()
+
+
+def test_group_cg_refuses_what_it_does_not_cover():
+    g = make_group(2, (16, 16, 16), method="cg")     # a grid the tiled sweep does not fit
+    with pytest.raises(RuntimeError, match="displacement space"):
+        g.run(E_LOAD)
+    g.close()

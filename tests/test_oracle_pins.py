@@ -488,3 +488,142 @@ def test_viscosity_nunan_keller_lattice_of_rigid_spheres(V, n):
     alpha, beta = 1 / (2 * rate_axial) - 1, 1 / (2 * rate_shear) - 1
     assert alpha == pytest.approx(NUNAN_KELLER[V][0], rel=0.04)
     assert beta == pytest.approx(NUNAN_KELLER[V][1], rel=0.02)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: the laminate rule at OBLIQUE normals and the mixed-BC projector tied to the one closed form the reference holds
+# for laminates, calc_isotropic_laminate F:26412-26446 (Milton, eq. 9.9, layers stacked along x).
+def _reference_laminate_formula(layers):
+    """calc_isotropic_laminate F:26412-26446 restated line by line: sums c1..c6 over the layers (phi, mu, lambda), then
+    C1111 = 1/c1, C1212 = C1313 = 1/c2, C2323 = c3, C1122 = C1133 = c4/c1, C2222 = C3333 = c5 + c4^2/c1, C2233 = c6 + c4^2/c1."""
+    c1 = c2 = c3 = c4 = c5 = c6 = 0.0
+    for phi, mu, lam in layers:
+        c1 += phi / (lam + 2 * mu)
+        c2 += phi / mu
+        c3 += phi * mu
+        c4 += phi * lam / (lam + 2 * mu)
+        c5 += phi * 4 * mu * (lam + mu) / (lam + 2 * mu)
+        c6 += phi * 2 * mu * lam / (lam + 2 * mu)
+    C = np.zeros((6, 6))
+    C[0, 0] = 1 / c1
+    C[1, 1] = C[2, 2] = c5 + c4 * c4 / c1
+    C[3, 3] = c3
+    C[4, 4] = C[5, 5] = 1 / c2
+    C[0, 1] = C[1, 0] = C[0, 2] = C[2, 0] = c4 / c1
+    C[1, 2] = C[2, 1] = c6 + c4 * c4 / c1
+    return C
+
+
+_IDX = [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]   # component order 11,22,33,23,13,12
+
+
+def _to_matrix(v):
+    m = np.zeros((3, 3))
+    for c, (i, j) in enumerate(_IDX):
+        m[i, j] = m[j, i] = v[c]
+    return m
+
+
+def _to_vector(m):
+    return np.array([m[i, j] for i, j in _IDX])
+
+
+def _apply_stiffness(C, e):
+    """sigma = C : eps for plain tensor components (shear strains enter twice, F:536, F:563-575)"""
+    w = np.array([1, 1, 1, 2, 2, 2.0])
+    return C @ (w * e)
+
+
+def _rotation_taking_ex_to(n):
+    n = np.asarray(n, dtype=np.float64) / np.linalg.norm(n)
+    t = np.array([0.0, 0.0, 1.0]) if abs(n[2]) < 0.9 else np.array([0.0, 1.0, 0.0])
+    b = np.cross(n, t)
+    b /= np.linalg.norm(b)
+    return np.stack([n, b, np.cross(n, b)], axis=1)    # columns: images of e_x, e_y, e_z; det = +1
+
+
+def test_reference_laminate_formula_equals_the_independent_one():
+    layers = [(0.2, 35.7, 142.9), (0.3, 10.0, 10.0), (0.5, 19.2, 28.8)]
+    assert np.abs(_reference_laminate_formula(layers) - isotropic_laminate_ceff(layers)).max() < 1e-12 * 200
+
+
+def test_laminate_rule_with_x_normal_is_the_reference_closed_form():
+    """Row L at n = e_x: for two linear phases the one-step solve of solve_newton (F:13157-13371) is exact, so the voxel's
+    response c1 P1(eps1) + c2 P2(eps2) is the two-layer laminate stiffness of F:26412-26446 applied to the mean strain."""
+    from oracle.ls_oracle import pk1_laminate
+    rng = np.random.default_rng(5)
+    m1, m2 = material_from_pair(E=100.0, nu=0.4), material_from_pair(E=25.0, nu=0.25)
+    mats = [(m1["mu"], m1["lambda"]), (m2["mu"], m2["lambda"])]
+    for _ in range(20):
+        c1 = float(rng.uniform(0.05, 0.95))
+        e = rng.standard_normal(6)
+        shape = (1, 1, 1)
+        P = pk1_laminate(e.reshape(6, 1, 1, 1) * np.ones(shape), [np.full(shape, c1), np.full(shape, 1 - c1)], mats,
+                         np.array([1.0, 0, 0]).reshape(3, 1, 1, 1) * np.ones(shape))[:, 0, 0, 0]
+        C = _reference_laminate_formula([(c1, *mats[0]), (1 - c1, *mats[1])])
+        assert np.abs(P - _apply_stiffness(C, e)).max() < 1e-11 * np.abs(P).max()
+
+
+def test_laminate_rule_at_oblique_normals_is_the_rotated_closed_form():
+    """Row L at any normal n = R e_x: P(eps, n) = R [C_lam : (R^T eps R)] R^T with C_lam from F:26412-26446 -- isotropic
+    phases, so rotating the frame rotates nothing but the normal.  This is the reference-held answer for oblique normals
+    (the demos only ever use n = e_x); it also shows covariance P(R eps R^T, R n) = R P(eps, n) R^T."""
+    from oracle.ls_oracle import pk1_laminate
+    rng = np.random.default_rng(6)
+    m1, m2 = material_from_pair(E=1.0, nu=0.3), material_from_pair(E=10.0, nu=0.2)
+    mats = [(m1["mu"], m1["lambda"]), (m2["mu"], m2["lambda"])]
+    nv = 64
+    shape = (nv, 1, 1)
+    n = rng.standard_normal((3, nv))
+    n /= np.linalg.norm(n, axis=0)
+    c1 = rng.uniform(0.02, 0.98, nv)
+    e = rng.standard_normal((6, nv))
+    P = pk1_laminate(e.reshape(6, nv, 1, 1), [c1.reshape(shape), (1 - c1).reshape(shape)], mats, n.reshape(3, nv, 1, 1))[:, :, 0, 0]
+    for v in range(nv):
+        R = _rotation_taking_ex_to(n[:, v])
+        C = _reference_laminate_formula([(c1[v], *mats[0]), (1 - c1[v], *mats[1])])
+        want = _to_vector(R @ _to_matrix(_apply_stiffness(C, _to_vector(R.T @ _to_matrix(e[:, v]) @ R))) @ R.T)
+        assert np.abs(P[:, v] - want).max() < 1e-11 * np.abs(want).max()
+    # covariance under an arbitrary rotation of strain and normal together
+    Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] = -Q[:, 0]
+    e2 = np.stack([_to_vector(Q @ _to_matrix(e[:, v]) @ Q.T) for v in range(nv)], axis=1)
+    P2 = pk1_laminate(e2.reshape(6, nv, 1, 1), [c1.reshape(shape), (1 - c1).reshape(shape)], mats, (Q @ n).reshape(3, nv, 1, 1))[:, :, 0, 0]
+    for v in range(nv):
+        assert np.abs(P2[:, v] - _to_vector(Q @ _to_matrix(P[:, v]) @ Q.T)).max() < 1e-11 * np.abs(P[:, v]).max()
+
+
+def test_mixed_bc_projector_on_the_laminate_demo_closed_form():
+    """Row B (setBCProjector F:20599-20665, 9x9 pseudo-inverse; applyBCProjector F:20263-20270): the three-layer laminate of
+    demo/elasticity/laminate under prescribed mean STRESS.  Ceff of a layered medium is exact for the staggered grid, so the
+    converged mean strain must be Ceff^-1 : S with Ceff from F:26412-26446 -- for the fully stress-driven case (P = 0) and a
+    mixed one (eps_11 prescribed, the other five components stress-driven)."""
+    shape = (10, 1, 1)
+    mats = [material_from_pair(E=100.0, nu=0.4), material_from_pair(E=25.0, nu=0.25), material_from_pair(E=50.0, nu=0.3)]
+    fr = [0.2, 0.3, 0.5]
+    edges = np.round(np.cumsum([0.0] + fr) * 10).astype(int)
+    phis = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        p = np.zeros(shape)
+        p[a:b] = 1.0
+        phis.append(p)
+    C = _reference_laminate_formula([(f, m["mu"], m["lambda"]) for f, m in zip(fr, mats)])
+    w = np.array([1, 1, 1, 2, 2, 2.0])
+    Cw = C * w[None, :]                                 # sigma = Cw @ eps (plain tensor components)
+    # (a) all six stress components prescribed
+    S = np.array([1.0, 0.2, -0.3, 0.1, 0.05, -0.2])
+    o = LSOracle(*shape, mats=[(m["mu"], m["lambda"]) for m in mats], phis=phis, tol=1e-13, bc_tol=1e-10, maxiter=5000)
+    assert o.run(np.zeros(6), S0=S, P=np.zeros((6, 6))) is False
+    assert np.abs(o.eps.mean(axis=(1, 2, 3)) - np.linalg.solve(Cw, S)).max() < 1e-8 * np.abs(np.linalg.solve(Cw, S)).max()
+    assert np.abs(o.mean_stress() - S).max() < 1e-8
+    # (b) eps_11 = 0.01 prescribed, sigma_22 .. sigma_12 = 0: uniaxial strain in x with free lateral faces
+    Pm = np.zeros((6, 6))
+    Pm[0, 0] = 1.0
+    o = LSOracle(*shape, mats=[(m["mu"], m["lambda"]) for m in mats], phis=phis, tol=1e-13, bc_tol=1e-10, maxiter=5000)
+    assert o.run(np.array([0.01, 0, 0, 0, 0, 0]), S0=np.zeros(6), P=Pm) is False
+    # unknowns eps_2..6 from the five free stress rows
+    e_free = np.linalg.solve(Cw[1:, 1:], -Cw[1:, 0] * 0.01)
+    want = np.concatenate([[0.01], e_free])
+    assert np.abs(o.eps.mean(axis=(1, 2, 3)) - want).max() < 1e-8 * 0.01
+    assert abs(o.mean_stress()[0] - (Cw[0] @ want)) < 1e-8 * abs(Cw[0] @ want)
