@@ -150,8 +150,10 @@ void launch_sum1(const Grid& g, const double* x, double* partial, double* out1, 
 void launch_sc_sweep(const Grid& g, const ScalarParams& sp, const double* T, const FieldPtrs<kMaxPhases>& phi, double* f,
                      const Vec6& E, double* partial, double* sumsq6, hipStream_t s);
 // fast variant: a = per-voxel effective conductivity (launch_effective_moduli with 2 mu_p := mu_p, first array)
-void launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
-                          double* partial, double* sumsq6, hipStream_t s);
+// sumtau3 != nullptr: also the three sums of the flux polarisation (mixed boundary conditions); returns whether they were
+// produced (the LDS-tiled form does, the untiled one does not)
+bool launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
+                          double* partial, double* sumsq6, hipStream_t s, double* sumtau3 = nullptr);
 void launch_sc_grad(const Grid& g, const double* T, const FieldPtrs<3>& out, const Vec6& E, double* partial,
                     double* sumsq6, hipStream_t s);
 void launch_sc_flux(const Grid& g, const ScalarParams& sp, const FieldPtrs<3>& gr, const FieldPtrs<kMaxPhases>& phi,

@@ -807,6 +807,56 @@ __global__ __launch_bounds__(kBlock) void k_cgu_axpy(long n2, FieldPtrs<3> x, Fi
 // order does not depend on the schedule.
 constexpr int kCompactChunk = 16 * kBlock;
 
+// Order of the lists: bricks of 8 x 8 x 8 voxels (z fastest inside a brick, bricks in z, y, x order) instead of plain voxel
+// order.  An interface is a surface: in voxel order its voxels of one x plane are thousands of list entries away from their
+// x neighbours, in brick order a workgroup's 256 entries are a compact patch of the surface whose members share the rows
+// they gather from (the u gather of k_interface_strain fetched 9 separate 64-byte pieces per voxel: 580 B for 150 B of data)
+// and whose d values lie next to each other for k_delta_div.  FG_LAM_BRICK=0 restores voxel order (A/B runs).
+struct BrickWalk {
+  int nbx, nby, nbz;
+  long count;   // padded traversal length
+  int on;
+};
+inline BrickWalk brick_walk(const Grid& g) {
+  static const int env = getenv("FG_LAM_BRICK") ? atoi(getenv("FG_LAM_BRICK")) : 1;
+  BrickWalk w;
+  w.on = env;
+  w.nbx = (g.nx + 7) / 8;
+  w.nby = (g.ny + 7) / 8;
+  w.nbz = (g.nz + 7) / 8;
+  w.count = env ? (long)w.nbx * w.nby * w.nbz * 512 : (long)g.nx * g.ny * g.nz;
+  return w;
+}
+// traversal position t -> voxel (i, j, k); false: a padding position of a partial brick (or past the end)
+__device__ __forceinline__ bool walk_voxel(const BrickWalk& w, const Grid& g, long t, int* i, int* j, int* k) {
+  if (t >= w.count) return false;
+  if (!w.on) {
+    const long row = t / g.nz;
+    *k = (int)(t - row * g.nz);
+    *i = (int)(row / g.ny);
+    *j = (int)(row - (long)*i * g.ny);
+    return true;
+  }
+  const long b = t >> 9;
+  const int r = (int)(t & 511);
+  const int bk = (int)(b % w.nbz);
+  const long b2 = b / w.nbz;
+  const int bj = (int)(b2 % w.nby), bi = (int)(b2 / w.nby);
+  *i = bi * 8 + (r >> 6);
+  *j = bj * 8 + ((r >> 3) & 7);
+  *k = bk * 8 + (r & 7);
+  return *i < g.nx && *j < g.ny && *k < g.nz;
+}
+
+// Per-pass kernels over a list: chunk of 256 entries per workgroup, the chunks of one XCD contiguous in the list (blockIdx
+// round-robins over the 8 XCDs) so that neighbouring patches of the surface meet in one L2.
+__device__ __forceinline__ unsigned list_chunk() {
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  const unsigned per = (nb + 7) / 8;
+  const unsigned c = (b % 8) * per + b / 8;
+  return c;   // may be >= nb for the last XCD's tail: the caller's bounds check on the entry index covers it
+}
+
 __device__ __forceinline__ unsigned ordered_slot(bool flag, unsigned& base, unsigned* wcount) {
   const unsigned long long m = __ballot(flag);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -850,18 +900,17 @@ __global__ __launch_bounds__(kBlock) void k_scan_counts(unsigned* counts, int n)
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_mixed_list(Grid g, int nph, FieldPtrs<kMaxPhases> phi, unsigned* list,
+__global__ __launch_bounds__(kBlock) void k_mixed_list(Grid g, BrickWalk bw, int nph, FieldPtrs<kMaxPhases> phi, unsigned* list,
                                                        unsigned* counts) {
   __shared__ unsigned wcount[kBlock / 64];
-  const long nvox = (long)g.nx * g.ny * g.nz;
   unsigned base = list ? counts[blockIdx.x] : 0u;
   for (int r = 0; r < kCompactChunk / kBlock; ++r) {
     const long v = (long)blockIdx.x * kCompactChunk + r * kBlock + threadIdx.x;
     bool mixed = false;
     long off = 0;
-    if (v < nvox) {
-      const long row = v / g.nz;
-      off = row * g.nzp + (v - row * g.nz);
+    int vi, vj, vk;
+    if (walk_voxel(bw, g, v, &vi, &vj, &vk)) {
+      off = ((long)vi * g.ny + vj) * g.nzp + vk;
       for (int q = 0; q < nph; ++q) {
         const double f = phi.p[q][off];
         mixed = mixed || (f != 0.0 && f != 1.0);
@@ -905,20 +954,18 @@ __device__ __forceinline__ VoxelNeighbours voxel_neighbours(const Grid& g, int i
 }
 
 // aff == nullptr: count only.  slots: 8 ints per entry (self, xb, xf, yb, yf, zb, zf, unused).
-__global__ __launch_bounds__(kBlock) void k_affected_list(Grid g, const int* map, unsigned* aff, int* slots, unsigned* counts) {
+__global__ __launch_bounds__(kBlock) void k_affected_list(Grid g, BrickWalk bw, const int* map, unsigned* aff, int* slots,
+                                                          unsigned* counts) {
   __shared__ unsigned wcount[kBlock / 64];
-  const long nvox = (long)g.nx * g.ny * g.nz;
   unsigned base = aff ? counts[blockIdx.x] : 0u;
   for (int r = 0; r < kCompactChunk / kBlock; ++r) {
     const long v = (long)blockIdx.x * kCompactChunk + r * kBlock + threadIdx.x;
     bool any = false;
     long off = 0;
     int sl[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    if (v < nvox) {
-      const long row = v / g.nz;
-      const int k = (int)(v - row * g.nz);
-      const int i = (int)(row / g.ny), j = (int)(row - (long)i * g.ny);
-      off = row * g.nzp + k;
+    int i, j, k;
+    if (walk_voxel(bw, g, v, &i, &j, &k)) {
+      off = ((long)i * g.ny + j) * g.nzp + k;
       const VoxelNeighbours nb = voxel_neighbours(g, i, j, k);
       // x-slab (xw_hi != nx): the x neighbours of the two boundary planes live on other ranks; their part of the
       // divergence arrives as dense planes (k_delta_div_halo)
@@ -962,7 +1009,9 @@ __global__ __launch_bounds__(kBlock) void k_interface_static(Grid g, int nph, Fi
 __global__ __launch_bounds__(kBlock) void k_interface_strain(Grid g, FieldPtrs<3> u, Vec6 E, const unsigned* list, unsigned n,
                                                              double* epsc) {
   const double hx = g.hx, hy = g.hy, hz = g.hz;
-  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+  {
+    const unsigned idx = list_chunk() * kBlock + threadIdx.x;
+    if (idx >= n) return;
     const long off = list[idx];
     const long row = off / g.nzp;
     const int k = (int)(off - row * g.nzp);
@@ -982,7 +1031,9 @@ __global__ __launch_bounds__(kBlock) void k_interface_strain(Grid g, FieldPtrs<3
 template <int NPH>
 __global__ __launch_bounds__(kBlock) void k_interface_solve(StressParams sp, const double* epsc, const double* phic,
                                                             const double* nrmc, unsigned n, double* dtau, int* error_flag) {
-  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+  {
+    const unsigned idx = list_chunk() * kBlock + threadIdx.x;
+    if (idx >= n) return;
     double F[6], ph[NPH], nv[3], Pl[6], Pv[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) F[c] = epsc[(long)c * n + idx];
@@ -1001,7 +1052,9 @@ __global__ __launch_bounds__(kBlock) void k_interface_solve(StressParams sp, con
 __global__ __launch_bounds__(kBlock) void k_delta_div(Grid g, const unsigned* aff, const int* slots, unsigned n,
                                                       const double* dtau, FieldPtrs<3> f) {
   const double hx = g.hx, hy = g.hy, hz = g.hz;
-  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+  {
+    const unsigned e = list_chunk() * kBlock + threadIdx.x;
+    if (e >= n) return;
     const long off = aff[e];
     const int4 sa = reinterpret_cast<const int4*>(slots)[2 * (long)e];       // self, xb, xf, yb
     const int4 sb = reinterpret_cast<const int4*>(slots)[2 * (long)e + 1];   // yf, zb, zf, -
@@ -1443,7 +1496,12 @@ void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const Field
 }
 
 namespace {
-int compact_blocks(const Grid& g) { return (int)(((long)g.nx * g.ny * g.nz + kCompactChunk - 1) / kCompactChunk); }
+int compact_blocks(const Grid& g) { return (int)((brick_walk(g).count + kCompactChunk - 1) / kCompactChunk); }
+// one chunk of kBlock entries per workgroup, rounded up to a multiple of 8 (list_chunk deals whole runs to the XCDs)
+dim3 list_grid(unsigned n) {
+  const long nb = ((long)n + kBlock - 1) / kBlock;
+  return dim3((unsigned)(((nb + 7) / 8) * 8));
+}
 unsigned scan_counts(unsigned* counts, int nb, hipStream_t s) {
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(kBlock), 0, s, counts, nb);
   FG_HIP_CHECK(hipGetLastError());
@@ -1459,12 +1517,13 @@ unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& 
   const int nb = compact_blocks(g);
   unsigned* counts = nullptr;
   FG_HIP_CHECK(hipMalloc(&counts, ((size_t)nb + 1) * sizeof(unsigned)));
-  hipLaunchKernelGGL(k_mixed_list, dim3(nb), dim3(kBlock), 0, s, g, nph, phi, (unsigned*)nullptr, counts);
+  const BrickWalk bw = brick_walk(g);
+  hipLaunchKernelGGL(k_mixed_list, dim3(nb), dim3(kBlock), 0, s, g, bw, nph, phi, (unsigned*)nullptr, counts);
   const unsigned n = scan_counts(counts, nb, s);
   *list = nullptr;
   if (n) {
     FG_HIP_CHECK(hipMalloc(list, (size_t)n * sizeof(unsigned)));
-    hipLaunchKernelGGL(k_mixed_list, dim3(nb), dim3(kBlock), 0, s, g, nph, phi, *list, counts);
+    hipLaunchKernelGGL(k_mixed_list, dim3(nb), dim3(kBlock), 0, s, g, bw, nph, phi, *list, counts);
     FG_HIP_CHECK(hipGetLastError());
     FG_HIP_CHECK(hipStreamSynchronize(s));
   }
@@ -1481,14 +1540,15 @@ unsigned launch_affected_list(const Grid& g, const unsigned* list, unsigned n, u
   FG_HIP_CHECK(hipMalloc(&counts, ((size_t)nb + 1) * sizeof(unsigned)));
   hipLaunchKernelGGL(k_fill_int, dim3(grid_for(g.n, 1 << 16)), dim3(kBlock), 0, s, map, g.n, -1);
   if (n) hipLaunchKernelGGL(k_mixed_map, dim3(grid_for((long)n, 1 << 16)), dim3(kBlock), 0, s, list, n, map);
-  hipLaunchKernelGGL(k_affected_list, dim3(nb), dim3(kBlock), 0, s, g, map, (unsigned*)nullptr, (int*)nullptr, counts);
+  const BrickWalk bw = brick_walk(g);
+  hipLaunchKernelGGL(k_affected_list, dim3(nb), dim3(kBlock), 0, s, g, bw, map, (unsigned*)nullptr, (int*)nullptr, counts);
   const unsigned m = scan_counts(counts, nb, s);
   *aff = nullptr;
   *slots = nullptr;
   if (m) {
     FG_HIP_CHECK(hipMalloc(aff, (size_t)m * sizeof(unsigned)));
     FG_HIP_CHECK(hipMalloc(slots, (size_t)m * 8 * sizeof(int)));
-    hipLaunchKernelGGL(k_affected_list, dim3(nb), dim3(kBlock), 0, s, g, map, *aff, *slots, counts);
+    hipLaunchKernelGGL(k_affected_list, dim3(nb), dim3(kBlock), 0, s, g, bw, map, *aff, *slots, counts);
     FG_HIP_CHECK(hipGetLastError());
     FG_HIP_CHECK(hipStreamSynchronize(s));
   }
@@ -1509,7 +1569,7 @@ void launch_interface_delta(const Grid& g, const StressParams& sp, const FieldPt
                             unsigned n, double* epsc, const double* phic, const double* nrmc, double* dtau, int* error_flag,
                             hipStream_t s) {
   if (n == 0) return;
-  const dim3 grid(grid_for((long)n, 1 << 16));
+  const dim3 grid = list_grid(n);
   hipLaunchKernelGGL(k_interface_strain, grid, dim3(kBlock), 0, s, g, u, E, list, n, epsc);
   if (sp.pt.n <= 2) hipLaunchKernelGGL((k_interface_solve<2>), grid, dim3(kBlock), 0, s, sp, epsc, phic, nrmc, n, dtau, error_flag);
   else hipLaunchKernelGGL((k_interface_solve<kMaxPhases>), grid, dim3(kBlock), 0, s, sp, epsc, phic, nrmc, n, dtau, error_flag);
@@ -1585,7 +1645,7 @@ void launch_add_small(double* out, const double* in, int n, hipStream_t s) {
 void launch_delta_div(const Grid& g, const unsigned* aff, const int* slots, unsigned n, const double* dtau,
                       const FieldPtrs<3>& f, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(k_delta_div, dim3(grid_for((long)n, 1 << 16)), dim3(kBlock), 0, s, g, aff, slots, n, dtau, f);
+  hipLaunchKernelGGL(k_delta_div, list_grid(n), dim3(kBlock), 0, s, g, aff, slots, n, dtau, f);
   FG_HIP_CHECK(hipGetLastError());
 }
 

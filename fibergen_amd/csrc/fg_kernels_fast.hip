@@ -933,7 +933,9 @@ void launch_complement_check(const Grid& g, const double* phi0, const double* ph
 // images, so one barrier per step --, z neighbours from the adjacent lanes.  Rows 0 and TYR-1 and, for ZS = 0, lanes
 // 0 and 63 are halo.  T_k -> sums of squares of g_k = E + grad+ T_k and f = div-((a - 2 mu0) g_k), every T and a value
 // loaded once per tile (k_sc_sweep_fast: 8 loads per pair out of L2).
-template <int TYR, int ZS>
+// SUMT: the three sums of the flux polarisation tau = (a - 2 mu0) g as well (partial slots 3..5): <tau> drives the mixed
+// boundary conditions (initBCProjector F:20228-20239 in GammaOperatorStaggeredHeat F:20342-20350)
+template <int TYR, int ZS, bool SUMT = false>
 __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, double beta, const double* T, const double* a,
                                                                        double* fo, Vec6 E, double* partial, int nty, int ntz,
                                                                        int LX, int nt) {
@@ -944,7 +946,8 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, do
   constexpr int RW = NZS * 64;
   __shared__ double2 Tb[2][TYR][RW];
   __shared__ double2 Cb[2][TYR][RW];
-  __shared__ double red[TYR * NZS * 3];
+  constexpr int NA = SUMT ? 6 : 3;
+  __shared__ double red[TYR * NZS * NA];
 
   const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int r = wv / NZS, zs = wv % NZS;
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, do
   q0m.x = (ac.x + beta) * (E.v[0] + (Tn.x - Tc.x) * hx);
   q0m.y = (ac.y + beta) * (E.v[0] + (Tn.y - Tc.y) * hx);
   Tc = Tn; Tn = T2; ac = an;
-  double acc[3] = {0, 0, 0};
+  double acc[NA] = {};
 
   for (int st = 0; st < nsteps; ++st) {
     const int q = x0 + st;
@@ -1030,13 +1033,18 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, do
       acc[0] += g0x * g0x + g0y * g0y;
       acc[1] += g1x * g1x + g1y * g1y;
       acc[2] += g2x * g2x + g2y * g2y;
+      if (SUMT) {
+        acc[NA - 3] += q0x + q0y;
+        acc[NA - 2] += cc.x * g1x + cc.y * g1y;
+        acc[NA - 1] += cc.x * g2x + cc.y * g2y;
+      }
       store_f(oq, f);
     }
     q0m.x = q0x; q0m.y = q0y;
     Tc = Tn; Tn = T2; ac = an;
   }
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < NA; ++c) {
     double v = acc[c];
     v += dpp_move<0x128>(v);
     v += dpp_move<0x124>(v);
@@ -1046,20 +1054,29 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, do
   }
   if (l == 0) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) red[wv * 3 + c] = acc[c];
+    for (int c = 0; c < NA; ++c) red[wv * NA + c] = acc[c];
   }
   __syncthreads();
   if (threadIdx.x < 6) {
     double v = 0.0;
-    if (threadIdx.x < 3)
-      for (int w = 0; w < TYR * NZS; ++w) v += red[w * 3 + threadIdx.x];
+    if (threadIdx.x < NA)
+      for (int w = 0; w < TYR * NZS; ++w) v += red[w * NA + threadIdx.x];
     partial[(long)blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+// sums of the scalar sweep with SUMT: [0..2] norms, [3..5] tau -> sumsq6 = (norms, 0, 0, 0), sumtau3 = tau sums
+__global__ void k_sc_split_sums(double* sumsq6, double* sumtau3) {
+  const int c = threadIdx.x;
+  if (c < 3) {
+    sumtau3[c] = sumsq6[3 + c];
+    sumsq6[3 + c] = 0.0;
   }
 }
 
 template <int TYR, int ZS>
 void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E, double* partial,
-                      double* sumsq6, hipStream_t s) {
+                      double* sumsq6, hipStream_t s, double* sumtau3) {
   constexpr int NZS = ZS ? ZS : 1;
   constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
   const int nzh = g.nz / 2;
@@ -1073,6 +1090,15 @@ void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double*
   int nb = nty * ntz * ntx;
   if (nb >= 8) nb = ((nb + 7) / 8) * 8;
   const int nt = (double)g.n * sizeof(double) > 128.0 * 1024 * 1024 ? 1 : 0;
+  if (sumtau3) {
+    hipLaunchKernelGGL((k_sc_tile<TYR, ZS, true>), dim3(nb), dim3(TYR * NZS * 64), 0, s, g, -2 * mu_0, T, a, f, E, partial, nty,
+                       ntz, LX, nt);
+    FG_HIP_CHECK(hipGetLastError());
+    fold_sum(partial, nb, 6, sumsq6, s);
+    hipLaunchKernelGGL(k_sc_split_sums, dim3(1), dim3(64), 0, s, sumsq6, sumtau3);
+    FG_HIP_CHECK(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL((k_sc_tile<TYR, ZS>), dim3(nb), dim3(TYR * NZS * 64), 0, s, g, -2 * mu_0, T, a, f, E, partial, nty, ntz,
                      LX, nt);
   FG_HIP_CHECK(hipGetLastError());
@@ -1080,21 +1106,22 @@ void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double*
   FG_HIP_CHECK(hipGetLastError());
 }
 
-void launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
-                          double* partial, double* sumsq6, hipStream_t s) {
+bool launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
+                          double* partial, double* sumsq6, hipStream_t s, double* sumtau3) {
   static const int tile_env = getenv("FG_SC_TILE") ? atoi(getenv("FG_SC_TILE")) : 1;
   if (tile_env && u_tile_supported(g)) {
     const int nzh = g.nz / 2;
-    if (nzh == 64) launch_sc_tile_t<8, 1>(g, mu_0, T, a, f, E, partial, sumsq6, s);
-    else if (nzh == 128) launch_sc_tile_t<6, 2>(g, mu_0, T, a, f, E, partial, sumsq6, s);   // 48 KB of LDS images
-    else launch_sc_tile_t<8, 0>(g, mu_0, T, a, f, E, partial, sumsq6, s);
-    return;
+    if (nzh == 64) launch_sc_tile_t<8, 1>(g, mu_0, T, a, f, E, partial, sumsq6, s, sumtau3);
+    else if (nzh == 128) launch_sc_tile_t<6, 2>(g, mu_0, T, a, f, E, partial, sumsq6, s, sumtau3);   // 48 KB of LDS images
+    else launch_sc_tile_t<8, 0>(g, mu_0, T, a, f, E, partial, sumsq6, s, sumtau3);
+    return sumtau3 != nullptr;
   }
   const int nb = sweep_blocks((long)g.nx * g.ny * g.nzc);
   hipLaunchKernelGGL(k_sc_sweep_fast, dim3(nb), dim3(kBlock), 0, s, g, -2 * mu_0, T, a, f, E, partial, chunk_rows(g));
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
+  return false;   // the untiled sweep carries no sums of tau
 }
 
 template <int TYR, int ZS>

@@ -324,6 +324,7 @@ class Solver {
   bool cg_u_active_ = false;  // displacement-space CG is iterating: fu_ is the iterate u_e, fu_alt_ is free between steps
   double E_cur_[6] = {0, 0, 0, 0, 0, 0};   // prescribed strain the current (u, eps) state was built with
   double E_next_[6] = {0, 0, 0, 0, 0, 0};
+  bool sc_tau_sums_ = false;   // the last scalar sweep left the sums of tau in kSlotMean (mixed BC, tiled sweep)
   bool timing_ = false;
   double event_bias_ms_ = 0.0;   // reading of an empty event pair, subtracted from every timed kernel
   StageTimes times_;

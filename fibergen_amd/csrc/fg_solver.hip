@@ -34,6 +34,26 @@ __global__ void k_publish(const double* dsc, int n, const double* dsc2, int n2, 
   if (t == 0) *hseq = seq;
 }
 
+// Viscosity mode with mixed boundary conditions: DeltaOperatorStaggered F:20422-20460 hands adj = E - 2 alpha m <tau> to
+// GammaOperatorStaggered, whose applyBCProjector (F:20263-20270, bc_relax = 1) adds alpha MQ:<tau> at the end.  The tail sweep
+// forms  adj_c = E_c - coef * sums_c / N  from the six sums the divergence sweep left on the device (coef = 2 alpha m); this
+// kernel replaces the sums by  s - (alpha / coef) B s,  B the plain 6 x 6 matrix of v -> MQ:v, so that the sweep's adj carries
+// both terms -- no host round trip.
+struct Mat36 {
+  double a[36];
+};
+__global__ void k_bc_adjust_sums(double* sums, Mat36 B, double factor) {
+  if (threadIdx.x != 0) return;
+  double s[6], o[6];
+  for (int c = 0; c < 6; ++c) s[c] = sums[c];
+  for (int c = 0; c < 6; ++c) {
+    double t = 0.0;
+    for (int j = 0; j < 6; ++j) t += B.a[c * 6 + j] * s[j];
+    o[c] = s[c] - factor * t;
+  }
+  for (int c = 0; c < 6; ++c) sums[c] = o[c];
+}
+
 double now_seconds() {
   using clk = std::chrono::steady_clock;
   return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
@@ -478,8 +498,8 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     //   + 2 alpha m tau.   lambda0 = inf makes c20 = c10 in G0OperatorFourierStaggered (F:19749-19755).
     if (opt_.gamma_scheme != 0) throw std::runtime_error("viscosity mode supports gamma_scheme=staggered only");
     if (opt_.mixing != kMixVoigt) throw std::runtime_error("viscosity mode supports Voigt mixing only");
-    if (frobenius(BC_MQ_) >= kEps || opt_.bc_relax != 1.0)
-      throw std::runtime_error("viscosity mode supports prescribed mean values only (projector = identity)");
+    if (opt_.bc_relax != 1.0) throw std::runtime_error("viscosity mode supports bc_relax = 1 only");
+    const bool mixed_bc = !(frobenius(BC_MQ_) < kEps);   // initBCProjector / applyBCProjector inside GammaOperatorStaggered
     const double m = 1 / (4 * opt_.mu_0);
     const bool fused = opt_.fuse_stress_div != 0;
     if (fused) {
@@ -501,6 +521,17 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
       time_begin(1);
       launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
       time_end(1);
+    }
+    if (mixed_bc) {
+      Mat36 B;
+      for (int j = 0; j < 6; ++j) {
+        double e[6] = {0, 0, 0, 0, 0, 0}, col[6];
+        e[j] = 1.0;
+        voigt_mv(BC_MQ_, e, col);
+        for (int c = 0; c < 6; ++c) B.a[c * 6 + j] = col[c];
+      }
+      hipLaunchKernelGGL(k_bc_adjust_sums, dim3(1), dim3(64), 0, stream_, dscal_ + kSlotMean, B, alpha / (2 * alpha * m));
+      FG_HIP_CHECK(hipGetLastError());
     }
     const double mu_g = -1.0 / (4 * m);
     const double c12[2] = {-alpha / mu_g, -alpha / mu_g};
@@ -854,8 +885,11 @@ void Solver::u_pass_front(const double* E6) {
     z_done_ = false;
     if (opt_.u_loop >= 2) {
       // fast variant: effective conductivity a = sum_p phi_p mu_p precomputed (first moduli array)
-      launch_sc_sweep_fast(g_, opt_.mu_0, fu_, effective_moduli().p[0], fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
+      const bool mixed = !(frobenius(BC_MQ_) < kEps) && in_run_;
+      sc_tau_sums_ = launch_sc_sweep_fast(g_, opt_.mu_0, fu_, effective_moduli().p[0], fu_alt_, E, partial_, dscal_ + kSlotSumSq,
+                                          stream_, mixed ? dscal_ + kSlotMean : nullptr);
     } else {
+      sc_tau_sums_ = false;
       launch_sc_sweep(g_, scalar_params(opt_.mu_0, 1.0), fu_, phase_ptrs(), fu_alt_, E, partial_, dscal_ + kSlotSumSq, stream_);
     }
   } else if (opt_.mixing != kMixVoigt && opt_.u_loop < 2) {
@@ -1254,10 +1288,10 @@ bool Solver::run_one_step(const double* E0, const double* S0) {
       if (iter == 1 && fresh_step_)
         for (int i = 0; i < 6; ++i) E_cur_[i] = E[i];  // eps_1 = E (u_1 = 0)
       u_pass_front(E);
-      if (opt_.mode == 1 && mixed_bc) {
+      if (opt_.mode == 1 && mixed_bc && !sc_tau_sums_) {
         // heat / porous with mixed boundary conditions (initBCProjector in GammaOperatorStaggeredHeat F:20342-20350): the
-        // sweeps of the scalar modes carry no sums of tau, so <tau> = <P(g) - 2 mu0 g> is taken from the gradient field
-        // (two extra sweeps per pass; a rarely used combination)
+        // LDS-tiled sweep leaves the sums of tau in kSlotMean; where it does not apply, <tau> = <P(g) - 2 mu0 g> is taken
+        // from the gradient field (two extra sweeps per pass)
         ensure_eps();
         launch_sc_flux_mean(g_, scalar_params(opt_.mu_0, 1.0 / (double)nglobal_), ptrs3(eps_), phase_ptrs(), partial_,
                             dscal_ + kSlotMean, stream_);
@@ -1278,8 +1312,8 @@ bool Solver::run_one_step(const double* E0, const double* S0) {
       // applyBCProjector  F:20247-20270 with bc_relax = 1: eps_{k+1} = E + alpha MQ:<tau_k> + sym grad u_{k+1}
       double F0[6], t1[6];
       for (int c = 0; c < 6; ++c) F0[c] = hscal_[kSlotMean + c] / (double)nglobal_;
-      if (opt_.mode == 1)   // the flux-mean sweep has divided by N already; components 3..5 do not exist
-        for (int c = 0; c < 6; ++c) F0[c] = c < 3 ? hscal_[kSlotMean + c] : 0.0;
+      if (opt_.mode == 1)   // components 3..5 do not exist; the flux-mean sweep has divided by N already, the tiled sweep has not
+        for (int c = 0; c < 6; ++c) F0[c] = c < 3 ? hscal_[kSlotMean + c] / (sc_tau_sums_ ? (double)nglobal_ : 1.0) : 0.0;
       if (opt_.mixing != kMixVoigt)
         for (int c = 0; c < 6; ++c) F0[c] += hscal_[kSlotScratch + c] / (double)nglobal_;
       voigt_mv(BC_MQ_, F0, t1);

@@ -132,7 +132,7 @@ def _threads():
     return min(16, os.cpu_count() or 1)
 
 
-def test_config5_porous_256_three_passes():
+def test_config5_porous_256_four_passes():
     from fibergen_amd import LSSolver
     from fibergen_amd.rve import bench_rve
     from oracle.c_oracle import CRefScalar
@@ -145,17 +145,24 @@ def test_config5_porous_256_three_passes():
     s.set_num_phases(2)
     for p in range(2):
         s.set_phase(p, mus[p], 0.0, phis[p])
-    mu_0, _ = s.calc_ref_material()
-    g0 = _start_field(n, phi)[:3].copy()
-    s.set_field("epsilon", g0)
-    s.iterate(E, 3)
+    # the state of the scalar modes is the potential (fields cannot be set): four passes of LSSolver::run from the zero
+    # field, i.e. g_1 = E, then three passes with the full operator
+    s.set_options(tol=0.0, abs_tol=0.0, maxiter=4)
+    assert s.run(E) is False and s.iterations == 4
+    mu_0, _ = s.ref_material
     got = s.get_field("epsilon")
+    res = np.array(s.residuals)
     s.close()
     c = CRefScalar((n, n, n), DIMS, mus, phis, threads=_threads())
-    g = g0
-    for _ in range(3):
+    g = np.zeros((3, n, n, n))
+    prev, want = 0.0, []
+    for _ in range(4):
         g = c.basic_scheme(E, g, mu_0)
+        cur = math.sqrt(float((g.reshape(3, -1) ** 2).sum(axis=1).sum() / n ** 3))   # EpsilonErrorEstimator F:14591-14637, dim 3
+        want.append(abs(prev - cur) / (np.finfo(float).tiny + cur))
+        prev = cur
     assert rel_err(got, g) < 1e-11
+    assert np.abs(res - np.array(want)).max() < 1e-12
 
 
 def test_config5_viscosity_256_three_passes():

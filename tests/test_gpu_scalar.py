@@ -191,7 +191,9 @@ def test_scalar_cg_matches_oracle(grid, dims):
     b.close()
 
 
-@pytest.mark.parametrize("grid,u_loop", [((16, 16, 16), 1), ((12, 10, 6), 2), ((8, 16, 128), 2)])
+@pytest.mark.parametrize("grid,u_loop", [((16, 16, 16), 1), ((12, 10, 6), 2),
+                                         # grids the LDS-tiled sweep takes: it carries the sums of the flux polarisation itself
+                                         ((8, 16, 128), 2), ((6, 14, 256), 2), ((8, 14, 124), 2)])
 def test_scalar_mixed_boundary_conditions(grid, u_loop):
     """initBCProjector / applyBCProjector of GammaOperatorStaggeredHeat  F:20342-20350 with setBCProjector for dim 3
     (F:20599-20665): a flux prescribed in x, gradients prescribed in y and z."""

@@ -145,3 +145,31 @@ def test_fg_nunan_keller_demo_project(V, n):
     assert alpha == pytest.approx(NUNAN_KELLER[V][0], rel=0.03)
     assert beta == pytest.approx(NUNAN_KELLER[V][1], rel=0.025)
     assert mu_eff[3][3] == pytest.approx(mu_eff[4][4], rel=1e-4) and mu_eff[3][3] == pytest.approx(mu_eff[5][5], rel=1e-4)
+
+
+@pytest.mark.parametrize("method", ["basic", "cg"])
+@pytest.mark.parametrize("fuse", [0, 1])
+@pytest.mark.parametrize("diag,E", [([0, 0, 0, 0, 0, 0.5], [0, 0, 0, 0, 0, 1.0]),            # sigma_12 prescribed, the other shear rates zero
+                                    ([1, 1, 1, 0, 0, 0], [0.5, -0.5, 0, 0, 0, 0]),            # normal stresses prescribed
+                                    ([0, 0, 0, 0.5, 0.5, 0], [0, 0, 0, 0.3, -0.2, 0])])
+@pytest.mark.parametrize("grid", [(12, 10, 6), (8, 14, 124)])   # untiled / LDS-tiled divergence sweep
+def test_viscosity_mixed_boundary_conditions(grid, diag, E, fuse, method):
+    """DeltaOperatorStaggered F:20422-20460 runs GammaOperatorStaggered and with it initBCProjector / applyBCProjector
+    F:20228-20270: prescribed mean stress in the P components, prescribed mean shear rate (here zero) in the others."""
+    phi1 = sphere_phi(grid, 0.3)
+    s, o = _pair(grid, [1.0, 0.05], [1 - phi1, phi1], tol=1e-9, bc_tol=1e-8, maxiter=2000)
+    s.set_options(fuse_stress_div=fuse, method=method)
+    P = np.diag(np.array(diag, dtype=float))
+    s.set_bc_projector(P)
+    E = np.array(E, dtype=float)
+    S = np.zeros(6)
+    assert s.run(E, S) is False
+    assert (o.run_cg(E, S, P) if method == "cg" else o.run(E, S0=S, P=P)) is False
+    assert s.iterations == o.iterations
+    np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-9)
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8
+    assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-8
+    free = np.array(diag) == 0
+    assert np.abs(s.mean_stress()[free]).max() < 1e-7            # the stress-free (here: rate-free) components
+    np.testing.assert_allclose(s.mean_strain()[~free], E[~free], atol=1e-10)
+    s.close()
