@@ -44,11 +44,17 @@ class Fft3 {
   bool can_block_y(int nranks) const;
   void c2c_y_blocked(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale, int nranks,
                      int interleave = 1);
+  // x-contiguous intermediate layout between the y passes and the fused x pass: [zc/8][y][x][8] complex, so that a tile of the
+  // fused pass (8 kz columns x all x of one ky) is ONE contiguous run of nx * 128 bytes instead of nx segments ny*nzc*16 B
+  // apart; the scatter moves to the y passes (dir = -1: in plain -> out x-layout; dir = +1: in x-layout -> out plain),
+  // fused_g0(..., xlayout = true) works on it in place.  Out of place (in != out).
+  bool can_xlayout() const;
+  void c2c_y_xlayout(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale);
   bool can_fuse(int axis, int ncomp = 3) const;
   // ncomp = 3: elastic Green operator on three components; ncomp = 1: scalar (heat / porous) operator c10 / |k|^2
   // xjump != 0 (doubles): line point j of the x pass sits at j * ls + (j >> xsplit) * xjump (interleaved slab layout)
   void fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp = 3, int xsplit = 31,
-                long xjump = 0);
+                long xjump = 0, bool xlayout = false);
 
   bool fast_x() const { return fast_[0]; }
   bool fast_y() const { return fast_[1]; }

@@ -1123,8 +1123,42 @@ bool Fft3::can_fuse(int axis, int ncomp) const {
   return odd_[axis] == 3 ? xfused_mixed_p<3>(n / 3, a, 0, nullptr, stream_, true) : xfused_mixed_p<5>(n / 5, a, 0, nullptr, stream_, true);
 }
 
+bool Fft3::can_xlayout() const {
+  return fast_[0] && fast_[1] && g_.nx >= 8 && g_.nx <= 512 && g_.nzc % 8 == 0 && g_.ny >= 8;
+}
+
+void Fft3::c2c_y_xlayout(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale) {
+  if (!can_xlayout()) throw std::runtime_error("fft: x-contiguous layout not available for this grid");
+  StridedArgs a;
+  a.data = reinterpret_cast<cplx*>(in);
+  a.out = reinterpret_cast<cplx*>(out);
+  a.out_cs = out_cs / 2;
+  a.ncols = g_.nzc;
+  a.tiles_per_outer = 0;
+  a.scale = scale;
+  a.tw = tw_[1];
+  a.nt = stream_stores_ ? (1 | ((nt_loads_env() & 1) ? 2 : 0)) : 0;
+  a.xcd_order = 0;
+  const long plain_ls = g_.nzc, plain_os = (long)g_.ny * g_.nzc;
+  const long xl_ls = (long)g_.nx * 8, xl_os = 8, xl_ts = (long)g_.ny * g_.nx * 8;
+  if (dir < 0) {
+    a.ls = plain_ls;
+    a.os = plain_os;
+    a.ls_out = xl_ls;
+    a.os_out = xl_os;
+    a.ts_out = xl_ts;
+  } else {
+    a.ls = xl_ls;
+    a.os = xl_os;
+    a.ts_in = xl_ts;
+    a.ls_out = plain_ls;
+    a.os_out = plain_os;
+  }
+  strided_pow2_narrow(g_.ny, a, g_.nx, dir, ncomp, in_cs / 2, stream_);   // 8-column tiles: the layout's inner dimension
+}
+
 void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp, int xsplit,
-                    long xjump) {
+                    long xjump, bool xlayout) {
   if (ncomp != 1 && ncomp != 3) throw std::runtime_error("fft: fused Green-operator pass takes 1 or 3 components");
   if (!can_fuse(axis, ncomp)) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
   const int n = axis == 0 ? g_.nx : g_.ny;
@@ -1154,6 +1188,13 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
     if (!fast_[axis] || axis != 0 || ncomp != 3) throw std::runtime_error("fft: interleaved layout needs the radix x pass");
     a.xsplit = xsplit;
     a.xjump = xjump / 2;
+  }
+  if (xlayout) {
+    if (!can_xlayout() || axis != 0 || ncomp != 3 || xjump != 0) throw std::runtime_error("fft: x-contiguous layout: three components, x pass");
+    a.xl_ny = g_.ny;
+    a.ls = 8;
+    a.flat_cols = 0;
+    a.ncols = g_.ny * g_.nzc;   // (tiles = ncols / 8 = (nzc / 8) * ny)
   }
   const int nouter = axis == 0 ? 1 : g_.nx;
   if (!fast_[axis]) {

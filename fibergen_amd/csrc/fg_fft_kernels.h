@@ -50,6 +50,11 @@ struct StridedArgs {
   long os_out = 0;           // outer stride on the store side (out != nullptr)
   int split_in = 31, split_out = 31;
   long jump_in = 0, jump_out = 0;
+  // x-contiguous intermediate layout (Fft3::c2c_y_xlayout): one side of the y pass addresses [zc/8][y][x][8] instead of
+  // [x][y][zc] -- its line stride differs (ls_out; 0 = ls) and tile z of outer index o starts at o*os + z*ts (ts = 0: the
+  // plain layout's o*os + z*C)
+  long ls_out = 0;
+  long ts_in = 0, ts_out = 0;
 };
 
 template <int N, int C, int DIR>
@@ -72,10 +77,11 @@ struct StridedKernel {
       r.t = tid % C;
       r.jt = tid / C;
       int o = block / a.tiles_per_outer;
-      int col = (block % a.tiles_per_outer) * C + r.t;
+      const int tile = block % a.tiles_per_outer;
+      int col = tile * C + r.t;
       r.valid = col < a.ncols;
-      r.base = (long)o * a.os + col;
-      r.obase = a.out ? (long)o * a.os_out + col : r.base;
+      r.base = (long)o * a.os + (a.ts_in ? (long)tile * a.ts_in + r.t : (long)col);
+      r.obase = a.out ? (long)o * a.os_out + (a.ts_out ? (long)tile * a.ts_out + r.t : (long)col) : r.base;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int j = Line<N>::first_index(r.jt, q);
@@ -91,7 +97,7 @@ struct StridedKernel {
         cplx o = r.v[q];
         if (a.scale != 1.0) o = cscale(a.scale, o);
         const int j = Line<N>::last_index(r.jt, q);
-        cstore_stream(&dst[r.obase + (long)j * a.ls + (long)(j >> a.split_out) * a.jump_out], o, a.nt);
+        cstore_stream(&dst[r.obase + (long)j * (a.ls_out ? a.ls_out : a.ls) + (long)(j >> a.split_out) * a.jump_out], o, a.nt);
       }
     }
   }
@@ -342,6 +348,9 @@ struct XFusedArgs {
   // message per peer delivers): line point j sits at  j*ls + (j >> xsplit) * xjump  (XFusedKernel<.., XSPLIT = true> only)
   int xsplit = 31;
   long xjump = 0;
+  // x-contiguous layout [zc/8][y][x][8] (xl_ny = ny > 0; C = 8): tile b = zt * ny + y is the contiguous run of N * 8
+  // complex values at b * N * 8, line point j at + 8 j
+  int xl_ny = 0;
 };
 
 // NC = 3: the three components of the elastic problem and G0OperatorFourierStaggeredGeneral; NC = 1: the scalar modes
@@ -372,6 +381,14 @@ struct XFusedKernel {
     bool valid;
   };
   FG_HD static void locate(int block, int t, const XFusedArgs& a, long* base, int* jj, int* kk, bool* valid) {
+    if (a.xl_ny) {
+      const int zt = block / a.xl_ny;
+      *jj = a.jj0 + (block - zt * a.xl_ny);
+      *kk = zt * C + t;
+      *base = (long)block * N * C + t;
+      *valid = *kk < a.nzc;
+      return;
+    }
     const int o = block / a.tiles_per_outer;
     const int col = (block % a.tiles_per_outer) * C + t;
     *valid = col < a.ncols;

@@ -416,7 +416,7 @@ void Solver::fetch_norms_and_errors(const char* where) {
 // FFT / Green-operator chain of the displacement loop, enqueued without touching the host-side state: fu_alt_ then holds
 // u_{k+1}; adopt_back() makes it the current state.  If the iteration stops first, it is simply never adopted.
 void Solver::launch_pending_back() {
-  fft_g0_chain(fu_alt_, z_done_);
+  fft_g0_chain(fu_alt_, z_done_, -1.0, nullptr, opt_.mode == 0 ? tau_ : nullptr);   // tau_ is free in the displacement loop
   pending_back_ = false;
   back_ready_ = true;
 }
@@ -637,7 +637,7 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
     time_end(1);
   }
-  fft_g0_chain(fu_);
+  fft_g0_chain(fu_, false, -1.0, nullptr, tau_);   // the polarisation is dead once its divergence is taken
 
   // applyBCProjector  F:20247-20270: R = alpha*(bc_relax*MQ:F0 - (1-bc_relax)*M:(QC0:F00))
   Vec6 E, R;
@@ -662,7 +662,7 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
   for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
 }
 
-void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* c12) {  // alpha = -1: GammaOperator(..., -1)  F:20575
+void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* c12, double* xscratch) {  // alpha = -1: GammaOperator(..., -1)  F:20575
   if (opt_.mode == 1) {
     // G0OperatorStaggeredHeat  F:20118-20135 on one component: fftVector(., 1), c1 = c10/|k|^2, fftInvVector
     const double scale = 1 / (double)nglobal_;
@@ -710,6 +710,38 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     return;
   }
   bool fuse_x = false;
+  // x-contiguous layout for the fused pass: on by size (fields beyond the Infinity Cache, where the fused pass's tile of nx
+  // segments 2 MB apart is what bounds it) unless the option says otherwise; FG_X_LAYOUT overrides for A/B runs
+  static const int xl_env = getenv("FG_X_LAYOUT") ? atoi(getenv("FG_X_LAYOUT")) : -1;
+  const int xl_opt = xl_env >= 0 ? xl_env : opt_.x_layout;
+  const bool xl = xscratch && opt_.fuse_x && fft_->can_fuse(0) && fft_->can_xlayout() && g_.nx > 1 && g_.ny > 1 &&
+                  (xl_opt > 0 || (xl_opt < 0 && 3.0 * (double)g_.n * sizeof(double) > 1024.0 * 1024 * 1024));
+  if (xl) {
+    if (!z_done) {
+      time_begin(2);
+      fft_->r2c_z(buf, 3, g_.n);
+      time_end(2);
+    }
+    time_begin(3);
+    fft_->c2c_y_xlayout(buf, g_.n, xscratch, g_.n, 3, -1, 1.0);
+    time_end(3);
+    G0Params gp;
+    gp.c10 = -alpha / (opt_.mu_0);
+    gp.c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    gp.inv_h0 = 2.0 * nxg_ / g_.dx;
+    if (c12) gp.c10 = c12[0], gp.c20 = c12[1];
+    for (int a = 0; a < 3; ++a) gp.kpm[a] = g0_kpm_[a], gp.kp[a] = g0_kp_[a];
+    time_begin(5);
+    fft_->fused_g0(xscratch, g_.n, 0, 1 / (double)nglobal_, gp, 0, 3, 31, 0, true);
+    time_end(5);
+    time_begin(7);
+    fft_->c2c_y_xlayout(xscratch, g_.n, buf, g_.n, 3, +1, 1.0);
+    time_end(7);
+    time_begin(8);
+    fft_->c2r_z(buf, 3, g_.n);
+    time_end(8);
+    return;
+  }
   {
     // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
     const double scale = 1 / (double)nglobal_;
@@ -1393,7 +1425,7 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
     for (int c = 0; c < 6; ++c) E_cur_[c] = Eadd[c];
     u_pass_front(Eadd);   // sweeps fu_ (with E_cur_) into fu_alt_; its norm sums are not used here
     fu_ = keep;
-    fft_g0_chain(fu_alt_, z_done_);
+    fft_g0_chain(fu_alt_, z_done_, -1.0, nullptr, tau_);
   };
   // eps_0 = E (u_e = 0);  r = -Gamma0 (C - C0) E  (+ E - eps_0 = 0, adjustResidual F:10012-10022)
   // The CG scalars stay on the device (k_cgu_axpy forms alpha and beta from the sums the dot sweeps leave in

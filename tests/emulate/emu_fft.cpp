@@ -138,6 +138,80 @@ int emu_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, doub
   return 1;
 }
 
+// The y pass with the x-contiguous layout [zc/8][y][x][8] on one side (Fft3::c2c_y_xlayout's strides, 8-column tiles):
+// dir < 0: in plain [nx][NY][nzc] -> out x-layout; dir > 0: in x-layout -> out plain
+int emu_strided_xlayout(int NY, int dir, double* in, double* out, int nx, int nzc, double scale) {
+  std::vector<cplx> tw = make_pass_twiddles(NY);
+  StridedArgs a;
+  a.nt = 0;
+  a.xcd_order = 0;
+  a.data = reinterpret_cast<cplx*>(in);
+  a.out = reinterpret_cast<cplx*>(out);
+  a.out_cs = 0;
+  a.ncols = nzc;
+  a.scale = scale;
+  a.tw = tw.data();
+  a.tiles_per_outer = (nzc + 7) / 8;
+  const long plain_ls = nzc, plain_os = (long)NY * nzc, xl_ls = (long)nx * 8, xl_os = 8, xl_ts = (long)NY * nx * 8;
+  if (dir < 0) {
+    a.ls = plain_ls; a.os = plain_os; a.ls_out = xl_ls; a.os_out = xl_os; a.ts_out = xl_ts;
+  } else {
+    a.ls = xl_ls; a.os = xl_os; a.ts_in = xl_ts; a.ls_out = plain_ls; a.os_out = plain_os;
+  }
+#define CASE(n)                                                      \
+  if (NY == n) {                                                     \
+    strided_dir<n, 8>(a, (long)a.tiles_per_outer * nx, dir);         \
+    return 0;                                                        \
+  }
+  CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) CASE(512)
+#undef CASE
+  return 1;
+}
+
+// the fused x pass on the x-contiguous layout: data[3][nzc/8][ny][N][8]
+int emu_xfused_xlayout(int N, double* data, int ny, int nzc, int nzf, double scale, double c10, double c20,
+                       const double* kpm0, const double* kp0, const double* kpm1, const double* kp1, const double* kpm2,
+                       const double* kp2) {
+  std::vector<cplx> tw = make_pass_twiddles(N);
+  XFusedArgs a;
+  a.nt = 0;
+  a.xcd_order = 0;
+  a.data = reinterpret_cast<cplx*>(data);
+  a.ncols = ny * nzc;
+  a.comp_stride = (long)N * a.ncols;
+  a.ls = 8;
+  a.os = 0;
+  a.flat_cols = 0;
+  a.xl_ny = ny;
+  a.nzc = nzc;
+  a.nzf = nzf;
+  a.jj0 = 0;
+  a.scale = scale;
+  a.c10 = c10;
+  a.c20 = c20;
+  a.tw = tw.data();
+  std::vector<cplx> half_root = make_unit_roots(2 * N, N / 8 > 0 ? N / 8 : 1);
+  a.half_root = half_root.data();
+  a.inv_h = N > 1 ? kpm0[1] / std::sin(3.14159265358979323846 / N) : 1.0;
+  a.kpm[0] = kpm0; a.kpm[1] = kpm1; a.kpm[2] = kpm2;
+  a.kp[0] = reinterpret_cast<const cplx*>(kp0);
+  a.kp[1] = reinterpret_cast<const cplx*>(kp1);
+  a.kp[2] = reinterpret_cast<const cplx*>(kp2);
+#define CASE(n)                                                               \
+  if (N == n) {                                                               \
+    a.tiles_per_outer = a.ncols / 8;                                          \
+    for (int q = 0; q < 8; ++q) {                                             \
+      const double th = 3.14159265358979323846 * fft::Line<n>::last_index(0, q) / n;      \
+      a.xq[q] = cmake(std::cos(th), std::sin(th));                            \
+    }                                                                         \
+    run_blocks<XFusedKernel<n, 8>, XFusedArgs>((long)a.tiles_per_outer, a);   \
+    return 0;                                                                 \
+  }
+  CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) CASE(512)
+#undef CASE
+  return 1;
+}
+
 // generic fall-backs
 void emu_dft_strided(const double* src, double* dst, int n, int ncols, int nouter, int dir, double scale) {
   std::vector<cplx> w = make_unit_roots(n, n);

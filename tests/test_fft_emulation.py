@@ -121,3 +121,53 @@ def test_fused_x_pass(emu, N):
     G = np.where(live, G, F)              # padding columns: scaled spectrum passed through
     ref = np.fft.ifft(G, axis=1) * N
     assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("nx,ny", [(8, 16), (32, 8), (64, 256)])
+def test_x_contiguous_layout_chain(emu, nx, ny):
+    """Forward y pass writing [zc/8][y][x][8], the fused x pass on that layout, inverse y pass reading it back (the chain
+    Solver::fft_g0_chain takes on large grids) against numpy on the plain layout: same numbers as the plain chain, only
+    the addresses between the passes differ."""
+    rng = np.random.default_rng(nx * ny)
+    nzc, nzf = 16, 14
+    x = rng.standard_normal((3, nx, ny, nzc)) + 1j * rng.standard_normal((3, nx, ny, nzc))
+    xl = np.zeros((3, nzc // 8, ny, nx, 8), dtype=np.complex128)
+    for c in range(3):
+        assert emu.emu_strided_xlayout(ny, -1, P(np.ascontiguousarray(x[c]).view(np.float64)), P(xl[c].view(np.float64)), nx, nzc,
+                                       ctypes.c_double(1.0)) == 0
+    Fy = np.fft.fft(x, axis=2)
+    as_plain = lambda a: a.transpose(0, 3, 2, 1, 4).reshape(3, nx, ny, nzc)     # [c][zt][y][x][8] -> [c][x][y][zc]
+    assert np.abs(as_plain(xl) - Fy).max() / np.abs(Fy).max() < 1e-14
+    h = [1.0 / (2 * nx), 2.0 / (2 * ny), 0.5 / (2 * 26)]
+
+    def tables(n, cnt, hh):
+        half = n // 2 - 1 if n % 2 == 0 else n // 2
+        idx = np.arange(cnt)
+        xi = (np.pi / n) * np.where(idx <= half, idx, idx - n)
+        kpm = np.sin(xi) / hh
+        return kpm, kpm * np.exp(1j * xi)
+    kpm0, kp0 = tables(nx, nx, h[0])
+    kpm1, kp1 = tables(ny, ny, h[1])
+    kpm2, kp2 = tables(26, nzc, h[2])
+    c10, c20, scale = -1.0 / 0.9, -1.0 / (0.9 * (1 + 0.9 / 1.1)), 1.0 / (nx * ny)
+    args = [np.ascontiguousarray(a) for a in (kpm0, kp0.view(np.float64), kpm1, kp1.view(np.float64), kpm2, kp2.view(np.float64))]
+    assert emu.emu_xfused_xlayout(nx, P(xl.view(np.float64)), ny, nzc, nzf, ctypes.c_double(scale), ctypes.c_double(c10),
+                                  ctypes.c_double(c20), *[P(a) for a in args]) == 0
+    F = np.fft.fft(Fy, axis=1) * scale
+    K0, K1, K2 = kp0[:, None, None], kp1[None, :, None], kp2[None, None, :]
+    n2 = (kpm0 ** 2)[:, None, None] + (kpm1 ** 2)[None, :, None] + (kpm2 ** 2)[None, None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        c1, c2 = c10 / n2, c20 / (n2 * n2)
+        sdot = F[0] * K0 + F[1] * K1 + F[2] * K2
+        G = np.stack([c1 * F[0] + c2 * sdot * (-np.conj(K0)), c1 * F[1] + c2 * sdot * (-np.conj(K1)),
+                      c1 * F[2] + c2 * sdot * (-np.conj(K2))])
+    G[:, 0, 0, 0] = 0.0
+    live = (np.arange(nzc) < nzf)[None, None, None, :]
+    G = np.where(live, G, F)
+    Gx = np.fft.ifft(G, axis=1) * nx
+    assert np.abs(as_plain(xl) - Gx).max() / np.abs(Gx).max() < 1e-12
+    back = np.zeros((3, nx, ny, nzc), dtype=np.complex128)
+    for c in range(3):
+        assert emu.emu_strided_xlayout(ny, +1, P(xl[c].view(np.float64)), P(back[c].view(np.float64)), nx, nzc, ctypes.c_double(1.0)) == 0
+    ref = np.fft.ifft(Gx, axis=2) * ny
+    assert np.abs(back - ref).max() / np.abs(ref).max() < 1e-12

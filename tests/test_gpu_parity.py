@@ -589,3 +589,28 @@ def test_cg_in_displacement_space(grid, mixing):
         assert np.abs(seen[-1][1] - u).max() < 1e-12 * max(1.0, np.abs(u).max())
     assert rel_err(out[2][2], out[0][2]) < 1e-9
     assert np.abs(out[2][4] - out[0][4]).max() < 1e-9 * max(1.0, np.abs(out[0][4]).max())
+
+
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+@pytest.mark.parametrize("grid", [(16, 16, 128), (32, 8, 128), (8, 64, 124), (256, 16, 128)])
+def test_x_contiguous_intermediate_layout(grid, mixing):
+    """x_layout = 1: the forward y pass writes and the inverse y pass reads [zc/8][y][x][8], the fused x pass runs on
+    contiguous tiles (the default on large grids).  Same arithmetic as the plain layout: identical results."""
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    out = {}
+    for xl in (0, 1):
+        s = make_gpu_solver(grid, mixing=mixing, tol=1e-8, x_layout=xl)
+        assert s.run(E) is False
+        out[xl] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress())
+        s.close()
+    assert out[1][0] == out[0][0]
+    assert np.array_equal(out[1][1], out[0][1])
+    assert np.array_equal(out[1][2], out[0][2])
+    o = make_oracle(grid, mixing=mixing, tol=1e-8)
+    assert o.run(E) is False
+    assert out[1][0] == o.iterations and rel_err(out[1][2], o.eps) < 1e-9
+    # ... and in the displacement-space CG
+    s = make_gpu_solver(grid, mixing=mixing, tol=1e-9, method="cg", x_layout=1)
+    assert s.run(E) is False and o.run_cg(E) is False
+    assert s.iterations == o.iterations and rel_err(s.get_field("epsilon"), o.eps) < 1e-8
+    s.close()
