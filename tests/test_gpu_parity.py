@@ -611,6 +611,78 @@ def test_x_contiguous_intermediate_layout(grid, mixing):
     assert out[1][0] == o.iterations and rel_err(out[1][2], o.eps) < 1e-9
     # ... and in the displacement-space CG
     s = make_gpu_solver(grid, mixing=mixing, tol=1e-9, method="cg", x_layout=1)
+    o = make_oracle(grid, mixing=mixing, tol=1e-9)
     assert s.run(E) is False and o.run_cg(E) is False
     assert s.iterations == o.iterations and rel_err(s.get_field("epsilon"), o.eps) < 1e-8
+    s.close()
+
+
+def test_laminate_rule_at_oblique_normals_is_the_rotated_closed_form():
+    """The HIP laminate rule (get_field('sigma'), FG_STAGE_STRESS) at random oblique normals against the reference-held
+    closed form: P(eps, n) = R [C_lam : (R^T eps R)] R^T with C_lam from calc_isotropic_laminate F:26412-26446 and R e_x = n
+    (tests/test_oracle_pins.py holds the same statement for the oracle)."""
+    from fibergen_amd import LSSolver
+    from helpers import INCLUSION, MATRIX, lame
+    from test_oracle_pins import (_apply_stiffness, _reference_laminate_formula, _rotation_taking_ex_to, _to_matrix,
+                                  _to_vector)
+    rng = np.random.default_rng(21)
+    grid = (8, 6, 10)
+    nv = grid[0] * grid[1] * grid[2]
+    mats = [lame(**MATRIX), lame(**INCLUSION)]
+    n = rng.standard_normal((3, nv))
+    n /= np.linalg.norm(n, axis=0)
+    c1 = rng.uniform(0.02, 0.98, nv)
+    eps = rng.standard_normal((6, nv))
+    s = LSSolver(*grid)
+    s.set_num_phases(2)
+    s.set_phase(0, *mats[0], c1.reshape(grid))
+    s.set_phase(1, *mats[1], (1 - c1).reshape(grid))
+    s.set_normals(n.reshape((3,) + grid))
+    s.set_options(mixing_rule="laminate")
+    s.set_field("epsilon", eps.reshape((6,) + grid))
+    got = s.get_field("sigma").reshape(6, nv)
+    s.close()
+    for v in range(nv):
+        R = _rotation_taking_ex_to(n[:, v])
+        C = _reference_laminate_formula([(c1[v], *mats[0]), (1 - c1[v], *mats[1])])
+        want = _to_vector(R @ _to_matrix(_apply_stiffness(C, _to_vector(R.T @ _to_matrix(eps[:, v]) @ R))) @ R.T)
+        assert np.abs(got[:, v] - want).max() < 1e-11 * np.abs(want).max()
+
+
+def test_stress_driven_laminate_demo_closed_form():
+    """The mixed-BC projector on the GPU against the laminate closed form (F:26412-26446): the three-layer medium of
+    demo/elasticity/laminate under a fully prescribed mean stress and under uniaxial strain with free lateral faces."""
+    from fibergen_amd import LSSolver
+    from oracle.ls_oracle import material_from_pair
+    from test_oracle_pins import _reference_laminate_formula
+    shape = (10, 1, 1)
+    mats = [material_from_pair(E=100.0, nu=0.4), material_from_pair(E=25.0, nu=0.25), material_from_pair(E=50.0, nu=0.3)]
+    fr = [0.2, 0.3, 0.5]
+    edges = np.round(np.cumsum([0.0] + fr) * 10).astype(int)
+    Cw = _reference_laminate_formula([(f, m["mu"], m["lambda"]) for f, m in zip(fr, mats)]) * np.array([1, 1, 1, 2, 2, 2.0])[None, :]
+
+    def solver():
+        s = LSSolver(*shape)
+        s.set_num_phases(3)
+        for p, (a, b) in enumerate(zip(edges[:-1], edges[1:])):
+            phi = np.zeros(shape)
+            phi[a:b] = 1.0
+            s.set_phase(p, mats[p]["mu"], mats[p]["lambda"], phi)
+        s.set_options(tol=1e-13, bc_tol=1e-10, maxiter=5000)
+        return s
+    S = np.array([1.0, 0.2, -0.3, 0.1, 0.05, -0.2])
+    s = solver()
+    s.set_bc_projector(np.zeros((6, 6)))
+    assert s.run(np.zeros(6), S) is False
+    want = np.linalg.solve(Cw, S)
+    assert np.abs(s.mean_strain() - want).max() < 1e-8 * np.abs(want).max() and np.abs(s.mean_stress() - S).max() < 1e-8
+    s.close()
+    s = solver()
+    P = np.zeros((6, 6))
+    P[0, 0] = 1.0
+    s.set_bc_projector(P)
+    assert s.run(np.array([0.01, 0, 0, 0, 0, 0]), np.zeros(6)) is False
+    want = np.concatenate([[0.01], np.linalg.solve(Cw[1:, 1:], -Cw[1:, 0] * 0.01)])
+    assert np.abs(s.mean_strain() - want).max() < 1e-8 * 0.01
+    assert abs(s.mean_stress()[0] - Cw[0] @ want) < 1e-8 * abs(Cw[0] @ want)
     s.close()

@@ -627,3 +627,50 @@ def test_mixed_bc_projector_on_the_laminate_demo_closed_form():
     want = np.concatenate([[0.01], e_free])
     assert np.abs(o.eps.mean(axis=(1, 2, 3)) - want).max() < 1e-8 * 0.01
     assert abs(o.mean_stress()[0] - (Cw[0] @ want)) < 1e-8 * abs(Cw[0] @ want)
+
+
+def _rotate_stiffness(C, R):
+    """conventional Voigt stiffness of the medium rotated by R: sigma' = R sigma R^T for eps' = R eps R^T"""
+    out = np.zeros((6, 6))
+    w = np.array([1, 1, 1, 2, 2, 2.0])
+    for j in range(6):
+        e = np.zeros(6)
+        e[j] = 1.0
+        s0 = _apply_stiffness(C, _to_vector(R.T @ _to_matrix(e) @ R))
+        out[:, j] = _to_vector(R @ _to_matrix(s0) @ R.T) / w[j]
+    return out
+
+
+def diagonal_laminate(n):
+    """Three layers stacked along (1,1,0) on an n x n x 1 grid with interfaces through voxel corners: the band of voxels with
+    i + j = c - 1 is cut in half by the interface x + y = c, its normal is (1,1,0)/sqrt 2; fractions 1/4, 1/2, 1/4 exactly."""
+    cuts = [0, n // 4, n // 4 + n // 2]
+    layer = lambda t: 0 if t < cuts[1] else (1 if t < cuts[2] else 2)
+    phis = [np.zeros((n, n, 1)) for _ in range(3)]
+    for a in range(n):
+        for b in range(n):
+            t = (a + b) % n
+            phis[layer(t)][a, b, 0] += 0.5
+            phis[layer((t + 1) % n)][a, b, 0] += 0.5
+    normals = np.zeros((3, n, n, 1))
+    normals[0] = normals[1] = 1 / math.sqrt(2)
+    return phis, normals, [0.25, 0.5, 0.25]
+
+
+def test_rotated_laminate_converges_to_the_rotated_closed_form():
+    """A laminate at 45 degrees about z is not exact on the staggered grid (the layers cut voxels), but the effective
+    stiffness must converge to the closed form of F:26412-26446 rotated by 45 degrees, first order in the voxel size, and the
+    laminate mixing rule -- which knows the oblique normal -- must be closer than Voigt mixing at every resolution."""
+    ms = [material_from_pair(E=100.0, nu=0.4), material_from_pair(E=25.0, nu=0.25), material_from_pair(E=50.0, nu=0.3)]
+    th = math.pi / 4
+    R = np.array([[math.cos(th), -math.sin(th), 0], [math.sin(th), math.cos(th), 0], [0, 0, 1.0]])
+    err = {}
+    for n in (8, 16):
+        phis, normals, fr = diagonal_laminate(n)
+        Cl = _rotate_stiffness(_reference_laminate_formula([(f, m["mu"], m["lambda"]) for f, m in zip(fr, ms)]), R)
+        for mixing in ("laminate", "voigt"):
+            o = LSOracle(n, n, 1, mats=[(m["mu"], m["lambda"]) for m in ms], phis=phis, normals=normals, mixing_rule=mixing,
+                         tol=1e-10, maxiter=5000)
+            err[n, mixing] = np.abs(o.calc_effective_properties() - Cl).max() / np.abs(Cl).max()
+    assert err[16, "laminate"] < 0.012 and err[16, "laminate"] < 0.6 * err[8, "laminate"]
+    assert err[8, "laminate"] < 0.5 * err[8, "voigt"] and err[16, "laminate"] < 0.5 * err[16, "voigt"]
