@@ -649,9 +649,10 @@ def main():
                 ne = int(ne)
                 if ne % world:
                     raise RuntimeError("grid not divisible by the number of ranks")
-                phi2, normals2, par2 = bench_rve(ne, mix)
+                # every rank generates its own x-slab of the RVE only (the same values as the full field's)
+                phi2, normals2, par2 = bench_rve(ne, mix, x_range=(rank * (ne // world), (rank + 1) * (ne // world)))
                 d2 = DistributedLSSolver(ne, ne, ne, device=local_rank)
-                configure(d2, phi2, normals2, mix, "elasticity", slab=d2.slab)
+                configure(d2, phi2, normals2, mix, "elasticity")
                 del phi2, normals2
                 d2.calc_ref_material()
                 steps2 = max(5, args.steps // 2) if ne >= 512 else args.steps

@@ -868,7 +868,10 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s,
                    bool sum_tau, const PhaseTable* two_phase) {
-  const int nzh = g.nz / 2;
+  // FG_TILE_GENERIC=1: tiles of 62 pairs with halo lanes also where a z row is one or two whole waves (8-wave workgroups,
+  // two per CU: a knob for thin slabs, where the whole-row tiles give only one 11-step march per CU)
+  static const int generic_env = getenv("FG_TILE_GENERIC") ? atoi(getenv("FG_TILE_GENERIC")) : 0;
+  const int nzh = generic_env ? 0 : g.nz / 2;
   if (two_phase) {   // mod.p[0] is phi_1 of two complementary phases: the default tile shapes
     const PhaseLin lin = {2 * two_phase->mu[0] - 2 * mu_0, 2 * (two_phase->mu[1] - two_phase->mu[0]),
                           two_phase->lambda[0] - lambda_0, two_phase->lambda[1] - two_phase->lambda[0]};
