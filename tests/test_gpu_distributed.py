@@ -190,3 +190,22 @@ def test_cg_on_slabs_one_rank_per_process(tmp_path, transport, nproc, grid, mixi
         assert np.array_equal(r["residuals"], res[0]["residuals"])
         assert np.abs(r["residuals"] - np.array(o.residuals)).max() < 1e-9
         assert rel_err(r["mean_stress"], o.mean_stress()) < 1e-9
+
+
+@pytest.mark.parametrize("nproc,mixing,method", [(2, "voigt", "basic"), (4, "laminate", "basic"), (2, "laminate", "cg")])
+def test_rccl_ranks_at_128_cubed_equal_single_gpu_solver(tmp_path, nproc, mixing, method):
+    """BASELINE config 2's size through real RCCL ranks (sharing the GPU, loop-back sockets): 128^3, slabs of 64 / 32 planes,
+    blocks of 0.8-1.6 MB per peer and component -- against the single-GPU solver on the same problem (which the oracle checks
+    at this size in tests/test_gpu_fullsize_oracle.py)."""
+    from helpers import make_gpu_solver
+    grid = (128, 128, 128)
+    res = launch_rccl(nproc, str(tmp_path / "b"), "--backend", "hip", "--grid", "128,128,128", "--mixing", mixing, "--tol", "1e-5",
+                      "--method", method)
+    s = make_gpu_solver(grid, mixing=mixing, tol=1e-5, method=method)
+    assert s.run([1.0, 0, 0, 0, 0, 0.5]) is False
+    eps = np.concatenate([r["eps"] for r in res], axis=1)
+    assert all(str(r["transport"]) == "rccl" and int(r["iterations"]) == s.iterations for r in res)
+    assert np.abs(res[0]["residuals"] - np.array(s.residuals)).max() < 1e-11
+    assert rel_err(eps, s.get_field("epsilon")) < 1e-10
+    assert rel_err(res[0]["mean_stress"], s.mean_stress()) < 1e-11
+    s.close()
