@@ -27,7 +27,8 @@ class SlabGroup {
   void invalidate() { m_.clear(); }   // a member is being destroyed: the group must not be driven any more
 
   bool run(const double* E6, const double* S6);     // collective LSSolver::run; true = failed
-  bool run_cg(const double* E6, const double* S6);  // ... with method = cg (runCGElasticity F:23153-23247, displacement space)
+  bool run_cg(const double* E6, const double* S6);  // ... with method = cg (runCGElasticity F:23153-23247): displacement space
+                                                    // where the fast path applies, strain space otherwise
   void iterate(const double* E6, int n);            // n passes without the stop rule (bench, profiling)
   void mean_stress(double* out6);
   void mean_strain(double* out6);
@@ -40,6 +41,7 @@ class SlabGroup {
   bool fast_ok(bool allow_mixed_bc) const;
   void pass_fast(const double* E_cur, bool sum_tau, bool chain);       // steps 0..9 (chain: the speculative chain included)
   void pass_fast_chain();                                              // steps 1..9
+  bool run_cg_strain(const double* E0, const double* S0);
   bool agree_on_voting();                                              // does any rank carry a convergence callback?
   bool stop_requested() const;                                         // reduced flag word: some rank was cancelled
   void vote(double* v2);                                               // sums of two host values over the ranks

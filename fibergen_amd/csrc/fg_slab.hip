@@ -919,11 +919,19 @@ bool SlabGroup::run_cg(const double* E6, const double* S6) {
     s->slab_reset_state();
     s->recompute_bc();
   }
-  if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_MQ_) < kEps) || !fast_ok(false))
-    throw std::runtime_error("method=cg on slab-decomposed solvers runs in displacement space: prescribed mean strains, Voigt or "
-                             "laminate mixing, u_loop=2 and a grid the tiled sweep fits");
-  const double t_start = now_seconds();
+  {
+    const double se = std::sqrt(kEps);
+    double t[6];
+    voigt_mv(a.BC_P_, S0, t);
+    if (norm2(t, 6) > se * norm2(S0, 6)) throw std::runtime_error("Incompatible stress boundary condition specified");
+    voigt_mv(a.BC_Q_, E0, t);
+    if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
+  }
   prepare();
+  // mixed boundary conditions, grids the tiled sweep does not fit, u_loop < 2: the strain-space form (the vectors of
+  // runCGElasticity as 6-component fields, the operator = one pass of the strain-state pipeline)
+  if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_Q_) < kEps) || !fast_ok(false)) return run_cg_strain(E0, S0);
+  const double t_start = now_seconds();
   if (a.opt_.update_ref) {
     calc_ref_material();
     prepare();
@@ -1073,6 +1081,137 @@ bool SlabGroup::run_cg(const double* E6, const double* S6) {
     s->eps_stale_ = true;
     for (int c = 0; c < 6; ++c) s->E_cur_[c] = E.v[c];
     s->slab_materialise_eps();
+  }
+  synchronize();
+  const double dt = now_seconds() - t_start;
+  for (Solver* s : m_) s->solve_time_ += dt;
+  return failed;
+}
+
+// runCGElasticity  F:23153-23247 on the slabs in strain space: eps (in eps_), r, p, w as 6-component fields of the slab, the
+// Krylov operator eps -> -Gamma0 (C - C0) eps (krylovOperator F:20583-20587: one basicScheme pass with E = 0, mixed-BC
+// projector included) as one pass of the strain-state pipeline on a work field, the inner products all-reduced, alpha and
+// beta on the host -- the collective counterpart of Solver::run_cg.  Any configuration the slab driver runs.
+bool SlabGroup::run_cg_strain(const double* E0, const double* S0) {
+  Solver& a = *m_[0];
+  const double t_start = now_seconds();
+  const bool residual_est = a.opt_.error_estimator == 1;
+  const double small = std::numeric_limits<double>::min();
+  const double nglobal = (double)a.nglobal_;
+  for (Solver* s : m_) {
+    FG_HIP_CHECK(hipSetDevice(s->device_));
+    const size_t f6 = 6 * (size_t)s->g_.n * sizeof(double);
+    for (double** b : {&s->cg_r_, &s->cg_p_, &s->cg_w_})
+      if (!*b) FG_HIP_CHECK(hipMalloc(b, f6));
+    s->in_run_ = true;
+  }
+  if (a.opt_.update_ref) calc_ref_material();
+  const bool voting = agree_on_voting();
+  const bool mixed_bc = !(frobenius(a.BC_MQ_) < kEps);
+  Vec6 E, Z;
+  {
+    double t1[6], t2[6], t3[6];   // calcBCMean  F:20242-20245
+    voigt_mv(a.BC_QC0_, E0, t1);
+    for (int i = 0; i < 6; ++i) t2[i] = S0[i] - t1[i];
+    voigt_mv(a.BC_M_, t2, t3);
+    for (int i = 0; i < 6; ++i) E.v[i] = E0[i] + a.opt_.bc_relax * t3[i], Z.v[i] = 0.0;
+  }
+  // dst = operator(src): the pass works in place on eps_, so the field is copied into dst and dst takes eps_'s place
+  auto apply = [&](double* Solver::*src, double* Solver::*dst) {
+    for (Solver* s : m_) {
+      s->comm_wait(kXHaloU);
+      FG_HIP_CHECK(hipMemcpyAsync(s->*dst, s->*src, 6 * (size_t)s->g_.n * sizeof(double), hipMemcpyDeviceToDevice, s->stream_));
+      std::swap(s->eps_, s->*dst);
+      s->su_valid_ = false;
+      s->eps_stale_ = false;
+    }
+    pass_exact(Z.v, mixed_bc);
+    for (Solver* s : m_) {
+      std::swap(s->eps_, s->*dst);
+      s->su_valid_ = false;   // the displacement the pass left belongs to the work field, not to eps_
+      s->eps_stale_ = false;
+    }
+  };
+  auto dot = [&](int mode, double* Solver::*x, double* Solver::*y, double* Solver::*z, double alpha, int slot, int n) {
+    for (Solver* s : m_)
+      launch_cg(mode, s->g_, s->ptrs6(s->*x), s->ptrs6(s->*y), s->ptrs6(s->*z), E, alpha, s->partial_, s->dscal_ + slot, s->stream_);
+    if (n > 0) reduce_and_fetch(slot, n, false);
+  };
+  for (Solver* s : m_) {
+    s->comm_wait(kXHaloU);
+    launch_set_const6(s->g_, s->ptrs6(s->eps_), E, s->stream_);   // eps_0 = E
+    s->su_valid_ = false;
+    s->eps_stale_ = false;
+    for (int i = 0; i < 6; ++i) s->E_cur_[i] = E.v[i];
+  }
+  apply(&Solver::eps_, &Solver::cg_r_);                                          // r = -Gamma0 (C - C0) eps
+  dot(0, &Solver::cg_r_, &Solver::eps_, &Solver::eps_, 0.0, kSlotMean, 1);       // r += E - eps ; r:r
+  double gamma = a.hscal_[kSlotMean] / nglobal + small;
+  const double gamma_0 = gamma;
+  for (Solver* s : m_)
+    FG_HIP_CHECK(hipMemcpyAsync(s->cg_p_, s->cg_r_, 6 * (size_t)s->g_.n * sizeof(double), hipMemcpyDeviceToDevice, s->stream_));
+  double prev = 0.0;
+  long iter = 0;
+  bool failed = false;
+  for (;;) {
+    apply(&Solver::cg_p_, &Solver::cg_w_);                                       // w = -Gamma0 (C - C0) p
+    dot(1, &Solver::cg_p_, &Solver::cg_w_, &Solver::cg_w_, 0.0, kSlotMean, 1);   // p:(p - w)
+    const double alpha = gamma / (a.hscal_[kSlotMean] / nglobal + small);
+    dot(2, &Solver::eps_, &Solver::cg_p_, &Solver::cg_p_, alpha, kSlotSumSq, 6);  // eps += alpha p ; norms
+    double m[6], s9 = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      const double ss = a.hscal_[kSlotSumSq + c];
+      for (Solver* s : m_) s->sumsq_[c] = ss;
+      m[c] = std::sqrt(ss / nglobal);
+    }
+    for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
+    for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
+    const double cur = std::sqrt(s9);
+    double abs_err = std::fabs(prev - cur);
+    double rel_err = abs_err / (small + cur);
+    prev = cur;
+    if (residual_est) {   // update_cg(gamma, gamma0)  F:14397-14401
+      abs_err = std::sqrt(gamma);
+      rel_err = std::sqrt(gamma / gamma_0);
+    }
+    if (std::isnan(rel_err) || stop_requested()) {
+      failed = true;
+      break;
+    }
+    for (Solver* s : m_) s->residuals_.push_back(rel_err);
+    bool stop = false, cancelled = false;
+    for (Solver* s : m_) {
+      if (s->cb_ && s->cb_(s->cb_user_)) stop = true;
+      if (s->cancel_) cancelled = true;
+    }
+    if (voting) {
+      double v[2] = {stop ? 1.0 : 0.0, cancelled ? 1.0 : 0.0};
+      vote(v);
+      stop = v[0] != 0.0;
+      cancelled = v[1] != 0.0;
+    }
+    if (a.nranks_ > 1 && !voting) cancelled = false;
+    if (stop) break;
+    if (cancelled) {
+      failed = true;
+      break;
+    }
+    if (iter >= a.opt_.maxiter) break;
+    if (rel_err <= a.opt_.tol || abs_err <= a.opt_.abs_tol) {
+      if (bc_error(E0, S0) <= a.opt_.bc_tol) break;
+    }
+    iter++;
+    dot(3, &Solver::cg_r_, &Solver::cg_p_, &Solver::cg_w_, -alpha, kSlotMean, 1);   // r -= alpha (p - w) ; r:r
+    const double delta = a.hscal_[kSlotMean] / nglobal + small;
+    const double beta = delta / gamma;
+    gamma = delta;
+    dot(4, &Solver::cg_p_, &Solver::cg_r_, &Solver::cg_r_, beta, kSlotMean, 0);      // p = r + beta p
+  }
+  for (Solver* s : m_) {
+    s->in_run_ = false;
+    s->iterations_ = iter;
+    s->su_valid_ = false;
+    s->eps_stale_ = false;
   }
   synchronize();
   const double dt = now_seconds() - t_start;

@@ -173,7 +173,8 @@ def test_lone_slab_on_rccl_transport(loopback):
 
 @pytest.mark.parametrize("transport", ["callback", "rccl"])
 @pytest.mark.parametrize("nproc,grid,mixing,split", [(2, "8,16,128", "voigt", 0), (2, "8,16,128", "laminate", 1),
-                                                     (4, "16,16,128", "laminate", 0)])
+                                                     (4, "16,16,128", "laminate", 0),
+                                                     (2, "16,16,16", "laminate", 1)])    # strain-space form
 def test_cg_on_slabs_one_rank_per_process(tmp_path, transport, nproc, grid, mixing, split):
     """method = cg over the ranks: the inner products are all-reduced on the device, iteration counts and residual
     histories equal the oracle's CG on every rank"""

@@ -297,8 +297,31 @@ def test_group_cg_equals_single_gpu_cg(P, mixing):
     g.close()
 
 
-def test_group_cg_refuses_what_it_does_not_cover():
-    g = make_group(2, (16, 16, 16), method="cg")     # a grid the tiled sweep does not fit
-    with pytest.raises(RuntimeError, match="displacement space"):
-        g.run(E_LOAD)
+@pytest.mark.parametrize("P,grid,mixing", EXACT)
+def test_group_cg_in_strain_space_matches_oracle(P, grid, mixing):
+    """grids the tiled sweep does not fit: runCGElasticity with 6-component vectors, the operator = one pass of the
+    strain-state pipeline on the slabs"""
+    dims = (1.0, 2.0, 1.5)
+    g = make_group(P, grid, dims, mixing, tol=1e-9, method="cg")
+    o = make_oracle(grid, dims, mixing, tol=1e-9)
+    assert o.run_cg(E_LOAD) is False and g.run(E_LOAD) is False
+    assert g.iterations == o.iterations
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-9
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8
+    assert rel_err(g.mean_stress(), o.mean_stress()) < 1e-9
+    g.close()
+
+
+@pytest.mark.parametrize("P,grid,mixing", [(2, (8, 16, 128), "voigt"), (2, (16, 16, 16), "laminate"), (4, (16, 16, 128), "laminate")])
+def test_group_cg_mixed_bc(P, grid, mixing):
+    Pm = np.zeros((6, 6))
+    Pm[0, 0] = 1.0
+    g = make_group(P, grid, mixing=mixing, tol=1e-9, bc_tol=1e-8, maxiter=400, method="cg")
+    g.set_bc_projector(Pm)
+    o = make_oracle(grid, mixing=mixing, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    E, S = np.array([0.01, 0, 0, 0, 0, 0]), np.zeros(6)
+    assert o.run_cg(E, S, Pm) is False and g.run(E, S) is False
+    assert g.iterations == o.iterations
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8
+    assert np.abs(g.mean_stress()[1:]).max() < 1e-7
     g.close()
