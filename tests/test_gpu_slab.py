@@ -159,8 +159,8 @@ def test_errors():
         m.run(E_LOAD)
     assert m.transport == ""
     m.close()
-    g = make_group(2, (16, 16, 16), method="cg")
-    with pytest.raises(RuntimeError, match="basic scheme"):
+    g = make_group(2, (16, 16, 16), gamma_scheme="collocated")
+    with pytest.raises(RuntimeError, match="staggered Green operator"):
         g.run(E_LOAD)
     assert g.members[0].transport == "local"
     g.close()
