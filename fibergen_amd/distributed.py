@@ -190,6 +190,55 @@ class DistributedLSSolver(SlabMember):
         values[:] = acc.numpy()
 
 
+class GlobalViewSolver(DistributedLSSolver):
+    """A DistributedLSSolver that looks like ONE LSSolver to the project layer (`FG.decompose_slabs`): global arrays in
+    (every rank passes the whole field, its x-slab is cut out here), global arrays out (`get_field` gathers the slabs on
+    every rank -- meant for results of moderate size), scalars are collective anyway.  Load stepping is not available on
+    slabs: the standard list [0, 1] is one plain run."""
+
+    @property
+    def shape(self):
+        return (self.nx_global, self.ny, self.nz)
+
+    @property
+    def local_shape(self):
+        return (self.nx, self.ny, self.nz)
+
+    def set_phase(self, p, mu, lam, phi=None):
+        self._check(self._lib.fg_set_phase(self._h, int(p), float(mu), float(lam),
+                                           None if phi is None else self.slab(np.asarray(phi, dtype=np.float64)).ctypes.data_as(_lib.c_double_p)))
+
+    def set_normals(self, normals):
+        n = self.slab(np.asarray(normals, dtype=np.float64))
+        self._check(self._lib.fg_set_normals(self._h, n.ctypes.data_as(_lib.c_double_p)))
+
+    def _gather(self, local):
+        if self.nranks == 1:
+            return local
+        parts = [None] * self.nranks
+        self._dist.all_gather_object(parts, local, group=self.group)
+        return np.concatenate(parts, axis=1)
+
+    def get_field(self, name):
+        nc = self._lib.fg_field_components(self._h, name.encode())
+        out = np.empty((nc,) + self.local_shape)
+        self._check(self._lib.fg_get_field(self._h, name.encode(), out.ctypes.data_as(_lib.c_double_p)))
+        return self._gather(out)
+
+    def set_field(self, name, value):
+        v = self.slab(np.ascontiguousarray(value, dtype=np.float64))
+        self._check(self._lib.fg_set_field(self._h, name.encode(), v.ctypes.data_as(_lib.c_double_p)))
+
+    def run_load_steps(self, E, S=None, params=(0.0, 1.0), first=None, step_callback=None):
+        params = list(params)
+        if len(params) != 2 or params[0] != 0.0 or params[1] != 1.0:
+            raise RuntimeError("load stepping is not available on slab-decomposed solvers")
+        failed = self.run(E, S)
+        if step_callback is not None and step_callback(1):
+            return True
+        return failed
+
+
 class SlabGroup:
     """All P slabs of one problem in this process on ONE GPU (fg_slab_group_create).  Global arrays in and out;
     every collective call drives all members through the same steps the multi-GPU run executes."""

@@ -50,6 +50,8 @@ class FG:
         self._device = device
         self._shard = False
         self._shard_group = None
+        self._slabs = False
+        self._slab_group = None
         self._project = XMLProject()
         self._variables = {}
         self._py_enabled = True
@@ -198,6 +200,17 @@ class FG:
         self._shard = bool(enable)
         self._shard_group = group
 
+    def decompose_slabs(self, enable=True, group=None):
+        """Extension of the reference API for multi-GPU jobs (one process per GPU, torch.distributed initialised, this FG
+        created with device = LOCAL_RANK): the voxel grid of every load case is cut into x-slabs over the ranks
+        (fibergen_amd.distributed.DistributedLSSolver: RCCL all-to-all between the FFT axes, halo planes, all-reduced
+        norms).  Every rank runs the same project and sees the same results; fields returned by get_field are gathered.
+        nx and ny must be divisible by the number of ranks; no <loadsteps>."""
+        self._slabs = bool(enable)
+        self._slab_group = group
+        self._solver_valid = False
+        self._phase_valid = False
+
     def _load_case_shard(self):
         if not getattr(self, "_shard", False):
             return 0, 1
@@ -273,7 +286,13 @@ class FG:
         if scalar and mixing != "voigt":
             raise RuntimeError("mixing rule '%s' is not available in %s mode (voigt only)" % (mixing, mode))
 
-        lss = LSSolver(nx, ny, nz, dx, dy, dz, device=self._device)
+        if getattr(self, "_slabs", False):
+            from .distributed import GlobalViewSolver
+            if mode != "elasticity" or scheme != "staggered":
+                raise RuntimeError("slab decomposition runs the elasticity mode with the staggered Green operator")
+            lss = GlobalViewSolver(nx, ny, nz, dx, dy, dz, group=getattr(self, "_slab_group", None), device=self._device)
+        else:
+            lss = LSSolver(nx, ny, nz, dx, dy, dz, device=self._device)
         opts = {"mode": mode, "mixing_rule": mixing, "method": method, "gamma_scheme": scheme, "error_estimator": est}
         # <loadsteps>  F:15095-15119: a count (uniform steps i / n) or a list of <loadstep param=".."/>
         self._loadsteps = [0.0, 1.0]

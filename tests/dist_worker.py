@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--stop-rank", type=int, default=-1, help="only this rank installs a convergence callback ...")
     ap.add_argument("--stop-iter", type=int, default=0, help="... which asks to stop in this iteration")
+    ap.add_argument("--cancel-rank", type=int, default=-1,
+                    help="this rank calls fg_cancel from another thread a little while into an endless run (tol 0)")
     ap.add_argument("--bad-rank", type=int, default=-1,
                     help="laminate mixing: this rank's slab gets one voxel with THREE phases (a device-side error that only "
                          "this rank sees locally)")
@@ -162,6 +164,23 @@ def main():
         fg.shard_load_cases(True)
         rc = fg.run()
         np.savez(a.out + ".%d.npz" % rank, rc=rc, C=np.array(fg.get_effective_property()))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if a.backend == "fg-slabs":
+        # ONE project, its grid cut into x-slabs over the ranks behind the FG interface (FG.decompose_slabs)
+        from fibergen_amd import FG
+        if a.transport == "rccl":
+            os.environ["FG_SLAB_TRANSPORT"] = "rccl"
+        fg = FG(device=0)
+        fg.set_xml("""<settings><solver nx="%d" ny="%d" nz="%d"><tol>%g</tol><method>%s</method><mixing_rule>%s</mixing_rule>
+          <materials><matrix E="1" nu="0.3" /><inclusion E="10" nu="0.2" /></materials></solver>
+          <actions><select_material name="inclusion" /><place_fiber R="0.3" /><init_phase normals="1" /><calc_effective_properties /></actions>
+        </settings>""" % (grid + (a.tol, a.method, a.mixing)))
+        fg.decompose_slabs(True)
+        rc = fg.run()
+        np.savez(a.out + ".%d.npz" % rank, rc=rc, C=np.array(fg.get_effective_property()), eps=fg.get_field("epsilon"),
+                 vf=fg.get_volume_fraction("inclusion"), residuals=np.array(fg.get_residuals()))
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -207,6 +226,11 @@ def main():
             calls.append(1)
             return len(calls) >= a.stop_iter
         s.set_convergence_callback(cb)
+    if a.cancel_rank >= 0:
+        s.set_options(tol=-1.0, abs_tol=-1.0, maxiter=2000000)   # never converged: only the cancellation ends the run
+        if a.cancel_rank == rank:
+            import threading
+            threading.Timer(1.5, s.cancel).start()
     error = ""
     failed = None
     try:

@@ -210,3 +210,42 @@ def test_rccl_ranks_at_128_cubed_equal_single_gpu_solver(tmp_path, nproc, mixing
     assert rel_err(eps, s.get_field("epsilon")) < 1e-10
     assert rel_err(res[0]["mean_stress"], s.mean_stress()) < 1e-11
     s.close()
+
+
+@pytest.mark.parametrize("transport", ["callback", "rccl"])
+@pytest.mark.parametrize("method", ["basic", "cg"])
+def test_cancel_on_one_rank_stops_every_rank(tmp_path, transport, method):
+    """fg_cancel from another thread on rank 1 only, in a run that would never stop (tol 0): the request travels with the flag
+    word of the next reduction, every rank leaves the loop in the same pass and reports failure like the reference's
+    cancelled run (F:21206)."""
+    args = ("--backend", "hip", "--grid", "8,16,128", "--cancel-rank", "1", "--method", method)
+    res = (launch_rccl(2, str(tmp_path / "x"), *args) if transport == "rccl" else launch(2, str(tmp_path / "x"), *args))
+    assert bool(res[0]["failed"]) and bool(res[1]["failed"])
+    assert int(res[0]["iterations"]) == int(res[1]["iterations"]) > 3
+    assert np.array_equal(res[0]["residuals"], res[1]["residuals"])
+
+
+@pytest.mark.parametrize("nproc,grid,mixing,method,transport", [(2, "8,16,128", "voigt", "cg", "callback"),
+                                                                (2, "8,16,128", "laminate", "basic", "rccl"),
+                                                                (4, "16,16,16", "voigt", "cg", "callback")])
+def test_fg_project_on_slabs(tmp_path, nproc, grid, mixing, method, transport):
+    """FG.decompose_slabs: the project interface on top of the slab driver -- one XML project, its voxel grid cut into
+    x-slabs over the ranks (north_star: 'behind the same ... XML project interface ... slab-decomposed across the GPUs').
+    Every rank obtains the effective stiffness, gathered fields and scalars one process computes alone."""
+    from fibergen_amd import FG
+    g = [int(v) for v in grid.split(",")]
+    args = ("--backend", "fg-slabs", "--grid", grid, "--mixing", mixing, "--method", method, "--tol", "1e-8")
+    res = launch_rccl(nproc, str(tmp_path / "f"), *args) if transport == "rccl" else launch(nproc, str(tmp_path / "f"), *args)
+    fg = FG()
+    fg.set_xml("""<settings><solver nx="%d" ny="%d" nz="%d"><tol>1e-8</tol><method>%s</method><mixing_rule>%s</mixing_rule>
+      <materials><matrix E="1" nu="0.3" /><inclusion E="10" nu="0.2" /></materials></solver>
+      <actions><select_material name="inclusion" /><place_fiber R="0.3" /><init_phase normals="1" /><calc_effective_properties /></actions>
+    </settings>""" % (g[0], g[1], g[2], method, mixing))
+    assert fg.run() == 0
+    C = np.array(fg.get_effective_property())
+    for r in res:
+        assert int(r["rc"]) == 0
+        assert np.array_equal(r["C"], res[0]["C"]) and rel_err(r["C"], C) < 1e-9
+        assert r["eps"].shape == (6, g[0], g[1], g[2]) and rel_err(r["eps"], fg.get_field("epsilon")) < 1e-8
+        assert float(r["vf"]) == pytest.approx(fg.get_volume_fraction("inclusion"), rel=1e-13)
+        assert len(r["residuals"]) == len(fg.get_residuals())
