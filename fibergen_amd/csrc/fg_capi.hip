@@ -300,8 +300,8 @@ int fg_run_load_steps(fg_solver* s, const double* E6, const double* S6, const do
                       fg_loadstep_callback cb, void* user, int* failed) {
   return guarded(s, [&](fg::Solver& v) {
     if (!E6 || !params) throw std::runtime_error("NULL argument");
-    if (v.is_slab()) throw std::runtime_error("load stepping is not available on slab-decomposed solvers");
-    const bool f = v.run_load_steps(E6, S6, params, nparams, first, cb, user);
+    const bool f = v.is_slab() ? v.slab_group().run_load_steps(E6, S6, params, nparams, first, cb, user)
+                               : v.run_load_steps(E6, S6, params, nparams, first, cb, user);
     if (failed) *failed = f ? 1 : 0;
   });
 }

@@ -26,9 +26,12 @@ class SlabGroup {
   void set_members(std::vector<Solver*> members) { m_ = std::move(members); }
   void invalidate() { m_.clear(); }   // a member is being destroyed: the group must not be driven any more
 
-  bool run(const double* E6, const double* S6);     // collective LSSolver::run; true = failed
-  bool run_cg(const double* E6, const double* S6);  // ... with method = cg (runCGElasticity F:23153-23247): displacement space
-                                                    // where the fast path applies, strain space otherwise
+  bool run(const double* E6, const double* S6);     // collective LSSolver::run (one load step); true = failed
+  // runLoadsteppingSolver  F:21584-21685: steps first .. nparams-1 with params[i] * (E6, S6), each continuing from the one
+  // before; basic scheme or CG (runCGElasticity F:23153-23247: displacement space where the fast path applies, strain
+  // space otherwise)
+  bool run_load_steps(const double* E6, const double* S6, const double* params, int nparams, int first, LoadstepCallback step_cb,
+                      void* user);
   void iterate(const double* E6, int n);            // n passes without the stop rule (bench, profiling)
   void mean_stress(double* out6);
   void mean_strain(double* out6);
@@ -41,7 +44,10 @@ class SlabGroup {
   bool fast_ok(bool allow_mixed_bc) const;
   void pass_fast(const double* E_cur, bool sum_tau, bool chain);       // steps 0..9 (chain: the speculative chain included)
   void pass_fast_chain();                                              // steps 1..9
-  bool run_cg_strain(const double* E0, const double* S0);
+  bool run_step(const double* E0, const double* S0, bool fresh);
+  bool run_cg(const double* E0, const double* S0, bool fresh);
+  bool run_cg_strain(const double* E0, const double* S0, double prev0);
+  double current_norm9();
   bool agree_on_voting();                                              // does any rank carry a convergence callback?
   bool stop_requested() const;                                         // reduced flag word: some rank was cancelled
   void vote(double* v2);                                               // sums of two host values over the ranks

@@ -753,14 +753,24 @@ void SlabGroup::iterate(const double* E6, int n) {
 
 // LSSolver::run F:21247-21398 -> runLoadsteppingSolver (one load step) -> runBasic F:21716-21805, stop rule of
 // _converged F:21177-21244 -- the collective counterpart of Solver::run
+// runLoadsteppingSolver  F:21584-21685 on the slabs: step i prescribes params[i] * (E, S) and continues from the field of step
+// i - 1 (no extrapolation); LSSolver::run is the one-step case.
 bool SlabGroup::run(const double* E6, const double* S6) {
+  const double one = 1.0;
+  return run_load_steps(E6, S6, &one, 1, 0, nullptr, nullptr);
+}
+
+bool SlabGroup::run_load_steps(const double* E6, const double* S6, const double* params, int nparams, int first,
+                               LoadstepCallback step_cb, void* user) {
   check_members();
   Solver& a = *m_[0];
-  if (a.opt_.method == 1) return run_cg(E6, S6);
-  double E0[6], S0[6];
+  if (nparams < 1 || first < 0 || !params) throw std::runtime_error("invalid load steps");
+  if (a.opt_.loadstep_extrapolation_order > 0 && nparams - first > 1)
+    throw std::runtime_error("load-step extrapolation is not available on slab-decomposed solvers");
+  double Emax[6], Smax[6];
   for (int i = 0; i < 6; ++i) {
-    E0[i] = E6[i];
-    S0[i] = S6 ? S6[i] : 0.0;
+    Emax[i] = E6[i];
+    Smax[i] = S6 ? S6[i] : 0.0;
   }
   for (Solver* s : m_) {
     FG_HIP_CHECK(hipSetDevice(s->device_));
@@ -770,23 +780,65 @@ bool SlabGroup::run(const double* E6, const double* S6) {
   {
     const double se = std::sqrt(kEps);
     double t[6];
-    voigt_mv(a.BC_P_, S0, t);
-    if (norm2(t, 6) > se * norm2(S0, 6)) throw std::runtime_error("Incompatible stress boundary condition specified");
-    voigt_mv(a.BC_Q_, E0, t);
-    if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
+    voigt_mv(a.BC_P_, Smax, t);
+    if (norm2(t, 6) > se * norm2(Smax, 6)) throw std::runtime_error("Incompatible stress boundary condition specified");
+    voigt_mv(a.BC_Q_, Emax, t);
+    if (norm2(t, 6) > se * norm2(Emax, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
   }
+  for (int istep = first; istep < nparams; ++istep) {
+    double E[6], S[6];
+    for (int i = 0; i < 6; ++i) E[i] = params[istep] * Emax[i], S[i] = params[istep] * Smax[i];
+    const bool fresh = istep == first;
+    const bool failed = a.opt_.method == 1 ? run_cg(E, S, fresh) : run_step(E, S, fresh);
+    if (failed) return true;
+    if (step_cb && step_cb(user, istep)) return true;   // "Loadstep callback break request."
+  }
+  return false;
+}
+
+// norm of the strain field a continuing step finds (EpsilonErrorEstimator constructor  F:14612-14618), all ranks
+double SlabGroup::current_norm9() {
+  prepare();
+  for (Solver* s : m_) {
+    if (s->su_valid_ && s->eps_stale_) s->slab_materialise_eps();
+    launch_sum6(s->g_, s->ptrs6(s->eps_), true, s->partial_, s->dscal_ + kSlotMean, s->stream_);
+  }
+  reduce_and_fetch(kSlotMean, 6, false);
+  double s9 = 0.0;
+  for (int c = 0; c < 6; ++c) {
+    const double m = std::sqrt(m_[0]->hscal_[kSlotMean + c] / (double)m_[0]->nglobal_);
+    s9 += m * m * ((c >= 3) ? 2.0 : 1.0);
+  }
+  return std::sqrt(s9);
+}
+
+// runSolver / runBasic  F:21400-21433, F:21716-21805 for one load step, stop rule of _converged F:21177-21244 -- the
+// collective counterpart of Solver::run_one_step
+bool SlabGroup::run_step(const double* E0, const double* S0, bool fresh) {
+  Solver& a = *m_[0];
   const double t_start = now_seconds();
   prepare();
-  bool fast = fast_ok(true);
-  for (Solver* s : m_) {
-    FG_HIP_CHECK(hipMemsetAsync(s->eps_, 0, 6 * (size_t)s->g_.n * sizeof(double), s->stream_));   // F:21379
-    s->comm_wait(kXHaloU);
-    FG_HIP_CHECK(hipMemsetAsync(s->su_[s->su_cur_], 0, 3 * (size_t)s->ucs_ * sizeof(double), s->stream_));   // u_1 = 0 (eps_1 = E)
-    s->su_valid_ = fast;
-    s->eps_stale_ = fast;
-    s->in_run_ = true;
-    for (int i = 0; i < 6; ++i) s->E_cur_[i] = E0[i];
+  const bool fast_allowed = fast_ok(true);
+  bool fast = fast_allowed;
+  double prev = 0.0;   // EpsilonErrorEstimator  F:14591-14637: norms of the field the step starts from
+  if (fresh) {
+    for (Solver* s : m_) {
+      FG_HIP_CHECK(hipMemsetAsync(s->eps_, 0, 6 * (size_t)s->g_.n * sizeof(double), s->stream_));   // F:21379
+      s->comm_wait(kXHaloU);
+      FG_HIP_CHECK(hipMemsetAsync(s->su_[s->su_cur_], 0, 3 * (size_t)s->ucs_ * sizeof(double), s->stream_));   // u_1 = 0 (eps_1 = E)
+      s->su_valid_ = fast;
+      s->eps_stale_ = fast;
+      for (int i = 0; i < 6; ++i) s->E_cur_[i] = E0[i];
+    }
+  } else {
+    prev = current_norm9();
   }
+  for (Solver* s : m_) s->in_run_ = true;
+  // a continuing step in the displacement loop: the state is u of the previous load (eps = E_old + sym grad u); one
+  // unrecorded pass turns it into u' with eps' = E_new + sym grad u', the field the reference's first iteration of the step
+  // produces (Solver::run_one_step)
+  bool carry = !fresh && fast;
+  for (Solver* s : m_) carry = carry && s->su_valid_;
 
   // Stop decisions are collective.  Callbacks may be installed on some ranks only (rank 0 printing its progress) and may
   // answer differently; whether any rank has one is agreed once per run, and if so every pass ends with a vote on the
@@ -795,7 +847,6 @@ bool SlabGroup::run(const double* E6, const double* S6) {
   // travels with the flag word of the next pass's reduction.
   const bool voting = agree_on_voting();
 
-  double prev = 0.0;   // EpsilonErrorEstimator  F:14591-14637: norms of the zero field at construction
   long iter = 1;
   bool update_ref = a.opt_.update_ref != 0;
   double E[6], E_next[6];
@@ -816,18 +867,35 @@ bool SlabGroup::run(const double* E6, const double* S6) {
       if (fast) prepare();   // effective moduli are independent of the reference material, but may not exist yet
     }
     const bool mixed_bc = !(frobenius(a.BC_MQ_) < kEps);
+    if (carry) {
+      carry = false;
+      if (mixed_bc) {
+        fast = false;   // the correction of the prescribed mean needs <tau> of the old field: strain-state passes for this step
+      } else {
+        pass_fast(a.E_cur_, false, true);
+        for (Solver* s : m_) {
+          s->slab_adopt(E, true);
+          s->eps_stale_ = true;
+        }
+      }
+    }
     bool all_u = true;
     for (Solver* s : m_) all_u = all_u && s->su_valid_;
     bool pending = false;
     if (fast && all_u) {
-      if (iter == 1)
+      if (iter == 1 && fresh)
         for (Solver* s : m_)
           for (int i = 0; i < 6; ++i) s->E_cur_[i] = E[i];   // eps_1 = E (u_1 = 0)
       pass_fast(a.E_cur_, mixed_bc, !voting);
       pending = true;
     } else {
-      fast = false;
       pass_exact(E, mixed_bc);
+      // the pass leaves a displacement unless the projector's correction went into the strain: go on in displacement space
+      // after the unrecorded pass of a continuing state (carry)
+      bool have_u = fast && !mixed_bc;
+      for (Solver* s : m_) have_u = have_u && s->su_valid_;
+      if (have_u) carry = true;
+      else fast = false;
     }
     wait_norms();
     for (int i = 0; i < 6; ++i) E_next[i] = E[i];
@@ -907,30 +975,19 @@ bool SlabGroup::run(const double* E6, const double* S6) {
 // valid without any further exchange: per iteration the only traffic beyond the operator's own (two all-to-alls, halo of
 // u_w) are two all-reduces, p:(p - w) and the seven sums of the stop rule (norms of eps, r:r) -- innerProductL2
 // F:20955-21038 with the partial sums of the slabs added in rank order by the transport.
-bool SlabGroup::run_cg(const double* E6, const double* S6) {
+bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
   Solver& a = *m_[0];
   double E0[6], S0[6];
   for (int i = 0; i < 6; ++i) {
     E0[i] = E6[i];
     S0[i] = S6 ? S6[i] : 0.0;
   }
-  for (Solver* s : m_) {
-    FG_HIP_CHECK(hipSetDevice(s->device_));
-    s->slab_reset_state();
-    s->recompute_bc();
-  }
-  {
-    const double se = std::sqrt(kEps);
-    double t[6];
-    voigt_mv(a.BC_P_, S0, t);
-    if (norm2(t, 6) > se * norm2(S0, 6)) throw std::runtime_error("Incompatible stress boundary condition specified");
-    voigt_mv(a.BC_Q_, E0, t);
-    if (norm2(t, 6) > se * norm2(E0, 6)) throw std::runtime_error("Incompatible strain boundary condition specified");
-  }
   prepare();
+  // CG restarts every step from eps = E (F:23184); only the estimator remembers the field the step found (F:14612-14618)
+  const double prev0 = fresh ? 0.0 : current_norm9();
   // mixed boundary conditions, grids the tiled sweep does not fit, u_loop < 2: the strain-space form (the vectors of
   // runCGElasticity as 6-component fields, the operator = one pass of the strain-state pipeline)
-  if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_Q_) < kEps) || !fast_ok(false)) return run_cg_strain(E0, S0);
+  if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_Q_) < kEps) || !fast_ok(false)) return run_cg_strain(E0, S0, prev0);
   const double t_start = now_seconds();
   if (a.opt_.update_ref) {
     calc_ref_material();
@@ -995,7 +1052,7 @@ bool SlabGroup::run_cg(const double* E6, const double* S6) {
     wait_norms();
     gamma_cur = gamma_0 = a.hscal_[kSlotCg + 6] / nglobal + small;
   }
-  double prev = 0.0;   // estimator constructed on the zeroed field the run starts from
+  double prev = prev0;   // estimator constructed on the field the step starts from
   long iter = 0;
   bool failed = false, applied = false;
   for (;;) {
@@ -1092,7 +1149,7 @@ bool SlabGroup::run_cg(const double* E6, const double* S6) {
 // Krylov operator eps -> -Gamma0 (C - C0) eps (krylovOperator F:20583-20587: one basicScheme pass with E = 0, mixed-BC
 // projector included) as one pass of the strain-state pipeline on a work field, the inner products all-reduced, alpha and
 // beta on the host -- the collective counterpart of Solver::run_cg.  Any configuration the slab driver runs.
-bool SlabGroup::run_cg_strain(const double* E0, const double* S0) {
+bool SlabGroup::run_cg_strain(const double* E0, const double* S0, double prev0) {
   Solver& a = *m_[0];
   const double t_start = now_seconds();
   const bool residual_est = a.opt_.error_estimator == 1;
@@ -1150,7 +1207,7 @@ bool SlabGroup::run_cg_strain(const double* E0, const double* S0) {
   const double gamma_0 = gamma;
   for (Solver* s : m_)
     FG_HIP_CHECK(hipMemcpyAsync(s->cg_p_, s->cg_r_, 6 * (size_t)s->g_.n * sizeof(double), hipMemcpyDeviceToDevice, s->stream_));
-  double prev = 0.0;
+  double prev = prev0;
   long iter = 0;
   bool failed = false;
   for (;;) {

@@ -193,8 +193,7 @@ class DistributedLSSolver(SlabMember):
 class GlobalViewSolver(DistributedLSSolver):
     """A DistributedLSSolver that looks like ONE LSSolver to the project layer (`FG.decompose_slabs`): global arrays in
     (every rank passes the whole field, its x-slab is cut out here), global arrays out (`get_field` gathers the slabs on
-    every rank -- meant for results of moderate size), scalars are collective anyway.  Load stepping is not available on
-    slabs: the standard list [0, 1] is one plain run."""
+    every rank -- meant for results of moderate size), scalars are collective anyway."""
 
     @property
     def shape(self):
@@ -228,15 +227,6 @@ class GlobalViewSolver(DistributedLSSolver):
     def set_field(self, name, value):
         v = self.slab(np.ascontiguousarray(value, dtype=np.float64))
         self._check(self._lib.fg_set_field(self._h, name.encode(), v.ctypes.data_as(_lib.c_double_p)))
-
-    def run_load_steps(self, E, S=None, params=(0.0, 1.0), first=None, step_callback=None):
-        params = list(params)
-        if len(params) != 2 or params[0] != 0.0 or params[1] != 1.0:
-            raise RuntimeError("load stepping is not available on slab-decomposed solvers")
-        failed = self.run(E, S)
-        if step_callback is not None and step_callback(1):
-            return True
-        return failed
 
 
 class SlabGroup:
@@ -289,6 +279,9 @@ class SlabGroup:
     # collective calls: any member drives the group
     def run(self, E, S=None):
         return self.members[0].run(E, S)
+
+    def run_load_steps(self, E, S=None, params=(0.0, 1.0), first=None, step_callback=None):
+        return self.members[0].run_load_steps(E, S, params, first, step_callback)
 
     def iterate(self, E, n):
         self.members[0].iterate(E, n)

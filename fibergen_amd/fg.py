@@ -205,7 +205,7 @@ class FG:
         created with device = LOCAL_RANK): the voxel grid of every load case is cut into x-slabs over the ranks
         (fibergen_amd.distributed.DistributedLSSolver: RCCL all-to-all between the FFT axes, halo planes, all-reduced
         norms).  Every rank runs the same project and sees the same results; fields returned by get_field are gathered.
-        nx and ny must be divisible by the number of ranks; no <loadsteps>."""
+        nx and ny must be divisible by the number of ranks; <loadsteps> without extrapolation."""
         self._slabs = bool(enable)
         self._slab_group = group
         self._solver_valid = False

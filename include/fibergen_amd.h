@@ -110,7 +110,7 @@ int fg_run_load_case(fg_solver* s, const double* E6, const double* S6, int* fail
  * which then reports failure like the reference.  fg_run_load_case is the standard list {0, 1} with first = 1
  * (F:21591).  Option loadstep_extrapolation_order (int, 0..7; F:14696, default 0): from the second step on a step starts
  * from the polynomial through the converged strain fields of the last order + 1 steps (extrapolateLoadstepPolynomial
- * F:21468-21514; single-GPU solvers). */
+ * F:21468-21514; single-GPU solvers).  Slab-decomposed solvers: collective, basic scheme and CG, no extrapolation. */
 typedef int (*fg_loadstep_callback)(void* user, int istep);
 int fg_run_load_steps(fg_solver* s, const double* E6, const double* S6, const double* params, int nparams, int first,
                       fg_loadstep_callback cb, void* user, int* failed);

@@ -325,3 +325,42 @@ def test_group_cg_mixed_bc(P, grid, mixing):
     assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8
     assert np.abs(g.mean_stress()[1:]).max() < 1e-7
     g.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# load stepping on the slabs (runLoadsteppingSolver F:21584-21685): every step continues from the field of the one before
+@pytest.mark.parametrize("P,grid,mixing,method", [
+    (1, (8, 16, 128), "voigt", "basic"), (2, (8, 16, 128), "voigt", "basic"), (4, (16, 16, 128), "laminate", "basic"),   # displacement loop
+    (2, (16, 16, 16), "voigt", "basic"), (2, (32, 16, 64), "laminate", "basic"),                                          # strain-state pipeline
+    (2, (8, 16, 128), "laminate", "cg"), (2, (16, 16, 16), "voigt", "cg"),
+])
+def test_group_load_steps_match_oracle(P, grid, mixing, method):
+    E = np.array([1.0, 0.2, 0, 0, 0, 0.5])
+    params = [0.0, 0.25, 0.6, 1.0]
+    g = make_group(P, grid, mixing=mixing, tol=1e-8, method=method)
+    o = make_oracle(grid, mixing=mixing, tol=1e-8)
+    steps, its = [], []
+    assert o.run_load_steps(E, params=params, method=method) is False
+    assert g.run_load_steps(E, params=params, step_callback=lambda i: (steps.append(i), its.append(g.iterations)) and False) is False
+    assert steps == [0, 1, 2, 3] and its == o.step_iterations
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-10
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(g.mean_stress(), o.mean_stress()) < 1e-10
+    g.close()
+
+
+def test_group_load_steps_mixed_bc_and_stop_request():
+    grid = (8, 16, 128)
+    Pm = np.zeros((6, 6))
+    Pm[0, 0] = 1.0
+    g = make_group(2, grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    g.set_bc_projector(Pm)
+    o = make_oracle(grid, tol=1e-9, bc_tol=1e-8, maxiter=400)
+    assert o.run_load_steps([0.01, 0, 0, 0, 0, 0], np.zeros(6), Pm, params=[0.0, 0.5, 1.0]) is False
+    assert g.run_load_steps([0.01, 0, 0, 0, 0, 0], np.zeros(6), params=[0.0, 0.5, 1.0]) is False
+    assert g.iterations == o.iterations
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8
+    seen = []
+    assert g.run_load_steps([0.01, 0, 0, 0, 0, 0], np.zeros(6), params=[0.0, 0.5, 1.0], step_callback=lambda i: seen.append(i) or i == 1) is True
+    assert seen == [0, 1]
+    g.close()
