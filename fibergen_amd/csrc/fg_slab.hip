@@ -1182,7 +1182,12 @@ bool SlabGroup::run_cg_strain(const double* E0, const double* S0, double prev0) 
       s->su_valid_ = false;
       s->eps_stale_ = false;
     }
-    pass_exact(Z.v, mixed_bc);
+    try {
+      pass_exact(Z.v, mixed_bc);
+    } catch (...) {
+      for (Solver* s : m_) std::swap(s->eps_, s->*dst);   // eps_ is the iterate again before the error leaves
+      throw;
+    }
     for (Solver* s : m_) {
       std::swap(s->eps_, s->*dst);
       s->su_valid_ = false;   // the displacement the pass left belongs to the work field, not to eps_

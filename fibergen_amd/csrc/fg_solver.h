@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <memory>
 #include <string>
 #include <vector>
@@ -312,7 +313,7 @@ class Solver {
   double F00_[6];
   ConvergenceCallback cb_ = nullptr;
   void* cb_user_ = nullptr;
-  bool cancel_ = false;
+  std::atomic<bool> cancel_{false};   // set by fg_cancel, possibly from another thread
 
   std::vector<double> residuals_;
   long iterations_ = 0;

@@ -161,8 +161,11 @@ def draw_slab(seed):
         opts["fuse_x"] = int(rng.integers(0, 2))
     if rng.random() < 0.2:
         opts["phi_sweep"] = 0
+    # round 3: CG and load steps on the slabs (drawn last, so the earlier draws of a seed stay what they were)
+    method = "cg" if rng.random() < 0.35 else "basic"
+    steps = [0.0, 0.4, 1.0] if rng.random() < 0.3 else None
     return dict(P=P, shape=shape, dims=dims, mats=mats, phis=phis, normals=normals, mixing=mixing, bc=bc, opts=opts,
-                E=rng.uniform(-1.0, 1.0, size=6))
+                E=rng.uniform(-1.0, 1.0, size=6), method=method, steps=steps)
 
 
 @pytest.mark.parametrize("seed", range(N_SLAB))
@@ -179,15 +182,21 @@ def test_random_slab_group_matches_oracle(seed):
     for p, (m, phi) in enumerate(zip(c["mats"], c["phis"])):
         g.set_phase(p, m[0], m[1], phi)
     g.set_normals(c["normals"])
-    g.set_options(mixing_rule=c["mixing"], **common, **c["opts"])
+    g.set_options(mixing_rule=c["mixing"], method=c["method"], **common, **c["opts"])
     E, S0, P = c["E"].copy(), np.zeros(6), None
     if c["bc"] is not None:
         keep = np.array(PROJECTORS[c["bc"]], dtype=float)
         P = np.diag(keep)
         E = E * (keep > 0)
         g.set_bc_projector(P)
-    tag = "seed %d: %s" % (seed, {k: c[k] for k in ("P", "shape", "mixing", "opts", "bc")})
-    assert o.run(E, S0, P) is False and g.run(E, S0) is False, tag
+    tag = "seed %d: %s" % (seed, {k: c[k] for k in ("P", "shape", "mixing", "opts", "bc", "method", "steps")})
+    if c["steps"] is not None:
+        assert o.run_load_steps(E, S0, P, params=c["steps"], method=c["method"]) is False, tag
+        assert g.run_load_steps(E, S0, params=c["steps"]) is False, tag
+    elif c["method"] == "cg":
+        assert o.run_cg(E, S0, P) is False and g.run(E, S0) is False, tag
+    else:
+        assert o.run(E, S0, P) is False and g.run(E, S0) is False, tag
     assert g.iterations == o.iterations, tag
     assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-9, tag
     assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8, tag
@@ -237,8 +246,17 @@ def test_random_scalar_and_viscosity_problems_match_their_oracles(seed):
         E = c["E"].copy()
         E[:3] -= E[:3].mean()               # the prescribed fluid stress is traceless
         s.set_options(method=c["method"], **common)
-        ref_failed = o.run_cg(E) if c["method"] == "cg" else o.run(E)
-        failed = s.run(E)
+        if c["bc"]:                          # round 3: shear stresses prescribed, normal shear rates zero
+            P6 = np.diag([0.0, 0.0, 0.0, 0.5, 0.5, 0.5])
+            E = E * np.array([0, 0, 0, 1.0, 1.0, 1.0])
+            s.set_bc_projector(P6)
+            s.set_options(bc_tol=1e-8)
+            o.bc_tol = 1e-8
+            ref_failed = o.run_cg(E, np.zeros(6), P6) if c["method"] == "cg" else o.run(E, np.zeros(6), P6)
+            failed = s.run(E, np.zeros(6))
+        else:
+            ref_failed = o.run_cg(E) if c["method"] == "cg" else o.run(E)
+            failed = s.run(E)
     else:
         from oracle.scalar_oracle import ScalarOracle
         o = ScalarOracle(*shape, mus=c["mus"], phis=c["phis"], dx=dims[0], dy=dims[1], dz=dims[2], **common)
