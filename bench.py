@@ -576,6 +576,24 @@ def main():
     devices = [None] * world
     dist.all_gather_object(devices, "%s rank %d: %s" % (socket.gethostname(), rank, pci_bus_id(local_rank)))
 
+    def tune_exchange_mode(solver, E):
+        """Which exchange mode the links of THIS node like better is a measurement, not a guess: a few passes with the three
+        components in one all-to-all (one message per peer; latency-friendly) and with one all-to-all per component
+        overlapping the next component's transforms (bandwidth-friendly), outside the timed region -- like an FFT plan.
+        Every rank sees the same (max over ranks) timings and takes the same decision."""
+        trials = {}
+        for split in (0, 1):
+            solver.set_options(slab_split=split)
+            solver.iterate(E, 2)
+            sync_all(solver)
+            t0 = time.perf_counter()
+            solver.iterate(E, 4)
+            sync_all(solver)
+            trials[split] = max_over_ranks((time.perf_counter() - t0) / 4)
+        best = min(trials, key=trials.get)
+        solver.set_options(slab_split=best)
+        return best, {"one_exchange_for_three_components_ms": 1e3 * trials[0], "exchange_per_component_ms": 1e3 * trials[1]}
+
     replicas = None
     if not args.no_replicas:
         # every rank its own load case (calc_effective_properties' unit strains): no data-path collective
@@ -621,6 +639,7 @@ def main():
         del phi, normals
         d.calc_ref_material()
         E = np.array([1.0, 0, 0, 0, 0, 0])
+        split, split_trials = tune_exchange_mode(d, E)
         dts = timed_regions(lambda k: d.iterate(E, k), lambda: sync_all(d), args.steps, args.warmup, args.repeats)
         med = max_over_ranks(statistics.median(dts))
         lo, hi = max_over_ranks(min(dts)), max_over_ranks(max(dts))
@@ -638,6 +657,7 @@ def main():
             "loop_GBps_Amin": A_MIN_BYTES_PER_VOXEL * N * it_s / 1e9,
             "kernels": kern, "kernel_sum_ms": kernel_table.last_sum_ms, "replicas": replicas,
             "transport": d.transport, "rccl_ranks": world if d.transport == "rccl" else 0,
+            "slab_split": split, "slab_split_trials": split_trials,
             "devices": devices, "distinct_devices": len({x.split(": ")[1] for x in devices}),
             "alltoall_ms": xt["alltoall_fwd"] + xt["alltoall_bwd"], "exchange_ms_per_pass": xt,
             "alltoall_MB_per_gpu_per_pass": 2 * 3 * (world - 1) / world * (args.n // world) * args.n * (args.n // 2 + 1) * 16 / 1e6,
@@ -674,6 +694,7 @@ def main():
                 configure(d2, phi2, normals2, mix, "elasticity")
                 del phi2, normals2
                 d2.calc_ref_material()
+                split2, split_trials2 = tune_exchange_mode(d2, E)
                 steps2 = max(5, args.steps // 2) if ne >= 512 else args.steps
                 dts2 = timed_regions(lambda k: d2.iterate(E, k), lambda: sync_all(d2), steps2, min(args.warmup, 3), 3)
                 med2 = max_over_ranks(statistics.median(dts2))
@@ -682,6 +703,7 @@ def main():
                 line["also_slab"] = {"%d^3 %s" % (ne, mix): {
                     "it_s": steps2 / med2, "ms_per_step": 1e3 * med2 / steps2, "steps": steps2, "repeats": 3,
                     "rve": {"K": par2["K"], "R": par2["R"], "L": par2["L"]}, "transport": d2.transport,
+                    "slab_split": split2, "slab_split_trials": split_trials2,
                     "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern2.items()},
                     "alltoall_ms": xt2["alltoall_fwd"] + xt2["alltoall_bwd"], "exchange_ms_per_pass": xt2,
                     "alltoall_MB_per_gpu_per_pass": 2 * 3 * (world - 1) / world * (ne // world) * ne * (ne // 2 + 1) * 16 / 1e6}}
