@@ -356,7 +356,10 @@ def main():
                          "ONE GPU: all ranks share device 0 and the slab exchanges are staged through the host.  nccl-one-gpu: "
                          "the real RCCL path (torch's process group AND the library's transport) with all ranks on device 0 -- "
                          "every rank poses as a host of its own (NCCL_HOSTID), RCCL connects them over loop-back sockets")
-    args = ap.parse_args()
+    # ranks started by this script's own launcher take their arguments from the environment (torchrun's argparse trips over
+    # abbreviations such as --n before it hands the rest to the script)
+    args = ap.parse_args(json.loads(os.environ["FG_BENCH_ARGV"]) if "FG_BENCH_ARGV" in os.environ and "WORLD_SIZE" in os.environ
+                         else None)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Started plainly: launch the N ranks as fresh processes (torch.distributed.run, one rank per GPU) and relay
@@ -366,8 +369,9 @@ def main():
             port = sock.getsockname()[1]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["FG_BENCH_ARGV"] = json.dumps(sys.argv[1:])
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus)]
         proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
         lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
         for ln in proc.stdout.splitlines():
