@@ -251,6 +251,11 @@ double integrate_voxel(int levels, double tol, double r_voxel0, V3 p, double dx,
 
 }  // namespace
 
+// the cut volume on its own, for the reference's self-tests "halfspace cutting II / III" (F:23829-23862)
+extern "C" double ref_box_cut_volume(const double* x, const double* n, const double* x0, double dx, double dy, double dz) {
+  return box_cut_volume(mk(x[0], x[1], x[2]), mk(n[0], n[1], n[2]), mk(x0[0], x0[1], x0[2]), dx, dy, dz);
+}
+
 extern "C" int ref_voxelize(const ref_fiber* fibers, int nfibers, int nx, int ny, int nz, double dx, double dy, double dz,
                            const double* x0, int nphases, int matrix_mat, int smooth_levels, double smooth_tol,
                            double* phi, double* normals, double* real_volume, char* err, int errlen) {

@@ -674,3 +674,28 @@ def test_rotated_laminate_converges_to_the_rotated_closed_form():
             err[n, mixing] = np.abs(o.calc_effective_properties() - Cl).max() / np.abs(Cl).max()
     assert err[16, "laminate"] < 0.012 and err[16, "laminate"] < 0.6 * err[8, "laminate"]
     assert err[8, "laminate"] < 0.5 * err[8, "voigt"] and err[16, "laminate"] < 0.5 * err[16, "voigt"]
+
+
+@pytest.mark.parametrize("grid,dims", [
+    ((2, 1, 1), (1, 1, 1)),                # F:27261
+    ((41, 33, 11), (1, 1, 1)),             # F:27266
+    ((41, 33, 11), (41, 33, 11)),          # F:27271
+    ((8, 6, 4), (1, 2, 3)),
+])
+def test_heat_staggered_epsG0div_identity(grid, dims):
+    """run_tests_heat's 'staggered epsG0div identity'  F:23940-23973, as the reference runs it: a random 3-component field
+    through GammaOperatorStaggeredHeat (alpha = 1, E = 0) gives a discrete gradient field; C0 : . , divOperatorStaggeredHeat,
+    G0OperatorStaggeredHeat and epsOperatorStaggeredHeat must return it (tolerance sqrt(eps) like check_tol)."""
+    from oracle.scalar_oracle import ScalarOracle
+    nx, ny, nz = grid
+    one = np.ones(grid)
+    o = ScalarOracle(nx, ny, nz, mus=[1.0], phis=[one], dx=dims[0], dy=dims[1], dz=dims[2])
+    mu0 = 1324.3                                            # F:24007-24008
+    rng = np.random.default_rng(4)
+    tau = rng.standard_normal((3, nx, ny, nz))
+    Z = np.zeros(3)
+    org = o.eps_heat(Z, o.g0_heat(mu0, o.div_heat(tau), 1.0))       # GammaOperatorStaggeredHeat(0, ..., alpha = 1)
+    sigma = 2 * mu0 * org                                           # calcStressConst, lambda0 does not enter for dim 3
+    back = o.eps_heat(Z, o.g0_heat(mu0, o.div_heat(sigma), 1.0))
+    diff = np.abs(back - org).reshape(3, -1).max(axis=1)
+    assert np.linalg.norm(diff) <= SQRT_EPS * max(1.0, np.abs(org).max())

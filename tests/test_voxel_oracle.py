@@ -98,3 +98,54 @@ def test_hashin_demo_phase_fractions_and_mean_stress():
     assert np.abs(res["checker"] - 12.9203).max() < 2e-4
     assert np.abs(res["brute force"] - res["checker"]).max() < 2e-4
     assert np.abs(res["checker"] - 12.9152).min() > 4e-3                 # not the demo comment's (binary) value
+
+
+def test_reference_self_tests_of_the_plane_box_cut(tmp_path):
+    """The reference's own known answers for halfspace_box_cut_volume (F:1385-1577), 'halfspace cutting II' and 'III' of
+    run_tests (F:23829-23862), on the checker's restatement AND on the product's closed form (fg_plane_cut.h compiled for the
+    host): II -- axis-aligned planes through a 1 x 2 x 3 box cut off min(max(0, t), dim_j) * area; III -- mirroring the box,
+    the plane and the normal in one axis leaves the cut volume unchanged."""
+    import ctypes
+    import os
+    import subprocess
+    from oracle import voxel_oracle
+    lib = voxel_oracle.load()
+    lib.ref_box_cut_volume.restype = ctypes.c_double
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.ref_box_cut_volume.argtypes = [dp, dp, dp, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "emu_cut.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFG_HOST_EMULATION", "-ffp-contract=off", "-shared", "-fPIC", "-o", so,
+                           os.path.join(root, "tests", "emulate", "emu_cut.cpp")])
+    emu = ctypes.CDLL(so)
+    emu.emu_box_fraction.restype = ctypes.c_double
+    emu.emu_box_fraction.argtypes = [dp, dp, dp]
+    P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+    dim = np.array([1.0, 2.0, 3.0])
+    vol = dim.prod()
+
+    def both(x, n, x0):
+        v_ref = lib.ref_box_cut_volume(P(x), P(n), P(x0), *dim)
+        v_new = emu.emu_box_fraction(P(np.asarray(x) - np.asarray(x0)), P(n), P(dim)) * vol   # plane point relative to the box vertex
+        return v_ref, v_new
+    tol = 10 * np.finfo(float).eps * vol     # check_tol: sqrt(eps) in the reference; both forms are far better
+    for k in range(-10, 30):                  # halfspace cutting II
+        for j in range(3):
+            t = dim[j] * k / 30.0
+            n, x0 = np.zeros(3), np.zeros(3)
+            n[j] = 1.0
+            x0[j] = -t
+            want = min(max(0.0, t), dim[j]) * dim[(j + 1) % 3] * dim[(j + 2) % 3]
+            for v in both(np.zeros(3), n, x0):
+                assert abs(v - want) < tol
+    for k in range(-10, 30):                  # halfspace cutting III
+        for j in range(3):
+            n = np.full(3, 1 / np.sqrt(3))
+            x0 = np.full(3, -2.0 * k / 30.0)
+            a = both(np.zeros(3), n, x0)
+            x0[j] *= -1
+            n[j] *= -1
+            x = np.zeros(3)
+            x[j] += dim[j]
+            b = both(x, n, x0)
+            assert abs(a[0] - b[0]) < tol and abs(a[1] - b[1]) < tol and abs(a[0] - a[1]) < 1e-13 * vol
