@@ -230,6 +230,25 @@ def _hooke_list(E, mu, lam, alpha):
             E[3] * two_mu, E[4] * two_mu, E[5] * two_mu]
 
 
+def sym3_det(H):
+    """SymTensor3x3::det  F:9373-9382, components 11, 22, 33, 23, 13, 12 (element-wise on arrays)."""
+    return (H[0] * (H[1] * H[2] - H[3] * H[3])
+            - H[5] * (H[5] * H[2] - H[3] * H[4])
+            + H[4] * (H[5] * H[3] - H[1] * H[4]))
+
+
+def sym3_inv(H):
+    """SymTensor3x3::inv  F:9483-9488: cofactors times 1/det, the operation order of the reference (the laminate rule's
+    Hessian solve; pinned by the reference's 'symmetric left / right inverse' and 'sym determinant' self-tests F:23669-23736)."""
+    invdet = 1 / sym3_det(H)
+    return [(H[1] * H[2] - H[3] * H[3]) * invdet,
+            (H[0] * H[2] - H[4] * H[4]) * invdet,
+            (H[0] * H[1] - H[5] * H[5]) * invdet,
+            -(H[0] * H[3] - H[4] * H[5]) * invdet,
+            (H[5] * H[3] - H[4] * H[1]) * invdet,
+            -(H[5] * H[2] - H[3] * H[4]) * invdet]
+
+
 def laminate_split(Fbar, n, c1, c2, mat1, mat2, eps_g=LAMINATE_EPS_G, eps_a=LAMINATE_EPS_A):
     """LaminateMixedMaterialLaw::solve_newton for DIM==6  F:13157-13371.
 
@@ -275,17 +294,7 @@ def laminate_split(Fbar, n, c1, c2, mat1, mat2, eps_g=LAMINATE_EPS_G, eps_a=LAMI
         H.append(c1 * _dot9(dP1, dF1[k]) + c2 * _dot9(dP2, dF2[k]))
 
     with np.errstate(divide="ignore", invalid="ignore"):
-        # SymTensor3x3::det / inv  F:9373-9382, F:9483-9488
-        det = (H[0] * (H[1] * H[2] - H[3] * H[3])
-               - H[5] * (H[5] * H[2] - H[3] * H[4])
-               + H[4] * (H[5] * H[3] - H[1] * H[4]))
-        invdet = 1 / det
-        Hi = [(H[1] * H[2] - H[3] * H[3]) * invdet,
-              (H[0] * H[2] - H[4] * H[4]) * invdet,
-              (H[0] * H[1] - H[5] * H[5]) * invdet,
-              -(H[0] * H[3] - H[4] * H[5]) * invdet,
-              (H[5] * H[3] - H[4] * H[1]) * invdet,
-              -(H[5] * H[2] - H[3] * H[4]) * invdet]
+        Hi = sym3_inv(H)
         # Tensor3::mult(SymTensor3x3, Tensor3)  F:9516-9521
         da = [Hi[0] * g[0] + Hi[5] * g[1] + Hi[4] * g[2],
               Hi[5] * g[0] + Hi[1] * g[1] + Hi[3] * g[2],

@@ -699,3 +699,20 @@ def test_heat_staggered_epsG0div_identity(grid, dims):
     back = o.eps_heat(Z, o.g0_heat(mu0, o.div_heat(sigma), 1.0))
     diff = np.abs(back - org).reshape(3, -1).max(axis=1)
     assert np.linalg.norm(diff) <= SQRT_EPS * max(1.0, np.abs(org).max())
+
+
+def test_symmetric_3x3_inverse_and_determinant_self_tests():
+    """run_tests_math  F:23669-23736: 'symmetric left inverse', 'symmetric right inverse', 'sym determinant' -- the cofactor
+    inverse the laminate rule's Newton step solves its 3 x 3 Hessian with (SymTensor3x3::inv / det, F:9373-9382, F:9483-9488)."""
+    from oracle.ls_oracle import sym3_det, sym3_inv
+    rng = np.random.default_rng(8)
+
+    def full(h):
+        return np.array([[h[0], h[5], h[4]], [h[5], h[1], h[3]], [h[4], h[3], h[2]]])
+    for _ in range(50):
+        tau = [float(v) for v in rng.random(6)]      # SymTensor3x3::random: uniform entries
+        ep = sym3_inv(tau)
+        for prod in (full(ep) @ full(tau), full(tau) @ full(ep)):
+            d = prod - np.eye(3)
+            assert (d * d).sum() <= SQRT_EPS * max(1.0, np.abs(full(ep)).max() ** 2)
+    assert sym3_det([1.0, 2.0, 3.0, 0.0, 0.0, 0.0]) - 6 == 0.0
