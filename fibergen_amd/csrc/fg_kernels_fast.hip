@@ -978,8 +978,8 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, do
   const double hx = g.hx, hy = g.hy, hz = g.hz;
   const int nsteps = surplus ? 0 : (x0 + LX <= g.nx ? LX : g.nx - x0);
 
-  auto plane = [&](int q) {
-    const int x = q < 0 ? q + g.nx : (q >= g.nx ? q - g.nx : q);
+  auto plane = [&](int q) {   // x neighbours through Grid::xw_lo / xw_hi (periodic grid: both nx; x-slab: its spare planes)
+    const int x = q < 0 ? q + g.xw_lo : (q >= g.nx ? q - g.xw_hi : q);
     return (long)x * g.nyzp + rowoff;
   };
   auto store_f = [&](long off, double2 v) {

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(kBlock) void k_sc_grad(Grid g, const double* T, Fie
     const PairPos p = pair_pos_tiled(pidx, g, sw);
     if (p.k >= g.nz) continue;
     const bool second = p.k + 1 < g.nz;
-    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    // x neighbour through Grid::xw_hi: periodic in a whole grid, the spare plane of the right neighbour in an x-slab
+    const long xf = (p.i + 1 == g.nx ? (long)(g.nx - g.xw_hi) - p.i : 1L) * g.nyzp;
     const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
     const long ro = p.off - p.k;
     const int k = p.k;

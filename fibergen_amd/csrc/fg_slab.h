@@ -48,6 +48,7 @@ class SlabGroup {
   bool run_cg(const double* E0, const double* S0, bool fresh);
   bool run_cg_strain(const double* E0, const double* S0, double prev0);
   double current_norm9();
+  void require_scalar_fast() const;
   bool agree_on_voting();                                              // does any rank carry a convergence callback?
   bool stop_requested() const;                                         // reduced flag word: some rank was cancelled
   void vote(double* v2);                                               // sums of two host values over the ranks

@@ -157,7 +157,7 @@ bool Solver::slab_split() const {
 bool Solver::slab_interleave() const {
   static const int env = getenv("FG_SLAB_INTERLEAVE") ? atoi(getenv("FG_SLAB_INTERLEAVE")) : -1;
   if (env == 0 || opt_.slab_interleave == 0) return false;
-  if (slab_split() || !(nranks_ > 1 || slab_loopback())) return false;
+  if (slab_split() || !(nranks_ > 1 || slab_loopback()) || opt_.mode != 0) return false;
   const int nxl = g_.nx;
   return fft_ && fft_ys_ && fft_->can_block_y(nranks_) && opt_.fuse_x && nxg_ > 1 && fft_ys_->fast_x() && fft_ys_->can_fuse(0) &&
          nxl > 0 && (nxl & (nxl - 1)) == 0;
@@ -251,6 +251,9 @@ void Solver::slab_fetch_norms(int n) {
 }
 
 bool Solver::slab_fast_ok(bool allow_mixed_bc) const {
+  if (opt_.mode == 1)   // heat / porous: the tiled potential sweep + the fused one-component x pass, prescribed gradients
+    return opt_.u_loop >= 2 && opt_.gamma_scheme == 0 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
+           u_tile_supported(g_) && opt_.fuse_x && fft_ys_ && nxg_ > 1 && fft_ys_->can_fuse(0, 1) && frobenius(BC_MQ_) < kEps;
   if (!(opt_.u_loop >= 2 && opt_.u_tile && opt_.mode == 0 && opt_.gamma_scheme == 0 && pt_.n >= 1 &&
         (opt_.mixing == kMixVoigt || (opt_.mixing == kMixLaminate && normals_)) && opt_.bc_relax == 1.0 && u_tile_supported(g_)))
     return false;
@@ -264,9 +267,15 @@ void Solver::slab_moduli_step() {
   mod.p[1] = smod_ + ucs_;
   // two complementary phases: the sweep reads phi_1 (with its halo planes) and forms the moduli itself.  The decision is
   // local data; every rank of a run sees the same kind of phase fields (normalizePhi output or not)
-  slab_phi_ = two_phase_complementary();
-  if (slab_phi_) FG_HIP_CHECK(hipMemcpyAsync(smod_, phi_ + g_.n, (size_t)g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-  else launch_effective_moduli(g_, phase_table(), phase_ptrs(), mod, stream_);
+  slab_phi_ = opt_.mode == 0 && two_phase_complementary();
+  if (slab_phi_) {
+    FG_HIP_CHECK(hipMemcpyAsync(smod_, phi_ + g_.n, (size_t)g_.n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+  } else {
+    PhaseTable t = phase_table();
+    if (opt_.mode == 1)   // scalar modes: k_effective_moduli stores sum phi 2 mu, the sweep wants the conductivity sum phi mu
+      for (int q = 0; q < kMaxPhases; ++q) t.mu[q] = 0.5 * pt_.mu[q], t.lambda[q] = 0.0;
+    launch_effective_moduli(g_, t, phase_ptrs(), mod, stream_);
+  }
   slab_exchange(FG_PLAN_HALO_MODULI, 0, kXModuli);
   smod_dirty_ = false;
 }
@@ -283,6 +292,14 @@ void Solver::slab_front_fast(const double* E6, bool sum_tau, const double* u_src
   mod.p[0] = smod_;
   mod.p[1] = smod_ + ucs_;
   time_begin(0);
+  if (opt_.mode == 1) {
+    // heat / porous: T_k (component 0 of the displacement buffer, with its halo planes) -> sums of squares of g_k = E + grad T_k,
+    // f = div((a - 2 mu0) g_k)
+    launch_sc_sweep_fast(gu_, opt_.mu_0, u_in, smod_, fu_, E, partial_, dscal_ + kSlotSumSq, stream_);
+    time_end(0);
+    if (reduce) slab_reduce(kSlotSumSq, 6, false);
+    return;
+  }
   const bool laminate = opt_.mixing == kMixLaminate;
   if (laminate) {
     // laminate mixing = the Voigt sweep + the divergence of d = tau_laminate - tau_voigt on the interface voxels (see
@@ -304,7 +321,7 @@ void Solver::slab_front_fast(const double* E6, bool sum_tau, const double* u_src
 
 // second step of the sweep with laminate mixing: div d of the own interface voxels and of the neighbours' boundary planes
 void Solver::slab_front_laminate(bool sum_tau, bool reduce) {
-  if (opt_.mixing != kMixLaminate) return;
+  if (opt_.mixing != kMixLaminate || opt_.mode != 0) return;
   launch_delta_div(g_, aff_list_, aff_slots_, aff_n_, dtau_, ptrs3(fu_), stream_);
   comm_wait(kXHaloTau);
   launch_delta_div_halo(g_, halo_[2], halo_[3], ptrs3(fu_), stream_);
@@ -337,7 +354,8 @@ void Solver::slab_chain_step(int k) {
   const bool blocked = fft_->can_block_y(nranks_);
   // Large slabs are bandwidth bound on the links: component c's all-to-all overlaps the transforms of c + 1.  Small
   // slabs are latency bound (launches, RCCL start-up): the three components go through every stage together.
-  const bool split = slab_split();
+  const int NC = opt_.mode == 1 ? 1 : 3;   // heat / porous: one potential
+  const bool split = slab_split() && NC == 3;
   const bool inter = slab_interleave();   // batched mode, one message per peer: blocks of three components
   const SlabDims sd = slab_dims(nxg_, g_.ny, g_.nz, nranks_, rank_);
   auto forward = [&](int c0, int nc) {   // z r2c and y c2c (into the all-to-all layout) of components c0 .. c0 + nc - 1
@@ -381,8 +399,8 @@ void Solver::slab_chain_step(int k) {
       forward(k - 1, 1);
       slab_exchange(FG_PLAN_A2A_FORWARD, k - 1, kXA2AFwd + k - 1);
     } else if (k == 1) {
-      forward(0, 3);
-      slab_exchange(FG_PLAN_A2A_FORWARD, -1, kXA2AFwd);
+      forward(0, NC);
+      slab_exchange(FG_PLAN_A2A_FORWARD, NC == 1 ? 0 : -1, kXA2AFwd);
     }
   } else if (k == 4) {
     for (int c = 0; c < 3; ++c) comm_wait(kXA2AFwd + c);
@@ -399,7 +417,12 @@ void Solver::slab_chain_step(int k) {
     }
     const int jj0 = rank_ * nyl_;   // this rank's ky rows
     time_begin(5);
-    if (inter) {
+    if (NC == 1) {
+      // G0OperatorFourierStaggeredHeat  F:19758-19823: c1 = c10 / |k|^2, c10 = -alpha / (2 mu0), inside the fused x pass
+      gp.c10 = -alpha / (2 * opt_.mu_0);
+      gp.c20 = 0.0;
+      fft_ys_->fused_g0(R, n, 0, scale, gp, jj0, 1);
+    } else if (inter) {
       // y-slab [p][c][nxl][nyl][nzc]: component stride one block, x plane j at j * ls + (j / nxl) * 2 blocks
       int sh = 0;
       while ((1 << sh) < g_.nx) ++sh;
@@ -414,7 +437,7 @@ void Solver::slab_chain_step(int k) {
       if (nxg_ > 1) fft_ys_->c2c_x(R, 3, n, +1, 1.0);
     }
     time_end(5);
-    slab_exchange(FG_PLAN_A2A_BACKWARD, split ? 0 : -1, kXA2ABwd + 0);
+    slab_exchange(FG_PLAN_A2A_BACKWARD, (split || NC == 1) ? 0 : -1, kXA2ABwd + 0);
   } else if (k == 5 || k == 6) {
     if (split) slab_exchange(FG_PLAN_A2A_BACKWARD, k - 4, kXA2ABwd + k - 4);
   } else if (k >= 7 && k <= 9) {
@@ -424,7 +447,7 @@ void Solver::slab_chain_step(int k) {
       if (k == 9) finish();
     } else if (k == 7) {
       comm_wait(kXA2ABwd);
-      backward(0, 3);
+      backward(0, NC);
       finish();
     }
   } else {
@@ -482,7 +505,8 @@ void Solver::slab_materialise_eps() {
   XHalo h = {{u + 1 * ucs_ + lo, u + 2 * ucs_ + lo}, {u + 0 * ucs_ + hi, nullptr}};
   Vec6 E, R;
   for (int c = 0; c < 6; ++c) E.v[c] = E_cur_[c], R.v[c] = 0.0;
-  launch_eps_norm(g_, strided3(u, ucs_), ptrs6(eps_), E, R, false, partial_, dscal_ + kSlotScratch, h, stream_);
+  if (opt_.mode == 1) launch_sc_grad(gu_, u, ptrs3(eps_), E, partial_, dscal_ + kSlotScratch, stream_);   // g = E + grad+ T
+  else launch_eps_norm(g_, strided3(u, ucs_), ptrs6(eps_), E, R, false, partial_, dscal_ + kSlotScratch, h, stream_);
   eps_stale_ = false;
 }
 
@@ -505,15 +529,23 @@ void Solver::slab_reset_state() {
 void SlabGroup::check_members() const {
   if (m_.empty()) throw std::runtime_error("empty slab group");
   const Solver& a = *m_[0];
-  if (a.opt_.mode != 0 || a.opt_.gamma_scheme != 0)
-    throw std::runtime_error("slab-decomposed solvers run the elasticity mode with the staggered Green operator");
+  if (a.opt_.mode == 2 || a.opt_.gamma_scheme != 0)
+    throw std::runtime_error("slab-decomposed solvers run the elasticity and heat / porous modes with the staggered Green operator");
   if (a.pt_.n < 1) throw std::runtime_error("No materials specified");
   for (Solver* s : m_) {
     if (s->nranks_ > 1 && !s->comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
     if (s->opt_.mixing != a.opt_.mixing || s->pt_.n != a.pt_.n || s->opt_.u_loop != a.opt_.u_loop || s->opt_.u_tile != a.opt_.u_tile ||
-        s->opt_.slab_split != a.opt_.slab_split || s->opt_.slab_interleave != a.opt_.slab_interleave || s->opt_.method != a.opt_.method)
+        s->opt_.slab_split != a.opt_.slab_split || s->opt_.slab_interleave != a.opt_.slab_interleave || s->opt_.method != a.opt_.method ||
+        s->opt_.mode != a.opt_.mode)
       throw std::runtime_error("the members of a slab group must carry the same options and materials");
   }
+}
+
+// heat / porous on slabs: the potential-based fast path only (prescribed mean gradients, a grid the tiled sweep fits)
+void SlabGroup::require_scalar_fast() const {
+  if (m_[0]->opt_.mode == 1 && !fast_ok(false))
+    throw std::runtime_error("heat / porous on slab-decomposed solvers: prescribed mean gradients, Voigt mixing, u_loop=2, fuse_x=1 "
+                             "and a grid the tiled sweep fits (nz/2 >= 62, ny >= 14, local nx >= 4, nx a power of two <= 512)");
 }
 
 void SlabGroup::synchronize() {
@@ -616,8 +648,12 @@ void SlabGroup::mean_stress(double* out6) {
     FieldPtrs<3> nrm;
     for (int c = 0; c < 3; ++c) nrm.p[c] = s->normals_ ? s->normals_ + (long)c * s->g_.n : nullptr;
     // meanPK1: alpha /= nxyz (global), accumulate  F:12318-12340
-    launch_stress_mean(s->g_, s->stress_params(0.0, 0.0, 1.0 / (double)s->nglobal_), s->ptrs6(s->eps_), s->phase_ptrs(), nrm,
-                       s->partial_, s->dscal_ + kSlotMean, s->derr_, s->stream_);
+    if (s->opt_.mode == 1)
+      launch_sc_flux_mean(s->g_, s->scalar_params(0.0, 1.0 / (double)s->nglobal_), s->ptrs3(s->eps_), s->phase_ptrs(), s->partial_,
+                          s->dscal_ + kSlotMean, s->stream_);
+    else
+      launch_stress_mean(s->g_, s->stress_params(0.0, 0.0, 1.0 / (double)s->nglobal_), s->ptrs6(s->eps_), s->phase_ptrs(), nrm,
+                         s->partial_, s->dscal_ + kSlotMean, s->derr_, s->stream_);
   }
   reduce_and_fetch(kSlotMean, 6, false);
   for (int c = 0; c < 6; ++c) out6[c] = m_[0]->hscal_[kSlotMean + c];
@@ -638,9 +674,13 @@ double SlabGroup::volume_fraction(int p) {
 void SlabGroup::calc_ref_material() {
   check_members();
   prepare();
-  for (Solver* s : m_)
-    launch_tangent_minmax(s->g_, s->phase_table(), s->opt_.mixing, s->phase_ptrs(), s->partial_, s->dscal_ + kSlotMinMax, s->derr_,
-                          s->stream_);
+  for (Solver* s : m_) {
+    if (s->opt_.mode == 1)
+      launch_sc_minmax(s->g_, s->scalar_params(0.0, 1.0), s->phase_ptrs(), s->partial_, s->dscal_ + kSlotMinMax, s->stream_);
+    else
+      launch_tangent_minmax(s->g_, s->phase_table(), s->opt_.mixing, s->phase_ptrs(), s->partial_, s->dscal_ + kSlotMinMax, s->derr_,
+                            s->stream_);
+  }
   reduce_and_fetch(kSlotMinMax, 2, true);   // stored as (min, -max): one element-wise minimum serves both
   double lambda_min = m_[0]->hscal_[kSlotMinMax], lambda_max = -m_[0]->hscal_[kSlotMinMax + 1];
   if (lambda_min < 0) lambda_min = 0;   // F:12183-12223
@@ -728,7 +768,17 @@ void SlabGroup::pass_exact(const double* E6, bool mixed_bc) {
 void SlabGroup::iterate(const double* E6, int n) {
   check_members();
   prepare();
+  require_scalar_fast();
   Solver& a = *m_[0];
+  if (a.opt_.mode == 1)
+    for (Solver* s : m_)
+      if (!s->su_valid_) {   // no potential yet: T = 0 (g = E), like the start of a run
+        s->comm_wait(kXHaloU);
+        FG_HIP_CHECK(hipMemsetAsync(s->su_[s->su_cur_], 0, 3 * (size_t)s->ucs_ * sizeof(double), s->stream_));
+        s->su_valid_ = true;
+        s->eps_stale_ = true;
+        for (int i = 0; i < 6; ++i) s->E_cur_[i] = E6[i];
+      }
   const bool mixed_bc = !(frobenius(a.BC_MQ_) < kEps);
   const bool fast = fast_ok(false);
   int i = 0;
@@ -818,6 +868,7 @@ bool SlabGroup::run_step(const double* E0, const double* S0, bool fresh) {
   Solver& a = *m_[0];
   const double t_start = now_seconds();
   prepare();
+  require_scalar_fast();
   const bool fast_allowed = fast_ok(true);
   bool fast = fast_allowed;
   double prev = 0.0;   // EpsilonErrorEstimator  F:14591-14637: norms of the field the step starts from
@@ -983,6 +1034,7 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
     S0[i] = S6 ? S6[i] : 0.0;
   }
   prepare();
+  if (a.opt_.mode != 0) throw std::runtime_error("method=cg on slab-decomposed solvers: elasticity mode");
   // CG restarts every step from eps = E (F:23184); only the estimator remembers the field the step found (F:14612-14618)
   const double prev0 = fresh ? 0.0 : current_norm9();
   // mixed boundary conditions, grids the tiled sweep does not fit, u_loop < 2: the strain-space form (the vectors of

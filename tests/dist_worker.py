@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--mixed-bc", type=int, default=0)
     ap.add_argument("--split", type=int, default=-1)
     ap.add_argument("--method", default="basic")
+    ap.add_argument("--mode", default="elasticity")
     ap.add_argument("--out", required=True)
     ap.add_argument("--stop-rank", type=int, default=-1, help="only this rank installs a convergence callback ...")
     ap.add_argument("--stop-iter", type=int, default=0, help="... which asks to stop in this iteration")
@@ -186,6 +187,23 @@ def main():
         return
     from helpers import two_phase_setup
     from fibergen_amd.distributed import DistributedLSSolver
+    if a.mode in ("porous", "heat"):
+        # the scalar modes on the slabs: one member per process
+        from helpers import sphere_phi
+        phi1 = sphere_phi(grid, 0.3)
+        s = DistributedLSSolver(*grid, *dims, device=0, transport=a.transport or None)
+        s.set_options(mode=a.mode)
+        s.set_num_phases(2)
+        s.set_phase(0, 1.0, 0.0, s.slab(1 - phi1))
+        s.set_phase(1, 12.0, 0.0, s.slab(phi1))
+        s.set_options(tol=a.tol, slab_split=a.split)
+        failed = s.run(np.array([1.0, -0.5, 0.25]))
+        np.savez(a.out + ".%d.npz" % rank, eps=s.get_field("epsilon"), iterations=s.iterations, residuals=np.array(s.residuals),
+                 mean_stress=s.mean_stress(), failed=failed, transport=s.transport, mu_0=s.ref_material[0])
+        s.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     mats, phis, normals = two_phase_setup(grid, a.mixing)
     try:
         s = DistributedLSSolver(*grid, *dims, device=0, transport=a.transport or None)

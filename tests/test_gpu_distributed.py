@@ -249,3 +249,25 @@ def test_fg_project_on_slabs(tmp_path, nproc, grid, mixing, method, transport):
         assert r["eps"].shape == (6, g[0], g[1], g[2]) and rel_err(r["eps"], fg.get_field("epsilon")) < 1e-8
         assert float(r["vf"]) == pytest.approx(fg.get_volume_fraction("inclusion"), rel=1e-13)
         assert len(r["residuals"]) == len(fg.get_residuals())
+
+
+@pytest.mark.parametrize("transport", ["callback", "rccl"])
+@pytest.mark.parametrize("nproc,grid,split", [(2, "8,16,128", 0), (4, "16,16,128", 1)])
+def test_porous_mode_on_slabs_one_rank_per_process(tmp_path, transport, nproc, grid, split):
+    """mode = porous (BASELINE config 5's physics) cut into slabs: potential with halo planes, one-component all-to-all"""
+    from helpers import sphere_phi
+    from oracle.scalar_oracle import ScalarOracle
+    g = tuple(int(v) for v in grid.split(","))
+    args = ("--backend", "hip", "--grid", grid, "--mode", "porous", "--dims", "1,2,1.5", "--split", str(split), "--tol", "1e-9")
+    res = launch_rccl(nproc, str(tmp_path / "p"), *args) if transport == "rccl" else launch(nproc, str(tmp_path / "p"), *args)
+    phi1 = sphere_phi(g, 0.3)
+    o = ScalarOracle(*g, mus=[1.0, 12.0], phis=[1 - phi1, phi1], dx=1.0, dy=2.0, dz=1.5, tol=1e-9)
+    assert o.run(np.array([1.0, -0.5, 0.25])) is False
+    eps = np.concatenate([r["eps"] for r in res], axis=1)
+    assert all(int(r["iterations"]) == o.iterations for r in res)
+    assert rel_err(eps, o.eps) < 1e-10
+    for r in res:
+        assert np.array_equal(r["residuals"], res[0]["residuals"])
+        assert np.abs(r["residuals"] - np.array(o.residuals)).max() < 1e-11
+        assert rel_err(r["mean_stress"][:3], o.mean_stress()) < 1e-11
+        assert float(r["mu_0"]) == o.mu_0

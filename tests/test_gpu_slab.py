@@ -364,3 +364,57 @@ def test_group_load_steps_mixed_bc_and_stop_request():
     assert g.run_load_steps([0.01, 0, 0, 0, 0, 0], np.zeros(6), params=[0.0, 0.5, 1.0], step_callback=lambda i: seen.append(i) or i == 1) is True
     assert seen == [0, 1]
     g.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# heat / porous (scalar potential) on the slabs: the tiled potential sweep with halo planes, one-component transform chain
+def _scalar_group(P, grid, mus, phis, dims=(1.0, 1.0, 1.0), mode="porous", **kw):
+    from fibergen_amd.distributed import SlabGroup
+    g = SlabGroup(*grid, *dims, nranks=P)
+    g.set_options(mode=mode)
+    g.set_num_phases(len(mus))
+    for p, (mu, phi) in enumerate(zip(mus, phis)):
+        g.set_phase(p, mu, 0.0, phi)
+    g.set_options(**kw)
+    return g
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("P,grid", [(1, (8, 16, 128)), (2, (8, 16, 128)), (4, (16, 16, 128)), (2, (16, 32, 256)), (2, (8, 16, 124))])
+def test_scalar_group_run_matches_oracle(P, grid, split):
+    from helpers import sphere_phi
+    from oracle.scalar_oracle import ScalarOracle
+    dims = (1.0, 2.0, 1.5)
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 12.0], [1 - phi1, phi1]
+    E = np.array([1.0, -0.5, 0.25])
+    g = _scalar_group(P, grid, mus, phis, dims, tol=1e-9, slab_split=split)
+    o = ScalarOracle(*grid, mus=mus, phis=phis, dx=dims[0], dy=dims[1], dz=dims[2], tol=1e-9)
+    assert o.run(E) is False and g.run(E) is False
+    assert g.iterations == o.iterations
+    assert g.ref_material[0] == o.mu_0
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-11
+    got = g.get_field("epsilon")
+    assert got.shape == (3,) + grid and rel_err(got, o.eps) < 1e-10
+    assert rel_err(g.get_field("sigma"), o.pk1(o.eps)) < 1e-10
+    assert rel_err(g.mean_stress()[:3], o.mean_stress()) < 1e-11
+    np.testing.assert_allclose(g.mean_strain()[:3], E, atol=1e-12)
+    # raw passes continue from the state
+    g.iterate(E, 2)
+    g2 = o.basic_scheme(E, o.basic_scheme(E, o.eps))
+    assert rel_err(g.get_field("epsilon"), g2) < 1e-10
+    g.close()
+
+
+def test_scalar_group_refuses_what_it_does_not_cover():
+    from helpers import sphere_phi
+    phi1 = sphere_phi((16, 16, 16), 0.3)
+    g = _scalar_group(2, (16, 16, 16), [1.0, 12.0], [1 - phi1, phi1])   # a grid the tiled sweep does not fit
+    with pytest.raises(RuntimeError, match="heat / porous on slab-decomposed"):
+        g.run(np.array([1.0, 0, 0]))
+    g.close()
+    phi1 = sphere_phi((8, 16, 128), 0.3)
+    g = _scalar_group(2, (8, 16, 128), [1.0, 12.0], [1 - phi1, phi1], method="cg")
+    with pytest.raises(RuntimeError, match="elasticity mode"):
+        g.run(np.array([1.0, 0, 0]))
+    g.close()
