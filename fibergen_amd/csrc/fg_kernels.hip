@@ -1128,8 +1128,9 @@ __global__ __launch_bounds__(kBlock) void k_eps_delta(Grid g, FieldPtrs<3> u, Fi
     const PairPos p = pair_pos_tiled(pidx, g, ry);
     if (p.k >= g.nz) continue;
     const bool second = p.k + 1 < g.nz;
-    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
-    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    // x neighbours through Grid::xw_lo / xw_hi: periodic in a whole grid, the spare planes of the neighbours in an x-slab
+    const long xf = (p.i + 1 == g.nx ? (long)(g.nx - g.xw_hi) - p.i : 1L) * g.nyzp;
+    const long xb = (p.i == 0 ? (long)(g.xw_lo - 1) : -1L) * g.nyzp;
     const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
     const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
     const long rowoff = p.off - p.k;

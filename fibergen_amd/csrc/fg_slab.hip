@@ -409,6 +409,8 @@ void Solver::slab_chain_step(int k) {
     G0Params gp;
     gp.c10 = -alpha / (opt_.mu_0);
     gp.c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
+    if (opt_.mode == 2)   // dual Stokes scheme: Green operator of mu = -mu0 (= -1/(4 m)), lambda = inf: c20 = c10  (F:20444, F:19749-19755)
+      gp.c10 = gp.c20 = alpha / opt_.mu_0;
     gp.inv_h0 = 2.0 * nxg_ / g_.dx;
     G0Tables tb;
     for (int a = 0; a < 3; ++a) {
@@ -464,6 +466,7 @@ void Solver::slab_front_exact(bool sum_tau) {
   FieldPtrs<3> nrm;
   for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
   launch_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs6(eps_), phase_ptrs(), nrm, ptrs6(tau_), derr_, stream_);
+  sum_tau = sum_tau || opt_.mode == 2;   // viscosity: the Delta operator needs <tau> in every pass
   if (sum_tau) launch_sum6(g_, ptrs6(tau_), false, partial_, dscal_ + kSlotMean, stream_);
   const long plane = g_.nyzp, last = (long)(g_.nx - 1) * g_.nyzp;
   launch_copy(tau_ + 0 * g_.n + last, halo_[1], plane, stream_);     // tau0, my last plane  -> right (x-1 there)
@@ -483,6 +486,20 @@ void Solver::slab_div_exact() {
 void Solver::slab_back_exact(const double* E6, const double* R6) {
   comm_wait(kXHaloU);
   double* un = su_[su_cur_ ^ 1];
+  if (opt_.mode == 2) {
+    // DeltaOperatorStaggered  F:20438-20452 after the Green operator: eta = (E - coef <tau>) + sym grad u + coef tau, coef =
+    // 2 alpha / (4 mu0).  <tau> is the all-reduced sum in kSlotMean (mixed BC:
+    // the projector term in R6); tau itself is re-evaluated from the strain the pass started from -- its field was the all-to-all buffer
+    comm_wait(kXSums);
+    Vec6 Ev;
+    for (int c = 0; c < 6; ++c) Ev.v[c] = E6[c] + (R6 ? R6[c] : 0.0);   // mixed BC: alpha MQ:<tau> from the host (pass_exact)
+    const double alpha = -1.0, m = 1 / (4 * opt_.mu_0);
+    launch_eps_delta_recompute(gu_, strided3(un, ucs_), ptrs6(eps_), stress_params(opt_.mu_0, opt_.lambda_0, 1.0), phase_ptrs(),
+                               dscal_ + kSlotMean, (double)nglobal_, Ev, 2 * alpha * m, ptrs6(eps_), partial_, dscal_ + kSlotSumSq,
+                               stream_);
+    slab_reduce(kSlotSumSq, 6, false);
+    return;
+  }
   const SlabDims d = slab_dims(nxg_, g_.ny, g_.nz, nranks_, rank_);
   const long lo = slab_lo_plane(d) * d.plane, hi = slab_hi_plane(d) * d.plane;
   XHalo h = {{un + 1 * ucs_ + lo, un + 2 * ucs_ + lo}, {un + 0 * ucs_ + hi, nullptr}};
@@ -529,8 +546,9 @@ void Solver::slab_reset_state() {
 void SlabGroup::check_members() const {
   if (m_.empty()) throw std::runtime_error("empty slab group");
   const Solver& a = *m_[0];
-  if (a.opt_.mode == 2 || a.opt_.gamma_scheme != 0)
-    throw std::runtime_error("slab-decomposed solvers run the elasticity and heat / porous modes with the staggered Green operator");
+  if (a.opt_.gamma_scheme != 0) throw std::runtime_error("slab-decomposed solvers run the staggered Green operator");
+  if (a.opt_.mode == 2 && (a.opt_.mixing != kMixVoigt || a.opt_.bc_relax != 1.0))
+    throw std::runtime_error("viscosity mode supports Voigt mixing and bc_relax = 1 only");
   if (a.pt_.n < 1) throw std::runtime_error("No materials specified");
   for (Solver* s : m_) {
     if (s->nranks_ > 1 && !s->comm_) throw std::runtime_error("slab solver is not connected to a transport (fg_slab_connect_*)");
@@ -760,7 +778,7 @@ void SlabGroup::pass_exact(const double* E6, bool mixed_bc) {
   for (Solver* s : m_) s->slab_back_exact(E6, R);
   for (Solver* s : m_) s->slab_fetch_norms(6);
   for (Solver* s : m_) {
-    s->slab_adopt(E6, !add_R);
+    s->slab_adopt(E6, !add_R && a.opt_.mode == 0);   // viscosity: eta is not E + sym grad u, the strain field is the state
     s->eps_stale_ = false;
   }
 }
@@ -1034,7 +1052,7 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
     S0[i] = S6 ? S6[i] : 0.0;
   }
   prepare();
-  if (a.opt_.mode != 0) throw std::runtime_error("method=cg on slab-decomposed solvers: elasticity mode");
+  if (a.opt_.mode == 1) throw std::runtime_error("method=cg on slab-decomposed solvers: elasticity and viscosity modes");
   // CG restarts every step from eps = E (F:23184); only the estimator remembers the field the step found (F:14612-14618)
   const double prev0 = fresh ? 0.0 : current_norm9();
   // mixed boundary conditions, grids the tiled sweep does not fit, u_loop < 2: the strain-space form (the vectors of

@@ -415,6 +415,47 @@ def test_scalar_group_refuses_what_it_does_not_cover():
     g.close()
     phi1 = sphere_phi((8, 16, 128), 0.3)
     g = _scalar_group(2, (8, 16, 128), [1.0, 12.0], [1 - phi1, phi1], method="cg")
-    with pytest.raises(RuntimeError, match="elasticity mode"):
+    with pytest.raises(RuntimeError, match="method=cg on slab-decomposed"):
         g.run(np.array([1.0, 0, 0]))
+    g.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# viscosity (dual Stokes scheme, DeltaOperatorStaggered F:20422-20460) on the slabs: strain-state pipeline, <tau> all-reduced
+@pytest.mark.parametrize("method", ["basic", "cg"])
+@pytest.mark.parametrize("P,grid", [(1, (12, 10, 6)), (2, (12, 10, 6)), (2, (8, 14, 124)), (4, (16, 16, 128))])
+def test_viscosity_group_matches_oracle(P, grid, method):
+    from helpers import sphere_phi
+    from oracle.viscosity_oracle import ViscosityOracle
+    dims = (1.0, 2.0, 1.5)
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 0.05], [1 - phi1, phi1]
+    E = np.array([0.5, -0.5, 0.0, 0.2, 0.0, 1.0])
+    g = _scalar_group(P, grid, mus, phis, dims, mode="viscosity", tol=1e-8, method=method)
+    o = ViscosityOracle(*grid, *dims, mats=[(m, 0.0) for m in mus], phis=phis, tol=1e-8)
+    assert (o.run_cg(E) if method == "cg" else o.run(E)) is False and g.run(E) is False
+    assert g.iterations == o.iterations
+    assert g.ref_material[0] == o.mu_0
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-10
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(g.mean_stress(), o.mean_stress()) < 1e-10
+    np.testing.assert_allclose(g.mean_strain(), E, atol=1e-12)
+    g.close()
+
+
+@pytest.mark.parametrize("P,grid", [(2, (12, 10, 6)), (2, (8, 14, 124))])
+def test_viscosity_group_mixed_bc(P, grid):
+    from helpers import sphere_phi
+    from oracle.viscosity_oracle import ViscosityOracle
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 0.05], [1 - phi1, phi1]
+    Pm = np.diag([0.0, 0, 0, 0.5, 0.5, 0])
+    E, S = np.array([0, 0, 0, 0.3, -0.2, 0]), np.zeros(6)
+    g = _scalar_group(P, grid, mus, phis, mode="viscosity", tol=1e-9, bc_tol=1e-8, maxiter=2000)
+    g.set_bc_projector(Pm)
+    o = ViscosityOracle(*grid, mats=[(m, 0.0) for m in mus], phis=phis, tol=1e-9, bc_tol=1e-8, maxiter=2000)
+    assert o.run(E, S0=S, P=Pm) is False and g.run(E, S) is False
+    assert g.iterations == o.iterations
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8
+    assert rel_err(g.mean_stress(), o.mean_stress()) < 1e-8
     g.close()
