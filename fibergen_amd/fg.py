@@ -205,7 +205,8 @@ class FG:
         created with device = LOCAL_RANK): the voxel grid of every load case is cut into x-slabs over the ranks
         (fibergen_amd.distributed.DistributedLSSolver: RCCL all-to-all between the FFT axes, halo planes, all-reduced
         norms).  Every rank runs the same project and sees the same results; fields returned by get_field are gathered.
-        nx and ny must be divisible by the number of ranks; <loadsteps> without extrapolation."""
+        nx and ny must be divisible by the number of ranks; <loadsteps> without extrapolation; elasticity, viscosity, and heat /
+        porous on grids the tiled sweep fits."""
         self._slabs = bool(enable)
         self._slab_group = group
         self._solver_valid = False
@@ -288,8 +289,8 @@ class FG:
 
         if getattr(self, "_slabs", False):
             from .distributed import GlobalViewSolver
-            if mode != "elasticity" or scheme != "staggered":
-                raise RuntimeError("slab decomposition runs the elasticity mode with the staggered Green operator")
+            if scheme != "staggered":
+                raise RuntimeError("slab decomposition runs the staggered Green operator")
             lss = GlobalViewSolver(nx, ny, nz, dx, dy, dz, group=getattr(self, "_slab_group", None), device=self._device)
         else:
             lss = LSSolver(nx, ny, nz, dx, dy, dz, device=self._device)

@@ -113,6 +113,16 @@ def run_plan(a, dist, rank, P, grid):
     np.savez(a.out + ".%d.npz" % rank, errors=np.array(errors))
 
 
+def fg_slabs_project(grid, tol, method, mixing, mode):
+    """the XML project of the fg-slabs backend (also what the test process runs on one GPU)"""
+    mats = ('<matrix E="1" nu="0.3" /><inclusion E="10" nu="0.2" />' if mode == "elasticity" else
+            '<matrix mu="1" /><inclusion mu="%s" />' % ("0.05" if mode == "viscosity" else "10"))
+    return """<settings><solver nx="%d" ny="%d" nz="%d"><mode>%s</mode><tol>%g</tol><method>%s</method><mixing_rule>%s</mixing_rule>
+      <materials>%s</materials></solver>
+      <actions><select_material name="inclusion" /><place_fiber R="0.3" /><init_phase normals="1" /><calc_effective_properties /></actions>
+    </settings>""" % (grid[0], grid[1], grid[2], mode, tol, method, mixing, mats)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", default="plan")
@@ -174,10 +184,7 @@ def main():
         if a.transport == "rccl":
             os.environ["FG_SLAB_TRANSPORT"] = "rccl"
         fg = FG(device=0)
-        fg.set_xml("""<settings><solver nx="%d" ny="%d" nz="%d"><tol>%g</tol><method>%s</method><mixing_rule>%s</mixing_rule>
-          <materials><matrix E="1" nu="0.3" /><inclusion E="10" nu="0.2" /></materials></solver>
-          <actions><select_material name="inclusion" /><place_fiber R="0.3" /><init_phase normals="1" /><calc_effective_properties /></actions>
-        </settings>""" % (grid + (a.tol, a.method, a.mixing)))
+        fg.set_xml(fg_slabs_project(grid, a.tol, a.method, a.mixing, a.mode))
         fg.decompose_slabs(True)
         rc = fg.run()
         np.savez(a.out + ".%d.npz" % rank, rc=rc, C=np.array(fg.get_effective_property()), eps=fg.get_field("epsilon"),

@@ -225,28 +225,31 @@ def test_cancel_on_one_rank_stops_every_rank(tmp_path, transport, method):
     assert np.array_equal(res[0]["residuals"], res[1]["residuals"])
 
 
-@pytest.mark.parametrize("nproc,grid,mixing,method,transport", [(2, "8,16,128", "voigt", "cg", "callback"),
-                                                                (2, "8,16,128", "laminate", "basic", "rccl"),
-                                                                (4, "16,16,16", "voigt", "cg", "callback")])
-def test_fg_project_on_slabs(tmp_path, nproc, grid, mixing, method, transport):
+@pytest.mark.parametrize("nproc,grid,mixing,method,transport,mode", [
+    (2, "8,16,128", "voigt", "cg", "callback", "elasticity"),
+    (2, "8,16,128", "laminate", "basic", "rccl", "elasticity"),
+    (4, "16,16,16", "voigt", "cg", "callback", "elasticity"),
+    (2, "8,16,128", "voigt", "basic", "rccl", "porous"),
+    (2, "12,10,6", "voigt", "cg", "callback", "viscosity"),
+])
+def test_fg_project_on_slabs(tmp_path, nproc, grid, mixing, method, transport, mode):
     """FG.decompose_slabs: the project interface on top of the slab driver -- one XML project, its voxel grid cut into
     x-slabs over the ranks (north_star: 'behind the same ... XML project interface ... slab-decomposed across the GPUs').
-    Every rank obtains the effective stiffness, gathered fields and scalars one process computes alone."""
+    Every rank obtains the effective property, gathered fields and scalars one process computes alone."""
+    from dist_worker import fg_slabs_project
     from fibergen_amd import FG
     g = [int(v) for v in grid.split(",")]
-    args = ("--backend", "fg-slabs", "--grid", grid, "--mixing", mixing, "--method", method, "--tol", "1e-8")
+    args = ("--backend", "fg-slabs", "--grid", grid, "--mixing", mixing, "--method", method, "--tol", "1e-8", "--mode", mode)
     res = launch_rccl(nproc, str(tmp_path / "f"), *args) if transport == "rccl" else launch(nproc, str(tmp_path / "f"), *args)
     fg = FG()
-    fg.set_xml("""<settings><solver nx="%d" ny="%d" nz="%d"><tol>1e-8</tol><method>%s</method><mixing_rule>%s</mixing_rule>
-      <materials><matrix E="1" nu="0.3" /><inclusion E="10" nu="0.2" /></materials></solver>
-      <actions><select_material name="inclusion" /><place_fiber R="0.3" /><init_phase normals="1" /><calc_effective_properties /></actions>
-    </settings>""" % (g[0], g[1], g[2], method, mixing))
+    fg.set_xml(fg_slabs_project(g, 1e-8, method, mixing, mode))
     assert fg.run() == 0
     C = np.array(fg.get_effective_property())
+    ncomp = 3 if mode == "porous" else 6
     for r in res:
         assert int(r["rc"]) == 0
         assert np.array_equal(r["C"], res[0]["C"]) and rel_err(r["C"], C) < 1e-9
-        assert r["eps"].shape == (6, g[0], g[1], g[2]) and rel_err(r["eps"], fg.get_field("epsilon")) < 1e-8
+        assert r["eps"].shape == (ncomp, g[0], g[1], g[2]) and rel_err(r["eps"], fg.get_field("epsilon")) < 1e-8
         assert float(r["vf"]) == pytest.approx(fg.get_volume_fraction("inclusion"), rel=1e-13)
         assert len(r["residuals"]) == len(fg.get_residuals())
 
