@@ -551,9 +551,10 @@ def main():
     from fibergen_amd import LSSolver
     from fibergen_amd.distributed import DistributedLSSolver
     from fibergen_amd.rve import bench_rve
-    if scalar or stokes:
-        raise SystemExit("N > 1 measures the elasticity mode")
+    if (scalar or stokes) and args.mixing != "voigt":
+        raise SystemExit("the scalar and viscosity modes take Voigt mixing")
     phi, normals, par = bench_rve(args.n, args.mixing)
+    E_mode = np.array([1.0, 0, 0]) if scalar else (np.array([1.0, -1, 0, 0, 0, 0]) if stokes else None)
 
     def sync_all(obj):
         obj.synchronize()
@@ -606,6 +607,8 @@ def main():
         s.calc_ref_material()
         E = np.zeros(6)
         E[rank % 6] = 1.0
+        if E_mode is not None:
+            E = E_mode
         dts = timed_regions(lambda k: s.iterate(E, k), lambda: sync_all(s), args.steps, args.warmup, 3)
         med = max_over_ranks(statistics.median(dts))
         replicas = {"value": world * args.steps / med, "unit": "it/s", "ms_per_step": 1e3 * med / args.steps,
@@ -642,14 +645,14 @@ def main():
         configure(d, phi, normals, args.mixing, args.mode, slab=d.slab)
         del phi, normals
         d.calc_ref_material()
-        E = np.array([1.0, 0, 0, 0, 0, 0])
+        E = np.array([1.0, 0, 0, 0, 0, 0]) if E_mode is None else E_mode
         split, split_trials = tune_exchange_mode(d, E)
         dts = timed_regions(lambda k: d.iterate(E, k), lambda: sync_all(d), args.steps, args.warmup, args.repeats)
         med = max_over_ranks(statistics.median(dts))
         lo, hi = max_over_ranks(min(dts)), max_over_ranks(max(dts))
         it_s = args.steps / med
         local_n = (args.n // world, args.n, args.n)
-        kern, _, cnt = kernel_table(d, E, local_n, min(args.steps, 10), False)   # this rank's slab, HIP events
+        kern, _, cnt = kernel_table(d, E, local_n, min(args.steps, 10), scalar)   # this rank's slab, HIP events
         xt = exchange_times(d, cnt)
         dom = max(kern, key=lambda k: kern[k]["avg_ms"])
         line.update({
@@ -658,13 +661,13 @@ def main():
             "roofline": {"kernel": dom + " (rank 0's slab)", "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
                          "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]},
-            "loop_GBps_Amin": A_MIN_BYTES_PER_VOXEL * N * it_s / 1e9,
+            "loop_GBps_Amin": ((24 + 7 * 16) if scalar else A_MIN_BYTES_PER_VOXEL) * N * it_s / 1e9,
             "kernels": kern, "kernel_sum_ms": kernel_table.last_sum_ms, "replicas": replicas,
             "transport": d.transport, "rccl_ranks": world if d.transport == "rccl" else 0,
             "slab_split": split, "slab_split_trials": split_trials,
             "devices": devices, "distinct_devices": len({x.split(": ")[1] for x in devices}),
             "alltoall_ms": xt["alltoall_fwd"] + xt["alltoall_bwd"], "exchange_ms_per_pass": xt,
-            "alltoall_MB_per_gpu_per_pass": 2 * 3 * (world - 1) / world * (args.n // world) * args.n * (args.n // 2 + 1) * 16 / 1e6,
+            "alltoall_MB_per_gpu_per_pass": 2 * (1 if scalar else 3) * (world - 1) / world * (args.n // world) * args.n * (args.n // 2 + 1) * 16 / 1e6,
         })
         line["config"]["parallelism"] = ("x-slabs x%d: ONE problem, displacement loop per slab, per component one RCCL all-to-all "
                                          "each way between the FFT axes, +-1 halo planes of u, norms all-reduced" % world)
@@ -679,7 +682,7 @@ def main():
                          "basic_scheme_it_s": it_s, "value": med_cg, "ms_per_step": 1e3 / med_cg})
         d.close()
         timer.cancel()
-        if args.also_slab:
+        if args.also_slab and not scalar and not stokes:
             # the north-star target configuration through the same driver; whatever happens here, the headline line stands
             def give_up():
                 line["also_slab"] = {args.also_slab: {"error": "exceeded %d s" % args.slab_timeout}}
