@@ -165,7 +165,8 @@ void launch_g0_heat(const Grid& g, double* fh, const G0Tables& tb, double c10, h
 // CG in potential space (scalar modes): dot products of forward-difference gradients, point-wise updates
 void launch_sc_cg_dot(int mode, const Grid& g, const double* a, const double* b, const Vec6& E, double* partial, double* out7,
                       hipStream_t s);
-void launch_sc_cg_axpy(int mode, const Grid& g, double* x, double* y, double* r, const double* w, double a, hipStream_t s);
+void launch_sc_cg_axpy(int mode, const Grid& g, double* x, double* y, double* r, const double* w, double a, hipStream_t s,
+                       long count = 0 /* doubles to update; 0 = g.n (x-slabs: + the spare planes) */);
 void launch_sc_minmax(const Grid& g, const ScalarParams& sp, const FieldPtrs<kMaxPhases>& phi, double* partial,
                       double* out2, hipStream_t s);
 void launch_tangent_minmax(const Grid& g, const PhaseTable& pt, int mixing, const FieldPtrs<kMaxPhases>& phi,

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_sc_cg_dot(Grid g, const double* a, c
     const PairPos p = pair_pos_tiled(pidx, g, sw);
     if (p.k >= g.nz) continue;
     const bool second = p.k + 1 < g.nz;
-    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
+    const long xf = (p.i + 1 == g.nx ? (long)(g.nx - g.xw_hi) - p.i : 1L) * g.nyzp;   // Grid::xw_hi: x-slabs read their spare plane
     const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
     const long ro = p.off - p.k;
     const int k = p.k;
@@ -388,8 +388,9 @@ void launch_sc_cg_dot(int mode, const Grid& g, const double* a, const double* b,
   FG_HIP_CHECK(hipGetLastError());
 }
 
-void launch_sc_cg_axpy(int mode, const Grid& g, double* x, double* y, double* r, const double* w, double a, hipStream_t s) {
-  const long n2 = g.n / 2;
+void launch_sc_cg_axpy(int mode, const Grid& g, double* x, double* y, double* r, const double* w, double a, hipStream_t s,
+                       long count) {
+  const long n2 = (count > 0 ? count : g.n) / 2;
   const dim3 grid(grid_cap(n2, 1 << 16));
   if (mode == 0) hipLaunchKernelGGL((k_sc_cg_axpy<0>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, a);
   else hipLaunchKernelGGL((k_sc_cg_axpy<1>), grid, dim3(kBlock), 0, s, n2, x, y, r, w, a);

@@ -48,7 +48,8 @@ class SlabGroup {
   bool run_cg(const double* E0, const double* S0, bool fresh);
   bool run_cg_strain(const double* E0, const double* S0, double prev0);
   double current_norm9();
-  void require_scalar_fast() const;
+  void require_scalar_fast(bool allow_mixed_bc) const;
+  bool run_cg_scalar(const double* E0, double prev0);
   bool agree_on_voting();                                              // does any rank carry a convergence callback?
   bool stop_requested() const;                                         // reduced flag word: some rank was cancelled
   void vote(double* v2);                                               // sums of two host values over the ranks

@@ -253,7 +253,8 @@ void Solver::slab_fetch_norms(int n) {
 bool Solver::slab_fast_ok(bool allow_mixed_bc) const {
   if (opt_.mode == 1)   // heat / porous: the tiled potential sweep + the fused one-component x pass, prescribed gradients
     return opt_.u_loop >= 2 && opt_.gamma_scheme == 0 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
-           u_tile_supported(g_) && opt_.fuse_x && fft_ys_ && nxg_ > 1 && fft_ys_->can_fuse(0, 1) && frobenius(BC_MQ_) < kEps;
+           u_tile_supported(g_) && opt_.fuse_x && fft_ys_ && nxg_ > 1 && fft_ys_->can_fuse(0, 1) &&
+           (frobenius(BC_MQ_) < kEps || allow_mixed_bc);
   if (!(opt_.u_loop >= 2 && opt_.u_tile && opt_.mode == 0 && opt_.gamma_scheme == 0 && pt_.n >= 1 &&
         (opt_.mixing == kMixVoigt || (opt_.mixing == kMixLaminate && normals_)) && opt_.bc_relax == 1.0 && u_tile_supported(g_)))
     return false;
@@ -295,9 +296,12 @@ void Solver::slab_front_fast(const double* E6, bool sum_tau, const double* u_src
   if (opt_.mode == 1) {
     // heat / porous: T_k (component 0 of the displacement buffer, with its halo planes) -> sums of squares of g_k = E + grad T_k,
     // f = div((a - 2 mu0) g_k)
-    launch_sc_sweep_fast(gu_, opt_.mu_0, u_in, smod_, fu_, E, partial_, dscal_ + kSlotSumSq, stream_);
+    // (mixed BC: the sweep also leaves the three sums of the flux polarisation in kSlotMean; entries 3..5 stay zero)
+    if (sum_tau) FG_HIP_CHECK(hipMemsetAsync(dscal_ + kSlotMean, 0, 6 * sizeof(double), stream_));
+    launch_sc_sweep_fast(gu_, opt_.mu_0, u_in, smod_, fu_, E, partial_, dscal_ + kSlotSumSq, stream_,
+                         sum_tau ? dscal_ + kSlotMean : nullptr);
     time_end(0);
-    if (reduce) slab_reduce(kSlotSumSq, 6, false);
+    if (reduce) slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
     return;
   }
   const bool laminate = opt_.mixing == kMixLaminate;
@@ -560,10 +564,10 @@ void SlabGroup::check_members() const {
 }
 
 // heat / porous on slabs: the potential-based fast path only (prescribed mean gradients, a grid the tiled sweep fits)
-void SlabGroup::require_scalar_fast() const {
-  if (m_[0]->opt_.mode == 1 && !fast_ok(false))
-    throw std::runtime_error("heat / porous on slab-decomposed solvers: prescribed mean gradients, Voigt mixing, u_loop=2, fuse_x=1 "
-                             "and a grid the tiled sweep fits (nz/2 >= 62, ny >= 14, local nx >= 4, nx a power of two <= 512)");
+void SlabGroup::require_scalar_fast(bool allow_mixed_bc) const {
+  if (m_[0]->opt_.mode == 1 && !fast_ok(allow_mixed_bc))
+    throw std::runtime_error("heat / porous on slab-decomposed solvers: Voigt mixing, u_loop=2, fuse_x=1, bc_relax=1 and a grid the "
+                             "tiled sweep fits (nz/2 >= 62, ny >= 14, local nx >= 4, nx a power of two <= 512)");
 }
 
 void SlabGroup::synchronize() {
@@ -786,7 +790,7 @@ void SlabGroup::pass_exact(const double* E6, bool mixed_bc) {
 void SlabGroup::iterate(const double* E6, int n) {
   check_members();
   prepare();
-  require_scalar_fast();
+  require_scalar_fast(false);
   Solver& a = *m_[0];
   if (a.opt_.mode == 1)
     for (Solver* s : m_)
@@ -886,7 +890,7 @@ bool SlabGroup::run_step(const double* E0, const double* S0, bool fresh) {
   Solver& a = *m_[0];
   const double t_start = now_seconds();
   prepare();
-  require_scalar_fast();
+  require_scalar_fast(true);
   const bool fast_allowed = fast_ok(true);
   bool fast = fast_allowed;
   double prev = 0.0;   // EpsilonErrorEstimator  F:14591-14637: norms of the field the step starts from
@@ -1052,9 +1056,14 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
     S0[i] = S6 ? S6[i] : 0.0;
   }
   prepare();
-  if (a.opt_.mode == 1) throw std::runtime_error("method=cg on slab-decomposed solvers: elasticity and viscosity modes");
   // CG restarts every step from eps = E (F:23184); only the estimator remembers the field the step found (F:14612-14618)
   const double prev0 = fresh ? 0.0 : current_norm9();
+  if (a.opt_.mode == 1) {
+    if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_Q_) < kEps))
+      throw std::runtime_error("method=cg in heat / porous mode on slab-decomposed solvers: prescribed mean gradients");
+    require_scalar_fast(false);
+    return run_cg_scalar(E0, prev0);
+  }
   // mixed boundary conditions, grids the tiled sweep does not fit, u_loop < 2: the strain-space form (the vectors of
   // runCGElasticity as 6-component fields, the operator = one pass of the strain-state pipeline)
   if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_Q_) < kEps) || !fast_ok(false)) return run_cg_strain(E0, S0, prev0);
@@ -1200,6 +1209,136 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
     }
     iter++;
     if (!applied) direction_update(cur, nxt);
+  }
+  for (Solver* s : m_) {
+    s->in_run_ = false;
+    s->iterations_ = iter;
+    s->su_valid_ = true;
+    s->eps_stale_ = true;
+    for (int c = 0; c < 6; ++c) s->E_cur_[c] = E.v[c];
+    s->slab_materialise_eps();
+  }
+  synchronize();
+  const double dt = now_seconds() - t_start;
+  for (Solver* s : m_) s->solve_time_ += dt;
+  return failed;
+}
+
+// The same CG for the scalar modes, carried in potential space like Solver::run_cg_scalar (g = E + grad T_e; r, p, w = grad T_r,
+// T_p, T_w; runCG sends every non-hyperelastic mode to runCGElasticity F:22056-22066, whose inner product is the plain sum for
+// 3 components F:20961-20980).  T_e = component 0 of su_[cur], T_w = component 0 of su_[cur ^ 1] (the chain's output), T_r, T_p =
+// scg_.  The point-wise updates run over the spare planes too, so only T_w needs its halo exchange; alpha and beta on the host.
+bool SlabGroup::run_cg_scalar(const double* E0, double prev0) {
+  Solver& a = *m_[0];
+  const double t_start = now_seconds();
+  const bool residual_est = a.opt_.error_estimator == 1;
+  const double small = std::numeric_limits<double>::min();
+  const double nglobal = (double)a.nglobal_;
+  if (a.opt_.update_ref) {
+    calc_ref_material();
+    prepare();
+  }
+  const bool voting = agree_on_voting();
+  Vec6 E, Z;
+  for (int i = 0; i < 6; ++i) E.v[i] = i < 3 ? E0[i] : 0.0, Z.v[i] = 0.0;
+  auto T_e = [](Solver* s) { return s->su_[s->su_cur_]; };
+  auto T_w = [](Solver* s) { return s->su_[s->su_cur_ ^ 1]; };
+  auto T_r = [](Solver* s) { return s->scg_; };
+  auto T_p = [](Solver* s) { return s->scg_ + s->ucs_; };
+  auto apply = [&](bool from_p, const double* Eadd) {   // T_w = operator(T_in) with prescribed mean gradient Eadd
+    for (Solver* s : m_) s->slab_front_fast(Eadd, false, from_p ? T_p(s) : T_e(s), false);
+    pass_fast_chain();
+  };
+  auto dot = [&](int mode, bool first_is_p, bool second_is_w, int slot, int n) {
+    for (Solver* s : m_) {
+      s->comm_wait(kXHaloU);
+      s->comm_wait(kXSums);
+      launch_sc_cg_dot(mode, s->gu_, first_is_p ? T_p(s) : T_e(s), second_is_w ? T_w(s) : T_r(s), mode == 1 ? E : Z, s->partial_,
+                       s->dscal_ + slot, s->stream_);
+    }
+    reduce_and_fetch(slot, n, false);
+  };
+  for (Solver* s : m_) {
+    s->slab_cg_alloc();
+    s->comm_wait(kXHaloU);
+    FG_HIP_CHECK(hipMemsetAsync(T_e(s), 0, 3 * (size_t)s->ucs_ * sizeof(double), s->stream_));   // g_0 = E
+    s->su_valid_ = true;
+    s->eps_stale_ = true;
+    s->in_run_ = true;
+    for (int i = 0; i < 6; ++i) s->E_cur_[i] = E.v[i];
+  }
+  apply(false, E.v);
+  for (Solver* s : m_) {
+    s->comm_wait(kXHaloU);
+    const size_t f1 = (size_t)s->ucs_ * sizeof(double);
+    FG_HIP_CHECK(hipMemcpyAsync(T_r(s), T_w(s), f1, hipMemcpyDeviceToDevice, s->stream_));
+    FG_HIP_CHECK(hipMemcpyAsync(T_p(s), T_w(s), f1, hipMemcpyDeviceToDevice, s->stream_));   // p = r
+  }
+  dot(1, false, false, kSlotCg, 7);
+  double gamma = a.hscal_[kSlotCg + 6] / nglobal + small;
+  const double gamma_0 = gamma;
+  double prev = prev0;
+  long iter = 0;
+  bool failed = false;
+  for (;;) {
+    apply(true, Z.v);                       // T_w = operator(T_p)
+    dot(0, true, true, kSlotCg + 8, 1);     // p : (p - w)
+    const double alpha = gamma / (a.hscal_[kSlotCg + 8] / nglobal + small);
+    for (Solver* s : m_)   // g += alpha p ; r -= alpha (p - w), spare planes included
+      launch_sc_cg_axpy(0, s->gu_, T_e(s), T_p(s), T_r(s), T_w(s), alpha, s->stream_, s->ucs_);
+    dot(1, false, false, kSlotCg, 7);       // norms of g ; r : r
+    const double rr = a.hscal_[kSlotCg + 6];
+    for (Solver* s : m_) {
+      s->su_valid_ = true;
+      s->eps_stale_ = true;
+      for (int c = 0; c < 6; ++c) s->E_cur_[c] = E.v[c];
+    }
+    double s3 = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      const double ss = c < 3 ? a.hscal_[kSlotCg + c] : 0.0;
+      for (Solver* s : m_) s->sumsq_[c] = ss;
+      s3 += ss / nglobal;
+    }
+    const double cur = std::sqrt(s3);
+    double abs_err = std::fabs(prev - cur);
+    double rel_err = abs_err / (small + cur);
+    prev = cur;
+    if (residual_est) {   // update_cg(gamma, gamma0)  F:14397-14401
+      abs_err = std::sqrt(gamma);
+      rel_err = std::sqrt(gamma / gamma_0);
+    }
+    if (std::isnan(rel_err) || stop_requested()) {
+      failed = true;
+      break;
+    }
+    for (Solver* s : m_) s->residuals_.push_back(rel_err);
+    bool stop = false, cancelled = false;
+    for (Solver* s : m_) {
+      if (s->cb_ && s->cb_(s->cb_user_)) stop = true;
+      if (s->cancel_) cancelled = true;
+    }
+    if (voting) {
+      double v[2] = {stop ? 1.0 : 0.0, cancelled ? 1.0 : 0.0};
+      vote(v);
+      stop = v[0] != 0.0;
+      cancelled = v[1] != 0.0;
+    }
+    if (a.nranks_ > 1 && !voting) cancelled = false;
+    if (stop) break;
+    if (cancelled) {
+      failed = true;
+      break;
+    }
+    if (iter >= a.opt_.maxiter) break;
+    if (rel_err <= a.opt_.tol || abs_err <= a.opt_.abs_tol) {
+      double S0[6] = {0, 0, 0, 0, 0, 0};
+      if (bc_error(E.v, S0) <= a.opt_.bc_tol) break;
+    }
+    iter++;
+    const double delta = rr / nglobal + small;
+    const double beta = delta / gamma;
+    gamma = delta;
+    for (Solver* s : m_) launch_sc_cg_axpy(1, s->gu_, T_e(s), T_p(s), T_r(s), T_w(s), beta, s->stream_, s->ucs_);   // p = r + beta p
   }
   for (Solver* s : m_) {
     s->in_run_ = false;

@@ -413,10 +413,53 @@ def test_scalar_group_refuses_what_it_does_not_cover():
     with pytest.raises(RuntimeError, match="heat / porous on slab-decomposed"):
         g.run(np.array([1.0, 0, 0]))
     g.close()
-    phi1 = sphere_phi((8, 16, 128), 0.3)
-    g = _scalar_group(2, (8, 16, 128), [1.0, 12.0], [1 - phi1, phi1], method="cg")
-    with pytest.raises(RuntimeError, match="method=cg on slab-decomposed"):
+    g = _scalar_group(2, (16, 16, 16), [1.0, 12.0], [1 - phi1, phi1], method="cg")
+    with pytest.raises(RuntimeError, match="heat / porous on slab-decomposed"):
         g.run(np.array([1.0, 0, 0]))
+    g.close()
+
+
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("P,grid", [(1, (8, 16, 128)), (2, (8, 16, 128)), (4, (16, 16, 128)), (2, (16, 32, 256))])
+def test_scalar_group_cg_matches_oracle(P, grid, residual):
+    from helpers import sphere_phi
+    from oracle.scalar_oracle import ScalarOracle
+    dims = (1.0, 2.0, 1.5)
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 12.0], [1 - phi1, phi1]
+    E = np.array([1.0, -0.5, 0.25])
+    kw = dict(error_estimator="residual") if residual else {}
+    g = _scalar_group(P, grid, mus, phis, dims, tol=1e-10, method="cg", **kw)
+    o = ScalarOracle(*grid, mus=mus, phis=phis, dx=dims[0], dy=dims[1], dz=dims[2], tol=1e-10)
+    if residual:
+        o.error_estimator = "residual"
+    assert o.run_cg(E) is False and g.run(E) is False
+    assert g.iterations == o.iterations and len(g.residuals) == len(o.residuals)
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-10
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-9
+    assert rel_err(g.mean_stress()[:3], o.mean_stress()) < 1e-10
+    g.close()
+
+
+@pytest.mark.parametrize("P,grid", [(2, (8, 16, 128)), (4, (16, 16, 128)), (2, (8, 14, 124))])
+def test_scalar_group_mixed_bc(P, grid):
+    """a flux prescribed in x, gradients prescribed in y and z: the tiled sweep leaves the sums of the flux polarisation, the
+    correction of the prescribed mean is formed from their all-reduced values"""
+    from helpers import sphere_phi
+    from oracle.scalar_oracle import ScalarOracle
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 12.0], [1 - phi1, phi1]
+    P3 = np.diag([0.0, 1.0, 1.0])
+    P6 = np.diag([0.0, 1.0, 1.0, 0.5, 0.5, 0.5])
+    E, S = np.array([0.0, 0.3, -0.2]), np.array([1.5, 0.0, 0.0])
+    g = _scalar_group(P, grid, mus, phis, tol=1e-10, bc_tol=1e-9, maxiter=500)
+    g.set_bc_projector(P6)
+    o = ScalarOracle(*grid, mus=mus, phis=phis, tol=1e-10, bc_tol=1e-9, maxiter=500)
+    assert o.run(E, S, P3) is False and g.run(E, np.concatenate([S, np.zeros(3)])) is False
+    assert g.iterations == o.iterations
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-10
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-9
+    assert g.mean_stress()[0] == pytest.approx(1.5, rel=1e-8) and np.abs(g.mean_strain()[1:3] - E[1:]).max() < 1e-12
     g.close()
 
 
