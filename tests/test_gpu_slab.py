@@ -430,14 +430,28 @@ def test_scalar_group_cg_matches_oracle(P, grid, residual):
     E = np.array([1.0, -0.5, 0.25])
     kw = dict(error_estimator="residual") if residual else {}
     g = _scalar_group(P, grid, mus, phis, dims, tol=1e-10, method="cg", **kw)
-    o = ScalarOracle(*grid, mus=mus, phis=phis, dx=dims[0], dy=dims[1], dz=dims[2], tol=1e-10)
+    assert g.run(E) is False
     if residual:
-        o.error_estimator = "residual"
-    assert o.run_cg(E) is False and g.run(E) is False
-    assert g.iterations == o.iterations and len(g.residuals) == len(o.residuals)
-    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-10
-    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-9
-    assert rel_err(g.mean_stress()[:3], o.mean_stress()) < 1e-10
+        # (the scalar oracle restates the epsilon estimator only: the residual estimator is held against the single-GPU solver)
+        from fibergen_amd import LSSolver
+        s = LSSolver(*grid, *dims)
+        s.set_options(mode="porous")
+        s.set_num_phases(2)
+        for p in range(2):
+            s.set_phase(p, mus[p], 0.0, phis[p])
+        s.set_options(tol=1e-10, method="cg", **kw)
+        assert s.run(E) is False
+        assert g.iterations == s.iterations
+        assert np.abs(np.array(g.residuals) - np.array(s.residuals)).max() < 1e-10 * max(1.0, np.abs(np.array(s.residuals)).max())
+        assert rel_err(g.get_field("epsilon"), s.get_field("epsilon")) < 1e-10
+        s.close()
+    else:
+        o = ScalarOracle(*grid, mus=mus, phis=phis, dx=dims[0], dy=dims[1], dz=dims[2], tol=1e-10)
+        assert o.run_cg(E) is False
+        assert g.iterations == o.iterations and len(g.residuals) == len(o.residuals)
+        assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-10
+        assert rel_err(g.get_field("epsilon"), o.eps) < 1e-9
+        assert rel_err(g.mean_stress()[:3], o.mean_stress()) < 1e-10
     g.close()
 
 
