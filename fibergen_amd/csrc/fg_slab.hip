@@ -186,11 +186,12 @@ double* Solver::slab_buffer(int id) {
 void Solver::slab_exchange(int what, int comp, int done_slot) {
   SlabDims d = slab_dims(nxg_, g_.ny, g_.nz, nranks_, rank_);
   d.loopback = slab_loopback();
+  d.ncomp_u = opt_.mode == 1 ? 1 : 3;
   const size_t pb = (size_t)d.plane * sizeof(double);
   if (nranks_ == 1 && !d.loopback) {
     if (what == FG_PLAN_HALO_U || what == FG_PLAN_HALO_MODULI) {
       double* base = slab_buffer(what == FG_PLAN_HALO_U ? FG_BUF_U : FG_BUF_MODULI);
-      const int nc = what == FG_PLAN_HALO_U ? 3 : 2;
+      const int nc = what == FG_PLAN_HALO_U ? d.ncomp_u : 2;
       for (int c = 0; c < nc; ++c) {
         double* b = base + c * d.ucs;
         FG_HIP_CHECK(hipMemcpyAsync(b + slab_hi_plane(d) * d.plane, b, pb, hipMemcpyDeviceToDevice, stream_));

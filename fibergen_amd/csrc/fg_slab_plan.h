@@ -27,6 +27,7 @@ struct SlabDims {
   long ucs;          // doubles per displacement / moduli component including its 4 spare planes
   long block;        // doubles per all-to-all block
   bool loopback;     // test mode: a rank's own blocks / planes travel through the transport too (send / receive to itself)
+  int ncomp_u;       // components of the displacement buffer whose halo planes travel (3; heat / porous: the one potential)
 };
 
 // All-to-all of the three components in ONE message per peer (comp = -1): a peer's block holds its three components one
@@ -46,6 +47,7 @@ inline SlabDims slab_dims(int nx, int ny, int nz, int nranks, int rank) {
   d.ucs = g.n + 4 * g.nyzp;
   d.block = (long)d.nxl * d.nyl * g.nzp;
   d.loopback = false;
+  d.ncomp_u = 3;
   return d;
 }
 
@@ -103,7 +105,7 @@ inline SlabPlan slab_plan(const SlabDims& d, int what, int comp) {
     case FG_PLAN_HALO_U:      // three displacement components: plane 0 -> left's hi plane, last plane -> right's lo plane
     case FG_PLAN_HALO_MODULI: {
       const int buf = what == FG_PLAN_HALO_U ? FG_BUF_U : FG_BUF_MODULI;
-      const int nc = what == FG_PLAN_HALO_U ? 3 : 2;
+      const int nc = what == FG_PLAN_HALO_U ? d.ncomp_u : 2;
       if (P == 1 && !d.loopback) break;   // periodic inside the slab: the driver copies its own planes
       for (int c = 0; c < nc; ++c) {
         const long b = (long)c * d.ucs;
