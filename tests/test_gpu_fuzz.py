@@ -200,7 +200,9 @@ def test_random_slab_group_matches_oracle(seed):
     assert g.iterations == o.iterations, tag
     assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-9, tag
     assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8, tag
-    assert np.abs(g.mean_stress() - o.mean_stress()).max() < 1e-9 * max(1.0, np.abs(o.mean_stress()).max()), tag
+    # (CG stops on a norm difference: two runs that agree to 1e-8 in the field agree to that, not better, in its means)
+    mtol = 1e-8 if c["method"] == "cg" else 1e-9
+    assert np.abs(g.mean_stress() - o.mean_stress()).max() < mtol * max(1.0, np.abs(o.mean_stress()).max()), tag
     g.close()
 
 
