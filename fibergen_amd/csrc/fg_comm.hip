@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdint>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -140,6 +141,21 @@ __global__ void k_local_allreduce(ReducePtrs bufs, int nranks, int n, int min_op
   for (int r = 0; r < nranks; ++r) bufs.p[r][i] = a;
 }
 
+// The device copies of one in-process exchange as ONE launch (the 8 members of a 256^3 problem post 56 blocks per all-to-all:
+// as separate hipMemcpyAsync calls those tiny copies, not the kernels, bound the emulation of the multi-GPU run on one GPU).
+constexpr int kCopyBatch = 96;
+struct CopyBatch {
+  const double2* src[kCopyBatch];
+  double2* dst[kCopyBatch];
+  unsigned n2[kCopyBatch];   // 16-byte elements
+};
+__global__ void k_local_copy(CopyBatch ops) {
+  const double2* s = ops.src[blockIdx.y];
+  double2* d = ops.dst[blockIdx.y];
+  const unsigned n = ops.n2[blockIdx.y];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 class LocalHub {
  public:
   explicit LocalHub(int n) : n_(n), posted_(n), reduce_(n) {
@@ -157,6 +173,19 @@ class LocalHub {
       cur[r] = std::move(posted_[r].front());
       posted_[r].pop_front();
     }
+    CopyBatch batch;
+    int nb = 0;
+    size_t longest = 0;
+    auto flush = [&]() {
+      if (nb == 0) return;
+      unsigned gx = (unsigned)((longest / 16 + 255) / 256);
+      if (gx > 64) gx = 64;
+      if (gx < 1) gx = 1;
+      hipLaunchKernelGGL(k_local_copy, dim3(gx, nb), dim3(256), 0, stream, batch);
+      FG_HIP_CHECK(hipGetLastError());
+      nb = 0;
+      longest = 0;
+    };
     for (int dst = 0; dst < n_; ++dst) {
       std::vector<size_t> next(n_, 0);   // per source: position of the next unmatched send to dst
       for (const XOp& rv : cur[dst]) {
@@ -167,10 +196,19 @@ class LocalHub {
         while (k < cur[src].size() && !(cur[src][k].send && cur[src][k].peer == dst)) ++k;
         if (k == cur[src].size()) throw std::runtime_error("in-process exchange: receive without a matching send");
         if (cur[src][k].bytes != rv.bytes) throw std::runtime_error("in-process exchange: message sizes differ");
-        FG_HIP_CHECK(hipMemcpyAsync(rv.ptr, cur[src][k].ptr, rv.bytes, hipMemcpyDeviceToDevice, stream));
+        if (rv.bytes % 16 || ((uintptr_t)rv.ptr | (uintptr_t)cur[src][k].ptr) % 16 || rv.bytes / 16 > 0xffffffffu) {
+          FG_HIP_CHECK(hipMemcpyAsync(rv.ptr, cur[src][k].ptr, rv.bytes, hipMemcpyDeviceToDevice, stream));
+        } else {
+          batch.src[nb] = static_cast<const double2*>(cur[src][k].ptr);
+          batch.dst[nb] = static_cast<double2*>(rv.ptr);
+          batch.n2[nb] = (unsigned)(rv.bytes / 16);
+          if (rv.bytes > longest) longest = rv.bytes;
+          if (++nb == kCopyBatch) flush();
+        }
         ++k;
       }
     }
+    flush();
     for (int src = 0; src < n_; ++src) {   // every send must have found its receive
       size_t sends = 0, recvs_of_it = 0;
       for (const XOp& o : cur[src]) sends += o.send ? 1 : 0;
