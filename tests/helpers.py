@@ -66,3 +66,13 @@ def rel_err(a, b):
     d = np.abs(a - b).max()
     s = np.abs(b).max()
     return d / s if s > 0 else d
+
+
+def emulation_build_flags():
+    """g++ flags of the host builds of the kernels' per-thread code (tests/emulate); FG_EMU_SANITIZE=1 adds
+    AddressSanitizer + UBSan (the process must then run with libasan preloaded, see tests/test_emulation_sanitized.py)."""
+    import os
+    flags = ["-std=c++17", "-DFG_HOST_EMULATION", "-ffp-contract=off", "-shared", "-fPIC"]
+    if os.environ.get("FG_EMU_SANITIZE") == "1":
+        return ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] + flags
+    return ["-O2"] + flags

@@ -8,6 +8,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from helpers import emulation_build_flags
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dp = ctypes.POINTER(ctypes.c_double)
 
@@ -19,8 +21,7 @@ def P(a):
 @pytest.fixture(scope="module")
 def emu(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("emu") / "emu_fft.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFG_HOST_EMULATION", "-ffp-contract=off", "-shared", "-fPIC",
-                           "-o", out, os.path.join(ROOT, "tests", "emulate", "emu_fft.cpp")])
+    subprocess.check_call(["g++"] + emulation_build_flags() + ["-o", out, os.path.join(ROOT, "tests", "emulate", "emu_fft.cpp")])
     return ctypes.CDLL(out)
 
 

@@ -380,3 +380,30 @@ def test_raw_class_data_downsampled_with_centroid_normals(tmp_path):
     assert np.all(cosang[dom_incl] < 0.2) and np.all(cosang[~dom_incl & (phi[mixed] < 0.5)] > -0.2)
     assert np.mean(np.abs(cosang)) > 0.7
     assert np.isfinite(np.array(fg.get_mean_stress())).all()
+
+
+@pytest.mark.parametrize("launch", ["plain", "torchrun-slabs"])
+def test_example_run_project_script(tmp_path, launch):
+    """examples/run_project.py: the command-line form of the drop-in (one GPU; under torchrun the x-slab route over RCCL)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proj = tmp_path / "project.xml"
+    proj.write_text("""<settings><solver n="16"><method>basic</method><tol>1e-8</tol><mixing_rule>voigt</mixing_rule>
+      <materials><matrix E="1" nu="0.3" /><incl E="10" nu="0.2" /></materials></solver>
+      <actions><select_material name="incl" /><place_fiber type="capsule" cx="0.5" cy="0.5" cz="0.5" L="0" R="0.3" />
+      <run_load_case e11="0.01" /></actions></settings>""")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "examples", "run_project.py"), str(proj)]
+    if launch != "plain":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29731"] + cmd[1:]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "run() -> 0 ok" in out.stdout
+    line = [l for l in out.stdout.splitlines() if l.startswith("mean stress:")]
+    assert line, out.stdout
+    vals = np.array(eval(line[0].split(":", 1)[1]))   # noqa: S307 -- our own script's printed list
+    assert np.isfinite(vals).all() and vals.flat[0] > 0
+    (tmp_path / ("ms_%s.txt" % launch)).write_text(line[0])

@@ -11,6 +11,8 @@ from itertools import combinations
 import numpy as np
 import pytest
 
+from helpers import emulation_build_flags
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dp = ctypes.POINTER(ctypes.c_double)
 
@@ -18,8 +20,7 @@ dp = ctypes.POINTER(ctypes.c_double)
 @pytest.fixture(scope="module")
 def emu(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("emu") / "emu_cut.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFG_HOST_EMULATION", "-ffp-contract=off", "-shared", "-fPIC",
-                           "-o", out, os.path.join(ROOT, "tests", "emulate", "emu_cut.cpp")])
+    subprocess.check_call(["g++"] + emulation_build_flags() + ["-o", out, os.path.join(ROOT, "tests", "emulate", "emu_cut.cpp")])
     lib = ctypes.CDLL(out)
     lib.emu_cut_fraction.restype = ctypes.c_double
     lib.emu_cut_fraction.argtypes = [ctypes.c_double] * 4
