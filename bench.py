@@ -323,6 +323,8 @@ def measure_single(args, n_edge, mixing, mode, device, E, detail):
 
 
 def main():
+    # dmabuf IPC (the host driver has no legacy IPC): read by the HSA runtime when the first HIP call initialises it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)

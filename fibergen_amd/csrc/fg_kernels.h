@@ -152,6 +152,7 @@ void launch_sc_sweep(const Grid& g, const ScalarParams& sp, const double* T, con
 // fast variant: a = per-voxel effective conductivity (launch_effective_moduli with 2 mu_p := mu_p, first array)
 // sumtau3 != nullptr: also the three sums of the flux polarisation (mixed boundary conditions); returns whether they were
 // produced (the LDS-tiled form does, the untiled one does not)
+bool sc_sweep_tiled(const Grid& g);   // launch_sc_sweep_fast takes the tiled kernel (the one that can carry the sums of tau)
 bool launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
                           double* partial, double* sumsq6, hipStream_t s, double* sumtau3 = nullptr);
 void launch_sc_grad(const Grid& g, const double* T, const FieldPtrs<3>& out, const Vec6& E, double* partial,
@@ -161,7 +162,7 @@ void launch_sc_flux(const Grid& g, const ScalarParams& sp, const FieldPtrs<3>& g
 void launch_sc_flux_mean(const Grid& g, const ScalarParams& sp, const FieldPtrs<3>& gr, const FieldPtrs<kMaxPhases>& phi,
                          double* partial, double* out6, hipStream_t s);
 void launch_sc_div(const Grid& g, const FieldPtrs<3>& x, double scale, double* y, hipStream_t s);
-void launch_g0_heat(const Grid& g, double* fh, const G0Tables& tb, double c10, hipStream_t s);
+void launch_g0_heat(const Grid& g, double* fh, const G0Tables& tb, double c10, hipStream_t s, int jj0 = 0);
 // CG in potential space (scalar modes): dot products of forward-difference gradients, point-wise updates
 void launch_sc_cg_dot(int mode, const Grid& g, const double* a, const double* b, const Vec6& E, double* partial, double* out7,
                       hipStream_t s);

@@ -721,8 +721,9 @@ __global__ __launch_bounds__(kBlock) void k_sc_sweep_fast(Grid g, double beta, c
     const int lane = threadIdx.x & 63;
     const bool prev_ok = lane > 0 && p.k > 0;
     const bool next_ok = lane < 63 && p.k + 2 < g.nz && pidx_raw + 1 < npairs;
-    const long xf = (p.i + 1 == g.nx ? -(long)(g.nx - 1) : 1L) * g.nyzp;
-    const long xb = (p.i == 0 ? (long)(g.nx - 1) : -1L) * g.nyzp;
+    // x neighbours through Grid::xw_lo / xw_hi: periodic in a whole grid, the spare planes of T and a in an x-slab
+    const long xf = (p.i + 1 == g.nx ? (long)(g.nx - g.xw_hi) - p.i : 1L) * g.nyzp;
+    const long xb = (p.i == 0 ? (long)(g.xw_lo - 1) : -1L) * g.nyzp;
     const long yf = (p.j + 1 == g.ny ? -(long)(g.ny - 1) : 1L) * g.nzp;
     const long yb = (p.j == 0 ? (long)(g.ny - 1) : -1L) * g.nzp;
     const long ro = p.off - p.k;
@@ -1109,10 +1110,14 @@ void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double*
   FG_HIP_CHECK(hipGetLastError());
 }
 
+bool sc_sweep_tiled(const Grid& g) {
+  static const int tile_env = getenv("FG_SC_TILE") ? atoi(getenv("FG_SC_TILE")) : 1;
+  return tile_env && u_tile_supported(g);
+}
+
 bool launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
                           double* partial, double* sumsq6, hipStream_t s, double* sumtau3) {
-  static const int tile_env = getenv("FG_SC_TILE") ? atoi(getenv("FG_SC_TILE")) : 1;
-  if (tile_env && u_tile_supported(g)) {
+  if (sc_sweep_tiled(g)) {
     const int nzh = g.nz / 2;
     if (nzh == 64) launch_sc_tile_t<8, 1>(g, mu_0, T, a, f, E, partial, sumsq6, s, sumtau3);
     else if (nzh == 128) launch_sc_tile_t<6, 2>(g, mu_0, T, a, f, E, partial, sumsq6, s, sumtau3);   // 48 KB of LDS images

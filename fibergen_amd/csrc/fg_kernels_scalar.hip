@@ -205,14 +205,15 @@ __global__ __launch_bounds__(kBlock) void k_sc_div(Grid g, FieldPtrs<3> x, doubl
 }
 
 // G0OperatorFourierStaggeredGeneralHeat  F:19779-19823: T_hat = c10 / |k|^2 f_hat, zero mode 0
-__global__ __launch_bounds__(kBlock) void k_g0_heat(Grid g, cplx* fh, G0Tables tb, double c10) {
+// jj0: the slab driver's y-slab [nx][ny/P][nzc] holds the ky rows jj0 .. jj0 + g.ny - 1
+__global__ __launch_bounds__(kBlock) void k_g0_heat(Grid g, cplx* fh, G0Tables tb, double c10, int jj0) {
   const long nfreq = (long)g.nx * g.ny * g.nzc;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < nfreq; idx += (long)gridDim.x * blockDim.x) {
     const long row = idx / g.nzc;
     const int kk = (int)(idx - row * g.nzc);
     if (kk >= g.nzf) continue;
     const int ii = (int)(row / g.ny);
-    const int jj = (int)(row - (long)ii * g.ny);
+    const int jj = jj0 + (int)(row - (long)ii * g.ny);
     cplx e;
     if (ii == 0 && jj == 0 && kk == 0) {
       e = cmake(0.0, 0.0);
@@ -371,9 +372,9 @@ void launch_sc_div(const Grid& g, const FieldPtrs<3>& x, double scale, double* y
   FG_HIP_CHECK(hipGetLastError());
 }
 
-void launch_g0_heat(const Grid& g, double* fh, const G0Tables& tb, double c10, hipStream_t s) {
+void launch_g0_heat(const Grid& g, double* fh, const G0Tables& tb, double c10, hipStream_t s, int jj0) {
   const long nfreq = (long)g.nx * g.ny * g.nzc;
-  hipLaunchKernelGGL(k_g0_heat, dim3(grid_cap(nfreq, 1 << 20)), dim3(kBlock), 0, s, g, reinterpret_cast<cplx*>(fh), tb, c10);
+  hipLaunchKernelGGL(k_g0_heat, dim3(grid_cap(nfreq, 1 << 20)), dim3(kBlock), 0, s, g, reinterpret_cast<cplx*>(fh), tb, c10, jj0);
   FG_HIP_CHECK(hipGetLastError());
 }
 

@@ -252,9 +252,8 @@ void Solver::slab_fetch_norms(int n) {
 }
 
 bool Solver::slab_fast_ok(bool allow_mixed_bc) const {
-  if (opt_.mode == 1)   // heat / porous: the tiled potential sweep + the fused one-component x pass, prescribed gradients
-    return opt_.u_loop >= 2 && opt_.gamma_scheme == 0 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 &&
-           u_tile_supported(g_) && opt_.fuse_x && fft_ys_ && nxg_ > 1 && fft_ys_->can_fuse(0, 1) &&
+  if (opt_.mode == 1)   // heat / porous: the potential sweep on the precomputed conductivity
+    return opt_.u_loop >= 2 && opt_.gamma_scheme == 0 && pt_.n >= 1 && opt_.mixing == kMixVoigt && opt_.bc_relax == 1.0 && fft_ys_ &&
            (frobenius(BC_MQ_) < kEps || allow_mixed_bc);
   if (!(opt_.u_loop >= 2 && opt_.u_tile && opt_.mode == 0 && opt_.gamma_scheme == 0 && pt_.n >= 1 &&
         (opt_.mixing == kMixVoigt || (opt_.mixing == kMixLaminate && normals_)) && opt_.bc_relax == 1.0 && u_tile_supported(g_)))
@@ -299,8 +298,13 @@ void Solver::slab_front_fast(const double* E6, bool sum_tau, const double* u_src
     // f = div((a - 2 mu0) g_k)
     // (mixed BC: the sweep also leaves the three sums of the flux polarisation in kSlotMean; entries 3..5 stay zero)
     if (sum_tau) FG_HIP_CHECK(hipMemsetAsync(dscal_ + kSlotMean, 0, 6 * sizeof(double), stream_));
-    launch_sc_sweep_fast(gu_, opt_.mu_0, u_in, smod_, fu_, E, partial_, dscal_ + kSlotSumSq, stream_,
-                         sum_tau ? dscal_ + kSlotMean : nullptr);
+    const bool have_sums = launch_sc_sweep_fast(gu_, opt_.mu_0, u_in, smod_, fu_, E, partial_, dscal_ + kSlotSumSq, stream_,
+                                                sum_tau ? dscal_ + kSlotMean : nullptr);
+    if (sum_tau && !have_sums) {
+      // grids the tiled sweep does not fit: sums of tau = P(g) - 2 mu0 g from the gradient field (two more sweeps, as on one GPU)
+      launch_sc_grad(gu_, u_in, ptrs3(eps_), E, partial_, dscal_ + kSlotScratch, stream_);
+      launch_sc_flux_mean(g_, scalar_params(opt_.mu_0, 1.0), ptrs3(eps_), phase_ptrs(), partial_, dscal_ + kSlotMean, stream_);
+    }
     time_end(0);
     if (reduce) slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
     return;
@@ -425,10 +429,17 @@ void Solver::slab_chain_step(int k) {
     const int jj0 = rank_ * nyl_;   // this rank's ky rows
     time_begin(5);
     if (NC == 1) {
-      // G0OperatorFourierStaggeredHeat  F:19758-19823: c1 = c10 / |k|^2, c10 = -alpha / (2 mu0), inside the fused x pass
+      // G0OperatorFourierStaggeredHeat  F:19758-19823: c1 = c10 / |k|^2, c10 = -alpha / (2 mu0)
       gp.c10 = -alpha / (2 * opt_.mu_0);
       gp.c20 = 0.0;
-      fft_ys_->fused_g0(R, n, 0, scale, gp, jj0, 1);
+      if (opt_.fuse_x && nxg_ > 1 && fft_ys_->can_fuse(0, 1)) {
+        fft_ys_->fused_g0(R, n, 0, scale, gp, jj0, 1);   // inside the fused x pass
+      } else {
+        if (nxg_ > 1) fft_ys_->c2c_x(R, 1, n, -1, scale);
+        else fft_ys_->scale(R, 1, n, scale);
+        launch_g0_heat(make_grid(nxg_, nyl_, g_.nz, 1.0, 1.0, 1.0), R, tb, gp.c10, stream_, jj0);
+        if (nxg_ > 1) fft_ys_->c2c_x(R, 1, n, +1, 1.0);
+      }
     } else if (inter) {
       // y-slab [p][c][nxl][nyl][nzc]: component stride one block, x plane j at j * ls + (j / nxl) * 2 blocks
       int sh = 0;
@@ -567,8 +578,8 @@ void SlabGroup::check_members() const {
 // heat / porous on slabs: the potential-based fast path only (prescribed mean gradients, a grid the tiled sweep fits)
 void SlabGroup::require_scalar_fast(bool allow_mixed_bc) const {
   if (m_[0]->opt_.mode == 1 && !fast_ok(allow_mixed_bc))
-    throw std::runtime_error("heat / porous on slab-decomposed solvers: Voigt mixing, u_loop=2, fuse_x=1, bc_relax=1 and a grid the "
-                             "tiled sweep fits (nz/2 >= 62, ny >= 14, local nx >= 4, nx a power of two <= 512)");
+    throw std::runtime_error("heat / porous on slab-decomposed solvers: Voigt mixing, u_loop=2, bc_relax=1 (method=cg: prescribed "
+                             "mean gradients)");
 }
 
 void SlabGroup::synchronize() {

@@ -205,8 +205,8 @@ class FG:
         created with device = LOCAL_RANK): the voxel grid of every load case is cut into x-slabs over the ranks
         (fibergen_amd.distributed.DistributedLSSolver: RCCL all-to-all between the FFT axes, halo planes, all-reduced
         norms).  Every rank runs the same project and sees the same results; fields returned by get_field are gathered.
-        nx and ny must be divisible by the number of ranks; <loadsteps> without extrapolation; elasticity, viscosity, and heat /
-        porous on grids the tiled sweep fits."""
+        nx and ny must be divisible by the number of ranks; <loadsteps> without extrapolation; elasticity, viscosity, heat and
+        porous (Voigt mixing; CG with prescribed mean gradients)."""
         self._slabs = bool(enable)
         self._slab_group = group
         self._solver_valid = False

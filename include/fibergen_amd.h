@@ -185,8 +185,9 @@ fg_solver* fg_create_slab(int nx, int ny, int nz, double dx, double dy, double d
  * all stream-ordered: exchanges run on a second stream joined by events, the host waits only for the norms of the
  * stop rule.  Grids the tiled sweep does not fit take the strain-state pipeline (polarisation, halo of tau, divergence,
  * the same transform chain, halo of u, strain + norms) under the same driver.  method = cg (displacement space where the
- * tiled sweep applies, strain space otherwise), fg_run_load_steps, mode = heat / porous (tiled potential sweep, prescribed
- * mean gradients) and mode = viscosity (strain-state pipeline, basic scheme and CG) run on slabs as well.
+ * tiled sweep applies, strain space otherwise), fg_run_load_steps, mode = heat / porous (potential sweep with halo planes, any
+ * grid; basic scheme also with mixed boundary conditions, CG with prescribed mean gradients) and mode = viscosity (strain-state
+ * pipeline, basic scheme and CG) run on slabs as well.
  *
  * Transports (exactly one per solver, before the first collective call):
  *   fg_slab_connect_rccl      one process per GPU; RCCL (ncclSend / ncclRecv groups, ncclAllReduce) over xGMI.

@@ -284,3 +284,72 @@ def test_random_scalar_and_viscosity_problems_match_their_oracles(seed):
     ms = np.asarray(s.mean_stress())[:len(np.atleast_1d(o.mean_stress()))]
     assert np.abs(ms - o.mean_stress()).max() < 1e-9 * max(1.0, np.abs(o.mean_stress()).max()), tag
     s.close()
+
+
+def draw_scalar_slab(seed):
+    rng = np.random.default_rng(13000 + seed)
+    P = int(rng.choice([1, 2, 3, 4]))
+    if rng.random() < 0.3:                  # grids the tiled sweep fits
+        shape = (P * int(rng.choice([4, 8])), P * int(rng.choice([4, 6])) if P > 1 else 16, int(rng.choice([124, 128])))
+    else:
+        while True:
+            shape = (P * int(rng.choice([1, 2, 3, 4, 6])), P * int(rng.choice([1, 2, 3, 4, 5])), int(rng.choice(LENGTHS_Z[:9])))
+            if 8 <= shape[0] * shape[1] * shape[2] <= 20000:
+                break
+    dims = tuple(float(v) for v in rng.uniform(0.5, 2.0, size=3))
+    nph = int(rng.integers(1, 4))
+    mus = [float(rng.uniform(0.05, 20.0)) for _ in range(nph)]
+    if nph == 1:
+        phis = [np.ones(shape)]
+    elif nph == 2:
+        p1 = smooth_field(rng, shape)
+        phis = [1.0 - p1, p1]
+    else:
+        p1, p2 = smooth_field(rng, shape), smooth_field(rng, shape)
+        p2 = np.minimum(p2, 1.0 - p1)
+        phis = [1.0 - p1 - p2, p1, p2]
+    opts = {}
+    if rng.random() < 0.3:
+        opts["fuse_x"] = int(rng.integers(0, 2))
+    return dict(P=P, shape=shape, dims=dims, mus=mus, phis=phis, mode=str(rng.choice(["heat", "porous"])),
+                method="cg" if rng.random() < 0.35 else "basic", bc=rng.random() < 0.3, E=rng.uniform(-1.0, 1.0, size=3), opts=opts)
+
+
+@pytest.mark.parametrize("seed", range(N_SLAB))
+def test_random_scalar_slab_group_matches_oracle(seed):
+    """mode = heat / porous on the slab driver: any grid (tiled or untiled potential sweep with halo planes, fused or separate
+    x pass on the y-slab), basic scheme (also with a prescribed mean flux) and CG."""
+    from fibergen_amd.distributed import SlabGroup
+    from oracle.scalar_oracle import ScalarOracle
+    c = draw_scalar_slab(seed)
+    shape, dims = c["shape"], c["dims"]
+    common = dict(tol=1e-7, maxiter=300)
+    g = SlabGroup(*shape, *dims, nranks=c["P"])
+    g.set_options(mode=c["mode"])
+    g.set_num_phases(len(c["mus"]))
+    for p, (mu, phi) in enumerate(zip(c["mus"], c["phis"])):
+        g.set_phase(p, mu, 0.0, phi)
+    g.set_options(method=c["method"], **common, **c["opts"])
+    o = ScalarOracle(*shape, mus=c["mus"], phis=c["phis"], dx=dims[0], dy=dims[1], dz=dims[2], **common)
+    tag = "seed %d: %s" % (seed, {k: c[k] for k in ("P", "shape", "mode", "method", "bc", "opts")})
+    E = c["E"].copy()
+    if c["bc"] and c["method"] == "basic":
+        P3 = np.diag([1.0, 0.0, 1.0])       # gradient prescribed along x and z, zero mean flux along y
+        P6 = np.zeros((6, 6))
+        P6[:3, :3] = P3
+        E = E * np.array([1.0, 0.0, 1.0])
+        g.set_bc_projector(P6)
+        g.set_options(bc_tol=1e-8)
+        o.bc_tol = 1e-8
+        ref_failed = o.run(E, np.zeros(3), P3)
+        failed = g.run(E, np.zeros(6))
+    else:
+        ref_failed = o.run_cg(E) if c["method"] == "cg" else o.run(E)
+        failed = g.run(E)
+    assert failed == ref_failed, tag
+    assert g.iterations == o.iterations, tag
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-9, tag
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8, tag
+    mtol = 1e-8 if c["method"] == "cg" else 1e-9
+    assert np.abs(np.asarray(g.mean_stress())[:3] - o.mean_stress()).max() < mtol * max(1.0, np.abs(o.mean_stress()).max()), tag
+    g.close()
