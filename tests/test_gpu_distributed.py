@@ -230,6 +230,7 @@ def test_cancel_on_one_rank_stops_every_rank(tmp_path, transport, method):
     (2, "8,16,128", "laminate", "basic", "rccl", "elasticity"),
     (4, "16,16,16", "voigt", "cg", "callback", "elasticity"),
     (2, "8,16,128", "voigt", "basic", "rccl", "porous"),
+    (2, "12,10,6", "voigt", "cg", "rccl", "porous"),
     (2, "12,10,6", "voigt", "cg", "callback", "viscosity"),
 ])
 def test_fg_project_on_slabs(tmp_path, nproc, grid, mixing, method, transport, mode):
@@ -255,7 +256,8 @@ def test_fg_project_on_slabs(tmp_path, nproc, grid, mixing, method, transport, m
 
 
 @pytest.mark.parametrize("transport", ["callback", "rccl"])
-@pytest.mark.parametrize("nproc,grid,split", [(2, "8,16,128", 0), (4, "16,16,128", 1)])
+@pytest.mark.parametrize("nproc,grid,split", [(2, "8,16,128", 0), (4, "16,16,128", 1),
+                                              (2, "12,10,7", 0)])   # untiled sweep, separate x pass on the y-slab
 def test_porous_mode_on_slabs_one_rank_per_process(tmp_path, transport, nproc, grid, split):
     """mode = porous (BASELINE config 5's physics) cut into slabs: potential with halo planes, one-component all-to-all"""
     from helpers import sphere_phi
