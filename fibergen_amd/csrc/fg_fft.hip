@@ -840,9 +840,17 @@ void xfused_n(XFusedArgs a, int nouter, int ncomp, hipStream_t s) {
   // (half-segment tiles, C = 4, were measured for N = 512: 2.96 ms against 2.5 ms)
   // three components: 8-column (128-byte) tiles whatever the length -- more, smaller workgroups balance better over the
   // 256 CUs than 256-thread tiles of short lines (128^3: 0.037 -> 0.035 ms, 6 220 -> 6 315 it/s; 64^3: +1 %)
-  if (ncomp == 1) xfused_nc<N, XTileCols<N>::value, 1>(a, nouter, s);
-  else if (a.xjump != 0) xfused_nc<N, 8, 3, true>(a, nouter, s);   // slab decomposition, components interleaved per peer
-  else xfused_nc<N, 8, 3>(a, nouter, s);
+  if constexpr (N == 1024) {
+    // 1024-point lines: the exchange buffer of an 8-column tile (147 KB) leaves no room for 512 threads' worth of registers
+    // (16 waves: 128 VGPRs each, the three spectra alone take 96) -- half-segment tiles, still one pass instead of three
+    if (ncomp == 1) xfused_nc<N, 4, 1>(a, nouter, s);   // (8 columns = 16 waves at 128 VGPRs: 33 spilled)
+    else if (a.xjump != 0) throw std::runtime_error("fft: interleaved slab layout: x lines up to 512");
+    else xfused_nc<N, 4, 3>(a, nouter, s);
+  } else {
+    if (ncomp == 1) xfused_nc<N, XTileCols<N>::value, 1>(a, nouter, s);
+    else if (a.xjump != 0) xfused_nc<N, 8, 3, true>(a, nouter, s);   // slab decomposition, components interleaved per peer
+    else xfused_nc<N, 8, 3>(a, nouter, s);
+  }
 }
 
 template <int N, int C, int NC, bool XSPLIT>
@@ -1116,7 +1124,7 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
 // scale, Green operator, inverse transform -- one kernel for the three components.
 bool Fft3::can_fuse(int axis, int ncomp) const {
   const int n = axis == 0 ? g_.nx : g_.ny;
-  if (fast_[axis]) return n <= 512;
+  if (fast_[axis]) return n <= 1024;
   // p * 2^k with p = 3, 5: the three-component form only
   if (ncomp != 3 || (odd_[axis] != 3 && odd_[axis] != 5)) return false;
   XFusedArgs a = {};
@@ -1212,6 +1220,7 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
     case 128: xfused_n<128>(a, nouter, ncomp, stream_); break;
     case 256: xfused_n<256>(a, nouter, ncomp, stream_); break;
     case 512: xfused_n<512>(a, nouter, ncomp, stream_); break;
+    case 1024: xfused_n<1024>(a, nouter, ncomp, stream_); break;
     default: throw std::runtime_error("fft: unsupported fused length");
   }
 }

@@ -159,8 +159,8 @@ bool Solver::slab_interleave() const {
   if (env == 0 || opt_.slab_interleave == 0) return false;
   if (slab_split() || !(nranks_ > 1 || slab_loopback()) || opt_.mode != 0) return false;
   const int nxl = g_.nx;
-  return fft_ && fft_ys_ && fft_->can_block_y(nranks_) && opt_.fuse_x && nxg_ > 1 && fft_ys_->fast_x() && fft_ys_->can_fuse(0) &&
-         nxl > 0 && (nxl & (nxl - 1)) == 0;
+  return fft_ && fft_ys_ && fft_->can_block_y(nranks_) && opt_.fuse_x && nxg_ > 1 && nxg_ <= 512 && fft_ys_->fast_x() &&
+         fft_ys_->can_fuse(0) && nxl > 0 && (nxl & (nxl - 1)) == 0;
 }
 
 // Test mode for boxes with ONE GPU: a lone slab connected to a transport sends its all-to-all blocks and halo planes to

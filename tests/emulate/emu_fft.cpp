@@ -124,7 +124,7 @@ int emu_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, doub
   a.kp[2] = reinterpret_cast<const cplx*>(kp2);
 #define CASE(n)                                                               \
   if (N == n) {                                                               \
-    constexpr int C = 8; /* the product's tile width for three components */     \
+    constexpr int C = n == 1024 ? 4 : 8; /* the product's tile width for three components */ \
     a.tiles_per_outer = (a.ncols + C - 1) / C;                                \
     for (int q = 0; q < 8; ++q) {                                             \
       const double th = 3.14159265358979323846 * fft::Line<n>::last_index(0, q) / n;      \
@@ -133,7 +133,7 @@ int emu_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, doub
     run_blocks<XFusedKernel<n, C>, XFusedArgs>((long)a.tiles_per_outer, a);   \
     return 0;                                                                 \
   }
-  CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) CASE(512)
+  CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) CASE(512) CASE(1024)
 #undef CASE
   return 1;
 }

@@ -82,7 +82,7 @@ def test_generic_dft(emu, n):
     assert np.abs(dst[:, :n] - ref).max() < 1e-12 * max(1, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("N", [8, 32, 64, 128, 256, 512])
+@pytest.mark.parametrize("N", [8, 32, 64, 128, 256, 512, 1024])
 def test_fused_x_pass(emu, N):
     """The fused kernel of the hot loop (x-FFT, 1/N, Green operator with the transformed axis' factors rebuilt from
     e^{i pi kx/N}, inverse x-FFT) run thread by thread on the host against numpy: G0OperatorFourierStaggeredGeneral

@@ -696,3 +696,47 @@ def test_stress_driven_laminate_demo_closed_form():
     assert np.abs(s.mean_strain() - want).max() < 1e-8 * 0.01
     assert abs(s.mean_stress()[0] - Cw[0] @ want) < 1e-8 * abs(Cw[0] @ want)
     s.close()
+
+
+@pytest.mark.parametrize("mode,mixing", [("elasticity", "voigt"), ("elasticity", "laminate"), ("porous", "voigt")])
+def test_x_lines_of_1024_points_take_the_fused_pass(mode, mixing):
+    """nx = 1024: the fused x pass on half-segment (4-column) tiles -- an 8-column tile's exchange buffer would leave 16 waves
+    128 registers each.  Four passes of the default loop against the oracle, and against fuse_x = 0 (three separate passes)."""
+    grid = (1024, 16, 128)
+    E = np.array([0.01, -0.004, 0.002, 0.003, -0.001, 0.002])
+    if mode == "porous":
+        from fibergen_amd import LSSolver
+        from helpers import sphere_phi
+        from oracle.scalar_oracle import ScalarOracle
+        phi1 = sphere_phi(grid, 0.3)
+        mus, phis = [1.0, 9.0], [1 - phi1, phi1]
+        o = ScalarOracle(*grid, mus=mus, phis=phis, tol=-1.0, maxiter=4)
+        o.abs_tol = -1.0
+        o.run(E[:3])
+        out = []
+        for fuse in (1, 0):
+            s = LSSolver(*grid)
+            s.set_options(mode="porous")
+            s.set_num_phases(2)
+            for p in range(2):
+                s.set_phase(p, mus[p], 0.0, phis[p])
+            s.set_options(tol=-1.0, abs_tol=-1.0, maxiter=4, fuse_x=fuse)
+            s.run(E[:3])
+            assert s.iterations == o.iterations == 4
+            assert np.abs(np.array(s.residuals) - np.array(o.residuals)).max() < 1e-11
+            out.append(s.get_field("epsilon"))
+            s.close()
+        assert rel_err(out[0], o.eps) < 1e-11 and rel_err(out[0], out[1]) < 1e-12
+        return
+    o = make_oracle(grid, mixing=mixing, tol=-1.0, maxiter=4)
+    o.abs_tol = -1.0
+    o.run(E)
+    out = []
+    for fuse in (1, 0):
+        s = make_gpu_solver(grid, mixing=mixing, tol=-1.0, abs_tol=-1.0, maxiter=4, fuse_x=fuse)
+        s.run(E)
+        assert s.iterations == o.iterations == 4
+        assert np.abs(np.array(s.residuals) - np.array(o.residuals)).max() < 1e-11
+        out.append(s.get_field("epsilon"))
+        s.close()
+    assert rel_err(out[0], o.eps) < 1e-11 and rel_err(out[0], out[1]) < 1e-12
