@@ -50,6 +50,10 @@ class Fft3 {
   // fused_g0(..., xlayout = true) works on it in place.  Out of place (in != out).
   bool can_xlayout() const;
   void c2c_y_xlayout(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale);
+  // small grids: the z and y transforms of a z-y plane in one kernel (the complex plane [ny][nzc] in LDS, fg_fft_plane.h);
+  // dir = -1: r2c along z then c2c along y (= r2c_z + c2c_y), dir = +1: the inverse pair (= c2c_y + c2r_z), in place
+  bool can_plane() const;
+  void zy_plane(double* data, int ncomp, long comp_stride, int dir);
   bool can_fuse(int axis, int ncomp = 3) const;
   // ncomp = 3: elastic Green operator on three components; ncomp = 1: scalar (heat / porous) operator c10 / |k|^2
   // xjump != 0 (doubles): line point j of the x pass sits at j * ls + (j >> xsplit) * xjump (interleaved slab layout)

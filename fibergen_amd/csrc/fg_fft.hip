@@ -14,6 +14,7 @@
 #include <string>
 
 #include "fg_fft_kernels.h"
+#include "fg_fft_plane.h"
 #include "fg_fft_tables.h"
 #include "fg_hip_util.h"
 
@@ -72,6 +73,30 @@ __global__ __launch_bounds__(K::THREADS) void k_zpass(ZArgs a, long comp_stride)
   a.data += (long)blockIdx.y * comp_stride;
   typename K::Regs r;
   DevicePhases<K, ZArgs, 0>::run(r, blockIdx.x, threadIdx.x, lds, a);
+}
+
+// z + y transforms of one plane per workgroup (fg_fft_plane.h); blockIdx.y = component
+template <class K, int PH>
+struct DevicePhasesP {
+  __device__ __forceinline__ static void run(typename K::Regs& r, int block, int tid, double* lds, const PlaneArgs& a) {
+    K::template phase<PH>(r, block, tid, lds, a);
+    if constexpr (PH + 1 < K::NPHASE) {
+      if constexpr (K::barrier_after(PH) == 2 || K::THREADS <= 64) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      DevicePhasesP<K, PH + 1>::run(r, block, tid, lds, a);
+    }
+  }
+};
+template <class K>
+__global__ __launch_bounds__(K::THREADS) void k_plane(PlaneArgs a, long comp_stride) {
+  extern __shared__ __align__(16) double lds[];
+  a.data += (long)blockIdx.y * comp_stride;
+  typename K::Regs r;
+  DevicePhasesP<K, 0>::run(r, blockIdx.x, threadIdx.x, lds, a);
 }
 
 // tools/xfused_probe.hip compiles this file with -DFG_PROBE: cycle stamps (s_memtime) of one wave per sampled
@@ -820,6 +845,36 @@ void launch_strided(const StridedArgs& a, long nblocks, int ncomp, long comp_str
 }
 
 template <class K>
+void launch_plane(const PlaneArgs& a, int nplanes, int ncomp, long comp_stride, hipStream_t s) {
+  static PerDeviceOnce configured;
+  const size_t lds = K::LDS_DOUBLES * sizeof(double);
+  if (auto once = configured.first_use()) {
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plane<K>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(k_plane<K>, dim3((unsigned)nplanes, ncomp), dim3(K::THREADS), lds, s, a, comp_stride);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+// (ny, nz / 2) pairs the plane kernels are built for: THREADS = ny * nz / 16 <= 1024, the complex plane within the LDS
+template <int NY, int M>
+bool plane_nm(int ny, int m, bool probe, const PlaneArgs& a, int nplanes, int ncomp, long cs, int dir, hipStream_t s) {
+  if (ny != NY || m != M) return false;
+  if (probe) return true;
+  if (dir < 0) launch_plane<ZYKernel<NY, M>>(a, nplanes, ncomp, cs, s);
+  else launch_plane<YZKernel<NY, M>>(a, nplanes, ncomp, cs, s);
+  return true;
+}
+bool plane_dispatch(int ny, int m, bool probe, const PlaneArgs& a, int nplanes, int ncomp, long cs, int dir, hipStream_t s) {
+#define FG_PLANE(NY, M) plane_nm<NY, M>(ny, m, probe, a, nplanes, ncomp, cs, dir, s)
+  return FG_PLANE(16, 8) || FG_PLANE(16, 16) || FG_PLANE(16, 32) || FG_PLANE(16, 64) || FG_PLANE(32, 8) || FG_PLANE(32, 16) ||
+         FG_PLANE(32, 32) || FG_PLANE(32, 64) || FG_PLANE(64, 8) || FG_PLANE(64, 16) || FG_PLANE(64, 32) || FG_PLANE(64, 64) ||
+         FG_PLANE(128, 8) || FG_PLANE(128, 16) || FG_PLANE(128, 32) || FG_PLANE(128, 64) || FG_PLANE(256, 8) ||
+         FG_PLANE(256, 16) || FG_PLANE(256, 32);   // (256, 64): 264 KB
+#undef FG_PLANE
+}
+
+template <class K>
 void launch_z(const ZArgs& a, int ncomp, long comp_stride, int lines, hipStream_t s) {
   static PerDeviceOnce configured;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
@@ -1129,6 +1184,17 @@ bool Fft3::can_fuse(int axis, int ncomp) const {
   if (ncomp != 3 || (odd_[axis] != 3 && odd_[axis] != 5)) return false;
   XFusedArgs a = {};
   return odd_[axis] == 3 ? xfused_mixed_p<3>(n / 3, a, 0, nullptr, stream_, true) : xfused_mixed_p<5>(n / 5, a, 0, nullptr, stream_, true);
+}
+
+bool Fft3::can_plane() const {
+  if (!fast_[1] || !fast_[2] || g_.nz % 2) return false;
+  return plane_dispatch(g_.ny, g_.nz / 2, true, PlaneArgs{}, 0, 0, 0, 0, stream_);
+}
+
+void Fft3::zy_plane(double* data, int ncomp, long comp_stride, int dir) {
+  PlaneArgs a = {data, (long)g_.ny * g_.nzp, g_.nzp, tw_[2], wz_, tw_[1]};
+  if (!can_plane() || !plane_dispatch(g_.ny, g_.nz / 2, false, a, g_.nx, ncomp, comp_stride, dir, stream_))
+    throw std::runtime_error("fft: plane kernels not available for this grid");
 }
 
 bool Fft3::can_xlayout() const {

@@ -73,6 +73,7 @@ struct SolverOptions {
   int slab_loopback = 0;        // test mode: a lone slab sends to itself through its transport (see Solver::slab_loopback)
   int slab_split = -1;          // slab driver: all-to-all per component, overlapping the next component's transforms (1), one
                                 // exchange for the three components (0), or by slab size (-1)
+  int plane_fft = -1;           // z and y transforms of a z-y plane in one kernel (small grids): -1 where available, 0 off, 1 on
   int x_layout = -1;            // x-contiguous intermediate layout [zc/8][y][x][8] between the y passes and the fused x pass
                                 // (the spectrum goes through tau_, free in the displacement loop): 1 on, 0 off, -1 by size
   int fuse_z = 0;               // attach the z r2c transform to the untiled fast sweep (u_tile = 0): 1 on, 0 off, -1 by size
@@ -195,6 +196,7 @@ class Solver {
   // r2c (unless z_done: buf already holds the z spectrum), y, x + Green operator + x^-1, y^-1, c2r on 3 components
   // c12: optional {c10, c20} replacing the factors derived from (mu_0, lambda_0, alpha)
   // xscratch: three free components the spectrum may pass through in the x-contiguous layout (nullptr: in place, plain layout)
+  bool plane_fft_on() const;
   void fft_g0_chain(double* buf, bool z_done = false, double alpha = -1.0, const double* c12 = nullptr, double* xscratch = nullptr);
   void ensure_eps();                    // materialise eps = E + sym grad u if the loop left it implicit
   void recompute_bc();

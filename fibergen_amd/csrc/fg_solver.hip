@@ -662,17 +662,32 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
   for (int c = 0; c < 6; ++c) E_cur_[c] = E6[c];
 }
 
+// z and y transforms of a plane in one kernel (grids whose complex z-y plane fits the LDS): option plane_fft (-1 = where
+// available), FG_PLANE_FFT overrides for A/B runs
+bool Solver::plane_fft_on() const {
+  static const int env = getenv("FG_PLANE_FFT") ? atoi(getenv("FG_PLANE_FFT")) : -1;
+  const int v = env >= 0 ? env : opt_.plane_fft;
+  return v != 0 && nranks_ == 1 && fft_->can_plane();
+}
+
 void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* c12, double* xscratch) {  // alpha = -1: GammaOperator(..., -1)  F:20575
   if (opt_.mode == 1) {
     // G0OperatorStaggeredHeat  F:20118-20135 on one component: fftVector(., 1), c1 = c10/|k|^2, fftInvVector
     const double scale = 1 / (double)nglobal_;
     const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
-    time_begin(2);
-    fft_->r2c_z(buf, 1, g_.n);
-    time_end(2);
-    time_begin(3);
-    fft_->c2c_y(buf, 1, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
-    time_end(3);
+    const bool plane = plane_fft_on() && has_x;
+    if (plane) {
+      time_begin(2);
+      fft_->zy_plane(buf, 1, g_.n, -1);
+      time_end(2);
+    } else {
+      time_begin(2);
+      fft_->r2c_z(buf, 1, g_.n);
+      time_end(2);
+      time_begin(3);
+      fft_->c2c_y(buf, 1, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
+      time_end(3);
+    }
     const double c10 = -alpha / (2 * opt_.mu_0);  // G0OperatorFourierStaggeredHeat  F:19759-19764
     if (opt_.fuse_x && fft_->can_fuse(0, 1) && has_x) {
       // x transform, 1/N, scalar Green operator and inverse x transform in one kernel
@@ -701,6 +716,12 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
       fft_->c2c_x(buf, 1, g_.n, +1, 1.0);
       time_end(6);
     }
+    if (plane) {
+      time_begin(8);
+      fft_->zy_plane(buf, 1, g_.n, +1);
+      time_end(8);
+      return;
+    }
     time_begin(7);
     fft_->c2c_y(buf, 1, g_.n, +1, 1.0);
     time_end(7);
@@ -709,7 +730,7 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     time_end(8);
     return;
   }
-  bool fuse_x = false;
+  bool fuse_x = false, plane = false;
   // x-contiguous layout for the fused pass: on by size (fields beyond the Infinity Cache, where the fused pass's tile of nx
   // segments 2 MB apart is what bounds it) unless the option says otherwise; FG_X_LAYOUT overrides for A/B runs
   static const int xl_env = getenv("FG_X_LAYOUT") ? atoi(getenv("FG_X_LAYOUT")) : -1;
@@ -746,14 +767,21 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
     const double scale = 1 / (double)nglobal_;
     const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
-    if (!z_done) {  // the displacement sweep may already have written the z spectrum
+    plane = plane_fft_on() && !z_done && has_x;
+    if (plane) {   // small grids: z and y transforms of a plane in one kernel
       time_begin(2);
-      fft_->r2c_z(buf, 3, g_.n);
+      fft_->zy_plane(buf, 3, g_.n, -1);
       time_end(2);
+    } else {
+      if (!z_done) {  // the displacement sweep may already have written the z spectrum
+        time_begin(2);
+        fft_->r2c_z(buf, 3, g_.n);
+        time_end(2);
+      }
+      time_begin(3);
+      fft_->c2c_y(buf, 3, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
+      time_end(3);
     }
-    time_begin(3);
-    fft_->c2c_y(buf, 3, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
-    time_end(3);
     fuse_x = opt_.fuse_x && fft_->can_fuse(0);
     if (!fuse_x) {
       time_begin(4);
@@ -788,13 +816,18 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     fft_->c2c_x(buf, 3, g_.n, +1, 1.0);
     time_end(6);
   }
+  if (plane) {
+    time_begin(8);
+    fft_->zy_plane(buf, 3, g_.n, +1);
+    time_end(8);
+    return;
+  }
   time_begin(7);
   fft_->c2c_y(buf, 3, g_.n, +1, 1.0);
   time_end(7);
   time_begin(8);
   fft_->c2r_z(buf, 3, g_.n);
   time_end(8);
-
 }
 
 // ------------------------------------------------------------------ displacement-based pass

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../fibergen_amd/csrc/fg_fft_kernels.h"
+#include "../../fibergen_amd/csrc/fg_fft_plane.h"
 #include "../../fibergen_amd/csrc/fg_fft_tables.h"
 
 using namespace fg;
@@ -232,5 +233,23 @@ void emu_c2r_generic(const double* src, double* dst, int nz, long nrows) {
   int nzc = nz / 2 + 1, nzp = 2 * nzc;
   for (long r = 0; r < nrows; ++r)
     for (int m = 0; m < nz; ++m) c2r_point(reinterpret_cast<const cplx*>(src + r * nzp), dst + r * nzp, nz, m, w.data());
+}
+
+// z + y transforms of whole planes in one kernel (fg_fft_plane.h): data[nplanes][ny][2*nzc] real rows, in place
+int emu_plane(int ny, int nz, int dir, double* data, int nplanes) {
+  const int M = nz / 2, nzc = nz / 2 + 1;
+  std::vector<cplx> twz = make_pass_twiddles(M), twy = make_pass_twiddles(ny);
+  std::vector<cplx> wz = make_unit_roots(nz, M + 1);
+  PlaneArgs a = {data, (long)ny * 2 * nzc, 2 * nzc, twz.data(), wz.data(), twy.data()};
+#define CASE(n, m)                                                        \
+  if (ny == n && M == m) {                                                \
+    if (dir < 0) run_blocks<ZYKernel<n, m>, PlaneArgs>(nplanes, a);       \
+    else run_blocks<YZKernel<n, m>, PlaneArgs>(nplanes, a);               \
+    return 0;                                                             \
+  }
+  CASE(16, 8) CASE(16, 16) CASE(16, 32) CASE(16, 64) CASE(32, 8) CASE(32, 16) CASE(32, 32) CASE(32, 64) CASE(64, 8) CASE(64, 16)
+  CASE(64, 32) CASE(64, 64) CASE(128, 8) CASE(128, 16) CASE(128, 32) CASE(128, 64) CASE(256, 8) CASE(256, 16) CASE(256, 32)
+#undef CASE
+  return 1;
 }
 }

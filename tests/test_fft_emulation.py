@@ -172,3 +172,34 @@ def test_x_contiguous_layout_chain(emu, nx, ny):
         assert emu.emu_strided_xlayout(ny, +1, P(xl[c].view(np.float64)), P(back[c].view(np.float64)), nx, nzc, ctypes.c_double(1.0)) == 0
     ref = np.fft.ifft(Gx, axis=2) * ny
     assert np.abs(back - ref).max() / np.abs(ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("ny,nz", [(16, 16), (16, 32), (16, 64), (16, 128), (32, 16), (32, 32), (32, 64), (32, 128), (64, 16),
+                                   (64, 32), (64, 64), (64, 128), (128, 16), (128, 32), (128, 64), (128, 128), (256, 16), (256, 32),
+                                   (256, 64)])
+def test_plane_kernels(emu, ny, nz):
+    """fg_fft_plane.h: z and y transforms of whole planes in one kernel (the plane in LDS), forward and inverse, against numpy
+    and -- bit for bit -- against the separate z and y passes."""
+    rng = np.random.default_rng(ny * 1000 + nz)
+    npl, nzc = 3, nz // 2 + 1
+    x = rng.standard_normal((npl, ny, nz))
+    buf = np.full((npl, ny, 2 * nzc), np.nan)
+    buf[:, :, :nz] = x
+    assert emu.emu_plane(ny, nz, -1, P(buf), npl) == 0
+    ref = np.fft.fft(np.fft.rfft(x, axis=2), axis=1)
+    assert np.abs(buf.view(np.complex128) - ref).max() / np.abs(ref).max() < 1e-14
+    b2 = np.full((npl, ny, 2 * nzc), np.nan)
+    b2[:, :, :nz] = x
+    assert emu.emu_r2c(nz, P(b2), ctypes.c_long(npl * ny)) == 0
+    assert emu.emu_strided(ny, -1, P(b2), nzc, npl, ctypes.c_double(1.0)) == 0
+    assert np.array_equal(b2, buf)
+    # inverse of an arbitrary (non-Hermitian) spectrum: FFTW c2r semantics
+    X = rng.standard_normal((npl, ny, nzc)) + 1j * rng.standard_normal((npl, ny, nzc))
+    b3 = X.copy().view(np.float64).copy()
+    assert emu.emu_plane(ny, nz, +1, P(b3), npl) == 0
+    ref3 = np.fft.irfft(np.fft.ifft(X, axis=1) * ny, n=nz, axis=2) * nz
+    assert np.abs(b3[:, :, :nz] - ref3).max() / np.abs(ref3).max() < 1e-14
+    b4 = X.copy().view(np.float64).copy()
+    assert emu.emu_strided(ny, +1, P(b4), nzc, npl, ctypes.c_double(1.0)) == 0
+    assert emu.emu_c2r(nz, P(b4), ctypes.c_long(npl * ny)) == 0
+    assert np.array_equal(b4[:, :, :nz], b3[:, :, :nz])

@@ -740,3 +740,43 @@ def test_x_lines_of_1024_points_take_the_fused_pass(mode, mixing):
         out.append(s.get_field("epsilon"))
         s.close()
     assert rel_err(out[0], o.eps) < 1e-11 and rel_err(out[0], out[1]) < 1e-12
+
+
+@pytest.mark.parametrize("grid,mode,mixing", [((8, 32, 32), "elasticity", "voigt"), ((16, 64, 64), "elasticity", "laminate"),
+                                              ((8, 128, 128), "elasticity", "voigt"), ((4, 32, 128), "elasticity", "voigt"),
+                                              ((4, 128, 32), "elasticity", "laminate"), ((8, 64, 128), "porous", "voigt"),
+                                              ((16, 64, 32), "viscosity", "voigt"), ((8, 256, 64), "elasticity", "voigt"),
+                                              ((8, 16, 16), "elasticity", "laminate"), ((4, 256, 16), "elasticity", "voigt"),
+                                              ((8, 32, 16), "porous", "voigt")])
+def test_plane_fft_equals_the_separate_passes(grid, mode, mixing):
+    """plane_fft: the z and y transforms of a z-y plane in one kernel (fg_fft_plane.h; the plane lives in LDS) against the
+    separate passes, five passes of the loop: the same butterflies in the same order, so the iterates agree to rounding of
+    the contraction choices (<= 1e-14); and against the oracle."""
+    from fibergen_amd import LSSolver
+    from helpers import sphere_phi
+    E = np.array([0.01, -0.004, 0.002, 0.003, -0.001, 0.002])
+    out = []
+    for plane in (1, 0):
+        if mode == "elasticity":
+            s = make_gpu_solver(grid, (1.0, 1.2, 0.9), mixing=mixing, tol=-1.0, abs_tol=-1.0, maxiter=5, plane_fft=plane)
+            Erun = E
+        else:
+            phi1 = sphere_phi(grid, 0.3)
+            s = LSSolver(*grid, 1.0, 1.2, 0.9)
+            s.set_options(mode=mode)
+            s.set_num_phases(2)
+            s.set_phase(0, 1.0, 0.0, 1 - phi1)
+            s.set_phase(1, 7.0, 0.0, phi1)
+            s.set_options(tol=-1.0, abs_tol=-1.0, maxiter=5, plane_fft=plane)
+            Erun = E[:3] if mode == "porous" else E - np.array([E[:3].mean()] * 3 + [0, 0, 0])
+        s.run(Erun)
+        out.append((np.array(s.residuals), s.get_field("epsilon"), s.stage_times() if False else None))
+        s.close()
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-13
+    assert rel_err(out[0][1], out[1][1]) < 1e-13
+    if mode == "elasticity":
+        o = make_oracle(grid, (1.0, 1.2, 0.9), mixing=mixing, tol=-1.0, maxiter=5)
+        o.abs_tol = -1.0
+        o.run(E)
+        assert np.abs(out[0][0] - np.array(o.residuals)).max() < 1e-11
+        assert rel_err(out[0][1], o.eps) < 1e-11
