@@ -120,6 +120,10 @@ def kernel_table(s, E, n, steps, scalar):
             name, alg = "stress_div", 80 * N   # SURVEY 8d "S + div: 80"
         if k == "g0" and times["c2c_x_fwd"] == 0:
             name = "xfft_g0_xifft"             # x-FFT, Green operator, inverse x-FFT: 48 B/voxel
+        if k == "r2c_z" and times["c2c_y_fwd"] == 0 and n[1] > 1:
+            name = "zy_plane_fwd"              # plane kernel: r2c along z + c2c along y in one pass (fg_fft_plane.h)
+        if k == "c2r_z" and times["c2c_y_inv"] == 0 and n[1] > 1:
+            name = "yz_plane_inv"
         kern[name] = {"avg_ms": avg, "alg_GB": alg / 1e9, "GBps": (alg / 1e9) / (avg / 1e3)}
     return kern, times, cnt
 
@@ -128,7 +132,7 @@ def kernel_table(s, E, n, steps, scalar):
 PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"), "u_eps_stress_div_r2cz": ("k_u_fast_z",),
               "stress_div": ("k_stress_div_voigt",), "xfft_g0_xifft": ("k_xfused",), "eps_norm": ("k_eps_norm",),
               "stress": ("k_stress",), "div": ("k_div",), "g0": ("k_g0",), "r2c_z": ("k_zpass",), "c2r_z": ("k_zpass",),
-              "c2c_y_fwd": ("k_strided",), "c2c_y_inv": ("k_strided",)}
+              "c2c_y_fwd": ("k_strided",), "c2c_y_inv": ("k_strided",), "zy_plane_fwd": ("k_plane",), "yz_plane_inv": ("k_plane",)}
 
 
 def committed_traffic(n, mixing, slot, default_options):

@@ -5,8 +5,8 @@
 // launch ramps and cache bandwidth, not HBM.  Here one workgroup owns a plane of one component: rows -> registers -> z
 // transform (exchanges through LDS) -> spectrum of all rows in LDS -> y transform of its kz columns -> store; the inverse
 // runs the other way.  Same arithmetic as R2CKernel / StridedKernel / C2RKernel (Line<N>, r2c_split, c2r_merge): every line
-// transform is the same sequence of butterflies, the results equal those of the separate passes bit for bit; the host
-// emulation (tests/emulate) runs these very functions.
+// transform is the same sequence of butterflies -- in the host emulation (tests/emulate runs these very functions) the
+// results equal those of the separate passes bit for bit, on the device to the rounding of the compiler's contraction choices.
 //
 // Thread maps (THREADS = NY * M / 8, M = nz / 2):
 //   z side: row = tid / TZ, jt = tid % TZ   (TZ = M / 8 threads per row, lanes along the row: 128-byte segments per row)

@@ -599,7 +599,8 @@ def test_x_contiguous_intermediate_layout(grid, mixing):
     E = np.array([1.0, 0, 0, 0, 0, 0.5])
     out = {}
     for xl in (0, 1):
-        s = make_gpu_solver(grid, mixing=mixing, tol=1e-8, x_layout=xl)
+        # (plane_fft = 0: the plain-layout run must take the very kernels the x-layout run takes, not the plane kernels)
+        s = make_gpu_solver(grid, mixing=mixing, tol=1e-8, x_layout=xl, plane_fft=0)
         assert s.run(E) is False
         out[xl] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress())
         s.close()
