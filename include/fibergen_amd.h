@@ -89,7 +89,10 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * exchange for the three components; -1 = by slab size, default), slab_interleave (-1 = default: in the one-exchange mode a
  * peer's three components travel as ONE message where the sizes allow; 0 = one message per peer and component),
  * slab_loopback (test mode on one GPU: a lone slab that is
- * connected to a transport sends its all-to-all blocks and halo planes to itself through that transport). */
+ * connected to a transport sends its all-to-all blocks and halo planes to itself through that transport),
+ * x_layout (-1 = default: on grids whose three components exceed 1 GB the spectrum between the y passes and the fused x pass
+ * is stored x-contiguous, [zc/8][y][x][8]; 0 / 1 force it off / on), plane_fft (-1 = default: where the complex z-y plane
+ * fits the LDS -- ny * nz <= 128^2, 256 x 64 -- the z and y transforms of a plane run as ONE kernel; 0 = separate passes). */
 int fg_set_option_d(fg_solver* s, const char* key, double value);
 int fg_set_option_i(fg_solver* s, const char* key, long value);
 
