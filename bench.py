@@ -131,8 +131,10 @@ def kernel_table(s, E, n, steps, scalar):
 # HIP-event slot name -> kernel names in the rocprofv3 counter summaries under profiles/
 PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"), "u_eps_stress_div_r2cz": ("k_u_fast_z",),
               "stress_div": ("k_stress_div_voigt",), "xfft_g0_xifft": ("k_xfused",), "eps_norm": ("k_eps_norm",),
-              "stress": ("k_stress",), "div": ("k_div",), "g0": ("k_g0",), "r2c_z": ("k_zpass",), "c2r_z": ("k_zpass",),
-              "c2c_y_fwd": ("k_strided",), "c2c_y_inv": ("k_strided",), "zy_plane_fwd": ("k_plane",), "yz_plane_inv": ("k_plane",)}
+              "stress": ("k_stress",), "div": ("k_div",), "g0": ("k_g0",), "r2c_z": ("k_zpass<fg::fft::R2CKernel",),
+              "c2r_z": ("k_zpass<fg::fft::C2RKernel",), "c2c_y_fwd": ("k_strided<fg::fft::StridedKernel<*, -1>",),
+              "c2c_y_inv": ("k_strided<fg::fft::StridedKernel<*, 1>",), "zy_plane_fwd": ("k_plane<fg::fft::ZYKernel",),
+              "yz_plane_inv": ("k_plane<fg::fft::YZKernel",)}
 
 
 def committed_traffic(n, mixing, slot, default_options):
@@ -156,9 +158,14 @@ def committed_traffic(n, mixing, slot, default_options):
         return None, None
     newest = max(files, key=version)
     rows = list(csv.DictReader(open(newest)))
+    def matches(name, w):   # "k_x": the name before its template list; "k_x<...": a prefix, `*` = any run of characters
+        if "<" not in w:
+            return name.split("<")[0] == w
+        head, _, tail = w.partition("*")
+        return name.startswith(head) and (not tail or tail in name[len(head):])
     for w in PMC_KERNEL[slot]:
         for row in rows:
-            if row["kernel"].split("<")[0] == w:
+            if matches(row["kernel"], w):
                 return float(row["total_GB"]) * 1e9, "profiles/" + os.path.basename(newest)
     return None, None
 
