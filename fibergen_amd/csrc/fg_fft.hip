@@ -75,11 +75,30 @@ __global__ __launch_bounds__(K::THREADS) void k_zpass(ZArgs a, long comp_stride)
   DevicePhases<K, ZArgs, 0>::run(r, blockIdx.x, threadIdx.x, lds, a);
 }
 
+// tools/xfused_probe.hip compiles this file with -DFG_PROBE: cycle stamps (s_memtime) of one wave per sampled
+// workgroup at every phase boundary of the fused x pass, to see where a tile's time goes.  Empty in the library.
+#ifdef FG_PROBE
+#ifndef FG_PROBE_STRIDE
+#define FG_PROBE_STRIDE 256
+#endif
+constexpr int kProbeBlocks = 64, kProbeSlots = 40, kProbeStride = FG_PROBE_STRIDE;
+__device__ unsigned long long g_probe[kProbeBlocks][kProbeSlots];
+#define FG_PROBE_MARK(ph)                                                                        \
+  do {                                                                                           \
+    if (tid == FG_PROBE_THREAD && block % kProbeStride == 0 && block / kProbeStride < kProbeBlocks) \
+      g_probe[block / kProbeStride][(ph)] = __builtin_readcyclecounter();                        \
+  } while (0)
+#else
+#define FG_PROBE_MARK(ph) do { } while (0)
+#endif
+
 // z + y transforms of one plane per workgroup (fg_fft_plane.h); blockIdx.y = component
 template <class K, int PH>
 struct DevicePhasesP {
   __device__ __forceinline__ static void run(typename K::Regs& r, int block, int tid, double* lds, const PlaneArgs& a) {
+    FG_PROBE_MARK(PH);
     K::template phase<PH>(r, block, tid, lds, a);
+    if constexpr (PH + 1 == K::NPHASE) FG_PROBE_MARK(PH + 1);
     if constexpr (PH + 1 < K::NPHASE) {
       if constexpr (K::barrier_after(PH) == 2 || K::THREADS <= 64) {
         __syncthreads();
@@ -98,23 +117,6 @@ __global__ __launch_bounds__(K::THREADS) void k_plane(PlaneArgs a, long comp_str
   typename K::Regs r;
   DevicePhasesP<K, 0>::run(r, blockIdx.x, threadIdx.x, lds, a);
 }
-
-// tools/xfused_probe.hip compiles this file with -DFG_PROBE: cycle stamps (s_memtime) of one wave per sampled
-// workgroup at every phase boundary of the fused x pass, to see where a tile's time goes.  Empty in the library.
-#ifdef FG_PROBE
-#ifndef FG_PROBE_STRIDE
-#define FG_PROBE_STRIDE 256
-#endif
-constexpr int kProbeBlocks = 64, kProbeSlots = 40, kProbeStride = FG_PROBE_STRIDE;
-__device__ unsigned long long g_probe[kProbeBlocks][kProbeSlots];
-#define FG_PROBE_MARK(ph)                                                                        \
-  do {                                                                                           \
-    if (tid == FG_PROBE_THREAD && block % kProbeStride == 0 && block / kProbeStride < kProbeBlocks) \
-      g_probe[block / kProbeStride][(ph)] = __builtin_readcyclecounter();                        \
-  } while (0)
-#else
-#define FG_PROBE_MARK(ph) do { } while (0)
-#endif
 
 template <class K, int PH>
 struct DevicePhasesX {
