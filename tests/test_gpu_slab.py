@@ -522,3 +522,23 @@ def test_viscosity_group_mixed_bc(P, grid):
     assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8
     assert rel_err(g.mean_stress(), o.mean_stress()) < 1e-8
     g.close()
+
+
+@pytest.mark.parametrize("P,mixing,split", [(2, "voigt", 0), (4, "laminate", 1), (8, "voigt", 0)])
+def test_slabs_with_x_lines_of_1024_points(P, mixing, split):
+    """nx = 1024 over P slabs: the y-slab's fused x pass takes the 4-column tiles of the 1024-point lines (the one-message-per-
+    peer layout stays with lines up to 512); four passes against the single-GPU solver, which the oracle checks at this grid
+    (test_x_lines_of_1024_points_take_the_fused_pass)."""
+    grid = (1024, 16, 128)
+    E = np.array([0.01, -0.004, 0.002, 0.003, -0.001, 0.002])
+    s = make_gpu_solver(grid, mixing=mixing, tol=-1.0, abs_tol=-1.0, maxiter=4)
+    s.run(E)
+    ref_res, ref_eps, ref_ms = np.array(s.residuals), s.get_field("epsilon"), s.mean_stress()
+    s.close()
+    g = make_group(P, grid, mixing=mixing, tol=-1.0, abs_tol=-1.0, maxiter=4, slab_split=split)
+    g.run(E)
+    assert g.iterations == 4
+    assert np.abs(np.array(g.residuals) - ref_res).max() < 1e-11
+    assert rel_err(g.get_field("epsilon"), ref_eps) < 1e-11
+    assert rel_err(g.mean_stress(), ref_ms) < 1e-12
+    g.close()
