@@ -24,20 +24,26 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 E_LOAD = np.array([0.01, -0.003, 0.002, 0.004, -0.001, 0.0025])
 
 
+def load(a):
+    return E_LOAD[:3] if a.mode in ("heat", "porous") else E_LOAD
+
+
 def solve(n, phi1, normals, cell, a):
     from fibergen_amd import LSSolver
     from helpers import INCLUSION, MATRIX, lame
     s = LSSolver(n, n, n, cell, cell, cell)
+    if a.mode != "elasticity":
+        s.set_options(mode=a.mode)
     s.set_num_phases(2)
-    m0, m1 = lame(**MATRIX), lame(**INCLUSION)
+    m0, m1 = (lame(**MATRIX), lame(**INCLUSION)) if a.mode == "elasticity" else ((1.0, 0.0), (10.0, 0.0))
     phi0 = 1.0 - phi1
     s.set_phase(0, m0[0], m0[1], phi0)
     del phi0
     s.set_phase(1, m1[0], m1[1], phi1)
     if normals is not None:
         s.set_normals(normals)
-    s.set_options(mixing_rule=a.mixing, method="basic", tol=-1.0, abs_tol=-1.0, maxiter=a.passes)
-    failed = s.run(E_LOAD)
+    s.set_options(mixing_rule=a.mixing, method=a.method, tol=-1.0, abs_tol=-1.0, maxiter=a.passes)
+    failed = s.run(load(a))
     res = dict(failed=bool(failed), it=int(s.iterations), res=[float(r) for r in s.residuals], ms=s.mean_stress().tolist(),
                me=s.mean_strain().tolist(), ref=[float(v) for v in s.ref_material], vf=float(s.volume_fraction(1)))
     return s, res
@@ -48,13 +54,15 @@ def main():
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--passes", type=int, default=4)
     ap.add_argument("--mixing", default="voigt", choices=["voigt", "laminate"])
+    ap.add_argument("--method", default="basic", choices=["basic", "cg"])
+    ap.add_argument("--mode", default="elasticity", choices=["elasticity", "porous", "heat"])
     a = ap.parse_args()
     import psutil
     from fibergen_amd.rve import bench_rve
     n, N = a.n, 2 * a.n
     t0 = time.time()
     phi1, normals, par = bench_rve(n, a.mixing)
-    out = {"small": n, "big": N, "mixing": a.mixing, "passes": a.passes, "rve": par, "rve_s": round(time.time() - t0, 1),
+    out = {"small": n, "big": N, "mixing": a.mixing, "method": a.method, "mode": a.mode, "passes": a.passes, "rve": par, "rve_s": round(time.time() - t0, 1),
            "host_available_GB": round(psutil.virtual_memory().available / 1e9, 1)}
     s, small = solve(n, phi1, normals, 1.0, a)
     eps_small = s.get_field("epsilon")
@@ -84,14 +92,15 @@ def main():
 
     # the strain field, octant by octant (needs 6 N^3 doubles on the host)
     out["field_checked"] = False
-    if psutil.virtual_memory().available > 6 * 8 * N ** 3 + 16e9:
+    ncomp = 3 if a.mode in ("heat", "porous") else 6
+    if psutil.virtual_memory().available > ncomp * 8 * N ** 3 + 16e9:
         eps_big = s.get_field("epsilon")
         scale = float(np.abs(eps_small).max())
         worst = 0.0
         for ox in (0, n):
             for oy in (0, n):
                 for oz in (0, n):
-                    for c in range(6):
+                    for c in range(ncomp):
                         d = np.abs(eps_big[c, ox:ox + n, oy:oy + n, oz:oz + n] - eps_small[c]).max()
                         worst = max(worst, float(d))
         del eps_big
@@ -102,12 +111,13 @@ def main():
 
     s.synchronize()
     t0 = time.time()
-    s.iterate(E_LOAD, 5)
+    s.iterate(load(a), 5)
     s.synchronize()
     dt = time.time() - t0
     out["big_ms_per_pass"] = round(dt / 5 * 1e3, 2)
     out["big_it_s"] = round(5 / dt, 3)
-    out["big_loop_alg_GBps"] = round(296.0 * N ** 3 / (dt / 5) / 1e9, 1)
+    if a.mode == "elasticity":
+        out["big_loop_alg_GBps"] = round(296.0 * N ** 3 / (dt / 5) / 1e9, 1)
     s.close()
     out["ok"] = bool(ok)
     print(json.dumps(out))
