@@ -277,7 +277,9 @@ class FG:
         if scheme == "auto":
             scheme = "staggered"
         if scheme not in ("staggered", "collocated") or (scheme == "collocated" and scalar):  # scalar: any non-elastic mode
-            raise RuntimeError("Unknown gamma scheme '%s' (MI355X path: staggered, collocated for elasticity)" % scheme)
+            raise RuntimeError("gamma scheme '%s' is not built on the MI355X path (staggered; collocated for elasticity): set "
+                               "<gamma_scheme>staggered</gamma_scheme> -- the schemes differ by their discretisation error, "
+                               "nothing is substituted silently" % scheme)
         est = self._child_value(solver, "error_estimator", "epsilon", str)
         if est not in ("epsilon", "residual"):
             raise RuntimeError("error estimator '%s' is not available (epsilon, residual)" % est)
