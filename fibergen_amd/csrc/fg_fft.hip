@@ -230,22 +230,22 @@ __global__ __launch_bounds__(256) void k_mixed_combine(const cplx* src, cplx* ds
     // the table index r * step mod N advances by step with one conditional subtraction (no division)
     if (DIR < 0) {   // output s = o:  sum_r w_N^{r (k + M s)} Y_r
       const int step = k + M * o;   // < N
-      int idx = 0;
+      int wi = 0;
 #pragma unroll
       for (int r = 0; r < p; ++r) {
-        acc = cadd(acc, cmul(in[r], w[idx]));
-        idx += step;
-        if (idx >= N) idx -= N;
+        acc = cadd(acc, cmul(in[r], w[wi]));
+        wi += step;
+        if (wi >= N) wi -= N;
       }
       dst[base + ((long)k + (long)M * o) * ls] = cscale(scale, acc);
     } else {         // output r = o:  conj(w_N^{r k}) sum_s X_s conj(w_p^{r s})
       const int step = (int)(((long)o * M) % N);
-      int idx = 0;
+      int wi = 0;
 #pragma unroll
       for (int sidx = 0; sidx < p; ++sidx) {
-        acc = cadd(acc, cmul(in[sidx], cconj(w[idx])));
-        idx += step;
-        if (idx >= N) idx -= N;
+        acc = cadd(acc, cmul(in[sidx], cconj(w[wi])));
+        wi += step;
+        if (wi >= N) wi -= N;
       }
       acc = cmul(acc, cconj(w[o * k]));   // o k < N
       dst[base + ((long)p * k + o) * ls] = cscale(scale, acc);
