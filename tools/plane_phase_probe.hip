@@ -19,25 +19,26 @@ __global__ void k_fill(double* x, long n) {
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 128;
   const int dir = argc > 2 ? atoi(argv[2]) : -1;
+  const int ncomp = argc > 3 ? atoi(argv[3]) : 3;   // workgroups = n * ncomp (round quantisation on 256 CUs)
   Grid g = make_grid(n, n, n, 1.0, 1.0, 1.0);
   hipStream_t s;
   FG_HIP_CHECK(hipStreamCreate(&s));
   Fft3 fft(g, s);
   double* data = nullptr;
-  FG_HIP_CHECK(hipMalloc(&data, 3 * g.n * sizeof(double)));
-  k_fill<<<(unsigned)((3 * g.n + 255) / 256), 256, 0, s>>>(data, 3 * g.n);
+  FG_HIP_CHECK(hipMalloc(&data, 4 * g.n * sizeof(double)));
+  k_fill<<<(unsigned)((4 * g.n + 255) / 256), 256, 0, s>>>(data, 4 * g.n);
   hipEvent_t e0, e1;
   FG_HIP_CHECK(hipEventCreate(&e0));
   FG_HIP_CHECK(hipEventCreate(&e1));
   const int reps = 20;
-  for (int r = 0; r < 3; ++r) fft.zy_plane(data, 3, g.n, dir);
+  for (int r = 0; r < 3; ++r) fft.zy_plane(data, ncomp, g.n, dir);
   FG_HIP_CHECK(hipEventRecord(e0, s));
-  for (int r = 0; r < reps; ++r) fft.zy_plane(data, 3, g.n, dir);
+  for (int r = 0; r < reps; ++r) fft.zy_plane(data, ncomp, g.n, dir);
   FG_HIP_CHECK(hipEventRecord(e1, s));
   FG_HIP_CHECK(hipStreamSynchronize(s));
   float ms = 0;
   FG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  printf("%d^3 plane kernel dir %d: %.2f us per launch\n", n, dir, 1e3 * ms / reps);
+  printf("%d^3 plane kernel dir %d, %d components (%d workgroups): %.2f us per launch\n", n, dir, ncomp, n * ncomp, 1e3 * ms / reps);
   static unsigned long long h[kProbeBlocks][kProbeSlots];
   FG_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe), sizeof(h)));
   double mean[kProbeSlots] = {0};
