@@ -501,10 +501,24 @@ class FG:
     def get_distance_evals(self):
         return 0
 
-    def get_A2(self):
-        raise RuntimeError("fibre orientation statistics are outside the MI355X hot path")
+    def _axes(self):
+        """unit axes of the fibres placed so far (place_fiber; the random generator is outside the MI355X path)"""
+        if not self._fibers:
+            raise RuntimeError("no fibres placed: orientation moments are undefined")
+        a = np.array([f.a for f in self._fibers], dtype=float)
+        return a / np.sqrt((a * a).sum(axis=1))[:, None]
 
-    get_A4 = get_A2
+    def get_A2(self):
+        """FiberGenerator::updateMoments F:6263-6275 + getA2 F:6683-6686: sum of a (x) a over the fibres, trace-normalised"""
+        a = self._axes()
+        A2 = np.einsum("ni,nj->ij", a, a)
+        return (A2 / np.trace(A2)).tolist()
+
+    def get_A4(self):
+        """getA4 F:6689-6707: sum of a (x) a (x) a (x) a, scaled by the trace of its contraction A4_iikl"""
+        a = self._axes()
+        A4 = np.einsum("ni,nj,nk,nl->ijkl", a, a, a, a)
+        return (A4 / np.trace(np.einsum("iikl->kl", A4))).tolist()
 
     def get_B_from_A(self, a0, a1, a2):
         raise RuntimeError("fibre orientation statistics are outside the MI355X hot path")

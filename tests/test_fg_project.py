@@ -137,3 +137,22 @@ def test_unknown_settings_raise_like_reference(monkeypatch):
     fg.set("solver.method", "nesterov2")
     with pytest.raises(RuntimeError, match="solver method"):
         fg.init_lss()
+
+
+def test_orientation_moments_of_placed_fibres():
+    """get_A2 / get_A4 (F:25155-25180): moments of the placed fibres' axes, FiberGenerator::updateMoments F:6263-6275 with the
+    trace normalisations of getA2 / getA4 F:6683-6707 (place_fiber needs the solver, i.e. a GPU: the fibres are set directly)."""
+    from fibergen_amd import FG
+    from fibergen_amd.fg import _Fiber
+    fg = FG()
+    with pytest.raises(RuntimeError, match="no fibres"):
+        fg.get_A2()
+    fg._fibers = [_Fiber("capsule", [0.5, 0.5, 0.5], ax, 0.2, 0.1, 1) for ax in ([1, 0, 0], [0, 2, 0], [1, 1, 0])]
+    A2 = np.array(fg.get_A2())
+    axes = np.array([[1, 0, 0], [0, 1, 0], [2 ** -0.5, 2 ** -0.5, 0]])
+    ref2 = sum(np.outer(a, a) for a in axes)
+    assert np.allclose(A2, ref2 / np.trace(ref2)) and abs(np.trace(A2) - 1) < 1e-15
+    A4 = np.array(fg.get_A4())
+    ref4 = sum(np.einsum("i,j,k,l->ijkl", a, a, a, a) for a in axes)
+    assert A4.shape == (3, 3, 3, 3) and np.allclose(A4, ref4 / 3.0)      # the contraction of each unit axis' term has trace 1
+    assert np.allclose(np.einsum("iikl->kl", A4), A2)                     # A4_iikl = A2 for unit axes
