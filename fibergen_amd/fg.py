@@ -10,7 +10,7 @@ pieces of FGProject (F:26516-26781), FG<T,R,DIM> (F:24836-26490) and run_actions
 XML subset: <settings> dx,dy,dz,x0,y0,z0, <variables>, <python>, <solver n nx ny nz mult>
 with tol, abs_tol, bc_tol, maxiter, method, gamma_scheme, mode, mixing_rule,
 error_estimator, ref_scale, update_ref, bc_relax, <laminate_mixing>, <materials>;
-actions select_material, place_fiber, read_raw_data, init_phase, run_load_case,
+actions select_material, place_fiber, print_A2, read_raw_data, init_phase, run_load_case,
 calc_effective_properties, calc_isotropic_laminate, python, print_timings, exit,
 group-*, skip.  Everything numeric is evaluated as a Python expression over the project
 variables, like the reference's embedded interpreter (F:744-756).
@@ -911,6 +911,9 @@ class FG:
             return None
         if name == "python":
             self._exec_python(act.text or "")
+            return None
+        if name == "print_A2":   # F:25747-25752
+            log.info("A2: %s", self.get_A2())
             return None
         if name == "print_timings":
             log.info("solve time: %g s", self._lss.solve_time if self._lss else 0.0)
