@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
   CHECK(fg_volume_fraction(s, 1, &vf));
   printf("n = %d, inclusion fraction %.6f, %ld iterations%s, solve time %.3f ms\n", n, vf, fg_get_iterations(s),
          failed ? " (FAILED)" : "", 1e3 * fg_get_solve_time(s));
-  printf("mean stress: %.9e %.9e %.9e %.3e %.3e %.3e\n", sig[0], sig[1], sig[2], sig[3], sig[4], sig[5]);
+  printf("mean stress: %.9e %.9e %.9e %.9e %.9e %.9e\n", sig[0], sig[1], sig[2], sig[3], sig[4], sig[5]);
   fg_destroy(s);
   free(phi0);
   free(phi1);
