@@ -391,20 +391,25 @@ def main():
                          "every rank poses as a host of its own (NCCL_HOSTID), RCCL connects them over loop-back sockets")
     # ranks started by this script's own launcher take their arguments from the environment (torchrun's argparse trips over
     # abbreviations such as --n before it hands the rest to the script)
-    args = ap.parse_args(json.loads(os.environ["FG_BENCH_ARGV"]) if "FG_BENCH_ARGV" in os.environ and "WORLD_SIZE" in os.environ
-                         else None)
+    # -- only when the launcher's own marker names this rank's parent process chain: a stale FG_BENCH_ARGV in the environment
+    # of a manual `torchrun bench.py ...` must not override that command line)
+    launched = ("FG_BENCH_ARGV" in os.environ and "WORLD_SIZE" in os.environ and
+                os.environ.get("FG_BENCH_LAUNCHED", "") == os.environ.get("TORCHELASTIC_RUN_ID", "?"))
+    args = ap.parse_args(json.loads(os.environ["FG_BENCH_ARGV"]) if launched else None)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Started plainly: launch the N ranks as fresh processes (torch.distributed.run, one rank per GPU) and relay
         # rank 0's line.  Nothing in this process has touched the GPU (numpy only so far), and nothing is exec'ed.
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
+        # The rendezvous store picks its own free port (c10d endpoint :0) -- no bind-close-reuse window for another job
+        # on a shared box to take the port in between.
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        run_id = "fgbench-%d-%d" % (os.getpid(), int(time.time()))
         env["FG_BENCH_ARGV"] = json.dumps(sys.argv[1:])
+        env["FG_BENCH_LAUNCHED"] = run_id
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus)]
+               "--rdzv-backend", "c10d", "--rdzv-endpoint", "127.0.0.1:0", "--rdzv-id", run_id, "--local-addr", "127.0.0.1",
+               os.path.abspath(__file__), "--gpus", str(args.gpus)]
         proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
         lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
         for ln in proc.stdout.splitlines():

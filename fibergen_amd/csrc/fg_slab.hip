@@ -874,8 +874,13 @@ bool SlabGroup::run_load_steps(const double* E6, const double* S6, const double*
     for (int i = 0; i < 6; ++i) E[i] = params[istep] * Emax[i], S[i] = params[istep] * Smax[i];
     const bool fresh = istep == first;
     const bool failed = a.opt_.method == 1 ? run_cg(E, S, fresh) : run_step(E, S, fresh);
-    if (failed) return true;
-    if (step_cb && step_cb(user, istep)) return true;   // "Loadstep callback break request."
+    // The step's outcome and the load-step callback's answer are agreed over the ranks: a callback that exists on one
+    // rank only (or answers differently per rank) must not let that rank return while the others enter the next step's
+    // collectives.  One tiny all-reduce per load step.
+    double v[2] = {failed ? 1.0 : 0.0, 0.0};
+    if (!failed && step_cb && step_cb(user, istep)) v[1] = 1.0;   // "Loadstep callback break request."
+    if (a.nranks_ > 1) vote(v);
+    if (v[0] != 0.0 || v[1] != 0.0) return true;
   }
   return false;
 }

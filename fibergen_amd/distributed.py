@@ -211,12 +211,29 @@ class GlobalViewSolver(DistributedLSSolver):
         n = self.slab(np.asarray(normals, dtype=np.float64))
         self._check(self._lib.fg_set_normals(self._h, n.ctypes.data_as(_lib.c_double_p)))
 
+    # Largest global field get_field will assemble on every rank (bytes); FG_GATHER_LIMIT_GB overrides.  Beyond it the
+    # caller should read the slabs (DistributedLSSolver.get_field with local shapes) instead of P copies of everything.
+    GATHER_LIMIT = int(float(__import__("os").environ.get("FG_GATHER_LIMIT_GB", "16")) * 2 ** 30)
+
     def _gather(self, local):
+        """The slabs of all ranks, concatenated along x, on every rank: one all_gather of a float64 tensor (on the device
+        for an nccl group, on the host for gloo) -- no pickling, no per-object staging."""
         if self.nranks == 1:
             return local
-        parts = [None] * self.nranks
-        self._dist.all_gather_object(parts, local, group=self.group)
-        return np.concatenate(parts, axis=1)
+        total = local.nbytes * self.nranks
+        if total > self.GATHER_LIMIT:
+            raise RuntimeError("get_field: the global field is %.1f GB (limit %.1f GB, FG_GATHER_LIMIT_GB): read the slabs "
+                               "rank by rank instead of gathering it on every rank" % (total / 2 ** 30, self.GATHER_LIMIT / 2 ** 30))
+        import torch
+        dist = self._dist
+        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+        on_device = dist.get_backend(self.group) == "nccl"
+        if on_device:
+            t = t.cuda()
+        out = torch.empty(self.nranks * t.numel(), dtype=t.dtype, device=t.device)   # flat: the form gloo and nccl both take
+        dist.all_gather_into_tensor(out, t.reshape(-1), group=self.group)
+        parts = (out.cpu() if on_device else out).numpy().reshape((self.nranks,) + tuple(local.shape))
+        return np.concatenate(list(parts), axis=1)
 
     def get_field(self, name):
         nc = self._lib.fg_field_components(self._h, name.encode())

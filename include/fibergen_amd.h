@@ -138,7 +138,11 @@ int fg_get_ref_material(const fg_solver* s, double* mu_0, double* lambda_0);
 
 /* get_raw_field  F:15396-15684.  Names: "epsilon" (6), "sigma" (6, evaluated with C0 = 0),
  * "u" (3), "phi" (nphases), "normals" (3); work buffers for stage tests: "tau" (6), "f" (3),
- * "f_hat" (3 complex components in the padded layout [nx][ny][nz/2+1][2]), "sumsq" (6 scalars). */
+ * "f_hat" (3 complex components in the padded layout [nx][ny][nz/2+1][2]), "sumsq" (6 scalars).
+ * The work buffers hold what the LAST fg_run_stage left there and nothing else: between stages "tau" is scratch of the
+ * transform chain (the x-contiguous spectrum layout of large grids, the all-to-all halves of a slab solver, CG vectors),
+ * so after fg_iterate / fg_run_* its contents are unspecified -- read "tau" directly after FG_STAGE_STRESS only.  The
+ * same holds for fg_device_pointer("tau" | "f", c). */
 int fg_field_components(const fg_solver* s, const char* name);
 int fg_get_field(fg_solver* s, const char* name, double* out);
 int fg_set_field(fg_solver* s, const char* name, const double* in);
@@ -222,7 +226,9 @@ const char* fg_slab_transport(const fg_solver* s);
  * pass.  fg_cancel from another thread takes effect with the next pass's reduction.  Convergence callbacks (F:21215) may be
  * installed on some ranks only and may answer differently: when any rank has one, every pass ends with a vote and the
  * run stops everywhere as soon as one callback asks for it (the transform chain of the next pass is then no longer
- * enqueued speculatively, which costs the overlap of the host with the device). */
+ * enqueued speculatively, which costs the overlap of the host with the device).  The same holds for fg_run_load_steps: the
+ * outcome of every step and the answer of the load-step callback (which may exist on one rank only) are summed over the
+ * ranks after the step, and every rank returns in the same step when any rank failed or asked to stop. */
 
 /* Measurement: with stage timing on (fg_enable_stage_timing) the exchanges of a slab solver are bracketed by HIP events on
  * the exchange stream and waited for one by one; ms[0] all-to-all forward, ms[1] all-to-all backward, ms[2] halo planes,

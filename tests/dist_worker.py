@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--stop-rank", type=int, default=-1, help="only this rank installs a convergence callback ...")
     ap.add_argument("--stop-iter", type=int, default=0, help="... which asks to stop in this iteration")
+    ap.add_argument("--step-stop-rank", type=int, default=-1,
+                    help="load stepping over [0, 0.5, 1]: only this rank installs a load-step callback, which asks to stop "
+                         "after step 1 (ADVICE r3: the answer must take every rank along)")
     ap.add_argument("--cancel-rank", type=int, default=-1,
                     help="this rank calls fg_cancel from another thread a little while into an endless run (tol 0)")
     ap.add_argument("--bad-rank", type=int, default=-1,
@@ -259,7 +262,14 @@ def main():
     error = ""
     failed = None
     try:
-        failed = s.run(E, S)
+        if a.step_stop_rank >= 0:
+            def step_cb(i):
+                calls.append(i)
+                return i == 1
+            failed = s.run_load_steps(E, S, params=[0.0, 0.5, 1.0],
+                                      step_callback=step_cb if a.step_stop_rank == rank else None)
+        else:
+            failed = s.run(E, S)
     except RuntimeError as e:
         error = str(e)
     if error:

@@ -3,6 +3,7 @@
 // device does between __syncthreads(); build with g++ -DFG_HOST_EMULATION.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "../../fibergen_amd/csrc/fg_fft_kernels.h"
@@ -20,13 +21,45 @@ struct PhaseLoop {
   }
 };
 
+// Kernels that replace some workgroup barriers by wave-local fences (K::barrier_after(PH): 2 = __syncthreads, 1 = fence of
+// one wave, see fg_fft_plane.h) are emulated accordingly: the phases between two workgroup barriers run WAVE BY WAVE -- all
+// phases of that stretch for the 64 threads of one wave, then the next wave -- in an order that alternates from block to
+// block (highest wave first / lowest wave first).  A dependency between waves that sits behind a mere wave fence then reads
+// LDS the other wave has not written yet (NaN or a stale value) in one of the two orders, and the comparison with numpy fails.
+template <class K, class = void>
+struct HasFenceTable : std::false_type {};
+template <class K>
+struct HasFenceTable<K, std::void_t<decltype(K::barrier_after(0))>> : std::bool_constant<!std::is_same_v<decltype(K::barrier_after(0)), bool>> {};
+
+template <class K, class Args, int PH>
+struct FencedLoop {
+  // runs phases PH .. (last phase of the stretch that starts at PH) for threads [t0, t1); returns nothing: the stretch end is static
+  static constexpr int stretch_end(int ph) { return (ph + 1 >= K::NPHASE || K::barrier_after(ph) == 2) ? ph : stretch_end(ph + 1); }
+  template <int P, int END>
+  static void wave(std::vector<typename K::Regs>& regs, int block, double* lds, const Args& a, int t0, int t1) {
+    for (int tid = t0; tid < t1; ++tid) K::template phase<P>(regs[tid], block, tid, lds, a);
+    if constexpr (P < END) wave<P + 1, END>(regs, block, lds, a, t0, t1);
+  }
+  static void run(std::vector<typename K::Regs>& regs, int block, double* lds, const Args& a) {
+    constexpr int END = stretch_end(PH);
+    constexpr int NW = (K::THREADS + 63) / 64;
+    for (int i = 0; i < NW; ++i) {
+      const int w = (block & 1) ? i : NW - 1 - i;
+      const int t0 = w * 64, t1 = t0 + 64 < K::THREADS ? t0 + 64 : K::THREADS;
+      wave<PH, END>(regs, block, lds, a, t0, t1);
+    }
+    if constexpr (END + 1 < K::NPHASE) FencedLoop<K, Args, END + 1>::run(regs, block, lds, a);
+  }
+};
+
 template <class K, class Args>
 static void run_blocks(long nblocks, const Args& a) {
   std::vector<typename K::Regs> regs(K::THREADS);
   std::vector<double> lds(K::LDS_DOUBLES);
   for (long b = 0; b < nblocks; ++b) {
     for (auto& x : lds) x = NAN;  // catch reads of never-written LDS
-    PhaseLoop<K, Args, 0>::run(regs, (int)b, lds.data(), a);
+    if constexpr (HasFenceTable<K>::value) FencedLoop<K, Args, 0>::run(regs, (int)b, lds.data(), a);
+    else PhaseLoop<K, Args, 0>::run(regs, (int)b, lds.data(), a);
   }
 }
 

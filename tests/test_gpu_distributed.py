@@ -126,6 +126,17 @@ def test_rccl_ranks_mixed_bc(tmp_path):
     assert rel_err(eps, o.eps) < 1e-8
 
 
+@pytest.mark.parametrize("transport", ["callback", "rccl"])
+def test_loadstep_callback_on_one_rank_stops_every_rank(tmp_path, transport):
+    """a load-step callback that exists on ONE rank only answers for all of them (its break request is voted over
+    the ranks after every step); before, that rank returned alone and the others hung in the next step's collectives."""
+    args = ("--backend", "hip", "--grid", "8,16,128", "--step-stop-rank", "1")
+    res = (launch_rccl(2, str(tmp_path / "l"), *args) if transport == "rccl" else launch(2, str(tmp_path / "l"), *args))
+    assert [bool(r["failed"]) for r in res] == [True, True]          # "Loadstep callback break request" on both ranks
+    assert [int(r["callback_calls"]) for r in res] == [0, 2]         # steps 0 and 1 were seen by rank 1 only
+    assert np.array_equal(res[0]["residuals"], res[1]["residuals"])
+
+
 # ---- collective stop and error decisions (round 3): a rank that alone wants to stop, or alone sees a device-side error, must
 #      take every other rank with it in the same pass -- the others have already enqueued the next pass's exchanges
 @pytest.mark.parametrize("transport", ["callback", "rccl"])
