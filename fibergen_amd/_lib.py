@@ -75,6 +75,7 @@ SIGNATURES = {
     "fg_enable_stage_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "fg_get_stage_times": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long)]),
     "fg_get_stage_timing_bias": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+    "fg_get_counter": (ctypes.c_long, [ctypes.c_void_p, ctypes.c_char_p]),
     "fg_get_comm_times": (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     "fg_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     "fg_hbm_stream": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p]),

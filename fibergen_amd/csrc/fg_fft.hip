@@ -1019,6 +1019,7 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
     }
   }
   if (fast_[2]) wz_ = upload(make_unit_roots(g.nz, g.nz / 2 + 1));
+  if (fast_[2] && is_pow2(g.nz / 2) && g.nz / 2 >= 16) tw4_z_ = upload(make_pass_twiddles4(g.nz / 2));
   if (need_scratch) FG_HIP_CHECK(hipMalloc(&scratch_, g.n * sizeof(double)));
   // three components larger than the 256 MB Infinity Cache: nothing a pass writes is still cached when the next reads it
   stream_stores_ = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
@@ -1031,6 +1032,7 @@ Fft3::~Fft3() {
     if (wgen_[a]) (void)hipFree(wgen_[a]);
   }
   if (wz_) (void)hipFree(wz_);
+  if (tw4_z_) (void)hipFree(tw4_z_);
   if (scratch_) (void)hipFree(scratch_);
 }
 

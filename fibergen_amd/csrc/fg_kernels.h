@@ -82,6 +82,12 @@ void launch_eps_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s, bool sum_tau = false,
                    const PhaseTable* two_phase = nullptr);
+// the tiled sweep with BOTH z transforms attached (fg_kernels_zsweep.hip): uhat = z half spectrum of u_k (what the inverse
+// y pass leaves), fhat = z half spectrum of f_{k+1} (what the forward y pass takes); tables as for launch_u_fast_z
+bool uz_tile_supported(const Grid& g);
+void launch_uz_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& uhat, const FieldPtrs<2>& mod,
+                    const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, hipStream_t s, bool sum_tau,
+                    const PhaseTable* two_phase, const cplx* tw_z, const cplx* w_z);
 void launch_complement_check(const Grid& g, const double* phi0, const double* phi1, int* flag, hipStream_t s);
 bool u_fast_z_supported(const Grid& g);
 void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,

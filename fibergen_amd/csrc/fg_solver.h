@@ -76,6 +76,7 @@ struct SolverOptions {
   int plane_fft = -1;           // z and y transforms of a z-y plane in one kernel (small grids): -1 where available, 0 off, 1 on
   int x_layout = -1;            // x-contiguous intermediate layout [zc/8][y][x][8] between the y passes and the fused x pass
                                 // (the spectrum goes through tau_, free in the displacement loop): 1 on, 0 off, -1 by size
+  int z_sweep = -1;             // displacement sweep with both z transforms attached (k_uz_tile; Voigt, one GPU): -1 where it pays, 0 off, 1 on
   int fuse_z = 0;               // attach the z r2c transform to the untiled fast sweep (u_tile = 0): 1 on, 0 off, -1 by size
                                 // (measured +3 % at 128^3, -1 % at 256^3, -5 % at 512^3 against the untiled sweep)
 };
@@ -177,6 +178,7 @@ class Solver {
   }
   void reset_stage_times();
   double event_bias_ms() const { return event_bias_ms_; }
+  long zsweep_passes() const { return zsweep_passes_; }   // passes taken by the z-attached sweep (fg_get_counter)
 
  private:
   // one pass  dst = E - Gamma0 : (C - C0) : src  (defaults: the solver's strain field, in place)
@@ -197,7 +199,8 @@ class Solver {
   // c12: optional {c10, c20} replacing the factors derived from (mu_0, lambda_0, alpha)
   // xscratch: three free components the spectrum may pass through in the x-contiguous layout (nullptr: in place, plain layout)
   bool plane_fft_on() const;
-  void fft_g0_chain(double* buf, bool z_done = false, double alpha = -1.0, const double* c12 = nullptr, double* xscratch = nullptr);
+  void fft_g0_chain(double* buf, bool z_done = false, double alpha = -1.0, const double* c12 = nullptr, double* xscratch = nullptr,
+                    bool skip_c2r = false);
   void ensure_eps();                    // materialise eps = E + sym grad u if the loop left it implicit
   void recompute_bc();
   double bc_error(const double* E_cur, const double* S_cur);
@@ -324,6 +327,12 @@ class Solver {
 
   bool u_valid_ = false;    // fu_ holds the displacement belonging to the current strain state
   bool z_done_ = false;     // the last displacement sweep wrote the z spectrum of f (not f)
+  bool u_zspec_ = false;    // fu_ holds the z half spectrum of the displacement (state of the z-attached sweep), not u
+  bool z_skip_back_ = false;   // the pending transform chain stops before the c2r pass (its result feeds the z-attached sweep)
+  bool zsweep_ok_ = false;  // set by the basic-scheme loops: u_pass_front may run the z-attached sweep
+  long zsweep_passes_ = 0;
+  bool zsweep_on() const;
+  void ensure_u_real();     // fu_ back to real space (c2r along z) if it holds the z spectrum
   bool eps_stale_ = false;  // eps_ has not been written since fu_ changed
   bool in_run_ = false;
   bool fresh_step_ = true;   // the load step being run starts from the zeroed field (not from a previous step)

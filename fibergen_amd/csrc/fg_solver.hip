@@ -416,7 +416,7 @@ void Solver::fetch_norms_and_errors(const char* where) {
 // FFT / Green-operator chain of the displacement loop, enqueued without touching the host-side state: fu_alt_ then holds
 // u_{k+1}; adopt_back() makes it the current state.  If the iteration stops first, it is simply never adopted.
 void Solver::launch_pending_back() {
-  fft_g0_chain(fu_alt_, z_done_, -1.0, nullptr, opt_.mode == 0 ? tau_ : nullptr);   // tau_ is free in the displacement loop
+  fft_g0_chain(fu_alt_, z_done_, -1.0, nullptr, opt_.mode == 0 ? tau_ : nullptr, z_skip_back_);   // tau_ is free in the displacement loop
   pending_back_ = false;
   back_ready_ = true;
 }
@@ -428,6 +428,7 @@ void Solver::adopt_back() {
   fu_ = fu_alt_;
   fu_alt_ = t;
   u_valid_ = true;
+  u_zspec_ = z_skip_back_;
   eps_stale_ = true;
   for (int c = 0; c < 6; ++c) E_cur_[c] = E_next_[c];
   if (timing_) times_.count++;
@@ -670,7 +671,7 @@ bool Solver::plane_fft_on() const {
   return v != 0 && nranks_ == 1 && fft_->can_plane();
 }
 
-void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* c12, double* xscratch) {  // alpha = -1: GammaOperator(..., -1)  F:20575
+void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* c12, double* xscratch, bool skip_c2r) {  // alpha = -1: GammaOperator(..., -1)  F:20575
   if (opt_.mode == 1) {
     // G0OperatorStaggeredHeat  F:20118-20135 on one component: fftVector(., 1), c1 = c10/|k|^2, fftInvVector
     const double scale = 1 / (double)nglobal_;
@@ -758,6 +759,7 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     time_begin(7);
     fft_->c2c_y_xlayout(xscratch, g_.n, buf, g_.n, 3, +1, 1.0);
     time_end(7);
+    if (skip_c2r) return;   // the z-attached sweep takes the z half spectrum
     time_begin(8);
     fft_->c2r_z(buf, 3, g_.n);
     time_end(8);
@@ -825,6 +827,7 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
   time_begin(7);
   fft_->c2c_y(buf, 3, g_.n, +1, 1.0);
   time_end(7);
+  if (skip_c2r) return;   // the z-attached sweep takes the z half spectrum
   time_begin(8);
   fft_->c2r_z(buf, 3, g_.n);
   time_end(8);
@@ -945,6 +948,10 @@ void Solver::u_pass_front(const double* E6) {
     E.v[c] = E_cur_[c];
     E_next_[c] = E6[c];
   }
+  if (!(zsweep_ok_ && zsweep_on() && opt_.mode == 0 && opt_.mixing == kMixVoigt && opt_.u_loop >= 2)) {
+    ensure_u_real();
+    z_skip_back_ = false;
+  }
   time_begin(0);
   if (opt_.mode == 1) {
     z_done_ = false;
@@ -989,7 +996,32 @@ void Solver::u_pass_front(const double* E6) {
     }
     const bool want_z = !laminate && (opt_.fuse_z > 0 || (opt_.fuse_z < 0 && (long)g_.nx * g_.ny * g_.nz <= (1L << 22)));
     z_done_ = want_z && fft_->fast_z() && u_fast_z_supported(g_);
-    if (opt_.u_tile && u_tile_supported(g_)) {
+    z_skip_back_ = false;
+    if (!laminate && zsweep_ok_ && zsweep_on()) {
+      // the sweep with both z transforms attached: state = z half spectrum of u_k, output = z half spectrum of f_{k+1};
+      // the transform chain then starts at the y pass and stops before the c2r pass
+      if (!u_zspec_) {   // entering the loop with u in real space: one r2c pass (unnormalised, hence the 1/nz)
+        fft_->r2c_z(fu_, 3, g_.n);
+        fft_->scale(fu_, 3, g_.n, 1.0 / (double)g_.nz);
+        u_zspec_ = true;
+      }
+      z_done_ = true;
+      z_skip_back_ = true;
+      ++zsweep_passes_;
+      const bool sum_tau = !(frobenius(BC_MQ_) < kEps);
+      if (two_phase_complementary()) {
+        FieldPtrs<2> ph;
+        ph.p[0] = phi_ + g_.n;
+        ph.p[1] = nullptr;
+        const PhaseTable t = phase_table();
+        launch_uz_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), ph, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, stream_,
+                       sum_tau, &t, fft_->z_twiddles4(), fft_->z_roots());
+      } else {
+        launch_uz_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_,
+                       dscal_ + kSlotSumSq, stream_, sum_tau, nullptr, fft_->z_twiddles4(), fft_->z_roots());
+      }
+    } else if (opt_.u_tile && u_tile_supported(g_)) {
+      ensure_u_real();
       z_done_ = false;
       const bool sum_tau = !(frobenius(BC_MQ_) < kEps);   // mixed BC: sums of tau land in kSlotMean
       if (two_phase_complementary()) {
@@ -1043,7 +1075,24 @@ void Solver::u_pass_back() {
   adopt_back();
 }
 
+// The z-attached sweep (fg_kernels_zsweep.hip) keeps the displacement as its z half spectrum between passes; everything else
+// reads u in real space.
+bool Solver::zsweep_on() const {
+  static const int env = getenv("FG_Z_SWEEP") ? atoi(getenv("FG_Z_SWEEP")) : -1;
+  const int v = env >= 0 ? env : opt_.z_sweep;
+  if (v == 0 || nranks_ != 1 || slab_layout_ || opt_.mode != 0 || !opt_.u_tile) return false;
+  if (!(fft_->fast_z() && fft_->z_twiddles4() && uz_tile_supported(g_))) return false;
+  return v > 0 || g_.nz >= 256;   // default: where the z rows are long enough to pay (FG_Z_SWEEP / option z_sweep override)
+}
+
+void Solver::ensure_u_real() {
+  if (!u_zspec_) return;
+  fft_->c2r_z(fu_, 3, g_.n);
+  u_zspec_ = false;
+}
+
 void Solver::ensure_eps() {
+  ensure_u_real();
   if (slab_layout_ && su_valid_ && eps_stale_) {   // slab driver: the state is su_[cur] with its halo planes
     slab_materialise_eps();
     return;
@@ -1077,10 +1126,17 @@ void Solver::iterate(const double* E6, int n) {
       basic_scheme(E6);  // leaves u in fu_ and eps in eps_
       ++i;
     }
-    for (; i < n; ++i) {
-      u_pass_front(E6);
-      u_pass_back();
+    zsweep_ok_ = true;
+    try {
+      for (; i < n; ++i) {
+        u_pass_front(E6);
+        u_pass_back();
+      }
+    } catch (...) {
+      zsweep_ok_ = false;
+      throw;
     }
+    zsweep_ok_ = false;
     return;
   }
   for (; i < n; ++i) basic_scheme(E6);
@@ -1313,6 +1369,11 @@ bool Solver::run_one_step(const double* E0, const double* S0) {
     for (int i = 0; i < 6; ++i) E_cur_[i] = E0[i];
   }
   in_run_ = true;
+  struct ZGuard {   // the z-attached sweep is the basic scheme's: CG and the accessors read u in real space
+    bool& flag;
+    explicit ZGuard(bool& f) : flag(f) { flag = true; }
+    ~ZGuard() { flag = false; }
+  } zguard(zsweep_ok_);
 
   double prev = prev0;
   long iter = 1;

@@ -83,6 +83,8 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * strain field is the state, one kernel per reference routine where fuse_* are 0 too),
  * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (rows per workgroup of
  * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled), fuse_z (untiled sweep with the z transform attached),
+ * z_sweep (-1 = default: where it pays; 0 / 1 off / on: the tiled sweep with BOTH z transforms attached -- the state between
+ * passes is the z half spectrum of u, the c2r and r2c passes disappear; Voigt mixing, nz = 128 or 256, one GPU),
  * phi_sweep (1 = default: with two phases whose fractions are complementary bit for bit the tiled sweep reads phi_1 and
  * forms the effective moduli itself; 0 = always the two precomputed moduli arrays), laminate_overlap (1 = default: the interface kernels of the laminate correction run on a second stream beside the
  * displacement sweep; 0 = one stream), slab_split (slab driver: 1 = one all-to-all per component, overlapping the transforms of the next component; 0 = one
@@ -166,6 +168,10 @@ int fg_get_stage_times(const fg_solver* s, double* ms /* [FG_NUM_TIMED_KERNELS] 
 /* What a pair of HIP events reads with nothing between them on this solver's stream (measured when timing is switched
  * on, milliseconds); it has been subtracted from every figure fg_get_stage_times reports. */
 int fg_get_stage_timing_bias(const fg_solver* s, double* ms);
+/* Which form of the loop ran (no counterpart in the reference; tests and bench.py name the kernels they measured):
+ * "zsweep_passes" = passes taken by the displacement sweep with both z transforms attached (option z_sweep) since the
+ * solver was created.  Unknown names give -1. */
+long fg_get_counter(const fg_solver* s, const char* name);
 
 /* Measurement helper (no counterpart in the reference): achieved HBM bandwidth of a streaming copy a = b and of the
  * triad a = b + s*c on `device`, arrays of `megabytes` MB each, best of `reps` launches, in GB/s of bytes moved
