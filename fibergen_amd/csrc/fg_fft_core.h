@@ -233,17 +233,34 @@ struct Pass4 {
       dftR<R, DIR>(v + b * R);
     }
   }
+  // Exchanges in the contiguous-line layout (LdsMap::sm == 1: phys(m, c) = pad8(m) + c * sc).  The padded position of a
+  // slot is ONE run-time base per butterfly plus a compile-time offset: the r-th output of a butterfly sits r * NS points
+  // after the first, and pad8(m0 + r NS) - pad8(m0) is a constant for the NS that occur (1: m0 = 4 j, no carry into bit 3;
+  // 4: m0 % 8 < 4, the carry is r >> 1; >= 8: multiples of 8 pass through the padding); inputs are multiples of 8 apart.
+  // (With lds_put / lds_get per slot the compiler either rebuilds every padded index or parks dozens of them in registers.)
+  static constexpr int out_off(int r) { return NS >= 8 ? r * (NS + NS / 8) : (NS == 4 ? 4 * r + (r >> 1) : r * NS); }
+  static_assert(NS == 1 || NS == 4 || NS >= 8, "radix-4 schedule: Ns is a power of 4 (a last radix-2 pass scatters nothing)");
+  static_assert(T % 8 == 0 && NBF % 8 == 0, "line length >= 32");
   FG_HD static void to_lds(const cplx* v, int jt, double* lds, const LdsMap& L, int c) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b) {
+      double* const p = lds + c * L.sc + pad8(out_index(jt, b, 0));
 #pragma unroll
-      for (int r = 0; r < R; ++r) lds_put(lds, L, out_index(jt, b, r), c, v[b * R + r]);
+      for (int r = 0; r < R; ++r) {
+        p[out_off(r)] = v[b * R + r].re;
+        p[out_off(r) + L.im_off] = v[b * R + r].im;
+      }
+    }
   }
   FG_HD static void from_lds(cplx* v, int jt, const double* lds, const LdsMap& L, int c) {
+    const double* const p = lds + c * L.sc + pad8(jt);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int r = 0; r < R; ++r) v[b * R + r] = lds_get(lds, L, in_index(jt, b, r), c);
+      for (int r = 0; r < R; ++r) {
+        const int off = (b * T + r * NBF) + (b * T + r * NBF) / 8;
+        v[b * R + r] = cmake(p[off], p[off + L.im_off]);
+      }
   }
 };
 

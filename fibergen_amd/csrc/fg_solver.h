@@ -76,7 +76,7 @@ struct SolverOptions {
   int plane_fft = -1;           // z and y transforms of a z-y plane in one kernel (small grids): -1 where available, 0 off, 1 on
   int x_layout = -1;            // x-contiguous intermediate layout [zc/8][y][x][8] between the y passes and the fused x pass
                                 // (the spectrum goes through tau_, free in the displacement loop): 1 on, 0 off, -1 by size
-  int z_sweep = -1;             // displacement sweep with both z transforms attached (k_uz_tile; Voigt, one GPU): -1 where it pays, 0 off, 1 on
+  int z_sweep = -1;             // displacement sweep with both z transforms attached (k_uz_tile; Voigt, one GPU): 1 on; 0 / -1 off (it ties the three kernels it replaces, see EXPERIMENTS.md)
   int fuse_z = 0;               // attach the z r2c transform to the untiled fast sweep (u_tile = 0): 1 on, 0 off, -1 by size
                                 // (measured +3 % at 128^3, -1 % at 256^3, -5 % at 512^3 against the untiled sweep)
 };

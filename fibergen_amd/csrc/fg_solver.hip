@@ -1082,7 +1082,7 @@ bool Solver::zsweep_on() const {
   const int v = env >= 0 ? env : opt_.z_sweep;
   if (v == 0 || nranks_ != 1 || slab_layout_ || opt_.mode != 0 || !opt_.u_tile) return false;
   if (!(fft_->fast_z() && fft_->z_twiddles4() && uz_tile_supported(g_))) return false;
-  return v > 0 || g_.nz >= 256;   // default: where the z rows are long enough to pay (FG_Z_SWEEP / option z_sweep override)
+  return v > 0;   // opt-in: at 256^3 the attached transforms are LDS-bound and the sweep only ties the three kernels it replaces (EXPERIMENTS.md, round 4)
 }
 
 void Solver::ensure_u_real() {

@@ -83,8 +83,9 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * strain field is the state, one kernel per reference routine where fuse_* are 0 too),
  * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (rows per workgroup of
  * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled), fuse_z (untiled sweep with the z transform attached),
- * z_sweep (-1 = default: where it pays; 0 / 1 off / on: the tiled sweep with BOTH z transforms attached -- the state between
- * passes is the z half spectrum of u, the c2r and r2c passes disappear; Voigt mixing, nz = 128 or 256, one GPU),
+ * z_sweep (1 = on; default off: the tiled sweep with BOTH z transforms attached -- the state between passes is the z half
+ * spectrum of u, the c2r and r2c passes disappear; Voigt mixing, nz = 128 or 256, one GPU; measured equal to the three
+ * kernels it replaces, kept as an option),
  * phi_sweep (1 = default: with two phases whose fractions are complementary bit for bit the tiled sweep reads phi_1 and
  * forms the effective moduli itself; 0 = always the two precomputed moduli arrays), laminate_overlap (1 = default: the interface kernels of the laminate correction run on a second stream beside the
  * displacement sweep; 0 = one stream), slab_split (slab driver: 1 = one all-to-all per component, overlapping the transforms of the next component; 0 = one

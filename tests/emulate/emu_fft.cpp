@@ -102,7 +102,7 @@ int emu_line4(int N, int dir, double* data, int nlines) {
     for (int l = 0; l < nlines; ++l) line4_run<n>(x + (long)l * n, dir, tw.data()); \
     return 0;                                                          \
   }
-  CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) CASE(512)
+  CASE(32) CASE(64) CASE(128) CASE(256) CASE(512)
 #undef CASE
   return 1;
 }
