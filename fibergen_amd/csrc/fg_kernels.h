@@ -104,6 +104,12 @@ void launch_cgu_dot(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldP
 void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r,
                      const FieldPtrs<3>& w, const double* sc, int i_num, int i_den, double nvox, double small, hipStream_t s,
                      long count = 0 /* doubles per component to update; 0 = g.n (x-slabs: + the spare planes) */);
+// the same sweeps in k_u_tile's tiling (grids of u_tile_supported), the update fused with its norms and OUT OF PLACE:
+// mode 0: out7[0] = grad_s a : (grad_s a - grad_s b); mode 1: A = a + alpha y -> ao, B = b - alpha (y - w) -> bo with
+// alpha = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small), out7[0..5] = sums of (E + grad_s A)_c^2, out7[6] = B : B
+void launch_cgu_tile(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldPtrs<3>& b, const FieldPtrs<3>& y,
+                     const FieldPtrs<3>& w, const FieldPtrs<3>& ao, const FieldPtrs<3>& bo, const Vec6& E, const double* sc,
+                     int i_num, int i_den, double nvox, double small, double* partial, double* out7, hipStream_t s);
 // interface voxels (some phase fraction strictly between 0 and 1): allocates and fills the list of their element
 // offsets in voxel order (*list, hipFree by the caller), returns the count
 unsigned launch_mixed_list(const Grid& g, int nph, const FieldPtrs<kMaxPhases>& phi, unsigned** list, hipStream_t s);

@@ -537,6 +537,198 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   }
 }
 
+// Tiled marching form of the vector sweeps of the conjugate gradients in displacement space (k_cgu_dot / k_cgu_axpy,
+// fg_kernels.hip; innerProductL2 F:20955-21038, the updates of runCGElasticity F:23201-23240): k_u_tile's tiling (rows = waves,
+// lanes = z pairs, march along x; x neighbours in registers, y neighbours through LDS, z neighbours by DPP) for the staggered
+// gradients of TWO displacement fields A and B at once, every value loaded once per tile.
+//   MODE 0:  A = a, B = b as stored;  partial[0] = sum grad_s A : (grad_s A - grad_s B)               (p : (p - w))
+//   MODE 1:  A = a + alpha y,  B = b - alpha (y - w)  (eps += alpha p ; r -= alpha (p - w) with the alpha the device holds),
+//            stored to ao / bo -- OUT OF PLACE: the halo rows of a tile re-evaluate the update of rows the neighbouring tile owns,
+//            which must still find the old values --, partial[0..5] = sums of (E + grad_s A)_c^2, partial[6] = sum grad_s B : grad_s B.
+// The untiled pair (axpy sweep 144 B per voxel + dot sweep 48 B with recomputed neighbours) took 0.46 + 0.23 ms at 256^3.
+template <int TYR, int ZS, int MODE>
+__global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_cgu_tile(Grid g, FieldPtrs<3> a, FieldPtrs<3> b, FieldPtrs<3> y,
+                                                                        FieldPtrs<3> w, FieldPtrs<3> ao, FieldPtrs<3> bo, Vec6 E,
+                                                                        const double* sc, int i_num, int i_den, double nvox,
+                                                                        double small, double* partial, int nty, int ntz, int LX,
+                                                                        int nt) {
+  constexpr bool FULLROW = ZS > 0;
+  constexpr int NZS = ZS ? ZS : 1;
+  constexpr int TYU = TYR - 2;
+  constexpr int TZU = FULLROW ? 64 * NZS : 62;
+  constexpr int RW = NZS * 64;
+  constexpr int NS = 7;
+  extern __shared__ __align__(16) double2 tile_lds[];
+  double2(*Xb)[TYR][RW] = reinterpret_cast<double2(*)[TYR][RW]>(tile_lds);   // [6][TYR][RW]: A0 A1 A2 B0 B1 B2 of the plane
+  __shared__ double red[TYR * NZS * NS];
+
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int r = wv / NZS, zs = wv % NZS;
+  const int li = zs * 64 + l;
+  const int zprev = (zs + NZS - 1) % NZS, znext = (zs + 1) % NZS;
+  const int nzh = g.nz / 2;
+  int bi = blockIdx.x;
+  {
+    const int nb = gridDim.x;
+    if (nb % 8 == 0) bi = (bi % 8) * (nb / 8) + bi / 8;
+  }
+  const int tz = bi % ntz;
+  bi /= ntz;
+  const int ty = bi % nty;
+  const int tx = bi / nty;
+  const bool surplus = tx * LX >= g.nx;
+  const int j0 = min(ty * TYU, g.ny - TYU), kp0 = min(tz * TZU, nzh - TZU), x0 = surplus ? 0 : tx * LX;
+  const int jr = j0 - 1 + r;
+  const int j = jr < 0 ? jr + g.ny : (jr >= g.ny ? jr - g.ny : jr);
+  const int kr = FULLROW ? li : kp0 - 1 + l;
+  const int kp = kr < 0 ? kr + nzh : (kr >= nzh ? kr - nzh : kr);
+  const bool own = r >= 1 && r <= TYU && jr >= ty * TYU && (FULLROW || (l >= 1 && l <= TZU && kr >= tz * TZU));
+  const long rowoff = (long)j * g.nzp + 2 * kp;
+  const int rm = r > 0 ? r - 1 : 0, rp = r + 1 < TYR ? r + 1 : TYR - 1;
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const int nsteps = surplus ? -2 : (x0 + LX <= g.nx ? LX : g.nx - x0);
+  const double al = MODE == 1 ? (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small) : 0.0;
+
+  auto plane = [&](int q) {
+    const int x = q < 0 ? q + g.xw_lo : (q >= g.nx ? q - g.xw_hi : q);
+    return (long)x * g.nyzp + rowoff;
+  };
+  auto store = [&](double* base, long off, double2 v) {
+    if (nt) {
+      typedef double fg_v2d __attribute__((ext_vector_type(2)));
+      fg_v2d t;
+      t.x = v.x;
+      t.y = v.y;
+      __builtin_nontemporal_store(t, reinterpret_cast<fg_v2d*>(base + off));
+    } else {
+      st2(base, off, v);
+    }
+  };
+  auto prev_y = [&](double v) { return dpp_move<0x138>(v); };
+  auto next_x = [&](double v) { return dpp_move<0x130>(v); };
+  // the two fields of plane q (as stored, or updated), and their store where this thread owns the voxels of an owned plane
+  auto fetch = [&](int q, double2 (&A)[3], double2 (&B)[3], bool keep) {
+    const long o = plane(q);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      A[c] = ld2(a.p[c], o);
+      B[c] = ld2(b.p[c], o);
+      if (MODE == 1) {
+        const double2 yv = ld2(y.p[c], o), wv2 = ld2(w.p[c], o);
+        A[c].x = A[c].x + al * yv.x;
+        A[c].y = A[c].y + al * yv.y;
+        B[c].x = B[c].x - al * (yv.x - wv2.x);
+        B[c].y = B[c].y - al * (yv.y - wv2.y);
+        if (keep && own) {
+          store(ao.p[c], o, A[c]);
+          store(bo.p[c], o, B[c]);
+        }
+      }
+    }
+  };
+
+  double acc[NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) acc[c] = 0.0;
+  if (nsteps > 0) {   // uniform per workgroup
+    double2 Ac[3], Bc[3], An[3], Bn[3];
+    fetch(x0 - 1, Ac, Bc, false);
+    fetch(x0, An, Bn, true);
+    double2 dA1 = make_double2(0.0, 0.0), dA2 = dA1, dB1 = dA1, dB2 = dA1;
+    for (int st = -1; st < nsteps; ++st) {
+      const int q = x0 + st;
+      // y neighbours through LDS
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        Xb[c][r][li] = Ac[c];
+        Xb[3 + c][r][li] = Bc[c];
+      }
+      __syncthreads();
+      const double2 A0yb = Xb[0][rm][li], A1yf = Xb[1][rp][li], A2yb = Xb[2][rm][li];
+      const double2 B0yb = Xb[3][rm][li], B1yf = Xb[4][rp][li], B2yb = Xb[5][rm][li];
+      double A0zb = prev_y(Ac[0].y), A1zb = prev_y(Ac[1].y), A2zf = next_x(Ac[2].x);
+      double B0zb = prev_y(Bc[0].y), B1zb = prev_y(Bc[1].y), B2zf = next_x(Bc[2].x);
+      if (FULLROW) {
+        if (l == 0) {
+          A0zb = Xb[0][r][zprev * 64 + 63].y;
+          A1zb = Xb[1][r][zprev * 64 + 63].y;
+          B0zb = Xb[3][r][zprev * 64 + 63].y;
+          B1zb = Xb[4][r][zprev * 64 + 63].y;
+        }
+        if (l == 63) {
+          A2zf = Xb[2][r][znext * 64].x;
+          B2zf = Xb[5][r][znext * 64].x;
+        }
+      }
+      __syncthreads();   // the image is free for the next plane
+      if (own && st >= 0) {
+        // staggered symmetric gradients of the two voxels  (F:18632-18686 without the prescribed strain)
+        double2 ga[6], gb[6];
+        ga[0].x = (An[0].x - Ac[0].x) * hx;  ga[0].y = (An[0].y - Ac[0].y) * hx;
+        ga[1].x = (A1yf.x - Ac[1].x) * hy;   ga[1].y = (A1yf.y - Ac[1].y) * hy;
+        ga[2].x = (Ac[2].y - Ac[2].x) * hz;  ga[2].y = (A2zf - Ac[2].y) * hz;
+        ga[3].x = 0.5 * ((Ac[2].x - A2yb.x) * hy + (Ac[1].x - A1zb) * hz);
+        ga[3].y = 0.5 * ((Ac[2].y - A2yb.y) * hy + (Ac[1].y - Ac[1].x) * hz);
+        ga[4].x = 0.5 * (dA2.x * hx + (Ac[0].x - A0zb) * hz);
+        ga[4].y = 0.5 * (dA2.y * hx + (Ac[0].y - Ac[0].x) * hz);
+        ga[5].x = 0.5 * (dA1.x * hx + (Ac[0].x - A0yb.x) * hy);
+        ga[5].y = 0.5 * (dA1.y * hx + (Ac[0].y - A0yb.y) * hy);
+        gb[0].x = (Bn[0].x - Bc[0].x) * hx;  gb[0].y = (Bn[0].y - Bc[0].y) * hx;
+        gb[1].x = (B1yf.x - Bc[1].x) * hy;   gb[1].y = (B1yf.y - Bc[1].y) * hy;
+        gb[2].x = (Bc[2].y - Bc[2].x) * hz;  gb[2].y = (B2zf - Bc[2].y) * hz;
+        gb[3].x = 0.5 * ((Bc[2].x - B2yb.x) * hy + (Bc[1].x - B1zb) * hz);
+        gb[3].y = 0.5 * ((Bc[2].y - B2yb.y) * hy + (Bc[1].y - Bc[1].x) * hz);
+        gb[4].x = 0.5 * (dB2.x * hx + (Bc[0].x - B0zb) * hz);
+        gb[4].y = 0.5 * (dB2.y * hx + (Bc[0].y - Bc[0].x) * hz);
+        gb[5].x = 0.5 * (dB1.x * hx + (Bc[0].x - B0yb.x) * hy);
+        gb[5].y = 0.5 * (dB1.y * hx + (Bc[0].y - B0yb.y) * hy);
+        double sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double wgt = c < 3 ? 1.0 : 2.0;
+          if (MODE == 0) {
+            sx += wgt * (ga[c].x * (ga[c].x - gb[c].x));
+            sy += wgt * (ga[c].y * (ga[c].y - gb[c].y));
+          } else {
+            const double ex = E.v[c] + ga[c].x, ey = E.v[c] + ga[c].y;
+            acc[c] += ex * ex + ey * ey;
+            sx += wgt * (gb[c].x * gb[c].x);
+            sy += wgt * (gb[c].y * gb[c].y);
+          }
+        }
+        acc[MODE == 0 ? 0 : 6] += sx + sy;
+      }
+      // advance one plane
+      dA1.x = An[1].x - Ac[1].x; dA1.y = An[1].y - Ac[1].y;
+      dA2.x = An[2].x - Ac[2].x; dA2.y = An[2].y - Ac[2].y;
+      dB1.x = Bn[1].x - Bc[1].x; dB1.y = Bn[1].y - Bc[1].y;
+      dB2.x = Bn[2].x - Bc[2].x; dB2.y = Bn[2].y - Bc[2].y;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { Ac[c] = An[c]; Bc[c] = Bn[c]; }
+      if (st + 1 < nsteps) fetch(q + 2, An, Bn, st + 2 < nsteps);   // plane q + 2: the forward x neighbour of the next step
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NS; ++c) {
+    double v = acc[c];
+    v += dpp_move<0x128>(v);
+    v += dpp_move<0x124>(v);
+    v += dpp_move<0x122>(v);
+    v += dpp_move<0x121>(v);
+    acc[c] = (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+  }
+  if (l == 0) {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) red[wv * NS + c] = acc[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double v = 0.0;
+    for (int q = 0; q < TYR * NZS; ++q) v += red[q * NS + threadIdx.x];
+    partial[(long)blockIdx.x * NS + threadIdx.x] = v;
+  }
+}
+
 // The second half of k_u_tile on its own, for passes whose state is the strain field (viscosity mode; mixed boundary
 // conditions): eps -> f = div((C - C0) : eps) and the six sums of the polarisation, Voigt mixing with the precomputed
 // effective moduli.  Same tiling (rows = waves, lanes = z pairs, march along x, y neighbours of tau through LDS -- two
@@ -1166,6 +1358,50 @@ void launch_eps_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   if (nzh == 64) launch_eps_tile_t<8, 1>(g, mu_0, lambda_0, eps, mod, f, partial, sum6, s);
   else if (nzh == 128) launch_eps_tile_t<6, 2>(g, mu_0, lambda_0, eps, mod, f, partial, sum6, s);
   else launch_eps_tile_t<8, 0>(g, mu_0, lambda_0, eps, mod, f, partial, sum6, s);
+}
+
+template <int TYR, int ZS, int MODE>
+void launch_cgu_tile_t(const Grid& g, const FieldPtrs<3>& a, const FieldPtrs<3>& b, const FieldPtrs<3>& y, const FieldPtrs<3>& w,
+                       const FieldPtrs<3>& ao, const FieldPtrs<3>& bo, const Vec6& E, const double* sc, int i_num, int i_den,
+                       double nvox, double small, double* partial, double* out7, hipStream_t s) {
+  constexpr int NZS = ZS ? ZS : 1;
+  constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
+  const int nzh = g.nz / 2;
+  const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
+  int LX = march_length(g.nx, (long)nty * ntz, device_cu_count());
+  if (LX > g.nx) LX = g.nx;
+  const int ntx = (g.nx + LX - 1) / LX;
+  int nb = nty * ntz * ntx;
+  if (nb >= 8) nb = ((nb + 7) / 8) * 8;
+  const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
+  static PerDeviceOnce configured;
+  if (auto once = configured.first_use()) {
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgu_tile<TYR, ZS, MODE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  const int nt = (MODE == 1 && 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024) ? 1 : 0;
+  hipLaunchKernelGGL((k_cgu_tile<TYR, ZS, MODE>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, a, b, y, w, ao, bo, E, sc, i_num, i_den,
+                     nvox, small, partial, nty, ntz, LX, nt);
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 7, out7, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+// mode 0: out7[0] = a : (a - b) in the gradient inner product (y, w, ao, bo, sc unused); mode 1: the update
+// A = a + alpha y, B = b - alpha (y - w) -> ao, bo (buffers other than a, b, y, w) with out7 = norms of E + grad_s A, B : B
+void launch_cgu_tile(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldPtrs<3>& b, const FieldPtrs<3>& y,
+                     const FieldPtrs<3>& w, const FieldPtrs<3>& ao, const FieldPtrs<3>& bo, const Vec6& E, const double* sc,
+                     int i_num, int i_den, double nvox, double small, double* partial, double* out7, hipStream_t s) {
+  const int nzh = g.nz / 2;
+#define FG_CGT(R, Z)                                                                                                          \
+  do {                                                                                                                        \
+    if (mode == 0) launch_cgu_tile_t<R, Z, 0>(g, a, b, y, w, ao, bo, E, sc, i_num, i_den, nvox, small, partial, out7, s);       \
+    else launch_cgu_tile_t<R, Z, 1>(g, a, b, y, w, ao, bo, E, sc, i_num, i_den, nvox, small, partial, out7, s);                 \
+  } while (0)
+  if (nzh == 64) FG_CGT(8, 1);
+  else if (nzh == 128) FG_CGT(6, 2);
+  else FG_CGT(8, 0);
+#undef FG_CGT
 }
 
 bool u_fast_z_supported(const Grid& g) {
