@@ -255,6 +255,7 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
     else if (k == "slab_interleave") o.slab_interleave = value < 0 ? -1 : (value != 0);
     else if (k == "fuse_z") o.fuse_z = value < 0 ? -1 : (value != 0);
     else if (k == "z_sweep") o.z_sweep = value < 0 ? -1 : (value != 0);
+    else if (k == "cg_fused") o.cg_fused = value < 0 ? -1 : (value != 0);
     else if (k == "x_layout") o.x_layout = value < 0 ? -1 : (value != 0);
     else if (k == "plane_fft") o.plane_fft = value < 0 ? -1 : (value != 0);
     else if (k == "u_loop") o.u_loop = (int)value;

@@ -88,6 +88,12 @@ bool uz_tile_supported(const Grid& g);
 void launch_uz_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& uhat, const FieldPtrs<2>& mod,
                     const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, hipStream_t s, bool sum_tau,
                     const PhaseTable* two_phase, const cplx* tw_z, const cplx* w_z);
+// the tiled sweep on the NEW search direction of the conjugate gradients, formed on the fly: p_new = r + b p_old with
+// b = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small), stored to p_new (a buffer of its own), f = div((C - C0) : grad_s p_new)
+void launch_u_tile_cg(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& p_old, const FieldPtrs<3>& r,
+                      const FieldPtrs<3>& p_new, const FieldPtrs<2>& mod, const FieldPtrs<3>& f, const Vec6& E, const double* sc,
+                      int i_num, int i_den, double nvox, double small, double* partial, double* sumsq6, hipStream_t s,
+                      const PhaseTable* two_phase);
 void launch_complement_check(const Grid& g, const double* phi0, const double* phi1, int* flag, hipStream_t s);
 bool u_fast_z_supported(const Grid& g);
 void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,

@@ -318,10 +318,24 @@ struct PhaseLin {
   double a0, da, b0, db;
 };
 
-template <int TYR, int ZS, bool SUMT, bool PHI2>
+// CGP: the sweep's displacement is the NEW search direction of the conjugate gradients, formed on the fly:
+// u := r + b u  (u_p = u_r + beta u_p, F:23235-23240) with b = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small) from the
+// sums the dot sweeps left on the device, stored to po wherever this thread owns the voxels (out of place: halo rows and
+// lanes form the value of voxels the neighbouring tile owns from the OLD direction) -- the separate update sweep
+// (k_cgu_axpy<1>: 72 B per voxel) becomes 24 B more read and 24 B more written here.
+struct CgDirection {
+  const double* r[3];
+  double* po[3];
+  const double* sc;
+  int i_num, i_den;
+  double nvox, small;
+};
+
+template <int TYR, int ZS, bool SUMT, bool PHI2, bool CGP = false>
 __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, double beta, double gamma, FieldPtrs<3> u,
                                                                       FieldPtrs<2> mod, FieldPtrs<3> fo, Vec6 E, double* partial,
-                                                                      int nty, int ntz, int LX, int nt, PhaseLin lin) {
+                                                                      int nty, int ntz, int LX, int nt, PhaseLin lin,
+                                                                      CgDirection cg) {
   constexpr bool FULLROW = ZS > 0;
   constexpr int NZS = ZS ? ZS : 1;        // waves per row
   constexpr int TYU = TYR - 2;            // rows with output
@@ -383,13 +397,25 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
   auto prev_y = [&](double v) { return dpp_move<0x138>(v); };  // lane i <- i-1 (lane 0: fixed up below when ZS >= 1)
   auto next_x = [&](double v) { return dpp_move<0x130>(v); };  // lane i <- i+1 (lane 63: likewise)
 
+  const double cgb = CGP ? (cg.sc[cg.i_num] / cg.nvox + cg.small) / (cg.sc[cg.i_den] / cg.nvox + cg.small) : 0.0;
+  // the displacement of component c at offset o (CGP: the new direction, kept where `keep` says the plane is this tile's)
+  auto load_u = [&](int c, long o, bool keep) {
+    double2 v = ld2(u.p[c], o);
+    if (CGP) {
+      const double2 rv = ld2(cg.r[c], o);
+      v.x = rv.x + cgb * v.x;
+      v.y = rv.y + cgb * v.y;
+      if (keep && own) st2(cg.po[c], o, v);
+    }
+    return v;
+  };
   double2 uc[3], un[3], u2[3];
   {
     const long o0 = plane(x0 - 1), o1 = plane(x0);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      uc[c] = ld2(u.p[c], o0);
-      un[c] = ld2(u.p[c], o1);
+      uc[c] = load_u(c, o0, false);
+      un[c] = load_u(c, o1, nsteps > 0);
     }
   }
   double2 dx1 = make_double2(0.0, 0.0), dx2 = dx1;          // U1, U2 minus their previous plane (warm-up: unused)
@@ -408,7 +434,7 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
     // u two planes ahead (consumed next step); the moduli of this plane are first needed after the LDS exchange
     const long o2 = plane(q + 2), oq = plane(q);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) u2[c] = ld2(u.p[c], o2);
+    for (int c = 0; c < 3; ++c) u2[c] = load_u(c, o2, st + 2 >= 0 && st + 2 < nsteps);
     const double2 Ac = ld2(mod.p[0], oq);
     double2 Bc = Ac;
     if (!PHI2) Bc = ld2(mod.p[1], oq);
@@ -1029,10 +1055,10 @@ inline int march_length(int nx, long tiles, int cus) {
   return best;
 }
 
-template <int TYR, int ZS, bool SUMT, bool PHI2 = false>
+template <int TYR, int ZS, bool SUMT, bool PHI2 = false, bool CGP = false>
 void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                      const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s,
-                     const PhaseLin& lin = PhaseLin{0, 0, 0, 0}) {
+                     const PhaseLin& lin = PhaseLin{0, 0, 0, 0}, const CgDirection& cg = CgDirection{}) {
   constexpr int NZS = ZS ? ZS : 1;
   constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
   const int nzh = g.nz / 2;
@@ -1047,12 +1073,12 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   const size_t lds = 6 * TYR * NZS * 64 * sizeof(double2);
   static PerDeviceOnce configured;
   if (auto once = configured.first_use()) {
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, ZS, SUMT, PHI2>),
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_u_tile<TYR, ZS, SUMT, PHI2, CGP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   const int nt = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
-  hipLaunchKernelGGL((k_u_tile<TYR, ZS, SUMT, PHI2>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f, E,
-                     partial, nty, ntz, LX, nt, lin);
+  hipLaunchKernelGGL((k_u_tile<TYR, ZS, SUMT, PHI2, CGP>), dim3(nb), dim3(TYR * NZS * 64), lds, s, g, -2 * mu_0, -lambda_0, u, mod, f,
+                     E, partial, nty, ntz, LX, nt, lin, cg);
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, SUMT ? 12 : 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
@@ -1098,6 +1124,35 @@ void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
     else FG_TILE(8, 0);
   }
 #undef FG_TILE
+}
+
+// k_u_tile with the search direction of the conjugate gradients formed on the fly: u := r + b u -> po (see CgDirection);
+// the default tile shapes, no sums of tau
+void launch_u_tile_cg(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& p_old, const FieldPtrs<3>& r,
+                      const FieldPtrs<3>& p_new, const FieldPtrs<2>& mod, const FieldPtrs<3>& f, const Vec6& E, const double* sc,
+                      int i_num, int i_den, double nvox, double small, double* partial, double* sumsq6, hipStream_t s,
+                      const PhaseTable* two_phase) {
+  CgDirection cg;
+  for (int c = 0; c < 3; ++c) cg.r[c] = r.p[c], cg.po[c] = p_new.p[c];
+  cg.sc = sc;
+  cg.i_num = i_num;
+  cg.i_den = i_den;
+  cg.nvox = nvox;
+  cg.small = small;
+  const int nzh = g.nz / 2;
+  PhaseLin lin = {0, 0, 0, 0};
+  if (two_phase)
+    lin = PhaseLin{2 * two_phase->mu[0] - 2 * mu_0, 2 * (two_phase->mu[1] - two_phase->mu[0]), two_phase->lambda[0] - lambda_0,
+                   two_phase->lambda[1] - two_phase->lambda[0]};
+#define FG_CGK(R, Z)                                                                                                            \
+  do {                                                                                                                          \
+    if (two_phase) launch_u_tile_t<R, Z, false, true, true>(g, mu_0, lambda_0, p_old, mod, f, E, partial, sumsq6, s, lin, cg);   \
+    else launch_u_tile_t<R, Z, false, false, true>(g, mu_0, lambda_0, p_old, mod, f, E, partial, sumsq6, s, lin, cg);            \
+  } while (0)
+  if (nzh == 64) FG_CGK(8, 1);
+  else if (nzh == 128) FG_CGK(6, 2);
+  else FG_CGK(8, 0);
+#undef FG_CGK
 }
 
 // *flag := 0 unless phi0 == 1 - phi1 bit for bit at every voxel (what normalizePhi F:17613-17626 produces for two phases);

@@ -76,6 +76,7 @@ struct SolverOptions {
   int plane_fft = -1;           // z and y transforms of a z-y plane in one kernel (small grids): -1 where available, 0 off, 1 on
   int x_layout = -1;            // x-contiguous intermediate layout [zc/8][y][x][8] between the y passes and the fused x pass
                                 // (the spectrum goes through tau_, free in the displacement loop): 1 on, 0 off, -1 by size
+  int cg_fused = -1;            // displacement-space CG with fused vector sweeps (run_cg_u): -1 where the tiled sweep fits, 0 off, 1 on
   int z_sweep = -1;             // displacement sweep with both z transforms attached (k_uz_tile; Voigt, one GPU): 1 on; 0 / -1 off (it ties the three kernels it replaces, see EXPERIMENTS.md)
   int fuse_z = 0;               // attach the z r2c transform to the untiled fast sweep (u_tile = 0): 1 on, 0 off, -1 by size
                                 // (measured +3 % at 128^3, -1 % at 256^3, -5 % at 512^3 against the untiled sweep)
@@ -288,6 +289,7 @@ class Solver {
   double* tau_ = nullptr;      // 6
   double* fu_ = nullptr;       // 3 (real f / u, complex f_hat / u_hat); after a pass it holds u
   double *cg_r_ = nullptr, *cg_p_ = nullptr, *cg_w_ = nullptr;  // CG residual, direction, operator image (6 each)
+  double* fu_cg_ = nullptr;   // fused displacement-space CG: the alternate buffer of the iterate (3 components; swapped with fu_)
   unsigned* mixed_list_ = nullptr;  // element offsets of the interface voxels (laminate mixing, displacement loop)
   unsigned mixed_n_ = 0;
   bool mixed_dirty_ = true;

@@ -189,7 +189,7 @@ void Solver::release() {
   if (aff_list_) (void)hipFree(aff_list_);
   if (aff_slots_) (void)hipFree(aff_slots_);
   if (dtau_) (void)hipFree(dtau_);
-  double* bufs[] = {eps_, tau_, fu_, fu_alt_, phi_, normals_, partial_, dscal_, cg_r_, cg_p_, cg_w_, mod_};
+  double* bufs[] = {eps_, tau_, fu_, fu_alt_, phi_, normals_, partial_, dscal_, cg_r_, cg_p_, cg_w_, mod_, fu_cg_};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (hscal_) (void)hipHostFree(hscal_);
@@ -1505,6 +1505,21 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
   if (!cg_r_) FG_HIP_CHECK(hipMalloc(&cg_r_, 2 * f3));
   double* u_r = cg_r_;
   double* u_p = cg_r_ + 3 * g_.n;
+  // Fused form (option cg_fused, default where the tiled sweep fits; Voigt mixing): the vector work of an iteration is two
+  // tiled sweeps instead of four kernels -- p:(p - w) (launch_cgu_tile mode 0), and the update of eps and r together with the
+  // norms of the new eps and r:r (mode 1) -- and the direction update p = r + beta p is formed inside the operator's
+  // displacement sweep (launch_u_tile_cg).  Updates are out of place (the tiles' halo rows re-evaluate them), so u_e, u_r and
+  // u_p alternate between two buffers each; fu_ stays the current iterate.
+  static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
+  const int fused_opt = fused_env >= 0 ? fused_env : opt_.cg_fused;
+  const bool fused = fused_opt != 0 && opt_.mixing == kMixVoigt && opt_.u_tile && u_tile_supported(g_) && !slab_layout_;
+  double *r_alt = nullptr, *p_alt = nullptr;
+  if (fused) {
+    if (!cg_p_) FG_HIP_CHECK(hipMalloc(&cg_p_, 2 * f3));
+    if (!fu_cg_) FG_HIP_CHECK(hipMalloc(&fu_cg_, f3));
+    r_alt = cg_p_;
+    p_alt = cg_p_ + 3 * g_.n;
+  }
   for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
   in_run_ = true;
   cg_u_active_ = true;
@@ -1521,6 +1536,26 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
     fu_ = keep;
     fft_g0_chain(fu_alt_, z_done_, -1.0, nullptr, tau_);
   };
+  // fused form: u_p := u_r + beta u_p (beta from the sums at dscal_[i_num] / dscal_[i_den]) inside the sweep of the operator
+  auto apply_dir = [&](int i_num, int i_den) {
+    FieldPtrs<2> m;
+    const PhaseTable t = phase_table();
+    const bool two = two_phase_complementary();
+    if (two) {
+      m.p[0] = phi_ + g_.n;
+      m.p[1] = nullptr;
+    } else {
+      m = effective_moduli();
+    }
+    time_begin(0);
+    launch_u_tile_cg(g_, opt_.mu_0, opt_.lambda_0, ptrs3(u_p), ptrs3(u_r), ptrs3(p_alt), m, ptrs3(fu_alt_), Z, dscal_, i_num, i_den,
+                     (double)nglobal_, std::numeric_limits<double>::min(), partial_, dscal_ + kSlotSumSq, stream_, two ? &t : nullptr);
+    time_end(0);
+    z_done_ = false;
+    fft_g0_chain(fu_alt_, false, -1.0, nullptr, tau_);
+    std::swap(u_p, p_alt);
+  };
+  int beta_num = 0, beta_den = 0;   // fused form: slots of the pending direction update
   // eps_0 = E (u_e = 0);  r = -Gamma0 (C - C0) E  (+ E - eps_0 = 0, adjustResidual F:10012-10022)
   // The CG scalars stay on the device (k_cgu_axpy forms alpha and beta from the sums the dot sweeps leave in
   // dscal_): the host fetches only the seven sums of the stop rule, and -- when no callback can look at the state
@@ -1545,20 +1580,37 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
   bool applied = false;   // u_w = operator(u_p) of the coming iteration is already enqueued
   for (;;) {
     const int cur = (int)(iter & 1), nxt = cur ^ 1;
-    if (!applied) apply(u_p, Z.v);                                                    // u_w = operator(u_p)
+    if (!applied) {
+      if (fused && iter > 0) apply_dir(beta_num, beta_den);                            // p = r + beta p ; u_w = operator(u_p)
+      else apply(u_p, Z.v);                                                           // u_w = operator(u_p)
+    }
     applied = false;
+    if (fused) {
+      launch_cgu_tile(0, g_, ptrs3(u_p), ptrs3(fu_alt_), ptrs3(u_p), ptrs3(fu_alt_), ptrs3(fu_cg_), ptrs3(r_alt), Z, dscal_, 0, 0, nvox,
+                      small, partial_, dscal_ + s0, stream_);                                         // p : (p - w)
+      // eps += alpha p ; r -= alpha (p - w) into the alternate buffers, with the norms of the new eps and r : r
+      launch_cgu_tile(1, g_, ptrs3(fu_), ptrs3(u_r), ptrs3(u_p), ptrs3(fu_alt_), ptrs3(fu_cg_), ptrs3(r_alt), E, dscal_, blk[cur] + 6, s0,
+                      nvox, small, partial_, dscal_ + blk[nxt], stream_);
+      std::swap(fu_, fu_cg_);
+      std::swap(u_r, r_alt);
+    } else {
     launch_cgu_dot(0, g_, ptrs3(u_p), ptrs3(fu_alt_), Z, partial_, dscal_ + s0, stream_);   // p : (p - w)
     // eps += alpha p ; r -= alpha (p - w),  alpha = gamma / (p:(p - w) / N + tiny)
     launch_cgu_axpy(0, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), dscal_, blk[cur] + 6, s0, nvox, small, stream_);
     launch_cgu_dot(1, g_, ptrs3(fu_), ptrs3(u_r), E, partial_, dscal_ + blk[nxt], stream_);   // norms of eps ; r : r
+    }
     FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotCg, dscal_ + blk[nxt], 7 * sizeof(double), hipMemcpyDeviceToHost, stream_));
     FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, stream_));
     FG_HIP_CHECK(hipEventRecord(ev_copy_, stream_));
     if (!cb_ && iter < opt_.maxiter) {
       // p = r + beta p (beta = delta / gamma) and the next operator application, enqueued behind the copies
-      launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), dscal_, blk[nxt] + 6, blk[cur] + 6, nvox, small,
-                      stream_);
-      apply(u_p, Z.v);
+      if (fused) {
+        apply_dir(blk[nxt] + 6, blk[cur] + 6);
+      } else {
+        launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), dscal_, blk[nxt] + 6, blk[cur] + 6, nvox, small,
+                        stream_);
+        apply(u_p, Z.v);
+      }
       applied = true;
     }
     FG_HIP_CHECK(hipEventSynchronize(ev_copy_));
@@ -1599,9 +1651,15 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
       if (bc_error(E0, S0) <= opt_.bc_tol) break;
     }
     iter++;
-    if (!applied)   // p = r + beta p
-      launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), dscal_, blk[nxt] + 6, blk[cur] + 6, nvox, small,
-                      stream_);
+    if (!applied) {   // p = r + beta p
+      if (fused) {
+        beta_num = blk[nxt] + 6;   // formed inside the next operator application
+        beta_den = blk[cur] + 6;
+      } else {
+        launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), dscal_, blk[nxt] + 6, blk[cur] + 6, nvox, small,
+                        stream_);
+      }
+    }
   }
   cg_u_active_ = false;
   iterations_ = iter;
