@@ -1512,7 +1512,8 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
   // u_p alternate between two buffers each; fu_ stays the current iterate.
   static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
   const int fused_opt = fused_env >= 0 ? fused_env : opt_.cg_fused;
-  const bool fused = fused_opt != 0 && opt_.mixing == kMixVoigt && opt_.u_tile && u_tile_supported(g_) && !slab_layout_;
+  const bool fused = fused_opt != 0 && opt_.u_tile && u_tile_supported(g_) && !slab_layout_;
+  const bool fused_dir = fused && opt_.mixing == kMixVoigt;   // laminate mixing: the interface kernels read u_p as a stored field
   double *r_alt = nullptr, *p_alt = nullptr;
   if (fused) {
     if (!cg_p_) FG_HIP_CHECK(hipMalloc(&cg_p_, 2 * f3));
@@ -1581,7 +1582,7 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
   for (;;) {
     const int cur = (int)(iter & 1), nxt = cur ^ 1;
     if (!applied) {
-      if (fused && iter > 0) apply_dir(beta_num, beta_den);                            // p = r + beta p ; u_w = operator(u_p)
+      if (fused_dir && iter > 0) apply_dir(beta_num, beta_den);                        // p = r + beta p ; u_w = operator(u_p)
       else apply(u_p, Z.v);                                                           // u_w = operator(u_p)
     }
     applied = false;
@@ -1604,7 +1605,7 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
     FG_HIP_CHECK(hipEventRecord(ev_copy_, stream_));
     if (!cb_ && iter < opt_.maxiter) {
       // p = r + beta p (beta = delta / gamma) and the next operator application, enqueued behind the copies
-      if (fused) {
+      if (fused_dir) {
         apply_dir(blk[nxt] + 6, blk[cur] + 6);
       } else {
         launch_cgu_axpy(1, g_, ptrs3(fu_), ptrs3(u_p), ptrs3(u_r), ptrs3(fu_alt_), dscal_, blk[nxt] + 6, blk[cur] + 6, nvox, small,
@@ -1652,7 +1653,7 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
     }
     iter++;
     if (!applied) {   // p = r + beta p
-      if (fused) {
+      if (fused_dir) {
         beta_num = blk[nxt] + 6;   // formed inside the next operator application
         beta_den = blk[cur] + 6;
       } else {
