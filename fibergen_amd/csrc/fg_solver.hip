@@ -1512,7 +1512,14 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
   // u_p alternate between two buffers each; fu_ stays the current iterate.
   static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
   const int fused_opt = fused_env >= 0 ? fused_env : opt_.cg_fused;
-  const bool fused = fused_opt != 0 && opt_.u_tile && u_tile_supported(g_) && !slab_layout_;
+  bool fused = fused_opt != 0 && opt_.u_tile && u_tile_supported(g_) && !slab_layout_;
+  if (fused && (!cg_p_ || !fu_cg_)) {
+    // nine more components (the alternates of u_e, u_r, u_p): on grids that fill the card (1024^3: 78 GB) the four-kernel form
+    size_t free_b = 0, total_b = 0;
+    FG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = (cg_p_ ? 0 : 2 * f3) + (fu_cg_ ? 0 : f3);
+    if (free_b < need + (size_t)(0.02 * (double)total_b)) fused = false;
+  }
   const bool fused_dir = fused && opt_.mixing == kMixVoigt;   // laminate mixing: the interface kernels read u_p as a stored field
   double *r_alt = nullptr, *p_alt = nullptr;
   if (fused) {
