@@ -1186,10 +1186,20 @@ void launch_complement_check(const Grid& g, const double* phi0, const double* ph
 // loaded once per tile (k_sc_sweep_fast: 8 loads per pair out of L2).
 // SUMT: the three sums of the flux polarisation tau = (a - 2 mu0) g as well (partial slots 3..5): <tau> drives the mixed
 // boundary conditions (initBCProjector F:20228-20239 in GammaOperatorStaggeredHeat F:20342-20350)
-template <int TYR, int ZS, bool SUMT = false>
+// CGP: T := r + b T, the new search direction of the conjugate gradients in potential space, formed on the fly and stored to
+// po where this thread owns the voxels (see CgDirection at k_u_tile)
+struct ScCgDirection {
+  const double* r;
+  double* po;
+  const double* sc;
+  int i_num, i_den;
+  double nvox, small;
+};
+
+template <int TYR, int ZS, bool SUMT = false, bool CGP = false>
 __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, double beta, const double* T, const double* a,
                                                                        double* fo, Vec6 E, double* partial, int nty, int ntz,
-                                                                       int LX, int nt) {
+                                                                       int LX, int nt, ScCgDirection cg) {
   constexpr bool FULLROW = ZS > 0;
   constexpr int NZS = ZS ? ZS : 1;
   constexpr int TYU = TYR - 2;
@@ -1242,8 +1252,19 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, do
     }
   };
 
+  const double cgb = CGP ? (cg.sc[cg.i_num] / cg.nvox + cg.small) / (cg.sc[cg.i_den] / cg.nvox + cg.small) : 0.0;
+  auto load_T = [&](long o, bool keep) {
+    double2 v = ld2(T, o);
+    if (CGP) {
+      const double2 rv = ld2(cg.r, o);
+      v.x = rv.x + cgb * v.x;
+      v.y = rv.y + cgb * v.y;
+      if (keep && own) st2(cg.po, o, v);
+    }
+    return v;
+  };
   // plane x0 - 1 gives the x flux entering plane x0
-  double2 Tc = ld2(T, plane(x0 - 1)), Tn = ld2(T, plane(x0)), T2 = ld2(T, plane(x0 + 1));
+  double2 Tc = load_T(plane(x0 - 1), false), Tn = load_T(plane(x0), nsteps > 0), T2 = load_T(plane(x0 + 1), nsteps > 1);
   double2 ac = ld2(a, plane(x0 - 1)), an = ld2(a, plane(x0));
   double2 q0m;   // x flux of the previous plane
   q0m.x = (ac.x + beta) * (E.v[0] + (Tn.x - Tc.x) * hx);
@@ -1254,7 +1275,7 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_tile(Grid g, do
   for (int st = 0; st < nsteps; ++st) {
     const int q = x0 + st;
     const long oq = plane(q);
-    T2 = ld2(T, plane(q + 2));   // two planes ahead of T, one of a (the last step's are unused but in range)
+    T2 = load_T(plane(q + 2), st + 2 < nsteps);   // two planes ahead of T, one of a (the last step's are unused but in range)
     an = ld2(a, plane(q + 1));
     const double2 cc = make_double2(ac.x + beta, ac.y + beta);
     const int img = st & 1;
@@ -1327,7 +1348,7 @@ __global__ void k_sc_split_sums(double* sumsq6, double* sumtau3) {
 
 template <int TYR, int ZS>
 void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E, double* partial,
-                      double* sumsq6, hipStream_t s, double* sumtau3) {
+                      double* sumsq6, hipStream_t s, double* sumtau3, const ScCgDirection* cgd = nullptr) {
   constexpr int NZS = ZS ? ZS : 1;
   constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
   const int nzh = g.nz / 2;
@@ -1343,18 +1364,194 @@ void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double*
   const int nt = (double)g.n * sizeof(double) > 128.0 * 1024 * 1024 ? 1 : 0;
   if (sumtau3) {
     hipLaunchKernelGGL((k_sc_tile<TYR, ZS, true>), dim3(nb), dim3(TYR * NZS * 64), 0, s, g, -2 * mu_0, T, a, f, E, partial, nty,
-                       ntz, LX, nt);
+                       ntz, LX, nt, ScCgDirection{});
     FG_HIP_CHECK(hipGetLastError());
     fold_sum(partial, nb, 6, sumsq6, s);
     hipLaunchKernelGGL(k_sc_split_sums, dim3(1), dim3(64), 0, s, sumsq6, sumtau3);
     FG_HIP_CHECK(hipGetLastError());
     return;
   }
-  hipLaunchKernelGGL((k_sc_tile<TYR, ZS>), dim3(nb), dim3(TYR * NZS * 64), 0, s, g, -2 * mu_0, T, a, f, E, partial, nty, ntz,
-                     LX, nt);
+  if (cgd)
+    hipLaunchKernelGGL((k_sc_tile<TYR, ZS, false, true>), dim3(nb), dim3(TYR * NZS * 64), 0, s, g, -2 * mu_0, T, a, f, E, partial, nty,
+                       ntz, LX, nt, *cgd);
+  else
+    hipLaunchKernelGGL((k_sc_tile<TYR, ZS>), dim3(nb), dim3(TYR * NZS * 64), 0, s, g, -2 * mu_0, T, a, f, E, partial, nty, ntz,
+                       LX, nt, ScCgDirection{});
   FG_HIP_CHECK(hipGetLastError());
   fold_sum(partial, nb, 6, sumsq6, s);
   FG_HIP_CHECK(hipGetLastError());
+}
+
+// Scalar sibling of k_cgu_tile (conjugate gradients in potential space, k_sc_cg_dot / k_sc_cg_axpy of fg_kernels_scalar.hip):
+// gradients are forward differences, so a tile needs the NEXT plane (registers), the next row (LDS) and the next lane (DPP).
+//   MODE 0:  partial[0] = sum grad A . (grad A - grad B),  A = a, B = b
+//   MODE 1:  A = a + alpha y -> ao,  B = b - alpha (y - w) -> bo (out of place),  partial[0..2] = sums of (E + grad A)_c^2,
+//            partial[6] = sum grad B . grad B
+template <int TYR, int ZS, int MODE>
+__global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_sc_cgu_tile(Grid g, const double* a, const double* b, const double* y,
+                                                                           const double* w, double* ao, double* bo, Vec6 E,
+                                                                           const double* sc, int i_num, int i_den, double nvox,
+                                                                           double small, double* partial, int nty, int ntz, int LX) {
+  constexpr bool FULLROW = ZS > 0;
+  constexpr int NZS = ZS ? ZS : 1;
+  constexpr int TYU = TYR - 2;
+  constexpr int TZU = FULLROW ? 64 * NZS : 62;
+  constexpr int RW = NZS * 64;
+  constexpr int NS = 7;
+  __shared__ double2 Xb[2][2][TYR][RW];   // [image][A, B][row][pair]
+  __shared__ double red[TYR * NZS * NS];
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int r = wv / NZS, zs = wv % NZS;
+  const int li = zs * 64 + l;
+  const int znext = (zs + 1) % NZS;
+  const int nzh = g.nz / 2;
+  int bi = blockIdx.x;
+  {
+    const int nb = gridDim.x;
+    if (nb % 8 == 0) bi = (bi % 8) * (nb / 8) + bi / 8;
+  }
+  const int tz = bi % ntz;
+  bi /= ntz;
+  const int ty = bi % nty;
+  const int tx = bi / nty;
+  const bool surplus = tx * LX >= g.nx;
+  const int j0 = min(ty * TYU, g.ny - TYU), kp0 = min(tz * TZU, nzh - TZU), x0 = surplus ? 0 : tx * LX;
+  const int jr = j0 - 1 + r;
+  const int j = jr < 0 ? jr + g.ny : (jr >= g.ny ? jr - g.ny : jr);
+  const int kr = FULLROW ? li : kp0 - 1 + l;
+  const int kp = kr < 0 ? kr + nzh : (kr >= nzh ? kr - nzh : kr);
+  const bool own = r >= 1 && r <= TYU && jr >= ty * TYU && (FULLROW || (l >= 1 && l <= TZU && kr >= tz * TZU));
+  const long rowoff = (long)j * g.nzp + 2 * kp;
+  const int rp = r + 1 < TYR ? r + 1 : TYR - 1;
+  const double hx = g.hx, hy = g.hy, hz = g.hz;
+  const int nsteps = surplus ? 0 : (x0 + LX <= g.nx ? LX : g.nx - x0);
+  const double al = MODE == 1 ? (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small) : 0.0;
+  auto plane = [&](int q) {
+    const int x = q < 0 ? q + g.xw_lo : (q >= g.nx ? q - g.xw_hi : q);
+    return (long)x * g.nyzp + rowoff;
+  };
+  auto fetch = [&](int q, double2& A, double2& B, bool keep) {
+    const long o = plane(q);
+    A = ld2(a, o);
+    B = ld2(b, o);
+    if (MODE == 1) {
+      const double2 yv = ld2(y, o), wv2 = ld2(w, o);
+      A.x = A.x + al * yv.x;
+      A.y = A.y + al * yv.y;
+      B.x = B.x - al * (yv.x - wv2.x);
+      B.y = B.y - al * (yv.y - wv2.y);
+      if (keep && own) {
+        st2(ao, o, A);
+        st2(bo, o, B);
+      }
+    }
+  };
+  double acc[NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) acc[c] = 0.0;
+  if (nsteps > 0) {
+    double2 Ac, Bc, An, Bn;
+    fetch(x0, Ac, Bc, true);
+    fetch(x0 + 1, An, Bn, nsteps > 1);
+    for (int st = 0; st < nsteps; ++st) {
+      const int img = st & 1;
+      Xb[img][0][r][li] = Ac;
+      Xb[img][1][r][li] = Bc;
+      __syncthreads();
+      const double2 Ayf = Xb[img][0][rp][li], Byf = Xb[img][1][rp][li];
+      double Azf = dpp_move<0x130>(Ac.x), Bzf = dpp_move<0x130>(Bc.x);
+      if (FULLROW && l == 63) {
+        Azf = Xb[img][0][r][znext * 64].x;
+        Bzf = Xb[img][1][r][znext * 64].x;
+      }
+      if (own) {
+        const double ga0x = (An.x - Ac.x) * hx, ga0y = (An.y - Ac.y) * hx;
+        const double ga1x = (Ayf.x - Ac.x) * hy, ga1y = (Ayf.y - Ac.y) * hy;
+        const double ga2x = (Ac.y - Ac.x) * hz, ga2y = (Azf - Ac.y) * hz;
+        const double gb0x = (Bn.x - Bc.x) * hx, gb0y = (Bn.y - Bc.y) * hx;
+        const double gb1x = (Byf.x - Bc.x) * hy, gb1y = (Byf.y - Bc.y) * hy;
+        const double gb2x = (Bc.y - Bc.x) * hz, gb2y = (Bzf - Bc.y) * hz;
+        if (MODE == 0) {
+          acc[0] += (ga0x * (ga0x - gb0x) + ga1x * (ga1x - gb1x) + ga2x * (ga2x - gb2x)) +
+                    (ga0y * (ga0y - gb0y) + ga1y * (ga1y - gb1y) + ga2y * (ga2y - gb2y));
+        } else {
+          const double e0x = E.v[0] + ga0x, e0y = E.v[0] + ga0y, e1x = E.v[1] + ga1x, e1y = E.v[1] + ga1y;
+          const double e2x = E.v[2] + ga2x, e2y = E.v[2] + ga2y;
+          acc[0] += e0x * e0x + e0y * e0y;
+          acc[1] += e1x * e1x + e1y * e1y;
+          acc[2] += e2x * e2x + e2y * e2y;
+          acc[6] += (gb0x * gb0x + gb1x * gb1x + gb2x * gb2x) + (gb0y * gb0y + gb1y * gb1y + gb2y * gb2y);
+        }
+      }
+      Ac = An;
+      Bc = Bn;
+      if (st + 1 < nsteps) fetch(x0 + st + 2, An, Bn, st + 2 < nsteps);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NS; ++c) {
+    double v = acc[c];
+    v += dpp_move<0x128>(v);
+    v += dpp_move<0x124>(v);
+    v += dpp_move<0x122>(v);
+    v += dpp_move<0x121>(v);
+    acc[c] = (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+  }
+  if (l == 0) {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) red[wv * NS + c] = acc[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double v = 0.0;
+    for (int q = 0; q < TYR * NZS; ++q) v += red[q * NS + threadIdx.x];
+    partial[(long)blockIdx.x * NS + threadIdx.x] = v;
+  }
+}
+
+template <int TYR, int ZS>
+void launch_sc_cgu_tile_t(int mode, const Grid& g, const double* a, const double* b, const double* y, const double* w, double* ao,
+                          double* bo, const Vec6& E, const double* sc, int i_num, int i_den, double nvox, double small,
+                          double* partial, double* out7, hipStream_t s) {
+  constexpr int NZS = ZS ? ZS : 1;
+  constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
+  const int nzh = g.nz / 2;
+  const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
+  int LX = march_length(g.nx, (long)nty * ntz, 2 * device_cu_count());
+  if (LX > g.nx) LX = g.nx;
+  const int ntx = (g.nx + LX - 1) / LX;
+  int nb = nty * ntz * ntx;
+  if (nb >= 8) nb = ((nb + 7) / 8) * 8;
+  if (mode == 0)
+    hipLaunchKernelGGL((k_sc_cgu_tile<TYR, ZS, 0>), dim3(nb), dim3(TYR * NZS * 64), 0, s, g, a, b, y, w, ao, bo, E, sc, i_num, i_den, nvox,
+                       small, partial, nty, ntz, LX);
+  else
+    hipLaunchKernelGGL((k_sc_cgu_tile<TYR, ZS, 1>), dim3(nb), dim3(TYR * NZS * 64), 0, s, g, a, b, y, w, ao, bo, E, sc, i_num, i_den, nvox,
+                       small, partial, nty, ntz, LX);
+  FG_HIP_CHECK(hipGetLastError());
+  fold_sum(partial, nb, 7, out7, s);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+// the scalar modes' CG vector sweeps in the tiled form (grids of sc_sweep_tiled), see k_sc_cgu_tile
+void launch_sc_cgu_tile(int mode, const Grid& g, const double* a, const double* b, const double* y, const double* w, double* ao,
+                        double* bo, const Vec6& E, const double* sc, int i_num, int i_den, double nvox, double small, double* partial,
+                        double* out7, hipStream_t s) {
+  const int nzh = g.nz / 2;
+  if (nzh == 64) launch_sc_cgu_tile_t<8, 1>(mode, g, a, b, y, w, ao, bo, E, sc, i_num, i_den, nvox, small, partial, out7, s);
+  else if (nzh == 128) launch_sc_cgu_tile_t<6, 2>(mode, g, a, b, y, w, ao, bo, E, sc, i_num, i_den, nvox, small, partial, out7, s);
+  else launch_sc_cgu_tile_t<8, 0>(mode, g, a, b, y, w, ao, bo, E, sc, i_num, i_den, nvox, small, partial, out7, s);
+}
+
+// the tiled scalar sweep on the new search direction T_p = T_r + b T_p (b from the device sums), stored to p_new
+void launch_sc_sweep_cg(const Grid& g, double mu_0, const double* p_old, const double* r, double* p_new, const double* a, double* f,
+                        const Vec6& E, const double* sc, int i_num, int i_den, double nvox, double small, double* partial,
+                        double* sumsq6, hipStream_t s) {
+  ScCgDirection cg = {r, p_new, sc, i_num, i_den, nvox, small};
+  const int nzh = g.nz / 2;
+  if (nzh == 64) launch_sc_tile_t<8, 1>(g, mu_0, p_old, a, f, E, partial, sumsq6, s, nullptr, &cg);
+  else if (nzh == 128) launch_sc_tile_t<6, 2>(g, mu_0, p_old, a, f, E, partial, sumsq6, s, nullptr, &cg);
+  else launch_sc_tile_t<8, 0>(g, mu_0, p_old, a, f, E, partial, sumsq6, s, nullptr, &cg);
 }
 
 bool sc_sweep_tiled(const Grid& g) {

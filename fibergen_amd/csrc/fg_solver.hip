@@ -1711,6 +1711,99 @@ bool Solver::run_cg_scalar(const double* E0, double prev0) {
   apply(fu_, E.v);
   FG_HIP_CHECK(hipMemcpyAsync(T_r, fu_alt_, f1, hipMemcpyDeviceToDevice, stream_));
   FG_HIP_CHECK(hipMemcpyAsync(T_p, fu_alt_, f1, hipMemcpyDeviceToDevice, stream_));
+  // Fused form (option cg_fused; as in run_cg_u): p.(p - w) and the update of T_e, T_r with their norms as two tiled sweeps,
+  // the direction update inside the operator's sweep, the CG scalars on the device, the next operator application enqueued
+  // before the host waits for the sums.  Out of place: T_e, T_r, T_p alternate between two components each (the spare
+  // components of fu_ and cg_r_).  Not with a convergence callback (accessors read fu_'s first component in between).
+  static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
+  const int fused_opt = fused_env >= 0 ? fused_env : opt_.cg_fused;
+  if (fused_opt != 0 && !cb_ && opt_.u_loop >= 2 && sc_sweep_tiled(g_) && !slab_layout_) {
+    const int blk[2] = {kSlotCg, kSlotCg + 8}, s0 = kSlotCg + 16;
+    const double nvox = (double)nglobal_;
+    double *e_cur = fu_, *e_alt = fu_ + g_.n, *r_cur = T_r, *r_alt = cg_r_ + 2 * g_.n, *p_cur = T_p, *p_alt = cg_r_ + 3 * g_.n;
+    const double* cond = effective_moduli().p[0];
+    auto apply_dir = [&](int i_num, int i_den) {   // T_p := T_r + beta T_p inside the sweep; T_w = operator(T_p)
+      time_begin(0);
+      launch_sc_sweep_cg(g_, opt_.mu_0, p_cur, r_cur, p_alt, cond, fu_alt_, Z, dscal_, i_num, i_den, nvox, small, partial_,
+                         dscal_ + kSlotSumSq, stream_);
+      time_end(0);
+      fft_g0_chain(fu_alt_, false);
+      std::swap(p_cur, p_alt);
+    };
+    launch_sc_cg_dot(1, g_, e_cur, r_cur, E, partial_, dscal_ + blk[0], stream_);   // gamma_0 = r.r / N + tiny
+    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotCg + 6, dscal_ + blk[0] + 6, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    check_device_error("cg");
+    double gamma_cur = hscal_[kSlotCg + 6] / nvox + small;
+    const double gamma_0 = gamma_cur;
+    double prev = prev0;
+    long iter = 0;
+    bool failed = false, applied = false;
+    for (;;) {
+      const int cur = (int)(iter & 1), nxt = cur ^ 1;
+      if (!applied) apply(p_cur, Z.v);   // the first iteration: p = r (every later application is enqueued ahead, see below)
+      applied = false;
+      launch_sc_cgu_tile(0, g_, p_cur, fu_alt_, p_cur, fu_alt_, e_alt, r_alt, Z, dscal_, 0, 0, nvox, small, partial_, dscal_ + s0, stream_);
+      launch_sc_cgu_tile(1, g_, e_cur, r_cur, p_cur, fu_alt_, e_alt, r_alt, E, dscal_, blk[cur] + 6, s0, nvox, small, partial_,
+                         dscal_ + blk[nxt], stream_);
+      std::swap(e_cur, e_alt);
+      std::swap(r_cur, r_alt);
+      FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotCg, dscal_ + blk[nxt], 7 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+      FG_HIP_CHECK(hipEventRecord(ev_copy_, stream_));
+      if (iter < opt_.maxiter) {   // the next direction and operator application, enqueued behind the copies
+        apply_dir(blk[nxt] + 6, blk[cur] + 6);
+        applied = true;
+      }
+      FG_HIP_CHECK(hipEventSynchronize(ev_copy_));
+      if (*herr_ != 0) check_device_error("cg");
+      double s3 = 0.0;
+      for (int c = 0; c < 6; ++c) {
+        sumsq_[c] = c < 3 ? hscal_[kSlotCg + c] : 0.0;
+        const double m = std::sqrt(sumsq_[c] / nvox);
+        s3 += m * m;
+      }
+      const double curn = std::sqrt(s3);
+      double abs_err = std::fabs(prev - curn);
+      double rel_err = abs_err / (small + curn);
+      prev = curn;
+      if (opt_.error_estimator == 1) {   // update_cg(gamma, gamma0)  F:14397-14401 with the gamma this iteration started from
+        abs_err = std::sqrt(gamma_cur);
+        rel_err = std::sqrt(gamma_cur / gamma_0);
+      }
+      gamma_cur = hscal_[kSlotCg + 6] / nvox + small;   // delta = r.r after the update: the next gamma
+      if (std::isnan(rel_err) || cancel_) {
+        failed = true;
+        break;
+      }
+      residuals_.push_back(rel_err);
+      if (iter >= opt_.maxiter) break;
+      if (rel_err <= opt_.tol || abs_err <= opt_.abs_tol) {
+        // bc_error reads the strain of the current iterate: fu_'s first component must be it
+        if (e_cur != fu_) {
+          FG_HIP_CHECK(hipMemcpyAsync(fu_, e_cur, f1, hipMemcpyDeviceToDevice, stream_));
+          std::swap(e_cur, e_alt);
+        }
+        u_valid_ = true;
+        eps_stale_ = true;
+        for (int c = 0; c < 6; ++c) E_cur_[c] = E.v[c];
+        double S0[6] = {0, 0, 0, 0, 0, 0};
+        if (bc_error(E.v, S0) <= opt_.bc_tol) break;
+      }
+      iter++;
+    }
+    if (e_cur != fu_) FG_HIP_CHECK(hipMemcpyAsync(fu_, e_cur, f1, hipMemcpyDeviceToDevice, stream_));
+    in_run_ = false;
+    cg_u_active_ = false;
+    iterations_ = iter;
+    u_valid_ = true;
+    eps_stale_ = true;
+    for (int c = 0; c < 6; ++c) E_cur_[c] = E.v[c];
+    ensure_eps();
+    FG_HIP_CHECK(hipStreamSynchronize(stream_));
+    solve_time_ += now_seconds() - t_start;
+    return failed;
+  }
   launch_sc_cg_dot(1, g_, fu_, T_r, E, partial_, dscal_ + kSlotSumSq, stream_);
   fetch(kSlotSumSq, 7);
   double gamma = hscal_[kSlotSumSq + 6] / (double)nglobal_ + small;
