@@ -110,6 +110,11 @@ void launch_cgu_dot(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldP
 void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r,
                      const FieldPtrs<3>& w, const double* sc, int i_num, int i_den, double nvox, double small, hipStream_t s,
                      long count = 0 /* doubles per component to update; 0 = g.n (x-slabs: + the spare planes) */);
+// out-of-place point-wise updates on `count` doubles per component from offset `off` (the spare planes of an x-slab's vectors
+// when the fused sweeps below wrote the own planes): mode 0: xo = x + a y, ro = r - a (y - w); mode 1: xo = r + a y
+void launch_cgu_axpy_oop(int mode, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r, const FieldPtrs<3>& w,
+                         const FieldPtrs<3>& xo, const FieldPtrs<3>& ro, const double* sc, int i_num, int i_den, double nvox,
+                         double small, long off, long count, hipStream_t s);
 // the same sweeps in k_u_tile's tiling (grids of u_tile_supported), the update fused with its norms and OUT OF PLACE:
 // mode 0: out7[0] = grad_s a : (grad_s a - grad_s b); mode 1: A = a + alpha y -> ao, B = b - alpha (y - w) -> bo with
 // alpha = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small), out7[0..5] = sums of (E + grad_s A)_c^2, out7[6] = B : B

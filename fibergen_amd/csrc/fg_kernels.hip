@@ -1486,6 +1486,42 @@ void launch_cgu_dot(int mode, const Grid& g, const FieldPtrs<3>& a, const FieldP
   FG_HIP_CHECK(hipGetLastError());
 }
 
+// The same updates OUT OF PLACE on `count` doubles per component from offset `off` on (x-slabs with the fused CG sweeps: the tile
+// kernels write the own planes of the alternate buffers, this one their spare planes -- the halo planes stay valid without an
+// exchange because the updates are point-wise with coefficients every rank forms from the same all-reduced sums).
+//   MODE 0:  xo = x + a y ;  ro = r - a (y - w)          MODE 1:  xo = r + a y
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_cgu_axpy_oop(long n2, long off, FieldPtrs<3> x, FieldPtrs<3> y, FieldPtrs<3> r,
+                                                         FieldPtrs<3> w, FieldPtrs<3> xo, FieldPtrs<3> ro, const double* sc, int i_num,
+                                                         int i_den, double nvox, double small) {
+  const double a = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+    const long o = off + 2 * i;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double2 yv = ld2(y.p[c], o), rv = ld2(r.p[c], o);
+      if (MODE == 0) {
+        const double2 xv = ld2(x.p[c], o), wv = ld2(w.p[c], o);
+        st2(xo.p[c], o, make_double2(xv.x + a * yv.x, xv.y + a * yv.y));
+        st2(ro.p[c], o, make_double2(rv.x - a * (yv.x - wv.x), rv.y - a * (yv.y - wv.y)));
+      } else {
+        st2(xo.p[c], o, make_double2(rv.x + a * yv.x, rv.y + a * yv.y));
+      }
+    }
+  }
+}
+
+void launch_cgu_axpy_oop(int mode, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r, const FieldPtrs<3>& w,
+                         const FieldPtrs<3>& xo, const FieldPtrs<3>& ro, const double* sc, int i_num, int i_den, double nvox,
+                         double small, long off, long count, hipStream_t s) {
+  const long n2 = count / 2;
+  if (n2 <= 0) return;
+  const dim3 grid(grid_for(n2, 1 << 16));
+  if (mode == 0) hipLaunchKernelGGL((k_cgu_axpy_oop<0>), grid, dim3(kBlock), 0, s, n2, off, x, y, r, w, xo, ro, sc, i_num, i_den, nvox, small);
+  else hipLaunchKernelGGL((k_cgu_axpy_oop<1>), grid, dim3(kBlock), 0, s, n2, off, x, y, r, w, xo, ro, sc, i_num, i_den, nvox, small);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
 void launch_cgu_axpy(int mode, const Grid& g, const FieldPtrs<3>& x, const FieldPtrs<3>& y, const FieldPtrs<3>& r,
                      const FieldPtrs<3>& w, const double* sc, int i_num, int i_den, double nvox, double small, hipStream_t s,
                      long count) {

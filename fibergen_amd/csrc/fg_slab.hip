@@ -349,6 +349,41 @@ void Solver::slab_cg_alloc() {
   FG_HIP_CHECK(hipMemsetAsync(scg_, 0, 6 * (size_t)ucs_ * sizeof(double), stream_));
 }
 
+bool Solver::slab_cg_alloc_fused() {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  const size_t f3 = 3 * (size_t)ucs_ * sizeof(double);
+  if (!scg2_ || !su_alt_) {
+    size_t free_b = 0, total_b = 0;
+    FG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    if (free_b < (scg2_ ? 0 : 2 * f3) + (su_alt_ ? 0 : f3) + (size_t)(0.02 * (double)total_b)) return false;
+    if (!scg2_) FG_HIP_CHECK(hipMalloc(&scg2_, 2 * f3));
+    if (!su_alt_) FG_HIP_CHECK(hipMalloc(&su_alt_, f3));
+    FG_HIP_CHECK(hipMemsetAsync(scg2_, 0, 2 * f3, stream_));
+    FG_HIP_CHECK(hipMemsetAsync(su_alt_, 0, f3, stream_));
+  }
+  return true;
+}
+
+void Solver::slab_front_fast_cg(const double* E6, int i_num, int i_den, double nvox, double small) {
+  comm_wait(kXHaloU);
+  comm_wait(kXModuli);
+  comm_wait(kXSums);
+  Vec6 E;
+  for (int c = 0; c < 6; ++c) E.v[c] = E6[c];
+  FieldPtrs<2> mod;
+  mod.p[0] = smod_;
+  mod.p[1] = smod_ + ucs_;
+  const PhaseTable pt2 = phase_table();
+  time_begin(0);
+  launch_u_tile_cg(gu_, opt_.mu_0, opt_.lambda_0, strided3(cgs_p_, ucs_), strided3(cgs_r_, ucs_), strided3(cgs_pa_, ucs_), mod, ptrs3(fu_),
+                   E, dscal_, i_num, i_den, nvox, small, partial_, dscal_ + kSlotSumSq, stream_, slab_phi_ ? &pt2 : nullptr);
+  // the spare planes of the new direction, point-wise (its halo planes stay valid without an exchange)
+  launch_cgu_axpy_oop(1, strided3(cgs_p_, ucs_), strided3(cgs_p_, ucs_), strided3(cgs_r_, ucs_), strided3(cgs_p_, ucs_),
+                      strided3(cgs_pa_, ucs_), strided3(cgs_pa_, ucs_), dscal_, i_num, i_den, nvox, small, g_.n, ucs_ - g_.n, stream_);
+  time_end(0);
+  std::swap(cgs_p_, cgs_pa_);
+}
+
 // The transform chain of one pass, cut into steps that each end in one exchange (k = 1..9):
 //   1..3  component c = k-1: z r2c, y c2c into the all-to-all layout          | all-to-all(c) forward
 //   4     x c2c + Green operator + x c2c^-1 on the y-slab, three components   | all-to-all(0) back
@@ -1099,8 +1134,13 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
 
   auto u_e = [](Solver* s) { return s->su_[s->su_cur_]; };
   auto u_w = [](Solver* s) { return s->su_[s->su_cur_ ^ 1]; };
-  auto u_r = [](Solver* s) { return s->scg_; };
-  auto u_p = [](Solver* s) { return s->scg_ + 3 * s->ucs_; };
+  auto u_r = [](Solver* s) { return s->cgs_r_; };
+  auto u_p = [](Solver* s) { return s->cgs_p_; };
+  // Fused form (option cg_fused, as Solver::run_cg_u): p:(p - w) and the update of eps, r with their norms as two tiled sweeps
+  // (the own planes of the alternate buffers; their spare planes by a point-wise kernel), the direction update inside the
+  // operator's sweep (Voigt mixing).
+  static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
+  bool fused = (fused_env >= 0 ? fused_env : a.opt_.cg_fused) != 0;
   // u_w = operator(u_in) with prescribed mean Eadd: sweep + transform chain; the halo planes of u_w are on their way
   auto apply = [&](bool from_p, const double* Eadd) {
     for (Solver* s : m_) s->slab_front_fast(Eadd, false, from_p ? u_p(s) : u_e(s), false);
@@ -1126,6 +1166,23 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
 
   for (Solver* s : m_) {
     s->slab_cg_alloc();
+    s->cgs_r_ = s->scg_;
+    s->cgs_p_ = s->scg_ + 3 * s->ucs_;
+  }
+  if (fused) {
+    // every member (every rank) must take the same form: the decision is the logical AND over the group
+    double v[2] = {0.0, 0.0};
+    for (Solver* s : m_)
+      if (!s->slab_cg_alloc_fused()) v[0] = 1.0;
+    if (a.nranks_ > 1) vote(v);
+    fused = v[0] == 0.0;
+  }
+  const bool fused_dir = fused && a.opt_.mixing == kMixVoigt;
+  for (Solver* s : m_) {
+    if (fused) {
+      s->cgs_ra_ = s->scg2_;
+      s->cgs_pa_ = s->scg2_ + 3 * s->ucs_;
+    }
     s->comm_wait(kXHaloU);
     FG_HIP_CHECK(hipMemsetAsync(u_e(s), 0, 3 * (size_t)s->ucs_ * sizeof(double), s->stream_));   // eps_0 = E
     s->su_valid_ = true;
@@ -1133,6 +1190,13 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
     s->in_run_ = true;
     for (int i = 0; i < 6; ++i) s->E_cur_[i] = E0[i];
   }
+  auto apply_dir = [&](int cur, int nxt) {   // fused: p = r + beta p inside the sweep; u_w = operator(u_p)
+    for (Solver* s : m_) {
+      s->comm_wait(kXSums);
+      s->slab_front_fast_cg(Z.v, blk[nxt] + 6, blk[cur] + 6, nglobal, small);
+    }
+    pass_fast_chain();
+  };
   apply(false, E.v);   // r = -Gamma0 (C - C0) E  (+ E - eps_0 = 0, adjustResidual F:10012-10022)
   for (Solver* s : m_) {
     s->comm_wait(kXHaloU);
@@ -1151,28 +1215,52 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
   double prev = prev0;   // estimator constructed on the field the step starts from
   long iter = 0;
   bool failed = false, applied = false;
+  int dir_cur = 0, dir_nxt = 1;   // fused: slots of the pending direction update
   for (;;) {
     const int cur = (int)(iter & 1), nxt = cur ^ 1;
-    if (!applied) apply(true, Z.v);   // u_w = operator(u_p)
+    if (!applied) {
+      if (fused_dir && iter > 0) apply_dir(dir_cur, dir_nxt);
+      else apply(true, Z.v);   // u_w = operator(u_p)
+    }
     applied = false;
     for (Solver* s : m_) {
       s->comm_wait(kXHaloU);
       s->comm_wait(kXSums);
-      launch_cgu_dot(0, s->gu_, strided3(u_p(s), s->ucs_), strided3(u_w(s), s->ucs_), Z, s->partial_, s->dscal_ + s0, s->stream_);
+      if (fused)
+        launch_cgu_tile(0, s->gu_, strided3(u_p(s), s->ucs_), strided3(u_w(s), s->ucs_), strided3(u_p(s), s->ucs_),
+                        strided3(u_w(s), s->ucs_), strided3(s->su_alt_, s->ucs_), strided3(s->cgs_ra_, s->ucs_), Z, s->dscal_, 0, 0,
+                        nglobal, small, s->partial_, s->dscal_ + s0, s->stream_);
+      else
+        launch_cgu_dot(0, s->gu_, strided3(u_p(s), s->ucs_), strided3(u_w(s), s->ucs_), Z, s->partial_, s->dscal_ + s0, s->stream_);
       s->slab_reduce(s0, 1, false);   // p : (p - w)
     }
     for (Solver* s : m_) {
       s->comm_wait(kXSums);
       // eps += alpha p ; r -= alpha (p - w),  alpha = gamma / (p:(p - w) / N + tiny); spare planes included
-      launch_cgu_axpy(0, s->gu_, strided3(u_e(s), s->ucs_), strided3(u_p(s), s->ucs_), strided3(u_r(s), s->ucs_),
-                      strided3(u_w(s), s->ucs_), s->dscal_, blk[cur] + 6, s0, nglobal, small, s->stream_, s->ucs_);
-      launch_cgu_dot(1, s->gu_, strided3(u_e(s), s->ucs_), strided3(u_r(s), s->ucs_), E, s->partial_, s->dscal_ + blk[nxt], s->stream_);
+      if (fused) {
+        launch_cgu_tile(1, s->gu_, strided3(u_e(s), s->ucs_), strided3(u_r(s), s->ucs_), strided3(u_p(s), s->ucs_),
+                        strided3(u_w(s), s->ucs_), strided3(s->su_alt_, s->ucs_), strided3(s->cgs_ra_, s->ucs_), E, s->dscal_,
+                        blk[cur] + 6, s0, nglobal, small, s->partial_, s->dscal_ + blk[nxt], s->stream_);
+        launch_cgu_axpy_oop(0, strided3(u_e(s), s->ucs_), strided3(u_p(s), s->ucs_), strided3(u_r(s), s->ucs_),
+                            strided3(u_w(s), s->ucs_), strided3(s->su_alt_, s->ucs_), strided3(s->cgs_ra_, s->ucs_), s->dscal_,
+                            blk[cur] + 6, s0, nglobal, small, s->g_.n, s->ucs_ - s->g_.n, s->stream_);
+        std::swap(s->su_[s->su_cur_], s->su_alt_);
+        std::swap(s->cgs_r_, s->cgs_ra_);
+      } else {
+        launch_cgu_axpy(0, s->gu_, strided3(u_e(s), s->ucs_), strided3(u_p(s), s->ucs_), strided3(u_r(s), s->ucs_),
+                        strided3(u_w(s), s->ucs_), s->dscal_, blk[cur] + 6, s0, nglobal, small, s->stream_, s->ucs_);
+        launch_cgu_dot(1, s->gu_, strided3(u_e(s), s->ucs_), strided3(u_r(s), s->ucs_), E, s->partial_, s->dscal_ + blk[nxt], s->stream_);
+      }
       s->slab_reduce(blk[nxt], 7, false);   // norms of eps ; r : r
     }
     fetch7(blk[nxt]);
     if (!voting && iter < a.opt_.maxiter) {   // the next direction and operator application, enqueued behind the copies
-      direction_update(cur, nxt);
-      apply(true, Z.v);
+      if (fused_dir) {
+        apply_dir(cur, nxt);
+      } else {
+        direction_update(cur, nxt);
+        apply(true, Z.v);
+      }
       applied = true;
     }
     wait_norms();
@@ -1225,7 +1313,10 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
       if (bc_error(E0, S0) <= a.opt_.bc_tol) break;
     }
     iter++;
-    if (!applied) direction_update(cur, nxt);
+    if (!applied) {
+      if (fused_dir) dir_cur = cur, dir_nxt = nxt;   // formed inside the next operator application
+      else direction_update(cur, nxt);
+    }
   }
   for (Solver* s : m_) {
     s->in_run_ = false;

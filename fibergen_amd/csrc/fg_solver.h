@@ -229,6 +229,10 @@ class Solver {
   void slab_front_fast(const double* E6, bool sum_tau, const double* u_src = nullptr, bool reduce = true);
   void slab_front_laminate(bool sum_tau, bool reduce = true);
   void slab_cg_alloc();                                  // u_r, u_p of the displacement-space CG (with spare planes)
+  bool slab_cg_alloc_fused();                            // + the alternate buffers of the fused sweeps; false: they do not fit
+  // the tiled sweep on the new search direction u_p = u_r + beta u_p (formed on the fly, own planes -> cgs_pa_, spare planes
+  // point-wise), Voigt mixing; then cgs_p_ / cgs_pa_ are swapped
+  void slab_front_fast_cg(const double* E6, int i_num, int i_den, double nvox, double small);
   void slab_fetch_norms(int n);                          // D2H of the reduced sums (+ flag word), event for the host
   void comm_time_begin();
   void comm_time_end(int category);
@@ -266,6 +270,11 @@ class Solver {
   int su_cur_ = 0;
   bool su_valid_ = false;               // su_[su_cur_] (with valid halo planes) is the state: eps = E_cur_ + sym grad u
   double* scg_ = nullptr;               // displacement-space CG on slabs: u_r, u_p (3 components of ucs_ doubles each)
+  // fused CG sweeps on slabs (out of place): the alternates of u_r, u_p (scg2_) and of u_e (su_alt_, swapped with su_[su_cur_]),
+  // and which half of each pair is current
+  double* scg2_ = nullptr;
+  double* su_alt_ = nullptr;
+  double *cgs_r_ = nullptr, *cgs_p_ = nullptr, *cgs_ra_ = nullptr, *cgs_pa_ = nullptr;
   double* smod_ = nullptr;              // effective moduli, 2 components of ucs_ doubles
   bool smod_dirty_ = true;
   bool slab_phi_ = false;               // smod_ component 0 holds phi_1 (two complementary phases), not the moduli

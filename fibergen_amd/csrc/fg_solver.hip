@@ -210,7 +210,7 @@ void Solver::release() {
   }
   comm_.reset();
   fft_ys_.reset();
-  for (double* b : {su_[0], su_[1], smod_, scg_})
+  for (double* b : {su_[0], su_[1], smod_, scg_, scg2_, su_alt_})
     if (b) (void)hipFree(b);
   if (ev_c2x_) (void)hipEventDestroy(ev_c2x_);
   if (ev_norm_) (void)hipEventDestroy(ev_norm_);

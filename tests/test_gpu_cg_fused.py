@@ -87,3 +87,26 @@ def test_fused_scalar_cg_matches_oracle_and_unfused(grid, dims, estimator):
     assert res[0][0].shape == res[1][0].shape and np.abs(res[0][0] - res[1][0]).max() < 1e-12
     assert rel_err(res[1][1], res[0][1]) < 1e-10
     assert np.abs(res[1][2] - res[0][2]).max() < 1e-10 * max(1.0, np.abs(res[0][2]).max())
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_fused_cg_on_slabs_equals_unfused(P, mixing):
+    """The slab driver's CG with the fused sweeps (own planes of the alternate buffers by the tile kernels, their spare planes
+    point-wise, so the halo planes stay valid without an exchange) against the four-kernel form and the single-GPU solver."""
+    from test_gpu_slab import make_group
+    grid = (32, 32, 128)
+    ref = make_gpu_solver(grid, mixing=mixing, tol=1e-8, method="cg")
+    assert ref.run(E_LOAD) is False
+    out = []
+    for fused in (0, 1):
+        g = make_group(P, grid, mixing=mixing, tol=1e-8, method="cg", cg_fused=fused)
+        assert g.run(E_LOAD) is False
+        assert g.iterations == ref.iterations
+        assert np.abs(np.array(g.residuals) - np.array(ref.residuals)).max() < 1e-11
+        assert rel_err(g.get_field("epsilon"), ref.get_field("epsilon")) < 1e-10
+        out.append((np.array(g.residuals), g.get_field("epsilon")))
+        g.close()
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-12
+    assert rel_err(out[1][1], out[0][1]) < 1e-11
+    ref.close()
