@@ -57,9 +57,9 @@ def _start_field(n, phi):
     return eps
 
 
-def _passes_against_cref(n, mixing, passes):
+def _passes_against_cref(n, mixing, passes, **opts):
     mats, phis, normals = _workload(n, mixing)
-    s = _gpu(n, mats, phis, normals, mixing)
+    s = _gpu(n, mats, phis, normals, mixing, **opts)
     mu_0, lam_0 = s.calc_ref_material()
     # closed form of calcRefMaterial for isotropic phases with phi covering [0, 1]  (F:22283-22313, F:12763-12771):
     # tangent eigenvalues {2 mu, 2 mu + 3 lambda} of the mixture, extremes at the pure phases
@@ -70,6 +70,8 @@ def _passes_against_cref(n, mixing, passes):
     s.iterate(E_LOAD, passes)            # pass 1: strain-state pipeline; then the displacement loop
     got = s.get_field("epsilon")
     sumsq = s.get_field("sumsq")          # norm sweep of the last displacement pass: belongs to eps_{passes-1}
+    if opts.get("z_sweep"):
+        assert s.counter("zsweep_passes") == passes - 1   # every displacement pass took the sweep under test
     s.close()
     c = _cref(n, mats, phis, normals, mixing)
     eps = eps0
@@ -85,6 +87,12 @@ def _passes_against_cref(n, mixing, passes):
 @pytest.mark.parametrize("mixing", ["voigt", "laminate"])
 def test_bench_workload_256_three_passes(mixing):
     _passes_against_cref(256, mixing, 3)
+
+
+def test_bench_workload_256_zsweep_four_passes():
+    """The same bars for the displacement sweep with both z transforms attached (option z_sweep): passes 2-4 carry the z half
+    spectrum of u from sweep to sweep, the fourth pass ends with the c2r pass that brings u back for the strain field."""
+    _passes_against_cref(256, "voigt", 4, z_sweep=1)
 
 
 def test_bench_workload_512_laminate_two_passes():
