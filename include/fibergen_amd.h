@@ -86,6 +86,9 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * z_sweep (1 = on; default off: the tiled sweep with BOTH z transforms attached -- the state between passes is the z half
  * spectrum of u, the c2r and r2c passes disappear; Voigt mixing, nz = 128 or 256, one GPU; measured equal to the three
  * kernels it replaces, kept as an option),
+ * cg_fused (-1 = default: where the tiled sweep fits; 0 / 1: method = cg in displacement / potential space with the vector
+ * work of an iteration as two tiled sweeps and the direction update inside the operator's sweep -- out of place, nine more
+ * components; falls back to the four-kernel form when they do not fit),
  * phi_sweep (1 = default: with two phases whose fractions are complementary bit for bit the tiled sweep reads phi_1 and
  * forms the effective moduli itself; 0 = always the two precomputed moduli arrays), laminate_overlap (1 = default: the interface kernels of the laminate correction run on a second stream beside the
  * displacement sweep; 0 = one stream), slab_split (slab driver: 1 = one all-to-all per component, overlapping the transforms of the next component; 0 = one
