@@ -178,6 +178,8 @@ void launch_sc_sweep(const Grid& g, const ScalarParams& sp, const double* T, con
 bool sc_sweep_tiled(const Grid& g);   // launch_sc_sweep_fast takes the tiled kernel (the one that can carry the sums of tau)
 bool launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
                           double* partial, double* sumsq6, hipStream_t s, double* sumtau3 = nullptr);
+void launch_sc_cg_axpy_oop(int mode, const double* x, const double* y, const double* r, const double* w, double* xo, double* ro,
+                           const double* sc, int i_num, int i_den, double nvox, double small, long off, long count, hipStream_t s);
 // CG in potential space, tiled and fused like launch_cgu_tile / launch_u_tile_cg (grids of sc_sweep_tiled)
 void launch_sc_cgu_tile(int mode, const Grid& g, const double* a, const double* b, const double* y, const double* w, double* ao,
                         double* bo, const Vec6& E, const double* sc, int i_num, int i_den, double nvox, double small, double* partial,

@@ -389,6 +389,37 @@ void launch_sc_cg_dot(int mode, const Grid& g, const double* a, const double* b,
   FG_HIP_CHECK(hipGetLastError());
 }
 
+// the same updates out of place on `count` doubles from offset `off`, with the coefficient formed on the device (x-slabs with
+// the fused CG sweeps: the spare planes of the alternate buffers, see k_cgu_axpy_oop)
+//   MODE 0:  xo = x + a y ;  ro = r - a (y - w)          MODE 1:  xo = r + a y
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_sc_cg_axpy_oop(long n2, long off, const double* x, const double* y, const double* r,
+                                                           const double* w, double* xo, double* ro, const double* sc, int i_num,
+                                                           int i_den, double nvox, double small) {
+  const double a = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+    const long o = off + 2 * i;
+    const double2 yv = ld2(y, o), rv = ld2(r, o);
+    if (MODE == 0) {
+      const double2 xv = ld2(x, o), wv = ld2(w, o);
+      st2(xo, o, make_double2(xv.x + a * yv.x, xv.y + a * yv.y));
+      st2(ro, o, make_double2(rv.x - a * (yv.x - wv.x), rv.y - a * (yv.y - wv.y)));
+    } else {
+      st2(xo, o, make_double2(rv.x + a * yv.x, rv.y + a * yv.y));
+    }
+  }
+}
+
+void launch_sc_cg_axpy_oop(int mode, const double* x, const double* y, const double* r, const double* w, double* xo, double* ro,
+                           const double* sc, int i_num, int i_den, double nvox, double small, long off, long count, hipStream_t s) {
+  const long n2 = count / 2;
+  if (n2 <= 0) return;
+  const int nb = grid_cap(n2, 1 << 14);
+  if (mode == 0) hipLaunchKernelGGL((k_sc_cg_axpy_oop<0>), dim3(nb), dim3(kBlock), 0, s, n2, off, x, y, r, w, xo, ro, sc, i_num, i_den, nvox, small);
+  else hipLaunchKernelGGL((k_sc_cg_axpy_oop<1>), dim3(nb), dim3(kBlock), 0, s, n2, off, x, y, r, w, xo, ro, sc, i_num, i_den, nvox, small);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
 void launch_sc_cg_axpy(int mode, const Grid& g, double* x, double* y, double* r, const double* w, double a, hipStream_t s,
                        long count) {
   const long n2 = (count > 0 ? count : g.n) / 2;

@@ -384,6 +384,20 @@ void Solver::slab_front_fast_cg(const double* E6, int i_num, int i_den, double n
   std::swap(cgs_p_, cgs_pa_);
 }
 
+void Solver::slab_front_fast_sc_cg(int i_num, int i_den, double nvox, double small) {
+  comm_wait(kXHaloU);
+  comm_wait(kXModuli);
+  comm_wait(kXSums);
+  Vec6 Z;
+  for (int c = 0; c < 6; ++c) Z.v[c] = 0.0;
+  time_begin(0);
+  launch_sc_sweep_cg(gu_, opt_.mu_0, cgs_p_, cgs_r_, cgs_pa_, smod_, fu_, Z, dscal_, i_num, i_den, nvox, small, partial_,
+                     dscal_ + kSlotSumSq, stream_);
+  launch_sc_cg_axpy_oop(1, cgs_p_, cgs_p_, cgs_r_, cgs_p_, cgs_pa_, cgs_pa_, dscal_, i_num, i_den, nvox, small, g_.n, ucs_ - g_.n, stream_);
+  time_end(0);
+  std::swap(cgs_p_, cgs_pa_);
+}
+
 // The transform chain of one pass, cut into steps that each end in one exchange (k = 1..9):
 //   1..3  component c = k-1: z r2c, y c2c into the all-to-all layout          | all-to-all(c) forward
 //   4     x c2c + Green operator + x c2c^-1 on the y-slab, three components   | all-to-all(0) back
@@ -1381,6 +1395,139 @@ bool SlabGroup::run_cg_scalar(const double* E0, double prev0) {
     const size_t f1 = (size_t)s->ucs_ * sizeof(double);
     FG_HIP_CHECK(hipMemcpyAsync(T_r(s), T_w(s), f1, hipMemcpyDeviceToDevice, s->stream_));
     FG_HIP_CHECK(hipMemcpyAsync(T_p(s), T_w(s), f1, hipMemcpyDeviceToDevice, s->stream_));   // p = r
+  }
+  // Fused form (option cg_fused; see Solver::run_cg_scalar and SlabGroup::run_cg): two tiled sweeps for the vector work, the
+  // direction update inside the operator's sweep, the CG scalars on the device (all-reduced there), the next operator
+  // application enqueued before the hosts wait for the sums.  Alternates: T_e in component 1 of its buffer (copied back to
+  // component 0 at the end), T_r / T_p in components 2, 3 of scg_.  Not with convergence callbacks (accessors read component 0).
+  static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
+  bool fused = (fused_env >= 0 ? fused_env : a.opt_.cg_fused) != 0 && !voting;
+  for (Solver* s : m_) fused = fused && sc_sweep_tiled(s->gu_);
+  if (fused) {
+    const int blk[2] = {kSlotCg, kSlotCg + 8}, s0 = kSlotCg + 16;
+    auto fetch7 = [&](int slot) {
+      for (Solver* s : m_) {
+        FG_HIP_CHECK(hipMemcpyAsync(s->hscal_ + kSlotCg, s->dscal_ + slot, 7 * sizeof(double), hipMemcpyDeviceToHost, s->comm_stream_));
+        FG_HIP_CHECK(hipMemcpyAsync(s->hscal_ + kSlotFlag, s->dscal_ + kSlotFlag, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                                    s->comm_stream_));
+        FG_HIP_CHECK(hipMemcpyAsync(s->herr_, s->derr_, sizeof(int), hipMemcpyDeviceToHost, s->comm_stream_));
+        FG_HIP_CHECK(hipEventRecord(s->ev_norm_, s->comm_stream_));
+      }
+    };
+    for (Solver* s : m_) {
+      s->cgs_r_ = s->scg_;
+      s->cgs_p_ = s->scg_ + s->ucs_;
+      s->cgs_ra_ = s->scg_ + 2 * s->ucs_;
+      s->cgs_pa_ = s->scg_ + 3 * s->ucs_;
+    }
+    std::vector<double*> e_cur(m_.size()), e_alt(m_.size());
+    for (size_t i = 0; i < m_.size(); ++i) e_cur[i] = T_e(m_[i]), e_alt[i] = T_e(m_[i]) + m_[i]->ucs_;
+    auto apply_dir = [&](int cur, int nxt) {
+      for (Solver* s : m_) {
+        s->comm_wait(kXSums);
+        s->slab_front_fast_sc_cg(blk[nxt] + 6, blk[cur] + 6, nglobal, small);
+      }
+      pass_fast_chain();
+    };
+    for (size_t i = 0; i < m_.size(); ++i) {
+      Solver* s = m_[i];
+      s->comm_wait(kXHaloU);
+      s->comm_wait(kXSums);
+      launch_sc_cg_dot(1, s->gu_, e_cur[i], s->cgs_r_, E, s->partial_, s->dscal_ + blk[0], s->stream_);
+      s->slab_reduce(blk[0], 7, false);   // gamma_0 = r.r / N + tiny
+    }
+    fetch7(blk[0]);
+    wait_norms();
+    double gamma_cur = a.hscal_[kSlotCg + 6] / nglobal + small;
+    const double gamma_0 = gamma_cur;
+    double prev = prev0;
+    long iter = 0;
+    bool failed = false, applied = false;
+    for (;;) {
+      const int cur = (int)(iter & 1), nxt = cur ^ 1;
+      if (!applied) {   // the first iteration: p = r
+        for (Solver* s : m_) s->slab_front_fast(Z.v, false, s->cgs_p_, false);
+        pass_fast_chain();
+      }
+      applied = false;
+      for (size_t i = 0; i < m_.size(); ++i) {
+        Solver* s = m_[i];
+        s->comm_wait(kXHaloU);
+        s->comm_wait(kXSums);
+        launch_sc_cgu_tile(0, s->gu_, s->cgs_p_, T_w(s), s->cgs_p_, T_w(s), e_alt[i], s->cgs_ra_, Z, s->dscal_, 0, 0, nglobal, small,
+                           s->partial_, s->dscal_ + s0, s->stream_);
+        s->slab_reduce(s0, 1, false);   // p . (p - w)
+      }
+      for (size_t i = 0; i < m_.size(); ++i) {
+        Solver* s = m_[i];
+        s->comm_wait(kXSums);
+        launch_sc_cgu_tile(1, s->gu_, e_cur[i], s->cgs_r_, s->cgs_p_, T_w(s), e_alt[i], s->cgs_ra_, E, s->dscal_, blk[cur] + 6, s0, nglobal,
+                           small, s->partial_, s->dscal_ + blk[nxt], s->stream_);
+        launch_sc_cg_axpy_oop(0, e_cur[i], s->cgs_p_, s->cgs_r_, T_w(s), e_alt[i], s->cgs_ra_, s->dscal_, blk[cur] + 6, s0, nglobal,
+                              small, s->g_.n, s->ucs_ - s->g_.n, s->stream_);
+        std::swap(e_cur[i], e_alt[i]);
+        std::swap(s->cgs_r_, s->cgs_ra_);
+        s->slab_reduce(blk[nxt], 7, false);   // norms of g ; r . r
+      }
+      fetch7(blk[nxt]);
+      if (iter < a.opt_.maxiter) {   // the next direction and operator application, enqueued behind the copies
+        apply_dir(cur, nxt);
+        applied = true;
+      }
+      wait_norms();
+      double s3 = 0.0;
+      for (int c = 0; c < 6; ++c) {
+        const double ss = c < 3 ? a.hscal_[kSlotCg + c] : 0.0;
+        for (Solver* s : m_) s->sumsq_[c] = ss;
+        s3 += ss / nglobal;
+      }
+      const double curn = std::sqrt(s3);
+      double abs_err = std::fabs(prev - curn);
+      double rel_err = abs_err / (small + curn);
+      prev = curn;
+      if (residual_est) {   // update_cg(gamma, gamma0)  F:14397-14401 with the gamma this iteration started from
+        abs_err = std::sqrt(gamma_cur);
+        rel_err = std::sqrt(gamma_cur / gamma_0);
+      }
+      gamma_cur = a.hscal_[kSlotCg + 6] / nglobal + small;
+      if (std::isnan(rel_err) || stop_requested()) {
+        failed = true;
+        break;
+      }
+      for (Solver* s : m_) s->residuals_.push_back(rel_err);
+      if (iter >= a.opt_.maxiter) break;
+      if (rel_err <= a.opt_.tol || abs_err <= a.opt_.abs_tol) {
+        // bc_error reads the gradient of the current iterate: component 0 of the state buffer must be it
+        for (size_t i = 0; i < m_.size(); ++i) {
+          Solver* s = m_[i];
+          if (e_cur[i] != T_e(s)) {
+            FG_HIP_CHECK(hipMemcpyAsync(T_e(s), e_cur[i], (size_t)s->ucs_ * sizeof(double), hipMemcpyDeviceToDevice, s->stream_));
+            std::swap(e_cur[i], e_alt[i]);
+          }
+          s->su_valid_ = true;
+          s->eps_stale_ = true;
+          for (int c = 0; c < 6; ++c) s->E_cur_[c] = E.v[c];
+        }
+        double S0[6] = {0, 0, 0, 0, 0, 0};
+        if (bc_error(E.v, S0) <= a.opt_.bc_tol) break;
+      }
+      iter++;
+    }
+    for (size_t i = 0; i < m_.size(); ++i) {
+      Solver* s = m_[i];
+      if (e_cur[i] != T_e(s))
+        FG_HIP_CHECK(hipMemcpyAsync(T_e(s), e_cur[i], (size_t)s->ucs_ * sizeof(double), hipMemcpyDeviceToDevice, s->stream_));
+      s->in_run_ = false;
+      s->iterations_ = iter;
+      s->su_valid_ = true;
+      s->eps_stale_ = true;
+      for (int c = 0; c < 6; ++c) s->E_cur_[c] = E.v[c];
+      s->slab_materialise_eps();
+    }
+    synchronize();
+    const double dt = now_seconds() - t_start;
+    for (Solver* s : m_) s->solve_time_ += dt;
+    return failed;
   }
   dot(1, false, false, kSlotCg, 7);
   double gamma = a.hscal_[kSlotCg + 6] / nglobal + small;

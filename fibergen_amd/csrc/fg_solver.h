@@ -233,6 +233,7 @@ class Solver {
   // the tiled sweep on the new search direction u_p = u_r + beta u_p (formed on the fly, own planes -> cgs_pa_, spare planes
   // point-wise), Voigt mixing; then cgs_p_ / cgs_pa_ are swapped
   void slab_front_fast_cg(const double* E6, int i_num, int i_den, double nvox, double small);
+  void slab_front_fast_sc_cg(int i_num, int i_den, double nvox, double small);   // the scalar modes' sibling (potential space)
   void slab_fetch_norms(int n);                          // D2H of the reduced sums (+ flag word), event for the host
   void comm_time_begin();
   void comm_time_end(int category);

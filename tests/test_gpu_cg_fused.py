@@ -110,3 +110,22 @@ def test_fused_cg_on_slabs_equals_unfused(P, mixing):
     assert np.abs(out[0][0] - out[1][0]).max() < 1e-12
     assert rel_err(out[1][1], out[0][1]) < 1e-11
     ref.close()
+
+
+@pytest.mark.parametrize("P,grid", [(1, (8, 16, 128)), (2, (8, 16, 128)), (4, (16, 16, 128))])
+def test_fused_scalar_cg_on_slabs_equals_unfused(P, grid):
+    """The scalar modes' CG on slabs with the fused sweeps against the host-scalar form."""
+    from test_gpu_slab import _scalar_group
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 12.0], [1 - phi1, phi1]
+    E = np.array([1.0, -0.5, 0.25])
+    out = []
+    for fused in (0, 1):
+        g = _scalar_group(P, grid, mus, phis, (1.0, 2.0, 1.5), tol=1e-10, method="cg", cg_fused=fused)
+        assert g.run(E) is False
+        out.append((g.iterations, np.array(g.residuals), g.get_field("epsilon"), g.mean_stress()))
+        g.close()
+    assert out[0][0] == out[1][0]
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-12
+    assert rel_err(out[1][2], out[0][2]) < 1e-10
+    assert rel_err(out[1][3], out[0][3]) < 1e-11
