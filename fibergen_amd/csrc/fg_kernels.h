@@ -166,6 +166,10 @@ void launch_copy(const double* src, double* dst, long ndoubles, hipStream_t s);
 void launch_lincomb(int n, const double* const* in, const double* w, double* out, long ndoubles, hipStream_t s);
 void launch_cg(int mode, const Grid& g, const FieldPtrs<6>& x, const FieldPtrs<6>& y, const FieldPtrs<6>& z, const Vec6& E,
                double a, double* partial, double* out6, hipStream_t s);
+// strain-space CG with the scalars on the device: mode 5: eps += a p, r -= a (p - w) in one sweep, out7 = sums of eps_c^2 and r:r;
+// mode 6: p = r + a p;  a = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small)
+void launch_cg_dev(int mode, const Grid& g, const FieldPtrs<6>& e, const FieldPtrs<6>& r, const FieldPtrs<6>& p, const FieldPtrs<6>& w,
+                   const double* sc, int i_num, int i_den, double nvox, double small, double* partial, double* out7, hipStream_t s);
 void launch_set_const6(const Grid& g, const FieldPtrs<6>& x, const Vec6& E, hipStream_t s);
 void launch_sum6(const Grid& g, const FieldPtrs<6>& x, bool square, double* partial, double* out6, hipStream_t s);
 void launch_sum1(const Grid& g, const double* x, double* partial, double* out1, hipStream_t s);

@@ -1747,6 +1747,68 @@ void launch_copy(const double* src, double* dst, long ndoubles, hipStream_t s) {
   FG_HIP_CHECK(hipGetLastError());
 }
 
+// Round 4: the same iteration with the CG scalars on the device (a = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small) from
+// the sums the sweeps leave there, as in k_cgu_axpy) and the two updates of an iteration in ONE sweep:
+//   MODE 5  eps <- eps + a p ;  r <- r - a (p - w)      per-component sums eps_c^2 (partial 0..5) and sum r:r (partial 6)
+//   MODE 6  p <- r + a p
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_cg_dev(Grid g, FieldPtrs<6> e, FieldPtrs<6> r, FieldPtrs<6> pp, FieldPtrs<6> w,
+                                                   const double* sc, int i_num, int i_den, double nvox, double small,
+                                                   double* partial) {
+  __shared__ double smem[4 * 7];
+  const double a = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small);
+  const long npairs = (long)g.nx * g.ny * g.nzc;
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (long pidx = (long)blockIdx.x * blockDim.x + threadIdx.x; pidx < npairs; pidx += (long)gridDim.x * blockDim.x) {
+    const PairPos p = pair_pos(pidx, g);
+    if (p.k >= g.nz) continue;
+    const bool second = p.k + 1 < g.nz;
+    double sx = 0.0, sy = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double2 pv = ld2(pp.p[c], p.off);
+      double2 rv = ld2(r.p[c], p.off);
+      if (MODE == 5) {
+        double2 ev = ld2(e.p[c], p.off);
+        const double2 wv = ld2(w.p[c], p.off);
+        ev.x = ev.x + a * pv.x;
+        ev.y = ev.y + a * pv.y;
+        rv.x = rv.x - a * (pv.x - wv.x);
+        rv.y = rv.y - a * (pv.y - wv.y);
+        st2(e.p[c], p.off, ev);
+        st2(r.p[c], p.off, rv);
+        acc[c] += ev.x * ev.x + (second ? ev.y * ev.y : 0.0);
+        const double wgt = c < 3 ? 1.0 : 2.0;
+        sx += wgt * (rv.x * rv.x);
+        sy += wgt * (rv.y * rv.y);
+      } else {
+        st2(pp.p[c], p.off, make_double2(rv.x + a * pv.x, rv.y + a * pv.y));
+      }
+    }
+    if (MODE == 5) acc[6] += sx + (second ? sy : 0.0);
+  }
+  if (MODE == 5) {
+    block_reduce<7>(acc, smem, OpSum());
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < 7; ++c) partial[(long)blockIdx.x * 7 + c] = acc[c];
+    }
+  }
+}
+
+void launch_cg_dev(int mode, const Grid& g, const FieldPtrs<6>& e, const FieldPtrs<6>& r, const FieldPtrs<6>& p, const FieldPtrs<6>& w,
+                   const double* sc, int i_num, int i_den, double nvox, double small, double* partial, double* out7, hipStream_t s) {
+  const int nb = reduce_blocks(g);
+  if (mode == 5) {
+    hipLaunchKernelGGL((k_cg_dev<5>), dim3(nb), dim3(kBlock), 0, s, g, e, r, p, w, sc, i_num, i_den, nvox, small, partial);
+    FG_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 7, 0.0, out7);
+  } else {
+    hipLaunchKernelGGL((k_cg_dev<6>), dim3(nb), dim3(kBlock), 0, s, g, e, r, p, w, sc, i_num, i_den, nvox, small, partial);
+  }
+  FG_HIP_CHECK(hipGetLastError());
+}
+
 void launch_cg(int mode, const Grid& g, const FieldPtrs<6>& x, const FieldPtrs<6>& y, const FieldPtrs<6>& z, const Vec6& E,
                double a, double* partial, double* out6, hipStream_t s) {
   const int nb = reduce_blocks(g);
