@@ -21,10 +21,10 @@
 //   B1 | barrier | B2 | barrier | c2r of the plane after next BESIDE the r2c of the finished lines | barrier
 // (the transforms are two thirds of a step's instructions: with the r2c behind the c2r's barrier, as first built, the waves
 // holding both roles ran them back to back while the others idled -- 18 k cycles per step, tools/uz_probe.hip)
-// LDS: two U images (3 NR line regions each: c2r scratch, then the natural-order real rows; planes q and q + 1 -- the
-//      stencil reads plane q and its y / z neighbours from LDS instead of carrying them in registers across the transforms) |
-//      tau exchange [3][NR][M] pairs | F image (3 TY line regions in the FFT's padded re / im layout, written by B2) |
-//      pass twiddles | edges | sums.
+// LDS (UzGeom): F image (3 TY line regions in the FFT's padded re / im layout, written by B2) | two U images (3 NR line
+//      regions each: c2r scratch, then the natural-order real rows; planes q and q + 1 -- the stencil reads plane q and its
+//      y / z neighbours from LDS instead of carrying them in registers across the transforms) | tau exchange [3][NR][M] pairs |
+//      pass twiddles | unit roots | edges | sums.
 #include "fg_kernels.h"
 
 #include <cstdlib>
@@ -40,8 +40,8 @@ namespace {
 
 using namespace fft;
 
-// tools/uz_probe.hip compiles this file with -DFG_PROBE_UZ: cycle stamps of three waves (first c2r-only wave, a wave with both
-// transform roles, the last wave) of sampled workgroups inside one marching step.  Empty in the library.
+// tools/uz_probe.hip compiles this file with -DFG_PROBE_UZ: cycle stamps of three waves (the first and a middle c2r wave, the
+// last = r2c wave) of sampled workgroups inside one marching step.  Empty in the library.
 #ifdef FG_PROBE_UZ
 constexpr int kUzProbeBlocks = 64, kUzProbeSlots = 16;
 __device__ unsigned long long g_uz_probe[kUzProbeBlocks][3][kUzProbeSlots];
