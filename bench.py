@@ -89,7 +89,7 @@ def timed_regions(iterate, sync, steps, warmup, repeats):
     return out
 
 
-def kernel_table(s, E, n, steps, scalar):
+def kernel_table(s, E, n, steps, scalar, stokes=False):
     """per-kernel durations, measured live with HIP events on the solver's stream -> {name: avg_ms, alg_GB, GBps}"""
     s.enable_stage_timing(True)
     s.iterate(E, steps)
@@ -121,6 +121,11 @@ def kernel_table(s, E, n, steps, scalar):
                 name, alg = "u_eps_stress_div_r2cz", (32 * n[2] + 48 * (n[2] // 2 + 1)) * n[0] * n[1]
         elif k == "stress" and times["div"] == 0:
             name, alg = "stress_div", 80 * N   # SURVEY 8d "S + div: 80"
+        if stokes and k == "eps_norm":
+            # viscosity: the slot is the Delta-operator tail k_eps_delta (F:20438-20452): strain from u, the polarisation
+            # re-evaluated from the old stress field and the two phase fractions, eta written, norms: 3 u + 6 old + 2 phi in,
+            # 6 out = 136 B per voxel (rounds 1-4 priced it as the elastic strain sweep, 72 B)
+            name, alg = "eps_delta_norm", (3 + 6 + 2 + 6) * 8 * N
         if k == "g0" and times["c2c_x_fwd"] == 0:
             name = "xfft_g0_xifft"             # x-FFT, Green operator, inverse x-FFT: 48 B/voxel
         if k == "r2c_z" and times["c2c_y_fwd"] == 0 and n[1] > 1:
@@ -134,7 +139,8 @@ def kernel_table(s, E, n, steps, scalar):
 # HIP-event slot name -> kernel names in the rocprofv3 counter summaries under profiles/
 PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"), "u_eps_stress_div_r2cz": ("k_u_fast_z",),
               "c2rz_u_eps_stress_div_r2cz": ("k_uz_tile",),
-              "stress_div": ("k_stress_div_voigt",), "xfft_g0_xifft": ("k_xfused",), "eps_norm": ("k_eps_norm",),
+              "stress_div": ("k_stress_div_voigt", "k_eps_tile"), "xfft_g0_xifft": ("k_xfused",), "eps_norm": ("k_eps_norm",),
+              "eps_delta_norm": ("k_eps_delta",),
               "stress": ("k_stress",), "div": ("k_div",), "g0": ("k_g0",), "r2c_z": ("k_zpass<fg::fft::R2CKernel",),
               "c2r_z": ("k_zpass<fg::fft::C2RKernel",), "c2c_y_fwd": ("k_strided<fg::fft::StridedKernel<*, -1>",),
               "c2c_y_inv": ("k_strided<fg::fft::StridedKernel<*, 1>",), "zy_plane_fwd": ("k_plane<fg::fft::ZYKernel",),
@@ -305,7 +311,7 @@ def measure_single(args, n_edge, mixing, mode, device, E, detail):
            "ms_per_step_min": 1e3 * min(dts) / args.steps, "ms_per_step_max": 1e3 * max(dts) / args.steps,
            "repeats": len(dts), "rve": {"K": par["K"], "R": float(par["R"]), "L": float(par["L"]), "vf": float(phi.mean()),
                                         "interface_voxel_fraction": float(((phi > 0) & (phi < 1)).mean())}}
-    kern, times, cnt = kernel_table(s, E, n, min(args.steps, 20), scalar)
+    kern, times, cnt = kernel_table(s, E, n, min(args.steps, 20), scalar, mode == "viscosity")
     dom = max(kern, key=lambda k: kern[k]["avg_ms"])
     res["dominant_kernel"] = {"kernel": dom, **kern[dom], "frac_of_hbm_peak": kern[dom]["GBps"] / HBM_PEAK_GBS}
     res["kernels"] = kern
@@ -353,11 +359,15 @@ def measure_single(args, n_edge, mixing, mode, device, E, detail):
                                  "host_MB_out": (eps_h.nbytes + sig_h.nbytes) / 1e6,
                                  "it_s_inclusive": s.iterations / (t3 - t0), "it_s_run_only": s.iterations / (t2 - t1)}
         del eps_h, sig_h
-        # the reference's default method (runCGElasticity F:23153-23247) on the same workload: reported beside the basic scheme in
-        # every detailed line (`value` is its rate only with --method cg)
-        med_cg, lo_cg, hi_cg = cg_rate(s, E, args.steps, 5 if args.method == "cg" else 3, s.synchronize)
-        res["cg"] = {"it_s": med_cg, "it_s_min": lo_cg, "it_s_max": hi_cg, "iterations_per_run": args.steps + 1}
     return s, res, phi, normals
+
+
+def cg_leg(args, s, E):
+    """the reference's default method (runCGElasticity F:23153-23247) on the same workload: reported beside the basic scheme in
+    every detailed line (`value` is its rate only with --method cg).  Run as the LAST measurement on the solver (it allocates the
+    CG vectors and rewrites method / tol / maxiter), right before the solver is closed."""
+    med_cg, lo_cg, hi_cg = cg_rate(s, E, args.steps, 5 if args.method == "cg" else 3, s.synchronize)
+    return {"it_s": med_cg, "it_s_min": lo_cg, "it_s_max": hi_cg, "iterations_per_run": args.steps + 1}
 
 
 def main():
@@ -478,18 +488,14 @@ def main():
             "kernel_sum_ms": res["kernel_sum_ms"], "hip_event_bias_ms_subtracted": res["hip_event_bias_ms_subtracted"],
             "kernels": kern, "rve": res["rve"],
         }
-        if args.method == "cg":
-            out.update({"value": res["cg"]["it_s"], "ms_per_step": 1e3 / res["cg"]["it_s"], "cg": res["cg"],
-                        "basic_scheme_it_s": it_s})
-        elif "cg" in res:
-            # the reference's default method on the same workload (one operator application + the fused vector sweeps per iteration)
-            out["cg_method"] = dict(res["cg"], unit="CG it/s", note="runCGElasticity through fg_run_load_case, maxiter = steps")
+        out["kernel_sum_note"] = ("sum of the per-kernel HIP-event brackets (event-pair bias subtracted): each bracket includes the "
+                                  "kernel's launch gap, so the sum may exceed ms_per_step by a few per cent")
         if not scalar and not stokes:
             # north_star names the Green-operator apply on its own (">= 50 % of the HBM roofline in the Gamma0-apply
             # kernel"): in the default pipeline it is fused into the x pass, so time the stand-alone kernel of the
             # one-kernel-per-routine pipeline as well (96 B per frequency)
             s.set_options(fuse_x=0)
-            k2, _, _ = kernel_table(s, E, n, 5, scalar)
+            k2, _, _ = kernel_table(s, E, n, 5, scalar, stokes)
             s.set_options(fuse_x=1)
             if "g0" in k2:
                 out["gamma0_apply_standalone"] = {"kernel": "k_g0 (fuse_x=0)", **k2["g0"],
@@ -506,6 +512,13 @@ def main():
                     out["hbm_stream"]["gamma0_apply_frac_of_measured"] = out["gamma0_apply_standalone"]["GBps"] / best
         except Exception as e:  # noqa: BLE001
             out["hbm_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        res["cg"] = cg_leg(args, s, E)   # last use of the solver
+        if args.method == "cg":
+            out.update({"value": res["cg"]["it_s"], "ms_per_step": 1e3 / res["cg"]["it_s"], "cg": res["cg"],
+                        "basic_scheme_it_s": it_s})
+        else:
+            # the reference's default method on the same workload (one operator application + the fused vector sweeps per iteration)
+            out["cg_method"] = dict(res["cg"], unit="CG it/s", note="runCGElasticity through fg_run_load_case, maxiter = steps")
         s.close()
         out["cache_stream"] = cache_stream(local_rank)
         if args.slab_members > 0 and not scalar and not stokes:
@@ -661,9 +674,11 @@ def main():
         if E_mode is not None:
             E = E_mode
         dts = timed_regions(lambda k: s.iterate(E, k), lambda: sync_all(s), args.steps, args.warmup, 3)
-        med = max_over_ranks(statistics.median(dts))
+        own = statistics.median(dts)
+        med = max_over_ranks(own)
         replicas = {"value": world * args.steps / med, "unit": "it/s", "ms_per_step": 1e3 * med / args.steps,
-                    "scaling": "weak", "parallelism": "one load case per GPU x%d, no collective" % world}
+                    "scaling": "weak", "parallelism": "one load case per GPU x%d, no collective" % world,
+                    "rank0_single_gpu_it_s": args.steps / own}
         s.close()
 
     line = {"metric": metric, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -681,10 +696,10 @@ def main():
     def watchdog():
         # a stalled exchange must not cost the whole line: report the replicas with the error, exit non-zero
         fb = dict(line)
-        fb.update({"value": replicas["value"] if replicas else None, "ms_per_step": replicas["ms_per_step"] if replicas else None,
-                   "scaling": "weak", "replicas": replicas,
+        fb.update({"value": None, "ms_per_step": None, "scaling": "strong", "replicas": replicas,
                    "slab": {"error": "slab-decomposed section exceeded %d s" % args.slab_timeout}})
-        fb["config"] = dict(line["config"], parallelism="load-case replicas (slab section stalled)")
+        fb["config"] = dict(line["config"], parallelism="x-slabs x%d (slab section stalled: no value; the load-case replicas "
+                                                        "are under `replicas`)" % world)
         emit(fb, 3)
     timer = threading.Timer(args.slab_timeout, watchdog)
     timer.daemon = True
@@ -703,7 +718,7 @@ def main():
         lo, hi = max_over_ranks(min(dts)), max_over_ranks(max(dts))
         it_s = args.steps / med
         local_n = (args.n // world, args.n, args.n)
-        kern, _, cnt = kernel_table(d, E, local_n, min(args.steps, 10), scalar)   # this rank's slab, HIP events
+        kern, _, cnt = kernel_table(d, E, local_n, min(args.steps, 10), scalar, stokes)   # this rank's slab, HIP events
         xt = exchange_times(d, cnt)
         dom = max(kern, key=lambda k: kern[k]["avg_ms"])
         line.update({
@@ -713,7 +728,12 @@ def main():
                          "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
                          "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]},
             "loop_GBps_Amin": ((24 + 7 * 16) if scalar else A_MIN_BYTES_PER_VOXEL) * N * it_s / 1e9,
-            "kernels": kern, "kernel_sum_ms": kernel_table.last_sum_ms, "replicas": replicas,
+            "kernels": kern, "kernel_sum_ms": kernel_table.last_sum_ms,
+            "kernel_sum_note": "rank 0's slab; sum of per-kernel HIP-event brackets (event-pair bias subtracted), exchanges excluded",
+            "replicas": replicas,
+            # the same problem on ONE GPU of this very node (rank 0's replica above): the line states its own speed-up
+            "single_gpu_it_s": replicas["rank0_single_gpu_it_s"] if replicas else None,
+            "speedup_over_single_gpu": it_s / replicas["rank0_single_gpu_it_s"] if replicas else None,
             "transport": d.transport, "rccl_ranks": world if d.transport == "rccl" else 0,
             "slab_split": split, "slab_split_trials": split_trials,
             "devices": devices, "distinct_devices": len({x.split(": ")[1] for x in devices}),
@@ -769,12 +789,29 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["also_slab"] = {args.also_slab: {"error": "%s: %s" % (type(e).__name__, e)}}
     except Exception as e:  # noqa: BLE001
-        line.update({"value": replicas["value"] if replicas else None, "ms_per_step": replicas["ms_per_step"] if replicas else None,
-                     "scaling": "weak", "replicas": replicas, "slab": {"error": "%s: %s" % (type(e).__name__, e)}})
-        line["config"]["parallelism"] = "load-case replicas (slab section failed)"
+        line.update({"value": None, "ms_per_step": None, "scaling": "strong", "replicas": replicas,
+                     "slab": {"error": "%s: %s" % (type(e).__name__, e)}})
+        line["config"]["parallelism"] = ("x-slabs x%d (slab section failed: no value; the load-case replicas are under "
+                                         "`replicas`)" % world)
         timer.cancel()
         emit(line, 4)
     timer.cancel()
+    if rank == 0 and not args.no_cpu_baseline and not scalar and not stokes:
+        # north_star's table for N > 1: the CPU path timed in this same run (rank 0, every solver closed; the other ranks wait
+        # at the barrier below) and it/s per grid beside it
+        try:
+            phi, normals, _ = bench_rve(args.n, args.mixing)
+            line["cpu_baseline"] = cpu_baseline(n, args.mixing, phi, normals, args.cpu_budget, ())
+            tab = {"%d^3 %s" % (args.n, args.mixing): {"gpus": world, "gpu_it_s": line.get("value"),
+                                                       "single_gpu_it_s": line.get("single_gpu_it_s"),
+                                                       "cpu_it_s": line["cpu_baseline"]["value"],
+                                                       "cpu_threads": line["cpu_baseline"]["cores"]}}
+            for k, v in (line.get("also_slab") or {}).items():
+                if "it_s" in v:
+                    tab[k] = {"gpus": world, "gpu_it_s": v["it_s"]}
+            line["per_grid"] = tab
+        except Exception as e:  # noqa: BLE001
+            line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(line), flush=True)
     try:

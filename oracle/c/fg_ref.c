@@ -368,6 +368,63 @@ void ref_component_norm(size_t N, const double* eps, double* m6) {
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------
+ * Vector routines of runCGElasticity  F:23153-23247 (the loop itself is driven from oracle/c_oracle.py: CRefCG), for
+ * fields of `dim` components (6: strain fields, 3: the gradient fields of the scalar modes). */
+
+/* innerProductL2  F:20871-20953 (a : (b - c), c != NULL) and F:20955-21038 (a : b): shear terms doubled for dim 6,
+ * static schedule over the rows, the sum divided by the number of voxels */
+double ref_inner_l2(int nx, int ny, int nz, int dim, const double* a, const double* b, const double* c) {
+  const size_t N = (size_t)nx * ny * nz;
+  double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static) collapse(2)
+  for (int ii = 0; ii < nx; ii++)
+    for (int jj = 0; jj < ny; jj++) {
+      size_t k = IDX(ii, jj, 0);
+      for (int kk = 0; kk < nz; kk++, k++) {
+        if (dim == 6) {
+          if (c)
+            s += a[k] * (b[k] - c[k]) + a[N + k] * (b[N + k] - c[N + k]) + a[2 * N + k] * (b[2 * N + k] - c[2 * N + k]) +
+                 2 * (a[3 * N + k] * (b[3 * N + k] - c[3 * N + k]) + a[4 * N + k] * (b[4 * N + k] - c[4 * N + k]) +
+                      a[5 * N + k] * (b[5 * N + k] - c[5 * N + k]));
+          else
+            s += a[k] * b[k] + a[N + k] * b[N + k] + a[2 * N + k] * b[2 * N + k] +
+                 2 * (a[3 * N + k] * b[3 * N + k] + a[4 * N + k] * b[4 * N + k] + a[5 * N + k] * b[5 * N + k]);
+        } else {
+          if (c) s += a[k] * (b[k] - c[k]) + a[N + k] * (b[N + k] - c[N + k]) + a[2 * N + k] * (b[2 * N + k] - c[2 * N + k]);
+          else s += a[k] * b[k] + a[N + k] * b[N + k] + a[2 * N + k] * b[2 * N + k];
+        }
+      }
+    }
+  return s / (double)N;
+}
+
+/* TensorField::xpay  F:9819-9838: t = x + a y  (t may alias x or y) */
+void ref_xpay(size_t n, const double* x, double a, const double* y, double* t) {
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; i++) t[i] = x[i] + a * y[i];
+}
+
+/* TensorField::xpaymz  F:9993-10010: t = x + a (y - z) */
+void ref_xpaymz(size_t n, const double* x, double a, const double* y, const double* z, double* t) {
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; i++) t[i] = x[i] + a * (y[i] - z[i]);
+}
+
+/* TensorField::adjustResidual  F:10012-10022: r[j] += E[j] - z[j] */
+void ref_adjust_residual(size_t N, int dim, const double* E, const double* z, double* r) {
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int j = 0; j < dim; j++)
+    for (size_t i = 0; i < N; i++) r[j * N + i] += E[j] - z[j * N + i];
+}
+
+/* TensorField::setConstant(vector)  F:10044-10056 */
+void ref_set_constant(size_t N, int dim, const double* E, double* t) {
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int j = 0; j < dim; j++)
+    for (size_t i = 0; i < N; i++) t[j * N + i] = E[j];
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
  * Scalar modes (mode = heat / porous, BASELINE config 5): 3-component gradient field g = E + grad T, one potential T.
  * Same conventions as above; the loop nests follow the reference's traversal orders. */
 

@@ -121,6 +121,60 @@ class CRef:
         return e
 
 
+class CRefCG(CRef):
+    """runCGElasticity  F:23153-23247 on the C loop nests (prescribed mean strain: calcBCMean returns E0, bc_error = 0):
+    krylovOperator F:20583-20587 = basicScheme with E = 0, innerProductL2 F:20871-21038, xpay F:9819-9838, xpaymz
+    F:9993-10010, adjustResidual F:10012-10022; error estimators: epsilon F:14591-14637, residual F:14382-14405.
+    The checker of the GPU's CG at BASELINE's sizes (tests/test_gpu_fullsize_oracle.py); itself held against
+    LSOracle._run_cg_step in tests/test_c_oracle.py."""
+
+    def inner_l2(self, a, b, c=None):
+        self.lib.ref_inner_l2.restype = ctypes.c_double
+        return float(self.lib.ref_inner_l2(self.nx, self.ny, self.nz, 6, _P(a), _P(b), _P(c) if c is not None else None))
+
+    def run_cg(self, E, mu_0, lambda_0, maxiter, tol=0.0, abs_tol=0.0, estimator="epsilon", start_norm=0.0):
+        """Returns (eps, residual history, iteration count as LSSolver::run reports it)."""
+        import math
+        lib, d, sz = self.lib, ctypes.c_double, ctypes.c_size_t
+        small = float(np.finfo(float).tiny)
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        Z = np.zeros(6)
+        shape = (6, self.nx, self.ny, self.nz)
+        n6 = 6 * self.N
+        eps = np.empty(shape)
+        lib.ref_set_constant(sz(self.N), 6, _P(E), _P(eps))            # epsilon.setConstant(E)  F:23183
+        r = self.basic_scheme(Z, eps, mu_0, lambda_0)                  # krylovOperator
+        lib.ref_adjust_residual(sz(self.N), 6, _P(E), _P(eps), _P(r))
+        gamma = self.inner_l2(r, r) + small
+        gamma0 = gamma
+        p = r.copy()
+        prev = start_norm      # EpsilonErrorEstimator's norm of the field the step started from (zero field: 0)
+        residuals, it = [], 0
+        while True:
+            w = self.basic_scheme(Z, p, mu_0, lambda_0)
+            alpha = self.inner_l2(p, p, w) + small
+            alpha = gamma / alpha
+            lib.ref_xpay(sz(n6), _P(eps), d(alpha), _P(p), _P(eps))
+            if estimator == "residual":
+                abs_err, rel_err = math.sqrt(gamma), math.sqrt(gamma / gamma0)
+            else:
+                m = self.component_norm(eps)
+                cur = math.sqrt(float((m * m).sum() + (m[3:] * m[3:]).sum()))
+                abs_err = abs(prev - cur)
+                rel_err = abs_err / (small + cur)
+                prev = cur
+            residuals.append(rel_err)
+            if it >= maxiter or rel_err <= tol or abs_err <= abs_tol:
+                break
+            it += 1
+            lib.ref_xpaymz(sz(n6), _P(r), d(-alpha), _P(p), _P(w), _P(r))
+            delta = self.inner_l2(r, r) + small
+            beta = delta / gamma
+            gamma = delta
+            lib.ref_xpay(sz(n6), _P(r), d(beta), _P(p), _P(p))
+        return eps, residuals, it
+
+
 class CRefScalar:
     """One pass of basicScheme in the scalar modes (heat / porous, BASELINE config 5): GammaOperatorStaggeredHeat
     F:20342-20351 with prescribed mean gradients -- polarisation, divOperatorStaggeredHeat, r2c + 1/N, the heat Green

@@ -246,6 +246,7 @@ class ScalarOracle:
         r = self.basic_scheme(Z, eps)
         r = r + (E0[:, None, None, None] - eps)
         gamma = self.inner_l2(r, r) + SMALLEST
+        gamma0 = gamma
         p = r.copy()
         it = 0
         while True:
@@ -254,10 +255,15 @@ class ScalarOracle:
             alpha = gamma / alpha
             eps = eps + alpha * p
             self.eps = eps
-            cur = float(np.linalg.norm(self.component_norm(eps)))
-            abs_err = abs(prev - cur)
-            rel_err = abs_err / (SMALLEST + cur)
-            prev = cur
+            if getattr(self, "error_estimator", "epsilon") == "residual":
+                # ResidualErrorEstimator::update_cg  F:14382-14405
+                abs_err = math.sqrt(gamma)
+                rel_err = math.sqrt(gamma / gamma0)
+            else:
+                cur = float(np.linalg.norm(self.component_norm(eps)))
+                abs_err = abs(prev - cur)
+                rel_err = abs_err / (SMALLEST + cur)
+                prev = cur
             if math.isnan(rel_err):
                 self.error = "NaN detected in solution. Aborting."
                 return True

@@ -74,3 +74,31 @@ def test_c_scalar_and_viscosity_passes_equal_numpy_oracles(grid, dims):
     E6 = np.array([1.0, -1.0, 0.0, 0.2, -0.1, 0.3])
     assert np.array_equal(cv.calc_stress(vo.mu_0, 0.0, eps), vo.calc_stress(vo.mu_0, vo.lambda_0, eps))
     assert rel_err(cv.basic_scheme(E6, eps, vo.mu_0), vo.basic_scheme(E6, eps)) < 1e-12
+
+
+@pytest.mark.parametrize("grid,dims", GRIDS[:3])
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+@pytest.mark.parametrize("estimator", ["epsilon", "residual"])
+def test_c_cg_equals_numpy_oracle_per_iteration(grid, dims, mixing, estimator):
+    """runCGElasticity on the C loop nests (CRefCG: the checker of the GPU's CG at 256^3 / 512^3) against LSOracle._run_cg_step,
+    iteration by iteration: the residual history after k iterations and the strain field of every k."""
+    from oracle.c_oracle import CRefCG
+    E = np.array([1.0, 0.0, 0.0, 0.0, 0.0, 0.5])
+    mats, phis, normals = two_phase_setup(grid, mixing)
+    c = CRefCG(grid, dims, mats, phis, normals, mixing, threads=2)
+    for k in range(4):
+        o = make_oracle(grid, dims, mixing, tol=0.0)
+        o.abs_tol = 0.0
+        o.maxiter = k
+        o.error_estimator = estimator
+        assert o.run_cg(E) is False
+        eps, res, it = c.run_cg(E, o.mu_0, o.lambda_0, maxiter=k, estimator=estimator)
+        assert it == o.iterations == k and len(res) == len(o.residuals) == k + 1
+        assert np.abs(np.array(res) - np.array(o.residuals)).max() < 1e-13
+        assert rel_err(eps, o.eps) < 1e-12
+    # a converged run stops at the same iteration
+    o = make_oracle(grid, dims, mixing, tol=1e-5)
+    o.error_estimator = estimator
+    assert o.run_cg(E) is False
+    eps, res, it = c.run_cg(E, o.mu_0, o.lambda_0, maxiter=o.maxiter, tol=1e-5, abs_tol=o.abs_tol, estimator=estimator)
+    assert it == o.iterations and rel_err(eps, o.eps) < 1e-11

@@ -64,10 +64,9 @@ def test_fused_scalar_cg_matches_oracle_and_unfused(grid, dims, estimator):
     phi1 = sphere_phi(grid, 0.3)
     mus, phis = [1.0, 50.0], [1 - phi1, phi1]
     E = np.array([1.0, -0.5, 0.25])
-    o = None
-    if estimator == "epsilon":   # (the scalar oracle restates the default estimator only; "residual": fused against unfused)
-        o = ScalarOracle(*grid, mus=mus, phis=phis, dx=dims[0], dy=dims[1], dz=dims[2], tol=1e-10)
-        assert o.run_cg(E) is False
+    o = ScalarOracle(*grid, mus=mus, phis=phis, dx=dims[0], dy=dims[1], dz=dims[2], tol=1e-10)
+    o.error_estimator = estimator   # "residual": ResidualErrorEstimator F:14382-14405
+    assert o.run_cg(E) is False
     res = []
     for fused in (0, 1):
         s = LSSolver(*grid, *dims)
@@ -77,11 +76,10 @@ def test_fused_scalar_cg_matches_oracle_and_unfused(grid, dims, estimator):
             s.set_phase(p, mus[p], 0.0, phis[p])
         s.set_options(tol=1e-10, method="cg", error_estimator=estimator, cg_fused=fused)
         assert s.run(E) is False
-        if o is not None:
-            assert s.iterations == o.iterations
-            np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-10)
-            assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8
-            assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-9
+        assert s.iterations == o.iterations
+        np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-10)
+        assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8
+        assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-9
         res.append((np.array(s.residuals), s.get_field("epsilon"), s.get_field("u")))
         s.close()
     assert res[0][0].shape == res[1][0].shape and np.abs(res[0][0] - res[1][0]).max() < 1e-12

@@ -198,3 +198,48 @@ def test_config5_viscosity_256_three_passes():
     for _ in range(3):
         eps = c.basic_scheme(E, eps, mu_0, lam_0)
     assert rel_err(got, eps) < 1e-11
+
+
+# ---- the conjugate gradients at the sizes bench.py times them (runCGElasticity F:23153-23247): `iters` CG iterations from the
+#      zero field through LSSolver::run (fg_run_load_case) against the same loop on the C loop nests (oracle/c_oracle.CRefCG,
+#      held against the NumPy oracle per iteration in tests/test_c_oracle.py); fused tiled sweeps (k_cgu_tile, k_u_tile<..CGP>)
+#      and the four-kernel form
+def _cg_against_cref(n, mixing, iters, fused_forms=(1, 0), estimator="epsilon"):
+    from oracle.c_oracle import CRefCG
+    import os
+    mats, phis, normals = _workload(n, mixing)
+    got = {}
+    for fused in fused_forms:
+        s = _gpu(n, mats, phis, normals, mixing, method="cg", tol=0.0, abs_tol=0.0, maxiter=iters, cg_fused=fused,
+                 error_estimator=estimator)
+        assert s.run(E_LOAD) is False
+        assert s.iterations == iters
+        got[fused] = (s.ref_material, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress().copy())
+        s.close()
+    (mu_0, lam_0) = got[fused_forms[0]][0]
+    c = CRefCG((n, n, n), DIMS, mats, phis, normals, mixing, threads=min(16, os.cpu_count() or 1))
+    eps, residuals, it = c.run_cg(E_LOAD, mu_0, lam_0, maxiter=iters, estimator=estimator)
+    assert it == iters
+    want_stress = c.mean_stress(eps)
+    for fused in fused_forms:
+        _, res, e, ms = got[fused]
+        assert res.shape == (iters + 1,)
+        assert np.abs(res - np.array(residuals)).max() < 1e-11
+        assert rel_err(e, eps) < 1e-10
+        assert rel_err(ms, want_stress) < 1e-10
+
+
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_cg_256_four_iterations_fused_and_unfused(mixing):
+    _cg_against_cref(256, mixing, 4)
+
+
+def test_cg_256_residual_estimator():
+    _cg_against_cref(256, "voigt", 3, fused_forms=(1,), estimator="residual")
+
+
+def test_cg_512_laminate_three_iterations():
+    psutil = pytest.importorskip("psutil")
+    if psutil.virtual_memory().available < 128 * 2 ** 30:
+        pytest.skip("needs ~100 GB of free host memory for the 512^3 CG checker")
+    _cg_against_cref(512, "laminate", 3, fused_forms=(1,))

@@ -344,6 +344,29 @@ def test_scalar_layered_medium_series_and_parallel_means():
     assert np.abs(K - np.diag(np.diag(K))).max() < 1e-12
 
 
+def test_scalar_cg_residual_estimator_on_layers():
+    """ResidualErrorEstimator F:14382-14405 in the scalar modes' CG (runCGElasticity F:23153-23247): the first entry of the
+    history is sqrt(gamma_0 / gamma_0) = 1, the history is sqrt(gamma_k / gamma_0) of the recurrence residual, and the run
+    converges to the layered medium's closed form like the default estimator's."""
+    from oracle.scalar_oracle import ScalarOracle
+    shape, mus, fr = (20, 4, 6), [1.0, 5.0, 0.5], [0.2, 0.3, 0.5]
+    harm = 1.0 / sum(f / m for f, m in zip(fr, mus))
+    E = np.array([1.0, 0.0, 0.0])
+    out = {}
+    for est in ("epsilon", "residual"):
+        o = ScalarOracle(*shape, mus=mus, phis=_layers_x(shape, fr), tol=1e-12, maxiter=500)
+        o.error_estimator = est
+        assert o.run_cg(E) is False
+        assert o.mean_stress()[0] == pytest.approx(harm, rel=1e-9)
+        out[est] = o
+    r = out["residual"].residuals
+    assert r[0] == 1.0 and r[-1] <= 1e-12 and all(b < 10 * a for a, b in zip(r, r[1:]))
+    # the residual of the final iterate, formed directly: r = E - eps - Gamma0 (C - C0) eps, within the recurrence's drift
+    o = out["residual"]
+    res = o.basic_scheme(np.zeros(3), o.eps) + (E[:, None, None, None] - o.eps)
+    assert math.sqrt(o.inner_l2(res, res)) < 1e-9
+
+
 def test_scalar_homogeneous_medium_and_operator_identity():
     from oracle.scalar_oracle import ScalarOracle
     shape = (6, 5, 4)

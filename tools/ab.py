@@ -41,10 +41,12 @@ def main():
             s.iterate(E, a.steps)
             s.synchronize()
             dts.append(time.perf_counter() - t0)
+        ms = [float(v) for v in s.mean_stress()]   # after 5 + 5 * steps passes: equal across variants that change no arithmetic
         kern, _, _ = kernel_table(s, E, n, 10, False)
         med = statistics.median(dts)
         print(json.dumps({"variant": variant, "it_s": a.steps / med, "ms_per_step": 1e3 * med / a.steps,
-                          "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items()}}), flush=True)
+                          "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items()},
+                          "mean_stress": ms, "env": {k: v for k, v in os.environ.items() if k.startswith("FG_")}}), flush=True)
         s.close()
 
 
