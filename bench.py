@@ -114,11 +114,6 @@ def kernel_table(s, E, n, steps, scalar, stokes=False):
         elif k == "stress" and times["div"] == 0 and times["eps_norm"] == 0:
             # displacement sweep: strain operator + polarisation + divergence + norms, 3 u + phi in, 3 f out
             name, alg = "u_eps_stress_div", 56 * N
-            if times["r2c_z"] == 0 and times["c2r_z"] == 0 and times["c2c_y_inv"] > 0:
-                # option z_sweep: c2r and r2c along z inside the sweep (half spectra of u in and of f out + phi: 56 B per voxel)
-                name, alg = "c2rz_u_eps_stress_div_r2cz", (48 * (n[2] // 2 + 1) + 8 * n[2]) * n[0] * n[1]
-            elif times["r2c_z"] == 0:
-                name, alg = "u_eps_stress_div_r2cz", (32 * n[2] + 48 * (n[2] // 2 + 1)) * n[0] * n[1]
         elif k == "stress" and times["div"] == 0:
             name, alg = "stress_div", 80 * N   # SURVEY 8d "S + div: 80"
         if stokes and k == "eps_norm":
@@ -137,8 +132,7 @@ def kernel_table(s, E, n, steps, scalar, stokes=False):
 
 
 # HIP-event slot name -> kernel names in the rocprofv3 counter summaries under profiles/
-PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"), "u_eps_stress_div_r2cz": ("k_u_fast_z",),
-              "c2rz_u_eps_stress_div_r2cz": ("k_uz_tile",),
+PMC_KERNEL = {"u_eps_stress_div": ("k_u_tile", "k_u_fast"),
               "stress_div": ("k_stress_div_voigt", "k_eps_tile"), "xfft_g0_xifft": ("k_xfused",), "eps_norm": ("k_eps_norm",),
               "eps_delta_norm": ("k_eps_delta",),
               "stress": ("k_stress",), "div": ("k_div",), "g0": ("k_g0",), "r2c_z": ("k_zpass<fg::fft::R2CKernel",),
@@ -299,10 +293,6 @@ def measure_single(args, n_edge, mixing, mode, device, E, detail):
     configure(s, phi, normals, mixing, mode)
     if args.u_tile is not None:
         s.set_options(u_tile=args.u_tile)
-    if args.fuse_z is not None:
-        s.set_options(fuse_z=args.fuse_z)
-    if getattr(args, "z_sweep", None) is not None:
-        s.set_options(z_sweep=args.z_sweep)
     s.calc_ref_material()
     scalar = mode in ("porous", "heat")
     dts = timed_regions(lambda k: s.iterate(E, k), s.synchronize, args.steps, args.warmup, args.repeats)
@@ -390,9 +380,6 @@ def main():
                     help="N = 1: further single-GPU workloads n:mixing[:mode] reported under `also` ('' = none): the other "
                          "BASELINE sizes and config 5 (porous / Stokes)")
     ap.add_argument("--u-tile", type=int, default=None, help="override the solver's u_tile option (0, 8, 12, 16)")
-    ap.add_argument("--fuse-z", type=int, default=None, help="override the solver's fuse_z option")
-    ap.add_argument("--z-sweep", type=int, default=None, help="override the solver's z_sweep option (1: the displacement sweep "
-                    "with both z transforms attached)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
     ap.add_argument("--slab-members", type=int, default=1,
@@ -445,7 +432,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE = %d: the launcher's rank count is used" % (args.gpus, world), file=sys.stderr)
-    default_options = args.u_tile is None and args.fuse_z is None and args.z_sweep is None and args.mode == "elasticity"
+    default_options = args.u_tile is None and args.mode == "elasticity"
     scalar = args.mode in ("porous", "heat")
     stokes = args.mode == "viscosity"
     n = (args.n,) * 3

@@ -253,8 +253,6 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
     else if (k == "slab_loopback") o.slab_loopback = value != 0;
     else if (k == "slab_split") o.slab_split = value < 0 ? -1 : (value != 0);
     else if (k == "slab_interleave") o.slab_interleave = value < 0 ? -1 : (value != 0);
-    else if (k == "fuse_z") o.fuse_z = value < 0 ? -1 : (value != 0);
-    else if (k == "z_sweep") o.z_sweep = value < 0 ? -1 : (value != 0);
     else if (k == "cg_fused") o.cg_fused = value < 0 ? -1 : (value != 0);
     else if (k == "x_layout") o.x_layout = value < 0 ? -1 : (value != 0);
     else if (k == "plane_fft") o.plane_fft = value < 0 ? -1 : (value != 0);
@@ -439,8 +437,7 @@ int fg_get_stage_timing_bias(const fg_solver* s, double* ms) {
 
 long fg_get_counter(const fg_solver* s, const char* name) {
   if (!s || !s->impl || !name) return -1;
-  if (std::string(name) == "zsweep_passes") return s->impl->zsweep_passes();
-  return -1;
+  return s->impl->counter(name);
 }
 
 int fg_get_comm_times(const fg_solver* s, double* ms) {

@@ -66,7 +66,6 @@ class Fft3 {
   const cplx* x_twiddles() const { return tw_[0]; }
   const cplx* z_twiddles() const { return tw_[2]; }  // pass twiddles of M = nz/2 (fast z path)
   const cplx* z_roots() const { return wz_; }        // e^{-2 pi i k/nz}, k = 0..nz/2
-  const cplx* z_twiddles4() const { return tw4_z_; } // pass twiddles of M = nz/2 in the four-points-per-thread schedule (Line4)
 
  private:
   void strided(double* data, int ncomp, long comp_stride, int axis, int dir, double scale);
@@ -77,7 +76,6 @@ class Fft3 {
   int stream_stores_ = 0;  // FFT passes use cache-bypassing stores (fields larger than the Infinity Cache)
   cplx* tw_[3];      // per-axis pass twiddles (fast path) ; z: for M = nz/2
   cplx* half_root_[2];  // e^{-i pi j/n}, j < n/8, of x and y (fused Green-operator pass)
-  cplx* tw4_z_ = nullptr;
   cplx* wz_;         // w^k = e^{-2 pi i k/nz}, k = 0..nz/2   (fast z path)
   cplx* wgen_[3];    // e^{-2 pi i k/n}, k = 0..n-1           (generic path)
   double* scratch_;  // one padded component (generic path)

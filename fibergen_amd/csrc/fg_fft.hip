@@ -178,8 +178,7 @@ __global__ void k_scale(double* x, long n, double s) {
 }
 
 int nt_loads_env() {
-  static const int v = getenv("FG_NT_LOADS") ? atoi(getenv("FG_NT_LOADS")) : 15;   // (c2r, bit 8: since it reads every coefficient once)
-  return v;
+  return 15;   // streaming loads in r2c, the strided passes, the fused x pass and the mirrored c2r (bits 1, 2, 4, 8)
 }
 
 bool fast_len(int n) { return is_pow2(n) && n >= 8 && n <= 1024; }
@@ -195,8 +194,6 @@ bool fast_len(int n) { return is_pow2(n) && n >= 8 && n <= 1024; }
 constexpr int kMaxOddFactor = 25;   // 25: the decimal sizes 200, 400, 800
 
 int mixed_factor(int n) {   // p if n = p * 2^k with 2^k a fast length, else 0
-  static const int off = getenv("FG_FFT_NO_MIXED") ? atoi(getenv("FG_FFT_NO_MIXED")) : 0;   // A/B knob: O(n^2) path
-  if (off) return 0;
   for (int p = 3; p <= kMaxOddFactor; p += 2)
     if (n % p == 0 && fast_len(n / p)) return p;
   return 0;
@@ -921,8 +918,7 @@ void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
   }
   a.tiles_per_outer = (a.ncols + C - 1) / C;
   const long nblocks = (long)a.tiles_per_outer * nouter;
-  static const int remap_env = getenv("FG_XFUSED_XCD") ? atoi(getenv("FG_XFUSED_XCD")) : 1;
-  a.xcd_order = remap_env;
+  a.xcd_order = 1;   // every XCD a contiguous run of tiles (512^3 1.84 -> 1.80 ms, 256^3 0.200 -> 0.188 ms)
   static cplx xq[8];
   static bool have_xq = false;
   if (!have_xq) {
@@ -975,9 +971,8 @@ void strided_pow2_narrow(int n, const StridedArgs& a, int nouter, int dir, int n
 void strided_pow2(int n, const StridedArgs& a, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
   // short lines use 16- to 256-column tiles (256 threads); when the columns do not fill the last tile of a row -- 128^3:
   // 72 columns = 4.5 tiles of 16 -- 8-column tiles waste nothing and balance better: y passes 0.028 -> 0.026 ms,
-  // 128^3 6 365 -> 6 590 it/s, 64^3 +2 % (FG_STRIDED_NARROW=0: the wide tiles)
-  static const int narrow_env = getenv("FG_STRIDED_NARROW") ? atoi(getenv("FG_STRIDED_NARROW")) : 1;
-  if (narrow_env && n <= 128 && a.ncols % (2048 / n > 8 ? 2048 / n : 8) != 0) return strided_pow2_narrow(n, a, nouter, dir, ncomp, cs, s);
+  // 128^3 6 365 -> 6 590 it/s, 64^3 +2 %
+  if (n <= 128 && a.ncols % (2048 / n > 8 ? 2048 / n : 8) != 0) return strided_pow2_narrow(n, a, nouter, dir, ncomp, cs, s);
   switch (n) {
     case 8: strided_n<8>(a, nouter, dir, ncomp, cs, s); break;
     case 16: strided_n<16>(a, nouter, dir, ncomp, cs, s); break;
@@ -1019,7 +1014,6 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
     }
   }
   if (fast_[2]) wz_ = upload(make_unit_roots(g.nz, g.nz / 2 + 1));
-  if (fast_[2] && is_pow2(g.nz / 2) && g.nz / 2 >= 16) tw4_z_ = upload(make_pass_twiddles4(g.nz / 2));
   if (need_scratch) FG_HIP_CHECK(hipMalloc(&scratch_, g.n * sizeof(double)));
   // three components larger than the 256 MB Infinity Cache: nothing a pass writes is still cached when the next reads it
   stream_stores_ = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
@@ -1032,7 +1026,6 @@ Fft3::~Fft3() {
     if (wgen_[a]) (void)hipFree(wgen_[a]);
   }
   if (wz_) (void)hipFree(wz_);
-  if (tw4_z_) (void)hipFree(tw4_z_);
   if (scratch_) (void)hipFree(scratch_);
 }
 
@@ -1348,9 +1341,8 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
   if (fast_[2]) {
     ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_ ? (1 | ((nt_loads_env() & 4) ? 2 : 0)) : 0};
     // the real split right after the last pass, mirrored values by wave shuffle instead of a round trip of the spectrum
-    // through LDS (R2CKernel<.., MIRROR>): 512^3 1.30 -> 1.16 ms, 256^3 0.158 -> 0.155 ms (FG_R2C_MIRROR=0: through LDS)
-    static const int mirror_env = getenv("FG_R2C_MIRROR") ? atoi(getenv("FG_R2C_MIRROR")) : 1;
-    if (mirror_env) {
+    // through LDS (R2CKernel<.., MIRROR>): 512^3 1.30 -> 1.16 ms, 256^3 0.158 -> 0.155 ms
+    {
       switch (g_.nz / 2) {
 #define FG_CASE(m) case m: launch_z<R2CKernel<m, ZLines<m>::value, true>>(a, ncomp, comp_stride, ZLines<m>::value, stream_); return;
         FG_CASE(64) FG_CASE(128) FG_CASE(256) FG_CASE(512)
@@ -1431,9 +1423,8 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
   if (fast_[2]) {
     ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_ ? (1 | ((nt_loads_env() & 8) ? 2 : 0)) : 0};
     // every coefficient read once: the mirrored one comes from the neighbouring lane (C2RKernel<.., MIRROR>); 256^3
-    // 0.164 -> 0.151 ms, 512^3 1.38 -> 1.19 ms (FG_C2R_MIRROR=0: two loads per point)
-    static const int mirror_env = getenv("FG_C2R_MIRROR") ? atoi(getenv("FG_C2R_MIRROR")) : 1;
-    if (mirror_env) {
+    // 0.164 -> 0.151 ms, 512^3 1.38 -> 1.19 ms
+    {
       switch (g_.nz / 2) {
 #define FG_CASE(m) case m: launch_z<C2RKernel<m, ZLines<m>::value, true>>(a, ncomp, comp_stride, ZLines<m>::value, stream_); return;
         FG_CASE(64) FG_CASE(128) FG_CASE(256) FG_CASE(512)

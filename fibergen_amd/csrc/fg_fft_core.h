@@ -192,105 +192,6 @@ struct Line {
   }
 };
 
-// ---------------------------------------------------------------- four points per thread
-// The same Stockham scheme with T = N/4 threads per line, radix 4 (+ one radix-2 pass when log2 N is odd): half the
-// registers of the 8-point form and twice the threads per line, at the price of one more exchange.  For kernels whose
-// threads carry other state beside the transform (fg_kernels_zsweep.hip).  Twiddles: make_pass_twiddles4.
-constexpr int num_passes4(int N) { return (ilog2(N) + 1) / 2; }
-constexpr int pass_radix4(int N, int p) { return (p < ilog2(N) / 2) ? 4 : 2; }
-constexpr int pass_ns4(int N, int p) { return p == 0 ? 1 : pass_ns4(N, p - 1) * pass_radix4(N, p - 1); }
-constexpr int tw_block4(int N, int p) { return (pass_radix4(N, p) - 1) * (N / pass_radix4(N, p)); }
-constexpr int tw_offset4(int N, int p) { return p <= 1 ? 0 : tw_offset4(N, p - 1) + tw_block4(N, p - 1); }
-constexpr int tw_total4(int N) {
-  return num_passes4(N) <= 1 ? 1 : tw_offset4(N, num_passes4(N) - 1) + tw_block4(N, num_passes4(N) - 1);
-}
-
-template <int N, int P>
-struct Pass4 {
-  static constexpr int R = pass_radix4(N, P);
-  static constexpr int NS = pass_ns4(N, P);
-  static constexpr int T = N / 4;
-  static constexpr int NB = 4 / R;
-  static constexpr int NBF = N / R;
-  FG_HD static int in_index(int jt, int b, int r) { return jt + b * T + r * NBF; }
-  FG_HD static int out_index(int jt, int b, int r) {
-    int j = jt + b * T;
-    return (j / NS) * NS * R + (j % NS) + r * NS;
-  }
-  template <int DIR>
-  FG_HD static void compute(cplx* v, int jt, const cplx* tw) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (NS > 1) {
-        int j = jt + b * T;
-#pragma unroll
-        for (int r = 1; r < R; ++r) {
-          cplx w = tw[(r - 1) * NBF + j];
-          if (DIR > 0) w = cconj(w);
-          v[b * R + r] = cmul(v[b * R + r], w);
-        }
-      }
-      dftR<R, DIR>(v + b * R);
-    }
-  }
-  // Exchanges in the contiguous-line layout (LdsMap::sm == 1: phys(m, c) = pad8(m) + c * sc).  The padded position of a
-  // slot is ONE run-time base per butterfly plus a compile-time offset: the r-th output of a butterfly sits r * NS points
-  // after the first, and pad8(m0 + r NS) - pad8(m0) is a constant for the NS that occur (1: m0 = 4 j, no carry into bit 3;
-  // 4: m0 % 8 < 4, the carry is r >> 1; >= 8: multiples of 8 pass through the padding); inputs are multiples of 8 apart.
-  // (With lds_put / lds_get per slot the compiler either rebuilds every padded index or parks dozens of them in registers.)
-  static constexpr int out_off(int r) { return NS >= 8 ? r * (NS + NS / 8) : (NS == 4 ? 4 * r + (r >> 1) : r * NS); }
-  static_assert(NS == 1 || NS == 4 || NS >= 8, "radix-4 schedule: Ns is a power of 4 (a last radix-2 pass scatters nothing)");
-  static_assert(T % 8 == 0 && NBF % 8 == 0, "line length >= 32");
-  FG_HD static void to_lds(const cplx* v, int jt, double* lds, const LdsMap& L, int c) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      double* const p = lds + c * L.sc + pad8(out_index(jt, b, 0));
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        p[out_off(r)] = v[b * R + r].re;
-        p[out_off(r) + L.im_off] = v[b * R + r].im;
-      }
-    }
-  }
-  FG_HD static void from_lds(cplx* v, int jt, const double* lds, const LdsMap& L, int c) {
-    const double* const p = lds + c * L.sc + pad8(jt);
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int off = (b * T + r * NBF) + (b * T + r * NBF) / 8;
-        v[b * R + r] = cmake(p[off], p[off + L.im_off]);
-      }
-  }
-};
-
-// phases as in Line<N>; after the last compute phase slot q = (b, r) of the last pass (radix RL) holds point
-// jt + (b + r * 4 / RL) * T
-template <int N>
-struct Line4 {
-  static constexpr int NP = num_passes4(N);
-  static constexpr int NPHASE = 2 * NP - 1;
-  static constexpr int T = N / 4;
-  template <int DIR, int PH>
-  FG_HD static void phase(cplx* v, int jt, double* lds, const LdsMap& L, int c, const cplx* tw) {
-    constexpr int P = (PH + 1) / 2;
-    if (PH % 2 == 1) {
-      Pass4<N, P>::from_lds(v, jt, lds, L, c);
-    } else {
-      Pass4<N, P>::template compute<DIR>(v, jt, tw + tw_offset4(N, P));
-      if (P + 1 < NP) Pass4<N, P>::to_lds(v, jt, lds, L, c);
-    }
-  }
-  FG_HD static int first_index(int jt, int q) {
-    constexpr int R = pass_radix4(N, 0);
-    return Pass4<N, 0>::in_index(jt, q / R, q % R);
-  }
-  FG_HD static int last_index(int jt, int q) {
-    constexpr int R = pass_radix4(N, NP - 1);
-    return Pass4<N, NP - 1>::out_index(jt, q / R, q % R);
-  }
-};
-
 // ---------------------------------------------------------------- r2c / c2r glue
 // Real line of length 2M packed as M complex z_m = x[2m] + i x[2m+1].
 // Forward split:  X[k] = (Z[k] + conj Z[M-k])/2 - i/2 * w^k (Z[k] - conj Z[M-k]),  w = e^{-2 pi i/(2M)}

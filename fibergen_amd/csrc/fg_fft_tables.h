@@ -44,28 +44,4 @@ inline std::vector<cplx> make_pass_twiddles(int N) {
   return tw;
 }
 
-// Pass twiddles of the four-points-per-thread schedule (Line4: radix 4, one last radix-2 pass for odd log2 N), same layout
-inline std::vector<cplx> make_pass_twiddles4(int N) {
-  using namespace fft;
-  std::vector<cplx> tw;
-  if (!is_pow2(N) || N < 4) return tw;
-  const long double two_pi = 6.283185307179586476925286766559005768L;
-  int np = num_passes4(N);
-  int ns = 1;
-  for (int p = 0; p < np; ++p) {
-    int R = pass_radix4(N, p);
-    if (p >= 1) {
-      int nbf = N / R;
-      for (int r = 1; r < R; ++r)
-        for (int j = 0; j < nbf; ++j) {
-          long double a = two_pi * (long double)(r * (j % ns)) / (long double)(ns * R);
-          tw.push_back(cmake((double)cosl(a), (double)-sinl(a)));
-        }
-    }
-    ns *= R;
-  }
-  if (tw.empty()) tw.push_back(cmake(1.0, 0.0));
-  return tw;
-}
-
 }  // namespace fg

@@ -70,8 +70,6 @@ void launch_effective_moduli(const Grid& g, const PhaseTable& pt, const FieldPtr
                              hipStream_t s);
 void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s);
-// the same sweep with the z transform attached (f is replaced by its half spectrum along z); tw_z / w_z are
-// the z-pass tables of the FFT plan (Fft3::z_twiddles, Fft3::z_roots)
 // tiled variant (every strain / polarisation value computed once; y neighbours through LDS, x by marching)
 bool u_tile_supported(const Grid& g);
 // the polarisation + divergence half of the tiled sweep for a stored strain field (same grids as u_tile_supported):
@@ -82,12 +80,6 @@ void launch_eps_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s, bool sum_tau = false,
                    const PhaseTable* two_phase = nullptr);
-// the tiled sweep with BOTH z transforms attached (fg_kernels_zsweep.hip): uhat = z half spectrum of u_k (what the inverse
-// y pass leaves), fhat = z half spectrum of f_{k+1} (what the forward y pass takes); tables as for launch_u_fast_z
-bool uz_tile_supported(const Grid& g);
-void launch_uz_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& uhat, const FieldPtrs<2>& mod,
-                    const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, hipStream_t s, bool sum_tau,
-                    const PhaseTable* two_phase, const cplx* tw_z, const cplx* w_z);
 // the tiled sweep on the NEW search direction of the conjugate gradients, formed on the fly: p_new = r + b p_old with
 // b = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small), stored to p_new (a buffer of its own), f = div((C - C0) : grad_s p_new)
 void launch_u_tile_cg(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& p_old, const FieldPtrs<3>& r,
@@ -95,10 +87,6 @@ void launch_u_tile_cg(const Grid& g, double mu_0, double lambda_0, const FieldPt
                       int i_num, int i_den, double nvox, double small, double* partial, double* sumsq6, hipStream_t s,
                       const PhaseTable* two_phase);
 void launch_complement_check(const Grid& g, const double* phi0, const double* phi1, int* flag, hipStream_t s);
-bool u_fast_z_supported(const Grid& g);
-void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
-                     const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, const cplx* tw_z,
-                     const cplx* w_z, hipStream_t s);
 // u_k -> sums of squares of eps_k and tau = (C - C0) : eps_k for any mixing rule (strain never stored)
 void launch_u_stress(const Grid& g, const StressParams& sp, const FieldPtrs<3>& u, const FieldPtrs<kMaxPhases>& phi,
                      const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, const Vec6& E, double* partial, double* sumsq6,

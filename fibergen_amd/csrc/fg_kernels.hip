@@ -811,32 +811,22 @@ constexpr int kCompactChunk = 16 * kBlock;
 // order.  An interface is a surface: in voxel order its voxels of one x plane are thousands of list entries away from their
 // x neighbours, in brick order a workgroup's 256 entries are a compact patch of the surface whose members share the rows
 // they gather from (the u gather of k_interface_strain fetched 9 separate 64-byte pieces per voxel: 580 B for 150 B of data)
-// and whose d values lie next to each other for k_delta_div.  FG_LAM_BRICK=0 restores voxel order (A/B runs).
+// and whose d values lie next to each other for k_delta_div (512^3: stage 2.40 -> 2.12 ms against voxel order).
 struct BrickWalk {
   int nbx, nby, nbz;
   long count;   // padded traversal length
-  int on;
 };
 inline BrickWalk brick_walk(const Grid& g) {
-  static const int env = getenv("FG_LAM_BRICK") ? atoi(getenv("FG_LAM_BRICK")) : 1;
   BrickWalk w;
-  w.on = env;
   w.nbx = (g.nx + 7) / 8;
   w.nby = (g.ny + 7) / 8;
   w.nbz = (g.nz + 7) / 8;
-  w.count = env ? (long)w.nbx * w.nby * w.nbz * 512 : (long)g.nx * g.ny * g.nz;
+  w.count = (long)w.nbx * w.nby * w.nbz * 512;
   return w;
 }
 // traversal position t -> voxel (i, j, k); false: a padding position of a partial brick (or past the end)
 __device__ __forceinline__ bool walk_voxel(const BrickWalk& w, const Grid& g, long t, int* i, int* j, int* k) {
   if (t >= w.count) return false;
-  if (!w.on) {
-    const long row = t / g.nz;
-    *k = (int)(t - row * g.nz);
-    *i = (int)(row / g.ny);
-    *j = (int)(row - (long)*i * g.ny);
-    return true;
-  }
   const long b = t >> 9;
   const int r = (int)(t & 511);
   const int bk = (int)(b % w.nbz);

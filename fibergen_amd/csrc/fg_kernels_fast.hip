@@ -8,7 +8,6 @@
 
 #include <cstdlib>
 
-#include "fg_fft_core.h"
 #include "fg_hip_util.h"
 #include "fg_kernels_common.h"
 
@@ -159,118 +158,6 @@ __global__ __launch_bounds__(kBlock) void k_u_fast(Grid g, double beta, double g
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) st2(fo.p[c], pp.off, make_double2(fout[0][c], p.second ? fout[1][c] : 0.0));
-    }
-  }
-  block_reduce<6>(acc, smem, OpSum());
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) partial[(long)blockIdx.x * 6 + c] = acc[c];
-  }
-}
-
-// The same sweep with the z transform of the divergence attached: a workgroup owns whole z rows (M = nz/2
-// pairs each), so the packed-real r2c of those rows (F:7232, see fg_fft_kernels.h R2CKernel) runs on the
-// freshly computed f in LDS and the half spectrum is what goes to memory -- f itself is never stored, which
-// removes the r2c pass (one read + one write of the three components per iteration).
-// LDS: two images of 3*LINES lines (re / im planes, padded as in fg_fft_core.h) used in turn by the stages:
-//   stencil -> image 0 | pass 0: image 0 -> 1 | pass 1: 1 -> 0 | ... | split: image NP%2 -> global
-template <int M>
-__global__ __launch_bounds__(kBlock) void k_u_fast_z(Grid g, double beta, double gamma, FieldPtrs<3> u, FieldPtrs<2> mod,
-                                                     FieldPtrs<3> fo, Vec6 E, double* partial, Sweep sw, const cplx* tw,
-                                                     const cplx* wz) {
-  using namespace fft;
-  constexpr int LINES = kBlock / M;  // z rows per workgroup
-  constexpr int T = M / 8;           // FFT threads per line
-  constexpr int NL = 3 * LINES;      // FFT lines per workgroup (3 components)
-  constexpr int LS = M + M / 8 + 2;  // line stride in doubles
-  constexpr int IMG = 2 * LS * NL;   // doubles per LDS image
-  constexpr int NP = num_passes(M);
-  __shared__ double lds[2 * IMG];
-  __shared__ double smem[4 * 6];
-  __shared__ long rowoff[LINES];
-  const LdsMap L = {1, LS, LS * NL};
-  const long nrows = (long)g.nx * g.ny;
-  const BlockRun run = block_run((nrows + LINES - 1) / LINES);
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  if (run.count > 0) {  // uniform per workgroup
-    const int l = threadIdx.x / M, m = threadIdx.x % M;
-    const long t_raw = run.first * LINES + l;
-    const bool valid = t_raw < nrows;
-    // row ordinal in the L2-aware order [y chunk][x][row in chunk] -> (i, j)
-    unsigned t = (unsigned)(valid ? t_raw : nrows - 1);
-    const int jr = (int)(t & (unsigned)(sw.ry - 1));
-    t >>= sw.ry_shift;
-    const unsigned jc = fast_div(t, sw.by_nx);
-    const int lane = threadIdx.x & 63;
-    UPos p;
-    p.i = (int)(t - jc * (unsigned)g.nx);
-    p.j = (int)jc * sw.ry + jr;
-    p.k = 2 * m;
-    p.ro = ((long)p.i * g.ny + p.j) * g.nzp;
-    p.second = true;
-    p.prev_ok = lane > 0 && m > 0;
-    p.next_ok = lane < 63 && m + 1 < M;
-    if (m == 0) rowoff[l] = valid ? p.ro : -1;
-    double fout[2][3], eout[2][6];
-    u_fast_pair<false>(g, beta, gamma, u, mod, E, p, fout, eout);
-    if (valid) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) acc[c] = eout[0][c] * eout[0][c] + eout[1][c] * eout[1][c];
-    }
-    // packed line point m of component c: z_m = f[2m] + i f[2m+1]
-#pragma unroll
-    for (int c = 0; c < 3; ++c) lds_put(lds, L, m, c * LINES + l, cmake(fout[0][c], fout[1][c]));
-    __syncthreads();
-
-    const bool fft_thread = threadIdx.x < NL * T;
-    const int line = threadIdx.x / T, jt = threadIdx.x % T;  // line = comp * LINES + row in workgroup
-    cplx v[8];
-    if (fft_thread) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = lds_get(lds, L, Line<M>::first_index(jt, q), line);
-      Pass<M, 0>::template compute<-1>(v, jt, tw + tw_offset(M, 0));
-      Pass<M, 0>::to_lds(v, jt, lds + IMG, L, line);
-    }
-    __syncthreads();
-    if (fft_thread) {
-      Pass<M, 1>::from_lds(v, jt, lds + IMG, L, line);
-      Pass<M, 1>::template compute<-1>(v, jt, tw + tw_offset(M, 1));
-      if (NP > 2) {
-        Pass<M, 1>::to_lds(v, jt, lds, L, line);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) lds_put(lds, L, Line<M>::last_index(jt, q), line, v[q]);
-      }
-    }
-    __syncthreads();
-    if (NP > 2) {
-      if (fft_thread) {
-        Pass<M, (NP > 2 ? 2 : 1)>::from_lds(v, jt, lds, L, line);
-        Pass<M, (NP > 2 ? 2 : 1)>::template compute<-1>(v, jt, tw + tw_offset(M, (NP > 2 ? 2 : 1)));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) lds_put(lds + IMG, L, Line<M>::last_index(jt, q), line, v[q]);
-      }
-      __syncthreads();
-    }
-    // natural-order spectrum of the packed line -> half spectrum of the real line (r2c_split)
-    const double* spec = lds + (NP % 2) * IMG;
-    if (fft_thread) {
-      const int comp = line / LINES;
-      const long off = rowoff[line % LINES];
-      if (off >= 0) {
-        cplx* out = reinterpret_cast<cplx*>(fo.p[comp] + off);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int kk = jt + q * T;
-          const cplx zk = lds_get(spec, L, kk, line);
-          const cplx zm = lds_get(spec, L, (M - kk) % M, line);
-          out[kk] = r2c_split(zk, zm, wz[kk]);
-        }
-        if (jt == 0) {  // k = M (Nyquist): Z[M] := Z[0]
-          const cplx z0 = lds_get(spec, L, 0, line);
-          out[M] = r2c_split(z0, z0, wz[M]);
-        }
-      }
     }
   }
   block_reduce<6>(acc, smem, OpSum());
@@ -1087,10 +974,7 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
                    const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s,
                    bool sum_tau, const PhaseTable* two_phase) {
-  // FG_TILE_GENERIC=1: tiles of 62 pairs with halo lanes also where a z row is one or two whole waves (8-wave workgroups,
-  // two per CU: a knob for thin slabs, where the whole-row tiles give only one 11-step march per CU)
-  static const int generic_env = getenv("FG_TILE_GENERIC") ? atoi(getenv("FG_TILE_GENERIC")) : 0;
-  const int nzh = generic_env ? 0 : g.nz / 2;
+  const int nzh = g.nz / 2;
   if (two_phase) {   // mod.p[0] is phi_1 of two complementary phases: the default tile shapes
     const PhaseLin lin = {2 * two_phase->mu[0] - 2 * mu_0, 2 * (two_phase->mu[1] - two_phase->mu[0]),
                           two_phase->lambda[0] - lambda_0, two_phase->lambda[1] - two_phase->lambda[0]};
@@ -1354,9 +1238,7 @@ void launch_sc_tile_t(const Grid& g, double mu_0, const double* T, const double*
   const int nzh = g.nz / 2;
   const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
   const int cus = device_cu_count();
-  static const int lx_env = getenv("FG_SC_TILE_LX") ? atoi(getenv("FG_SC_TILE_LX")) : 0;   // -1: the rule of round 1
-  int LX = lx_env > 0 ? lx_env : march_length(g.nx, (long)nty * ntz, 2 * cus);   // the light scalar sweep runs two workgroups per CU at full speed
-  if (lx_env < 0) LX = ((long)nty * ntz * ((g.nx + 31) / 32) < 2L * cus) ? 16 : 32;
+  int LX = march_length(g.nx, (long)nty * ntz, 2 * cus);   // the light scalar sweep runs two workgroups per CU at full speed
   if (LX > g.nx) LX = g.nx;
   const int ntx = (g.nx + LX - 1) / LX;
   int nb = nty * ntz * ntx;
@@ -1555,8 +1437,7 @@ void launch_sc_sweep_cg(const Grid& g, double mu_0, const double* p_old, const d
 }
 
 bool sc_sweep_tiled(const Grid& g) {
-  static const int tile_env = getenv("FG_SC_TILE") ? atoi(getenv("FG_SC_TILE")) : 1;
-  return tile_env && u_tile_supported(g);
+  return u_tile_supported(g);
 }
 
 bool launch_sc_sweep_fast(const Grid& g, double mu_0, const double* T, const double* a, double* f, const Vec6& E,
@@ -1654,34 +1535,6 @@ void launch_cgu_tile(int mode, const Grid& g, const FieldPtrs<3>& a, const Field
   else if (nzh == 128) FG_CGT(6, 2);
   else FG_CGT(8, 0);
 #undef FG_CGT
-}
-
-bool u_fast_z_supported(const Grid& g) {
-  const int M = g.nz / 2;
-  return g.nz % 2 == 0 && (M == 32 || M == 64 || M == 128 || M == 256) && g.nzc >= M + 1;
-}
-
-void launch_u_fast_z(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
-                     const FieldPtrs<3>& fhat, const Vec6& E, double* partial, double* sumsq6, const cplx* tw_z,
-                     const cplx* w_z, hipStream_t s) {
-  const int M = g.nz / 2;
-  const long nrows = (long)g.nx * g.ny;
-  const int lines = kBlock / M;
-  long nbl = (nrows + lines - 1) / lines;
-  if (nbl >= 8) nbl = ((nbl + 7) / 8) * 8;
-  const int nb = (int)nbl;
-  const Sweep sw = chunk_rows(g);
-  const double beta = -2 * mu_0, gamma = -lambda_0;
-  switch (M) {
-    case 32: hipLaunchKernelGGL(k_u_fast_z<32>, dim3(nb), dim3(kBlock), 0, s, g, beta, gamma, u, mod, fhat, E, partial, sw, tw_z, w_z); break;
-    case 64: hipLaunchKernelGGL(k_u_fast_z<64>, dim3(nb), dim3(kBlock), 0, s, g, beta, gamma, u, mod, fhat, E, partial, sw, tw_z, w_z); break;
-    case 128: hipLaunchKernelGGL(k_u_fast_z<128>, dim3(nb), dim3(kBlock), 0, s, g, beta, gamma, u, mod, fhat, E, partial, sw, tw_z, w_z); break;
-    case 256: hipLaunchKernelGGL(k_u_fast_z<256>, dim3(nb), dim3(kBlock), 0, s, g, beta, gamma, u, mod, fhat, E, partial, sw, tw_z, w_z); break;
-    default: throw std::runtime_error("launch_u_fast_z: unsupported nz");
-  }
-  FG_HIP_CHECK(hipGetLastError());
-  fold_sum(partial, nb, 6, sumsq6, s);
-  FG_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace fg

@@ -143,20 +143,17 @@ void Solver::comm_time_end(int category) {
 }
 
 // One slab has nothing to overlap; otherwise split when a component of the slab is >= 32 MB (512^3 on 8 GPUs: 135 MB,
-// 256^3 on 8: 17 MB).  Option slab_split / FG_SLAB_SPLIT = 0 / 1 override (tests, A/B runs).
+// 256^3 on 8: 17 MB).  Option slab_split = 0 / 1 overrides (tests, A/B runs).
 bool Solver::slab_split() const {
-  static const int env = getenv("FG_SLAB_SPLIT") ? atoi(getenv("FG_SLAB_SPLIT")) : -1;
-  if (env >= 0) return env != 0;
   if (opt_.slab_split >= 0) return opt_.slab_split != 0;
   return (nranks_ > 1 || slab_loopback()) && (double)g_.n * sizeof(double) >= 32.0 * 1024 * 1024;
 }
 
 // Batched exchanges (no split) with the three components of a peer in one message: needs the y pass that writes / reads the
-// blocked layout and the radix fused x pass (powers of two all round).  Option slab_interleave / FG_SLAB_INTERLEAVE = 0 keeps
+// blocked layout and the radix fused x pass (powers of two all round).  Option slab_interleave = 0 keeps
 // one message per peer and component.
 bool Solver::slab_interleave() const {
-  static const int env = getenv("FG_SLAB_INTERLEAVE") ? atoi(getenv("FG_SLAB_INTERLEAVE")) : -1;
-  if (env == 0 || opt_.slab_interleave == 0) return false;
+  if (opt_.slab_interleave == 0) return false;
   if (slab_split() || !(nranks_ > 1 || slab_loopback()) || opt_.mode != 0) return false;
   const int nxl = g_.nx;
   return fft_ && fft_ys_ && fft_->can_block_y(nranks_) && opt_.fuse_x && nxg_ > 1 && nxg_ <= 512 && fft_ys_->fast_x() &&
@@ -1153,8 +1150,7 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
   // Fused form (option cg_fused, as Solver::run_cg_u): p:(p - w) and the update of eps, r with their norms as two tiled sweeps
   // (the own planes of the alternate buffers; their spare planes by a point-wise kernel), the direction update inside the
   // operator's sweep (Voigt mixing).
-  static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
-  bool fused = (fused_env >= 0 ? fused_env : a.opt_.cg_fused) != 0;
+  bool fused = a.opt_.cg_fused != 0;
   // u_w = operator(u_in) with prescribed mean Eadd: sweep + transform chain; the halo planes of u_w are on their way
   auto apply = [&](bool from_p, const double* Eadd) {
     for (Solver* s : m_) s->slab_front_fast(Eadd, false, from_p ? u_p(s) : u_e(s), false);
@@ -1183,11 +1179,14 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
     s->cgs_r_ = s->scg_;
     s->cgs_p_ = s->scg_ + 3 * s->ucs_;
   }
-  if (fused) {
-    // every member (every rank) must take the same form: the decision is the logical AND over the group
-    double v[2] = {0.0, 0.0};
-    for (Solver* s : m_)
-      if (!s->slab_cg_alloc_fused()) v[0] = 1.0;
+  {
+    // every member (every rank) must take the same form: the decision is the logical AND over the group -- of the option
+    // as well as of the allocation (a rank whose cg_fused says 0 votes too: the vote is unconditional, so no rank can miss
+    // the all-reduce the others enter)
+    double v[2] = {fused ? 0.0 : 1.0, 0.0};
+    if (fused)
+      for (Solver* s : m_)
+        if (!s->slab_cg_alloc_fused()) v[0] = 1.0;
     if (a.nranks_ > 1) vote(v);
     fused = v[0] == 0.0;
   }
@@ -1400,9 +1399,13 @@ bool SlabGroup::run_cg_scalar(const double* E0, double prev0) {
   // direction update inside the operator's sweep, the CG scalars on the device (all-reduced there), the next operator
   // application enqueued before the hosts wait for the sums.  Alternates: T_e in component 1 of its buffer (copied back to
   // component 0 at the end), T_r / T_p in components 2, 3 of scg_.  Not with convergence callbacks (accessors read component 0).
-  static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
-  bool fused = (fused_env >= 0 ? fused_env : a.opt_.cg_fused) != 0 && !voting;
+  bool fused = a.opt_.cg_fused != 0 && !voting;
   for (Solver* s : m_) fused = fused && sc_sweep_tiled(s->gu_);
+  if (a.nranks_ > 1) {   // the two forms issue different reductions: every rank takes the form all of them can take
+    double v[2] = {fused ? 0.0 : 1.0, 0.0};
+    vote(v);
+    fused = v[0] == 0.0;
+  }
   if (fused) {
     const int blk[2] = {kSlotCg, kSlotCg + 8}, s0 = kSlotCg + 16;
     auto fetch7 = [&](int slot) {

@@ -77,9 +77,6 @@ struct SolverOptions {
   int x_layout = -1;            // x-contiguous intermediate layout [zc/8][y][x][8] between the y passes and the fused x pass
                                 // (the spectrum goes through tau_, free in the displacement loop): 1 on, 0 off, -1 by size
   int cg_fused = -1;            // displacement-space CG with fused vector sweeps (run_cg_u): -1 where the tiled sweep fits, 0 off, 1 on
-  int z_sweep = -1;             // displacement sweep with both z transforms attached (k_uz_tile; Voigt, one GPU): 1 on; 0 / -1 off (it ties the three kernels it replaces, see EXPERIMENTS.md)
-  int fuse_z = 0;               // attach the z r2c transform to the untiled fast sweep (u_tile = 0): 1 on, 0 off, -1 by size
-                                // (measured +3 % at 128^3, -1 % at 256^3, -5 % at 512^3 against the untiled sweep)
 };
 
 enum Stage {
@@ -179,7 +176,9 @@ class Solver {
   }
   void reset_stage_times();
   double event_bias_ms() const { return event_bias_ms_; }
-  long zsweep_passes() const { return zsweep_passes_; }   // passes taken by the z-attached sweep (fg_get_counter)
+  // fg_get_counter: "interface_voxels" / "affected_voxels" = lengths of the laminate correction's lists (0 before they are
+  // built), "fft_plan_reused" = 1 if this solver took its FFT tables from the per-device cache; -1 = unknown name
+  long counter(const std::string& name) const;
 
  private:
   // one pass  dst = E - Gamma0 : (C - C0) : src  (defaults: the solver's strain field, in place)
@@ -196,12 +195,11 @@ class Solver {
   void build_laminate_lists();          // interface / affected voxel lists of the laminate correction (once per geometry)
   void u_pass_front(const double* E6);  // u_k (fu_) -> sums of squares of eps_k, f_{k+1} (fu_alt_)
   void u_pass_back();                   // f_{k+1} -> u_{k+1}, buffers swapped
-  // r2c (unless z_done: buf already holds the z spectrum), y, x + Green operator + x^-1, y^-1, c2r on 3 components
+  // r2c, y, x + Green operator + x^-1, y^-1, c2r on 3 components
   // c12: optional {c10, c20} replacing the factors derived from (mu_0, lambda_0, alpha)
   // xscratch: three free components the spectrum may pass through in the x-contiguous layout (nullptr: in place, plain layout)
   bool plane_fft_on() const;
-  void fft_g0_chain(double* buf, bool z_done = false, double alpha = -1.0, const double* c12 = nullptr, double* xscratch = nullptr,
-                    bool skip_c2r = false);
+  void fft_g0_chain(double* buf, double alpha = -1.0, const double* c12 = nullptr, double* xscratch = nullptr);
   void ensure_eps();                    // materialise eps = E + sym grad u if the loop left it implicit
   void recompute_bc();
   double bc_error(const double* E_cur, const double* S_cur);
@@ -301,6 +299,7 @@ class Solver {
   double *cg_r_ = nullptr, *cg_p_ = nullptr, *cg_w_ = nullptr;  // CG residual, direction, operator image (6 each)
   double* fu_cg_ = nullptr;   // fused displacement-space CG: the alternate buffer of the iterate (3 components; swapped with fu_)
   unsigned* mixed_list_ = nullptr;  // element offsets of the interface voxels (laminate mixing, displacement loop)
+  bool plan_reused_ = false;        // the FFT tables came from the per-device cache (Fft3::acquire)
   unsigned mixed_n_ = 0;
   bool mixed_dirty_ = true;
   unsigned* aff_list_ = nullptr;    // voxels whose divergence stencil touches an interface voxel
@@ -338,13 +337,6 @@ class Solver {
   double sumsq_[6];
 
   bool u_valid_ = false;    // fu_ holds the displacement belonging to the current strain state
-  bool z_done_ = false;     // the last displacement sweep wrote the z spectrum of f (not f)
-  bool u_zspec_ = false;    // fu_ holds the z half spectrum of the displacement (state of the z-attached sweep), not u
-  bool z_skip_back_ = false;   // the pending transform chain stops before the c2r pass (its result feeds the z-attached sweep)
-  bool zsweep_ok_ = false;  // set by the basic-scheme loops: u_pass_front may run the z-attached sweep
-  long zsweep_passes_ = 0;
-  bool zsweep_on() const;
-  void ensure_u_real();     // fu_ back to real space (c2r along z) if it holds the z spectrum
   bool eps_stale_ = false;  // eps_ has not been written since fu_ changed
   bool in_run_ = false;
   bool fresh_step_ = true;   // the load step being run starts from the zeroed field (not from a previous step)

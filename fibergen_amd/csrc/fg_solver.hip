@@ -377,9 +377,8 @@ void Solver::fetch_norms_and_errors(const char* where) {
   static_assert(kSlotMean == kSlotSumSq + 6, "the displacement sweep writes norms and tau sums as one block of 12");
   const bool mixed_u = pending_back_ && !(frobenius(BC_MQ_) < kEps);
   const int nfetch = mixed_u ? 12 : 6;
-  static const int poll = getenv("FG_POLL") ? atoi(getenv("FG_POLL")) : 1;
   const int n2 = (mixed_u && opt_.mixing != kMixVoigt) ? 6 : 0;   // mixed BC + laminate: + sums of the interface differences
-  if (poll) {
+  {
     // one tiny kernel publishes sums + error flag + sequence number in pinned host memory; the host spins on the number
     const unsigned seq = ++publish_seq_;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, stream_, dscal_ + kSlotSumSq, nfetch, dscal_ + kSlotScratch, n2, derr_,
@@ -396,14 +395,6 @@ void Solver::fetch_norms_and_errors(const char* where) {
       __builtin_ia32_pause();
 #endif
     }
-  } else {
-    if (n2)
-      FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotScratch, dscal_ + kSlotScratch, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotSumSq, dscal_ + kSlotSumSq, nfetch * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    FG_HIP_CHECK(hipMemcpyAsync(herr_, derr_, sizeof(int), hipMemcpyDeviceToHost, stream_));
-    FG_HIP_CHECK(hipEventRecord(ev_copy_, stream_));
-    if (pending_back_) launch_pending_back();
-    FG_HIP_CHECK(hipEventSynchronize(ev_copy_));
   }
   if (*herr_ != 0) {
     FG_HIP_CHECK(hipMemsetAsync(derr_, 0, sizeof(int), stream_));
@@ -416,7 +407,7 @@ void Solver::fetch_norms_and_errors(const char* where) {
 // FFT / Green-operator chain of the displacement loop, enqueued without touching the host-side state: fu_alt_ then holds
 // u_{k+1}; adopt_back() makes it the current state.  If the iteration stops first, it is simply never adopted.
 void Solver::launch_pending_back() {
-  fft_g0_chain(fu_alt_, z_done_, -1.0, nullptr, opt_.mode == 0 ? tau_ : nullptr, z_skip_back_);   // tau_ is free in the displacement loop
+  fft_g0_chain(fu_alt_, -1.0, nullptr, opt_.mode == 0 ? tau_ : nullptr);   // tau_ is free in the displacement loop
   pending_back_ = false;
   back_ready_ = true;
 }
@@ -428,7 +419,6 @@ void Solver::adopt_back() {
   fu_ = fu_alt_;
   fu_alt_ = t;
   u_valid_ = true;
-  u_zspec_ = z_skip_back_;
   eps_stale_ = true;
   for (int c = 0; c < 6; ++c) E_cur_[c] = E_next_[c];
   if (timing_) times_.count++;
@@ -453,6 +443,13 @@ void Solver::enable_stage_timing(bool on) {
   }
   timing_ = on;
 }
+long Solver::counter(const std::string& name) const {
+  if (name == "interface_voxels") return (long)mixed_n_;
+  if (name == "affected_voxels") return (long)aff_n_;
+  if (name == "fft_plan_reused") return plan_reused_ ? 1 : 0;
+  return -1;
+}
+
 void Solver::reset_stage_times() {
   for (int i = 0; i < kNumTimedKernels; ++i) times_.ms[i] = 0.0;
   for (int i = 0; i < 4; ++i) comm_ms_[i] = 0.0;
@@ -536,7 +533,7 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     }
     const double mu_g = -1.0 / (4 * m);
     const double c12[2] = {-alpha / mu_g, -alpha / mu_g};
-    fft_g0_chain(fu_, false, alpha, c12);
+    fft_g0_chain(fu_, alpha, c12);
     // adj = E - 2 alpha m <tau>;  eta = adj + sym grad u;  eta.xpay(eta, 2 alpha m, tau_copy)  F:20438-20452, one sweep
     Vec6 Ev;
     for (int c = 0; c < 6; ++c) Ev.v[c] = E6[c];
@@ -638,7 +635,7 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     launch_div(g_, ptrs6(tau_), ptrs3(fu_), XHalo{{nullptr, nullptr}, {nullptr, nullptr}}, stream_);
     time_end(1);
   }
-  fft_g0_chain(fu_, false, -1.0, nullptr, tau_);   // the polarisation is dead once its divergence is taken
+  fft_g0_chain(fu_, -1.0, nullptr, tau_);   // the polarisation is dead once its divergence is taken
 
   // applyBCProjector  F:20247-20270: R = alpha*(bc_relax*MQ:F0 - (1-bc_relax)*M:(QC0:F00))
   Vec6 E, R;
@@ -666,12 +663,10 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
 // z and y transforms of a plane in one kernel (grids whose complex z-y plane fits the LDS): option plane_fft (-1 = where
 // available), FG_PLANE_FFT overrides for A/B runs
 bool Solver::plane_fft_on() const {
-  static const int env = getenv("FG_PLANE_FFT") ? atoi(getenv("FG_PLANE_FFT")) : -1;
-  const int v = env >= 0 ? env : opt_.plane_fft;
-  return v != 0 && nranks_ == 1 && fft_->can_plane();
+  return opt_.plane_fft != 0 && nranks_ == 1 && fft_->can_plane();
 }
 
-void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* c12, double* xscratch, bool skip_c2r) {  // alpha = -1: GammaOperator(..., -1)  F:20575
+void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* xscratch) {  // alpha = -1: GammaOperator(..., -1)  F:20575
   if (opt_.mode == 1) {
     // G0OperatorStaggeredHeat  F:20118-20135 on one component: fftVector(., 1), c1 = c10/|k|^2, fftInvVector
     const double scale = 1 / (double)nglobal_;
@@ -734,16 +729,13 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
   bool fuse_x = false, plane = false;
   // x-contiguous layout for the fused pass: on by size (fields beyond the Infinity Cache, where the fused pass's tile of nx
   // segments 2 MB apart is what bounds it) unless the option says otherwise; FG_X_LAYOUT overrides for A/B runs
-  static const int xl_env = getenv("FG_X_LAYOUT") ? atoi(getenv("FG_X_LAYOUT")) : -1;
-  const int xl_opt = xl_env >= 0 ? xl_env : opt_.x_layout;
+  const int xl_opt = opt_.x_layout;
   const bool xl = xscratch && opt_.fuse_x && fft_->can_fuse(0) && fft_->can_xlayout() && g_.nx > 1 && g_.ny > 1 &&
                   (xl_opt > 0 || (xl_opt < 0 && 3.0 * (double)g_.n * sizeof(double) > 1024.0 * 1024 * 1024));
   if (xl) {
-    if (!z_done) {
-      time_begin(2);
-      fft_->r2c_z(buf, 3, g_.n);
-      time_end(2);
-    }
+    time_begin(2);
+    fft_->r2c_z(buf, 3, g_.n);
+    time_end(2);
     time_begin(3);
     fft_->c2c_y_xlayout(buf, g_.n, xscratch, g_.n, 3, -1, 1.0);
     time_end(3);
@@ -759,7 +751,6 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     time_begin(7);
     fft_->c2c_y_xlayout(xscratch, g_.n, buf, g_.n, 3, +1, 1.0);
     time_end(7);
-    if (skip_c2r) return;   // the z-attached sweep takes the z half spectrum
     time_begin(8);
     fft_->c2r_z(buf, 3, g_.n);
     time_end(8);
@@ -769,17 +760,15 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
     // fftVector  F:18481-18510: r2c in z, c2c in y, c2c in x; the 1/N of F:18501-18506 rides on the last pass
     const double scale = 1 / (double)nglobal_;
     const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
-    plane = plane_fft_on() && !z_done && has_x;
+    plane = plane_fft_on() && has_x;
     if (plane) {   // small grids: z and y transforms of a plane in one kernel
       time_begin(2);
       fft_->zy_plane(buf, 3, g_.n, -1);
       time_end(2);
     } else {
-      if (!z_done) {  // the displacement sweep may already have written the z spectrum
-        time_begin(2);
-        fft_->r2c_z(buf, 3, g_.n);
-        time_end(2);
-      }
+      time_begin(2);
+      fft_->r2c_z(buf, 3, g_.n);
+      time_end(2);
       time_begin(3);
       fft_->c2c_y(buf, 3, g_.n, -1, (has_x || !has_y) ? 1.0 : scale);
       time_end(3);
@@ -827,7 +816,6 @@ void Solver::fft_g0_chain(double* buf, bool z_done, double alpha, const double* 
   time_begin(7);
   fft_->c2c_y(buf, 3, g_.n, +1, 1.0);
   time_end(7);
-  if (skip_c2r) return;   // the z-attached sweep takes the z half spectrum
   time_begin(8);
   fft_->c2r_z(buf, 3, g_.n);
   time_end(8);
@@ -948,13 +936,8 @@ void Solver::u_pass_front(const double* E6) {
     E.v[c] = E_cur_[c];
     E_next_[c] = E6[c];
   }
-  if (!(zsweep_ok_ && zsweep_on() && opt_.mode == 0 && opt_.mixing == kMixVoigt && opt_.u_loop >= 2)) {
-    ensure_u_real();
-    z_skip_back_ = false;
-  }
   time_begin(0);
   if (opt_.mode == 1) {
-    z_done_ = false;
     if (opt_.u_loop >= 2) {
       // fast variant: effective conductivity a = sum_p phi_p mu_p precomputed (first moduli array)
       const bool mixed = !(frobenius(BC_MQ_) < kEps) && in_run_;
@@ -966,7 +949,6 @@ void Solver::u_pass_front(const double* E6) {
     }
   } else if (opt_.mixing != kMixVoigt && opt_.u_loop < 2) {
     // laminate mixing, exact order: strain + polarisation from u in one sweep (tau stored), divergence as its own sweep
-    z_done_ = false;
     FieldPtrs<3> nrm;
     for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
     launch_u_stress(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, nrm, ptrs6(tau_), E, partial_,
@@ -994,35 +976,7 @@ void Solver::u_pass_front(const double* E6) {
         FG_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
       }
     }
-    const bool want_z = !laminate && (opt_.fuse_z > 0 || (opt_.fuse_z < 0 && (long)g_.nx * g_.ny * g_.nz <= (1L << 22)));
-    z_done_ = want_z && fft_->fast_z() && u_fast_z_supported(g_);
-    z_skip_back_ = false;
-    if (!laminate && zsweep_ok_ && zsweep_on()) {
-      // the sweep with both z transforms attached: state = z half spectrum of u_k, output = z half spectrum of f_{k+1};
-      // the transform chain then starts at the y pass and stops before the c2r pass
-      if (!u_zspec_) {   // entering the loop with u in real space: one r2c pass (unnormalised, hence the 1/nz)
-        fft_->r2c_z(fu_, 3, g_.n);
-        fft_->scale(fu_, 3, g_.n, 1.0 / (double)g_.nz);
-        u_zspec_ = true;
-      }
-      z_done_ = true;
-      z_skip_back_ = true;
-      ++zsweep_passes_;
-      const bool sum_tau = !(frobenius(BC_MQ_) < kEps);
-      if (two_phase_complementary()) {
-        FieldPtrs<2> ph;
-        ph.p[0] = phi_ + g_.n;
-        ph.p[1] = nullptr;
-        const PhaseTable t = phase_table();
-        launch_uz_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), ph, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, stream_,
-                       sum_tau, &t, fft_->z_twiddles4(), fft_->z_roots());
-      } else {
-        launch_uz_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_,
-                       dscal_ + kSlotSumSq, stream_, sum_tau, nullptr, fft_->z_twiddles4(), fft_->z_roots());
-      }
-    } else if (opt_.u_tile && u_tile_supported(g_)) {
-      ensure_u_real();
-      z_done_ = false;
+    if (opt_.u_tile && u_tile_supported(g_)) {
       const bool sum_tau = !(frobenius(BC_MQ_) < kEps);   // mixed BC: sums of tau land in kSlotMean
       if (two_phase_complementary()) {
         // two phases with phi_0 = 1 - phi_1: the sweep reads phi_1 and forms the moduli itself (8 B per voxel less)
@@ -1036,10 +990,7 @@ void Solver::u_pass_front(const double* E6) {
         launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_,
                       dscal_ + kSlotSumSq, opt_.u_tile, stream_, sum_tau);
       }
-    } else if (z_done_)
-      launch_u_fast_z(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
-                      fft_->z_twiddles(), fft_->z_roots(), stream_);
-    else
+    } else   // grids the tiles do not fit (odd nz, short rows): the untiled sweep
       launch_u_fast(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
                     stream_);
     if (laminate) {
@@ -1061,7 +1012,6 @@ void Solver::u_pass_front(const double* E6) {
         launch_sum_dtau(dtau_, mixed_n_, partial_, dscal_ + kSlotScratch, stream_);
     }
   } else {
-    z_done_ = false;
     launch_u_stress_div_voigt(g_, stress_params(opt_.mu_0, opt_.lambda_0, 1.0), ptrs3(fu_), phi, ptrs3(fu_alt_), E,
                               partial_, dscal_ + kSlotSumSq, stream_);
   }
@@ -1075,24 +1025,7 @@ void Solver::u_pass_back() {
   adopt_back();
 }
 
-// The z-attached sweep (fg_kernels_zsweep.hip) keeps the displacement as its z half spectrum between passes; everything else
-// reads u in real space.
-bool Solver::zsweep_on() const {
-  static const int env = getenv("FG_Z_SWEEP") ? atoi(getenv("FG_Z_SWEEP")) : -1;
-  const int v = env >= 0 ? env : opt_.z_sweep;
-  if (v == 0 || nranks_ != 1 || slab_layout_ || opt_.mode != 0 || !opt_.u_tile) return false;
-  if (!(fft_->fast_z() && fft_->z_twiddles4() && uz_tile_supported(g_))) return false;
-  return v > 0;   // opt-in: at 256^3 the attached transforms are LDS-bound and the sweep only ties the three kernels it replaces (EXPERIMENTS.md, round 4)
-}
-
-void Solver::ensure_u_real() {
-  if (!u_zspec_) return;
-  fft_->c2r_z(fu_, 3, g_.n);
-  u_zspec_ = false;
-}
-
 void Solver::ensure_eps() {
-  ensure_u_real();
   if (slab_layout_ && su_valid_ && eps_stale_) {   // slab driver: the state is su_[cur] with its halo planes
     slab_materialise_eps();
     return;
@@ -1126,17 +1059,10 @@ void Solver::iterate(const double* E6, int n) {
       basic_scheme(E6);  // leaves u in fu_ and eps in eps_
       ++i;
     }
-    zsweep_ok_ = true;
-    try {
-      for (; i < n; ++i) {
-        u_pass_front(E6);
-        u_pass_back();
-      }
-    } catch (...) {
-      zsweep_ok_ = false;
-      throw;
+    for (; i < n; ++i) {
+      u_pass_front(E6);
+      u_pass_back();
     }
-    zsweep_ok_ = false;
     return;
   }
   for (; i < n; ++i) basic_scheme(E6);
@@ -1369,11 +1295,6 @@ bool Solver::run_one_step(const double* E0, const double* S0) {
     for (int i = 0; i < 6; ++i) E_cur_[i] = E0[i];
   }
   in_run_ = true;
-  struct ZGuard {   // the z-attached sweep is the basic scheme's: CG and the accessors read u in real space
-    bool& flag;
-    explicit ZGuard(bool& f) : flag(f) { flag = true; }
-    ~ZGuard() { flag = false; }
-  } zguard(zsweep_ok_);
 
   double prev = prev0;
   long iter = 1;
@@ -1510,8 +1431,7 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
   // norms of the new eps and r:r (mode 1) -- and the direction update p = r + beta p is formed inside the operator's
   // displacement sweep (launch_u_tile_cg).  Updates are out of place (the tiles' halo rows re-evaluate them), so u_e, u_r and
   // u_p alternate between two buffers each; fu_ stays the current iterate.
-  static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
-  const int fused_opt = fused_env >= 0 ? fused_env : opt_.cg_fused;
+  const int fused_opt = opt_.cg_fused;
   bool fused = fused_opt != 0 && opt_.u_tile && u_tile_supported(g_) && !slab_layout_;
   if (fused && (!cg_p_ || !fu_cg_)) {
     // nine more components (the alternates of u_e, u_r, u_p): on grids that fill the card (1024^3: 78 GB) the four-kernel form
@@ -1542,7 +1462,7 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
     for (int c = 0; c < 6; ++c) E_cur_[c] = Eadd[c];
     u_pass_front(Eadd);   // sweeps fu_ (with E_cur_) into fu_alt_; its norm sums are not used here
     fu_ = keep;
-    fft_g0_chain(fu_alt_, z_done_, -1.0, nullptr, tau_);
+    fft_g0_chain(fu_alt_, -1.0, nullptr, tau_);
   };
   // fused form: u_p := u_r + beta u_p (beta from the sums at dscal_[i_num] / dscal_[i_den]) inside the sweep of the operator
   auto apply_dir = [&](int i_num, int i_den) {
@@ -1559,8 +1479,7 @@ bool Solver::run_cg_u(const double* E0, double prev0) {
     launch_u_tile_cg(g_, opt_.mu_0, opt_.lambda_0, ptrs3(u_p), ptrs3(u_r), ptrs3(p_alt), m, ptrs3(fu_alt_), Z, dscal_, i_num, i_den,
                      (double)nglobal_, std::numeric_limits<double>::min(), partial_, dscal_ + kSlotSumSq, stream_, two ? &t : nullptr);
     time_end(0);
-    z_done_ = false;
-    fft_g0_chain(fu_alt_, false, -1.0, nullptr, tau_);
+    fft_g0_chain(fu_alt_, -1.0, nullptr, tau_);
     std::swap(u_p, p_alt);
   };
   int beta_num = 0, beta_den = 0;   // fused form: slots of the pending direction update
@@ -1705,7 +1624,7 @@ bool Solver::run_cg_scalar(const double* E0, double prev0) {
     for (int c = 0; c < 6; ++c) E_cur_[c] = Eadd[c];
     u_pass_front(Eadd);
     fu_ = keep;
-    fft_g0_chain(fu_alt_, false);
+    fft_g0_chain(fu_alt_);
   };
   FG_HIP_CHECK(hipMemsetAsync(fu_, 0, f1, stream_));
   apply(fu_, E.v);
@@ -1715,8 +1634,7 @@ bool Solver::run_cg_scalar(const double* E0, double prev0) {
   // the direction update inside the operator's sweep, the CG scalars on the device, the next operator application enqueued
   // before the host waits for the sums.  Out of place: T_e, T_r, T_p alternate between two components each (the spare
   // components of fu_ and cg_r_).  Not with a convergence callback (accessors read fu_'s first component in between).
-  static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
-  const int fused_opt = fused_env >= 0 ? fused_env : opt_.cg_fused;
+  const int fused_opt = opt_.cg_fused;
   if (fused_opt != 0 && !cb_ && opt_.u_loop >= 2 && sc_sweep_tiled(g_) && !slab_layout_) {
     const int blk[2] = {kSlotCg, kSlotCg + 8}, s0 = kSlotCg + 16;
     const double nvox = (double)nglobal_;
@@ -1727,7 +1645,7 @@ bool Solver::run_cg_scalar(const double* E0, double prev0) {
       launch_sc_sweep_cg(g_, opt_.mu_0, p_cur, r_cur, p_alt, cond, fu_alt_, Z, dscal_, i_num, i_den, nvox, small, partial_,
                          dscal_ + kSlotSumSq, stream_);
       time_end(0);
-      fft_g0_chain(fu_alt_, false);
+      fft_g0_chain(fu_alt_);
       std::swap(p_cur, p_alt);
     };
     launch_sc_cg_dot(1, g_, e_cur, r_cur, E, partial_, dscal_ + blk[0], stream_);   // gamma_0 = r.r / N + tiny
@@ -1908,8 +1826,7 @@ bool Solver::run_cg(const double* E0, const double* S0, double prev0) {
   // Round 4 (option cg_fused): the CG scalars on the device, the updates of eps and r as ONE sweep with their norms, the next
   // direction and operator application enqueued before the host waits for the seven sums of the stop rule -- one host
   // synchronisation per iteration instead of three, 528 instead of 576 bytes per voxel of vector work.
-  static const int fused_env = getenv("FG_CG_FUSED") ? atoi(getenv("FG_CG_FUSED")) : -1;
-  if ((fused_env >= 0 ? fused_env : opt_.cg_fused) != 0) {
+  if (opt_.cg_fused != 0) {
     const int blk[2] = {kSlotCg, kSlotCg + 8}, s0 = kSlotCg + 16;
     const double nvox = (double)nglobal_;
     FG_HIP_CHECK(hipMemcpyAsync(dscal_ + blk[0] + 6, dscal_ + kSlotMean, sizeof(double), hipMemcpyDeviceToDevice, stream_));   // gamma_0
@@ -2150,7 +2067,7 @@ void Solver::get_field(const std::string& name, double* out) {
     launch_sc_div(g_, ptrs3(eps_), 2 * opt_.mu_0, tb, stream_);    // calcStressConst + divOperatorStaggeredHeat
     const bool timing = timing_;
     timing_ = false;
-    fft_g0_chain(tb, false, 1.0);
+    fft_g0_chain(tb, 1.0);
     timing_ = timing;
     download_unpadded(tb, out);
     return;
@@ -2178,7 +2095,7 @@ void Solver::get_field(const std::string& name, double* out) {
     const double c12[2] = {-a / mu_g, -a / mu_g};
     const bool timing = timing_;
     timing_ = false;
-    fft_g0_chain(fu_, false, a, c12);
+    fft_g0_chain(fu_, a, c12);
     timing_ = timing;
     for (int c = 0; c < 3; ++c) download_unpadded(fu_ + (long)c * g_.n, out + (long)c * g_.nxyz);
     return;

@@ -213,27 +213,36 @@ class GlobalViewSolver(DistributedLSSolver):
 
     # Largest global field get_field will assemble on every rank (bytes); FG_GATHER_LIMIT_GB overrides.  Beyond it the
     # caller should read the slabs (DistributedLSSolver.get_field with local shapes) instead of P copies of everything.
-    GATHER_LIMIT = int(float(__import__("os").environ.get("FG_GATHER_LIMIT_GB", "16")) * 2 ** 30)
+    GATHER_LIMIT_GB = 16.0      # default of FG_GATHER_LIMIT_GB (read at every call)
+    GATHER_CHUNK = 256 * 2 ** 20   # bytes of a rank's slab per all_gather: the staging buffers stay at (P + 1) x this
 
     def _gather(self, local):
-        """The slabs of all ranks, concatenated along x, on every rank: one all_gather of a float64 tensor (on the device
-        for an nccl group, on the host for gloo) -- no pickling, no per-object staging."""
+        """The slabs of all ranks, concatenated along x, on every rank: all_gathers of float64 pieces of at most GATHER_CHUNK
+        bytes per rank (on this solver's device for an nccl group -- (P + 1) x 256 MB of staging whatever the field's size,
+        so a card the solver has filled still serves get_field --, on the host for gloo); no pickling.  The piece count
+        follows from the slab's size alone, so every rank issues the same sequence."""
         if self.nranks == 1:
             return local
+        import os
+        limit = int(float(os.environ.get("FG_GATHER_LIMIT_GB", self.GATHER_LIMIT_GB)) * 2 ** 30)
         total = local.nbytes * self.nranks
-        if total > self.GATHER_LIMIT:
+        if total > limit:
             raise RuntimeError("get_field: the global field is %.1f GB (limit %.1f GB, FG_GATHER_LIMIT_GB): read the slabs "
-                               "rank by rank instead of gathering it on every rank" % (total / 2 ** 30, self.GATHER_LIMIT / 2 ** 30))
+                               "rank by rank instead of gathering it on every rank" % (total / 2 ** 30, limit / 2 ** 30))
         import torch
         dist = self._dist
-        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+        flat = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64)).reshape(-1)
         on_device = dist.get_backend(self.group) == "nccl"
-        if on_device:
-            t = t.cuda()
-        out = torch.empty(self.nranks * t.numel(), dtype=t.dtype, device=t.device)   # flat: the form gloo and nccl both take
-        dist.all_gather_into_tensor(out, t.reshape(-1), group=self.group)
-        parts = (out.cpu() if on_device else out).numpy().reshape((self.nranks,) + tuple(local.shape))
-        return np.concatenate(list(parts), axis=1)
+        dev = torch.device("cuda", int(self.device)) if on_device else torch.device("cpu")
+        n = flat.numel()
+        step = max(1, self.GATHER_CHUNK // 8)
+        parts = np.empty((self.nranks, n))
+        for lo in range(0, n, step):
+            piece = flat[lo:lo + step].to(dev)
+            out = torch.empty(self.nranks * piece.numel(), dtype=piece.dtype, device=dev)   # flat: the form gloo and nccl both take
+            dist.all_gather_into_tensor(out, piece, group=self.group)
+            parts[:, lo:lo + piece.numel()] = out.cpu().numpy().reshape(self.nranks, -1)
+        return np.concatenate(list(parts.reshape((self.nranks,) + tuple(local.shape))), axis=1)
 
     def get_field(self, name):
         nc = self._lib.fg_field_components(self._h, name.encode())

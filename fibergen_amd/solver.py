@@ -101,7 +101,7 @@ class LSSolver:
                 if v not in ("epsilon", "residual"):
                     raise RuntimeError("error estimator '%s' is not available (epsilon, residual)" % v)
                 self._check(self._lib.fg_set_option_i(self._h, b"error_estimator", 1 if v == "residual" else 0))
-            elif k in ("u_loop", "fuse_x", "fuse_z", "z_sweep", "cg_fused", "fuse_stress_div", "u_tile", "x_layout", "plane_fft", "slab_split", "slab_interleave", "slab_loopback", "laminate_overlap", "phi_sweep"):
+            elif k in ("u_loop", "fuse_x", "cg_fused", "fuse_stress_div", "u_tile", "x_layout", "plane_fft", "slab_split", "slab_interleave", "slab_loopback", "laminate_overlap", "phi_sweep"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
             elif k in ("maxiter", "loadstep_extrapolation_order"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
@@ -168,7 +168,7 @@ class LSSolver:
         return bool(failed.value)
 
     def counter(self, name):
-        """fg_get_counter: e.g. "zsweep_passes" (passes taken by the sweep with both z transforms attached)."""
+        """fg_get_counter: "interface_voxels", "affected_voxels" (laminate lists), "fft_plan_reused"; -1 = unknown name."""
         return int(self._lib.fg_get_counter(self._h, name.encode()))
 
     def iterate(self, E, n):

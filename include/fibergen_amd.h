@@ -82,13 +82,12 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * displacement, fast kernels; 1 = the same with the reference's operation order, iterates bit-identical to 0; 0 = the
  * strain field is the state, one kernel per reference routine where fuse_* are 0 too),
  * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (rows per workgroup of
- * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled), fuse_z (untiled sweep with the z transform attached),
- * z_sweep (1 = on; default off: the tiled sweep with BOTH z transforms attached -- the state between passes is the z half
- * spectrum of u, the c2r and r2c passes disappear; Voigt mixing, nz = 128 or 256, one GPU; measured equal to the three
- * kernels it replaces, kept as an option),
+ * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled),
  * cg_fused (-1 = default: where the tiled sweep fits; 0 / 1: method = cg in displacement / potential space with the vector
  * work of an iteration as two tiled sweeps and the direction update inside the operator's sweep -- out of place, nine more
- * components; falls back to the four-kernel form when they do not fit),
+ * components; falls back to the four-kernel form when they do not fit; in the scalar modes (potential space) a registered
+ * convergence callback also selects the four-kernel form, whose accessors see the iterate in place -- its residual history
+ * equals the fused one's to rounding (different summation order), tests/test_gpu_cg_fused.py),
  * phi_sweep (1 = default: with two phases whose fractions are complementary bit for bit the tiled sweep reads phi_1 and
  * forms the effective moduli itself; 0 = always the two precomputed moduli arrays), laminate_overlap (1 = default: the interface kernels of the laminate correction run on a second stream beside the
  * displacement sweep; 0 = one stream), slab_split (slab driver: 1 = one all-to-all per component, overlapping the transforms of the next component; 0 = one
@@ -172,9 +171,9 @@ int fg_get_stage_times(const fg_solver* s, double* ms /* [FG_NUM_TIMED_KERNELS] 
 /* What a pair of HIP events reads with nothing between them on this solver's stream (measured when timing is switched
  * on, milliseconds); it has been subtracted from every figure fg_get_stage_times reports. */
 int fg_get_stage_timing_bias(const fg_solver* s, double* ms);
-/* Which form of the loop ran (no counterpart in the reference; tests and bench.py name the kernels they measured):
- * "zsweep_passes" = passes taken by the displacement sweep with both z transforms attached (option z_sweep) since the
- * solver was created.  Unknown names give -1. */
+/* Sizes and set-up facts of this solver (no counterpart in the reference; bench.py prices the laminate correction with them):
+ * "interface_voxels" / "affected_voxels" = lengths of the laminate correction's voxel lists (0 until a laminate pass built
+ * them), "fft_plan_reused" = 1 if the solver took its FFT tables from the per-device cache.  Unknown names give -1. */
 long fg_get_counter(const fg_solver* s, const char* name);
 
 /* Measurement helper (no counterpart in the reference): achieved HBM bandwidth of a streaming copy a = b and of the

@@ -151,7 +151,6 @@ def main():
                          "loop-back interface instead of refusing the duplicate device")
     a = ap.parse_args()
     if a.transport == "rccl":
-        import os
         os.environ["NCCL_HOSTID"] = "fibergen-test-rank-%s" % os.environ.get("RANK", "0")
         os.environ["NCCL_SOCKET_IFNAME"] = "lo"
         os.environ["NCCL_IB_DISABLE"] = "1"
@@ -164,6 +163,26 @@ def main():
     dims = tuple(float(v) for v in a.dims.split(","))
     if a.backend == "plan":
         run_plan(a, dist, rank, P, grid)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if a.backend == "gather":
+        # GlobalViewSolver._gather (the all-gather behind get_field) on a stand-in object: pieces of 1 KB per rank, so the
+        # field below travels in several all_gathers whose last one is ragged
+        from types import SimpleNamespace
+        from fibergen_amd.distributed import GlobalViewSolver
+        me = SimpleNamespace(nranks=P, group=None, _dist=dist, device=0, GATHER_LIMIT_GB=16.0, GATHER_CHUNK=1024)
+        local = (1000.0 * rank + np.arange(6 * 3 * 5 * 7, dtype=np.float64)).reshape(6, 3, 5, 7)
+        got = GlobalViewSolver._gather(me, local)
+        want = np.concatenate([(1000.0 * r + np.arange(6 * 3 * 5 * 7, dtype=np.float64)).reshape(6, 3, 5, 7) for r in range(P)], axis=1)
+        errors = [] if got.shape == want.shape and np.array_equal(got, want) else ["gathered field differs"]
+        os.environ["FG_GATHER_LIMIT_GB"] = "1e-9"   # read at call time
+        try:
+            GlobalViewSolver._gather(me, local)
+            errors.append("limit not enforced")
+        except RuntimeError:
+            pass
+        np.savez(a.out + ".%d.npz" % rank, errors=np.array(errors))
         dist.barrier()
         dist.destroy_process_group()
         return

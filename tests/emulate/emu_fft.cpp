@@ -69,43 +69,7 @@ static void strided_dir(StridedArgs a, long nblocks, int dir) {
   else run_blocks<StridedKernel<N, C, +1>, StridedArgs>(nblocks, a);
 }
 
-// one line of N points with four points per thread (Line4): T = N / 4 "threads", phases in turn
-template <int N>
-static void line4_run(cplx* x, int dir, const cplx* tw) {
-  constexpr int T = N / 4, LS = N + N / 8 + 2;
-  std::vector<double> lds(2 * LS, NAN);
-  const LdsMap L = {1, 2 * LS, LS};
-  std::vector<cplx> regs(4 * T);
-  for (int jt = 0; jt < T; ++jt)
-    for (int q = 0; q < 4; ++q) regs[4 * jt + q] = x[Line4<N>::first_index(jt, q)];
-  auto phases = [&](auto self, auto ph) -> void {
-    constexpr int PH = decltype(ph)::value;
-    for (int jt = 0; jt < T; ++jt) {
-      if (dir < 0) Line4<N>::template phase<-1, PH>(&regs[4 * jt], jt, lds.data(), L, 0, tw);
-      else Line4<N>::template phase<+1, PH>(&regs[4 * jt], jt, lds.data(), L, 0, tw);
-    }
-    if constexpr (PH + 1 < Line4<N>::NPHASE) self(self, std::integral_constant<int, PH + 1>{});
-  };
-  phases(phases, std::integral_constant<int, 0>{});
-  for (int jt = 0; jt < T; ++jt)
-    for (int q = 0; q < 4; ++q) x[Line4<N>::last_index(jt, q)] = regs[4 * jt + q];
-}
-
 extern "C" {
-
-// c2c of `nlines` contiguous lines of N points with the four-points-per-thread schedule (fg_fft_core.h Line4)
-int emu_line4(int N, int dir, double* data, int nlines) {
-  std::vector<cplx> tw = make_pass_twiddles4(N);
-  cplx* x = reinterpret_cast<cplx*>(data);
-#define CASE(n)                                                        \
-  if (N == n) {                                                        \
-    for (int l = 0; l < nlines; ++l) line4_run<n>(x + (long)l * n, dir, tw.data()); \
-    return 0;                                                          \
-  }
-  CASE(32) CASE(64) CASE(128) CASE(256) CASE(512)
-#undef CASE
-  return 1;
-}
 
 // c2c along a strided axis of data[nouter][N][ncols] (ls = ncols, os = N*ncols), device tile geometry
 int emu_strided(int N, int dir, double* data, int ncols, int nouter, double scale) {

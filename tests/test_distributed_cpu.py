@@ -30,6 +30,15 @@ def test_exchange_plan_over_gloo(tmp_path, nproc, grid):
         assert list(r["errors"]) == []
 
 
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_get_field_gather_in_pieces_over_gloo(tmp_path, nproc):
+    """GlobalViewSolver._gather: the slabs travel in bounded pieces (ragged last piece), every rank ends with the global
+    field, FG_GATHER_LIMIT_GB is read at call time."""
+    res = launch(nproc, str(tmp_path / "g"), "--backend", "gather")
+    for r in res:
+        assert list(r["errors"]) == []
+
+
 def test_plan_is_consistent_across_ranks():
     """Every send has exactly one matching receive of the same size on the peer, in the same per-pair order."""
     from fibergen_amd.distributed import slab_plan

@@ -37,18 +37,6 @@ def test_strided_c2c(emu, N, d):
     assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-14
 
 
-@pytest.mark.parametrize("N", [32, 64, 128, 256, 512])
-@pytest.mark.parametrize("d", [-1, 1])
-def test_line4_c2c(emu, N, d):
-    """Line4 (four points per thread, radix 4 / 2: the transform inside the z-attached displacement sweep) against numpy."""
-    rng = np.random.default_rng(N + d)
-    x = rng.standard_normal((5, N)) + 1j * rng.standard_normal((5, N))
-    y = x.copy()
-    assert emu.emu_line4(N, d, P(y.view(np.float64)), 5) == 0
-    ref = np.fft.fft(x, axis=1) if d < 0 else np.fft.ifft(x, axis=1) * N
-    assert np.abs(y - ref).max() < 1e-12 * N
-
-
 @pytest.mark.parametrize("nz", [16, 32, 64, 128, 256, 512, 1024, 2048])
 def test_r2c_c2r(emu, nz):
     rng = np.random.default_rng(nz)

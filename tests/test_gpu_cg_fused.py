@@ -87,6 +87,34 @@ def test_fused_scalar_cg_matches_oracle_and_unfused(grid, dims, estimator):
     assert np.abs(res[1][2] - res[0][2]).max() < 1e-10 * max(1.0, np.abs(res[0][2]).max())
 
 
+def test_scalar_cg_with_callback_equals_run_without():
+    """Scalar modes: a convergence callback selects the four-kernel form (the accessors read the iterate in place), a run without
+    one the fused sweeps (include/fibergen_amd.h, cg_fused).  The two histories come from different summation orders and must
+    agree to the bar that holds between fused and unfused."""
+    from fibergen_amd import LSSolver
+    grid, dims = (8, 14, 128), (1.0, 2.0, 1.5)
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 50.0], [1 - phi1, phi1]
+    E = np.array([1.0, -0.5, 0.25])
+    out = []
+    for with_cb in (False, True):
+        s = LSSolver(*grid, *dims)
+        s.set_options(mode="porous")
+        s.set_num_phases(2)
+        for p in range(2):
+            s.set_phase(p, mus[p], 0.0, phis[p])
+        s.set_options(tol=1e-10, method="cg", cg_fused=1)
+        seen = []
+        if with_cb:
+            s.set_convergence_callback(lambda: seen.append(s.mean_stress().copy()) and False)
+        assert s.run(E) is False
+        out.append((s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress().copy(), len(seen)))
+        s.close()
+    assert out[0][0] == out[1][0] and out[1][4] >= out[1][0] and out[0][4] == 0
+    assert out[0][1].shape == out[1][1].shape and np.abs(out[0][1] - out[1][1]).max() < 1e-12
+    assert rel_err(out[1][2], out[0][2]) < 1e-10 and rel_err(out[1][3], out[0][3]) < 1e-11
+
+
 @pytest.mark.parametrize("P", [1, 2, 4])
 @pytest.mark.parametrize("mixing", ["voigt", "laminate"])
 def test_fused_cg_on_slabs_equals_unfused(P, mixing):

@@ -353,68 +353,3 @@ def test_random_scalar_slab_group_matches_oracle(seed):
     mtol = 1e-8 if c["method"] == "cg" else 1e-9
     assert np.abs(np.asarray(g.mean_stress())[:3] - o.mean_stress()).max() < mtol * max(1.0, np.abs(o.mean_stress()).max()), tag
     g.close()
-
-
-# ---- round 4: the displacement sweep with both z transforms attached (option z_sweep) on random problems
-N_ZSWEEP = int(os.environ.get("FG_FUZZ_SEEDS", "40"))
-
-
-def draw_zsweep(seed):
-    rng = np.random.default_rng(9000 + seed)
-    nz = 256 if rng.random() < 0.25 else 128
-    # grids the sweep takes: nz/2 = 64 or 128, ny >= 16 (also not a multiple of the tile height, not a power of two), nx >= 4
-    shape = (int(rng.choice([4, 5, 6, 8, 12, 16] if nz == 128 else [4, 5, 8])), int(rng.choice([16, 17, 20, 24, 32] if nz == 128 else [16, 20])), nz)
-    dims = tuple(float(v) for v in rng.uniform(0.5, 2.0, size=3))
-    nph = int(rng.integers(1, 4))
-    mats = [lame(E=float(rng.uniform(0.5, 20.0)), nu=float(rng.uniform(0.05, 0.4))) for _ in range(nph)]
-    if nph == 1:
-        phis = [np.ones(shape)]
-    elif nph == 2:
-        p1 = smooth_field(rng, shape)
-        phis = [1.0 - p1, p1]
-    else:
-        p1, p2 = smooth_field(rng, shape), smooth_field(rng, shape)
-        p2 = np.minimum(p2, 1.0 - p1)
-        phis = [1.0 - p1 - p2, p1, p2]
-    opts = {"z_sweep": 1}
-    if rng.random() < 0.3:
-        opts["fuse_x"] = int(rng.integers(0, 2))
-    if rng.random() < 0.25:
-        opts["phi_sweep"] = 0                # two phases through the effective-moduli arrays
-    if rng.random() < 0.2:
-        opts["x_layout"] = 1
-    bc = str(rng.choice(list(PROJECTORS))) if rng.random() < 0.3 else None
-    steps = [0.0, 0.4, 1.0] if rng.random() < 0.25 else None
-    return dict(shape=shape, dims=dims, mats=mats, phis=phis, opts=opts, bc=bc, steps=steps, E=rng.uniform(-1.0, 1.0, size=6))
-
-
-@pytest.mark.parametrize("seed", range(N_ZSWEEP))
-def test_random_zsweep_matches_oracle(seed):
-    from fibergen_amd import LSSolver
-    from oracle.ls_oracle import LSOracle
-    c = draw_zsweep(seed)
-    shape, dims = c["shape"], c["dims"]
-    common = dict(tol=1e-7, maxiter=400)
-    o = LSOracle(*shape, *dims, mats=c["mats"], phis=c["phis"], normals=None, mixing_rule="voigt", **common)
-    s = LSSolver(*shape, *dims)
-    s.set_num_phases(len(c["mats"]))
-    for p, (m, phi) in enumerate(zip(c["mats"], c["phis"])):
-        s.set_phase(p, m[0], m[1], phi)
-    s.set_options(mixing_rule="voigt", **common, **c["opts"])
-    E, S0, P = c["E"].copy(), np.zeros(6), None
-    if c["bc"] is not None:
-        keep = np.array(PROJECTORS[c["bc"]], dtype=float)
-        P = np.diag(keep)
-        E = E * (keep > 0)
-        s.set_bc_projector(P)
-    params = c["steps"] or [0.0, 1.0]
-    tag = "seed %d: %s" % (seed, {k: c[k] for k in ("shape", "opts", "bc", "steps")})
-    assert o.run_load_steps(E, S0, P, params=params, method="basic") is False, tag
-    assert s.run_load_steps(E, S0, params=params) is False, tag
-    assert s.counter("zsweep_passes") > 0, tag
-    assert s.iterations == o.iterations, tag
-    r, rr = np.array(s.residuals), np.array(o.residuals)
-    assert r.shape == rr.shape and np.abs(r - rr).max() < 1e-9, tag
-    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8, tag
-    assert np.abs(s.mean_stress() - o.mean_stress()).max() < 1e-9 * max(1.0, np.abs(o.mean_stress()).max()), tag
-    s.close()

@@ -324,31 +324,6 @@ def test_displacement_based_loop_is_bit_identical(grid):
     assert o.iterations == c[0] and rel_err(c[2], o.eps) < 1e-9
 
 
-@pytest.mark.parametrize("grid", [(8, 8, 64), (6, 10, 64), (5, 3, 64), (8, 8, 128), (4, 6, 256), (4, 4, 512), (16, 8, 1024)])
-def test_displacement_sweep_with_z_transform_attached(grid):
-    """fuse_z: the fast displacement sweep hands the z half spectrum of f to the FFT chain instead of f
-    (whole z rows per workgroup, r2c in LDS).  Same iterates as with the separate r2c pass, and the
-    oracle's fixed point.  nz = 1024 is outside the attached transform's range and takes the separate pass."""
-    E = np.array([0.2, -0.1, 1.0, 0.3, 0, 0.5])
-    res = {}
-    for flag in (0, 1):
-        s = make_gpu_solver(grid, tol=1e-8)
-        s.set_options(u_tile=0)
-        s._check(s._lib.fg_set_option_i(s._h, b"fuse_z", flag))
-        assert s.run(E) is False
-        res[flag] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.get_field("u"), s.mean_stress())
-        s.close()
-    a, b = res[0], res[1]
-    assert a[0] == b[0]
-    assert np.abs(a[1] - b[1]).max() < 1e-12
-    assert rel_err(b[2], a[2]) < 1e-12 and rel_err(b[4], a[4]) < 1e-12
-    assert np.abs(b[3] - a[3]).max() < 1e-12 * max(1.0, np.abs(a[3]).max())
-    if grid[2] <= 256 and grid[0] * grid[1] <= 64:
-        o = make_oracle(grid, tol=1e-8)
-        assert o.run(E) is False
-        assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9
-
-
 def test_callback_field_access_inside_displacement_loop():
     """Accessors called from the convergence callback materialise the strain on demand."""
     s = make_gpu_solver((16, 16, 16), tol=1e-8)
@@ -520,7 +495,7 @@ def test_tiled_displacement_sweep(grid, rows):
     res = {}
     for flag in (0, rows):
         s = make_gpu_solver(grid, tol=1e-8)
-        s.set_options(u_tile=flag, fuse_z=0)
+        s.set_options(u_tile=flag)
         assert s.run(E) is False
         res[flag] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress())
         s.close()
