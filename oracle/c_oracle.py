@@ -26,7 +26,8 @@ def load(build=True, native=False):
     """native: the reference's release flags (-O3 -march=native), compiled on this very host (cpu_baseline only)."""
     name = "libfg_ref_native.so" if native else "libfg_ref.so"
     so = os.path.join(_HERE, "c", name)
-    if native or (not os.path.exists(so) and build):
+    fresh = native and os.environ.get("FG_REF_NATIVE_BUILT") == "1" and os.path.exists(so)   # built by the parent process on this host
+    if (native and not fresh) or (not os.path.exists(so) and build):
         # the native library is always rebuilt: one made on another machine may carry instructions this host lacks
         if native and os.path.exists(so):
             os.remove(so)
@@ -238,21 +239,41 @@ class CRefViscosity(CRef):
 class CRefLoop:
     """The loop of basicScheme as the reference runs it: ONE strain field that every routine works on in place
     (tau aliases epsilon, F:15153-15155, F:20558-20578), buffers allocated once, `threads` OpenMP threads
-    (the reference's <num_threads>, default 1, F:25226).  cpu_baseline only; the checker is CRef."""
+    (the reference's <num_threads>, default 1, F:25226).  cpu_baseline only; the checker is CRef.
 
-    def __init__(self, n, dims, mats, phis, normals=None, mixing="voigt", threads=1, native=True):
+    fft = "own" (default where the grid is a power of two): the threaded row-column transform of oracle/c/fg_fft_ref.c, so that
+    every thread of a pass is an OpenMP thread (OMP_PROC_BIND / OMP_PLACES pin all of them) and the work fields are first
+    touched by the threads that sweep them; "pocketfft": scipy.fft with `workers` threads (rounds 2-4)."""
+
+    def __init__(self, n, dims, mats, phis, normals=None, mixing="voigt", threads=1, native=True, fft="own"):
         self.lib = load(native=native)
+        lib = self.lib
         self.nx, self.ny, self.nz = n
         self.dims = tuple(float(d) for d in dims)
         self.N = self.nx * self.ny * self.nz
         self.mu = np.array([m[0] for m in mats], dtype=np.float64)
         self.lam = np.array([m[1] for m in mats], dtype=np.float64)
-        self.phi = np.ascontiguousarray(np.stack(phis), dtype=np.float64)
-        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
         self.mixing = {"voigt": 0, "laminate": 1}[mixing]
         self.threads = int(threads)
-        self.eps = np.zeros((6,) + tuple(n))       # the one strain / polarisation field
-        self.f = np.zeros((3,) + tuple(n))         # divergence / displacement work field
+        lib.ref_set_threads(self.threads)
+        lib.ref_fft_plan.restype = ctypes.c_void_p
+        self.own_fft = fft == "own" and bool(lib.ref_fft_supported(*n))
+        self.plan = ctypes.c_void_p(lib.ref_fft_plan(*n)) if self.own_fft else None
+        plane = self.ny * self.nz
+
+        def placed(ncomp, src=None, plane_elems=plane):
+            # pages placed by the threads that sweep them (ref_first_touch: per component a static loop over the x-planes)
+            a = np.empty((ncomp, self.nx, plane_elems))
+            lib.ref_first_touch(_P(a), ncomp, self.nx, ctypes.c_size_t(plane_elems))
+            if src is not None:
+                a[:] = np.asarray(src, dtype=np.float64).reshape(a.shape)
+            return a
+        self.phi = placed(len(phis), np.stack(phis)).reshape((len(phis),) + tuple(n))
+        self.normals = None if normals is None else placed(3, normals).reshape((3,) + tuple(n))
+        self.eps = placed(6).reshape((6,) + tuple(n))       # the one strain / polarisation field
+        self.f = placed(3).reshape((3,) + tuple(n))         # divergence / displacement work field
+        nzc = self.nz // 2 + 1
+        self.fh = placed(3, None, 2 * self.ny * nzc).view(np.complex128).reshape(3, self.nx, self.ny, nzc) if self.own_fft else None
         self.zero6 = np.zeros(6)
         self.norms = np.zeros(6)
         self.eps_g = np.finfo(float).eps
@@ -273,16 +294,23 @@ class CRefLoop:
             raise RuntimeError("The laminate mixing rule supports only two phase mixtures")
         lib.ref_div(self.nx, self.ny, self.nz, *map(d, self.dims), _P(self.eps), _P(self.f))
         t = time.perf_counter()
-        fh = scipy.fft.rfftn(self.f, axes=(1, 2, 3), workers=self.threads)
+        if self.own_fft:
+            fh = self.fh
+            lib.ref_fft_r2c(self.plan, 3, _P(self.f), fh.ctypes.data_as(_dp))
+        else:
+            fh = scipy.fft.rfftn(self.f, axes=(1, 2, 3), workers=self.threads)
         self.fft_seconds += time.perf_counter() - t
         v = fh.view(np.float64)
-        lib.ref_scale(ctypes.c_size_t(v.size), d(1 / float(self.N)), _P(v))
+        lib.ref_scale(ctypes.c_size_t(v.size), d(1 / float(self.N)), v.ctypes.data_as(_dp))
         lib.ref_g0(self.nx, self.ny, self.nz, *map(d, self.dims), d(mu_0), d(lambda_0), d(-1.0), fh.ctypes.data_as(ctypes.c_void_p))
         t = time.perf_counter()
-        u = scipy.fft.irfftn(fh, s=(self.nx, self.ny, self.nz), axes=(1, 2, 3), workers=self.threads, norm="forward",
-                             overwrite_x=True)
+        if self.own_fft:
+            lib.ref_fft_c2r(self.plan, 3, fh.ctypes.data_as(_dp), _P(self.f))
+            u = self.f
+        else:
+            u = np.ascontiguousarray(scipy.fft.irfftn(fh, s=(self.nx, self.ny, self.nz), axes=(1, 2, 3), workers=self.threads,
+                                                      norm="forward", overwrite_x=True))
         self.fft_seconds += time.perf_counter() - t
-        u = np.ascontiguousarray(u)
         lib.ref_eps(self.nx, self.ny, self.nz, *map(d, self.dims), _P(E), _P(u), _P(self.eps))
         lib.ref_add(ctypes.c_size_t(self.N), _P(self.zero6), _P(self.eps))          # applyBCProjector's eps.add(R)  F:20269
         lib.ref_component_norm(ctypes.c_size_t(self.N), _P(self.eps), _P(self.norms))

@@ -102,3 +102,51 @@ def test_c_cg_equals_numpy_oracle_per_iteration(grid, dims, mixing, estimator):
     assert o.run_cg(E) is False
     eps, res, it = c.run_cg(E, o.mu_0, o.lambda_0, maxiter=o.maxiter, tol=1e-5, abs_tol=o.abs_tol, estimator=estimator)
     assert it == o.iterations and rel_err(eps, o.eps) < 1e-11
+
+
+@pytest.mark.parametrize("grid", [(4, 8, 16), (8, 4, 8), (2, 2, 4), (16, 32, 64), (64, 16, 32)])
+def test_c_fft_matches_numpy(grid):
+    """oracle/c's own threaded row-column transform (the cpu_baseline's stand-in for threaded FFTW): r2c against numpy's rfftn,
+    c2r with FFTW's semantics on a spectrum that is NOT Hermitian (imaginary parts of the DC / Nyquist bins ignored), round trip."""
+    import ctypes
+    from oracle.c_oracle import _P, load
+    lib = load()
+    lib.ref_fft_plan.restype = ctypes.c_void_p
+    assert lib.ref_fft_supported(*grid) == 1 and lib.ref_fft_supported(6, 8, 8) == 0
+    lib.ref_set_threads(3)
+    plan = ctypes.c_void_p(lib.ref_fft_plan(*grid))
+    rng = np.random.default_rng(5)
+    f = rng.standard_normal((3,) + grid)
+    fh = np.empty((3,) + grid[:2] + (grid[2] // 2 + 1,), dtype=np.complex128)
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.ref_fft_r2c(plan, 3, _P(f), fh.ctypes.data_as(dp))
+    ref = np.fft.rfftn(f, axes=(1, 2, 3))
+    assert np.abs(fh - ref).max() < 1e-13 * np.abs(ref).max()
+    spec = rng.standard_normal(fh.shape) + 1j * rng.standard_normal(fh.shape)
+    want = np.fft.irfftn(spec, s=grid, axes=(1, 2, 3)) * float(np.prod(grid))
+    u = np.empty_like(f)
+    lib.ref_fft_c2r(plan, 3, spec.copy().ctypes.data_as(dp), _P(u))
+    assert np.abs(u - want).max() < 1e-13 * np.abs(want).max()
+    lib.ref_fft_c2r(plan, 3, fh.ctypes.data_as(dp), _P(u))
+    assert np.abs(u / float(np.prod(grid)) - f).max() < 1e-13
+    lib.ref_fft_plan_free(plan)
+
+
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+def test_cpu_baseline_loop_equals_checker(mixing):
+    """CRefLoop (bench.py's cpu_baseline: in place, own transform, placed buffers) performs the passes of CRef (the checker)."""
+    from oracle.c_oracle import CRefLoop
+    grid, dims = (16, 16, 16), (1.0, 1.0, 1.0)
+    mats, phis, normals = two_phase_setup(grid, mixing)
+    E = np.array([1.0, 0.0, 0.0, 0.0, 0.0, 0.5])
+    c = CRef(grid, dims, mats, phis, normals, mixing, threads=2)
+    loops = [CRefLoop(grid, dims, mats, phis, normals, mixing, threads=2, native=False, fft=f) for f in ("own", "pocketfft")]
+    assert loops[0].own_fft and not loops[1].own_fft
+    eps = np.zeros((6,) + grid)
+    for _ in range(3):
+        eps = c.basic_scheme(E, eps, 0.7, 0.0)
+        for lp in loops:
+            lp.one_pass(E, 0.7, 0.0)
+    for lp in loops:
+        assert rel_err(lp.eps, eps) < 1e-12
+        assert rel_err(lp.norms, c.component_norm(eps)) < 1e-12
