@@ -177,7 +177,7 @@ class Solver {
   void reset_stage_times();
   double event_bias_ms() const { return event_bias_ms_; }
   // fg_get_counter: "interface_voxels" / "affected_voxels" = lengths of the laminate correction's lists (0 before they are
-  // built), "fft_plan_reused" = 1 if this solver took its FFT tables from the per-device cache; -1 = unknown name
+  // built); -1 = unknown name
   long counter(const std::string& name) const;
 
  private:
@@ -299,7 +299,6 @@ class Solver {
   double *cg_r_ = nullptr, *cg_p_ = nullptr, *cg_w_ = nullptr;  // CG residual, direction, operator image (6 each)
   double* fu_cg_ = nullptr;   // fused displacement-space CG: the alternate buffer of the iterate (3 components; swapped with fu_)
   unsigned* mixed_list_ = nullptr;  // element offsets of the interface voxels (laminate mixing, displacement loop)
-  bool plan_reused_ = false;        // the FFT tables came from the per-device cache (Fft3::acquire)
   unsigned mixed_n_ = 0;
   bool mixed_dirty_ = true;
   unsigned* aff_list_ = nullptr;    // voxels whose divergence stencil touches an interface voxel

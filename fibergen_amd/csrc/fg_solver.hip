@@ -446,7 +446,6 @@ void Solver::enable_stage_timing(bool on) {
 long Solver::counter(const std::string& name) const {
   if (name == "interface_voxels") return (long)mixed_n_;
   if (name == "affected_voxels") return (long)aff_n_;
-  if (name == "fft_plan_reused") return plan_reused_ ? 1 : 0;
   return -1;
 }
 

@@ -168,7 +168,7 @@ class LSSolver:
         return bool(failed.value)
 
     def counter(self, name):
-        """fg_get_counter: "interface_voxels", "affected_voxels" (laminate lists), "fft_plan_reused"; -1 = unknown name."""
+        """fg_get_counter: "interface_voxels", "affected_voxels" (lengths of the laminate lists); -1 = unknown name."""
         return int(self._lib.fg_get_counter(self._h, name.encode()))
 
     def iterate(self, E, n):
