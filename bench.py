@@ -197,6 +197,41 @@ def physical_cores():
 A_STAGE_BYTES_PER_VOXEL = 632   # the reference's pass structure, every stage reading its inputs and writing its outputs once
 
 
+def cpu_limits():
+    """What the node lets this process use: CPUs in the affinity mask, the CFS bandwidth quota of its control group (cgroup v2
+    cpu.max or v1 cpu.cfs_quota_us / cpu.cfs_period_us) in CPUs, and the throttling counter to take differences of.  A thread
+    sweep that stops scaling at 16 threads on a 128-core host is what a quota of about that many CPUs looks like from inside."""
+    out = {"affinity_cpus": None, "cgroup_quota_cpus": None}
+    try:
+        out["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        out["cgroup_quota_cpus"] = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            out["cgroup_quota_cpus"] = None if q <= 0 else q / per
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def cpu_throttled():
+    """(periods throttled, seconds throttled) of this control group so far, or None"""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            kv = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+            n = int(kv.get("nr_throttled", 0))
+            t = float(kv["throttled_usec"]) / 1e6 if "throttled_usec" in kv else float(kv.get("throttled_time", 0)) / 1e9
+            return n, t
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def cpu_passes(grid, mixing, phi_path, normals_path, threads, max_passes, max_seconds, bind=True):
     """One run of the CPU stand-in (oracle/cpu_loop.py) in a process of its own with `threads` OpenMP threads, pinned one per
     core and spread over the sockets (OMP_PROC_BIND=spread, OMP_PLACES=cores: every thread of a pass is an OpenMP thread since
@@ -230,7 +265,10 @@ def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
     ncpu = os.cpu_count() or 1
     cores, sockets = physical_cores()
     per_socket = (cores // sockets) if cores and sockets else None
-    counts = sorted({t for t in (16, 32, per_socket or 64, cores or ncpu) if t and t <= ncpu})
+    limits = cpu_limits()
+    usable = min(x for x in (ncpu, limits["affinity_cpus"], limits["cgroup_quota_cpus"]) if x)
+    counts = sorted({t for t in (8, 16, 32, per_socket or 64, cores or ncpu) if t and t <= ncpu})
+    thr0 = cpu_throttled()
     t_start = time.perf_counter()
     tmp = tempfile.mkdtemp(prefix="fg_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 
@@ -270,12 +308,17 @@ def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
         shutil.rmtree(tmp, ignore_errors=True)
     ordered = [sweep[k] for k in sorted(sweep)]
     monotone = all(b >= 0.97 * a for a, b in zip(ordered, ordered[1:]))
+    thr1 = cpu_throttled()
+    limits["usable_cpus"] = usable
+    if thr0 and thr1:
+        limits["cfs_throttled_periods_during_sweep"] = thr1[0] - thr0[0]
+        limits["cfs_throttled_seconds_during_sweep"] = round(thr1[1] - thr0[1], 3)
     N = n[0] * n[1] * n[2]
     return {"value": sweep[best], "unit": "it/s", "cores": int(best), "kind": "port",
             "one_thread_it_s": one, "host_cpus": ncpu, "physical_cores": cores, "sockets": sockets, "fft_share": shares[best],
             "thread_sweep_it_s": {str(k): v for k, v in sorted(sweep.items())}, "per_grid": per_grid,
             "cpu_GBps": A_STAGE_BYTES_PER_VOXEL * N * sweep[best] / 1e9,
-            "scales_with_threads": monotone,
+            "scales_with_threads": monotone, "cpu_limits": limits,
             "note": ("it/s grows with the thread count over the sweep" if monotone else
                      "does not scale over the whole sweep: best at %d of %s threads" % (best, "/".join(str(k) for k in counts))) +
                     "; cpu_GBps prices a pass at the reference's 632 B/voxel (SURVEY 8d)",
@@ -411,7 +454,7 @@ def main():
     ap.add_argument("--also", default="128:voigt,512:laminate,256:voigt:porous,256:voigt:viscosity",
                     help="N = 1: further single-GPU workloads n:mixing[:mode] reported under `also` ('' = none): the other "
                          "BASELINE sizes and config 5 (porous / Stokes)")
-    ap.add_argument("--u-tile", type=int, default=None, help="override the solver's u_tile option (0, 8, 12, 16)")
+    ap.add_argument("--u-tile", type=int, default=None, help="override the solver's u_tile option (0 = untiled sweep, 1 = tiled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
     ap.add_argument("--slab-members", type=int, default=1,

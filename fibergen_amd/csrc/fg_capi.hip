@@ -243,8 +243,7 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       o.gamma_scheme = (int)value;
     }
     else if (k == "u_tile") {
-      if (value != 0 && value != 8 && value != 12 && value != 16) throw std::runtime_error("u_tile must be 0, 8, 12 or 16");
-      o.u_tile = (int)value;
+      o.u_tile = value != 0;
       v.invalidate_interface_lists();
     }
     else if (k == "fuse_x") o.fuse_x = value != 0;

@@ -997,15 +997,11 @@ void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
   }
 #define FG_TILE(R, Z) launch_u_tile_t<R, Z, false>(g, mu_0, lambda_0, u, mod, f, E, partial, sumsq6, s)
   if (nzh == 64) {          // a z row is one wave
-    if (rows == 16) FG_TILE(16, 1);
-    else if (rows == 12) FG_TILE(12, 1);
-    else FG_TILE(8, 1);
+    FG_TILE(8, 1);
   } else if (nzh == 128) {  // a z row is two waves: 6 rows x 2 segments (256^3: 0.268 ms against 0.325 ms with halo lanes;
     FG_TILE(6, 2);          // 8 x 2 = 16 waves in lock-step 0.38 ms, 4 x 2 0.31 ms)
   } else {                  // general: tiles of 62 pairs with halo lanes
-    if (rows == 16) FG_TILE(16, 0);
-    else if (rows == 12) FG_TILE(12, 0);
-    else FG_TILE(8, 0);
+    FG_TILE(8, 0);       // (12- and 16-row tiles move fewer halo bytes -- 512^3: 8.95 -> 8.5 GB -- in the same time: rounds 1 and 5)
   }
 #undef FG_TILE
 }

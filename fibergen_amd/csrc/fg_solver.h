@@ -66,8 +66,8 @@ struct SolverOptions {
                                 // mixing 2 = the Voigt sweep + divergence of (tau_laminate - tau_voigt) at the interface)
   int fuse_stress_div = 1;      // Voigt mixing: polarisation + divergence in one sweep
   int fuse_x = 1;               // fuse x-FFT + Green operator + inverse x-FFT when the length allows
-  int u_tile = 8;               // fast displacement sweep (u_loop = 2) as the LDS-tiled marching kernel where the grid allows:
-                                // rows per workgroup (8, 12, 16), 0 = off.  512^3: 2.8 -> 1.95 ms per sweep
+  int u_tile = 1;               // fast displacement sweep (u_loop = 2) as the LDS-tiled marching kernel where the grid allows
+                                // (0 = the untiled sweep everywhere).  512^3: 2.8 -> 1.95 ms per sweep
   int phi_sweep = 1;            // two complementary phases: the tiled sweep reads phi_1 instead of the two moduli arrays
   int laminate_overlap = 1;     // displacement loop with laminate mixing: interface kernels on a second stream beside the sweep
   int slab_loopback = 0;        // test mode: a lone slab sends to itself through its transport (see Solver::slab_loopback)

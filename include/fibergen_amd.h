@@ -81,8 +81,8 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * cg only), and the implementation switches u_loop (2 = default: the loop carries the
  * displacement, fast kernels; 1 = the same with the reference's operation order, iterates bit-identical to 0; 0 = the
  * strain field is the state, one kernel per reference routine where fuse_* are 0 too),
- * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (rows per workgroup of
- * the tiled displacement sweep: 8 default, 12, 16, 0 = untiled),
+ * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (1 = default: the
+ * LDS-tiled displacement sweep where the grid allows; 0 = the untiled sweep everywhere),
  * cg_fused (-1 = default: where the tiled sweep fits; 0 / 1: method = cg in displacement / potential space with the vector
  * work of an iteration as two tiled sweeps and the direction update inside the operator's sweep -- out of place, nine more
  * components; falls back to the four-kernel form when they do not fit; in the scalar modes (potential space) a registered

@@ -14,12 +14,49 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def launch(nproc, out, *args, timeout=600):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    port = str(29500 + (os.getpid() % 2000))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "dist_worker.py"),
-           "--out", out, *args]
-    subprocess.run(cmd, check=True, env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    """`nproc` worker processes of tests/dist_worker.py with the environment torch.distributed's env:// rendez-vous reads
+    (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port) -- started directly: the elastic
+    launcher of `python -m torch.distributed.run` costs an interpreter start and a torch import of its own per test, and the
+    GPU suite launches sixty of these.  Raises CalledProcessError (with the failing rank's stderr) like subprocess.run(check=True)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(nproc), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--out", out, *args]
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+             for r in range(nproc)]
+    import threading
+    errs = [b""] * nproc
+
+    def drain(i):   # (a rank that fills its stderr pipe must not block while the others wait for it in a collective)
+        errs[i] = procs[i].stderr.read()
+    readers = [threading.Thread(target=drain, args=(i,), daemon=True) for i in range(nproc)]
+    for t in readers:
+        t.start()
+    deadline = __import__("time").monotonic() + timeout
+    failed = None
+    try:
+        for r, p in enumerate(procs):
+            p.wait(timeout=max(1.0, deadline - __import__("time").monotonic()))
+            if p.returncode != 0 and failed is None:
+                failed = r
+                break   # the others may hang in a collective waiting for it: stop them below
+    except subprocess.TimeoutExpired:
+        failed = -1
+    if failed is not None:
+        __import__("time").sleep(1.0)   # let the other ranks report their own error first
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p in procs:
+        p.wait()
+    for t in readers:
+        t.join(timeout=5)
+    if failed is not None:
+        if failed < 0:
+            raise subprocess.TimeoutExpired(cmd, timeout, stderr=b"\n".join(errs))
+        raise subprocess.CalledProcessError(procs[failed].returncode, cmd, stderr=b"\n".join(errs))
     return [np.load(out + ".%d.npz" % r) for r in range(nproc)]
 
 

@@ -72,7 +72,7 @@ def draw(seed):
     if rng.random() < 0.3:
         opts["fuse_x"] = int(rng.integers(0, 2))
     if rng.random() < 0.3:
-        opts["u_tile"] = int(rng.choice([0, 8, 12, 16]))
+        opts["u_tile"] = int(rng.choice([0, 1]))
     if rng.random() < 0.3:
         opts["fuse_stress_div"] = int(rng.integers(0, 2))
     bc = None

@@ -486,20 +486,19 @@ def test_laminate_mixing_as_correction_of_the_voigt_sweep(grid):
     assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9 and rel_err(b[3], o.get_field("sigma")) < 1e-9
 
 
-@pytest.mark.parametrize("rows", [8, 16])
 @pytest.mark.parametrize("grid", [(16, 16, 128), (8, 16, 124), (32, 32, 256), (5, 14, 128), (6, 20, 130), (40, 30, 128)])
-def test_tiled_displacement_sweep(grid, rows):
+def test_tiled_displacement_sweep(grid):
     """u_tile: the LDS-tiled marching variant of the fast sweep (each strain / polarisation value computed once;
     halo rows and lanes, overlapping last tiles, periodic wrap in all directions) gives the same iterates."""
     E = np.array([0.2, -0.1, 1.0, 0.3, 0, 0.5])
     res = {}
-    for flag in (0, rows):
+    for flag in (0, 1):
         s = make_gpu_solver(grid, tol=1e-8)
         s.set_options(u_tile=flag)
         assert s.run(E) is False
         res[flag] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress())
         s.close()
-    a, b = res[0], res[rows]
+    a, b = res[0], res[1]
     assert a[0] == b[0]
     assert np.abs(a[1] - b[1]).max() < 1e-12
     assert rel_err(b[2], a[2]) < 1e-11 and rel_err(b[3], a[3]) < 1e-12
