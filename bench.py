@@ -174,6 +174,72 @@ def committed_traffic(n, mixing, slot, default_options):
     return None, None
 
 
+def live_traffic(args, slot):
+    """HBM bytes per launch of kernel `slot`, measured NOW on this box: two short child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, kernel trace only, as MI355X_MICROARCH.md's HBM section
+    prescribes; the child does a handful of passes of the same workload and nothing else), FETCH_SIZE doubled for gfx950, KB ->
+    bytes, averaged over the launches of the kernel.  -> (bytes, {"fetch": .., "write": .., "launches": ..}) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if slot not in PMC_KERNEL:
+        return None, "no kernel name known for slot %s" % slot
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        return None, "rocprofv3 not on PATH"
+
+    def matches(name, w):   # "k_x": the name before its template list; "k_x<...": a prefix, `*` = any run of characters
+        name = name[name.index("k_"):] if "k_" in name else name
+        if "<" not in w:
+            return name.split("<")[0].split("(")[0] == w
+        head, _, tail = w.partition("*")
+        return name.startswith(head) and (not tail or tail in name[len(head):])
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="fg_pmc_")
+        try:
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--traffic-child", "--n", str(args.n), "--mixing", args.mixing, "--mode", args.mode]
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240,
+                               env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+            vals = []
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == counter and any(matches(r["Kernel_Name"], w) for w in PMC_KERNEL[slot]):
+                        vals.append(float(r["Counter_Value"]))
+            if p.returncode != 0 or not vals:
+                return None, "%s pass: rc %d, %d launches of the kernel seen (%s)" % (
+                    counter, p.returncode, len(vals), (p.stderr.strip().splitlines() or [""])[-1][:160])
+            got[counter] = (sum(vals) / len(vals), len(vals))
+        except (subprocess.TimeoutExpired, OSError) as e:
+            return None, "%s pass: %s" % (counter, type(e).__name__)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    fetch = 2 * got["FETCH_SIZE"][0] * 1024
+    write = got["WRITE_SIZE"][0] * 1024
+    return fetch + write, {"fetch_bytes": fetch, "write_bytes": write, "launches_averaged": got["FETCH_SIZE"][1],
+                           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate child runs of this script on this "
+                                     "box; FETCH_SIZE x 2 (gfx950), KB -> bytes"}
+
+
+def traffic_child(args):
+    """the workload of live_traffic's child runs: a handful of passes, nothing else"""
+    from fibergen_amd import LSSolver
+    from fibergen_amd.rve import bench_rve
+    phi, normals, _ = bench_rve(args.n, args.mixing)
+    s = LSSolver(args.n, args.n, args.n)
+    configure(s, phi, normals, args.mixing, args.mode)
+    s.calc_ref_material()
+    E = np.zeros(3 if args.mode in ("porous", "heat") else 6)
+    E[0] = 1.0
+    if args.mode == "viscosity":
+        E = np.array([1.0, -1, 0, 0, 0, 0])
+    s.iterate(E, 6)
+    s.synchronize()
+    s.close()
+
+
 def physical_cores():
     """(physical cores, sockets) of this host from /proc/cpuinfo; (None, None) when it cannot be read"""
     try:
@@ -232,7 +298,7 @@ def cpu_throttled():
     return None
 
 
-def cpu_passes(grid, mixing, phi_path, normals_path, threads, max_passes, max_seconds, bind=True):
+def cpu_passes(grid, mixing, phi_path, normals_path, threads, max_passes, max_seconds, bind=True, loops="reference"):
     """One run of the CPU stand-in (oracle/cpu_loop.py) in a process of its own with `threads` OpenMP threads, pinned one per
     core and spread over the sockets (OMP_PROC_BIND=spread, OMP_PLACES=cores: every thread of a pass is an OpenMP thread since
     the transforms are oracle/c's own), buffers first touched by the threads that sweep them.
@@ -241,7 +307,7 @@ def cpu_passes(grid, mixing, phi_path, normals_path, threads, max_passes, max_se
     if bind:
         env.update(OMP_PROC_BIND="spread", OMP_PLACES="cores")
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_loop.py"), "--grid", str(grid), "--mixing", mixing, "--phi", phi_path,
-           "--threads", str(threads), "--max-passes", str(max_passes), "--max-seconds", str(max_seconds)]
+           "--threads", str(threads), "--max-passes", str(max_passes), "--max-seconds", str(max_seconds), "--loops", loops]
     if normals_path:
         cmd += ["--normals", normals_path]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -287,6 +353,13 @@ def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
             sweep[th], shares[th], _ = cpu_passes(n[0], mixing, pp, npth, th, 20, min(3.0, budget_s / (2 * len(counts))))
         best = max(sweep, key=sweep.get)
         one = cpu_passes(n[0], mixing, pp, npth, 1, 1, 0.0)[0] if n[0] <= 256 else None
+        # what the reference's traversal orders cost: the same sweep with the two stencil operators z-innermost (same values)
+        tuned = {}
+        for th in counts:
+            try:
+                tuned[th] = cpu_passes(n[0], mixing, pp, npth, th, 20, min(2.0, budget_s / (3 * len(counts))), loops="contiguous")[0]
+            except Exception:  # noqa: BLE001
+                break
         per_grid = {"%d^3 %s" % (n[0], mixing): {"it_s": sweep[best], "threads": int(best), "fft_share": shares[best]}}
         for ne, mix, ph, nr in others:
             key = "%d^3 %s" % (ne, mix)
@@ -319,6 +392,12 @@ def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
             "thread_sweep_it_s": {str(k): v for k, v in sorted(sweep.items())}, "per_grid": per_grid,
             "cpu_GBps": A_STAGE_BYTES_PER_VOXEL * N * sweep[best] / 1e9,
             "scales_with_threads": monotone, "cpu_limits": limits,
+            "tuned_loops_sweep_it_s": {str(k): v for k, v in sorted(tuned.items())},
+            "tuned_loops_note": "NOT the baseline: the same pass with divOperatorStaggered / epsOperatorStaggered restated z-innermost "
+                                "(oracle/c ref_div_contig / ref_eps_contig, bit-identical values).  The reference runs their x- and y-"
+                                "difference nests z-OUTERMOST (F:18864-18887, F:18646-18675): strided inner loops, and neighbouring z -- "
+                                "one cache line -- on different threads; `value` keeps those orders because they are the reference's "
+                                "OpenMP path",
             "note": ("it/s grows with the thread count over the sweep" if monotone else
                      "does not scale over the whole sweep: best at %d of %s threads" % (best, "/".join(str(k) for k in counts))) +
                     "; cpu_GBps prices a pass at the reference's 632 B/voxel (SURVEY 8d)",
@@ -456,6 +535,10 @@ def main():
                          "BASELINE sizes and config 5 (porous / Stokes)")
     ap.add_argument("--u-tile", type=int, default=None, help="override the solver's u_tile option (0 = untiled sweep, 1 = tiled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: do not run the two rocprofv3 counter passes that measure roofline.traffic on this box (the figure "
+                         "is then read from the newest committed PMC summary and flagged as such)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=25.0)
     ap.add_argument("--slab-members", type=int, default=1,
                     help="N = 1: also run the slab driver with this many slabs on the one GPU (0 = skip)")
@@ -477,6 +560,10 @@ def main():
     launched = ("FG_BENCH_ARGV" in os.environ and "WORLD_SIZE" in os.environ and
                 os.environ.get("FG_BENCH_LAUNCHED", "") == os.environ.get("TORCHELASTIC_RUN_ID", "?"))
     args = ap.parse_args(json.loads(os.environ["FG_BENCH_ARGV"]) if launched else None)
+
+    if args.traffic_child:
+        traffic_child(args)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Started plainly: launch the N ranks as fresh processes (torch.distributed.run, one rank per GPU) and relay
@@ -527,6 +614,7 @@ def main():
         traffic, traffic_src = committed_traffic(args.n, args.mixing, dom, default_options)
         roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_from_committed_profile": traffic_src,
+                "traffic_measured_in_this_run": False,
                 "alg_bytes_per_launch": int(kern[dom]["alg_GB"] * 1e9), "avg_launch_ms": kern[dom]["avg_ms"]}
         it_s = res["it_s"]
         if args.method == "cg":
@@ -582,6 +670,15 @@ def main():
             # the reference's default method on the same workload (one operator application + the fused vector sweeps per iteration)
             out["cg_method"] = dict(res["cg"], unit="CG it/s", note="runCGElasticity through fg_run_load_case, maxiter = steps")
         s.close()
+        if not args.no_live_traffic and default_options:
+            # the counter passes of the dominant kernel on THIS box, now that the solver is closed (children of this process)
+            live, info = live_traffic(args, dom)
+            if live is not None:
+                roof.update({"traffic": live, "traffic_measured_in_this_run": True, "traffic_detail": info,
+                             "traffic_over_algorithmic": live / roof["alg_bytes_per_launch"]})
+                roof.pop("traffic_from_committed_profile", None)
+            else:
+                roof["traffic_live_pass_failed"] = info
         out["cache_stream"] = cache_stream(local_rank)
         if args.slab_members > 0 and not scalar and not stokes:
             # the same problem through the slab driver on this one GPU (P = 1: a lone slab, halo = own planes, the

@@ -345,6 +345,53 @@ void ref_eps(int nx, int ny, int nz, double dx, double dy, double dz, const doub
   }
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The two stencil operators with z innermost in EVERY loop nest (cpu_baseline's "tuned_loops" figure only).  The reference's
+ * divOperatorStaggered / epsOperatorStaggered run their x- and y-difference nests with z OUTERMOST and x resp. y innermost
+ * (F:18864-18887, F:18646-18675): every access of the inner loop is ny*nzp*8 resp. nzp*8 bytes from the previous one, and
+ * under `omp for collapse(2)` neighbouring z -- adjacent doubles of ONE cache line -- belong to different threads (false sharing
+ * on every store).  ref_div / ref_eps above keep those orders (they ARE the reference's OpenMP path, and why it stops scaling
+ * at a few dozen threads); these two compute the same values element for element (same operands, same operation order per
+ * element: bit-identical, tests/test_c_oracle.py) with unit-stride inner loops, to show what the traversal order costs. */
+void ref_div_contig(int nx, int ny, int nz, double dx, double dy, double dz, const double* x, double* y) {
+  const size_t N = (size_t)nx * ny * nz;
+  const double hx = nx / dx, hy = ny / dy, hz = nz / dz;
+  const double *x0 = x, *x1 = x + N, *x2 = x + 2 * N, *x3 = x + 3 * N, *x4 = x + 4 * N, *x5 = x + 5 * N;
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int ii = 0; ii < nx; ii++)
+    for (int jj = 0; jj < ny; jj++) {
+      const int xf = (ii + 1) % nx, xb = (ii + nx - 1) % nx, jf = (jj + 1) % ny, jb = (jj + ny - 1) % ny;
+      for (int kk = 0; kk < nz; kk++) {
+        const int kf = (kk + 1) % nz, kb = (kk + nz - 1) % nz;
+        const size_t k = IDX(ii, jj, kk);
+        y[k] = (x0[k] - x0[IDX(xb, jj, kk)]) * hx + (x5[IDX(ii, jf, kk)] - x5[k]) * hy + (x4[IDX(ii, jj, kf)] - x4[k]) * hz;
+        y[N + k] = (x5[IDX(xf, jj, kk)] - x5[k]) * hx + (x1[k] - x1[IDX(ii, jb, kk)]) * hy + (x3[IDX(ii, jj, kf)] - x3[k]) * hz;
+        y[2 * N + k] = (x4[IDX(xf, jj, kk)] - x4[k]) * hx + (x3[IDX(ii, jf, kk)] - x3[k]) * hy + (x2[k] - x2[IDX(ii, jj, kb)]) * hz;
+      }
+    }
+}
+
+void ref_eps_contig(int nx, int ny, int nz, double dx, double dy, double dz, const double* E, const double* x, double* y) {
+  const size_t N = (size_t)nx * ny * nz;
+  const double hx = nx / dx, hy = ny / dy, hz = nz / dz;
+  const double *u0 = x, *u1 = x + N, *u2 = x + 2 * N;
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int ii = 0; ii < nx; ii++)
+    for (int jj = 0; jj < ny; jj++) {
+      const int xf = (ii + 1) % nx, xb = (ii + nx - 1) % nx, yf = (jj + 1) % ny, yb = (jj + ny - 1) % ny;
+      for (int kk = 0; kk < nz; kk++) {
+        const int zf = (kk + 1) % nz, zb = (kk + nz - 1) % nz;
+        const size_t k = IDX(ii, jj, kk);
+        y[3 * N + k] = E[3] + 0.5 * ((u2[k] - u2[IDX(ii, yb, kk)]) * hy + (u1[k] - u1[IDX(ii, jj, zb)]) * hz);
+        y[4 * N + k] = E[4] + 0.5 * ((u2[k] - u2[IDX(xb, jj, kk)]) * hx + (u0[k] - u0[IDX(ii, jj, zb)]) * hz);
+        y[5 * N + k] = E[5] + 0.5 * ((u1[k] - u1[IDX(xb, jj, kk)]) * hx + (u0[k] - u0[IDX(ii, yb, kk)]) * hy);
+        y[k] = E[0] + (u0[IDX(xf, jj, kk)] - u0[k]) * hx;
+        y[N + k] = E[1] + (u1[IDX(ii, yf, kk)] - u1[k]) * hy;
+        y[2 * N + k] = E[2] + (u2[IDX(ii, jj, zf)] - u2[k]) * hz;
+      }
+    }
+}
+
 /* TensorField::add(R)  F:9841-9854 (called even when R == 0, F:20269) */
 void ref_add(size_t N, const double* R, double* eps) {
 #pragma omp parallel for schedule(static) collapse(2)

@@ -245,8 +245,12 @@ class CRefLoop:
     every thread of a pass is an OpenMP thread (OMP_PROC_BIND / OMP_PLACES pin all of them) and the work fields are first
     touched by the threads that sweep them; "pocketfft": scipy.fft with `workers` threads (rounds 2-4)."""
 
-    def __init__(self, n, dims, mats, phis, normals=None, mixing="voigt", threads=1, native=True, fft="own"):
+    def __init__(self, n, dims, mats, phis, normals=None, mixing="voigt", threads=1, native=True, fft="own", loops="reference"):
+        """loops = "reference": the stencil operators in the reference's traversal orders (z outermost in the x- and y-difference
+        nests, F:18864-18887, F:18646-18675); "contiguous": the same values with z innermost everywhere (ref_div_contig /
+        ref_eps_contig: what the traversal order costs, reported beside the baseline, never as it)."""
         self.lib = load(native=native)
+        self.contig = loops == "contiguous"
         lib = self.lib
         self.nx, self.ny, self.nz = n
         self.dims = tuple(float(d) for d in dims)
@@ -292,7 +296,7 @@ class CRefLoop:
                                _P(self.lam), self.mixing, d(mu_0), d(lambda_0), d(1.0), d(self.eps_g), d(self.eps_a),
                                _P(self.eps)):
             raise RuntimeError("The laminate mixing rule supports only two phase mixtures")
-        lib.ref_div(self.nx, self.ny, self.nz, *map(d, self.dims), _P(self.eps), _P(self.f))
+        (lib.ref_div_contig if self.contig else lib.ref_div)(self.nx, self.ny, self.nz, *map(d, self.dims), _P(self.eps), _P(self.f))
         t = time.perf_counter()
         if self.own_fft:
             fh = self.fh
@@ -311,7 +315,7 @@ class CRefLoop:
             u = np.ascontiguousarray(scipy.fft.irfftn(fh, s=(self.nx, self.ny, self.nz), axes=(1, 2, 3), workers=self.threads,
                                                       norm="forward", overwrite_x=True))
         self.fft_seconds += time.perf_counter() - t
-        lib.ref_eps(self.nx, self.ny, self.nz, *map(d, self.dims), _P(E), _P(u), _P(self.eps))
+        (lib.ref_eps_contig if self.contig else lib.ref_eps)(self.nx, self.ny, self.nz, *map(d, self.dims), _P(E), _P(u), _P(self.eps))
         lib.ref_add(ctypes.c_size_t(self.N), _P(self.zero6), _P(self.eps))          # applyBCProjector's eps.add(R)  F:20269
         lib.ref_component_norm(ctypes.c_size_t(self.N), _P(self.eps), _P(self.norms))
         return self.norms

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--max-passes", type=int, default=20)
     ap.add_argument("--max-seconds", type=float, default=3.0)
     ap.add_argument("--fft", default="own", choices=["own", "pocketfft"])
+    ap.add_argument("--loops", default="reference", choices=["reference", "contiguous"])
     a = ap.parse_args()
     from helpers import INCLUSION, MATRIX, lame
     from oracle.c_oracle import CRefLoop
@@ -36,7 +37,7 @@ def main():
     mats = [lame(**MATRIX), lame(**INCLUSION)]
     E = np.array([1.0, 0, 0, 0, 0, 0])
     mu_0 = 0.5 * (mats[0][0] + mats[1][0])   # any positive reference medium: the cost is identical
-    c = CRefLoop(n, (1.0, 1.0, 1.0), mats, [1 - np.asarray(phi), phi], normals, a.mixing, threads=a.threads, fft=a.fft)
+    c = CRefLoop(n, (1.0, 1.0, 1.0), mats, [1 - np.asarray(phi), phi], normals, a.mixing, threads=a.threads, fft=a.fft, loops=a.loops)
     c.one_pass(E, mu_0, 0.0)   # warm-up: OpenMP team, page faults of the scratch buffers
     c.fft_seconds = 0.0
     t0 = time.perf_counter()
@@ -46,7 +47,7 @@ def main():
         it += 1
     dt = time.perf_counter() - t0
     print(json.dumps({"it_s": it / dt, "fft_share": c.fft_seconds / dt, "passes": it, "threads": a.threads,
-                      "fft": "own" if c.own_fft else "pocketfft",
+                      "fft": "own" if c.own_fft else "pocketfft", "loops": a.loops,
                       "omp": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")}}), flush=True)
 
 

@@ -150,3 +150,26 @@ def test_cpu_baseline_loop_equals_checker(mixing):
     for lp in loops:
         assert rel_err(lp.eps, eps) < 1e-12
         assert rel_err(lp.norms, c.component_norm(eps)) < 1e-12
+
+
+@pytest.mark.parametrize("grid,dims", GRIDS)
+def test_contiguous_stencil_operators_equal_reference_order(grid, dims):
+    """ref_div_contig / ref_eps_contig (z innermost; cpu_baseline's "tuned_loops" figure) against the loop nests in the
+    reference's traversal orders: the same values bit for bit."""
+    import ctypes
+    from oracle.c_oracle import _P, load
+    lib = load()
+    lib.ref_set_threads(3)
+    rng = np.random.default_rng(3)
+    d = [ctypes.c_double(v) for v in dims]
+    tau = rng.standard_normal((6,) + grid)
+    f1, f2 = np.empty((3,) + grid), np.empty((3,) + grid)
+    lib.ref_div(*grid, *d, _P(tau), _P(f1))
+    lib.ref_div_contig(*grid, *d, _P(tau), _P(f2))
+    assert np.array_equal(f1, f2)
+    u = rng.standard_normal((3,) + grid)
+    E = np.array([0.3, -0.2, 0.1, 0.05, -0.07, 0.02])
+    e1, e2 = np.empty((6,) + grid), np.empty((6,) + grid)
+    lib.ref_eps(*grid, *d, _P(E), _P(u), _P(e1))
+    lib.ref_eps_contig(*grid, *d, _P(E), _P(u), _P(e2))
+    assert np.array_equal(e1, e2)
