@@ -333,7 +333,8 @@ def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
     per_socket = (cores // sockets) if cores and sockets else None
     limits = cpu_limits()
     usable = min(x for x in (ncpu, limits["affinity_cpus"], limits["cgroup_quota_cpus"]) if x)
-    counts = sorted({t for t in (8, 16, 32, per_socket or 64, cores or ncpu) if t and t <= ncpu})
+    # thread counts up to what the node grants (a CFS quota of 16 CPUs makes 32 threads slower than 16: throttling, not the code)
+    counts = sorted({t for t in (4, 8, 16, 32, per_socket or 64, cores or ncpu, int(usable)) if t and t <= usable})
     thr0 = cpu_throttled()
     t_start = time.perf_counter()
     tmp = tempfile.mkdtemp(prefix="fg_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -398,7 +399,9 @@ def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
                                 "difference nests z-OUTERMOST (F:18864-18887, F:18646-18675): strided inner loops, and neighbouring z -- "
                                 "one cache line -- on different threads; `value` keeps those orders because they are the reference's "
                                 "OpenMP path",
-            "note": ("it/s grows with the thread count over the sweep" if monotone else
+            "note": ("the node grants this process %g CPUs (affinity %s, cgroup quota %s of %d logical CPUs): the sweep stops there; "
+                     % (usable, limits["affinity_cpus"], limits["cgroup_quota_cpus"], ncpu)) +
+                    ("it/s grows with the thread count over the sweep" if monotone else
                      "does not scale over the whole sweep: best at %d of %s threads" % (best, "/".join(str(k) for k in counts))) +
                     "; cpu_GBps prices a pass at the reference's 632 B/voxel (SURVEY 8d)",
             "sample": "passes of the same %dx%dx%d RVE for <= 3 s per thread count (%s threads; value = best; every count in a "

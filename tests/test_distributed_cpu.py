@@ -18,6 +18,14 @@ def launch(nproc, out, *args, timeout=600):
     (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port) -- started directly: the elastic
     launcher of `python -m torch.distributed.run` costs an interpreter start and a torch import of its own per test, and the
     GPU suite launches sixty of these.  Raises CalledProcessError (with the failing rank's stderr) like subprocess.run(check=True)."""
+    if os.environ.get("FG_TEST_LAUNCHER") == "torchrun":   # the elastic launcher, for comparison
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+        port = str(29500 + (os.getpid() % 2000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "dist_worker.py"),
+               "--out", out, *args]
+        subprocess.run(cmd, check=True, env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        return [np.load(out + ".%d.npz" % r) for r in range(nproc)]
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
