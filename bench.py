@@ -547,8 +547,8 @@ def main():
                     help="N = 1: also run the slab driver with this many slabs on the one GPU (0 = skip)")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the load-case replica measurement")
     ap.add_argument("--slab-timeout", type=int, default=300)
-    ap.add_argument("--also-slab", default="512:laminate",
-                    help="N > 1: one more slab-decomposed workload n:mixing after the headline one, reported under `also_slab` "
+    ap.add_argument("--also-slab", default="128:voigt,512:laminate",
+                    help="N > 1: further slab-decomposed workloads n:mixing[,n:mixing...] after the headline one, reported under `also_slab` "
                          "(default: BASELINE's north-star target configuration; '' = none).  Its failure or timeout leaves "
                          "the headline line untouched")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo", "nccl-one-gpu"],
@@ -779,6 +779,12 @@ def main():
             sys.exit(5)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # a host-side group for the last barrier: rank 0 times the CPU path there while the others wait in a socket read (a barrier
+    # of the nccl group would keep one core per waiting rank spinning beside the CPU measurement)
+    try:
+        host_group = dist.new_group(backend="gloo") if args.dist_backend != "gloo" else None
+    except Exception:  # noqa: BLE001
+        host_group = None
     from fibergen_amd import LSSolver
     from fibergen_amd.distributed import DistributedLSSolver
     from fibergen_amd.rve import bench_rve
@@ -921,40 +927,44 @@ def main():
         d.close()
         timer.cancel()
         if args.also_slab and not scalar and not stokes:
-            # the north-star target configuration through the same driver; whatever happens here, the headline line stands
-            def give_up():
-                line["also_slab"] = {args.also_slab: {"error": "exceeded %d s" % args.slab_timeout}}
-                emit(line, 0)
-            timer = threading.Timer(args.slab_timeout, give_up)
-            timer.daemon = True
-            timer.start()
-            try:
-                ne, mix = args.also_slab.split(":")
-                ne = int(ne)
-                if ne % world:
-                    raise RuntimeError("grid not divisible by the number of ranks")
-                # every rank generates its own x-slab of the RVE only (the same values as the full field's)
-                phi2, normals2, par2 = bench_rve(ne, mix, x_range=(rank * (ne // world), (rank + 1) * (ne // world)))
-                d2 = DistributedLSSolver(ne, ne, ne, device=local_rank)
-                configure(d2, phi2, normals2, mix, "elasticity")
-                del phi2, normals2
-                d2.calc_ref_material()
-                split2, split_trials2 = tune_exchange_mode(d2, E)
-                steps2 = max(5, args.steps // 2) if ne >= 512 else args.steps
-                dts2 = timed_regions(lambda k: d2.iterate(E, k), lambda: sync_all(d2), steps2, min(args.warmup, 3), 3)
-                med2 = max_over_ranks(statistics.median(dts2))
-                kern2, _, cnt2 = kernel_table(d2, E, (ne // world, ne, ne), min(steps2, 10), False)
-                xt2 = exchange_times(d2, cnt2)
-                line["also_slab"] = {"%d^3 %s" % (ne, mix): {
-                    "it_s": steps2 / med2, "ms_per_step": 1e3 * med2 / steps2, "steps": steps2, "repeats": 3,
-                    "rve": {"K": par2["K"], "R": par2["R"], "L": par2["L"]}, "transport": d2.transport,
-                    "slab_split": split2, "slab_split_trials": split_trials2,
-                    "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern2.items()},
-                    "alltoall_ms": xt2["alltoall_fwd"] + xt2["alltoall_bwd"], "exchange_ms_per_pass": xt2,
-                    "alltoall_MB_per_gpu_per_pass": 2 * 3 * (world - 1) / world * (ne // world) * ne * (ne // 2 + 1) * 16 / 1e6}}
-                d2.close()
-            except Exception as e:  # noqa: BLE001
-                line["also_slab"] = {args.also_slab: {"error": "%s: %s" % (type(e).__name__, e)}}
+            # the other BASELINE grids (128^3; 512^3 laminate = the north-star target configuration) through the same driver, one
+            # after the other; whatever happens here, the headline line stands
+            line["also_slab"] = {}
+            for item in [a for a in args.also_slab.split(",") if a]:
+                def give_up(item=item):
+                    line["also_slab"][item] = {"error": "exceeded %d s" % args.slab_timeout}
+                    emit(line, 0)
+                timer = threading.Timer(args.slab_timeout, give_up)
+                timer.daemon = True
+                timer.start()
+                try:
+                    ne, mix = item.split(":")
+                    ne = int(ne)
+                    if ne % world:
+                        raise RuntimeError("grid not divisible by the number of ranks")
+                    # every rank generates its own x-slab of the RVE only (the same values as the full field's)
+                    phi2, normals2, par2 = bench_rve(ne, mix, x_range=(rank * (ne // world), (rank + 1) * (ne // world)))
+                    d2 = DistributedLSSolver(ne, ne, ne, device=local_rank)
+                    configure(d2, phi2, normals2, mix, "elasticity")
+                    del phi2, normals2
+                    d2.calc_ref_material()
+                    split2, split_trials2 = tune_exchange_mode(d2, E)
+                    steps2 = max(5, args.steps // 2) if ne >= 512 else args.steps
+                    dts2 = timed_regions(lambda k: d2.iterate(E, k), lambda: sync_all(d2), steps2, min(args.warmup, 3), 3)
+                    med2 = max_over_ranks(statistics.median(dts2))
+                    kern2, _, cnt2 = kernel_table(d2, E, (ne // world, ne, ne), min(steps2, 10), False)
+                    xt2 = exchange_times(d2, cnt2)
+                    line["also_slab"]["%d^3 %s" % (ne, mix)] = {
+                        "it_s": steps2 / med2, "ms_per_step": 1e3 * med2 / steps2, "steps": steps2, "repeats": 3,
+                        "rve": {"K": par2["K"], "R": par2["R"], "L": par2["L"]}, "transport": d2.transport,
+                        "slab_split": split2, "slab_split_trials": split_trials2,
+                        "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern2.items()},
+                        "alltoall_ms": xt2["alltoall_fwd"] + xt2["alltoall_bwd"], "exchange_ms_per_pass": xt2,
+                        "alltoall_MB_per_gpu_per_pass": 2 * 3 * (world - 1) / world * (ne // world) * ne * (ne // 2 + 1) * 16 / 1e6}
+                    d2.close()
+                except Exception as e:  # noqa: BLE001
+                    line["also_slab"][item] = {"error": "%s: %s" % (type(e).__name__, e)}
+                timer.cancel()
     except Exception as e:  # noqa: BLE001
         line.update({"value": None, "ms_per_step": None, "scaling": "strong", "replicas": replicas,
                      "slab": {"error": "%s: %s" % (type(e).__name__, e)}})
@@ -963,6 +973,10 @@ def main():
         timer.cancel()
         emit(line, 4)
     timer.cancel()
+    try:
+        torch.cuda.synchronize(local_rank)
+    except Exception:  # noqa: BLE001
+        pass
     if rank == 0 and not args.no_cpu_baseline and not scalar and not stokes:
         # north_star's table for N > 1: the CPU path timed in this same run (rank 0, every solver closed; the other ranks wait
         # at the barrier below) and it/s per grid beside it
@@ -982,7 +996,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     try:
-        dist.barrier()
+        dist.barrier(group=host_group) if host_group is not None else dist.barrier()
         dist.destroy_process_group()
     except Exception:  # noqa: BLE001
         pass

@@ -755,3 +755,19 @@ def test_plane_fft_equals_the_separate_passes(grid, mode, mixing):
         o.run(E)
         assert np.abs(out[0][0] - np.array(o.residuals)).max() < 1e-11
         assert rel_err(out[0][1], o.eps) < 1e-11
+
+
+def test_counters_report_the_laminate_lists():
+    """fg_get_counter: the lengths of the laminate correction's voxel lists (what bench.py prices its kernels with); unknown
+    names give -1."""
+    from helpers import two_phase_setup
+    grid = (16, 16, 128)
+    s = make_gpu_solver(grid, mixing="laminate", tol=1e-6)
+    assert s.counter("interface_voxels") == 0 and s.counter("no_such_counter") == -1
+    assert s.run(np.array([1.0, 0, 0, 0, 0, 0.5])) is False
+    _, phis, _ = two_phase_setup(grid, "laminate")
+    mixed = int((((phis[0] != 0) & (phis[0] != 1)) | ((phis[1] != 0) & (phis[1] != 1))).sum())   # k_mixed_list's criterion
+    assert s.counter("interface_voxels") == mixed > 0
+    # every interface voxel is affected, and so are its six stencil neighbours at most
+    assert mixed <= s.counter("affected_voxels") <= 7 * mixed
+    s.close()
