@@ -188,6 +188,8 @@ def live_traffic(args, slot):
     prof = shutil.which("rocprofv3")
     if not prof:
         return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler: no nested counter passes"
 
     def matches(name, w):   # "k_x": the name before its template list; "k_x<...": a prefix, `*` = any run of characters
         name = name[name.index("k_"):] if "k_" in name else name

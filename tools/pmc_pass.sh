@@ -8,6 +8,6 @@ export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag
 rm -rf "$out"
 timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out" -- \
-  python3 bench.py --n "$n" --mixing "$mix" --steps 3 --warmup 1 --repeats 1 --sustain-s 0.05 --also "" --slab-members 0 \
+  python3 bench.py --n "$n" --mixing "$mix" --steps 3 --warmup 1 --repeats 1 --sustain-s 0.05 --also "" --slab-members 0 --no-live-traffic \
   --no-cpu-baseline > gpurun_out/pmc_$tag.log 2>&1
 echo "pmc $tag rc=$?"

@@ -8,7 +8,7 @@ out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- \
   python3 bench.py --n "$n" --mixing "$mix" --steps 20 --warmup 3 --repeats 3 --sustain-s 0.5 --also "" --slab-members 0 \
-  --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
+  --no-cpu-baseline --no-live-traffic > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
 echo "stats rc=$?"
 cp $(find "$out/stats" -name "*kernel_stats.csv" | head -1) "$out/kernel_stats.csv" 2>/dev/null
 tools/pmc_pass.sh ${tag}_fetch "$n" "$mix" FETCH_SIZE
