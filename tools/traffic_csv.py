@@ -4,6 +4,11 @@ FETCH_SIZE is doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.
 import csv, glob, sys, collections, re
 
 def short(name):
+    # the tiled sweeps keep their template arguments: k_u_tile<.., CGP = true> (the CG's direction update inside the sweep) moves
+    # other bytes than the basic scheme's k_u_tile<.., false>
+    m = re.search(r"(k_(?:u|cgu|sc|sc_cgu|eps)_tile<[^>]*>)", name)
+    if m:
+        return m.group(1)
     m = re.search(r"(k_[a-z0-9_]+(<[A-Za-z0-9_:]+<[^>]*>)?)", name)
     return m.group(1) if m else name[:60]
 
