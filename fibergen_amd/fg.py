@@ -909,6 +909,56 @@ class FG:
             self._laminate_Ceff = C
             log.info("Effective stiffness matrix (Voigt notation):\n%s", C)
             return None
+        if name == "calc_HS_bounds":
+            # Hashin-Shtrikman bounds of a two-phase isotropic mixture  F:25730-25742, HashinBounds::get F:7463-7484; the two
+            # materials are read with the postfixes "1" / "2" (Material("", "1").readSettings: mu1 + lambda1, E1 + nu1, ..., phi1)
+            ms = []
+            for post in ("1", "2"):
+                attrs = {k[:-1]: v for k, v in act.attrib.items() if k.endswith(post) and k[:-1] in _materials.NAMES}
+                c = _materials.material_constants(attrs, self._eval)
+                ms.append((c["mu"], c["lambda"], self._eval(act.attrib.get("phi" + post, "0"))))
+            (mu1, l1, p1), (mu2, l2, p2) = ms
+            k1, k2 = l1 + 2.0 / 3.0 * mu1, l2 + 2.0 / 3.0 * mu2
+            kl = k2 + p1 * (k1 - k2) * (k2 + 4.0 / 3.0 * mu2) / (k2 + 4.0 / 3.0 * mu2 + p2 * (k1 - k2))
+            ku = k1 + p2 * (k2 - k1) * (k1 + 4.0 / 3.0 * mu1) / (k1 + 4.0 / 3.0 * mu1 + p1 * (k2 - k1))
+            if ku < kl:
+                kl, ku = ku, kl
+            mul = mu2 + p1 * (mu1 - mu2) / (1 + 2 * p2 * (mu1 - mu2) / (5 * mu2) + 4 * p2 * (mu1 - mu2) / (15 * k2 + 20 * mu2))
+            muu = mu1 + p2 * (mu2 - mu1) / (1 + 2 * p1 * (mu2 - mu1) / (5 * mu1) + 4 * p1 * (mu2 - mu1) / (15 * k1 + 20 * mu1))
+            if muu < mul:
+                mul, muu = muu, mul
+            self._hs_bounds = {"lower": {"K": kl, "mu": mul, "lambda": kl - 2.0 / 3.0 * mul},
+                               "upper": {"K": ku, "mu": muu, "lambda": ku - 2.0 / 3.0 * muu}}
+            log.info("HS lower bounds: K=%g mu=%g lambda=%g", kl, mul, kl - 2.0 / 3.0 * mul)
+            log.info("HS upper bounds: K=%g mu=%g lambda=%g", ku, muu, ku - 2.0 / 3.0 * muu)
+            return None
+        if name == "write_voxel_data":
+            # LSSolver::writeData  F:17076-17126: one tab-separated row per voxel (x slowest): indices, the normal if the
+            # project carries normals, one column per material with its volume fraction
+            fn = self._attr(act, "filename", None, str)
+            if not fn:
+                raise RuntimeError("write_voxel_data: filename missing")
+            self.init_lss()
+            self.init_phase()
+            nx, ny, nz = self._lss.shape
+            cols = [np.repeat(np.arange(nx), ny * nz), np.tile(np.repeat(np.arange(ny), nz), nx), np.tile(np.arange(nz), nx * ny)]
+            head = ["i_x", "i_y", "i_z"]
+            if self._normals is not None:
+                head += ["n_x", "n_y", "n_z"]
+                cols += [np.asarray(self._normals[c]).reshape(-1) for c in range(3)]
+            head += list(self._phase_names)
+            cols += [np.asarray(self._phi[m]).reshape(-1) for m in range(len(self._phase_names))]
+            with open(fn, "w") as f:
+                f.write("\t".join(head))
+                for row in zip(*cols):
+                    f.write("\n" + "\t".join(("%d" % v) if i < 3 else ("%g" % v) for i, v in enumerate(row)))
+            return None
+        if name in ("init_fibers", "tune_num_threads"):
+            # init_fibers F:25615-25618: placed fibres need no generation (the random generator is out of scope);
+            # tune_num_threads F:25774-25780 tunes the OpenMP team of the CPU solver: nothing to tune on the GPU path
+            if name == "tune_num_threads":
+                self.init_lss()
+            return None
         if name == "python":
             self._exec_python(act.text or "")
             return None

@@ -156,3 +156,29 @@ def test_orientation_moments_of_placed_fibres():
     ref4 = sum(np.einsum("i,j,k,l->ijkl", a, a, a, a) for a in axes)
     assert A4.shape == (3, 3, 3, 3) and np.allclose(A4, ref4 / 3.0)      # the contraction of each unit axis' term has trace 1
     assert np.allclose(np.einsum("iikl->kl", A4), A2)                     # A4_iikl = A2 for unit axes
+
+
+def test_calc_hs_bounds_action_and_the_hashin_demo_constant():
+    """<calc_HS_bounds> (F:25730-25742, HashinBounds::get F:7463-7484).  Reference-held pin: the Hashin demo's matrix is chosen so
+    that its bulk modulus equals the coated sphere's -- `k_star = 4.305343511446667 (theoretical)` in
+    demo/elasticity/hashin/project.xml:32 -- and the coated-sphere assemblage attains the Hashin-Shtrikman bound of (core,
+    coating) at the core's volume share (0.2 / 0.4)^3."""
+    fg = FG.__new__(FG)        # the action needs no solver and no device
+    fg._project = None
+    import xml.etree.ElementTree as ET
+    act = ET.fromstring('<calc_HS_bounds mu1="5" lambda1="4" phi1="0.125" mu2="3" lambda2="2" phi2="0.875" />')
+    fg._eval = lambda text, typ=float: typ(float(text))
+    assert fg._run_action(act) is None
+    lo, hi = fg._hs_bounds["lower"], fg._hs_bounds["upper"]
+    assert lo["K"] <= hi["K"] and lo["mu"] <= hi["mu"]
+    assert lo["K"] == pytest.approx(4.305343511446667, rel=1e-11)          # the demo's k_star (its lambda is given to 12 digits)
+    assert lo["K"] == pytest.approx(3.63867684478 + 2.0 / 3.0, rel=1e-11)   # = lambda_matrix + 2/3 mu_matrix of the demo
+    assert lo["lambda"] == pytest.approx(lo["K"] - 2.0 / 3.0 * lo["mu"], rel=1e-15)
+    # one phase only: both bounds are that material; other constant pairs are read like any material (E, nu)
+    act = ET.fromstring('<calc_HS_bounds E1="10" nu1="0.2" phi1="1" mu2="3" lambda2="2" phi2="0" />')
+    fg._run_action(act)
+    c = materials.material_constants({"E": 10, "nu": 0.2})
+    for b in ("lower", "upper"):
+        assert fg._hs_bounds[b]["K"] == pytest.approx(c["K"], rel=1e-14) and fg._hs_bounds[b]["mu"] == pytest.approx(c["mu"], rel=1e-14)
+    with pytest.raises(RuntimeError, match="Incomplete material definition"):
+        fg._run_action(ET.fromstring('<calc_HS_bounds mu1="5" phi1="0.5" mu2="3" lambda2="2" phi2="0.5" />'))

@@ -407,3 +407,29 @@ def test_example_run_project_script(tmp_path, launch):
     vals = np.array(eval(line[0].split(":", 1)[1]))   # noqa: S307 -- our own script's printed list
     assert np.isfinite(vals).all() and vals.flat[0] > 0
     (tmp_path / ("ms_%s.txt" % launch)).write_text(line[0])
+
+
+def test_small_caller_side_actions(tmp_path):
+    """<calc_HS_bounds>, <write_voxel_data> (LSSolver::writeData F:17076-17126), <init_fibers>, <tune_num_threads> in a project:
+    the Hashin-Shtrikman bound of (core, coating) brackets the computed stiffness of a two-phase cell, the voxel table has one row
+    per voxel with the phase columns summing to one."""
+    out = tmp_path / "voxels.txt"
+    fg = FG()
+    fg.set_xml("""<settings><solver n="16"><tol>1e-8</tol><method>cg</method>
+      <materials><matrix mu="3" lambda="2" /><core mu="5" lambda="4" /></materials></solver>
+      <actions><init_fibers /><tune_num_threads tmeas="0.01" />
+        <select_material name="core" /><place_fiber R="0.3" />
+        <calc_HS_bounds mu1="5" lambda1="4" phi1="0.1131" mu2="3" lambda2="2" phi2="0.8869" />
+        <run_load_case e11="1" e22="1" e33="1" />
+        <write_voxel_data filename="%s" /></actions></settings>""" % out)
+    assert fg.run() == 0
+    k_eff = np.array(fg.get_mean_stress())[:3].mean() / 3
+    vf = fg.get_volume_fraction("core")
+    assert vf == pytest.approx(0.1131, rel=2e-2)
+    lo, hi = fg._hs_bounds["lower"]["K"], fg._hs_bounds["upper"]["K"]
+    assert lo * (1 - 2e-3) <= k_eff <= hi * (1 + 2e-3)     # (fractions rounded to four digits, voxelised sphere)
+    rows = out.read_text().split("\n")
+    assert rows[0].split("\t") == ["i_x", "i_y", "i_z", "matrix", "core"] and len(rows) == 1 + 16 ** 3
+    tab = np.array([[float(v) for v in r.split("\t")] for r in rows[1:]])
+    assert np.array_equal(tab[:, 2], np.tile(np.arange(16), 256)) and np.array_equal(tab[:, 0], np.repeat(np.arange(16), 256))
+    assert np.abs(tab[:, 3] + tab[:, 4] - 1).max() < 1e-5 and tab[:, 4].mean() == pytest.approx(vf, rel=1e-4)
