@@ -235,3 +235,43 @@ def test_cg_512_laminate_three_iterations():
     if psutil.virtual_memory().available < 128 * 2 ** 30:
         pytest.skip("needs ~100 GB of free host memory for the 512^3 CG checker")
     _cg_against_cref(512, "laminate", 3, fused_forms=(1,))
+
+
+# ---- large NON-cubic grids with mixed-radix axes (p 2^k lengths: 3 * 64, 5 * 32, 25 * 8) and every tile shape of the sweep
+#      (nz/2 = 64: one wave per row, 128: two, 96: halo lanes), against the C loop nests like the cubes above
+@pytest.mark.parametrize("grid,dims,mixing", [
+    ((192, 160, 128), (1.0, 1.0, 1.0), "voigt"),       # x = 3 * 64, y = 5 * 32; a z row is one wave
+    ((96, 200, 256), (1.5, 1.0, 2.0), "laminate"),     # y = 25 * 8; a z row is two waves; anisotropic cell
+    ((160, 96, 192), (1.0, 2.0, 1.0), "laminate"),     # z = 2 * 96 = 2 * 3 * 32: packed rows of a mixed-radix length, halo-lane tiles
+])
+def test_large_noncubic_mixed_radix_grids_three_passes(grid, dims, mixing):
+    from helpers import two_phase_setup
+    from fibergen_amd import LSSolver
+    from oracle.c_oracle import CRef
+    import os
+    mats, phis, normals = two_phase_setup(grid, mixing)
+    s = LSSolver(*grid, *dims)
+    s.set_num_phases(2)
+    for p in range(2):
+        s.set_phase(p, mats[p][0], mats[p][1], phis[p])
+    s.set_normals(normals)
+    s.set_options(mixing_rule=mixing)
+    mu_0, lam_0 = s.calc_ref_material()
+    x = [(np.arange(n) + 0.5) / n for n in grid]
+    w = np.sin(2 * np.pi * x[0])[:, None, None] * np.cos(4 * np.pi * x[1])[None, :, None] + 0.5 * np.sin(6 * np.pi * x[2])[None, None, :]
+    eps0 = np.empty((6,) + grid)
+    for c in range(6):
+        eps0[c] = E_LOAD[c] + 0.05 * (c + 1) * phis[1] + 0.02 * (6 - c) * w
+    s.set_field("epsilon", eps0)
+    s.iterate(E_LOAD, 3)
+    got = s.get_field("epsilon")
+    sumsq = s.get_field("sumsq")
+    s.close()
+    c = CRef(grid, dims, mats, phis, normals, mixing, threads=min(16, os.cpu_count() or 1))
+    eps, prev = eps0, None
+    for _ in range(3):
+        prev = eps
+        eps = c.basic_scheme(E_LOAD, eps, mu_0, lam_0)
+    assert rel_err(got, eps) < 1e-11
+    want = (c.component_norm(prev) ** 2) * float(np.prod(grid))
+    assert np.abs(sumsq / want - 1).max() < 1e-12
