@@ -115,3 +115,20 @@ def test_hbm_stream_helper():
     assert lib.fg_hbm_stream(0, 512, 2, ctypes.byref(c), ctypes.byref(t)) == 0
     assert 1000.0 < c.value < 8000.0 and 1000.0 < t.value < 8000.0
     assert lib.fg_hbm_stream(0, 0, 1, ctypes.byref(c), ctypes.byref(t)) != 0   # bad size: error code, no exception
+
+
+def test_runs_are_reproducible_bit_for_bit():
+    """The reductions of the loop are fixed-order (DPP folds inside a wave, fixed fold over the workgroups, no float atomics) and
+    the laminate correction has one writer per voxel: two runs of the same problem on fresh solvers give the same residual
+    history, strain field and mean stress bit for bit -- basic scheme and CG, Voigt and laminate mixing."""
+    from helpers import make_gpu_solver
+    E = np.array([1.0, 0.0, 0.0, 0.0, 0.0, 0.5])
+    for mixing, method in (("voigt", "basic"), ("laminate", "basic"), ("laminate", "cg")):
+        out = []
+        for _ in range(2):
+            s = make_gpu_solver((64, 48, 128), mixing=mixing, tol=1e-7, method=method)
+            assert s.run(E) is False
+            out.append((np.array(s.residuals), s.get_field("epsilon"), s.mean_stress().copy()))
+            s.close()
+        assert np.array_equal(out[0][0], out[1][0]), (mixing, method)
+        assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]), (mixing, method)

@@ -275,3 +275,57 @@ def test_large_noncubic_mixed_radix_grids_three_passes(grid, dims, mixing):
     assert rel_err(got, eps) < 1e-11
     want = (c.component_norm(prev) ** 2) * float(np.prod(grid))
     assert np.abs(sumsq / want - 1).max() < 1e-12
+
+
+def test_cg_on_large_noncubic_grid_three_iterations():
+    """runCGElasticity on a mixed-radix non-cubic grid (y = 25 * 8, two waves per z row, laminate mixing, anisotropic cell)
+    against CRefCG: fused and four-kernel form."""
+    from helpers import two_phase_setup
+    from fibergen_amd import LSSolver
+    from oracle.c_oracle import CRefCG
+    import os
+    grid, dims, mixing, iters = (96, 200, 256), (1.5, 1.0, 2.0), "laminate", 3
+    mats, phis, normals = two_phase_setup(grid, mixing)
+    got = {}
+    for fused in (1, 0):
+        s = LSSolver(*grid, *dims)
+        s.set_num_phases(2)
+        for p in range(2):
+            s.set_phase(p, mats[p][0], mats[p][1], phis[p])
+        s.set_normals(normals)
+        s.set_options(mixing_rule=mixing, method="cg", tol=0.0, abs_tol=0.0, maxiter=iters, cg_fused=fused)
+        assert s.run(E_LOAD) is False and s.iterations == iters
+        got[fused] = (s.ref_material, np.array(s.residuals), s.get_field("epsilon"))
+        s.close()
+    c = CRefCG(grid, dims, mats, phis, normals, mixing, threads=min(16, os.cpu_count() or 1))
+    eps, residuals, it = c.run_cg(E_LOAD, *got[1][0], maxiter=iters)
+    assert it == iters
+    for fused in (1, 0):
+        assert np.abs(got[fused][1] - np.array(residuals)).max() < 1e-11
+        assert rel_err(got[fused][2], eps) < 1e-10
+
+
+def test_porous_mode_on_large_noncubic_grid_four_passes():
+    """The scalar modes on a mixed-radix non-cubic grid (x = 3 * 64, y = 5 * 32) against the C loop nests."""
+    from helpers import sphere_phi
+    from fibergen_amd import LSSolver
+    from oracle.c_oracle import CRefScalar
+    grid, dims = (192, 160, 128), (1.0, 2.0, 1.5)
+    phi = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 10.0], [1.0 - phi, phi]
+    E = np.array([1.0, -0.5, 0.25])
+    s = LSSolver(*grid, *dims)
+    s.set_options(mode="porous")
+    s.set_num_phases(2)
+    for p in range(2):
+        s.set_phase(p, mus[p], 0.0, phis[p])
+    s.set_options(tol=0.0, abs_tol=0.0, maxiter=4)
+    assert s.run(E) is False and s.iterations == 4
+    mu_0, _ = s.ref_material
+    got = s.get_field("epsilon")
+    s.close()
+    c = CRefScalar(grid, dims, mus, phis, threads=_threads())
+    g = np.zeros((3,) + grid)
+    for _ in range(4):
+        g = c.basic_scheme(E, g, mu_0)
+    assert rel_err(got, g) < 1e-11
