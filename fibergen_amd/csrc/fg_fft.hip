@@ -886,7 +886,7 @@ void launch_z(const ZArgs& a, int ncomp, long comp_stride, int lines, hipStream_
   FG_HIP_CHECK(hipGetLastError());
 }
 
-template <int N, int C, int NC, bool XSPLIT = false>
+template <int N, int C, int NC, bool XSPLIT = false, int NTC = -1>
 void xfused_nc(XFusedArgs a, int nouter, hipStream_t s);
 
 template <int N>
@@ -903,13 +903,18 @@ void xfused_n(XFusedArgs a, int nouter, int ncomp, hipStream_t s) {
   } else {
     if (ncomp == 1) xfused_nc<N, XTileCols<N>::value, 1>(a, nouter, s);
     else if (a.xjump != 0) xfused_nc<N, 8, 3, true>(a, nouter, s);   // slab decomposition, components interleaved per peer
+    // cache-resident grids with short lines: the tile's loads without branches and all issued up front, so that the first
+    // component's transform starts when ITS eight loads have landed (s_waitcnt vmcnt(16)) instead of after all 24 -- r5, one job:
+    // K4 at 128^3 31.5 -> 28.5 us (7 560 -> 7 705 it/s), 64^3 10.0 -> 9.3 us (+1.2 %); 256^3 and 512^3 (streaming, nt = 3)
+    // measured equal and keep the run-time flags
+    else if ((N == 64 || N == 128) && a.nt == 0) xfused_nc<N, 8, 3, false, ((N == 64 || N == 128) ? 16 : -1)>(a, nouter, s);
     else xfused_nc<N, 8, 3>(a, nouter, s);
   }
 }
 
-template <int N, int C, int NC, bool XSPLIT>
+template <int N, int C, int NC, bool XSPLIT, int NTC>
 void xfused_nc(XFusedArgs a, int nouter, hipStream_t s) {
-  using K = XFusedKernel<N, C, NC, XSPLIT>;
+  using K = XFusedKernel<N, C, NC, XSPLIT, NTC>;
   static PerDeviceOnce configured;
   const size_t lds = K::LDS_DOUBLES * sizeof(double);
   if (auto once = configured.first_use()) {

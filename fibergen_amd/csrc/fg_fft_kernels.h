@@ -355,7 +355,10 @@ struct XFusedArgs {
 
 // NC = 3: the three components of the elastic problem and G0OperatorFourierStaggeredGeneral; NC = 1: the scalar modes
 // (one potential, G0OperatorFourierStaggeredGeneralHeat  F:19779-19823: c1 = c10 / |k|^2).
-template <int N, int C, int NC = 3, bool XSPLIT = false>
+// NTC >= 0: the streaming flags are the compile-time constant NTC and the loads of a tile carry no branch (columns past the
+// end read the tile's first column and are never stored), so that the first transform waits for ITS component's loads only
+// (s_waitcnt vmcnt(16)) instead of for all of them; NTC = -1: flags from XFusedArgs::nt at run time.
+template <int N, int C, int NC = 3, bool XSPLIT = false, int NTC = -1>
 struct XFusedKernel {
   static constexpr int T = N / 8;
   static constexpr int THREADS = T * C;
@@ -430,9 +433,19 @@ struct XFusedKernel {
         {
           const int j = Line<N>::first_index(r.jt, q);
           const long off = (long)j * a.ls + (XSPLIT ? (long)(j >> a.xsplit) * a.xjump : 0L);
-          r.v[c][q] = r.valid ? cload_stream(&a.data[c * a.comp_stride + r.base + off], a.nt) : cmake(0.0, 0.0);
+          if constexpr (NTC >= 0) {
+            const long lbase = r.valid ? r.base : r.base - r.t;
+            r.v[c][q] = cload_stream(&a.data[c * a.comp_stride + lbase + off], NTC & 3);
+          } else {
+            r.v[c][q] = r.valid ? cload_stream(&a.data[c * a.comp_stride + r.base + off], a.nt) : cmake(0.0, 0.0);
+          }
         }
       }
+#if defined(__HIP_DEVICE_COMPILE__)
+      // (NTC & 16: all loads of the tile are issued before anything else -- the scheduler otherwise sinks the loads of the
+      // second and third component behind the first pass of the first)
+      if constexpr (NTC >= 0 && (NTC & 16) != 0) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     if (TR < NC) {
       Line<N>::template phase<-1, LP>(r.v[comp], r.jt, lds, L, r.t, tw);
@@ -500,7 +513,7 @@ struct XFusedKernel {
         for (int q = 0; q < 8; ++q) {
           const int j = Line<N>::last_index(r.jt, q);
           const long off = (long)j * a.ls + (XSPLIT ? (long)(j >> a.xsplit) * a.xjump : 0L);
-          cstore_stream(&a.data[comp * a.comp_stride + r.base + off], r.v[comp][q], a.nt);
+          cstore_stream(&a.data[comp * a.comp_stride + r.base + off], r.v[comp][q], NTC >= 0 ? (NTC & 3) : a.nt);
         }
       }
     }
