@@ -901,7 +901,11 @@ void xfused_n(XFusedArgs a, int nouter, int ncomp, hipStream_t s) {
     else if (a.xjump != 0) throw std::runtime_error("fft: interleaved slab layout: x lines up to 512");
     else xfused_nc<N, 4, 3>(a, nouter, s);
   } else {
-    if (ncomp == 1) xfused_nc<N, XTileCols<N>::value, 1>(a, nouter, s);
+    // (r5: the scalar modes' pass keeps its pass twiddles in LDS like the three-component one -- XFusedKernel::TW_LDS -- 256^3 porous
+    // K4 0.083 -> 0.073 ms, 2 765 -> 2 830 it/s; on cache-resident grids also the branch-free loads, 128^3 porous 14 030 -> 14 370)
+    if (ncomp == 1 && (N == 64 || N == 128) && a.nt == 0)
+      xfused_nc<N, XTileCols<N>::value, 1, false, ((N == 64 || N == 128) ? 16 : -1)>(a, nouter, s);
+    else if (ncomp == 1) xfused_nc<N, XTileCols<N>::value, 1>(a, nouter, s);
     else if (a.xjump != 0) xfused_nc<N, 8, 3, true>(a, nouter, s);   // slab decomposition, components interleaved per peer
     // cache-resident grids with short lines: the tile's loads without branches and all issued up front, so that the first
     // component's transform starts when ITS eight loads have landed (s_waitcnt vmcnt(16)) instead of after all 24 -- r5, one job:

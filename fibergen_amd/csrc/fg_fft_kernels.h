@@ -373,7 +373,7 @@ struct XFusedKernel {
   // stores, so every twiddled pass waited for the stores of the previous component to be acknowledged
   // (N = 512: 2.55 -> 1.85 ms; for the same reason a workgroup handles ONE tile: in a loop over tiles the next
   // tile's loads would queue behind the stores of the previous one).
-  static constexpr bool TW_LDS = N >= 64 && NC == 3;
+  static constexpr bool TW_LDS = N >= 64;   // (r5: for one component too)
   static constexpr int TW_OFF = (PINGPONG ? 2 : 1) * BUF_DOUBLES;
   static constexpr int LDS_DOUBLES = TW_OFF + (TW_LDS ? 2 * tw_total(N) : 0);
   static constexpr int NPHASE = 2 * NC * NPL;   // NC forward + NC inverse transforms

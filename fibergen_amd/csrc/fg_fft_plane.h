@@ -43,52 +43,19 @@ struct PlaneGeom {
   static constexpr int NPZ = Line<M>::NPHASE, NPY = Line<NY>::NPHASE;
   FG_HD static LdsMap zmap() { return LdsMap{1, LZ, LZ * NY}; }
   FG_HD static LdsMap ymap() { return LdsMap{M + 1, 1, PY * (M + 1)}; }
-  // The pass twiddles of both transforms and the roots of the real split behind the plane image (128 x 128: 4.7 KB of the 12 KB
-  // the image leaves free).  A workgroup is alone on its CU, so every table read through the vector memory path is an exposed
-  // round trip to the L2 between two exchanges (the ISA showed five: "L7 W6 .. W0" after a barrier); from LDS it is a ds_read
-  // (r5, 128^3: plane kernels 33 -> see EXPERIMENTS.md).  Where the tables do not fit, they stay in global memory.
-  static constexpr int TWZ = tw_total(M), TWY = tw_total(NY), NWZ = M + 1;
-  static constexpr int TAB_DOUBLES = 2 * (TWZ + TWY + NWZ);
-  static constexpr bool TAB_LDS = (size_t)(LDS_DOUBLES + TAB_DOUBLES) * sizeof(double) <= 160 * 1024;
-  static constexpr int OFF_TWZ = LDS_DOUBLES, OFF_TWY = OFF_TWZ + 2 * TWZ, OFF_WZ = OFF_TWY + 2 * TWY;
-  static constexpr int LDS_TOTAL = LDS_DOUBLES + (TAB_LDS ? TAB_DOUBLES : 0);
-  FG_HD static const cplx* twz(const double* lds, const PlaneArgs& a) {
-    if constexpr (TAB_LDS) return reinterpret_cast<const cplx*>(lds + OFF_TWZ);
-    else return a.tw_z;
-  }
-  FG_HD static const cplx* twy(const double* lds, const PlaneArgs& a) {
-    if constexpr (TAB_LDS) return reinterpret_cast<const cplx*>(lds + OFF_TWY);
-    else return a.tw_y;
-  }
-  FG_HD static const cplx* wz(const double* lds, const PlaneArgs& a) {
-    if constexpr (TAB_LDS) return reinterpret_cast<const cplx*>(lds + OFF_WZ);
-    else return a.wz;
-  }
-  // phase 0 of both kernels: every thread copies its share (visible after the WORKGROUP barrier that follows phase 0)
-  FG_HD static void stage_tables(int tid, double* lds, const PlaneArgs& a) {
-    if constexpr (TAB_LDS) {
-      cplx* tz = reinterpret_cast<cplx*>(lds + OFF_TWZ);
-      cplx* ty = reinterpret_cast<cplx*>(lds + OFF_TWY);
-      cplx* w = reinterpret_cast<cplx*>(lds + OFF_WZ);
-      for (int i = tid; i < TWZ; i += THREADS) tz[i] = a.tw_z[i];
-      for (int i = tid; i < TWY; i += THREADS) ty[i] = a.tw_y[i];
-      for (int i = tid; i < NWZ; i += THREADS) w[i] = a.wz[i];
-    }
-  }
 };
 
 // forward: real rows -> r2c along z -> c2c along y, in place (fftVector's first two passes, F:18481-18500)
 template <int NY, int M>
 struct ZYKernel {
   using G = PlaneGeom<NY, M>;
-  static constexpr int THREADS = G::THREADS, LDS_DOUBLES = G::LDS_TOTAL;
+  static constexpr int THREADS = G::THREADS, LDS_DOUBLES = G::LDS_DOUBLES;
   static constexpr int NPZ = G::NPZ, NPY = G::NPY, TZ = G::TZ, TY = G::TY;
   static constexpr int PH_SPLIT = NPZ, PH_PUT = NPZ + 1, PH_GATHER_A = NPZ + 2, PH_A = NPZ + 3, PH_GATHER_B = PH_A + NPY,
                        PH_B = PH_GATHER_B + 1, NPHASE = PH_B + NPY;
   // Synchronisation after phase PH: 2 = workgroup barrier, 1 = wave-local fence.  The TZ threads of a row sit in one wave
   // (TZ divides 64), so the z side exchanges inside waves; the columns of the y side span waves; the Nyquist round is wave 0's.
-  // (after phase 0 a workgroup barrier where the tables were staged into LDS by all threads)
-  static constexpr int barrier_after(int PH) { return PH == 0 && G::TAB_LDS ? 2 : (PH < PH_SPLIT ? 1 : (PH < PH_A + NPY - 1 ? 2 : 1)); }
+  static constexpr int barrier_after(int PH) { return PH < PH_SPLIT ? 1 : (PH < PH_A + NPY - 1 ? 2 : 1); }
   struct Regs {
     cplx v[8];
     cplx xm;        // X[M] of the row (jt == 0)
@@ -109,9 +76,8 @@ struct ZYKernel {
         const cplx* in = reinterpret_cast<const cplx*>(r.plane + (long)r.row * a.nzp);
 #pragma unroll
         for (int q = 0; q < 8; ++q) r.v[q] = in[Line<M>::first_index(r.jt, q)];
-        G::stage_tables(tid, lds, a);
       }
-      Line<M>::template phase<-1, PH>(r.v, r.jt, lds, LZm, r.row, G::twz(lds, a));
+      Line<M>::template phase<-1, PH>(r.v, r.jt, lds, LZm, r.row, a.tw_z);
       if (PH == NPZ - 1) {   // natural-order spectrum of the packed row
 #pragma unroll
         for (int q = 0; q < 8; ++q) lds_put(lds, LZm, Line<M>::last_index(r.jt, q), r.row, r.v[q]);
@@ -120,11 +86,11 @@ struct ZYKernel {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int k = r.jt + q * TZ;
-        r.v[q] = r2c_split(lds_get(lds, LZm, k, r.row), lds_get(lds, LZm, (M - k) % M, r.row), G::wz(lds, a)[k]);
+        r.v[q] = r2c_split(lds_get(lds, LZm, k, r.row), lds_get(lds, LZm, (M - k) % M, r.row), a.wz[k]);
       }
       if (r.jt == 0) {
         const cplx z0 = lds_get(lds, LZm, 0, r.row);
-        r.xm = r2c_split(z0, z0, G::wz(lds, a)[M]);   // k = M (Nyquist): Z[M] := Z[0]
+        r.xm = r2c_split(z0, z0, a.wz[M]);   // k = M (Nyquist): Z[M] := Z[0]
       }
     } else if constexpr (PH == PH_PUT) {
 #pragma unroll
@@ -135,7 +101,7 @@ struct ZYKernel {
       for (int q = 0; q < 8; ++q) r.v[q] = lds_get(lds, LYm, Line<NY>::first_index(r.jy, q), r.col);
     } else if constexpr (PH < PH_GATHER_B) {
       constexpr int LP = PH - PH_A;
-      Line<NY>::template phase<-1, LP>(r.v, r.jy, lds, LYm, r.col, G::twy(lds, a));
+      Line<NY>::template phase<-1, LP>(r.v, r.jy, lds, LYm, r.col, a.tw_y);
       if (LP == NPY - 1) store(r, r.jy, r.col, a);
     } else if constexpr (PH == PH_GATHER_B) {
       if (tid < TY) {
@@ -145,7 +111,7 @@ struct ZYKernel {
     } else {
       constexpr int LP = PH - PH_B;
       if (tid < TY) {
-        Line<NY>::template phase<-1, LP>(r.v, tid, lds, LYm, M, G::twy(lds, a));
+        Line<NY>::template phase<-1, LP>(r.v, tid, lds, LYm, M, a.tw_y);
         if (LP == NPY - 1) store(r, tid, M, a);
       }
     }
@@ -162,13 +128,11 @@ struct ZYKernel {
 template <int NY, int M>
 struct YZKernel {
   using G = PlaneGeom<NY, M>;
-  static constexpr int THREADS = G::THREADS, LDS_DOUBLES = G::LDS_TOTAL;
+  static constexpr int THREADS = G::THREADS, LDS_DOUBLES = G::LDS_DOUBLES;
   static constexpr int NPZ = G::NPZ, NPY = G::NPY, TZ = G::TZ, TY = G::TY;
   static constexpr int PH_B = NPY, PH_MERGE = 2 * NPY, PH_Z = 2 * NPY + 1, NPHASE = PH_Z + NPZ;
   // y side: workgroup barriers; the Nyquist round (wave 0 alone) wave-local; both sides of the merge: workgroup; z side: wave-local
-  static constexpr int barrier_after(int PH) {
-    return (PH == 0 && G::TAB_LDS) || PH < NPY - 1 ? 2 : (PH < PH_MERGE - 1 ? 1 : (PH <= PH_MERGE ? 2 : 1));
-  }
+  static constexpr int barrier_after(int PH) { return PH < NPY - 1 ? 2 : (PH < PH_MERGE - 1 ? 1 : (PH <= PH_MERGE ? 2 : 1)); }
   struct Regs {
     cplx v[8];
     double* plane;
@@ -186,9 +150,8 @@ struct YZKernel {
         r.jy = tid / M;
         r.col = tid % M;
         load(r, r.jy, r.col, a);
-        G::stage_tables(tid, lds, a);
       }
-      Line<NY>::template phase<+1, PH>(r.v, r.jy, lds, LYm, r.col, G::twy(lds, a));
+      Line<NY>::template phase<+1, PH>(r.v, r.jy, lds, LYm, r.col, a.tw_y);
       if (PH == NPY - 1) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) lds_put(lds, LYm, Line<NY>::last_index(r.jy, q), r.col, r.v[q]);
@@ -197,7 +160,7 @@ struct YZKernel {
       constexpr int LP = PH - PH_B;
       if (tid < TY) {
         if (LP == 0) load(r, tid, M, a);
-        Line<NY>::template phase<+1, LP>(r.v, tid, lds, LYm, M, G::twy(lds, a));
+        Line<NY>::template phase<+1, LP>(r.v, tid, lds, LYm, M, a.tw_y);
         if (LP == NPY - 1) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) lds_put(lds, LYm, Line<NY>::last_index(tid, q), M, r.v[q]);
@@ -209,11 +172,11 @@ struct YZKernel {
         const int m = Line<M>::first_index(r.jt, q);
         cplx xk = lds_get(lds, LYm, r.row, m), xmk = lds_get(lds, LYm, r.row, M - m);
         if (m == 0) { xk.im = 0.0; xmk.im = 0.0; }   // FFTW's c2r ignores the imaginary parts of the DC and Nyquist bins
-        r.v[q] = c2r_merge(xk, xmk, G::wz(lds, a)[m]);
+        r.v[q] = c2r_merge(xk, xmk, a.wz[m]);
       }
     } else {
       constexpr int LP = PH - PH_Z;
-      Line<M>::template phase<+1, LP>(r.v, r.jt, lds, LZm, r.row, G::twz(lds, a));
+      Line<M>::template phase<+1, LP>(r.v, r.jt, lds, LZm, r.row, a.tw_z);
       if (LP == NPZ - 1) {
         cplx* out = reinterpret_cast<cplx*>(r.plane + (long)r.row * a.nzp);
 #pragma unroll
