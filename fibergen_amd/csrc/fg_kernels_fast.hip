@@ -320,11 +320,14 @@ __global__ __launch_bounds__(TYR * (ZS ? ZS : 1) * 64) void k_u_tile(Grid g, dou
     FG_K1_MARK(1);
     // u two planes ahead (consumed next step); the moduli of this plane are first needed after the LDS exchange
     const long o2 = plane(q + 2), oq = plane(q);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) u2[c] = load_u(c, o2, st + 2 >= 0 && st + 2 < nsteps);
+    // (the moduli first: they are this step's critical load -- loads return in order (vmcnt), and behind the three prefetches of
+    // plane q + 2 the wait for them was `s_waitcnt vmcnt(0)`, now vmcnt(3).  r5, one job, old / new library alternating: 128^3
+    // 7 666-7 690 -> 7 736-7 743 it/s, 256^3 and 512^3 within the noise -- the steps wait on the memory queue, not on one load)
     const double2 Ac = ld2(mod.p[0], oq);
     double2 Bc = Ac;
     if (!PHI2) Bc = ld2(mod.p[1], oq);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u2[c] = load_u(c, o2, st + 2 >= 0 && st + 2 < nsteps);
     // ---- y neighbours of u through LDS
 #pragma unroll
     for (int c = 0; c < 3; ++c) Ub[c][r][li] = uc[c];
