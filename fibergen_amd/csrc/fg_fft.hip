@@ -906,12 +906,17 @@ void xfused_n(XFusedArgs a, int nouter, int ncomp, hipStream_t s) {
     if (ncomp == 1 && (N == 64 || N == 128) && a.nt == 0)
       xfused_nc<N, XTileCols<N>::value, 1, false, ((N == 64 || N == 128) ? 16 : -1)>(a, nouter, s);
     else if (ncomp == 1) xfused_nc<N, XTileCols<N>::value, 1>(a, nouter, s);
+    // Cache-resident fields (nt = 0: three components within the Infinity Cache -- 128^3 and below, and the slabs of 256^3 on 8
+    // GPUs) with lines up to 256 points: the tile's loads without branches and all issued up front, so that the first component's
+    // transform starts when ITS eight loads have landed (s_waitcnt vmcnt(16)) instead of after all 24.  r5, one job each: K4 at
+    // 128^3 31.5 -> 28.5 us (7 560 -> 7 705 it/s), 64^3 10.0 -> 9.3 us; one slab of eight at 256^3 (interleaved layout) 42.6 ->
+    // 38.9 us, 256 x 32 x 256 33.4 -> 30.0 us; 256^3 and 512^3 on one GPU (streaming, nt = 3) measured equal and keep the
+    // run-time flags
+    else if (a.xjump != 0 && (N == 64 || N == 128 || N == 256) && a.nt == 0)
+      xfused_nc<N, 8, 3, true, ((N == 64 || N == 128 || N == 256) ? 16 : -1)>(a, nouter, s);
     else if (a.xjump != 0) xfused_nc<N, 8, 3, true>(a, nouter, s);   // slab decomposition, components interleaved per peer
-    // cache-resident grids with short lines: the tile's loads without branches and all issued up front, so that the first
-    // component's transform starts when ITS eight loads have landed (s_waitcnt vmcnt(16)) instead of after all 24 -- r5, one job:
-    // K4 at 128^3 31.5 -> 28.5 us (7 560 -> 7 705 it/s), 64^3 10.0 -> 9.3 us (+1.2 %); 256^3 and 512^3 (streaming, nt = 3)
-    // measured equal and keep the run-time flags
-    else if ((N == 64 || N == 128) && a.nt == 0) xfused_nc<N, 8, 3, false, ((N == 64 || N == 128) ? 16 : -1)>(a, nouter, s);
+    else if ((N == 64 || N == 128 || N == 256) && a.nt == 0)
+      xfused_nc<N, 8, 3, false, ((N == 64 || N == 128 || N == 256) ? 16 : -1)>(a, nouter, s);
     else xfused_nc<N, 8, 3>(a, nouter, s);
   }
 }
