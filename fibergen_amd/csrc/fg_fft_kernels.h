@@ -366,7 +366,10 @@ struct XFusedKernel {
   static constexpr int NPL = Line<N>::NPHASE;   // phases of one line transform
   // with two exchanges per transform the LDS image is double-buffered: the barrier after a gather
   // can then be dropped (the next scatter goes to the other buffer), 12 instead of 24 per tile
-  static constexpr bool PINGPONG = num_passes(N) == 3;
+  // (one component, lines up to 256: ONE exchange image -- its few registers leave room for a third workgroup per CU, which the
+  // second image's 37 KB of LDS would take away: r5, old / new library alternating in one job, porous mode: 128^3 K4 15.7 -> 13.9 us,
+  // 14 296 -> 14 547 it/s; 256^3 0.0749 -> 0.0724 ms, 2 818 -> 2 838 it/s; 512^3 0.685 -> 0.689 ms: keeps two images)
+  static constexpr bool PINGPONG = num_passes(N) == 3 && (NC == 3 || N >= 512);
   static constexpr int BUF_DOUBLES = 2 * PN * C;
   // The pass twiddles sit in LDS behind the exchange buffers (N = 512: 14 KB, the tile then uses 158 of 160 KB).
   // A twiddle read through the vector memory path shares its in-order counter (vmcnt) with the tile's loads and
