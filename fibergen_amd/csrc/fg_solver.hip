@@ -660,7 +660,7 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
 }
 
 // z and y transforms of a plane in one kernel (grids whose complex z-y plane fits the LDS): option plane_fft (-1 = where
-// available), FG_PLANE_FFT overrides for A/B runs
+// available, 0 = off for A/B runs)
 bool Solver::plane_fft_on() const {
   return opt_.plane_fft != 0 && nranks_ == 1 && fft_->can_plane();
 }
@@ -727,7 +727,7 @@ void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* 
   }
   bool fuse_x = false, plane = false;
   // x-contiguous layout for the fused pass: on by size (fields beyond the Infinity Cache, where the fused pass's tile of nx
-  // segments 2 MB apart is what bounds it) unless the option says otherwise; FG_X_LAYOUT overrides for A/B runs
+  // segments 2 MB apart is what bounds it) unless the option x_layout says otherwise
   const int xl_opt = opt_.x_layout;
   const bool xl = xscratch && opt_.fuse_x && fft_->can_fuse(0) && fft_->can_xlayout() && g_.nx > 1 && g_.ny > 1 &&
                   (xl_opt > 0 || (xl_opt < 0 && 3.0 * (double)g_.n * sizeof(double) > 1024.0 * 1024 * 1024));

@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <string>
 #include <vector>
@@ -142,115 +143,193 @@ __global__ __launch_bounds__(kBrick* kBrick* kBrick) void k_vox_classify(VoxGrid
   iface[atomicAdd(iface_count, 1u)] = (unsigned)o;
 }
 
-// one thread per interface voxel: the octree walk with an explicit stack
+// what a node of an interface voxel's octree needs: the voxel's candidate list (its brick's) and centre
+struct RefineCtx {
+  VoxGrid g;
+  const Shape* shapes;
+  const int* brick_list;
+  int q0, q1;
+  V3 p0;
+  int smooth_levels;
+  double smooth_tol;
+  int* error;
+};
+
+// classification of the node (level, cen): true when it is closed -- full, empty or a leaf -- with its volume in *value
+__device__ bool node_closed(const RefineCtx& c, int level, V3 cen, double* value) {
+  const VoxGrid& g = c.g;
+  const double sc = ldexp(1.0, -level);
+  const double ex = g.hx * sc, ey = g.hy * sc, ez = g.hz * sc, r = g.r0 * sc, vbox = ex * ey * ez;
+  bool full = false, any = false;
+  double dmin = INFINITY, kmin = 0.0;
+  for (int q = c.q0; q < c.q1; ++q) {
+    const Shape& s = c.shapes[c.brick_list[q]];
+    if (shape_ball_distance(s, c.p0) > g.r0) continue;   // not in the voxel's list
+    V3 xs;
+    if (level == 0) {
+      const double d = shape_distance(s, c.p0, &xs);
+      if (d > g.r0) continue;
+      any = true;
+      if (d < dmin) dmin = d, kmin = s.kind == 1 ? 0.0 : 1.0 / s.R;
+    } else {
+      if (shape_distance(s, c.p0, &xs) > g.r0) continue;
+      const double d = shape_distance(s, cen, &xs);
+      if (d <= -r) {
+        full = true;
+        break;
+      }
+      if (fabs(d) < r) {
+        any = true;
+        if (d < dmin) dmin = d, kmin = s.kind == 1 ? 0.0 : 1.0 / s.R;
+      }
+    }
+  }
+  if (full) {
+    *value = vbox;
+    return true;
+  }
+  if (!any) {
+    *value = 0.0;
+    return true;
+  }
+  bool leaf;
+  if (c.smooth_levels < 0) {   // error estimate of the closest shape's tangent-plane approximation
+    const double Kd = r * kmin;
+    const double err = Kd > 1 ? 1.0 : Kd * Kd * pow(sc, 2.0 / 3.0);
+    leaf = err < c.smooth_tol;
+  } else {
+    leaf = level >= c.smooth_levels;
+  }
+  if (!leaf && level == kMaxDepth) {
+    *c.error = 1;
+    leaf = true;
+  }
+  if (!leaf) return false;
+  const V3 org = mk(cen.x - 0.5 * ex, cen.y - 0.5 * ey, cen.z - 0.5 * ez);
+  double v = 0.0;
+  for (int q = c.q0; q < c.q1; ++q) {
+    const Shape& s = c.shapes[c.brick_list[q]];
+    if (shape_ball_distance(s, c.p0) > g.r0) continue;
+    V3 xs;
+    if (shape_distance(s, c.p0, &xs) > g.r0) continue;
+    const double d = shape_distance(s, cen, &xs);
+    if (level > 0 && !(fabs(d) < r)) continue;
+    v += vbox * box_fraction_below_plane(xs - org, shape_normal(s, xs), ex, ey, ez);
+  }
+  *value = fmin(v, vbox);
+  return true;
+}
+
+__device__ inline V3 child_centre(const VoxGrid& g, int level, V3 cen, int c) {   // child c of the node (level, cen)
+  const double sc = ldexp(1.0, -level);
+  const double qx = 0.25 * g.hx * sc, qy = 0.25 * g.hy * sc, qz = 0.25 * g.hz * sc;
+  return mk(cen.x + ((c & 4) ? qx : -qx), cen.y + ((c & 2) ? qy : -qy), cen.z + ((c & 1) ? qz : -qz));
+}
+
+// volume of the subtree below the node (level0, cen0): the octree walk with an explicit stack
+__device__ double subtree_volume(const RefineCtx& c, int level0, V3 cen0) {
+  double acc[kMaxDepth + 1];   // volume collected by the open node of every level
+  int child[kMaxDepth + 1];    // next child of the open node of every level
+  V3 cen[kMaxDepth + 1];
+  int level = level0;
+  cen[level] = cen0;
+  bool entering = true;        // the node at `level` has just been reached (not yet classified)
+  for (;;) {
+    double value = 0.0;        // volume of this node, once closed
+    bool closed = false;
+    if (entering) {
+      closed = node_closed(c, level, cen[level], &value);
+      if (!closed) {
+        acc[level] = 0.0;
+        child[level] = 0;
+      }
+    }
+    if (!closed) {
+      // descend into the next child, or close the node when all eight are done
+      if (child[level] < 8) {
+        cen[level + 1] = child_centre(c.g, level, cen[level], child[level]++);
+        ++level;
+        entering = true;
+        continue;
+      }
+      const double sc = ldexp(1.0, -level);
+      value = fmin(acc[level], c.g.hx * sc * (c.g.hy * sc) * (c.g.hz * sc));
+    }
+    // the node is closed: hand its volume to the parent
+    if (level == level0) return value;
+    --level;
+    acc[level] += value;
+    entering = false;
+  }
+}
+
+__device__ inline RefineCtx refine_ctx(const VoxGrid& g, const Shape* shapes, const int* brick_start, const int* brick_list, size_t o,
+                                       int smooth_levels, double smooth_tol, int* error) {
+  const int k = (int)(o % g.nz), j = (int)((o / g.nz) % g.ny), i = (int)(o / ((size_t)g.nz * g.ny));
+  const int b = ((i / kBrick) * g.by + j / kBrick) * g.bz + k / kBrick;
+  RefineCtx c = {g, shapes, brick_list, brick_start[b], brick_start[b + 1], voxel_centre(g, i, j, k), smooth_levels, smooth_tol, error};
+  return c;
+}
+
+// one thread per interface voxel (grids with enough interface voxels to fill the device)
 __global__ __launch_bounds__(64) void k_vox_refine(VoxGrid g, const Shape* shapes, const int* brick_start, const int* brick_list,
                                                    const unsigned* iface, unsigned n_iface, int smooth_levels, double smooth_tol,
                                                    double* phi, int* error) {
   const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_iface) return;
   const size_t o = iface[w];
-  const int k = (int)(o % g.nz), j = (int)((o / g.nz) % g.ny), i = (int)(o / ((size_t)g.nz * g.ny));
-  const int b = ((i / kBrick) * g.by + j / kBrick) * g.bz + k / kBrick;
-  const int q0 = brick_start[b], q1 = brick_start[b + 1];
-  const V3 p0 = voxel_centre(g, i, j, k);
+  const RefineCtx c = refine_ctx(g, shapes, brick_start, brick_list, o, smooth_levels, smooth_tol, error);
+  phi[o] = subtree_volume(c, 0, c.p0) / (g.hx * g.hy * g.hz);
+}
 
-  double acc[kMaxDepth + 1];   // volume collected by the open node of every level
-  int child[kMaxDepth + 1];    // next child of the open node of every level
-  V3 cen[kMaxDepth + 1];
-  int level = 0;
-  cen[0] = p0;
-  double result = 0.0;
-  bool entering = true;        // the node at `level` has just been reached (not yet classified)
-  for (;;) {
-    const double sc = ldexp(1.0, -level);
-    const double ex = g.hx * sc, ey = g.hy * sc, ez = g.hz * sc, r = g.r0 * sc, vbox = ex * ey * ez;
-    double value = 0.0;        // volume of this node, once closed
-    bool closed = false;
-    if (entering) {
-      // classification of the node from the brick's candidates
-      bool full = false, any = false;
-      double dmin = INFINITY, kmin = 0.0;
-      for (int q = q0; q < q1; ++q) {
-        const Shape& s = shapes[brick_list[q]];
-        if (shape_ball_distance(s, p0) > g.r0) continue;   // not in the voxel's list
-        V3 xs;
-        if (level == 0) {
-          const double d = shape_distance(s, p0, &xs);
-          if (d > g.r0) continue;
-          any = true;
-          if (d < dmin) dmin = d, kmin = s.kind == 1 ? 0.0 : 1.0 / s.R;
-        } else {
-          if (shape_distance(s, p0, &xs) > g.r0) continue;
-          const double d = shape_distance(s, cen[level], &xs);
-          if (d <= -r) {
-            full = true;
-            break;
-          }
-          if (fabs(d) < r) {
-            any = true;
-            if (d < dmin) dmin = d, kmin = s.kind == 1 ? 0.0 : 1.0 / s.R;
-          }
-        }
+// A team of 8^D threads per interface voxel, for grids with few of them (a coarse grid with deep trees kept ONE lane busy
+// for seconds).  Thread t of the team owns the level-D node whose path from the root are the D octal digits of t; the
+// nodes above it are classified by every thread below them (cheap), the subtree by its owner alone.  The values then
+// climb the tree through LDS, the eight children of a node added in child order and clipped to the node's box exactly
+// as the one-thread walk does: the result is bit-identical to k_vox_refine's.
+template <int D>
+__global__ __launch_bounds__((1 << (3 * D)) < 64 ? 64 : (1 << (3 * D))) void k_vox_refine_team(
+    VoxGrid g, const Shape* shapes, const int* brick_start, const int* brick_list, const unsigned* iface, unsigned n_iface,
+    int smooth_levels, double smooth_tol, double* phi, int* error) {
+  constexpr int T = 1 << (3 * D), B = T < 64 ? 64 : T;
+  __shared__ double vals[B];
+  const int t = threadIdx.x % T;
+  const unsigned w = blockIdx.x * (B / T) + threadIdx.x / T;
+  const bool active = w < n_iface;
+  const size_t o = active ? iface[w] : 0;
+  int closed_at = D;   // level of the first closed node on this thread's path (D: its own subtree is open above)
+  double mine = 0.0;
+  if (active) {
+    const RefineCtx c = refine_ctx(g, shapes, brick_start, brick_list, o, smooth_levels, smooth_tol, error);
+    V3 cen = c.p0;
+    for (int l = 0; l < D; ++l) {
+      double v;
+      if (node_closed(c, l, cen, &v)) {
+        closed_at = l;
+        mine = (t & ((1 << (3 * (D - l))) - 1)) == 0 ? v : 0.0;   // carried by the node's first descendant
+        break;
       }
-      if (full) {
-        value = vbox, closed = true;
-      } else if (!any) {
-        value = 0.0, closed = true;
-      } else {
-        bool leaf;
-        if (smooth_levels < 0) {   // error estimate of the closest shape's tangent-plane approximation
-          const double Kd = r * kmin;
-          const double err = Kd > 1 ? 1.0 : Kd * Kd * pow(sc, 2.0 / 3.0);
-          leaf = err < smooth_tol;
-        } else {
-          leaf = level >= smooth_levels;
-        }
-        if (!leaf && level == kMaxDepth) {
-          *error = 1;
-          leaf = true;
-        }
-        if (leaf) {
-          const V3 org = mk(cen[level].x - 0.5 * ex, cen[level].y - 0.5 * ey, cen[level].z - 0.5 * ez);
-          double v = 0.0;
-          for (int q = q0; q < q1; ++q) {
-            const Shape& s = shapes[brick_list[q]];
-            if (shape_ball_distance(s, p0) > g.r0) continue;
-            V3 xs;
-            if (shape_distance(s, p0, &xs) > g.r0) continue;
-            const double d = shape_distance(s, cen[level], &xs);
-            if (level > 0 && !(fabs(d) < r)) continue;
-            v += vbox * box_fraction_below_plane(xs - org, shape_normal(s, xs), ex, ey, ez);
-          }
-          value = fmin(v, vbox), closed = true;
-        } else {
-          acc[level] = 0.0;
-          child[level] = 0;
-        }
-      }
+      cen = child_centre(g, l, cen, (t >> (3 * (D - 1 - l))) & 7);
     }
-    if (!closed) {
-      // descend into the next child, or close the node when all eight are done
-      if (child[level] < 8) {
-        const int c = child[level]++;
-        const double qx = 0.25 * ex, qy = 0.25 * ey, qz = 0.25 * ez;
-        cen[level + 1] = mk(cen[level].x + ((c & 4) ? qx : -qx), cen[level].y + ((c & 2) ? qy : -qy),
-                            cen[level].z + ((c & 1) ? qz : -qz));
-        ++level;
-        entering = true;
-        continue;
-      }
-      value = fmin(acc[level], vbox);
-    }
-    // the node is closed: hand its volume to the parent
-    if (level == 0) {
-      result = value;
-      break;
-    }
-    --level;
-    acc[level] += value;
-    entering = false;
+    if (closed_at == D) mine = subtree_volume(c, D, cen);
   }
-  phi[o] = result / (g.hx * g.hy * g.hz);
+  vals[threadIdx.x] = mine;
+  __syncthreads();
+#pragma unroll
+  for (int m = D - 1; m >= 0; --m) {
+    const int stride = 1 << (3 * (D - 1 - m));
+    if (active && (t & (8 * stride - 1)) == 0) {
+      double sum = 0.0;
+      for (int ch = 0; ch < 8; ++ch) sum += vals[threadIdx.x + ch * stride];
+      if (closed_at > m) {   // the node at level m is open: clip to its box
+        const double sc = ldexp(1.0, -m);
+        sum = fmin(sum, g.hx * sc * (g.hy * sc) * (g.hz * sc));
+      }
+      vals[threadIdx.x] = sum;
+    }
+    __syncthreads();
+  }
+  if (active && t == 0) phi[o] = vals[threadIdx.x] / (g.hx * g.hy * g.hz);
 }
 
 // interface normals: gradient of the distance to the closest shape of ANY material at the voxel centre
@@ -428,8 +507,18 @@ extern "C" int fg_voxelize(const fg_fiber* fibers, int nfibers, int nx, int ny, 
       unsigned n_iface = 0;
       FG_HIP_CHECK(hipMemcpy(&n_iface, d_count.p, sizeof(unsigned), hipMemcpyDeviceToHost));
       if (n_iface) {
-        hipLaunchKernelGGL(k_vox_refine, dim3((n_iface + 63) / 64), dim3(64), 0, 0, g, d_shapes.p, d_start.p, d_list.p, d_iface.p,
-                           n_iface, smooth_levels, smooth_tol, d_phi.p, d_error.p);
+        // threads per interface voxel: 8^depth, so that a coarse grid still fills the device (FG_VOX_TEAM_DEPTH: test hook)
+        int depth = n_iface <= 2048 ? 3 : n_iface <= 16384 ? 2 : n_iface <= 65536 ? 1 : 0;
+        if (const char* e = getenv("FG_VOX_TEAM_DEPTH")) depth = std::min(3, std::max(0, atoi(e)));
+        if (smooth_levels >= 0) depth = std::min(depth, smooth_levels);
+#define FG_REFINE(KERNEL, BLOCKS, THREADS)                                                                                   \
+  hipLaunchKernelGGL(KERNEL, dim3(BLOCKS), dim3(THREADS), 0, 0, g, d_shapes.p, d_start.p, d_list.p, d_iface.p, n_iface, \
+                     smooth_levels, smooth_tol, d_phi.p, d_error.p)
+        if (depth == 3) FG_REFINE(k_vox_refine_team<3>, n_iface, 512);
+        else if (depth == 2) FG_REFINE(k_vox_refine_team<2>, n_iface, 64);
+        else if (depth == 1) FG_REFINE(k_vox_refine_team<1>, (n_iface + 7) / 8, 64);
+        else FG_REFINE(k_vox_refine, (n_iface + 63) / 64, 64);
+#undef FG_REFINE
         FG_HIP_CHECK(hipGetLastError());
       }
       FG_HIP_CHECK(hipMemcpy(out, d_phi.p, N * sizeof(double), hipMemcpyDeviceToHost));

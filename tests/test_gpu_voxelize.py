@@ -140,3 +140,25 @@ def test_random_scenes_equal_checker(seed):
     assert np.abs(phi - phi_c).max() <= TOL, (seed, shape, kw)
     assert np.abs(nrm - nrm_c).max() <= 1e-13, (seed, shape, kw)
     assert real == real_c
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+@pytest.mark.parametrize("scene", ["fine", "coarse"])
+def test_team_refinement_equals_one_thread_walk(scene, depth, monkeypatch):
+    """Grids with few interface voxels give each of them 8^depth threads (k_vox_refine_team): the children's volumes are
+    added in child order and clipped per node as in the one-thread walk, so the fractions are bit-identical -- a voxel's
+    value does not depend on how many interface voxels its grid has."""
+    from fibergen_amd import geometry
+    if scene == "fine":
+        args = (random_capsules(12, 1, (1, 2)), (24, 20, 28), (1.0, 1.3, 0.9), (0.1, -0.2, 0.0), 3, 0)
+        kws = [dict(smooth_levels=-1, smooth_tol=1e-3), dict(smooth_levels=2, smooth_tol=0.0), dict(smooth_levels=4, smooth_tol=0.0)]
+    else:   # voxels larger than the shapes: deep trees, closed nodes right below the root
+        args = (random_capsules(15, 7), (6, 1, 2), (0.9, 1.7, 1.2), (0.0, 0.0, 0.0), 2, 0)
+        kws = [dict(smooth_levels=-1, smooth_tol=2e-3), dict(smooth_levels=1, smooth_tol=0.0)]
+    for kw in kws:
+        monkeypatch.setenv("FG_VOX_TEAM_DEPTH", "0")
+        want = geometry.voxelize(*args, want_normals=False, **kw)[0]
+        monkeypatch.setenv("FG_VOX_TEAM_DEPTH", str(depth))
+        got = geometry.voxelize(*args, want_normals=False, **kw)[0]
+        assert ((want > 0) & (want < 1)).any()
+        assert np.array_equal(got, want), (scene, depth, kw)

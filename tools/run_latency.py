@@ -13,5 +13,5 @@ for n in (64, 128, 256):
     s.calc_ref_material(); s.iterate(E, 10); s.synchronize()
     import time; t0 = time.perf_counter(); s.iterate(E, 200); s.synchronize(); it_it = 200 / (time.perf_counter() - t0)
     s.set_options(tol=1e-6, maxiter=10000); s.run(E)
-    print(os.environ.get("FG_POLL"), n, "run_load_case %.0f it/s, iterate %.0f it/s; converged run: %d iterations in %.2f ms" % (it_run, it_it, s.iterations, 1e3 * s.solve_time))
+    print(n, "run_load_case %.0f it/s, iterate %.0f it/s; converged run: %d iterations in %.2f ms" % (it_run, it_it, s.iterations, 1e3 * s.solve_time))
     s.close()
