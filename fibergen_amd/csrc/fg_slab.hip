@@ -168,7 +168,11 @@ bool Solver::slab_loopback() const { return nranks_ == 1 && comm_ && opt_.slab_l
 double* Solver::slab_buffer(int id) {
   switch (id) {
     case FG_BUF_SPECTRUM_X: return tau_;
-    case FG_BUF_SPECTRUM_Y: return (nranks_ == 1 && !slab_loopback()) ? tau_ : tau_ + 3 * g_.n;   // one slab: the identity
+    // one slab: the identity.  Otherwise the y-slab spectrum lands in fu_: f has been consumed by the forward y pass when the
+    // all-to-all of its component is posted, and the next sweep writes fu_ only behind the halo exchange that follows the
+    // backward all-to-all -- one field less in the working set of a pass (256^3 on 8 ranks: 291 -> 239 MB, inside the 256 MB
+    // Infinity Cache)
+    case FG_BUF_SPECTRUM_Y: return (nranks_ == 1 && !slab_loopback()) ? tau_ : fu_;
     case FG_BUF_U: return su_[su_cur_ ^ 1];                                  // the displacement the chain is producing
     case FG_BUF_MODULI: return smod_;
     case FG_BUF_HALO_SEND_LO: return halo_[0];

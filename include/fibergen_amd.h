@@ -256,7 +256,7 @@ int fg_device_pci_bus_id(int device, char* out, int capacity);
 #define FG_PLAN_HALO_MODULI 3   /* the same for the two effective-moduli arrays (once per geometry) */
 #define FG_PLAN_HALO_TAU 4      /* strain-state pipeline: tau0 | tau5, tau4 */
 #define FG_BUF_SPECTRUM_X 0     /* [3][P][nx/P][ny/P][nzp] blocked x-slab spectrum */
-#define FG_BUF_SPECTRUM_Y 1     /* [3][nx][ny/P][nzp] y-slab spectrum */
+#define FG_BUF_SPECTRUM_Y 1     /* [3][nx][ny/P][nzp] y-slab spectrum (shares its memory with the divergence field f) */
 #define FG_BUF_U 2              /* [3][nx/P + 4][ny][nzp] displacement with spare planes */
 #define FG_BUF_MODULI 3         /* [2][nx/P + 4][ny][nzp] */
 #define FG_BUF_HALO_SEND_LO 4
