@@ -19,7 +19,8 @@
 //     normal, no polyhedron is ever built (box_fraction_below_plane);
 //   * bricks of 8 x 8 x 8 voxels get their candidate shapes from a host-side binning of the bounding balls; a first
 //     kernel classifies every voxel (empty / full / interface) and compacts the interface voxels, a second one walks
-//     their trees -- the expensive 3 % of the voxels get their own, evenly loaded launch.
+//     their trees -- the expensive 3 % of the voxels get their own, evenly loaded launch: one thread per interface voxel
+//     on grids that have enough of them, a team of 8 / 64 / 512 threads (one subtree each) on coarse ones.
 // The checker (oracle/c/fg_voxel_ref.cpp) is the host restatement of the reference's recursive form.
 #include <hip/hip_runtime.h>
 
