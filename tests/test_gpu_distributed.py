@@ -2,6 +2,8 @@
 the ranks share it and the callback transport stages the exchanged bytes through the host).  The processes run the
 collective entry points of the C ABI exactly as an 8-GPU RCCL job does: separate solver objects, the exchange plan,
 all-reduced norms, identical stop decisions on every rank."""
+import os
+
 import numpy as np
 import pytest
 
@@ -287,3 +289,33 @@ def test_porous_mode_on_slabs_one_rank_per_process(tmp_path, transport, nproc, g
         assert np.abs(r["residuals"] - np.array(o.residuals)).max() < 1e-11
         assert rel_err(r["mean_stress"][:3], o.mean_stress()) < 1e-11
         assert float(r["mu_0"]) == o.mu_0
+
+
+@pytest.mark.parametrize("backend,launcher", [("nccl-one-gpu", "self"), ("gloo", "self"), ("nccl-one-gpu", "torchrun")])
+def test_bench_line_for_two_ranks(backend, launcher):
+    """`bench.py --gpus 2` (what the driver starts per N -- self-launched and under torch.distributed.run, both ranks on the one GPU of the box): the slab
+    section runs, the line carries the fields the contract and north_star's table ask for -- value over ALL ranks,
+    the same node's single-GPU rate, the kernels of rank 0's slab, the exchange times, the other grid through the same driver."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", backend, "--size", "128", "--steps", "4",
+           "--warmup", "2", "--repeats", "3", "--no-cpu-baseline", "--also-slab", "64:laminate", "--slab-timeout", "120"]
+    if launcher == "torchrun":   # the driver's command line for N > 1
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + cmd[1:]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["unit"] == "it/s"
+    assert line["value"] and line["value"] > 0 and abs(line["ms_per_step"] * line["value"] - 1e3) < 1e-6 * 1e3
+    assert line["scaling"] == "strong" and line["config"]["grid"] == [128, 128, 128]
+    assert line["single_gpu_it_s"] > 0 and line["speedup_over_single_gpu"] > 0 and line["replicas"]["value"] > 0
+    assert set(line["kernels"]) >= {"u_eps_stress_div", "xfft_g0_xifft"} and line["roofline"]["frac"] > 0
+    assert line["alltoall_ms"] >= 0 and line["distinct_devices"] == 1
+    assert line["also_slab"]["64^3 laminate"]["it_s"] > 0
