@@ -132,3 +132,33 @@ def test_runs_are_reproducible_bit_for_bit():
             s.close()
         assert np.array_equal(out[0][0], out[1][0]), (mixing, method)
         assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]), (mixing, method)
+
+
+def test_bench_line_of_the_default_command_on_a_small_grid():
+    """`python bench.py` (the driver's N = 1 command) on 64^3 with short budgets: the one JSON line keeps the contract's keys --
+    metric / value / unit / steps / warmup / ms_per_step, `roofline` with the traffic measured in the run by the two counter
+    passes, `cpu_baseline` from the C loop nests on this host, the per-kernel table, one `also` leg."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--size", "64", "--steps", "6", "--warmup", "2", "--repeats", "3",
+           "--sustain-s", "0.3", "--cpu-budget", "3", "--also", "32:laminate"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1   # ONE line
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["warmup"] == 2 and line["unit"] == "it/s" and line["dtype"] == "f64"
+    assert line["higher_is_better"] is True and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert abs(line["ms_per_step"] * line["value"] - 1e3) < 1e-3 and "workload" in line["config"]
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["traffic"] is None or rf["traffic"] > 0.5 * rf["alg_bytes_per_launch"]
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "it/s" and "sample" in cb
+    assert line["also"]["32^3 laminate"]["it_s"] > 0 and len(line["kernels"]) >= 4
