@@ -162,3 +162,11 @@ def test_bench_line_of_the_default_command_on_a_small_grid():
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "it/s" and "sample" in cb
     assert line["also"]["32^3 laminate"]["it_s"] > 0 and len(line["kernels"]) >= 4
+
+
+def test_driver_smoke_entry(capsys):
+    """__graft_entry__.smoke(): the invocation the driver runs before the bench."""
+    import __graft_entry__
+    __graft_entry__.smoke()
+    out = capsys.readouterr().out
+    assert "smoke voigt" in out and "smoke laminate" in out
