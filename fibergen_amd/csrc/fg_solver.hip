@@ -532,7 +532,7 @@ void Solver::basic_scheme(const double* E6, double* src, double* dst) {
     }
     const double mu_g = -1.0 / (4 * m);
     const double c12[2] = {-alpha / mu_g, -alpha / mu_g};
-    fft_g0_chain(fu_, alpha, c12);
+    fft_g0_chain(fu_, alpha, c12, fused ? tau_ : nullptr);   // (fused: the polarisation is never stored, its field is free for the x-contiguous layout)
     // adj = E - 2 alpha m <tau>;  eta = adj + sym grad u;  eta.xpay(eta, 2 alpha m, tau_copy)  F:20438-20452, one sweep
     Vec6 Ev;
     for (int c = 0; c < 6; ++c) Ev.v[c] = E6[c];

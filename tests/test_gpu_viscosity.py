@@ -48,6 +48,30 @@ def test_viscosity_run_matches_oracle(grid, dims):
     s.close()
 
 
+@pytest.mark.parametrize("grid", [(16, 16, 128), (32, 8, 128), (8, 64, 124)])
+def test_viscosity_x_contiguous_layout(grid):
+    """The x-contiguous intermediate layout (default on large grids; scratch = the polarisation field, which the fused sweeps never
+    store) in viscosity mode: same arithmetic as the plain layout, identical iterates; equal to the oracle."""
+    from fibergen_amd import LSSolver
+    from oracle.viscosity_oracle import ViscosityOracle
+    phi1 = sphere_phi(grid, 0.3)
+    E = np.array([0.5, -0.5, 0.0, 0.2, 0.0, 1.0])
+    out = {}
+    for xl in (0, 1):
+        s = LSSolver(*grid)
+        s.set_options(mode="viscosity", tol=1e-8, x_layout=xl, plane_fft=0)
+        s.set_num_phases(2)
+        s.set_phase(0, 1.0, 0.0, 1 - phi1)
+        s.set_phase(1, 0.05, 0.0, phi1)
+        assert s.run(E) is False
+        out[xl] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"))
+        s.close()
+    assert out[1][0] == out[0][0] and np.array_equal(out[1][1], out[0][1]) and np.array_equal(out[1][2], out[0][2])
+    o = ViscosityOracle(*grid, mats=[(1.0, 0.0), (0.05, 0.0)], phis=[1 - phi1, phi1], tol=1e-8)
+    assert o.run(E) is False
+    assert out[1][0] == o.iterations and rel_err(out[1][2], o.eps) < 1e-9
+
+
 def test_viscosity_layered_fluid_means():
     shape, fr, mus = (12, 4, 6), [0.25, 0.25, 0.5], [1.0, 4.0, 0.5]
     edges = np.round(np.cumsum([0.0] + fr) * shape[0]).astype(int)
