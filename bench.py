@@ -103,6 +103,7 @@ def kernel_table(s, E, n, steps, scalar, stokes=False):
         F = n[0] * n[1] * (n[2] // 2 + 1)
         ab = {k: 32 * F for k in ab}
         ab["stress"] = 24 * N
+    chunked = s.counter("pair_chunk_planes") > 0
     kern = {}
     for k, ms in times.items():
         avg = ms / max(cnt, 1)
@@ -125,8 +126,12 @@ def kernel_table(s, E, n, steps, scalar, stokes=False):
             name = "xfft_g0_xifft"             # x-FFT, Green operator, inverse x-FFT: 48 B/voxel
         if k == "r2c_z" and times["c2c_y_fwd"] == 0 and n[1] > 1:
             name = "zy_plane_fwd"              # plane kernel: r2c along z + c2c along y in one pass (fg_fft_plane.h)
+            if chunked:   # r2c(c) -> y(c) in runs of x planes (option pair_chunk): the slot holds both passes of every chunk
+                name, alg = "r2c_z+c2c_y_fwd_chunked", ab["r2c_z"] + ab["c2c_y_fwd"]
         if k == "c2r_z" and times["c2c_y_inv"] == 0 and n[1] > 1:
             name = "yz_plane_inv"
+        if k == "c2c_y_inv" and times["c2r_z"] == 0 and n[1] > 1 and chunked:
+            name, alg = "c2c_y_inv+c2r_z_chunked", ab["c2c_y_inv"] + ab["c2r_z"]
         kern[name] = {"avg_ms": avg, "alg_GB": alg / 1e9, "GBps": (alg / 1e9) / (avg / 1e3)}
     return kern, times, cnt
 

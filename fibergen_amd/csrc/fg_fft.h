@@ -21,6 +21,16 @@ struct G0Params {
   double inv_h0;   // 2 n / d of the axis the fused pass transforms (physical x)
 };
 
+// A run of x planes [x0, x0 + np) of the field (np < 0: all).  The z and y passes are local to x planes: the solver runs
+// them chunk by chunk (r2c(c) -> y(c), y^-1(c) -> c2r(c)) so that the hand-over between the two stays in the 256 MB Infinity
+// Cache (Solver::fft_g0_chain, option pair_chunk).  Same kernels, same per-line arithmetic: bit-identical to the whole-field
+// passes.  nt >= 0 overrides the streaming-access flags of the launch (bit 0 stores, bit 1 loads).  Power-of-two lengths only.
+struct PlaneWindow {
+  int x0 = 0;
+  int np = -1;
+  int nt = -1;
+};
+
 class Fft3 {
  public:
   Fft3(const Grid& g, hipStream_t stream);
@@ -33,10 +43,11 @@ class Fft3 {
   void inverse(double* data, int ncomp, long comp_stride);
 
   // single-axis entry points (used by the slab-decomposed driver and the stage tests)
-  void r2c_z(double* data, int ncomp, long comp_stride);
-  void c2c_y(double* data, int ncomp, long comp_stride, int dir, double scale);
+  void r2c_z(double* data, int ncomp, long comp_stride, const PlaneWindow* w = nullptr);
+  void c2c_y(double* data, int ncomp, long comp_stride, int dir, double scale, const PlaneWindow* w = nullptr);
   void c2c_x(double* data, int ncomp, long comp_stride, int dir, double scale);
-  void c2r_z(double* data, int ncomp, long comp_stride);
+  void c2r_z(double* data, int ncomp, long comp_stride, const PlaneWindow* w = nullptr);
+  bool can_window() const { return fast_[1] && fast_[2]; }   // the passes that take a PlaneWindow
   void scale(double* data, int ncomp, long comp_stride, double scale);
   // Slab decomposition (x-slab side): the y pass with the all-to-all layout on one side.  Plain layout
   // [nx][ny][nzc]; blocked layout [q][nx][ny/P][nzc] (block q = what peer q receives / sent), see StridedArgs.
@@ -49,7 +60,8 @@ class Fft3 {
   // apart; the scatter moves to the y passes (dir = -1: in plain -> out x-layout; dir = +1: in x-layout -> out plain),
   // fused_g0(..., xlayout = true) works on it in place.  Out of place (in != out).
   bool can_xlayout() const;
-  void c2c_y_xlayout(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale);
+  void c2c_y_xlayout(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale,
+                     const PlaneWindow* w = nullptr);
   // small grids: the z and y transforms of a z-y plane in one kernel (the complex plane [ny][nzc] in LDS, fg_fft_plane.h);
   // dir = -1: r2c along z then c2c along y (= r2c_z + c2c_y), dir = +1: the inverse pair (= c2c_y + c2r_z), in place
   bool can_plane() const;
@@ -68,7 +80,7 @@ class Fft3 {
   const cplx* z_roots() const { return wz_; }        // e^{-2 pi i k/nz}, k = 0..nz/2
 
  private:
-  void strided(double* data, int ncomp, long comp_stride, int axis, int dir, double scale);
+  void strided(double* data, int ncomp, long comp_stride, int axis, int dir, double scale, const PlaneWindow* w = nullptr);
   Grid g_;
   hipStream_t stream_;
   bool fast_[3];

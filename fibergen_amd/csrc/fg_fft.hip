@@ -1043,16 +1043,21 @@ Fft3::~Fft3() {
   if (scratch_) (void)hipFree(scratch_);
 }
 
-void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir, double scale) {
+void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir, double scale, const PlaneWindow* w) {
   const int n = axis == 0 ? g_.nx : g_.ny;
   const long ls = axis == 0 ? (long)g_.ny * g_.nzc : g_.nzc;
   const int ncols = axis == 0 ? g_.ny * g_.nzc : g_.nzc;
-  const int nouter = axis == 0 ? 1 : g_.nx;
+  int nouter = axis == 0 ? 1 : g_.nx;
   const long os = axis == 0 ? 0 : (long)g_.ny * g_.nzc;
+  const bool windowed = w && w->np >= 0;
+  if (windowed && (axis != 1 || !fast_[1] || w->x0 < 0 || w->x0 + w->np > g_.nx))
+    throw std::runtime_error("fft: plane windows need a power-of-two y pass");
   if (n == 1) return;  // identity; forward() never folds the scale into a length-1 axis
   if (fast_[axis]) {
     StridedArgs a;
     a.data = reinterpret_cast<cplx*>(data);
+    if (windowed) a.data += (long)w->x0 * os, nouter = w->np;
+    if (nouter == 0) return;
     a.ls = ls;
     a.os = os;
     a.ncols = ncols;
@@ -1060,6 +1065,7 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
     a.scale = scale;
     a.tw = tw_[axis];
     a.nt = stream_stores_ ? (1 | ((nt_loads_env() & 1) ? 2 : 0)) : 0;
+    if (w && w->nt >= 0) a.nt = w->nt;
     a.xcd_order = 0;   // (measured for the y passes: 512^3 -1..2 %, 256^3 +2 %)
     strided_pow2(n, a, nouter, dir, ncomp, comp_stride / 2, stream_);
     return;
@@ -1212,8 +1218,12 @@ bool Fft3::can_xlayout() const {
   return fast_[0] && fast_[1] && g_.nx >= 8 && g_.nx <= 512 && g_.nzc % 8 == 0 && g_.ny >= 8;
 }
 
-void Fft3::c2c_y_xlayout(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale) {
+void Fft3::c2c_y_xlayout(double* in, long in_cs, double* out, long out_cs, int ncomp, int dir, double scale, const PlaneWindow* w) {
   if (!can_xlayout()) throw std::runtime_error("fft: x-contiguous layout not available for this grid");
+  const bool windowed = w && w->np >= 0;
+  if (windowed && (w->x0 < 0 || w->x0 + w->np > g_.nx)) throw std::runtime_error("fft: plane window out of range");
+  const int x0 = windowed ? w->x0 : 0, np = windowed ? w->np : g_.nx;
+  if (np == 0) return;
   StridedArgs a;
   a.data = reinterpret_cast<cplx*>(in);
   a.out = reinterpret_cast<cplx*>(out);
@@ -1223,6 +1233,7 @@ void Fft3::c2c_y_xlayout(double* in, long in_cs, double* out, long out_cs, int n
   a.scale = scale;
   a.tw = tw_[1];
   a.nt = stream_stores_ ? (1 | ((nt_loads_env() & 1) ? 2 : 0)) : 0;
+  if (w && w->nt >= 0) a.nt = w->nt;
   a.xcd_order = 0;
   const long plain_ls = g_.nzc, plain_os = (long)g_.ny * g_.nzc;
   const long xl_ls = (long)g_.nx * 8, xl_os = 8, xl_ts = (long)g_.ny * g_.nx * 8;
@@ -1232,14 +1243,18 @@ void Fft3::c2c_y_xlayout(double* in, long in_cs, double* out, long out_cs, int n
     a.ls_out = xl_ls;
     a.os_out = xl_os;
     a.ts_out = xl_ts;
+    a.data += (long)x0 * plain_os;
+    a.out += (long)x0 * xl_os;
   } else {
     a.ls = xl_ls;
     a.os = xl_os;
     a.ts_in = xl_ts;
     a.ls_out = plain_ls;
     a.os_out = plain_os;
+    a.data += (long)x0 * xl_os;
+    a.out += (long)x0 * plain_os;
   }
-  strided_pow2_narrow(g_.ny, a, g_.nx, dir, ncomp, in_cs / 2, stream_);   // 8-column tiles: the layout's inner dimension
+  strided_pow2_narrow(g_.ny, a, np, dir, ncomp, in_cs / 2, stream_);   // 8-column tiles: the layout's inner dimension
 }
 
 void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp, int xsplit,
@@ -1343,17 +1358,24 @@ void Fft3::c2c_y_blocked(double* in, long in_cs, double* out, long out_cs, int n
   strided_pow2(g_.ny, a, g_.nx, dir, ncomp, in_cs / 2, stream_);
 }
 
-void Fft3::c2c_y(double* data, int ncomp, long comp_stride, int dir, double scale) {
-  strided(data, ncomp, comp_stride, 1, dir, scale);
+void Fft3::c2c_y(double* data, int ncomp, long comp_stride, int dir, double scale, const PlaneWindow* w) {
+  strided(data, ncomp, comp_stride, 1, dir, scale, w);
 }
 void Fft3::c2c_x(double* data, int ncomp, long comp_stride, int dir, double scale) {
   strided(data, ncomp, comp_stride, 0, dir, scale);
 }
 
-void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
-  const long nrows = (long)g_.nx * g_.ny;
+void Fft3::r2c_z(double* data, int ncomp, long comp_stride, const PlaneWindow* w) {
+  long nrows = (long)g_.nx * g_.ny;
+  if (w && w->np >= 0) {
+    if (!fast_[2] || w->x0 < 0 || w->x0 + w->np > g_.nx) throw std::runtime_error("fft: plane windows need a power-of-two z pass");
+    data += (long)w->x0 * g_.ny * g_.nzp;
+    nrows = (long)w->np * g_.ny;
+    if (nrows == 0) return;
+  }
   if (fast_[2]) {
     ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_ ? (1 | ((nt_loads_env() & 4) ? 2 : 0)) : 0};
+    if (w && w->nt >= 0) a.nt = w->nt;
     // the real split right after the last pass, mirrored values by wave shuffle instead of a round trip of the spectrum
     // through LDS (R2CKernel<.., MIRROR>): 512^3 1.30 -> 1.16 ms, 256^3 0.158 -> 0.155 ms
     {
@@ -1432,10 +1454,17 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride) {
   }
 }
 
-void Fft3::c2r_z(double* data, int ncomp, long comp_stride) {
-  const long nrows = (long)g_.nx * g_.ny;
+void Fft3::c2r_z(double* data, int ncomp, long comp_stride, const PlaneWindow* w) {
+  long nrows = (long)g_.nx * g_.ny;
+  if (w && w->np >= 0) {
+    if (!fast_[2] || w->x0 < 0 || w->x0 + w->np > g_.nx) throw std::runtime_error("fft: plane windows need a power-of-two z pass");
+    data += (long)w->x0 * g_.ny * g_.nzp;
+    nrows = (long)w->np * g_.ny;
+    if (nrows == 0) return;
+  }
   if (fast_[2]) {
     ZArgs a = {data, nrows, g_.nzp, tw_[2], wz_, stream_stores_ ? (1 | ((nt_loads_env() & 8) ? 2 : 0)) : 0};
+    if (w && w->nt >= 0) a.nt = w->nt;
     // every coefficient read once: the mirrored one comes from the neighbouring lane (C2RKernel<.., MIRROR>); 256^3
     // 0.164 -> 0.151 ms, 512^3 1.38 -> 1.19 ms
     {

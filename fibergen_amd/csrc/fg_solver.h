@@ -18,6 +18,7 @@
 #include "fg_fft.h"
 #include "fg_hostmath.h"
 #include "fg_kernels.h"
+#include "fg_transfer.h"
 
 namespace fg {
 
@@ -77,6 +78,11 @@ struct SolverOptions {
   int x_layout = -1;            // x-contiguous intermediate layout [zc/8][y][x][8] between the y passes and the fused x pass
                                 // (the spectrum goes through tau_, free in the displacement loop): 1 on, 0 off, -1 by size
   int cg_fused = -1;            // displacement-space CG with fused vector sweeps (run_cg_u): -1 where the tiled sweep fits, 0 off, 1 on
+  int pair_chunk = 0;           // z and y passes of the transform chain in runs of this many x planes, r2c(c) -> y(c) and
+                                // y^-1(c) -> c2r(c) (hand-over inside the Infinity Cache; measured slower, off by default)
+  int staged_copy = -1;         // host <-> device field transfers through the pinned-buffer pipeline (fg_transfer.h): -1 for
+                                // transfers of 8 MB and more, 1 always, 0 never (one strided copy)
+  int stage_chunk_kb = 16384;   // pipeline stage of the staged transfers (<= 16 MB; tests shrink it)
 };
 
 enum Stage {
@@ -213,8 +219,16 @@ class Solver {
   void fetch_norms_and_errors(const char* where);  // D2H of the sums of squares + error flag, waits for those copies only
   void launch_pending_back();
   void adopt_back();
-  void upload_padded(double* dst, const double* src_unpadded);
-  void download_unpadded(const double* src, double* dst_unpadded);
+  void upload_padded(double* dst, const double* src_unpadded, int ncomp = 1, long dstride = 0);
+  void download_unpadded(const double* src, double* dst_unpadded, int ncomp = 1, long dstride = 0);
+  bool staged_copy(size_t bytes) const;
+  void upload_rows(const std::vector<RowBlock>& blocks, long len, long pitch);
+  void download_rows(const std::vector<RowBlock>& blocks, long len, long pitch);
+  int pair_chunk_planes(int ncomp) const;
+  template <class A, class B>
+  void run_pairs(int pc, A first, B second);
+
+
   void time_begin(int stage);
   void time_end(int stage);
 

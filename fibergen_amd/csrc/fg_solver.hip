@@ -4,6 +4,8 @@
 #include <chrono>
 #include <cmath>
 #include <complex>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -264,7 +266,7 @@ void Solver::set_normals(const double* n_host) {
     FG_HIP_CHECK(hipMalloc(&normals_, 3 * g_.n * sizeof(double)));
     FG_HIP_CHECK(hipMemsetAsync(normals_, 0, 3 * g_.n * sizeof(double), stream_));
   }
-  for (int c = 0; c < 3; ++c) upload_padded(normals_ + (long)c * g_.n, n_host + (long)c * g_.nxyz);
+  upload_padded(normals_, n_host, 3, g_.n);
 }
 
 void Solver::set_bc_projector(const double* P36) {
@@ -347,18 +349,54 @@ StressParams Solver::stress_params(double mu_0, double lambda_0, double alpha) c
   return sp;
 }
 
-void Solver::upload_padded(double* dst, const double* src) {
-  FG_HIP_CHECK(hipSetDevice(device_));
-  FG_HIP_CHECK(hipStreamSynchronize(stream_));
-  FG_HIP_CHECK(hipMemcpy2D(dst, g_.nzp * sizeof(double), src, g_.nz * sizeof(double), g_.nz * sizeof(double),
-                           (size_t)g_.nx * g_.ny, hipMemcpyHostToDevice));
+// Boundary transfers (GetField / SetField F:26931-27010 copy row by row): large fields go through the staged pipeline of
+// fg_transfer.h (padding stripped / added on the device, whole chunks over the link, a team of host threads on the pageable
+// side), small ones through one strided copy.
+bool Solver::staged_copy(size_t bytes) const {
+  return opt_.staged_copy > 0 || (opt_.staged_copy < 0 && bytes >= (size_t)8 << 20);
 }
 
-void Solver::download_unpadded(const double* src, double* dst) {
+void Solver::upload_rows(const std::vector<RowBlock>& blocks, long len, long pitch) {
   FG_HIP_CHECK(hipSetDevice(device_));
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
-  FG_HIP_CHECK(hipMemcpy2D(dst, g_.nz * sizeof(double), src, g_.nzp * sizeof(double), g_.nz * sizeof(double),
-                           (size_t)g_.nx * g_.ny, hipMemcpyDeviceToHost));
+  size_t bytes = 0;
+  for (const RowBlock& b : blocks) bytes += (size_t)b.nrows * len * sizeof(double);
+  if (staged_copy(bytes)) {
+    HostStager::of_device(device_).upload(blocks, len, pitch, (size_t)std::max(1, opt_.stage_chunk_kb) << 10);
+    return;
+  }
+  for (const RowBlock& b : blocks)
+    FG_HIP_CHECK(hipMemcpy2D(b.dev, pitch * sizeof(double), b.host, len * sizeof(double), len * sizeof(double), (size_t)b.nrows,
+                             hipMemcpyHostToDevice));
+}
+
+void Solver::download_rows(const std::vector<RowBlock>& blocks, long len, long pitch) {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  size_t bytes = 0;
+  for (const RowBlock& b : blocks) bytes += (size_t)b.nrows * len * sizeof(double);
+  if (staged_copy(bytes)) {
+    HostStager::of_device(device_).download(blocks, len, pitch, (size_t)std::max(1, opt_.stage_chunk_kb) << 10);
+    return;
+  }
+  for (const RowBlock& b : blocks)
+    FG_HIP_CHECK(hipMemcpy2D(b.host, len * sizeof(double), b.dev, pitch * sizeof(double), len * sizeof(double), (size_t)b.nrows,
+                             hipMemcpyDeviceToHost));
+}
+
+// nc padded components [nx][ny][nzp], `dstride` doubles apart on the device <-> nc unpadded host components
+void Solver::upload_padded(double* dst, const double* src, int nc, long dstride) {
+  std::vector<RowBlock> blocks;
+  for (int c = 0; c < nc; ++c)
+    blocks.push_back(RowBlock{dst + (long)c * dstride, const_cast<double*>(src) + (long)c * g_.nxyz, (long)g_.nx * g_.ny});
+  upload_rows(blocks, g_.nz, g_.nzp);
+}
+
+void Solver::download_unpadded(const double* src, double* dst, int nc, long dstride) {
+  std::vector<RowBlock> blocks;
+  for (int c = 0; c < nc; ++c)
+    blocks.push_back(RowBlock{const_cast<double*>(src) + (long)c * dstride, dst + (long)c * g_.nxyz, (long)g_.nx * g_.ny});
+  download_rows(blocks, g_.nz, g_.nzp);
 }
 
 void Solver::check_device_error(const char* where) {
@@ -446,6 +484,7 @@ void Solver::enable_stage_timing(bool on) {
 long Solver::counter(const std::string& name) const {
   if (name == "interface_voxels") return (long)mixed_n_;
   if (name == "affected_voxels") return (long)aff_n_;
+  if (name == "pair_chunk_planes") return (long)pair_chunk_planes(opt_.mode == 1 ? 1 : 3);
   return -1;
 }
 
@@ -665,15 +704,31 @@ bool Solver::plane_fft_on() const {
   return opt_.plane_fft != 0 && nranks_ == 1 && fft_->can_plane();
 }
 
+// One chunked pair of the transform chain: first(c) then second(c) for runs c of `pc` x planes.
+template <class A, class B>
+void Solver::run_pairs(int pc, A first, B second) {
+  for (int x0 = 0; x0 < g_.nx; x0 += pc) {
+    const int np = std::min(pc, g_.nx - x0);
+    first(x0, np);
+    second(x0, np);
+  }
+}
+
 void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* xscratch) {  // alpha = -1: GammaOperator(..., -1)  F:20575
   if (opt_.mode == 1) {
     // G0OperatorStaggeredHeat  F:20118-20135 on one component: fftVector(., 1), c1 = c10/|k|^2, fftInvVector
     const double scale = 1 / (double)nglobal_;
     const bool has_x = g_.nx > 1, has_y = g_.ny > 1;
     const bool plane = plane_fft_on() && has_x;
+    const int pc1 = pair_chunk_planes(1);
     if (plane) {
       time_begin(2);
       fft_->zy_plane(buf, 1, g_.n, -1);
+      time_end(2);
+    } else if (pc1) {
+      time_begin(2);
+      run_pairs(pc1, [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->r2c_z(buf, 1, g_.n, &w); },
+                [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->c2c_y(buf, 1, g_.n, -1, 1.0, &w); });
       time_end(2);
     } else {
       time_begin(2);
@@ -717,6 +772,13 @@ void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* 
       time_end(8);
       return;
     }
+    if (pc1) {
+      time_begin(7);
+      run_pairs(pc1, [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->c2c_y(buf, 1, g_.n, +1, 1.0, &w); },
+                [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->c2r_z(buf, 1, g_.n, &w); });
+      time_end(7);
+      return;
+    }
     time_begin(7);
     fft_->c2c_y(buf, 1, g_.n, +1, 1.0);
     time_end(7);
@@ -731,13 +793,21 @@ void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* 
   const int xl_opt = opt_.x_layout;
   const bool xl = xscratch && opt_.fuse_x && fft_->can_fuse(0) && fft_->can_xlayout() && g_.nx > 1 && g_.ny > 1 &&
                   (xl_opt > 0 || (xl_opt < 0 && 3.0 * (double)g_.n * sizeof(double) > 1024.0 * 1024 * 1024));
+  const int pc = pair_chunk_planes(3);
   if (xl) {
-    time_begin(2);
-    fft_->r2c_z(buf, 3, g_.n);
-    time_end(2);
-    time_begin(3);
-    fft_->c2c_y_xlayout(buf, g_.n, xscratch, g_.n, 3, -1, 1.0);
-    time_end(3);
+    if (pc) {   // r2c(c) -> y(c) per run of x planes: the spectrum of a chunk is still in the Infinity Cache when the y pass reads it
+      time_begin(2);
+      run_pairs(pc, [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->r2c_z(buf, 3, g_.n, &w); },
+                [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->c2c_y_xlayout(buf, g_.n, xscratch, g_.n, 3, -1, 1.0, &w); });
+      time_end(2);
+    } else {
+      time_begin(2);
+      fft_->r2c_z(buf, 3, g_.n);
+      time_end(2);
+      time_begin(3);
+      fft_->c2c_y_xlayout(buf, g_.n, xscratch, g_.n, 3, -1, 1.0);
+      time_end(3);
+    }
     G0Params gp;
     gp.c10 = -alpha / (opt_.mu_0);
     gp.c20 = -alpha / (opt_.mu_0 * (1 + opt_.mu_0 / (opt_.lambda_0 + opt_.mu_0)));
@@ -747,6 +817,13 @@ void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* 
     time_begin(5);
     fft_->fused_g0(xscratch, g_.n, 0, 1 / (double)nglobal_, gp, 0, 3, 31, 0, true);
     time_end(5);
+    if (pc) {
+      time_begin(7);
+      run_pairs(pc, [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->c2c_y_xlayout(xscratch, g_.n, buf, g_.n, 3, +1, 1.0, &w); },
+                [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->c2r_z(buf, 3, g_.n, &w); });
+      time_end(7);
+      return;
+    }
     time_begin(7);
     fft_->c2c_y_xlayout(xscratch, g_.n, buf, g_.n, 3, +1, 1.0);
     time_end(7);
@@ -763,6 +840,11 @@ void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* 
     if (plane) {   // small grids: z and y transforms of a plane in one kernel
       time_begin(2);
       fft_->zy_plane(buf, 3, g_.n, -1);
+      time_end(2);
+    } else if (pc) {
+      time_begin(2);
+      run_pairs(pc, [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->r2c_z(buf, 3, g_.n, &w); },
+                [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->c2c_y(buf, 3, g_.n, -1, 1.0, &w); });
       time_end(2);
     } else {
       time_begin(2);
@@ -812,12 +894,28 @@ void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* 
     time_end(8);
     return;
   }
+  if (pc) {
+    time_begin(7);
+    run_pairs(pc, [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->c2c_y(buf, 3, g_.n, +1, 1.0, &w); },
+              [&](int x0, int np) { const PlaneWindow w = {x0, np}; fft_->c2r_z(buf, 3, g_.n, &w); });
+    time_end(7);
+    return;
+  }
   time_begin(7);
   fft_->c2c_y(buf, 3, g_.n, +1, 1.0);
   time_end(7);
   time_begin(8);
   fft_->c2r_z(buf, 3, g_.n);
   time_end(8);
+}
+
+// Planes per chunk of the paired z / y passes (0 = whole-field passes, the default).  Measured in round 6 and NOT faster:
+// a bytes-only pair of copy passes gains 1.32 x from 128-MB chunks (tools/mall_chunk_probe.hip), the transform passes lose
+// 3-10 % at every chunk size (EXPERIMENTS.md, round 6) -- they are bound by the requests a workgroup keeps in flight, which an
+// Infinity-Cache hit does not shorten.  Kept as an option: same kernels on the same lines, bit-identical iterates.
+int Solver::pair_chunk_planes(int) const {
+  if (opt_.pair_chunk <= 0 || !fft_->can_window() || g_.nx < 2 || g_.ny < 2 || plane_fft_on()) return 0;
+  return std::min(opt_.pair_chunk, g_.nx);
 }
 
 // ------------------------------------------------------------------ displacement-based pass
@@ -2050,15 +2148,13 @@ void Solver::get_field(const std::string& name, double* out) {
     return;
   }
   if (name == "f_hat") {  // complex [3][nx][ny][nz/2+1], row padding stripped
-    FG_HIP_CHECK(hipStreamSynchronize(stream_));
-    FG_HIP_CHECK(hipMemcpy2D(out, g_.nzf * sizeof(cplx), fu_, g_.nzc * sizeof(cplx), g_.nzf * sizeof(cplx),
-                             (size_t)3 * g_.nx * g_.ny, hipMemcpyDeviceToHost));
+    download_rows({RowBlock{fu_, out, (long)3 * g_.nx * g_.ny}}, 2 * g_.nzf, 2 * g_.nzc);
     return;
   }
   if (opt_.mode == 1 && name == "sigma") {  // calcStress with C0 = 0  F:15496-15508: the flux
     if (pt_.n < 1) throw std::runtime_error("No materials specified");
     launch_sc_flux(g_, scalar_params(0.0, 1.0), ptrs3(eps_), phase_ptrs(), ptrs3(tau_), stream_);
-    for (int c = 0; c < 3; ++c) download_unpadded(tau_ + (long)c * g_.n, out + (long)c * g_.nxyz);
+    download_unpadded(tau_, out, 3, g_.n);
     return;
   }
   if (opt_.mode == 1 && name == "u") {  // potential T = G0 div(C0 : g), alpha = 1  F:15536-15541
@@ -2079,7 +2175,7 @@ void Solver::get_field(const std::string& name, double* out) {
     for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
     launch_stress(g_, stress_params(0.0, 0.0, 1.0), ptrs6(eps_), phi, nrm, ptrs6(tau_), derr_, stream_);
     check_device_error("sigma");
-    for (int c = 0; c < 6; ++c) download_unpadded(tau_ + (long)c * g_.n, out + (long)c * g_.nxyz);
+    download_unpadded(tau_, out, 6, g_.n);
     return;
   }
   if (name == "u" && opt_.mode == 2) {
@@ -2096,7 +2192,7 @@ void Solver::get_field(const std::string& name, double* out) {
     timing_ = false;
     fft_g0_chain(fu_, a, c12);
     timing_ = timing;
-    for (int c = 0; c < 3; ++c) download_unpadded(fu_ + (long)c * g_.n, out + (long)c * g_.nxyz);
+    download_unpadded(fu_, out, 3, g_.n);
     return;
   }
   if (name == "u") {  // u = G0 div (C0 : eps), alpha = 1  F:15509-15521
@@ -2114,16 +2210,18 @@ void Solver::get_field(const std::string& name, double* out) {
     }
     launch_g0(g_, ptrs3(ub), tb, c10, c20, G0Layout{0, 0, 0}, stream_);
     fft_->inverse(ub, 3, g_.n);
-    for (int c = 0; c < 3; ++c) download_unpadded(ub + (long)c * g_.n, out + (long)c * g_.nxyz);
+    download_unpadded(ub, out, 3, g_.n);
     return;
   }
   const int nc = field_components(name);
   if (nc == 0) throw std::runtime_error("Unknown field '" + name + "'");
+  std::vector<RowBlock> blocks;
   for (int c = 0; c < nc; ++c) {
     double* d = device_component(name, c);
     if (!d) throw std::runtime_error("field '" + name + "' is not available");
-    download_unpadded(d, out + (long)c * g_.nxyz);
+    blocks.push_back(RowBlock{d, out + (long)c * g_.nxyz, (long)g_.nx * g_.ny});
   }
+  download_rows(blocks, g_.nz, g_.nzp);
 }
 
 void Solver::set_field(const std::string& name, const double* in) {
@@ -2133,9 +2231,7 @@ void Solver::set_field(const std::string& name, const double* in) {
   u_valid_ = false;
   su_valid_ = false;   // slab driver: the strain field is the state again
   if (name == "f_hat") {
-    FG_HIP_CHECK(hipStreamSynchronize(stream_));
-    FG_HIP_CHECK(hipMemcpy2D(fu_, g_.nzc * sizeof(cplx), in, g_.nzf * sizeof(cplx), g_.nzf * sizeof(cplx),
-                             (size_t)3 * g_.nx * g_.ny, hipMemcpyHostToDevice));
+    upload_rows({RowBlock{fu_, const_cast<double*>(in), (long)3 * g_.nx * g_.ny}}, 2 * g_.nzf, 2 * g_.nzc);
     return;
   }
   if (name == "normals") {
@@ -2144,11 +2240,13 @@ void Solver::set_field(const std::string& name, const double* in) {
   }
   const int nc = field_components(name);
   if (nc == 0 || name == "sigma" || name == "sumsq") throw std::runtime_error("field '" + name + "' cannot be set");
+  std::vector<RowBlock> blocks;
   for (int c = 0; c < nc; ++c) {
     double* d = device_component(name, c);
     if (!d) throw std::runtime_error("field '" + name + "' is not available");
-    upload_padded(d, in + (long)c * g_.nxyz);
+    blocks.push_back(RowBlock{d, const_cast<double*>(in) + (long)c * g_.nxyz, (long)g_.nx * g_.ny});
   }
+  upload_rows(blocks, g_.nz, g_.nzp);
 }
 
 }  // namespace fg

@@ -101,7 +101,7 @@ class LSSolver:
                 if v not in ("epsilon", "residual"):
                     raise RuntimeError("error estimator '%s' is not available (epsilon, residual)" % v)
                 self._check(self._lib.fg_set_option_i(self._h, b"error_estimator", 1 if v == "residual" else 0))
-            elif k in ("u_loop", "fuse_x", "cg_fused", "fuse_stress_div", "u_tile", "x_layout", "plane_fft", "slab_split", "slab_interleave", "slab_loopback", "laminate_overlap", "phi_sweep"):
+            elif k in ("u_loop", "fuse_x", "cg_fused", "fuse_stress_div", "u_tile", "x_layout", "plane_fft", "slab_split", "slab_interleave", "slab_loopback", "laminate_overlap", "phi_sweep", "pair_chunk", "staged_copy", "stage_chunk_kb"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
             elif k in ("maxiter", "loadstep_extrapolation_order"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))

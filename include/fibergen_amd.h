@@ -173,7 +173,8 @@ int fg_get_stage_times(const fg_solver* s, double* ms /* [FG_NUM_TIMED_KERNELS] 
 int fg_get_stage_timing_bias(const fg_solver* s, double* ms);
 /* Sizes and set-up facts of this solver (no counterpart in the reference; bench.py prices the laminate correction with them):
  * "interface_voxels" / "affected_voxels" = lengths of the laminate correction's voxel lists (0 until a laminate pass built
- * them).  Unknown names give -1. */
+ * them); "pair_chunk_planes" = x planes per chunk of the paired z / y transform passes (option pair_chunk; 0 = whole-field
+ * passes: stage timing then reports each pair in the slot of its first pass).  Unknown names give -1. */
 long fg_get_counter(const fg_solver* s, const char* name);
 
 /* Measurement helper (no counterpart in the reference): achieved HBM bandwidth of a streaming copy a = b and of the

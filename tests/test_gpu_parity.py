@@ -602,6 +602,69 @@ def test_x_contiguous_intermediate_layout(grid, mixing):
         s.close()
 
 
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+@pytest.mark.parametrize("grid,xl", [((16, 16, 128), 0), ((16, 16, 128), 1), ((32, 8, 128), 0), ((8, 64, 124), 1), ((64, 16, 64), 0)])
+def test_chunked_transform_pairs_are_bit_identical(grid, xl, mixing):
+    """pair_chunk = P: the z and y passes run in runs of P x planes, r2c(c) -> y(c) and y^-1(c) -> c2r(c) (on large grids the
+    hand-over then stays in the Infinity Cache).  Same kernels on the same lines: every iterate is bit-identical to the
+    whole-field passes, with the plain and the x-contiguous intermediate layout, for chunk lengths that do and do not divide
+    nx."""
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    out = {}
+    for pc in (0, 1, 3, grid[0] // 2, grid[0]):
+        s = make_gpu_solver(grid, mixing=mixing, tol=1e-8, x_layout=xl, plane_fft=0, pair_chunk=pc)
+        assert s.run(E) is False
+        out[pc] = (s.iterations, np.array(s.residuals), s.get_field("epsilon"), s.mean_stress(), s.get_field("u"))
+        s.close()
+    for pc in out:
+        assert out[pc][0] == out[0][0]
+        for k in (1, 2, 3, 4):
+            assert np.array_equal(out[pc][k], out[0][k]), (pc, k)
+    # ... in the conjugate gradients and the strain-state pipeline
+    for kw in (dict(method="cg"), dict(u_loop=0)):
+        res = []
+        for pc in (0, 3):
+            s = make_gpu_solver(grid, mixing=mixing, tol=1e-8, x_layout=xl, plane_fft=0, pair_chunk=pc, **kw)
+            assert s.run(E) is False
+            res.append((s.iterations, np.array(s.residuals), s.get_field("epsilon")))
+            s.close()
+        assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (8, 16, 5), (32, 8, 128), (40, 24, 66)])
+def test_staged_host_transfers_are_byte_identical(grid):
+    """staged_copy = 1: fields cross the boundary through the pinned-buffer pipeline (padding stripped / added on the device,
+    chunks on the copy engine, a team of host threads on the pageable side) instead of one strided copy -- the same bytes,
+    whatever the chunk size (rows that do not divide the chunk, one row per chunk, everything in one chunk)."""
+    rng = np.random.default_rng(5)
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    mats, phis, normals = two_phase_setup(grid, "laminate")
+    ref = None
+    for staged, kb in ((0, 16384), (1, 16384), (1, 1), (1, 7), (1, 64)):
+        from fibergen_amd import LSSolver
+        s = LSSolver(*grid, 1.0, 1.0, 1.0)
+        s.set_options(staged_copy=staged, stage_chunk_kb=kb)
+        s.set_num_phases(2)
+        for p in range(2):
+            s.set_phase(p, mats[p][0], mats[p][1], phis[p])
+        s.set_normals(normals)
+        s.set_options(mixing_rule="laminate", tol=1e-8)
+        eps0 = np.random.default_rng(7).standard_normal((6,) + grid)
+        s.set_field("epsilon", eps0)
+        back = s.get_field("epsilon")
+        assert np.array_equal(back, eps0)
+        assert np.array_equal(s.get_field("phi")[1], phis[1]) and np.array_equal(s.get_field("normals"), normals)
+        assert s.run(E) is False
+        got = (s.iterations, s.get_field("epsilon"), s.get_field("sigma"), s.get_field("u"), s.get_field("f_hat"))
+        s.close()
+        if ref is None:
+            ref = got
+        else:
+            assert got[0] == ref[0]
+            for a, b in zip(got[1:], ref[1:]):
+                assert np.array_equal(a, b)
+
+
 def test_laminate_rule_at_oblique_normals_is_the_rotated_closed_form():
     """The HIP laminate rule (get_field('sigma'), FG_STAGE_STRESS) at random oblique normals against the reference-held
     closed form: P(eps, n) = R [C_lam : (R^T eps R)] R^T with C_lam from calc_isotropic_laminate F:26412-26446 and R e_x = n
