@@ -341,10 +341,20 @@ def cpu_baseline(n, mixing, phi, normals, budget_s=25.0, others=()):
     limits = cpu_limits()
     usable = min(x for x in (ncpu, limits["affinity_cpus"], limits["cgroup_quota_cpus"]) if x)
     # thread counts up to what the node grants (a CFS quota of 16 CPUs makes 32 threads slower than 16: throttling, not the code)
-    counts = sorted({t for t in (4, 8, 16, 32, per_socket or 64, cores or ncpu, int(usable)) if t and t <= usable})
+    counts = sorted({t for t in (4, 8, 16, 32, per_socket or 64, cores or ncpu, int(usable)) if t and t <= usable}) or [1]
     thr0 = cpu_throttled()
     t_start = time.perf_counter()
-    tmp = tempfile.mkdtemp(prefix="fg_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    # inputs are handed to the child processes as files: memory-backed where /dev/shm has the room (a container's default is
+    # 64 MB; the 512^3 laminate leg stages 4 GB), the default temporary directory otherwise
+    biggest = max([n[0]] + [o[0] for o in others])
+    need_stage = 1.05 * 8 * biggest ** 3 * 4
+    stage_dir = None
+    try:
+        if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need_stage:
+            stage_dir = "/dev/shm"
+    except OSError:
+        stage_dir = None
+    tmp = tempfile.mkdtemp(prefix="fg_cpu_", dir=stage_dir)
 
     def stash(tag, ph, nr):
         pp = os.path.join(tmp, tag + "_phi.npy")
@@ -497,8 +507,9 @@ def measure_single(args, n_edge, mixing, mode, device, E, detail):
         # of the C ABI sees it -- phase fractions over PCIe in, the reference's default tolerance 1e-4, strain and stress
         # fields out.  Reported beside `value`, never as `value` (whose inputs are resident in HBM).
         mats = materials(mode)
+        phi0 = 1.0 - phi   # (the caller's array: formed before the clock starts)
         t0 = time.perf_counter()
-        s.set_phase(0, mats[0][0], mats[0][1], 1.0 - phi)
+        s.set_phase(0, mats[0][0], mats[0][1], phi0)
         s.set_phase(1, mats[1][0], mats[1][1], phi)
         s.synchronize()
         t1 = time.perf_counter()
@@ -611,6 +622,8 @@ def main():
     N = args.n ** 3
     metric = "LS iterations/sec (basic scheme, staggered grid, %s)" % (
         args.mode + " scalar mode" if scalar else ("Stokes flow, dual scheme" if stokes else "linear elastic"))
+    if args.gpus == 1 and args.method != "cg":
+        metric += "; value = fg_iterate passes/s, run_load_case_it_s = the same loop under the stop rule"
 
     if world == 1:
         # ------------------------------------------------------------------ one GPU
@@ -632,11 +645,15 @@ def main():
         per_voxel = (24 + 7 * 16) if scalar else A_MIN_BYTES_PER_VOXEL
         out = {
             "metric": metric, "value": it_s, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": None, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            # `value` times fg_iterate: K passes enqueued back to back, the stop rule's sums stay on the device.  The loop SURVEY
+            # 8d defines -- fg_run_load_case, the norms reaching the host every pass -- is run_load_case_it_s, here and top level
             "config": {"workload": "%d^3 two-phase fibre RVE (K=%d non-overlapping capsules, R=%.4f, L=%.3f, vf=%.3f), contrast 10, "
                                    "mixing=%s" % (args.n, res["rve"]["K"], res["rve"]["R"], res["rve"]["L"], res["rve"]["vf"], args.mixing),
-                       "grid": list(n), "mixing_rule": args.mixing, "mode": args.mode, "parallelism": "1 GPU"},
+                       "grid": list(n), "mixing_rule": args.mixing, "mode": args.mode, "parallelism": "1 GPU",
+                       "timed_call": "fg_iterate (no stop-rule hand-over to the host inside the timed region)",
+                       "run_load_case_it_s": res.get("run_load_case_it_s")},
             "roofline": roof,
             "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"], "repeats": res["repeats"],
             "sustained_it_s": res.get("sustained_it_s"), "run_load_case_it_s": res.get("run_load_case_it_s"),
@@ -660,6 +677,11 @@ def main():
             if "g0" in k2:
                 out["gamma0_apply_standalone"] = {"kernel": "k_g0 (fuse_x=0)", **k2["g0"],
                                                   "frac_of_hbm_peak": k2["g0"]["GBps"] / HBM_PEAK_GBS}
+                if 3 * 16 * args.n * args.n * (args.n // 2 + 1) < 2 * 256e6:
+                    # the three spectrum components are less than twice the 256 MB Infinity Cache: part of the kernel's bytes
+                    # are cache hits (FETCH_SIZE counts them too), a fraction of HBM peak above the copy rate is not an HBM
+                    # figure -- the one that is: gamma0_apply_standalone_512 (from the 512^3 leg under `also`)
+                    out["gamma0_apply_standalone"]["cache_assisted"] = True
         try:   # the measured roofline: streaming copy / triad of the library on this GPU, 1 GiB arrays
             import ctypes
             from fibergen_amd import _lib
@@ -727,6 +749,15 @@ def main():
                 elif mode2 == "viscosity":
                     E2 = np.array([1.0, -1, 0, 0, 0, 0])
                 s2, r2, phi2, nrm2 = measure_single(args, ne, mix, mode2, local_rank, E2, detail=False)
+                if mode2 == "elasticity" and 3 * 16 * ne * ne * (ne // 2 + 1) >= 2 * 256e6 and "gamma0_apply_standalone_512" not in out:
+                    # the stand-alone Green-operator kernel on a grid the Infinity Cache cannot help with (north_star's
+                    # ">= 50 % of the HBM roofline in the Gamma0-apply kernel", SURVEY 8d: 96 B per frequency)
+                    s2.set_options(fuse_x=0)
+                    k3, _, _ = kernel_table(s2, E2, (ne,) * 3, 5, False, False)
+                    s2.set_options(fuse_x=1)
+                    if "g0" in k3:
+                        out["gamma0_apply_standalone_512" if ne == 512 else "gamma0_apply_standalone_%d" % ne] = {
+                            "kernel": "k_g0 (fuse_x=0)", "grid": [ne] * 3, **k3["g0"], "frac_of_hbm_peak": k3["g0"]["GBps"] / HBM_PEAK_GBS}
                 s2.close()
                 r2["kernels"] = {k: {"avg_ms": v["avg_ms"], "GBps": v["GBps"]} for k, v in r2["kernels"].items()}
                 if 3 * 8 * (ne ** 2) * (ne + 2) < 200e6 and out.get("cache_stream"):
@@ -741,7 +772,11 @@ def main():
         if also:
             out["also"] = also
         if not args.no_cpu_baseline and not scalar and not stokes:
-            out["cpu_baseline"] = cpu_baseline(n, args.mixing, phi, normals, args.cpu_budget, cpu_others)
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, args.mixing, phi, normals, args.cpu_budget, cpu_others)
+            except Exception as e:  # noqa: BLE001  (the GPU measurements above must not be lost with the CPU leg)
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e), "value": None, "unit": "it/s", "kind": "port"}
+        if "value" in out.get("cpu_baseline", {}) and out["cpu_baseline"]["value"]:
             # (a ratio against a baseline that stops scaling says little: it is a top-level key only when the sweep grew with
             # the thread count; otherwise it stays inside cpu_baseline beside the note that says so)
             if out["cpu_baseline"]["scales_with_threads"]:

@@ -93,6 +93,7 @@ SIGNATURES = {
                                    ctypes.c_double, ctypes.c_double, ctypes.c_double, c_double_p, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p, c_double_p,
                                    ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
+    "fg_voxelize_team_depth": (ctypes.c_int, [ctypes.c_int]),
 }
 
 _lib = None

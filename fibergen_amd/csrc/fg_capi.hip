@@ -272,7 +272,7 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
       o.loadstep_extrapolation_order = (int)value;
     }
     else if (k == "error_estimator") {
-      if (value != 0 && value != 1) throw std::runtime_error("error_estimator must be 0 (epsilon) or 1 (residual)");
+      if (value < 0 || value > 4) throw std::runtime_error("Unknown error estimator (0 epsilon, 1 residual, 2 sigma, 3 energy, 4 none)");
       o.error_estimator = (int)value;
     }
     else throw std::runtime_error("unknown option '" + k + "'");

@@ -38,7 +38,15 @@ class Comm {
   virtual int rank() const = 0;
   virtual int size() const = 0;
   // Sends to / receives from one peer are matched in issue order (NCCL semantics).
+  // CONTRACT -- receiver-gated: bytes reach a receive buffer of THIS rank no earlier than this rank's own exchange() call that
+  // names the buffer has been reached on `stream` (RCCL: the receive is a kernel on the receiver's stream; LocalHub: one
+  // stream for all members; CallbackComm: synchronises).  The slab driver relies on it: the y-slab spectrum lands in fu_
+  // (Solver::slab_buffer, FG_BUF_SPECTRUM_Y), which holds the divergence field until the forward y pass of the component has
+  // consumed it, and is written again only behind comm_wait(kXHaloU).  A transport that PUSHES into a peer's buffer when the
+  // sender is ready (put / IPC writes) breaks that aliasing and must report pushes() = true: the driver then keeps the
+  // spectrum in the second half of the polarisation field instead (one more field in the working set of a pass).
   virtual void exchange(const XOp* ops, int n, hipStream_t stream) = 0;
+  virtual bool pushes() const { return false; }
   // in place on a device buffer; min_op: element-wise minimum instead of the sum
   virtual void allreduce(double* buf, int n, bool min_op, hipStream_t stream) = 0;
   // collectives issued between the two calls may be fused into one launch (RCCL group); no-ops elsewhere

@@ -56,6 +56,9 @@ long partial_rows(const Grid& g);  // rows (of up to 8 doubles) the partial-sum 
 
 void launch_stress(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps, const FieldPtrs<kMaxPhases>& phi,
                    const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, int* error_flag, hipStream_t s);
+// meanW  F:12239-12262: the sum of the energy densities (sp.alpha = 1; the caller divides by the number of voxels) in out6[0]
+void launch_energy_mean(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps, const FieldPtrs<kMaxPhases>& phi,
+                        const FieldPtrs<3>& normals, double* partial, double* out6, int* error_flag, hipStream_t s);
 void launch_stress_mean(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
                         const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& normals, double* partial, double* out6,
                         int* error_flag, hipStream_t s);
@@ -78,7 +81,7 @@ void launch_eps_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtr
                      const FieldPtrs<3>& f, double* partial, double* sum6, hipStream_t s);
 // two_phase != nullptr: mod.p[0] is phi_1 of two complementary phases (launch_complement_check), the sweep forms the moduli
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
-                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s, bool sum_tau = false,
+                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s, bool sum_tau = false,
                    const PhaseTable* two_phase = nullptr);
 // the tiled sweep on the NEW search direction of the conjugate gradients, formed on the fly: p_new = r + b p_old with
 // b = (sc[i_num] / nvox + small) / (sc[i_den] / nvox + small), stored to p_new (a buffer of its own), f = div((C - C0) : grad_s p_new)

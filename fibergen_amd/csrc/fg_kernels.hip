@@ -21,9 +21,12 @@ namespace {
 
 // ----------------------------------------------------------------------------- stress
 // calcStress  F:18134-18184.  REDUCE = false: tau <- P(eps) - C0:eps written out.
-// REDUCE = true: per-block partial sums of P (meanPK1  F:12312-12351, alpha already /N).
+// REDUCE = 1: per-block partial sums of P (meanPK1  F:12312-12351, alpha already /N).
+// REDUCE = 2: per-block partial sums of the energy density 1/2 P:eps (meanW  F:12239-12262 with the mixing rule's W: for
+// Voigt mixing sum_p phi_p 1/2 (C_p eps):eps = 1/2 P:eps; for laminate mixing c1 W1(F1) + c2 W2(F2) = 1/2 P:eps as well, the
+// cross term c1 c2 a.(sigma_1 - sigma_2) n vanishing with the traction jump the interface solve removes), in component 0.
 // MIX / NPH are compile-time so the Voigt two-phase sweep keeps a small register footprint.
-template <bool REDUCE, int MIX, int NPH>
+template <int REDUCE, int MIX, int NPH>
 __global__ __launch_bounds__(kBlock) void k_stress(Grid g, StressParams sp, FieldPtrs<6> eps, FieldPtrs<kMaxPhases> phi,
                                                    FieldPtrs<3> normals, FieldPtrs<6> tau, double* partial,
                                                    int* error_flag) {
@@ -58,6 +61,8 @@ __global__ __launch_bounds__(kBlock) void k_stress(Grid g, StressParams sp, Fiel
     for (int q = 0; q < NPH; ++q) ph[q] = f[q].x;
     nv[0] = nn[0].x; nv[1] = nn[1].x; nv[2] = nn[2].x;
     int err = stress_voxel<NPH>(F, ph, nv, sp, P0);
+    double w = 0.0;
+    if (REDUCE == 2) w = 0.5 * (P0[0] * F[0] + P0[1] * F[1] + P0[2] * F[2] + 2 * (P0[3] * F[3] + P0[4] * F[4] + P0[5] * F[5]));
     if (second) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) F[c] = e[c].y;
@@ -65,12 +70,15 @@ __global__ __launch_bounds__(kBlock) void k_stress(Grid g, StressParams sp, Fiel
       for (int q = 0; q < NPH; ++q) ph[q] = f[q].y;
       nv[0] = nn[0].y; nv[1] = nn[1].y; nv[2] = nn[2].y;
       err |= stress_voxel<NPH>(F, ph, nv, sp, P1);
+      if (REDUCE == 2) w += 0.5 * (P1[0] * F[0] + P1[1] * F[1] + P1[2] * F[2] + 2 * (P1[3] * F[3] + P1[4] * F[4] + P1[5] * F[5]));
     } else {
 #pragma unroll
       for (int c = 0; c < 6; ++c) P1[c] = 0.0;
     }
     if (err) atomicOr(error_flag, 1);
-    if (REDUCE) {
+    if (REDUCE == 2) {
+      acc[0] += w;
+    } else if (REDUCE) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) acc[c] += P0[c] + P1[c];
     } else {
@@ -1353,7 +1361,7 @@ int grid_for(long nwork, int max_blocks) {
 }  // namespace
 
 namespace {
-template <bool REDUCE>
+template <int REDUCE>
 void stress_dispatch(dim3 grid, const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
                      const FieldPtrs<kMaxPhases>& phi, const FieldPtrs<3>& normals, const FieldPtrs<6>& tau,
                      double* partial, int* error_flag, hipStream_t s) {
@@ -1381,7 +1389,7 @@ int reduce_blocks(const Grid& g) { return grid_for((long)g.nx * g.ny * g.nzc, kM
 void launch_stress(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps, const FieldPtrs<kMaxPhases>& phi,
                    const FieldPtrs<3>& normals, const FieldPtrs<6>& tau, int* error_flag, hipStream_t s) {
   const long npairs = (long)g.nx * g.ny * g.nzc;
-  stress_dispatch<false>(dim3(grid_for(npairs, 1 << 20)), g, sp, eps, phi, normals, tau, nullptr, error_flag, s);
+  stress_dispatch<0>(dim3(grid_for(npairs, 1 << 20)), g, sp, eps, phi, normals, tau, nullptr, error_flag, s);
 }
 
 void launch_stress_mean(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps,
@@ -1389,7 +1397,16 @@ void launch_stress_mean(const Grid& g, const StressParams& sp, const FieldPtrs<6
                         int* error_flag, hipStream_t s) {
   const int nb = reduce_blocks(g);
   FieldPtrs<6> none = {};
-  stress_dispatch<true>(dim3(nb), g, sp, eps, phi, normals, none, partial, error_flag, s);
+  stress_dispatch<1>(dim3(nb), g, sp, eps, phi, normals, none, partial, error_flag, s);
+  hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, out6);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_energy_mean(const Grid& g, const StressParams& sp, const FieldPtrs<6>& eps, const FieldPtrs<kMaxPhases>& phi,
+                        const FieldPtrs<3>& normals, double* partial, double* out6, int* error_flag, hipStream_t s) {
+  const int nb = reduce_blocks(g);
+  FieldPtrs<6> none = {};
+  stress_dispatch<2>(dim3(nb), g, sp, eps, phi, normals, none, partial, error_flag, s);
   hipLaunchKernelGGL(k_fold<OpSum>, dim3(1), dim3(kBlock), 0, s, partial, nb, 6, 0.0, out6);
   FG_HIP_CHECK(hipGetLastError());
 }

@@ -975,7 +975,7 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
 }
 
 void launch_u_tile(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<3>& u, const FieldPtrs<2>& mod,
-                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, int rows, hipStream_t s,
+                   const FieldPtrs<3>& f, const Vec6& E, double* partial, double* sumsq6, hipStream_t s,
                    bool sum_tau, const PhaseTable* two_phase) {
   const int nzh = g.nz / 2;
   if (two_phase) {   // mod.p[0] is phi_1 of two complementary phases: the default tile shapes

@@ -34,6 +34,9 @@ class SlabGroup {
                       void* user);
   void iterate(const double* E6, int n);            // n passes without the stop rule (bench, profiling)
   void mean_stress(double* out6);
+  double mean_energy();
+  void estimator_begin(bool fresh);
+  void estimator_update(double* abs_err, double* rel_err);
   void mean_strain(double* out6);
   double volume_fraction(int p);
   void calc_ref_material();

@@ -171,8 +171,10 @@ double* Solver::slab_buffer(int id) {
     // one slab: the identity.  Otherwise the y-slab spectrum lands in fu_: f has been consumed by the forward y pass when the
     // all-to-all of its component is posted, and the next sweep writes fu_ only behind the halo exchange that follows the
     // backward all-to-all -- one field less in the working set of a pass (256^3 on 8 ranks: 291 -> 239 MB, inside the 256 MB
-    // Infinity Cache)
-    case FG_BUF_SPECTRUM_Y: return (nranks_ == 1 && !slab_loopback()) ? tau_ : fu_;
+    // Infinity Cache).  Valid for receiver-gated transports only (Comm::exchange's contract); one that pushes gets tau_ + 3 n.
+    case FG_BUF_SPECTRUM_Y:
+      if (nranks_ == 1 && !slab_loopback()) return tau_;
+      return (comm_ && comm_->pushes()) ? tau_ + 3 * g_.n : fu_;
     case FG_BUF_U: return su_[su_cur_ ^ 1];                                  // the displacement the chain is producing
     case FG_BUF_MODULI: return smod_;
     case FG_BUF_HALO_SEND_LO: return halo_[0];
@@ -323,7 +325,7 @@ void Solver::slab_front_fast(const double* E6, bool sum_tau, const double* u_src
   }
   const PhaseTable pt2 = phase_table();
   launch_u_tile(gu_, opt_.mu_0, opt_.lambda_0, strided3(u_in, ucs_), mod, ptrs3(fu_), E, partial_, dscal_ + kSlotSumSq,
-                opt_.u_tile, stream_, sum_tau, slab_phi_ ? &pt2 : nullptr);
+                stream_, sum_tau, slab_phi_ ? &pt2 : nullptr);
   if (laminate) return;   // slab_front_laminate (next step: the planes of the neighbours have to be posted first)
   time_end(0);
   if (reduce) slab_reduce(kSlotSumSq, sum_tau ? 12 : 6, false);
@@ -743,6 +745,56 @@ void SlabGroup::mean_stress(double* out6) {
   for (int c = 0; c < 6; ++c) out6[c] = m_[0]->hscal_[kSlotMean + c];
 }
 
+// meanW  F:12239-12262 over all slabs
+double SlabGroup::mean_energy() {
+  check_members();
+  prepare();
+  for (Solver* s : m_) {
+    if (s->opt_.mode == 1) throw std::runtime_error("the energy error estimator is not available in heat / porous mode");
+    if (s->su_valid_ && s->eps_stale_) s->slab_materialise_eps();
+    FieldPtrs<3> nrm;
+    for (int c = 0; c < 3; ++c) nrm.p[c] = s->normals_ ? s->normals_ + (long)c * s->g_.n : nullptr;
+    launch_energy_mean(s->g_, s->stress_params(0.0, 0.0, 1.0), s->ptrs6(s->eps_), s->phase_ptrs(), nrm, s->partial_,
+                       s->dscal_ + kSlotMean, s->derr_, s->stream_);
+  }
+  reduce_and_fetch(kSlotMean, 6, false);
+  return m_[0]->hscal_[kSlotMean] / (double)m_[0]->nglobal_;
+}
+
+// the estimators that measure a mean of the strain field (Solver::estimator_begin / estimator_update), collectively: every
+// rank holds the same all-reduced means and so the same estimator state
+void SlabGroup::estimator_begin(bool fresh) {
+  Solver& a = *m_[0];
+  if (a.opt_.error_estimator < 2) return;
+  if (a.opt_.mode == 1) throw std::runtime_error("heat / porous mode supports the error estimators epsilon and residual");
+  double m[6] = {0, 0, 0, 0, 0, 0};
+  double w = 0.0;
+  if (a.opt_.error_estimator == 2 && !fresh) mean_stress(m);
+  if (a.opt_.error_estimator == 3 && !fresh) w = mean_energy();
+  for (Solver* s : m_) {
+    if (a.opt_.error_estimator == 2) s->est_.start_sigma(m);
+    if (a.opt_.error_estimator == 3) s->est_.start_energy(w);
+  }
+}
+
+void SlabGroup::estimator_update(double* abs_err, double* rel_err) {
+  Solver& a = *m_[0];
+  if (a.opt_.error_estimator == 2) {
+    double m[6];
+    mean_stress(m);
+    double ae = 0.0, re = 0.0;
+    for (Solver* s : m_) s->est_.update_sigma(m, &ae, &re);
+    *abs_err = ae, *rel_err = re;
+  } else if (a.opt_.error_estimator == 3) {
+    const double w = mean_energy();
+    double ae = 0.0, re = 0.0;
+    for (Solver* s : m_) s->est_.update_energy(w, &ae, &re);
+    *abs_err = ae, *rel_err = re;
+  } else if (a.opt_.error_estimator == 4) {
+    *abs_err = *rel_err = 1.0;
+  }
+}
+
 double SlabGroup::volume_fraction(int p) {
   check_members();
   prepare();
@@ -973,6 +1025,7 @@ bool SlabGroup::run_step(const double* E0, const double* S0, bool fresh) {
   } else {
     prev = current_norm9();
   }
+  estimator_begin(fresh);
   for (Solver* s : m_) s->in_run_ = true;
   // a continuing step in the displacement loop: the state is u of the previous load (eps = E_old + sym grad u); one
   // unrecorded pass turns it into u' with eps' = E_new + sym grad u', the field the reference's first iteration of the step
@@ -1057,9 +1110,10 @@ bool SlabGroup::run_step(const double* E0, const double* S0, bool fresh) {
     for (int c = 0; c < 6; ++c) s9 += mm[c] * mm[c];
     for (int c = 3; c < 6; ++c) s9 += mm[c] * mm[c];
     const double cur = std::sqrt(s9);
-    const double abs_err = std::fabs(prev - cur);
-    const double rel_err = abs_err / (small + cur);
+    double abs_err = std::fabs(prev - cur);
+    double rel_err = abs_err / (small + cur);
     prev = cur;
+    if (a.opt_.error_estimator >= 2) estimator_update(&abs_err, &rel_err);   // sigma / energy / none: F:14410-14587
 
     // _converged  F:21177-21244.  rel_err comes from all-reduced sums and is the same on every rank; so is the stop word.
     if (std::isnan(rel_err) || stop_requested()) {
@@ -1125,6 +1179,7 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
   prepare();
   // CG restarts every step from eps = E (F:23184); only the estimator remembers the field the step found (F:14612-14618)
   const double prev0 = fresh ? 0.0 : current_norm9();
+  estimator_begin(fresh);
   if (a.opt_.mode == 1) {
     if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_Q_) < kEps))
       throw std::runtime_error("method=cg in heat / porous mode on slab-decomposed solvers: prescribed mean gradients");
@@ -1133,7 +1188,9 @@ bool SlabGroup::run_cg(const double* E6, const double* S6, bool fresh) {
   }
   // mixed boundary conditions, grids the tiled sweep does not fit, u_loop < 2: the strain-space form (the vectors of
   // runCGElasticity as 6-component fields, the operator = one pass of the strain-state pipeline)
-  if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_Q_) < kEps) || !fast_ok(false)) return run_cg_strain(E0, S0, prev0);
+  // (and the estimators that measure a mean of the strain field: the iterate is a stored field there)
+  if (norm2(S0, 6) != 0.0 || !(frobenius(a.BC_Q_) < kEps) || !fast_ok(false) || a.opt_.error_estimator >= 2)
+    return run_cg_strain(E0, S0, prev0);
   const double t_start = now_seconds();
   if (a.opt_.update_ref) {
     calc_ref_material();
@@ -1707,6 +1764,7 @@ bool SlabGroup::run_cg_strain(const double* E0, const double* S0, double prev0) 
       abs_err = std::sqrt(gamma);
       rel_err = std::sqrt(gamma / gamma_0);
     }
+    if (a.opt_.error_estimator >= 2) estimator_update(&abs_err, &rel_err);   // update_cg -> update  F:14465, F:14584
     if (std::isnan(rel_err) || stop_requested()) {
       failed = true;
       break;

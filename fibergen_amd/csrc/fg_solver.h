@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -60,7 +62,8 @@ struct SolverOptions {
   int loadstep_extrapolation_order = 0;   // 0 = none, 1 = linear, ... (F:14696; method "polynomial" F:21468-21514)
   int slab_interleave = -1;     // -1: where available; 0: one message per peer and component
   int error_estimator = 0;      // 0 = epsilon (EpsilonErrorEstimator F:14591-14637), 1 = residual (ResidualErrorEstimator
-                                // F:14382-14405: abs = sqrt(gamma), rel = sqrt(gamma / gamma_0); method cg only)
+                                // F:14382-14405: abs = sqrt(gamma), rel = sqrt(gamma / gamma_0); method cg only),
+                                // 2 = sigma (F:14514-14587), 3 = energy (F:14410-14468), 4 = none (F:14370-14378)
   int method = 0;               // 0 = basic scheme (runBasic F:21716), 1 = conjugate gradients (runCGElasticity F:23153)
   int u_loop = 2;               // pure strain BC: displacement-based pass (0 off, 1 exact operation order: bit-identical
                                 // to 0, 2 precomputed effective moduli + FMA, agrees with 1 to rounding; with laminate
@@ -81,8 +84,40 @@ struct SolverOptions {
   int pair_chunk = 0;           // z and y passes of the transform chain in runs of this many x planes, r2c(c) -> y(c) and
                                 // y^-1(c) -> c2r(c) (hand-over inside the Infinity Cache; measured slower, off by default)
   int staged_copy = -1;         // host <-> device field transfers through the pinned-buffer pipeline (fg_transfer.h): -1 for
-                                // transfers of 8 MB and more, 1 always, 0 never (one strided copy)
+                                // downloads of 8 MB and more, 1 always (both directions), 0 never (one strided copy)
   int stage_chunk_kb = 16384;   // pipeline stage of the staged transfers (<= 16 MB; tests shrink it)
+};
+
+// The error estimators that re-measure a mean of the strain field every iteration (create_error_estimator F:14940-14972):
+// SigmaErrorEstimator F:14514-14587 (created with _mode = 2: from its third update on, the mean of the distances to the
+// last two mean stresses), EnergyErrorEstimator F:14410-14468, NoneErrorEstimator F:14370-14378 (always 1).  The solver
+// (one GPU or the slab group) supplies the measurement; norm_2 runs over the 9 mirrored entries (fix_dim).
+struct MeanEstimator {
+  double m_prev[6] = {0, 0, 0, 0, 0, 0}, m_pp[6] = {0, 0, 0, 0, 0, 0}, w_prev = 0.0;
+  long iter = 0;
+  static double norm9_diff(const double* a, const double* b) {
+    double s = 0.0;
+    for (int c = 0; c < 6; ++c) s += (a[c] - b[c]) * (a[c] - b[c]) * (c >= 3 ? 2.0 : 1.0);
+    return std::sqrt(s);
+  }
+  void start_sigma(const double* m) {
+    for (int c = 0; c < 6; ++c) m_prev[c] = m_pp[c] = m[c];
+    iter = 0;
+  }
+  void update_sigma(const double* m, double* abs_err, double* rel_err) {
+    const double zero[6] = {0, 0, 0, 0, 0, 0};
+    *abs_err = iter > 1 ? 0.5 * (norm9_diff(m_pp, m) + norm9_diff(m_prev, m)) : norm9_diff(m_prev, m);
+    *rel_err = *abs_err / (std::numeric_limits<double>::min() + norm9_diff(m, zero));
+    for (int c = 0; c < 6; ++c) m_pp[c] = m_prev[c], m_prev[c] = m[c];
+    ++iter;
+  }
+  void start_energy(double w) { w_prev = w, iter = 0; }
+  void update_energy(double w, double* abs_err, double* rel_err) {
+    *abs_err = std::fabs(w_prev - w);
+    *rel_err = *abs_err / (std::numeric_limits<double>::min() + std::fabs(w));
+    w_prev = w;
+    ++iter;
+  }
 };
 
 enum Stage {
@@ -142,6 +177,7 @@ class Solver {
   void iterate(const double* E6, int n);
 
   void mean_stress(double* out6);   // calcMeanStress  F:17793-17811
+  double mean_energy();             // meanW  F:12239-12262 of the current strain field
   void mean_strain(double* out6);   // TensorField::average  F:10171
   double volume_fraction(int p);
 
@@ -192,6 +228,10 @@ class Solver {
   void release();
   bool run_one_step(const double* E0, const double* S0);
   double current_norm9();
+  // estimators 2 (sigma), 3 (energy), 4 (none): constructor on the field a step starts from, update after an iteration
+  void estimator_begin(bool fresh);
+  void estimator_update(double* abs_err, double* rel_err);
+  MeanEstimator est_;
   bool run_cg(const double* E0, const double* S0, double prev0);
   bool run_cg_scalar(const double* E0, double prev0);  // heat / porous: CG in potential space
   bool run_cg_u(const double* E0, double prev0);      // the same CG carried in displacement space (Voigt, prescribed mean strains)
@@ -221,7 +261,7 @@ class Solver {
   void adopt_back();
   void upload_padded(double* dst, const double* src_unpadded, int ncomp = 1, long dstride = 0);
   void download_unpadded(const double* src, double* dst_unpadded, int ncomp = 1, long dstride = 0);
-  bool staged_copy(size_t bytes) const;
+  bool staged_copy(size_t bytes, bool download) const;
   void upload_rows(const std::vector<RowBlock>& blocks, long len, long pitch);
   void download_rows(const std::vector<RowBlock>& blocks, long len, long pitch);
   int pair_chunk_planes(int ncomp) const;

@@ -352,8 +352,12 @@ StressParams Solver::stress_params(double mu_0, double lambda_0, double alpha) c
 // Boundary transfers (GetField / SetField F:26931-27010 copy row by row): large fields go through the staged pipeline of
 // fg_transfer.h (padding stripped / added on the device, whole chunks over the link, a team of host threads on the pageable
 // side), small ones through one strided copy.
-bool Solver::staged_copy(size_t bytes) const {
-  return opt_.staged_copy > 0 || (opt_.staged_copy < 0 && bytes >= (size_t)8 << 20);
+// Measured on the MI355X boxes (tools/transfer_probe.py, 805 MB): uploads from pageable memory already run at the link's
+// rate through the runtime's own staging (54 GB/s), downloads into FRESH pageable memory do not (48 ms: the page faults of
+// the destination are taken one by one by the copying thread) -- the pipeline takes them on its team of host threads while
+// the next chunks are on the link: 18-19 ms (14.2 ms into memory that is already mapped, either way).
+bool Solver::staged_copy(size_t bytes, bool download) const {
+  return opt_.staged_copy > 0 || (opt_.staged_copy < 0 && download && bytes >= (size_t)8 << 20);
 }
 
 void Solver::upload_rows(const std::vector<RowBlock>& blocks, long len, long pitch) {
@@ -361,7 +365,7 @@ void Solver::upload_rows(const std::vector<RowBlock>& blocks, long len, long pit
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
   size_t bytes = 0;
   for (const RowBlock& b : blocks) bytes += (size_t)b.nrows * len * sizeof(double);
-  if (staged_copy(bytes)) {
+  if (staged_copy(bytes, false)) {
     HostStager::of_device(device_).upload(blocks, len, pitch, (size_t)std::max(1, opt_.stage_chunk_kb) << 10);
     return;
   }
@@ -375,7 +379,7 @@ void Solver::download_rows(const std::vector<RowBlock>& blocks, long len, long p
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
   size_t bytes = 0;
   for (const RowBlock& b : blocks) bytes += (size_t)b.nrows * len * sizeof(double);
-  if (staged_copy(bytes)) {
+  if (staged_copy(bytes, true)) {
     HostStager::of_device(device_).download(blocks, len, pitch, (size_t)std::max(1, opt_.stage_chunk_kb) << 10);
     return;
   }
@@ -1081,11 +1085,11 @@ void Solver::u_pass_front(const double* E6) {
         ph.p[0] = phi_ + g_.n;
         ph.p[1] = nullptr;
         const PhaseTable t = phase_table();
-        launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), ph, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, opt_.u_tile,
-                      stream_, sum_tau, &t);
+        launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), ph, ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq, stream_, sum_tau,
+                      &t);
       } else {
         launch_u_tile(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_,
-                      dscal_ + kSlotSumSq, opt_.u_tile, stream_, sum_tau);
+                      dscal_ + kSlotSumSq, stream_, sum_tau);
       }
     } else   // grids the tiles do not fit (odd nz, short rows): the untiled sweep
       launch_u_fast(g_, opt_.mu_0, opt_.lambda_0, ptrs3(fu_), effective_moduli(), ptrs3(fu_alt_), E, partial_, dscal_ + kSlotSumSq,
@@ -1188,6 +1192,43 @@ void Solver::mean_stress(double* out6) {
   FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
   FG_HIP_CHECK(hipStreamSynchronize(stream_));
   for (int c = 0; c < 6; ++c) out6[c] = hscal_[kSlotMean + c];
+}
+
+double Solver::mean_energy() {
+  FG_HIP_CHECK(hipSetDevice(device_));
+  ensure_eps();
+  if (pt_.n < 1) throw std::runtime_error("No materials specified");
+  if (opt_.mode == 1) throw std::runtime_error("the energy error estimator is not available in heat / porous mode");
+  FieldPtrs<3> nrm;
+  for (int c = 0; c < 3; ++c) nrm.p[c] = normals_ ? normals_ + (long)c * g_.n : nullptr;
+  launch_energy_mean(g_, stress_params(0.0, 0.0, 1.0), ptrs6(eps_), phase_ptrs(), nrm, partial_, dscal_ + kSlotMean, derr_, stream_);
+  FG_HIP_CHECK(hipMemcpyAsync(hscal_ + kSlotMean, dscal_ + kSlotMean, sizeof(double), hipMemcpyDeviceToHost, stream_));
+  FG_HIP_CHECK(hipStreamSynchronize(stream_));
+  return hscal_[kSlotMean] / (double)nglobal_;
+}
+
+// create_error_estimator  F:14940-14972 for the estimators that measure a mean of the strain field: their constructors run on
+// the field the step starts from (zero for a first step: <sigma> = 0, <W> = 0), update() after every iteration
+void Solver::estimator_begin(bool fresh) {
+  double m[6] = {0, 0, 0, 0, 0, 0};
+  if (opt_.error_estimator == 2) {
+    if (!fresh) mean_stress(m);
+    est_.start_sigma(m);
+  } else if (opt_.error_estimator == 3) {
+    est_.start_energy(fresh ? 0.0 : mean_energy());
+  }
+}
+
+void Solver::estimator_update(double* abs_err, double* rel_err) {
+  if (opt_.error_estimator == 2) {
+    double m[6];
+    mean_stress(m);
+    est_.update_sigma(m, abs_err, rel_err);
+  } else if (opt_.error_estimator == 3) {
+    est_.update_energy(mean_energy(), abs_err, rel_err);
+  } else if (opt_.error_estimator == 4) {
+    *abs_err = *rel_err = 1.0;
+  }
 }
 
 void Solver::mean_strain(double* out6) {
@@ -1372,12 +1413,16 @@ bool Solver::run_load_steps(const double* E6, const double* S6, const double* pa
 bool Solver::run_one_step(const double* E0, const double* S0) {
   // EpsilonErrorEstimator  F:14591-14637: constructed on the field the step starts from (zero for the first step)
   const double prev0 = fresh_step_ ? 0.0 : current_norm9();
+  if (opt_.error_estimator >= 2) {
+    if (opt_.mode == 1) throw std::runtime_error("heat / porous mode supports the error estimators epsilon and residual");
+    estimator_begin(fresh_step_);
+  }
   if (opt_.method == 1 && opt_.mode == 1) {
     (void)u_loop_eligible();   // throws for configurations the scalar modes do not support
     return run_cg_scalar(E0, prev0);
   }
   if (opt_.method == 1) return run_cg(E0, S0, prev0);
-  if (opt_.error_estimator != 0)   // ErrorEstimator::update  F:14359
+  if (opt_.error_estimator == 1)   // ErrorEstimator::update  F:14359
     throw std::runtime_error("Selected error estimator is not compatible with the selected solution method");
   const double t_start = now_seconds();
   for (int i = 0; i < 6; ++i) F00_[i] = 0.0;
@@ -1473,9 +1518,10 @@ bool Solver::run_one_step(const double* E0, const double* S0) {
     for (int c = 0; c < 6; ++c) s9 += m[c] * m[c];
     for (int c = 3; c < 6; ++c) s9 += m[c] * m[c];
     const double cur = std::sqrt(s9);
-    const double abs_err = std::fabs(prev - cur);
-    const double rel_err = abs_err / (small + cur);
+    double abs_err = std::fabs(prev - cur);
+    double rel_err = abs_err / (small + cur);
     prev = cur;
+    if (opt_.error_estimator >= 2) estimator_update(&abs_err, &rel_err);   // sigma / energy / none: F:14410-14587
 
     // _converged  F:21177-21244
     if (std::isnan(rel_err)) {
@@ -1888,7 +1934,8 @@ bool Solver::run_cg_scalar(const double* E0, double prev0) {
 
 bool Solver::run_cg(const double* E0, const double* S0, double prev0) {
   if (nranks_ != 1) throw std::runtime_error("slab-decomposed solvers run method=cg under the slab driver (fg_slab.hip)");
-  if (opt_.u_loop >= 2 && u_loop_eligible() && norm2(S0, 6) == 0.0) return run_cg_u(E0, prev0);
+  // (the estimators that measure a mean of the strain field run in strain space, where the iterate is a stored field)
+  if (opt_.u_loop >= 2 && u_loop_eligible() && norm2(S0, 6) == 0.0 && opt_.error_estimator < 2) return run_cg_u(E0, prev0);
   const double t_start = now_seconds();
   const size_t f6 = 6 * (size_t)g_.n * sizeof(double);
   for (double** b : {&cg_r_, &cg_p_, &cg_w_})
@@ -1963,6 +2010,7 @@ bool Solver::run_cg(const double* E0, const double* S0, double prev0) {
         rel_err = std::sqrt(gamma_cur / gamma_0);
       }
       gamma_cur = hscal_[kSlotCg + 6] / nvox + small;
+      if (opt_.error_estimator >= 2) estimator_update(&abs_err, &rel_err);   // update_cg -> update  F:14465, F:14584
       if (std::isnan(rel_err) || cancel_) {  // _converged  F:21177-21244
         failed = true;
         break;
@@ -2011,6 +2059,7 @@ bool Solver::run_cg(const double* E0, const double* S0, double prev0) {
       abs_err = std::sqrt(gamma);
       rel_err = std::sqrt(gamma / gamma_0);
     }
+    if (opt_.error_estimator >= 2) estimator_update(&abs_err, &rel_err);   // update_cg -> update  F:14465, F:14584
     if (std::isnan(rel_err) || cancel_) {  // _converged  F:21177-21244
       failed = true;
       break;

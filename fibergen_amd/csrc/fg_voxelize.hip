@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -390,6 +391,12 @@ struct DeviceArray {
 
 }  // namespace
 
+namespace {
+std::atomic<int> g_team_depth{-1};   // fg_voxelize_team_depth: -1 = by the number of interface voxels
+}
+
+extern "C" int fg_voxelize_team_depth(int depth) { return g_team_depth.exchange(depth < 0 ? -1 : std::min(depth, 3)); }
+
 extern "C" int fg_voxelize(const fg_fiber* fibers, int nfibers, int nx, int ny, int nz, double dx, double dy, double dz,
                            const double* x0, int nphases, int matrix_mat, int smooth_levels, double smooth_tol,
                            double* phi, double* normals, double* real_volume, int device, char* err, int errlen) {
@@ -508,9 +515,9 @@ extern "C" int fg_voxelize(const fg_fiber* fibers, int nfibers, int nx, int ny, 
       unsigned n_iface = 0;
       FG_HIP_CHECK(hipMemcpy(&n_iface, d_count.p, sizeof(unsigned), hipMemcpyDeviceToHost));
       if (n_iface) {
-        // threads per interface voxel: 8^depth, so that a coarse grid still fills the device (FG_VOX_TEAM_DEPTH: test hook)
+        // threads per interface voxel: 8^depth, so that a coarse grid still fills the device (fg_voxelize_team_depth: test hook)
         int depth = n_iface <= 2048 ? 3 : n_iface <= 16384 ? 2 : n_iface <= 65536 ? 1 : 0;
-        if (const char* e = getenv("FG_VOX_TEAM_DEPTH")) depth = std::min(3, std::max(0, atoi(e)));
+        if (const int forced = g_team_depth.load(); forced >= 0) depth = forced;
         if (smooth_levels >= 0) depth = std::min(depth, smooth_levels);
 #define FG_REFINE(KERNEL, BLOCKS, THREADS)                                                                                   \
   hipLaunchKernelGGL(KERNEL, dim3(BLOCKS), dim3(THREADS), 0, 0, g, d_shapes.p, d_start.p, d_list.p, d_iface.p, n_iface, \

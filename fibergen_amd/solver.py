@@ -98,9 +98,10 @@ class LSSolver:
                 self.scalar = v in ("heat", "porous")
                 self._check(self._lib.fg_set_option_i(self._h, b"mode", {"elasticity": 0, "viscosity": 2}.get(v, 1)))
             elif k == "error_estimator":
-                if v not in ("epsilon", "residual"):
-                    raise RuntimeError("error estimator '%s' is not available (epsilon, residual)" % v)
-                self._check(self._lib.fg_set_option_i(self._h, b"error_estimator", 1 if v == "residual" else 0))
+                kinds = {"epsilon": 0, "residual": 1, "sigma": 2, "energy": 3, "none": 4}   # create_error_estimator  F:14940-14972
+                if v not in kinds:
+                    raise RuntimeError("Unknown error estimator '%s'" % v)
+                self._check(self._lib.fg_set_option_i(self._h, b"error_estimator", kinds[v]))
             elif k in ("u_loop", "fuse_x", "cg_fused", "fuse_stress_div", "u_tile", "x_layout", "plane_fft", "slab_split", "slab_interleave", "slab_loopback", "laminate_overlap", "phi_sweep", "pair_chunk", "staged_copy", "stage_chunk_kb"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
             elif k in ("maxiter", "loadstep_extrapolation_order"):
@@ -242,9 +243,9 @@ class LSSolver:
             out = np.zeros(6)
         elif name == "f_hat":
             nzc = self.nz // 2 + 1
-            out = np.zeros((3, self.nx, self.ny, nzc, 2))
+            out = np.empty((3, self.nx, self.ny, nzc, 2))
         else:
-            out = np.zeros((nc,) + self.shape)
+            out = np.empty((nc,) + self.shape)   # (fg_get_field writes every element)
         self._check(self._lib.fg_get_field(self._h, name.encode(), _dp(out)))
         if name == "f_hat":
             return out.view(np.complex128)[..., 0]

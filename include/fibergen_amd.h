@@ -78,11 +78,13 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * gamma_scheme (0 = staggered, 1 = collocated: GammaOperatorCollocated F:20302-20310, Fourier-space 6x6 Gamma0),
  * method (0 = basic scheme, runBasic F:21716-21805; 1 = conjugate gradients, runCGElasticity
  * F:23153-23247, the reference's default), error_estimator (0 = epsilon F:14591-14637; 1 = residual F:14382-14405, method
- * cg only), and the implementation switches u_loop (2 = default: the loop carries the
+ * cg only; 2 = sigma F:14514-14587; 3 = energy F:14410-14468; 4 = none F:14370-14378 -- 2 and 3 re-measure <sigma> / <W> of
+ * the strain field after every iteration (two more sweeps), the conjugate gradients then iterate on the strain field), and the implementation switches u_loop (2 = default: the loop carries the
  * displacement, fast kernels; 1 = the same with the reference's operation order, iterates bit-identical to 0; 0 = the
  * strain field is the state, one kernel per reference routine where fuse_* are 0 too),
  * fuse_stress_div, fuse_x (1 = default; 0 selects the one-kernel-per-routine pipeline), u_tile (1 = default: the
- * LDS-tiled displacement sweep where the grid allows; 0 = the untiled sweep everywhere),
+ * LDS-tiled displacement sweep where the grid allows -- any non-zero value means "tiled", the tile shape follows from the
+ * grid; 0 = the untiled sweep everywhere),
  * cg_fused (-1 = default: where the tiled sweep fits; 0 / 1: method = cg in displacement / potential space with the vector
  * work of an iteration as two tiled sweeps and the direction update inside the operator's sweep -- out of place, nine more
  * components; falls back to the four-kernel form when they do not fit; in the scalar modes (potential space) a registered
@@ -294,6 +296,11 @@ typedef struct fg_fiber {
 int fg_voxelize(const fg_fiber* fibers, int nfibers, int nx, int ny, int nz, double dx, double dy, double dz,
                 const double* x0, int nphases, int matrix_mat, int smooth_levels, double smooth_tol,
                 double* phi, double* normals, double* real_volume, int device, char* err, int errlen);
+
+/* Test hook of the voxeliser (no counterpart in the reference): threads per interface voxel = 8^depth for the calls that
+ * follow in this process, depth 0 ... 3; -1 (the default) = chosen from the number of interface voxels.  Every depth gives
+ * bit-identical fractions (tests/test_gpu_voxelize.py).  Returns the previous setting. */
+int fg_voxelize_team_depth(int depth);
 
 #ifdef __cplusplus
 }

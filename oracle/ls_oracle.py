@@ -320,19 +320,13 @@ def laminate_split(Fbar, n, c1, c2, mat1, mat2, eps_g=LAMINATE_EPS_G, eps_a=LAMI
     return F1, F2
 
 
-def pk1_laminate(eps, phis, mats, normals, alpha=1.0):
-    """LaminateMixedMaterialLaw::PK1 + get_mix  F:13456-13558.
-
-    Pure voxels (some phi==1) -> that phase's Hooke law; voxels whose first
-    non-zero phase is the only one -> c1*Hooke(eps); two-phase voxels ->
-    c1 = phi of the first phase with 0<phi<1 (materials order), c2 := 1-c1,
-    laminate split, P = c1*Hooke_1(F1) + c2*Hooke_2(F2).  More than two
-    non-zero phases raise like the reference (F:13473).
-    """
+def _get_mix(eps, phis, mats, normals):
+    """LaminateMixedMaterialLaw::get_mix  F:13456-13525 on whole fields: walks the phases in <materials> order.
+    Returns (p1, c1, single, idx, m1, m2, cc1, cc2, F1, F2): phase index and fraction of the first phase per voxel, the
+    mask of voxels with one phase only, and for the two-phase voxels `idx` the materials, fractions (c2 := 1 - c1,
+    F:13523) and the two strains of the laminate split (None when there are no such voxels)."""
     shape = eps.shape[1:]
     nph = len(phis)
-    P = np.zeros_like(eps)
-    done = np.zeros(shape, dtype=bool)
     # walk phases like get_mix does
     p1 = np.full(shape, -1, dtype=np.int64)
     p2 = np.full(shape, -1, dtype=np.int64)
@@ -358,30 +352,74 @@ def pk1_laminate(eps, phis, mats, normals, alpha=1.0):
         p2 = np.where(take2, p, p2)
     if np.any(p1 < 0):
         raise RuntimeError("The laminate mixing rule supports only two phase mixtures")
-
     mus = np.array([m[0] for m in mats], dtype=np.float64)
     lams = np.array([m[1] for m in mats], dtype=np.float64)
     single = p2 < 0
-    # single-phase (pure, or lone partial phase): P = Hooke_p1(eps, c1*alpha)
-    mu1 = mus[p1]
-    lam1 = lams[p1]
-    P_single = hooke(eps, mu1, lam1, c1 * alpha)
     mixed = ~single
-    if np.any(mixed):
-        idx = np.nonzero(mixed)
-        e = [eps[i][idx] for i in range(6)]
-        nn = [normals[i][idx] for i in range(3)]
-        cc1 = c1[idx]
-        cc2 = 1.0 - cc1  # F:13523
-        m1 = (mus[p1[idx]], lams[p1[idx]])
-        m2 = (mus[p2[idx]], lams[p2[idx]])
-        F1, F2 = laminate_split(e, nn, cc1, cc2, m1, m2)
-        S1 = hooke(np.array(F1), m1[0], m1[1], cc1 * alpha)
-        S2 = hooke(np.array(F2), m2[0], m2[1], cc2 * alpha)
+    if not np.any(mixed):
+        return p1, c1, single, None, None, None, None, None, None, None
+    idx = np.nonzero(mixed)
+    e = [eps[i][idx] for i in range(6)]
+    nn = [normals[i][idx] for i in range(3)]
+    cc1 = c1[idx]
+    cc2 = 1.0 - cc1  # F:13523
+    m1 = (mus[p1[idx]], lams[p1[idx]])
+    m2 = (mus[p2[idx]], lams[p2[idx]])
+    F1, F2 = laminate_split(e, nn, cc1, cc2, m1, m2)
+    return p1, c1, single, idx, m1, m2, cc1, cc2, np.array(F1), np.array(F2)
+
+
+def pk1_laminate(eps, phis, mats, normals, alpha=1.0):
+    """LaminateMixedMaterialLaw::PK1 + get_mix  F:13456-13558.
+
+    Pure voxels (some phi==1) -> that phase's Hooke law; voxels whose first
+    non-zero phase is the only one -> c1*Hooke(eps); two-phase voxels ->
+    c1 = phi of the first phase with 0<phi<1 (materials order), c2 := 1-c1,
+    laminate split, P = c1*Hooke_1(F1) + c2*Hooke_2(F2).  More than two
+    non-zero phases raise like the reference (F:13473).
+    """
+    p1, c1, single, idx, m1, m2, cc1, cc2, F1, F2 = _get_mix(eps, phis, mats, normals)
+    mus = np.array([m[0] for m in mats], dtype=np.float64)
+    lams = np.array([m[1] for m in mats], dtype=np.float64)
+    # single-phase (pure, or lone partial phase): P = Hooke_p1(eps, c1*alpha)
+    P_single = hooke(eps, mus[p1], lams[p1], c1 * alpha)
+    if idx is not None:
+        S1 = hooke(F1, m1[0], m1[1], cc1 * alpha)
+        S2 = hooke(F2, m2[0], m2[1], cc2 * alpha)
         Pm = S1 + S2
         for i in range(6):
             P_single[i][idx] = Pm[i]
     return P_single
+
+
+def energy_hooke(E, mu, lam):
+    """LinearIsotropicMaterialLaw::W  F:11368-11373: 0.5 * S.dot(E) with S = PK1(E, 1) and SymTensor3x3::dot
+    F:9414-9417 (shear products doubled)."""
+    S = hooke(E, mu, lam, 1.0)
+    return 0.5 * (S[0] * E[0] + S[1] * E[1] + S[2] * E[2] + 2 * (S[3] * E[3] + S[4] * E[4] + S[5] * E[5]))
+
+
+def energy_voigt(eps, phis, mats):
+    """VoigtMixedMaterialLaw::W  F:12739-12750: sum_p phi_p W_p(eps), phases with phi <= 10 eps skipped."""
+    W = np.zeros(eps.shape[1:])
+    for phi, (mu, lam) in zip(phis, mats):
+        use = phi > VOIGT_THRESHOLD
+        W = np.where(use, W + phi * energy_hooke(eps, mu, lam), W)
+    return W
+
+
+def energy_laminate(eps, phis, mats, normals):
+    """LaminateMixedMaterialLaw::W  F:13527-13540: c1 W_1(F1) (+ c2 W_2(F2) at two-phase voxels) with the strains of
+    get_mix."""
+    p1, c1, single, idx, m1, m2, cc1, cc2, F1, F2 = _get_mix(eps, phis, mats, normals)
+    mus = np.array([m[0] for m in mats], dtype=np.float64)
+    lams = np.array([m[1] for m in mats], dtype=np.float64)
+    W = c1 * energy_hooke(eps, mus[p1], lams[p1])
+    if idx is not None:
+        Wm = cc1 * energy_hooke(F1, m1[0], m1[1])
+        Wm = Wm + cc2 * energy_hooke(F2, m2[0], m2[1])
+        W[idx] = Wm
+    return W
 
 
 # --------------------------------------------------------------------------
@@ -413,7 +451,7 @@ class LSOracle:
     lambda_0: float = 0.0
     update_ref: str = "loadstep"
     gamma_scheme: str = "staggered"               # or "collocated" (GammaOperatorCollocated F:20302-20310)
-    error_estimator: str = "epsilon"              # or "residual" (method cg only, F:14382-14405)
+    error_estimator: str = "epsilon"              # "residual" (method cg only, F:14382-14405), "sigma", "energy", "none"
     loadstep_extrapolation_order: int = 0         # 0 = none, 1 = linear, ...  (F:14696, F:14830; method "polynomial")
 
     def __post_init__(self):
@@ -460,6 +498,62 @@ class LSOracle:
         eps = self.eps if eps is None else eps
         P = self.pk1(eps, 1.0 / self.N)
         return P.reshape(6, -1).sum(axis=1)
+
+    def mean_energy(self, eps=None):
+        """meanW  F:12239-12262: sum of the voxels' energies / nxyz (mixing rule's W: F:12739-12750, F:13527-13540)."""
+        eps = self.eps if eps is None else eps
+        if self.mixing_rule == "voigt":
+            W = energy_voigt(eps, self.phis, self.mats)
+        elif self.mixing_rule == "laminate":
+            W = energy_laminate(eps, self.phis, self.mats, self.normals)
+        else:
+            raise RuntimeError("Unknown mixing rule '%s'" % self.mixing_rule)
+        return float(W.sum()) / self.N
+
+    def create_error_estimator(self, method):
+        """create_error_estimator  F:14940-14972 on the current strain field (the constructors measure it).  Returns
+        update(gamma, gamma0) -> (abs_err, rel_err): ErrorEstimator::update / update_cg."""
+        name = self.error_estimator
+        if name == "epsilon":    # EpsilonErrorEstimator  F:14591-14637
+            st = {"prev": self._norm9(self.component_norm(self.eps))}
+
+            def update(gamma=None, gamma0=None):
+                cur = self._norm9(self.component_norm(self.eps))
+                abs_err = abs(st["prev"] - cur)
+                st["prev"] = cur
+                return abs_err, abs_err / (SMALLEST + cur)
+            return update
+        if name == "residual":   # ResidualErrorEstimator  F:14382-14405: update() is the throwing base-class one (F:14353)
+            if method != "cg":
+                raise RuntimeError("Selected error estimator is not compatible with the selected solution method")
+            return lambda gamma, gamma0: (math.sqrt(gamma), math.sqrt(gamma / gamma0))
+        if name == "none":       # NoneErrorEstimator  F:14370-14378
+            return lambda gamma=None, gamma0=None: (1.0, 1.0)
+        if name == "energy":     # EnergyErrorEstimator  F:14410-14468
+            st = {"prev": self.mean_energy()}
+
+            def update(gamma=None, gamma0=None):
+                W = self.mean_energy()
+                abs_err = abs(st["prev"] - W)
+                st["prev"] = W
+                return abs_err, abs_err / (SMALLEST + abs(W))
+            return update
+        if name == "sigma":      # SigmaErrorEstimator  F:14514-14587, created with _mode = 2 for every method (F:14949)
+            m0 = self.mean_stress()
+            st = {"prev": m0, "pp": m0, "iter": 0}
+
+            def update(gamma=None, gamma0=None):
+                m = self.mean_stress()
+                if st["iter"] > 1:
+                    abs_err = 0.5 * (self._norm9(st["pp"] - m) + self._norm9(st["prev"] - m))
+                else:
+                    abs_err = self._norm9(st["prev"] - m)
+                rel_err = abs_err / (SMALLEST + self._norm9(m))
+                st["pp"], st["prev"] = st["prev"], m
+                st["iter"] += 1
+                return abs_err, rel_err
+            return update
+        raise RuntimeError("Unknown error estimator '%s'" % name)
 
     def mean_strain(self):
         """TensorField::average  F:10171-10210"""
@@ -823,8 +917,6 @@ class LSOracle:
                 last.append((float(params[istep - 1]), self.eps.copy()))
                 if len(last) >= 2:
                     self.eps = self.extrapolate_loadstep_polynomial(last, t)
-            if method != "cg" and self.error_estimator == "residual":
-                raise RuntimeError("Selected error estimator is not compatible with the selected solution method")  # F:14359
             failed = self._run_cg_step(t * E0, t * S0) if method == "cg" else self._run_basic_step(t * E0, t * S0)
             self.step_iterations.append(self.iterations)
             if failed:
@@ -847,8 +939,8 @@ class LSOracle:
 
     def _run_basic_step(self, E0, S0):
         """runBasic  F:21716-21805 for one load step"""
-        # EpsilonErrorEstimator ctor: norms of the field the step starts from  F:14612-14618
-        prev = self._norm9(self.component_norm(self.eps))
+        # the estimator's constructor measures the field the step starts from  F:21722, F:14612-14618
+        ee = self.create_error_estimator("basic")
         it = 1
         update_ref = self.update_ref != "never"
         E = E0
@@ -858,10 +950,7 @@ class LSOracle:
                 E = self.calc_bc_mean(E0, S0)
                 update_ref = False
             self.eps = self.basic_scheme(E, self.eps)
-            cur = self._norm9(self.component_norm(self.eps))
-            abs_err = abs(prev - cur)
-            rel_err = abs_err / (SMALLEST + cur)
-            prev = cur
+            abs_err, rel_err = ee()   # ee->update()  F:21786
             # _converged F:21177-21244
             if math.isnan(rel_err):
                 self.error = "NaN detected in solution. Aborting."
@@ -892,12 +981,12 @@ class LSOracle:
         return self.run_load_steps(E0, S0, P, params=[0.0, 1.0], method="cg")
 
     def _run_cg_step(self, E0, S0):
-        """runCGElasticity  F:23153-23247 for one load step.  error_estimator 'epsilon' (F:14591-14637, via update_cg
-        F:14633) or 'residual' (ResidualErrorEstimator F:14382-14405: abs = sqrt(gamma), rel = sqrt(gamma / gamma0))."""
+        """runCGElasticity  F:23153-23247 for one load step; the error estimator (create_error_estimator) is updated
+        through update_cg: 'residual' uses (gamma, gamma0), the others re-measure the strain field (F:14633, F:14465, F:14584)."""
         if self.update_ref != "never":
             self.calc_ref_material()
         E = self.calc_bc_mean(E0, S0)
-        prev = self._norm9(self.component_norm(self.eps))   # estimator constructed on the field the step starts from
+        ee = self.create_error_estimator("cg")   # constructed on the field the step starts from  F:23168
         Z = np.zeros(6)
         eps = np.empty_like(self.eps)
         eps[:] = E[:, None, None, None]          # epsilon.setConstant(E)  F:23184
@@ -913,14 +1002,7 @@ class LSOracle:
             alpha = gamma / alpha
             eps = eps + alpha * p
             self.eps = eps
-            if getattr(self, "error_estimator", "epsilon") == "residual":
-                abs_err = math.sqrt(gamma)
-                rel_err = math.sqrt(gamma / gamma0)
-            else:
-                cur = self._norm9(self.component_norm(eps))
-                abs_err = abs(prev - cur)
-                rel_err = abs_err / (SMALLEST + cur)
-                prev = cur
+            abs_err, rel_err = ee(gamma, gamma0)   # ee->update_cg(gamma, gamma0)  F:23219
             if math.isnan(rel_err):
                 self.error = "NaN detected in solution. Aborting."
                 return True

@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def launch(nproc, out, *args, timeout=600):
+def launch(nproc, out, *args, timeout=600, _attempt=0):
     """`nproc` worker processes of tests/dist_worker.py with the environment torch.distributed's env:// rendez-vous reads
     (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port) -- started directly: the elastic
     launcher of `python -m torch.distributed.run` costs an interpreter start and a torch import of its own per test, and the
@@ -42,16 +42,21 @@ def launch(nproc, out, *args, timeout=600):
     readers = [threading.Thread(target=drain, args=(i,), daemon=True) for i in range(nproc)]
     for t in readers:
         t.start()
-    deadline = __import__("time").monotonic() + timeout
+    import time as _time
+    deadline = _time.monotonic() + timeout
     failed = None
-    try:
-        for r, p in enumerate(procs):
-            p.wait(timeout=max(1.0, deadline - __import__("time").monotonic()))
-            if p.returncode != 0 and failed is None:
-                failed = r
-                break   # the others may hang in a collective waiting for it: stop them below
-    except subprocess.TimeoutExpired:
-        failed = -1
+    # poll ALL ranks: a rank r > 0 that dies while rank 0 blocks in a collective is noticed at once, not after rank 0's timeout
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]   # the others may hang in a collective waiting for it: stop them below
+        elif all(c == 0 for c in codes):
+            break
+        elif _time.monotonic() > deadline:
+            failed = -1
+        else:
+            _time.sleep(0.05)
     if failed is not None:
         __import__("time").sleep(1.0)   # let the other ranks report their own error first
         for p in procs:
@@ -64,7 +69,11 @@ def launch(nproc, out, *args, timeout=600):
     if failed is not None:
         if failed < 0:
             raise subprocess.TimeoutExpired(cmd, timeout, stderr=b"\n".join(errs))
-        raise subprocess.CalledProcessError(procs[failed].returncode, cmd, stderr=b"\n".join(errs))
+        blob = b"\n".join(errs)
+        if _attempt < 3 and (b"EADDRINUSE" in blob or b"ddress already in use" in blob):
+            # the port was free when it was probed and taken before rank 0 bound it (parallel test runs): once more, new port
+            return launch(nproc, out, *args, timeout=timeout, _attempt=_attempt + 1)
+        raise subprocess.CalledProcessError(procs[failed].returncode, cmd, stderr=blob)
     return [np.load(out + ".%d.npz" % r) for r in range(nproc)]
 
 

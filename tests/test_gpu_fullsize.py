@@ -162,6 +162,14 @@ def test_bench_line_of_the_default_command_on_a_small_grid():
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "it/s" and "sample" in cb
     assert line["also"]["32^3 laminate"]["it_s"] > 0 and len(line["kernels"]) >= 4
+    # what the line measures, said in the line: one GPU has no scaling mode; `value` is fg_iterate, the loop under
+    # the stop rule sits beside it -- top level and inside `config`, which the driver's record keeps whole; a Green-operator
+    # figure on a grid whose spectrum (3 x 16 B x 64 x 64 x 33 = 6.5 MB) lives in the Infinity Cache is flagged as such
+    assert line["scaling"] is None and "fg_iterate" in line["metric"] and "fg_iterate" in line["config"]["timed_call"]
+    assert line["run_load_case_it_s"] > 0 and line["config"]["run_load_case_it_s"] == line["run_load_case_it_s"]
+    assert line["gamma0_apply_standalone"]["cache_assisted"] is True
+    pc = line["pcie_inclusive"]
+    assert pc["upload_ms"] > 0 and pc["download_ms"] > 0 and pc["it_s_inclusive"] > 0
 
 
 def test_driver_smoke_entry(capsys):

@@ -665,6 +665,51 @@ def test_staged_host_transfers_are_byte_identical(grid):
                 assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("grid,dims", GRIDS + [((16, 16, 128), (1.0, 1.0, 1.0))])
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+@pytest.mark.parametrize("estimator", ["sigma", "energy"])
+def test_sigma_and_energy_estimators_match_oracle(grid, dims, mixing, estimator):
+    """error_estimator = sigma (SigmaErrorEstimator F:14514-14587) / energy (EnergyErrorEstimator F:14410-14468): the stop
+    rule watches <sigma> / <W> of the strain field after every iteration.  Iteration counts equal the oracle's, residual
+    histories to 1e-9 (differences of means that agree to rounding, divided by the mean), basic scheme and conjugate gradients;
+    the last grid runs the displacement loop with its tiled sweep (the strain field is materialised for the measurement)."""
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    tol = 1e-6
+    for method in ("basic", "cg"):
+        o = make_oracle(grid, dims, mixing, tol=tol, error_estimator=estimator)
+        s = make_gpu_solver(grid, dims, mixing, tol=tol, error_estimator=estimator, method=method)
+        assert (o.run_cg(E) if method == "cg" else o.run(E)) is False
+        assert s.run(E) is False
+        assert s.iterations == o.iterations and len(s.residuals) == len(o.residuals), (method, s.iterations, o.iterations)
+        assert np.abs(np.array(s.residuals) - np.array(o.residuals)).max() < 1e-9
+        assert rel_err(s.get_field("epsilon"), o.eps) < 1e-8 and rel_err(s.mean_stress(), o.mean_stress()) < 1e-9
+        s.close()
+
+
+@pytest.mark.parametrize("method", ["basic", "cg"])
+def test_none_estimator_runs_to_maxiter(method):
+    """error_estimator = none (NoneErrorEstimator F:14370-14378): abs = rel = 1, the run ends at maxiter (or on a callback's
+    request); residual with the basic scheme is the reference's run-time error (ErrorEstimator::update F:14353)."""
+    grid = (16, 16, 16)
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    o = make_oracle(grid, tol=1e-6, error_estimator="none", maxiter=9)
+    s = make_gpu_solver(grid, tol=1e-6, error_estimator="none", maxiter=9, method=method)
+    assert (o.run_cg(E) if method == "cg" else o.run(E)) is False and s.run(E) is False
+    assert s.iterations == o.iterations == 9 and list(s.residuals) == o.residuals and set(o.residuals) == {1.0}
+    assert rel_err(s.get_field("epsilon"), o.eps) < 1e-10
+    calls = []
+    s.set_convergence_callback(lambda: calls.append(1) or len(calls) >= 3)
+    assert s.run(E) is False and len(calls) == 3
+    s.close()
+    with pytest.raises(RuntimeError, match="Unknown error estimator"):
+        make_gpu_solver(grid, error_estimator="div_sigma")
+    s = make_gpu_solver(grid, mixing="voigt")
+    s.set_options(mode="porous", error_estimator="sigma")
+    with pytest.raises(RuntimeError, match="heat / porous mode supports the error estimators"):
+        s.run(np.array([1.0, 0, 0]))
+    s.close()
+
+
 def test_laminate_rule_at_oblique_normals_is_the_rotated_closed_form():
     """The HIP laminate rule (get_field('sigma'), FG_STAGE_STRESS) at random oblique normals against the reference-held
     closed form: P(eps, n) = R [C_lam : (R^T eps R)] R^T with C_lam from calc_isotropic_laminate F:26412-26446 and R e_x = n

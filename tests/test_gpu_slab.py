@@ -280,6 +280,27 @@ def test_group_cg_matches_oracle(P, grid, mixing, residual):
     g.close()
 
 
+@pytest.mark.parametrize("estimator", ["sigma", "energy", "none"])
+@pytest.mark.parametrize("method", ["basic", "cg"])
+@pytest.mark.parametrize("P,grid,mixing", [(2, (8, 16, 128), "voigt"), (2, (8, 16, 128), "laminate"), (2, (12, 10, 6), "laminate"),
+                                           (4, (16, 8, 16), "voigt")])
+def test_group_sigma_energy_none_estimators(P, grid, mixing, method, estimator):
+    """The estimators that measure a mean of the strain field (F:14370-14378, F:14410-14468, F:14514-14587) on the slabs: <sigma>
+    and <W> are all-reduced, every rank holds the same estimator state and takes the same stop decision."""
+    dims = (1.0, 2.0, 1.5)
+    kw = dict(error_estimator=estimator, tol=1e-6, maxiter=7 if estimator == "none" else 10000)
+    g = make_group(P, grid, dims, mixing, method=method, **kw)
+    o = make_oracle(grid, dims, mixing, **kw)
+    assert (o.run_cg(E_LOAD) if method == "cg" else o.run(E_LOAD)) is False
+    assert g.run(E_LOAD) is False
+    assert g.iterations == o.iterations and len(g.residuals) == len(o.residuals)
+    assert np.abs(np.array(g.residuals) - np.array(o.residuals)).max() < 1e-9
+    assert rel_err(g.get_field("epsilon"), o.eps) < 1e-8 and rel_err(g.mean_stress(), o.mean_stress()) < 1e-9
+    for m in g.members:
+        assert m.residuals == g.members[0].residuals and m.iterations == g.iterations
+    g.close()
+
+
 @pytest.mark.parametrize("P", [1, 2, 4])
 @pytest.mark.parametrize("mixing", ["voigt", "laminate"])
 def test_group_cg_equals_single_gpu_cg(P, mixing):

@@ -156,9 +156,14 @@ def test_team_refinement_equals_one_thread_walk(scene, depth, monkeypatch):
         args = (random_capsules(15, 7), (6, 1, 2), (0.9, 1.7, 1.2), (0.0, 0.0, 0.0), 2, 0)
         kws = [dict(smooth_levels=-1, smooth_tol=2e-3), dict(smooth_levels=1, smooth_tol=0.0)]
     for kw in kws:
-        monkeypatch.setenv("FG_VOX_TEAM_DEPTH", "0")
-        want = geometry.voxelize(*args, want_normals=False, **kw)[0]
-        monkeypatch.setenv("FG_VOX_TEAM_DEPTH", str(depth))
-        got = geometry.voxelize(*args, want_normals=False, **kw)[0]
+        from fibergen_amd import _lib
+        lib = _lib.load()
+        try:
+            lib.fg_voxelize_team_depth(0)
+            want = geometry.voxelize(*args, want_normals=False, **kw)[0]
+            lib.fg_voxelize_team_depth(depth)
+            got = geometry.voxelize(*args, want_normals=False, **kw)[0]
+        finally:
+            lib.fg_voxelize_team_depth(-1)
         assert ((want > 0) & (want < 1)).any()
         assert np.array_equal(got, want), (scene, depth, kw)

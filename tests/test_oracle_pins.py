@@ -344,6 +344,79 @@ def test_scalar_layered_medium_series_and_parallel_means():
     assert np.abs(K - np.diag(np.diag(K))).max() < 1e-12
 
 
+def test_energy_of_the_mixing_rules_is_half_stress_times_strain():
+    """meanW F:12239-12262 with VoigtMixedMaterialLaw::W F:12739-12750 / LaminateMixedMaterialLaw::W F:13527-13540.  For Hooke
+    phases W_p = 1/2 sigma_p : eps (F:11368-11373), so the Voigt energy is 1/2 P:eps voxel by voxel; at a laminate voxel
+    c1 W1(F1) + c2 W2(F2) = 1/2 P:eps + 1/2 c1 c2 a.(sigma_1 - sigma_2) n, and the interface solve removes the traction jump."""
+    from oracle.ls_oracle import energy_voigt, energy_laminate, pk1_voigt, pk1_laminate
+    rng = np.random.default_rng(11)
+    n = (6, 5, 4)
+    eps = rng.standard_normal((6,) + n)
+    phi = rng.random(n)
+    phi[0] = 0.0
+    phi[1] = 1.0
+    nrm = rng.standard_normal((3,) + n)
+    nrm /= np.sqrt((nrm ** 2).sum(axis=0))
+    mats = [(1.3, 0.7), (4.0, 2.5)]
+    phis = [1.0 - phi, phi]
+    dot = lambda P, e: P[0] * e[0] + P[1] * e[1] + P[2] * e[2] + 2 * (P[3] * e[3] + P[4] * e[4] + P[5] * e[5])
+    Wv = energy_voigt(eps, phis, mats)
+    assert np.abs(Wv - 0.5 * dot(pk1_voigt(eps, phis, mats), eps)).max() < 1e-13 * np.abs(Wv).max()
+    Wl = energy_laminate(eps, phis, mats, nrm)
+    assert np.abs(Wl - 0.5 * dot(pk1_laminate(eps, phis, mats, nrm), eps)).max() < 1e-12 * np.abs(Wl).max()
+    assert np.all(Wl <= Wv * (1 + 1e-12))   # relaxing the strain jump can only lower the energy
+    # one phase: both are that phase's 1/2 eps : C : eps
+    mu, lam = mats[0]
+    tr = eps[0] + eps[1] + eps[2]
+    W0 = mu * (eps[0] ** 2 + eps[1] ** 2 + eps[2] ** 2 + 2 * (eps[3] ** 2 + eps[4] ** 2 + eps[5] ** 2)) + 0.5 * lam * tr ** 2
+    assert np.abs(Wl[0] - W0[0]).max() < 1e-13 * np.abs(W0).max() and np.abs(Wv[0] - W0[0]).max() < 1e-13 * np.abs(W0).max()
+
+
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+@pytest.mark.parametrize("method", ["basic", "cg"])
+def test_sigma_energy_and_none_estimators(method, mixing):
+    """create_error_estimator F:14940-14972.  sigma (F:14514-14587, _mode = 2): abs = ||<sigma>_k - <sigma>_{k-1}|| for the
+    first two updates, then the mean of the distances to the last two means; energy (F:14410-14468): |<W>_k - <W>_{k-1}|;
+    none (F:14370-14378): always 1, the run ends at maxiter.  All estimators watch the same iteration: the iterates agree."""
+    from helpers import make_oracle
+    n = (8, 8, 8)
+    E = np.array([1.0, 0, 0, 0, 0, 0.5])
+    run = (lambda o: o.run_cg(E)) if method == "cg" else (lambda o: o.run(E))
+    seen = {}
+    for est in ("epsilon", "sigma", "energy", "none"):
+        o = make_oracle(n, mixing=mixing, tol=1e-7, error_estimator=est, maxiter=12 if est == "none" else 10000)
+        means, energies = [], []
+        o.callback = lambda o=o, means=means, energies=energies: (means.append(o.mean_stress()), energies.append(o.mean_energy())) and False
+        assert run(o) is False
+        seen[est] = (o, means, energies)
+        if est == "none":
+            assert o.residuals == [1.0] * len(o.residuals) and o.iterations == 12
+            continue
+        assert o.residuals[-1] <= 1e-7
+        r = np.array(o.residuals)
+        m = np.array(means)
+        n9 = lambda v: math.sqrt(float((v[:3] ** 2).sum() + 2 * (v[3:] ** 2).sum()))
+        if est == "sigma":
+            prev = [np.zeros(6), np.zeros(6)]   # constructed on the zero field: <sigma> = 0
+            for k in range(len(r)):
+                a = n9(prev[-1] - m[k]) if k < 2 else 0.5 * (n9(prev[-2] - m[k]) + n9(prev[-1] - m[k]))
+                assert r[k] == pytest.approx(a / n9(m[k]), rel=1e-12)
+                prev.append(m[k])
+            assert r[0] == pytest.approx(1.0, abs=1e-15)
+        if est == "energy":
+            w = np.array([0.0] + energies)
+            assert np.allclose(r, np.abs(np.diff(w)) / np.abs(w[1:]), rtol=1e-12, atol=0)
+            # Hill's lemma at the converged field: <W> = 1/2 <sigma>:<eps> (div and sym grad are adjoint on the staggered grid);
+            # the energy is stationary at the solution, so a run stopped on its change leaves a field error ~ sqrt(tol)
+            s, e = o.mean_stress(), o.mean_strain()
+            assert o.mean_energy() == pytest.approx(0.5 * (s[:3] @ e[:3] + 2 * s[3:] @ e[3:]), rel=2e-3)
+    # the iteration does not depend on who watches it
+    ref = seen["epsilon"][1]
+    for est in ("sigma", "energy"):
+        k = min(len(ref), len(seen[est][1]))
+        assert np.abs(np.array(ref[:k]) - np.array(seen[est][1][:k])).max() < 1e-12
+
+
 def test_scalar_cg_residual_estimator_on_layers():
     """ResidualErrorEstimator F:14382-14405 in the scalar modes' CG (runCGElasticity F:23153-23247): the first entry of the
     history is sqrt(gamma_0 / gamma_0) = 1, the history is sqrt(gamma_k / gamma_0) of the recurrence residual, and the run
