@@ -118,6 +118,9 @@ Solver::Solver(int nx, int ny, int nz, double dx, double dy, double dz, int devi
   herr_[1] = 0;
   hseq_ = reinterpret_cast<unsigned*>(herr_ + 1);
   FG_HIP_CHECK(hipMemsetAsync(derr_, 0, sizeof(int), stream_));
+  // fields of this size come back through the staged pipeline: its pinned buffers (a one-time cost of the process, ~18 ms)
+  // are allocated here rather than inside the first fg_get_field
+  if (staged_copy(6 * comp, true)) (void)HostStager::of_device(device_);
 
   fft_.reset(new Fft3(g_, stream_));
   if (slab_layout_) {   // halo planes of the strain-state pipeline of the slab driver (tau going out, tau coming in)
