@@ -15,6 +15,7 @@
 
 #include "fg_fft_kernels.h"
 #include "fg_fft_plane.h"
+#include "fg_fft_smooth.h"
 #include "fg_fft_tables.h"
 #include "fg_hip_util.h"
 
@@ -175,6 +176,121 @@ __global__ void k_c2r_generic(const double* src, double* dst, long nrows, int nz
 __global__ void k_scale(double* x, long n, double s) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= s;
+}
+
+// ---------------------------------------------------------------- lengths with factors 2, 3, 5, 7, 11, 13 (fg_fft_smooth.h)
+template <int C, int DIR>
+__global__ __launch_bounds__(256) void k_smooth_strided(SmoothArgs a, long comp_stride) {
+  extern __shared__ __align__(16) double lds[];
+  cplx* cur = reinterpret_cast<cplx*>(lds);
+  cplx* nxt = cur + (long)a.plan.n * C;
+  a.data += (long)blockIdx.y * comp_stride;
+  smooth_strided_load<C>(a, blockIdx.x, threadIdx.x, 256, cur);
+  __syncthreads();
+  const SmoothMap L = {C, 1, C, false};
+  int Ns = 1;
+  for (int f = 0; f < a.plan.nfac; ++f) {
+    smooth_pass_any<DIR>(a.plan.fac[f], cur, nxt, a.plan.n, Ns, L, a.w, 1, threadIdx.x, 256);
+    Ns *= a.plan.fac[f];
+    cplx* t = cur;
+    cur = nxt;
+    nxt = t;
+    __syncthreads();
+  }
+  smooth_strided_store<C>(a, blockIdx.x, threadIdx.x, 256, cur);
+}
+
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_smooth_z(SmoothZArgs a, long comp_stride, int lines) {
+  extern __shared__ __align__(16) double lds[];
+  const int M = a.plan.n, pitch = smooth_z_pitch(M);
+  cplx* cur = reinterpret_cast<cplx*>(lds);
+  cplx* nxt = cur + (long)lines * pitch;
+  a.data += (long)blockIdx.y * comp_stride;
+  const long row0 = (long)blockIdx.x * lines;
+  const SmoothMap L = {1, pitch, lines, true};
+  if (FWD) {
+    smooth_z_load_packed(a, row0, lines, threadIdx.x, 256, cur);
+  } else {
+    smooth_z_load_spectrum(a, row0, lines, threadIdx.x, 256, nxt);
+    __syncthreads();
+    smooth_z_merge(a, lines, threadIdx.x, 256, nxt, cur);
+  }
+  __syncthreads();
+  int Ns = 1;
+  for (int f = 0; f < a.plan.nfac; ++f) {
+    if (FWD) smooth_pass_any<-1>(a.plan.fac[f], cur, nxt, M, Ns, L, a.w, 2, threadIdx.x, 256);
+    else smooth_pass_any<+1>(a.plan.fac[f], cur, nxt, M, Ns, L, a.w, 2, threadIdx.x, 256);
+    Ns *= a.plan.fac[f];
+    cplx* t = cur;
+    cur = nxt;
+    nxt = t;
+    __syncthreads();
+  }
+  if (FWD) smooth_z_split_store(a, row0, lines, threadIdx.x, 256, cur);
+  else smooth_z_store_packed(a, row0, lines, threadIdx.x, 256, cur);
+}
+
+constexpr size_t kSmoothLdsMax = 156 * 1024;
+
+// columns per tile of a strided smooth pass: 8 (one 128-byte segment per line point) while two images fit the LDS, then 4, 2
+int smooth_tile_cols(int n) {
+  for (int c : {8, 4, 2})
+    if ((size_t)2 * n * c * sizeof(cplx) <= kSmoothLdsMax) return c;
+  return 0;
+}
+
+int smooth_z_lines(int M) {
+  const size_t per_line = (size_t)2 * smooth_z_pitch(M) * sizeof(cplx);
+  if (per_line > kSmoothLdsMax) return 0;
+  const size_t target = 64 * 1024;   // two workgroups per CU where that leaves at least four rows per tile
+  int lines = (int)(target / per_line);
+  if (lines < 4) lines = (int)std::min<size_t>(4, kSmoothLdsMax / per_line);
+  return std::max(1, std::min(lines, 32));
+}
+
+template <int C>
+void launch_smooth_strided_c(const SmoothArgs& a0, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
+  SmoothArgs a = a0;
+  a.tiles_per_outer = (a.ncols + C - 1) / C;
+  const size_t lds = (size_t)2 * a.plan.n * C * sizeof(cplx);
+  static PerDeviceOnce configured;
+  if (auto once = configured.first_use()) {
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_strided<C, -1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmoothLdsMax));
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_strided<C, +1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmoothLdsMax));
+  }
+  const dim3 grid((unsigned)((long)a.tiles_per_outer * nouter), ncomp);
+  if (dir < 0) hipLaunchKernelGGL((k_smooth_strided<C, -1>), grid, dim3(256), lds, s, a, cs);
+  else hipLaunchKernelGGL((k_smooth_strided<C, +1>), grid, dim3(256), lds, s, a, cs);
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_smooth_strided(const SmoothArgs& a, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
+  switch (smooth_tile_cols(a.plan.n)) {
+    case 8: launch_smooth_strided_c<8>(a, nouter, dir, ncomp, cs, s); break;
+    case 4: launch_smooth_strided_c<4>(a, nouter, dir, ncomp, cs, s); break;
+    case 2: launch_smooth_strided_c<2>(a, nouter, dir, ncomp, cs, s); break;
+    default: throw std::runtime_error("fft: line too long for the tile kernels");
+  }
+}
+
+void launch_smooth_z(const SmoothZArgs& a, bool fwd, int ncomp, long comp_stride, hipStream_t s) {
+  const int lines = smooth_z_lines(a.plan.n);
+  if (!lines) throw std::runtime_error("fft: row too long for the tile kernels");
+  const size_t lds = (size_t)2 * lines * smooth_z_pitch(a.plan.n) * sizeof(cplx);
+  static PerDeviceOnce configured;
+  if (auto once = configured.first_use()) {
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_z<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kSmoothLdsMax));
+    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_z<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kSmoothLdsMax));
+  }
+  const dim3 grid((unsigned)((a.nrows + lines - 1) / lines), ncomp);
+  if (fwd) hipLaunchKernelGGL(k_smooth_z<true>, grid, dim3(256), lds, s, a, comp_stride, lines);
+  else hipLaunchKernelGGL(k_smooth_z<false>, grid, dim3(256), lds, s, a, comp_stride, lines);
+  FG_HIP_CHECK(hipGetLastError());
 }
 
 int nt_loads_env() {
@@ -1009,6 +1125,7 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
     wgen_[a] = nullptr;
   }
   half_root_[0] = half_root_[1] = nullptr;
+  if (const char* e = getenv("FG_FFT_SMOOTH")) smooth_mode_ = atoi(e);   // (probe knob of the round's A/B runs)
   fast_[0] = fast_len(g.nx);
   fast_[1] = fast_len(g.ny);
   fast_[2] = (g.nz % 2 == 0) && fast_len(g.nz / 2);
@@ -1023,6 +1140,13 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
       const int m = a == 2 ? (len[a] % 2 == 0 ? len[a] / 2 : 0) : len[a];
       odd_[a] = m ? mixed_factor(m) : 0;
       if (odd_[a]) tw_[a] = upload(make_pass_twiddles(m / odd_[a]));
+      // lengths with small prime factors that the one-kernel p * 2^k passes (p = 3, 5, 7, 9) do not cover -- 100, 120, 200, 300,
+      // 400, 500 ...: the Stockham tile kernels of fg_fft_smooth.h (smooth_mode_: 2 = also where p * 2^k kernels exist, 0 = off)
+      SmoothPlan sp;
+      const bool one_kernel_mixed = odd_[a] == 3 || odd_[a] == 5 || odd_[a] == 7 || odd_[a] == 9;
+      if (m > 1 && smooth_mode_ && (smooth_mode_ > 1 || !one_kernel_mixed) && smooth_plan(m, &sp) &&
+          (a == 2 ? smooth_z_lines(m) > 0 : smooth_tile_cols(m) > 0))
+        smooth_[a] = sp;
       wgen_[a] = upload(make_unit_roots(len[a], len[a]));
       need_scratch = true;
     }
@@ -1068,6 +1192,20 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
     if (w && w->nt >= 0) a.nt = w->nt;
     a.xcd_order = 0;   // (measured for the y passes: 512^3 -1..2 %, 256^3 +2 %)
     strided_pow2(n, a, nouter, dir, ncomp, comp_stride / 2, stream_);
+    return;
+  }
+  if (smooth_[axis].n) {
+    SmoothArgs a;
+    a.data = reinterpret_cast<cplx*>(data);
+    a.ls = ls;
+    a.os = os;
+    a.ncols = ncols;
+    a.tiles_per_outer = 0;
+    a.scale = scale;
+    a.w = wgen_[axis];
+    a.nt = stream_stores_ ? 3 : 0;
+    a.plan = smooth_[axis];
+    launch_smooth_strided(a, nouter, dir, ncomp, comp_stride / 2, stream_);
     return;
   }
   if (odd_[axis]) {
@@ -1394,6 +1532,11 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride, const PlaneWindow* w
     }
     return;
   }
+  if (smooth_[2].n) {
+    SmoothZArgs a = {data, nrows, g_.nzp, wgen_[2], stream_stores_ ? 3 : 0, smooth_[2]};
+    launch_smooth_z(a, true, ncomp, comp_stride, stream_);
+    return;
+  }
   if (odd_[2]) {
     // nz = 2 M, M = p m: m-point kernels on the sub-rows of the packed real rows ([m][p] complex, line stride p), then
     // combine + real split per row through the scratch component
@@ -1481,6 +1624,11 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride, const PlaneWindow* w
 #undef FG_CASE
       default: throw std::runtime_error("fft: unsupported fast z length");
     }
+    return;
+  }
+  if (smooth_[2].n) {
+    SmoothZArgs a = {data, nrows, g_.nzp, wgen_[2], stream_stores_ ? 3 : 0, smooth_[2]};
+    launch_smooth_z(a, false, ncomp, comp_stride, stream_);
     return;
   }
   if (odd_[2]) {

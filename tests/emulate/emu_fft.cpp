@@ -8,6 +8,7 @@
 
 #include "../../fibergen_amd/csrc/fg_fft_kernels.h"
 #include "../../fibergen_amd/csrc/fg_fft_plane.h"
+#include "../../fibergen_amd/csrc/fg_fft_smooth.h"
 #include "../../fibergen_amd/csrc/fg_fft_tables.h"
 
 using namespace fg;
@@ -284,5 +285,88 @@ int emu_plane(int ny, int nz, int dir, double* data, int nplanes) {
   CASE(64, 32) CASE(64, 64) CASE(128, 8) CASE(128, 16) CASE(128, 32) CASE(128, 64) CASE(256, 8) CASE(256, 16) CASE(256, 32)
 #undef CASE
   return 1;
+}
+
+// Stockham tile kernels (fg_fft_smooth.h): the phases of k_smooth_strided / k_smooth_z for every thread of every workgroup,
+// in the device's order (load | barrier | one pass per radix, barriers between | store).  Returns 1 when the length has a
+// prime factor above 13.
+int emu_smooth_strided(int N, int dir, double* data, int ncols, int nouter, double scale, int C, int nthreads) {
+  SmoothArgs a;
+  if (!smooth_plan(N, &a.plan)) return 1;
+  std::vector<cplx> w = make_unit_roots(N, N);
+  a.data = reinterpret_cast<cplx*>(data);
+  a.ls = ncols;
+  a.os = (long)N * ncols;
+  a.ncols = ncols;
+  a.tiles_per_outer = (ncols + C - 1) / C;
+  a.scale = scale;
+  a.w = w.data();
+  a.nt = 0;
+  std::vector<cplx> img(2 * (size_t)N * C);
+  for (int b = 0; b < a.tiles_per_outer * nouter; ++b) {
+    for (auto& x : img) x = cmake(NAN, NAN);
+    cplx *cur = img.data(), *nxt = cur + (size_t)N * C;
+    for (int tid = 0; tid < nthreads; ++tid) {
+      if (C == 8) smooth_strided_load<8>(a, b, tid, nthreads, cur);
+      else if (C == 4) smooth_strided_load<4>(a, b, tid, nthreads, cur);
+      else smooth_strided_load<2>(a, b, tid, nthreads, cur);
+    }
+    const SmoothMap L = {C, 1, C, false};
+    int Ns = 1;
+    for (int f = 0; f < a.plan.nfac; ++f) {
+      for (int tid = 0; tid < nthreads; ++tid) {
+        if (dir < 0) smooth_pass_any<-1>(a.plan.fac[f], cur, nxt, N, Ns, L, a.w, 1, tid, nthreads);
+        else smooth_pass_any<+1>(a.plan.fac[f], cur, nxt, N, Ns, L, a.w, 1, tid, nthreads);
+      }
+      Ns *= a.plan.fac[f];
+      std::swap(cur, nxt);
+    }
+    for (int tid = 0; tid < nthreads; ++tid) {
+      if (C == 8) smooth_strided_store<8>(a, b, tid, nthreads, cur);
+      else if (C == 4) smooth_strided_store<4>(a, b, tid, nthreads, cur);
+      else smooth_strided_store<2>(a, b, tid, nthreads, cur);
+    }
+  }
+  return 0;
+}
+
+int emu_smooth_z(int nz, int fwd, double* data, long nrows, int lines, int nthreads) {
+  SmoothZArgs a;
+  const int M = nz / 2;
+  if (nz % 2 || !smooth_plan(M, &a.plan)) return 1;
+  std::vector<cplx> w = make_unit_roots(nz, nz);
+  a.data = data;
+  a.nrows = nrows;
+  a.nzp = 2 * (nz / 2 + 1);
+  a.w = w.data();
+  a.nt = 0;
+  const int pitch = smooth_z_pitch(M);
+  std::vector<cplx> img(2 * (size_t)lines * pitch);
+  const SmoothMap L = {1, pitch, lines, true};
+  for (long b = 0; b * lines < nrows; ++b) {
+    for (auto& x : img) x = cmake(NAN, NAN);
+    cplx *cur = img.data(), *nxt = cur + (size_t)lines * pitch;
+    const long row0 = b * lines;
+    if (fwd) {
+      for (int tid = 0; tid < nthreads; ++tid) smooth_z_load_packed(a, row0, lines, tid, nthreads, cur);
+    } else {
+      for (int tid = 0; tid < nthreads; ++tid) smooth_z_load_spectrum(a, row0, lines, tid, nthreads, nxt);
+      for (int tid = 0; tid < nthreads; ++tid) smooth_z_merge(a, lines, tid, nthreads, nxt, cur);
+    }
+    int Ns = 1;
+    for (int f = 0; f < a.plan.nfac; ++f) {
+      for (int tid = 0; tid < nthreads; ++tid) {
+        if (fwd) smooth_pass_any<-1>(a.plan.fac[f], cur, nxt, M, Ns, L, a.w, 2, tid, nthreads);
+        else smooth_pass_any<+1>(a.plan.fac[f], cur, nxt, M, Ns, L, a.w, 2, tid, nthreads);
+      }
+      Ns *= a.plan.fac[f];
+      std::swap(cur, nxt);
+    }
+    for (int tid = 0; tid < nthreads; ++tid) {
+      if (fwd) smooth_z_split_store(a, row0, lines, tid, nthreads, cur);
+      else smooth_z_store_packed(a, row0, lines, tid, nthreads, cur);
+    }
+  }
+  return 0;
 }
 }

@@ -203,3 +203,46 @@ def test_plane_kernels(emu, ny, nz):
     assert emu.emu_strided(ny, +1, P(b4), nzc, npl, ctypes.c_double(1.0)) == 0
     assert emu.emu_c2r(nz, P(b4), ctypes.c_long(npl * ny)) == 0
     assert np.array_equal(b4[:, :, :nz], b3[:, :, :nz])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stockham tile kernels for lengths with factors 2, 3, 5, 7, 11, 13 (fg_fft_smooth.h): the decimal grid sizes
+SMOOTH = [6, 10, 12, 15, 18, 20, 25, 30, 36, 49, 50, 60, 75, 77, 91, 100, 120, 121, 125, 150, 169, 200, 240, 250, 300, 360, 400,
+          500, 600, 640, 1000]
+
+
+@pytest.mark.parametrize("N", SMOOTH)
+@pytest.mark.parametrize("d", [-1, 1])
+def test_smooth_strided_c2c(emu, N, d):
+    rng = np.random.default_rng(N)
+    ncols, nouter = 11, 2   # ragged last tile
+    C = 8 if N <= 600 else 4
+    x = rng.standard_normal((nouter, N, ncols)) + 1j * rng.standard_normal((nouter, N, ncols))
+    y = x.copy()
+    nthreads = 256 if N % 7 else 64   # (the phase code takes any team size)
+    assert emu.emu_smooth_strided(N, d, P(y.view(np.float64)), ncols, nouter, ctypes.c_double(0.5), C, nthreads) == 0
+    ref = (np.fft.fft(x, axis=1) if d < 0 else np.fft.ifft(x, axis=1) * N) * 0.5
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-14
+
+
+@pytest.mark.parametrize("nz", [2 * n for n in SMOOTH if n <= 600])
+def test_smooth_r2c_c2r(emu, nz):
+    rng = np.random.default_rng(nz)
+    nrows, lines = 7, 3   # ragged last tile
+    nzc = nz // 2 + 1
+    x = rng.standard_normal((nrows, nz))
+    buf = np.full((nrows, 2 * nzc), np.nan)
+    buf[:, :nz] = x
+    assert emu.emu_smooth_z(nz, 1, P(buf), ctypes.c_long(nrows), lines, 256) == 0
+    ref = np.fft.rfft(x, axis=1)
+    assert np.abs(buf.view(np.complex128) - ref).max() / np.abs(ref).max() < 2e-14
+    X = rng.standard_normal((nrows, nzc)) + 1j * rng.standard_normal((nrows, nzc))   # non-Hermitian: DC / Nyquist imaginary parts ignored
+    buf = X.copy().view(np.float64).copy()
+    assert emu.emu_smooth_z(nz, 0, P(buf), ctypes.c_long(nrows), lines, 256) == 0
+    ref = np.fft.irfft(X, n=nz, axis=1) * nz
+    assert np.abs(buf[:, :nz] - ref).max() / np.abs(ref).max() < 2e-14
+
+
+def test_smooth_plan_rejects_large_primes(emu):
+    x = np.zeros((1, 34, 1), dtype=np.complex128)
+    assert emu.emu_smooth_strided(34, -1, P(x.view(np.float64)), 1, 1, ctypes.c_double(1.0), 8, 64) == 1   # 34 = 2 * 17

@@ -30,6 +30,9 @@ GRIDS = [
     ((72, 24, 240), (1.0, 1.0, 1.0)),     # 9*8, 3*8, nz/2 = 15*8
     ((200, 8, 400), (1.0, 1.0, 1.0)),     # 25*8, nz/2 = 25*8
     ((112, 72, 144), (1.0, 1.0, 1.0)),    # 7*16, 9*8, nz/2 = 9*8: single-kernel passes for p = 7, 9
+    ((20, 30, 36), (1.0, 1.5, 0.8)),      # 4*5, 2*3*5, nz/2 = 2*3*3: Stockham tile kernels on every axis (fg_fft_smooth.h)
+    ((25, 15, 44), (1.0, 1.0, 1.0)),      # 5*5, 3*5, nz/2 = 2*11
+    ((100, 12, 50), (1.0, 1.0, 1.0)),     # the decimal sizes: 4*5*5, nz/2 = 5*5
 ]
 EXACT = {}
 
@@ -96,7 +99,12 @@ def test_div_and_eps_stages(grid, dims):
                                        # (T = 8, 16, 32, 64 lanes per line), and nz/2 = 1024 (two loads / LDS split)
                                        ((8, 8, 128), (1.0, 1.0, 1.0)), ((8, 16, 512), (1.0, 1.0, 1.0)),
                                        ((8, 8, 1024), (1.0, 1.0, 1.0)), ((4, 8, 2048), (1.0, 1.0, 1.0)),
-                                       ((512, 8, 16), (1.0, 1.0, 1.0)), ((8, 1024, 16), (1.0, 1.0, 1.0))])
+                                       ((512, 8, 16), (1.0, 1.0, 1.0)), ((8, 1024, 16), (1.0, 1.0, 1.0)),
+                                       # Stockham tile kernels (fg_fft_smooth.h): the decimal sizes; 8- and 4-column tiles (> 600
+                                       # points); nz / 2 = 500 (four rows per tile), 7 * 11 * 13
+                                       ((100, 200, 300), (1.0, 1.0, 1.0)), ((500, 12, 400), (1.0, 1.0, 1.0)),
+                                       ((12, 1000, 20), (1.0, 1.0, 1.0)), ((1001, 10, 1000), (1.0, 1.0, 1.0)),
+                                       ((120, 240, 60), (1.0, 1.0, 1.0)), ((6, 10, 2002), (1.0, 1.0, 1.0))])
 def test_fft_forward_inverse(grid, dims):
     rng = np.random.default_rng(12)
     o = make_oracle(grid, dims) if max(grid) <= 64 else None
