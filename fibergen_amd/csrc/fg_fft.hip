@@ -179,117 +179,127 @@ __global__ void k_scale(double* x, long n, double s) {
 }
 
 // ---------------------------------------------------------------- lengths with factors 2, 3, 5, 7, 11, 13 (fg_fft_smooth.h)
-template <int C, int DIR>
-__global__ __launch_bounds__(256) void k_smooth_strided(SmoothArgs a, long comp_stride) {
-  extern __shared__ __align__(16) double lds[];
-  cplx* cur = reinterpret_cast<cplx*>(lds);
-  cplx* nxt = cur + (long)a.plan.n * C;
-  a.data += (long)blockIdx.y * comp_stride;
-  smooth_strided_load<C>(a, blockIdx.x, threadIdx.x, 256, cur);
+// one pass of the tile in LDS: read + butterfly, barrier, write, barrier
+template <int R, int DIR>
+__device__ __forceinline__ void smooth_dev_pass(cplx* img, int N, int Ns, const SmoothMap& L, const cplx* w, int wscale) {
+  cplx v[R];
+  const bool active = smooth_pass_read<R, DIR>(img, N, Ns, L, w, wscale, threadIdx.x, v);
   __syncthreads();
-  const SmoothMap L = {C, 1, C, false};
-  int Ns = 1;
-  for (int f = 0; f < a.plan.nfac; ++f) {
-    smooth_pass_any<DIR>(a.plan.fac[f], cur, nxt, a.plan.n, Ns, L, a.w, 1, threadIdx.x, 256);
-    Ns *= a.plan.fac[f];
-    cplx* t = cur;
-    cur = nxt;
-    nxt = t;
-    __syncthreads();
-  }
-  smooth_strided_store<C>(a, blockIdx.x, threadIdx.x, 256, cur);
+  if (active) smooth_pass_write<R>(img, N, Ns, L, threadIdx.x, v);
+  __syncthreads();
 }
 
-template <bool FWD>
-__global__ __launch_bounds__(256) void k_smooth_z(SmoothZArgs a, long comp_stride, int lines) {
+// RMAX: the largest radix the kernel is built for (32 with 256 threads, 16 with 1024: the butterfly lives in registers)
+template <int DIR, int RMAX>
+__device__ __forceinline__ void smooth_dev_passes(cplx* img, const SmoothPlan& plan, const SmoothMap& L, const cplx* w, int wscale) {
+  int Ns = 1;
+  for (int f = 0; f < plan.npass; ++f) {
+    const int R = plan.fac[f];
+    switch (R) {
+#define FG_R(r) case r: if constexpr (r <= RMAX) smooth_dev_pass<r, DIR>(img, plan.n, Ns, L, w, wscale); break;
+      FG_R(2) FG_R(3) FG_R(4) FG_R(5) FG_R(6) FG_R(7) FG_R(8) FG_R(9) FG_R(10) FG_R(11) FG_R(12) FG_R(13) FG_R(14) FG_R(15)
+      FG_R(16) FG_R(18) FG_R(20) FG_R(21) FG_R(22) FG_R(24) FG_R(25) FG_R(26) FG_R(27) FG_R(28) FG_R(30) FG_R(32)
+#undef FG_R
+      default: break;
+    }
+    Ns *= R;
+  }
+}
+
+// THREADS / RMAX classes: (256, 16), (256, 32), (1024, 16) -- registers follow the largest butterfly a kernel is built for
+template <int DIR, int THREADS, int RMAX>
+__global__ __launch_bounds__(THREADS) void k_smooth_strided(SmoothArgs a, long comp_stride) {
   extern __shared__ __align__(16) double lds[];
-  const int M = a.plan.n, pitch = smooth_z_pitch(M);
-  cplx* cur = reinterpret_cast<cplx*>(lds);
-  cplx* nxt = cur + (long)lines * pitch;
+  cplx* img = reinterpret_cast<cplx*>(lds);
   a.data += (long)blockIdx.y * comp_stride;
-  const long row0 = (long)blockIdx.x * lines;
-  const SmoothMap L = {1, pitch, lines, true};
+  constexpr int B = THREADS == 256 ? 16 : 8;
+  if (a.plan.lines == 8) smooth_strided_load<8, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else if (a.plan.lines == 4) smooth_strided_load<4, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else smooth_strided_load<2, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  __syncthreads();
+  const SmoothMap L = {a.plan.lines, 1, a.plan.lines, false};
+  smooth_dev_passes<DIR, RMAX>(img, a.plan, L, a.w, 1);
+  if (a.plan.lines == 8) smooth_strided_store<8>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else if (a.plan.lines == 4) smooth_strided_store<4>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else smooth_strided_store<2>(a, blockIdx.x, threadIdx.x, THREADS, img);
+}
+
+template <bool FWD, int THREADS, int RMAX>
+__global__ __launch_bounds__(THREADS) void k_smooth_z(SmoothZArgs a, long comp_stride) {
+  extern __shared__ __align__(16) double lds[];
+  cplx* img = reinterpret_cast<cplx*>(lds);
+  a.data += (long)blockIdx.y * comp_stride;
+  const long row0 = (long)blockIdx.x * a.plan.lines;
+  const SmoothMap L = {1, smooth_z_pitch(a.plan.n), a.plan.lines, true};
+  constexpr int B = THREADS == 256 ? 16 : 8;
   if (FWD) {
-    smooth_z_load_packed(a, row0, lines, threadIdx.x, 256, cur);
+    smooth_z_load_packed<B>(a, row0, threadIdx.x, THREADS, img);
   } else {
-    smooth_z_load_spectrum(a, row0, lines, threadIdx.x, 256, nxt);
+    smooth_z_load_spectrum<B>(a, row0, threadIdx.x, THREADS, img);
     __syncthreads();
-    smooth_z_merge(a, lines, threadIdx.x, 256, nxt, cur);
+    smooth_z_merge<B>(a, threadIdx.x, THREADS, img);
   }
   __syncthreads();
-  int Ns = 1;
-  for (int f = 0; f < a.plan.nfac; ++f) {
-    if (FWD) smooth_pass_any<-1>(a.plan.fac[f], cur, nxt, M, Ns, L, a.w, 2, threadIdx.x, 256);
-    else smooth_pass_any<+1>(a.plan.fac[f], cur, nxt, M, Ns, L, a.w, 2, threadIdx.x, 256);
-    Ns *= a.plan.fac[f];
-    cplx* t = cur;
-    cur = nxt;
-    nxt = t;
-    __syncthreads();
-  }
-  if (FWD) smooth_z_split_store(a, row0, lines, threadIdx.x, 256, cur);
-  else smooth_z_store_packed(a, row0, lines, threadIdx.x, 256, cur);
+  smooth_dev_passes<FWD ? -1 : +1, RMAX>(img, a.plan, L, a.w, 2);
+  if (FWD) smooth_z_split_store<B>(a, row0, threadIdx.x, THREADS, img);
+  else smooth_z_store_packed(a, row0, threadIdx.x, THREADS, img);
 }
 
-constexpr size_t kSmoothLdsMax = 156 * 1024;
-
-// columns per tile of a strided smooth pass: 8 (one 128-byte segment per line point) while two images fit the LDS, then 4, 2
-int smooth_tile_cols(int n) {
-  for (int c : {8, 4, 2})
-    if ((size_t)2 * n * c * sizeof(cplx) <= kSmoothLdsMax) return c;
-  return 0;
+template <class K>
+void smooth_configure(K kernel) {
+  FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmoothLdsMax));
 }
 
-int smooth_z_lines(int M) {
-  const size_t per_line = (size_t)2 * smooth_z_pitch(M) * sizeof(cplx);
-  if (per_line > kSmoothLdsMax) return 0;
-  const size_t target = 64 * 1024;   // two workgroups per CU where that leaves at least four rows per tile
-  int lines = (int)(target / per_line);
-  if (lines < 4) lines = (int)std::min<size_t>(4, kSmoothLdsMax / per_line);
-  return std::max(1, std::min(lines, 32));
-}
+// the kernel class of a plan: 0 = (256 threads, radices <= 16), 1 = (256, <= 32), 2 = (1024, <= 16)
+int smooth_class(const SmoothPlan& p) { return p.threads == 1024 ? 2 : (p.rmax() <= 16 ? 0 : 1); }
 
-template <int C>
-void launch_smooth_strided_c(const SmoothArgs& a0, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
+void launch_smooth_strided(const SmoothArgs& a0, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
   SmoothArgs a = a0;
+  const int C = a.plan.lines;
   a.tiles_per_outer = (a.ncols + C - 1) / C;
-  const size_t lds = (size_t)2 * a.plan.n * C * sizeof(cplx);
+  const size_t lds = (size_t)a.plan.n * C * sizeof(cplx);
   static PerDeviceOnce configured;
   if (auto once = configured.first_use()) {
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_strided<C, -1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmoothLdsMax));
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_strided<C, +1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmoothLdsMax));
+    smooth_configure(&k_smooth_strided<-1, 256, 16>);
+    smooth_configure(&k_smooth_strided<+1, 256, 16>);
+    smooth_configure(&k_smooth_strided<-1, 256, 32>);
+    smooth_configure(&k_smooth_strided<+1, 256, 32>);
+    smooth_configure(&k_smooth_strided<-1, 1024, 16>);
+    smooth_configure(&k_smooth_strided<+1, 1024, 16>);
   }
   const dim3 grid((unsigned)((long)a.tiles_per_outer * nouter), ncomp);
-  if (dir < 0) hipLaunchKernelGGL((k_smooth_strided<C, -1>), grid, dim3(256), lds, s, a, cs);
-  else hipLaunchKernelGGL((k_smooth_strided<C, +1>), grid, dim3(256), lds, s, a, cs);
+  switch (smooth_class(a.plan) * 2 + (dir < 0 ? 0 : 1)) {
+    case 0: hipLaunchKernelGGL((k_smooth_strided<-1, 256, 16>), grid, dim3(256), lds, s, a, cs); break;
+    case 1: hipLaunchKernelGGL((k_smooth_strided<+1, 256, 16>), grid, dim3(256), lds, s, a, cs); break;
+    case 2: hipLaunchKernelGGL((k_smooth_strided<-1, 256, 32>), grid, dim3(256), lds, s, a, cs); break;
+    case 3: hipLaunchKernelGGL((k_smooth_strided<+1, 256, 32>), grid, dim3(256), lds, s, a, cs); break;
+    case 4: hipLaunchKernelGGL((k_smooth_strided<-1, 1024, 16>), grid, dim3(1024), lds, s, a, cs); break;
+    default: hipLaunchKernelGGL((k_smooth_strided<+1, 1024, 16>), grid, dim3(1024), lds, s, a, cs); break;
+  }
   FG_HIP_CHECK(hipGetLastError());
 }
 
-void launch_smooth_strided(const SmoothArgs& a, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
-  switch (smooth_tile_cols(a.plan.n)) {
-    case 8: launch_smooth_strided_c<8>(a, nouter, dir, ncomp, cs, s); break;
-    case 4: launch_smooth_strided_c<4>(a, nouter, dir, ncomp, cs, s); break;
-    case 2: launch_smooth_strided_c<2>(a, nouter, dir, ncomp, cs, s); break;
-    default: throw std::runtime_error("fft: line too long for the tile kernels");
-  }
-}
-
 void launch_smooth_z(const SmoothZArgs& a, bool fwd, int ncomp, long comp_stride, hipStream_t s) {
-  const int lines = smooth_z_lines(a.plan.n);
-  if (!lines) throw std::runtime_error("fft: row too long for the tile kernels");
-  const size_t lds = (size_t)2 * lines * smooth_z_pitch(a.plan.n) * sizeof(cplx);
+  const int lines = a.plan.lines;
+  const size_t lds = (size_t)lines * smooth_z_pitch(a.plan.n) * sizeof(cplx);
   static PerDeviceOnce configured;
   if (auto once = configured.first_use()) {
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_z<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kSmoothLdsMax));
-    FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_z<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kSmoothLdsMax));
+    smooth_configure(&k_smooth_z<true, 256, 16>);
+    smooth_configure(&k_smooth_z<false, 256, 16>);
+    smooth_configure(&k_smooth_z<true, 256, 32>);
+    smooth_configure(&k_smooth_z<false, 256, 32>);
+    smooth_configure(&k_smooth_z<true, 1024, 16>);
+    smooth_configure(&k_smooth_z<false, 1024, 16>);
   }
   const dim3 grid((unsigned)((a.nrows + lines - 1) / lines), ncomp);
-  if (fwd) hipLaunchKernelGGL(k_smooth_z<true>, grid, dim3(256), lds, s, a, comp_stride, lines);
-  else hipLaunchKernelGGL(k_smooth_z<false>, grid, dim3(256), lds, s, a, comp_stride, lines);
+  switch (smooth_class(a.plan) * 2 + (fwd ? 0 : 1)) {
+    case 0: hipLaunchKernelGGL((k_smooth_z<true, 256, 16>), grid, dim3(256), lds, s, a, comp_stride); break;
+    case 1: hipLaunchKernelGGL((k_smooth_z<false, 256, 16>), grid, dim3(256), lds, s, a, comp_stride); break;
+    case 2: hipLaunchKernelGGL((k_smooth_z<true, 256, 32>), grid, dim3(256), lds, s, a, comp_stride); break;
+    case 3: hipLaunchKernelGGL((k_smooth_z<false, 256, 32>), grid, dim3(256), lds, s, a, comp_stride); break;
+    case 4: hipLaunchKernelGGL((k_smooth_z<true, 1024, 16>), grid, dim3(1024), lds, s, a, comp_stride); break;
+    default: hipLaunchKernelGGL((k_smooth_z<false, 1024, 16>), grid, dim3(1024), lds, s, a, comp_stride); break;
+  }
   FG_HIP_CHECK(hipGetLastError());
 }
 
@@ -1125,7 +1135,6 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
     wgen_[a] = nullptr;
   }
   half_root_[0] = half_root_[1] = nullptr;
-  if (const char* e = getenv("FG_FFT_SMOOTH")) smooth_mode_ = atoi(e);   // (probe knob of the round's A/B runs)
   fast_[0] = fast_len(g.nx);
   fast_[1] = fast_len(g.ny);
   fast_[2] = (g.nz % 2 == 0) && fast_len(g.nz / 2);
@@ -1141,12 +1150,11 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
       odd_[a] = m ? mixed_factor(m) : 0;
       if (odd_[a]) tw_[a] = upload(make_pass_twiddles(m / odd_[a]));
       // lengths with small prime factors that the one-kernel p * 2^k passes (p = 3, 5, 7, 9) do not cover -- 100, 120, 200, 300,
-      // 400, 500 ...: the Stockham tile kernels of fg_fft_smooth.h (smooth_mode_: 2 = also where p * 2^k kernels exist, 0 = off)
+      // 400, 500 ...: the Stockham tile kernels of fg_fft_smooth.h.  (Where a p * 2^k kernel exists it stays: measured in one job
+      // with the tile kernels forced on, 96^3 9 160 against 5 510 it/s, 192^3 2 030 / 1 270, 384^3 240 / 174, 448^3 123 / 91.)
       SmoothPlan sp;
       const bool one_kernel_mixed = odd_[a] == 3 || odd_[a] == 5 || odd_[a] == 7 || odd_[a] == 9;
-      if (m > 1 && smooth_mode_ && (smooth_mode_ > 1 || !one_kernel_mixed) && smooth_plan(m, &sp) &&
-          (a == 2 ? smooth_z_lines(m) > 0 : smooth_tile_cols(m) > 0))
-        smooth_[a] = sp;
+      if (m > 1 && !one_kernel_mixed && (a == 2 ? smooth_plan_z(m, &sp) : smooth_plan_strided(m, &sp))) smooth_[a] = sp;
       wgen_[a] = upload(make_unit_roots(len[a], len[a]));
       need_scratch = true;
     }

@@ -1,96 +1,48 @@
-// Transform passes for lengths that are NOT a power of two (nor 3, 5, 7, 9 times one): N = a product of the radices
-// 8, 4, 2, 3, 5, 7, 11, 13 -- the decimal grid sizes users of the reference pick (100, 200, 300, 400, 500 ...; FFTW takes any).
+// Transform passes for lengths that are NOT a power of two (nor 3, 5, 7, 9 times one): N = a product of the primes
+// 2, 3, 5, 7, 11, 13 -- the decimal grid sizes users of the reference pick (100, 200, 300, 400, 500 ...; FFTW takes any).
 //
-// Stockham autosort on a tile of lines held in LDS: a workgroup loads C whole lines (C adjacent columns for the strided
-// y / x passes: one 128-byte segment per line point for C = 8; C rows for the z passes), runs one pass per radix between two
-// LDS images (pass with radix R, Ns = product of the radices before it:  butterfly j < N/R reads points j + r N/R, multiplies
-// by w^{r (j mod Ns) N/(Ns R)}, transforms, writes points (j / Ns) Ns R + (j mod Ns) + r Ns -- natural order after the last
-// pass), and writes the tile back: one read and one write of the data per axis, like the power-of-two kernels (which stay
-// the faster ones for their lengths: 8 points per thread in registers, fewer LDS sweeps).
+// Stockham autosort on a tile of lines held in LDS, in the style of the power-of-two kernels (a thread = one butterfly held in
+// registers): a workgroup loads `lines` whole lines (adjacent columns for the strided y / x passes -- one 128-byte segment
+// per line point for 8 columns --, rows for the z passes) into ONE LDS image and runs a few passes with LARGE radices R <= 32
+// (N = 500 is 25 x 20, 300 is 25 x 12, 1000 is 10 x 10 x 10): in a pass thread (j, t) reads the points j + r N/R of line t,
+// multiplies by w^{r (j mod Ns) N/(Ns R)} (Ns = product of the radices before: none in the first pass), transforms the R
+// values in registers -- a composite butterfly built from the prime / 4 / 8 butterflies with constant twiddles --, and,
+// behind a barrier, writes them to the points (j / Ns) Ns R + (j mod Ns) + r Ns of the same image: natural order after the
+// last pass.  The planner picks the radices so that every pass has at most one butterfly per thread (N lines / R <= threads).
+// One read and one write of the data per axis, like the power-of-two kernels (which stay the faster ones for their lengths).
 // The per-thread code is FG_HD: tests/emulate runs it on the host against numpy.
 #pragma once
 
 #include "fg_fft_core.h"
+#include "fg_fft_roots.h"
 
 namespace fg {
 namespace fft {
 
-constexpr int kSmoothMaxFactors = 12;
+constexpr int kSmoothMaxPasses = 4;
+constexpr int kSmoothMaxRadix = 32;
+constexpr size_t kSmoothLdsMax = 156 * 1024;
 
 struct SmoothPlan {
-  int n = 0;       // line length (z passes: nz / 2)
-  int nfac = 0;
-  int fac[kSmoothMaxFactors] = {};
+  int n = 0;         // line length (z passes: nz / 2); 0 = no plan
+  int npass = 0;
+  int fac[kSmoothMaxPasses] = {};
+  int lines = 0;     // lines per tile (strided passes: columns)
+  int threads = 0;   // 256 or 1024
+  int rmax() const { int m = 0; for (int i = 0; i < npass; ++i) m = fac[i] > m ? fac[i] : m; return m; }
 };
 
-// radices in pass order; false when n has a prime factor above 13 (or too many factors)
-inline bool smooth_plan(int n, SmoothPlan* p) {
-  p->n = n;
-  p->nfac = 0;
-  if (n < 2) return false;
-  int m = n;
-  auto take = [&](int r) {
-    while (m % r == 0) {
-      if (p->nfac >= kSmoothMaxFactors) return false;
-      p->fac[p->nfac++] = r;
-      m /= r;
-    }
-    return true;
-  };
-  // odd radices first (their twiddle-free first pass is the expensive butterfly), then 8s, one 4 or 2
-  for (int r : {13, 11, 7, 5, 3})
-    if (!take(r)) return false;
-  while (m % 8 == 0) {
-    if (p->nfac >= kSmoothMaxFactors) return false;
-    p->fac[p->nfac++] = 8;
-    m /= 8;
-  }
-  if (!take(4) || !take(2)) return false;
-  return m == 1;
+constexpr bool smooth_is_base(int r) { return r == 2 || r == 4 || r == 8 || r == 3 || r == 5 || r == 7 || r == 11 || r == 13; }
+constexpr int smooth_first_factor(int r) {
+  for (int f : {13, 11, 7, 5, 3, 8, 4, 2})
+    if (r % f == 0) return f;
+  return 0;
 }
-
-// cos / sin (2 pi j / R), j = 1 .. (R - 1) / 2 (local constant tables: usable from host and device code alike)
-template <int R> FG_HD double odd_cos(int j);
-template <int R> FG_HD double odd_sin(int j);
-template <> FG_HD double odd_cos<3>(int j) {
-  constexpr double c[1] = {-0.5};
-  return c[j - 1];
-}
-template <> FG_HD double odd_sin<3>(int j) {
-  constexpr double s[1] = {0.8660254037844386467637232};
-  return s[j - 1];
-}
-template <> FG_HD double odd_cos<5>(int j) {
-  constexpr double c[2] = {0.3090169943749474241022934, -0.8090169943749474241022934};
-  return c[j - 1];
-}
-template <> FG_HD double odd_sin<5>(int j) {
-  constexpr double s[2] = {0.9510565162951535721164393, 0.587785252292473129168706};
-  return s[j - 1];
-}
-template <> FG_HD double odd_cos<7>(int j) {
-  constexpr double c[3] = {0.6234898018587335305250049, -0.2225209339563144042889026, -0.9009688679024191262361023};
-  return c[j - 1];
-}
-template <> FG_HD double odd_sin<7>(int j) {
-  constexpr double s[3] = {0.7818314824680298087084445, 0.9749279121818236070181317, 0.4338837391175581204757683};
-  return s[j - 1];
-}
-template <> FG_HD double odd_cos<11>(int j) {
-  constexpr double c[5] = {0.8412535328311811688618116, 0.4154150130018864255292741, -0.1423148382732851404437927, -0.6548607339452850640569251, -0.9594929736144973898903681};
-  return c[j - 1];
-}
-template <> FG_HD double odd_sin<11>(int j) {
-  constexpr double s[5] = {0.540640817455597582107636, 0.9096319953545183714117154, 0.989821441880932732376092, 0.7557495743542582837740358, 0.2817325568414296977114179};
-  return s[j - 1];
-}
-template <> FG_HD double odd_cos<13>(int j) {
-  constexpr double c[6] = {0.8854560256532098959003755, 0.5680647467311558025118076, 0.1205366802553230533490677, -0.3546048870425356259696379, -0.7485107481711010986346306, -0.9709418174260520271569823};
-  return c[j - 1];
-}
-template <> FG_HD double odd_sin<13>(int j) {
-  constexpr double s[6] = {0.4647231720437685456560153, 0.8229838658936563945796174, 0.9927088740980539928007516, 0.9350162426854148234397846, 0.6631226582407952023767855, 0.2393156642875577671487537};
-  return s[j - 1];
+constexpr bool smooth_radix_ok(int r) {   // 2 ... 32 with prime factors up to 13
+  if (r < 2 || r > kSmoothMaxRadix) return false;
+  for (int f : {2, 3, 5, 7, 11, 13})
+    while (r % f == 0) r /= f;
+  return r == 1;
 }
 
 // Natural-order DFT of an odd prime length: with a_m = x_m + x_{R-m}, b_m = x_m - x_{R-m} (m = 1 .. h = (R - 1) / 2)
@@ -114,9 +66,8 @@ FG_HD void dft_odd(cplx* v) {
     double cr = x0.re, ci = x0.im, sr = 0.0, si = 0.0;
 #pragma unroll
     for (int m = 1; m <= H; ++m) {
-      const int j = (m * k) % R;                       // compile-time after unrolling
-      const double cj = odd_cos<R>(j <= H ? j : R - j);
-      const double sj = (j <= H ? 1.0 : -1.0) * odd_sin<R>(j <= H ? j : R - j);
+      const int j = (m * k) % R;   // compile-time after unrolling
+      const double cj = root_cos<R>(j), sj = root_sin<R>(j);
       cr += cj * a[m - 1].re;
       ci += cj * a[m - 1].im;
       sr += sj * b[m - 1].re;
@@ -128,62 +79,161 @@ FG_HD void dft_odd(cplx* v) {
   }
 }
 
+// Natural-order DFT of R values in registers, R any product of the base radices: Cooley-Tukey with R = R1 R2, input index
+// n = R2 n1 + n2, output index k = k1 + R1 k2: R2 transforms of length R1 over n1, the constant twiddles w_R^{n2 k1}, R1
+// transforms of length R2 over n2.
 template <int R, int DIR>
-FG_HD void dft_any(cplx* v) {
+FG_HD void dft_reg(cplx* v) {
   if constexpr (R == 2) dft2<DIR>(v);
   else if constexpr (R == 4) dft4<DIR>(v);
   else if constexpr (R == 8) dft8<DIR>(v);
-  else dft_odd<R, DIR>(v);
+  else if constexpr (smooth_is_base(R)) dft_odd<R, DIR>(v);
+  else {
+    constexpr int R1 = smooth_first_factor(R), R2 = R / R1;
+    cplx a[R];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) {
+      cplx col[R1];
+#pragma unroll
+      for (int n1 = 0; n1 < R1; ++n1) col[n1] = v[R2 * n1 + n2];
+      dft_reg<R1, DIR>(col);
+#pragma unroll
+      for (int k1 = 0; k1 < R1; ++k1) {
+        const int m = (n2 * k1) % R;   // compile-time after unrolling
+        a[k1 * R2 + n2] = m == 0 ? col[k1] : cmul(col[k1], cmake(root_cos<R>(m), DIR * root_sin<R>(m)));
+      }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+      dft_reg<R2, DIR>(&a[k1 * R2]);
+#pragma unroll
+      for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = a[k1 * R2 + k2];
+    }
+  }
 }
 
 // Addressing of a tile in LDS: point p of line t sits at p * sp + t * sc.
-//   strided passes: sp = C, sc = 1 (the C columns of a line point are adjacent, as in memory); threads run over t fastest
-//   z passes:       sp = 1, sc = line pitch (a row is contiguous, as in memory);                threads run over j fastest
+//   strided passes: sp = lines, sc = 1 (the columns of a line point are adjacent, as in memory); threads run over t fastest
+//   z passes:       sp = 1, sc = line pitch (a row is contiguous, as in memory);                  threads run over j fastest
 struct SmoothMap {
   int sp, sc, lines;
   bool jfast;
 };
 
-// One pass for the thread `tid` of `nthreads`.  w: e^{-2 pi i k / (N * wscale)}, entry k * wscale = the N-th root's power k.
+// First half of a pass for thread `tid`: the R inputs of its butterfly, twiddled and transformed -> v.  Returns whether
+// the thread owns a butterfly.  w: entry k * wscale = e^{-2 pi i k / N}.
 template <int R, int DIR>
-FG_HD void smooth_pass(const cplx* in, cplx* out, int N, int Ns, const SmoothMap& L, const cplx* w, int wscale, int tid, int nthreads) {
+FG_HD bool smooth_pass_read(const cplx* img, int N, int Ns, const SmoothMap& L, const cplx* w, int wscale, int tid, cplx* v) {
   const int nb = N / R;
-  const int tws = (N / (Ns * R)) * wscale;
-  for (int idx = tid; idx < nb * L.lines; idx += nthreads) {
-    const int t = L.jfast ? idx / nb : idx % L.lines;
-    const int j = L.jfast ? idx % nb : idx / L.lines;
+  if (tid >= nb * L.lines) return false;
+  const int t = L.jfast ? tid / nb : tid % L.lines;
+  const int j = L.jfast ? tid % nb : tid / L.lines;
+  const cplx* src = img + (long)t * L.sc;
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = src[(long)(j + r * nb) * L.sp];
+  if (Ns > 1) {
+    // w^{r m}, m = (j mod Ns) N / (Ns R): the first power from the table, the others as products of two lower ones (error
+    // growth ~ log2 R roundings)
     const int k = j % Ns;
-    const cplx* src = in + (long)t * L.sc;
-    cplx v[R];
+    cplx p[R];
+    p[1] = w[(long)k * (N / (Ns * R)) * wscale];
+    if (DIR > 0) p[1] = cconj(p[1]);
+    v[1] = cmul(v[1], p[1]);
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = src[(j + r * nb) * L.sp];
-    if (Ns > 1) {
-#pragma unroll
-      for (int r = 1; r < R; ++r) {
-        const cplx tw = w[(long)r * k * tws];
-        v[r] = cmul(v[r], DIR < 0 ? tw : cconj(tw));
-      }
+    for (int r = 2; r < R; ++r) {
+      p[r] = cmul(p[r / 2], p[r - r / 2]);
+      v[r] = cmul(v[r], p[r]);
     }
-    dft_any<R, DIR>(v);
-    cplx* dst = out + (long)t * L.sc + (long)((j / Ns) * Ns * R + k) * L.sp;
-#pragma unroll
-    for (int r = 0; r < R; ++r) dst[(long)r * Ns * L.sp] = v[r];
   }
+  dft_reg<R, DIR>(v);
+  return true;
 }
 
-template <int DIR>
-FG_HD void smooth_pass_any(int R, const cplx* in, cplx* out, int N, int Ns, const SmoothMap& L, const cplx* w, int wscale, int tid,
-                           int nthreads) {
-  switch (R) {
-    case 2: smooth_pass<2, DIR>(in, out, N, Ns, L, w, wscale, tid, nthreads); break;
-    case 3: smooth_pass<3, DIR>(in, out, N, Ns, L, w, wscale, tid, nthreads); break;
-    case 4: smooth_pass<4, DIR>(in, out, N, Ns, L, w, wscale, tid, nthreads); break;
-    case 5: smooth_pass<5, DIR>(in, out, N, Ns, L, w, wscale, tid, nthreads); break;
-    case 7: smooth_pass<7, DIR>(in, out, N, Ns, L, w, wscale, tid, nthreads); break;
-    case 8: smooth_pass<8, DIR>(in, out, N, Ns, L, w, wscale, tid, nthreads); break;
-    case 11: smooth_pass<11, DIR>(in, out, N, Ns, L, w, wscale, tid, nthreads); break;
-    default: smooth_pass<13, DIR>(in, out, N, Ns, L, w, wscale, tid, nthreads); break;
+// Second half (behind a barrier: every thread has read its inputs): the outputs to their Stockham positions
+template <int R>
+FG_HD void smooth_pass_write(cplx* img, int N, int Ns, const SmoothMap& L, int tid, const cplx* v) {
+  const int nb = N / R;
+  const int t = L.jfast ? tid / nb : tid % L.lines;
+  const int j = L.jfast ? tid % nb : tid / L.lines;
+  cplx* dst = img + (long)t * L.sc + (long)((j / Ns) * Ns * R + j % Ns) * L.sp;
+#pragma unroll
+  for (int r = 0; r < R; ++r) dst[(long)r * Ns * L.sp] = v[r];
+}
+
+// ---- planner: lines per tile, threads per workgroup and the radices of the passes
+// radices of n in [lo, hi], at most kSmoothMaxPasses of them: fewest passes first, then the smallest largest radix; returned
+// largest first (the first pass has no twiddles)
+struct SmoothSearch {
+  int lo, hi, best[kSmoothMaxPasses], cur[kSmoothMaxPasses], nbest = 0;
+  void go(int rest, int depth, int maxr) {
+    if (rest == 1 && depth > 0) {
+      bool better = !nbest || depth < nbest;
+      if (!better && depth == nbest) better = cur[0] < best[0];   // (non-increasing lists: entry 0 is the largest radix)
+      if (better) {
+        for (int i = 0; i < depth; ++i) best[i] = cur[i];
+        nbest = depth;
+      }
+      return;
+    }
+    if (depth == kSmoothMaxPasses || (nbest && depth + 1 > nbest)) return;
+    for (int r = maxr < hi ? maxr : hi; r >= lo && r >= 2; --r) {   // non-increasing: every multiset once
+      if (rest % r || !smooth_radix_ok(r)) continue;
+      cur[depth] = r;
+      go(rest / r, depth + 1, r);
+    }
   }
+};
+
+inline bool smooth_factor(int n, int lo, int hi, int* fac, int* npass) {
+  SmoothSearch s;
+  s.lo = lo < 2 ? 2 : lo;
+  s.hi = hi;
+  s.go(n, 0, hi);
+  if (!s.nbest) return false;
+  for (int i = 0; i < s.nbest; ++i) fac[i] = s.best[i];
+  *npass = s.nbest;
+  return true;
+}
+
+FG_HD int smooth_z_pitch(int M) { return M + 1 + ((M + 1) % 2 == 0 ? 1 : 0); }   // odd: rows start on different banks
+
+inline bool smooth_try(int n, int lines, int threads, int hi, SmoothPlan* p) {
+  const int lo = (n * lines + threads - 1) / threads;
+  int fac[kSmoothMaxPasses], np = 0;
+  if (!smooth_factor(n, lo, hi, fac, &np)) return false;
+  p->n = n;
+  p->npass = np;
+  for (int i = 0; i < np; ++i) p->fac[i] = fac[i];
+  p->lines = lines;
+  p->threads = threads;
+  return true;
+}
+
+// strided pass over lines of n points: 8 columns (one 128-byte segment per line point) where the image fits, 256 threads where
+// radices up to 32 cover n * columns / 256 points per thread, else 1024 threads (radices up to 16)
+inline bool smooth_plan_strided(int n, SmoothPlan* p) {
+  *p = SmoothPlan();
+  if (n < 2) return false;
+  for (int cols : {8, 4, 2}) {
+    if ((size_t)n * cols * sizeof(cplx) > kSmoothLdsMax) continue;
+    // (256 threads, radices <= 16): half the registers, twice the resident workgroups; then radices <= 32; then 1024 threads
+    if (smooth_try(n, cols, 256, 16, p) || smooth_try(n, cols, 256, kSmoothMaxRadix, p) || smooth_try(n, cols, 1024, 16, p)) return true;
+  }
+  return false;
+}
+
+// z pass over rows of M = nz / 2 complex points: as many rows per tile as keep the image at <= 48 KB (three workgroups per
+// CU), at least one
+inline bool smooth_plan_z(int M, SmoothPlan* p) {
+  *p = SmoothPlan();
+  if (M < 2) return false;
+  const size_t line = (size_t)smooth_z_pitch(M) * sizeof(cplx);
+  for (int round = 0; round < 2; ++round)
+    for (int lines : {16, 8, 4, 2, 1}) {
+      if (line * lines > (round == 0 ? (size_t)48 * 1024 : kSmoothLdsMax)) continue;
+      if (smooth_try(M, lines, 256, 16, p) || smooth_try(M, lines, 256, kSmoothMaxRadix, p) || smooth_try(M, lines, 1024, 16, p)) return true;
+    }
+  return false;
 }
 
 struct SmoothArgs {
@@ -205,15 +255,32 @@ struct SmoothZArgs {
   SmoothPlan plan;     // of M = nz / 2
 };
 
-// ---- tile phases (between two workgroup barriers each; `tid` of `nthreads`)
+// ---- tile phases (between two workgroup barriers each; thread `tid` of `nthreads`)
+// A thread moves its elements in batches of B: ALL global loads of a batch are issued before the first value is used -- a loop
+// of load -> LDS store -> next load waits for the memory latency once per element (the first form of these kernels: 25 us per
+// 500-point tile, most of it in such loops).  B = 16 with 256 threads (64 KB in flight per workgroup), 8 with 1024.
+// idx / d for 0 <= idx < 2^20 and d < 2^13 without an integer division (exact: the float error is far below 1 / (2 d))
+FG_HD int smooth_div(int idx, float inv_d) { return (int)(((float)idx + 0.5f) * inv_d); }
+
 // strided pass: the tile = columns [col0, col0 + C) of outer index o, image [p][C]
-template <int C>
+template <int C, int B>
 FG_HD void smooth_strided_load(const SmoothArgs& a, int block, int tid, int nthreads, cplx* img) {
   const int o = block / a.tiles_per_outer, col0 = (block % a.tiles_per_outer) * C;
   const long base = (long)o * a.os + col0;
-  for (int idx = tid; idx < a.plan.n * C; idx += nthreads) {
-    const int p = idx / C, t = idx % C;
-    img[idx] = col0 + t < a.ncols ? cload_stream(&a.data[base + (long)p * a.ls + t], a.nt) : cmake(0.0, 0.0);
+  const int total = a.plan.n * C;
+  for (int i0 = tid; i0 < total; i0 += B * nthreads) {
+    cplx v[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int p = idx / C, t = idx % C;
+      v[i] = idx < total && col0 + t < a.ncols ? cload_stream(&a.data[base + (long)p * a.ls + t], a.nt) : cmake(0.0, 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      if (idx < total) img[idx] = v[i];
+    }
   }
 }
 
@@ -228,56 +295,111 @@ FG_HD void smooth_strided_store(const SmoothArgs& a, int block, int tid, int nth
 }
 
 // z passes: the tile = rows [row0, row0 + lines), image [l][pitch] (pitch >= M + 1)
-FG_HD int smooth_z_pitch(int M) { return M + 1 + ((M + 1) % 2 == 0 ? 1 : 0); }   // odd: rows start on different banks
-
 // r2c: the packed real row as M complex points -> image
-FG_HD void smooth_z_load_packed(const SmoothZArgs& a, long row0, int lines, int tid, int nthreads, cplx* img) {
-  const int M = a.plan.n, pitch = smooth_z_pitch(M);
-  for (int idx = tid; idx < lines * M; idx += nthreads) {
-    const int l = idx / M, m = idx % M;
-    const long row = row0 + l;
-    img[l * pitch + m] = row < a.nrows ? cload_stream(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[m], a.nt) : cmake(0.0, 0.0);
+template <int B>
+FG_HD void smooth_z_load_packed(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+  const int M = a.plan.n, pitch = smooth_z_pitch(M), total = a.plan.lines * M;
+  const float inv = 1.0f / (float)M;
+  for (int i0 = tid; i0 < total; i0 += B * nthreads) {
+    cplx v[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), m = idx - l * M;
+      const long row = row0 + l;
+      v[i] = idx < total && row < a.nrows ? cload_stream(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[m], a.nt) : cmake(0.0, 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), m = idx - l * M;
+      if (idx < total) img[l * pitch + m] = v[i];
+    }
   }
 }
 
 // r2c: the real split X[k], k = 0 .. M, of the transformed image -> memory (FFTW's r2c layout)
-FG_HD void smooth_z_split_store(const SmoothZArgs& a, long row0, int lines, int tid, int nthreads, const cplx* img) {
-  const int M = a.plan.n, pitch = smooth_z_pitch(M);
-  for (int idx = tid; idx < lines * (M + 1); idx += nthreads) {
-    const int l = idx / (M + 1), k = idx % (M + 1);
-    const long row = row0 + l;
-    if (row >= a.nrows) continue;
-    const cplx zk = img[l * pitch + (k == M ? 0 : k)], zmk = img[l * pitch + (k == 0 ? 0 : M - k)];
-    cstore_stream(&reinterpret_cast<cplx*>(a.data + row * a.nzp)[k], r2c_split(zk, zmk, a.w[k]), a.nt);
+template <int B>
+FG_HD void smooth_z_split_store(const SmoothZArgs& a, long row0, int tid, int nthreads, const cplx* img) {
+  const int M = a.plan.n, pitch = smooth_z_pitch(M), total = a.plan.lines * (M + 1);
+  const float inv = 1.0f / (float)(M + 1);
+  for (int i0 = tid; i0 < total; i0 += B * nthreads) {
+    cplx wk[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {   // the split roots first: loads in flight together
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), k = idx - l * (M + 1);
+      wk[i] = idx < total ? a.w[k] : cmake(0.0, 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), k = idx - l * (M + 1);
+      const long row = row0 + l;
+      if (idx >= total || row >= a.nrows) continue;
+      const cplx zk = img[l * pitch + (k == M ? 0 : k)], zmk = img[l * pitch + (k == 0 ? 0 : M - k)];
+      cstore_stream(&reinterpret_cast<cplx*>(a.data + row * a.nzp)[k], r2c_split(zk, zmk, wk[i]), a.nt);
+    }
   }
 }
 
 // c2r: the M + 1 coefficients of a row -> image
-FG_HD void smooth_z_load_spectrum(const SmoothZArgs& a, long row0, int lines, int tid, int nthreads, cplx* img) {
-  const int M = a.plan.n, pitch = smooth_z_pitch(M);
-  for (int idx = tid; idx < lines * (M + 1); idx += nthreads) {
-    const int l = idx / (M + 1), k = idx % (M + 1);
-    const long row = row0 + l;
-    cplx x = row < a.nrows ? cload_stream(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[k], a.nt) : cmake(0.0, 0.0);
-    if (k == 0 || k == M) x.im = 0.0;   // FFTW's c2r ignores the imaginary parts of the DC and Nyquist bins
-    img[l * pitch + k] = x;
+template <int B>
+FG_HD void smooth_z_load_spectrum(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+  const int M = a.plan.n, pitch = smooth_z_pitch(M), total = a.plan.lines * (M + 1);
+  const float inv = 1.0f / (float)(M + 1);
+  for (int i0 = tid; i0 < total; i0 += B * nthreads) {
+    cplx v[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), k = idx - l * (M + 1);
+      const long row = row0 + l;
+      v[i] = idx < total && row < a.nrows ? cload_stream(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[k], a.nt) : cmake(0.0, 0.0);
+      if (k == 0 || k == M) v[i].im = 0.0;   // FFTW's c2r ignores the imaginary parts of the DC and Nyquist bins
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), k = idx - l * (M + 1);
+      if (idx < total) img[l * pitch + k] = v[i];
+    }
   }
 }
 
-// c2r: Z'[k] = merge(X[k], X[M - k]), k < M, from one image into the other
-FG_HD void smooth_z_merge(const SmoothZArgs& a, int lines, int tid, int nthreads, const cplx* in, cplx* out) {
-  const int M = a.plan.n, pitch = smooth_z_pitch(M);
-  for (int idx = tid; idx < lines * M; idx += nthreads) {
-    const int l = idx / M, k = idx % M;
-    out[l * pitch + k] = c2r_merge(in[l * pitch + k], in[l * pitch + M - k], a.w[k]);
+// c2r: Z'[k] = merge(X[k], X[M - k]), k < M, in place: the merge pairs k and M - k, thread (l, k), k <= M / 2, owns both
+template <int B>
+FG_HD void smooth_z_merge(const SmoothZArgs& a, int tid, int nthreads, cplx* img) {
+  const int M = a.plan.n, pitch = smooth_z_pitch(M), half = M / 2 + 1, total = a.plan.lines * half;
+  const float inv = 1.0f / (float)half;
+  for (int i0 = tid; i0 < total; i0 += (B / 2) * nthreads) {
+    cplx w1[B / 2], w2[B / 2];
+#pragma unroll
+    for (int i = 0; i < B / 2; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), k = idx - l * half;
+      w1[i] = idx < total ? a.w[k] : cmake(0.0, 0.0);
+      w2[i] = idx < total ? a.w[M - k] : cmake(0.0, 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < B / 2; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), k = idx - l * half;
+      if (idx >= total) continue;
+      cplx* row = img + l * pitch;
+      const cplx xk = row[k], xm = row[M - k];
+      row[k] = c2r_merge(xk, xm, w1[i]);
+      if (k != 0 && M - k != k) row[M - k] = c2r_merge(xm, xk, w2[i]);
+    }
   }
 }
 
 // c2r: the M complex points of the inverse transform = the nz reals of the row -> memory
-FG_HD void smooth_z_store_packed(const SmoothZArgs& a, long row0, int lines, int tid, int nthreads, const cplx* img) {
+FG_HD void smooth_z_store_packed(const SmoothZArgs& a, long row0, int tid, int nthreads, const cplx* img) {
   const int M = a.plan.n, pitch = smooth_z_pitch(M);
-  for (int idx = tid; idx < lines * M; idx += nthreads) {
-    const int l = idx / M, m = idx % M;
+  const float inv = 1.0f / (float)M;
+  for (int idx = tid; idx < a.plan.lines * M; idx += nthreads) {
+    const int l = smooth_div(idx, inv), m = idx - l * M;
     const long row = row0 + l;
     if (row < a.nrows) cstore_stream(&reinterpret_cast<cplx*>(a.data + row * a.nzp)[m], img[l * pitch + m], a.nt);
   }

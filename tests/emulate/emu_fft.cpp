@@ -70,6 +70,35 @@ static void strided_dir(StridedArgs a, long nblocks, int dir) {
   else run_blocks<StridedKernel<N, C, +1>, StridedArgs>(nblocks, a);
 }
 
+// Stockham tile kernels (fg_fft_smooth.h): the phases of k_smooth_strided / k_smooth_z for every thread of every workgroup,
+// in the device's order (load | barrier | per pass: read + butterfly, barrier, write, barrier | store), with the plan the
+// library's planner makes.  Returns 1 when the length has no plan (a prime factor above 13).
+template <int DIR>
+static void emu_smooth_passes(cplx* img, const SmoothPlan& plan, const SmoothMap& L, const cplx* w, int wscale) {
+  std::vector<cplx> regs((size_t)plan.threads * kSmoothMaxRadix);
+  std::vector<char> active(plan.threads);
+  int Ns = 1;
+  for (int f = 0; f < plan.npass; ++f) {
+    const int R = plan.fac[f];
+    for (int half = 0; half < 2; ++half)
+      for (int tid = 0; tid < plan.threads; ++tid) {
+        cplx* v = &regs[(size_t)tid * kSmoothMaxRadix];
+        switch (R) {
+#define FG_R(r)                                                                                              \
+  case r:                                                                                                    \
+    if (half == 0) active[tid] = smooth_pass_read<r, DIR>(img, plan.n, Ns, L, w, wscale, tid, v);            \
+    else if (active[tid]) smooth_pass_write<r>(img, plan.n, Ns, L, tid, v);                                  \
+    break;
+          FG_R(2) FG_R(3) FG_R(4) FG_R(5) FG_R(6) FG_R(7) FG_R(8) FG_R(9) FG_R(10) FG_R(11) FG_R(12) FG_R(13) FG_R(14) FG_R(15)
+          FG_R(16) FG_R(18) FG_R(20) FG_R(21) FG_R(22) FG_R(24) FG_R(25) FG_R(26) FG_R(27) FG_R(28) FG_R(30) FG_R(32)
+#undef FG_R
+          default: std::abort();
+        }
+      }
+    Ns *= R;
+  }
+}
+
 extern "C" {
 
 // c2c along a strided axis of data[nouter][N][ncols] (ls = ncols, os = N*ncols), device tile geometry
@@ -287,13 +316,15 @@ int emu_plane(int ny, int nz, int dir, double* data, int nplanes) {
   return 1;
 }
 
-// Stockham tile kernels (fg_fft_smooth.h): the phases of k_smooth_strided / k_smooth_z for every thread of every workgroup,
-// in the device's order (load | barrier | one pass per radix, barriers between | store).  Returns 1 when the length has a
-// prime factor above 13.
-int emu_smooth_strided(int N, int dir, double* data, int ncols, int nouter, double scale, int C, int nthreads) {
+int emu_smooth_strided(int N, int dir, double* data, int ncols, int nouter, double scale, int* plan_out) {
   SmoothArgs a;
-  if (!smooth_plan(N, &a.plan)) return 1;
+  if (!smooth_plan_strided(N, &a.plan)) return 1;
+  if (plan_out) {
+    plan_out[0] = a.plan.lines, plan_out[1] = a.plan.threads, plan_out[2] = a.plan.npass;
+    for (int i = 0; i < a.plan.npass; ++i) plan_out[3 + i] = a.plan.fac[i];
+  }
   std::vector<cplx> w = make_unit_roots(N, N);
+  const int C = a.plan.lines, T = a.plan.threads;
   a.data = reinterpret_cast<cplx*>(data);
   a.ls = ncols;
   a.os = (long)N * ncols;
@@ -302,69 +333,55 @@ int emu_smooth_strided(int N, int dir, double* data, int ncols, int nouter, doub
   a.scale = scale;
   a.w = w.data();
   a.nt = 0;
-  std::vector<cplx> img(2 * (size_t)N * C);
+  std::vector<cplx> img((size_t)N * C);
+  const SmoothMap L = {C, 1, C, false};
   for (int b = 0; b < a.tiles_per_outer * nouter; ++b) {
     for (auto& x : img) x = cmake(NAN, NAN);
-    cplx *cur = img.data(), *nxt = cur + (size_t)N * C;
-    for (int tid = 0; tid < nthreads; ++tid) {
-      if (C == 8) smooth_strided_load<8>(a, b, tid, nthreads, cur);
-      else if (C == 4) smooth_strided_load<4>(a, b, tid, nthreads, cur);
-      else smooth_strided_load<2>(a, b, tid, nthreads, cur);
+    for (int tid = 0; tid < T; ++tid) {   // (the emulation takes the widest variant: more empty slots, the same elements)
+      if (C == 8) smooth_strided_load<8, 16>(a, b, tid, T, img.data());
+      else if (C == 4) smooth_strided_load<4, 16>(a, b, tid, T, img.data());
+      else smooth_strided_load<2, 16>(a, b, tid, T, img.data());
     }
-    const SmoothMap L = {C, 1, C, false};
-    int Ns = 1;
-    for (int f = 0; f < a.plan.nfac; ++f) {
-      for (int tid = 0; tid < nthreads; ++tid) {
-        if (dir < 0) smooth_pass_any<-1>(a.plan.fac[f], cur, nxt, N, Ns, L, a.w, 1, tid, nthreads);
-        else smooth_pass_any<+1>(a.plan.fac[f], cur, nxt, N, Ns, L, a.w, 1, tid, nthreads);
-      }
-      Ns *= a.plan.fac[f];
-      std::swap(cur, nxt);
-    }
-    for (int tid = 0; tid < nthreads; ++tid) {
-      if (C == 8) smooth_strided_store<8>(a, b, tid, nthreads, cur);
-      else if (C == 4) smooth_strided_store<4>(a, b, tid, nthreads, cur);
-      else smooth_strided_store<2>(a, b, tid, nthreads, cur);
+    if (dir < 0) emu_smooth_passes<-1>(img.data(), a.plan, L, a.w, 1);
+    else emu_smooth_passes<+1>(img.data(), a.plan, L, a.w, 1);
+    for (int tid = 0; tid < T; ++tid) {
+      if (C == 8) smooth_strided_store<8>(a, b, tid, T, img.data());
+      else if (C == 4) smooth_strided_store<4>(a, b, tid, T, img.data());
+      else smooth_strided_store<2>(a, b, tid, T, img.data());
     }
   }
   return 0;
 }
 
-int emu_smooth_z(int nz, int fwd, double* data, long nrows, int lines, int nthreads) {
+int emu_smooth_z(int nz, int fwd, double* data, long nrows, int* plan_out) {
   SmoothZArgs a;
   const int M = nz / 2;
-  if (nz % 2 || !smooth_plan(M, &a.plan)) return 1;
+  if (nz % 2 || !smooth_plan_z(M, &a.plan)) return 1;
+  if (plan_out) {
+    plan_out[0] = a.plan.lines, plan_out[1] = a.plan.threads, plan_out[2] = a.plan.npass;
+    for (int i = 0; i < a.plan.npass; ++i) plan_out[3 + i] = a.plan.fac[i];
+  }
   std::vector<cplx> w = make_unit_roots(nz, nz);
   a.data = data;
   a.nrows = nrows;
   a.nzp = 2 * (nz / 2 + 1);
   a.w = w.data();
   a.nt = 0;
-  const int pitch = smooth_z_pitch(M);
-  std::vector<cplx> img(2 * (size_t)lines * pitch);
+  const int pitch = smooth_z_pitch(M), lines = a.plan.lines, T = a.plan.threads;
+  std::vector<cplx> img((size_t)lines * pitch);
   const SmoothMap L = {1, pitch, lines, true};
   for (long b = 0; b * lines < nrows; ++b) {
     for (auto& x : img) x = cmake(NAN, NAN);
-    cplx *cur = img.data(), *nxt = cur + (size_t)lines * pitch;
     const long row0 = b * lines;
     if (fwd) {
-      for (int tid = 0; tid < nthreads; ++tid) smooth_z_load_packed(a, row0, lines, tid, nthreads, cur);
+      for (int tid = 0; tid < T; ++tid) smooth_z_load_packed<16>(a, row0, tid, T, img.data());
+      emu_smooth_passes<-1>(img.data(), a.plan, L, a.w, 2);
+      for (int tid = 0; tid < T; ++tid) smooth_z_split_store<16>(a, row0, tid, T, img.data());
     } else {
-      for (int tid = 0; tid < nthreads; ++tid) smooth_z_load_spectrum(a, row0, lines, tid, nthreads, nxt);
-      for (int tid = 0; tid < nthreads; ++tid) smooth_z_merge(a, lines, tid, nthreads, nxt, cur);
-    }
-    int Ns = 1;
-    for (int f = 0; f < a.plan.nfac; ++f) {
-      for (int tid = 0; tid < nthreads; ++tid) {
-        if (fwd) smooth_pass_any<-1>(a.plan.fac[f], cur, nxt, M, Ns, L, a.w, 2, tid, nthreads);
-        else smooth_pass_any<+1>(a.plan.fac[f], cur, nxt, M, Ns, L, a.w, 2, tid, nthreads);
-      }
-      Ns *= a.plan.fac[f];
-      std::swap(cur, nxt);
-    }
-    for (int tid = 0; tid < nthreads; ++tid) {
-      if (fwd) smooth_z_split_store(a, row0, lines, tid, nthreads, cur);
-      else smooth_z_store_packed(a, row0, lines, tid, nthreads, cur);
+      for (int tid = 0; tid < T; ++tid) smooth_z_load_spectrum<16>(a, row0, tid, T, img.data());
+      for (int tid = 0; tid < T; ++tid) smooth_z_merge<16>(a, tid, T, img.data());
+      emu_smooth_passes<+1>(img.data(), a.plan, L, a.w, 2);
+      for (int tid = 0; tid < T; ++tid) smooth_z_store_packed(a, row0, tid, T, img.data());
     }
   }
   return 0;

@@ -207,8 +207,12 @@ def test_plane_kernels(emu, ny, nz):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Stockham tile kernels for lengths with factors 2, 3, 5, 7, 11, 13 (fg_fft_smooth.h): the decimal grid sizes
-SMOOTH = [6, 10, 12, 15, 18, 20, 25, 30, 36, 49, 50, 60, 75, 77, 91, 100, 120, 121, 125, 150, 169, 200, 240, 250, 300, 360, 400,
-          500, 600, 640, 1000]
+SMOOTH = [6, 10, 12, 15, 18, 20, 25, 30, 36, 49, 50, 60, 75, 77, 91, 100, 120, 121, 125, 143, 150, 169, 200, 240, 250, 300, 360,
+          400, 480, 500, 600, 640, 700, 720, 900, 960, 1000, 1001, 1100, 1250]
+
+
+def _plan(buf):
+    return {"lines": int(buf[0]), "threads": int(buf[1]), "radices": [int(v) for v in buf[3:3 + buf[2]]]}
 
 
 @pytest.mark.parametrize("N", SMOOTH)
@@ -216,33 +220,52 @@ SMOOTH = [6, 10, 12, 15, 18, 20, 25, 30, 36, 49, 50, 60, 75, 77, 91, 100, 120, 1
 def test_smooth_strided_c2c(emu, N, d):
     rng = np.random.default_rng(N)
     ncols, nouter = 11, 2   # ragged last tile
-    C = 8 if N <= 600 else 4
     x = rng.standard_normal((nouter, N, ncols)) + 1j * rng.standard_normal((nouter, N, ncols))
     y = x.copy()
-    nthreads = 256 if N % 7 else 64   # (the phase code takes any team size)
-    assert emu.emu_smooth_strided(N, d, P(y.view(np.float64)), ncols, nouter, ctypes.c_double(0.5), C, nthreads) == 0
+    plan = np.zeros(8, dtype=np.int32)
+    assert emu.emu_smooth_strided(N, d, P(y.view(np.float64)), ncols, nouter, ctypes.c_double(0.5),
+                                  plan.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == 0
+    pl = _plan(plan)
+    # the planner's contract: the radices multiply to N, every pass has at most one butterfly per thread, the image fits the LDS
+    assert int(np.prod(pl["radices"])) == N and len(pl["radices"]) <= 4
+    assert all(N // r * pl["lines"] <= pl["threads"] and r <= (32 if pl["threads"] == 256 else 16) for r in pl["radices"])
+    assert N * pl["lines"] * 16 <= 156 * 1024
     ref = (np.fft.fft(x, axis=1) if d < 0 else np.fft.ifft(x, axis=1) * N) * 0.5
     assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-14
 
 
-@pytest.mark.parametrize("nz", [2 * n for n in SMOOTH if n <= 600])
+@pytest.mark.parametrize("nz", [2 * n for n in SMOOTH])
 def test_smooth_r2c_c2r(emu, nz):
     rng = np.random.default_rng(nz)
-    nrows, lines = 7, 3   # ragged last tile
+    nrows = 19   # ragged last tile
     nzc = nz // 2 + 1
     x = rng.standard_normal((nrows, nz))
     buf = np.full((nrows, 2 * nzc), np.nan)
     buf[:, :nz] = x
-    assert emu.emu_smooth_z(nz, 1, P(buf), ctypes.c_long(nrows), lines, 256) == 0
+    plan = np.zeros(8, dtype=np.int32)
+    assert emu.emu_smooth_z(nz, 1, P(buf), ctypes.c_long(nrows), plan.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == 0
+    pl = _plan(plan)
+    assert int(np.prod(pl["radices"])) == nz // 2 and all(nz // 2 // r * pl["lines"] <= pl["threads"] for r in pl["radices"])
     ref = np.fft.rfft(x, axis=1)
     assert np.abs(buf.view(np.complex128) - ref).max() / np.abs(ref).max() < 2e-14
     X = rng.standard_normal((nrows, nzc)) + 1j * rng.standard_normal((nrows, nzc))   # non-Hermitian: DC / Nyquist imaginary parts ignored
     buf = X.copy().view(np.float64).copy()
-    assert emu.emu_smooth_z(nz, 0, P(buf), ctypes.c_long(nrows), lines, 256) == 0
+    assert emu.emu_smooth_z(nz, 0, P(buf), ctypes.c_long(nrows), None) == 0
     ref = np.fft.irfft(X, n=nz, axis=1) * nz
     assert np.abs(buf[:, :nz] - ref).max() / np.abs(ref).max() < 2e-14
 
 
-def test_smooth_plan_rejects_large_primes(emu):
+def test_smooth_planner(emu):
+    """the decimal sizes in two passes of large radices (one butterfly per thread, 8-column tiles, 256 threads); 1000 in three
+    passes of 1024 threads; lengths with a prime factor above 13 have no plan"""
+    want = {100: [10, 10], 200: [20, 10], 300: [20, 15], 400: [20, 20], 500: [25, 20], 120: [12, 10], 240: [16, 15], 480: [24, 20],
+            600: [25, 24], 1000: [10, 10, 10], 144: [12, 12], 96: [12, 8]}
+    for N, radices in want.items():
+        x = np.zeros((1, N, 1), dtype=np.complex128)
+        plan = np.zeros(8, dtype=np.int32)
+        assert emu.emu_smooth_strided(N, -1, P(x.view(np.float64)), 1, 1, ctypes.c_double(1.0),
+                                      plan.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == 0
+        pl = _plan(plan)
+        assert pl["radices"] == radices and pl["lines"] == 8 and pl["threads"] == (1024 if N == 1000 else 256), (N, pl)
     x = np.zeros((1, 34, 1), dtype=np.complex128)
-    assert emu.emu_smooth_strided(34, -1, P(x.view(np.float64)), 1, 1, ctypes.c_double(1.0), 8, 64) == 1   # 34 = 2 * 17
+    assert emu.emu_smooth_strided(34, -1, P(x.view(np.float64)), 1, 1, ctypes.c_double(1.0), None) == 1   # 34 = 2 * 17
