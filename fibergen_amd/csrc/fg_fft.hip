@@ -245,6 +245,38 @@ __global__ __launch_bounds__(THREADS) void k_smooth_z(SmoothZArgs a, long comp_s
   else smooth_z_store_packed(a, row0, threadIdx.x, THREADS, img);
 }
 
+// x transform + Green operator + inverse x transform of the tile's NC components (NC images in LDS)
+template <int THREADS, int RMAX, int NC>
+__global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
+  extern __shared__ __align__(16) double lds[];
+  cplx* img = reinterpret_cast<cplx*>(lds);
+  constexpr int B = THREADS == 256 ? 16 : 8;
+  const int C = a.base.plan.lines;
+  const long comp = (long)a.base.plan.n * C;
+  const SmoothMap L = {C, 1, C, false};
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    SmoothArgs ac = a.base;
+    ac.data += (long)c * a.comp_stride;
+    if (C == 8) smooth_strided_load<8, B>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
+    else smooth_strided_load<4, B>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
+  }
+  __syncthreads();
+  for (int c = 0; c < NC; ++c) smooth_dev_passes<-1, RMAX>(img + c * comp, a.base.plan, L, a.base.w, 1);
+  if (C == 8) smooth_x_green<8, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else smooth_x_green<4, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  __syncthreads();
+  for (int c = 0; c < NC; ++c) smooth_dev_passes<+1, RMAX>(img + c * comp, a.base.plan, L, a.base.w, 1);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    SmoothArgs ac = a.base;
+    ac.data += (long)c * a.comp_stride;
+    ac.scale = 1.0;   // (the 1/N went in with the Green operator)
+    if (C == 8) smooth_strided_store<8>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
+    else smooth_strided_store<4>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
+  }
+}
+
 template <class K>
 void smooth_configure(K kernel) {
   FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmoothLdsMax));
@@ -275,6 +307,32 @@ void launch_smooth_strided(const SmoothArgs& a0, int nouter, int dir, int ncomp,
     case 3: hipLaunchKernelGGL((k_smooth_strided<+1, 256, 32>), grid, dim3(256), lds, s, a, cs); break;
     case 4: hipLaunchKernelGGL((k_smooth_strided<-1, 1024, 16>), grid, dim3(1024), lds, s, a, cs); break;
     default: hipLaunchKernelGGL((k_smooth_strided<+1, 1024, 16>), grid, dim3(1024), lds, s, a, cs); break;
+  }
+  FG_HIP_CHECK(hipGetLastError());
+}
+
+void launch_smooth_xfused(const SmoothXArgs& a0, hipStream_t s) {
+  SmoothXArgs a = a0;
+  const int C = a.base.plan.lines;
+  a.base.tiles_per_outer = (a.base.ncols + C - 1) / C;
+  const size_t lds = (size_t)a.ncomp * a.base.plan.n * C * sizeof(cplx);
+  static PerDeviceOnce configured;
+  if (auto once = configured.first_use()) {
+    smooth_configure(&k_smooth_xfused<256, 16, 3>);
+    smooth_configure(&k_smooth_xfused<256, 32, 3>);
+    smooth_configure(&k_smooth_xfused<1024, 16, 3>);
+    smooth_configure(&k_smooth_xfused<256, 16, 1>);
+    smooth_configure(&k_smooth_xfused<256, 32, 1>);
+    smooth_configure(&k_smooth_xfused<1024, 16, 1>);
+  }
+  const dim3 grid((unsigned)a.base.tiles_per_outer);
+  switch (smooth_class(a.base.plan) * 2 + (a.ncomp == 3 ? 0 : 1)) {
+    case 0: hipLaunchKernelGGL((k_smooth_xfused<256, 16, 3>), grid, dim3(256), lds, s, a); break;
+    case 1: hipLaunchKernelGGL((k_smooth_xfused<256, 16, 1>), grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((k_smooth_xfused<256, 32, 3>), grid, dim3(256), lds, s, a); break;
+    case 3: hipLaunchKernelGGL((k_smooth_xfused<256, 32, 1>), grid, dim3(256), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((k_smooth_xfused<1024, 16, 3>), grid, dim3(1024), lds, s, a); break;
+    default: hipLaunchKernelGGL((k_smooth_xfused<1024, 16, 1>), grid, dim3(1024), lds, s, a); break;
   }
   FG_HIP_CHECK(hipGetLastError());
 }
@@ -1153,7 +1211,7 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
       // 400, 500 ...: the Stockham tile kernels of fg_fft_smooth.h.  (Where a p * 2^k kernel exists it stays: measured in one job
       // with the tile kernels forced on, 96^3 9 160 against 5 510 it/s, 192^3 2 030 / 1 270, 384^3 240 / 174, 448^3 123 / 91.)
       SmoothPlan sp;
-      const bool one_kernel_mixed = odd_[a] == 3 || odd_[a] == 5 || odd_[a] == 7 || odd_[a] == 9;
+      const bool one_kernel_mixed = (odd_[a] == 3 || odd_[a] == 5 || odd_[a] == 7 || odd_[a] == 9) && m <= 1024;   // (their tile limit)
       if (m > 1 && !one_kernel_mixed && (a == 2 ? smooth_plan_z(m, &sp) : smooth_plan_strided(m, &sp))) smooth_[a] = sp;
       wgen_[a] = upload(make_unit_roots(len[a], len[a]));
       need_scratch = true;
@@ -1343,6 +1401,10 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
 bool Fft3::can_fuse(int axis, int ncomp) const {
   const int n = axis == 0 ? g_.nx : g_.ny;
   if (fast_[axis]) return n <= 1024;
+  if (axis == 0 && smooth_[0].n && (ncomp == 1 || ncomp == 3)) {   // the tile kernels' fused x pass: ncomp images in LDS
+    SmoothPlan sp;
+    return smooth_plan_xfused(n, ncomp, &sp);
+  }
   // p * 2^k with p = 3, 5: the three-component form only
   if (ncomp != 3 || (odd_[axis] != 3 && odd_[axis] != 5)) return false;
   XFusedArgs a = {};
@@ -1443,6 +1505,29 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
     a.ncols = g_.ny * g_.nzc;   // (tiles = ncols / 8 = (nzc / 8) * ny)
   }
   const int nouter = axis == 0 ? 1 : g_.nx;
+  if (!fast_[axis] && axis == 0 && smooth_[0].n) {
+    if (xjump != 0 || xlayout) throw std::runtime_error("fft: the tile kernels' fused x pass takes the plain layout");
+    SmoothXArgs x;
+    if (!smooth_plan_xfused(n, ncomp, &x.base.plan)) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
+    x.base.data = reinterpret_cast<cplx*>(data);
+    x.base.ls = (long)g_.ny * g_.nzc;
+    x.base.os = 0;
+    x.base.ncols = g_.ny * g_.nzc;
+    x.base.tiles_per_outer = 0;
+    x.base.scale = scale;
+    x.base.w = wgen_[0];
+    x.base.nt = stream_stores_ ? 3 : 0;
+    x.comp_stride = comp_stride / 2;
+    x.ncomp = ncomp;
+    x.nzc = g_.nzc;
+    x.nzf = g_.nzf;
+    x.jj0 = jj0;
+    x.c10 = gp.c10;
+    x.c20 = gp.c20;
+    for (int k = 0; k < 3; ++k) x.kpm[k] = gp.kpm[k], x.kp[k] = gp.kp[k];
+    launch_smooth_xfused(x, stream_);
+    return;
+  }
   if (!fast_[axis]) {
     a.nt = stream_stores_ ? 3 : 0;
     const bool ok = odd_[axis] == 3 ? xfused_mixed_p<3>(n / 3, a, nouter, wgen_[axis], stream_, false)

@@ -15,6 +15,7 @@
 
 #include "fg_fft_core.h"
 #include "fg_fft_roots.h"
+#include "fg_stage_math.h"
 
 namespace fg {
 namespace fft {
@@ -236,6 +237,17 @@ inline bool smooth_plan_z(int M, SmoothPlan* p) {
   return false;
 }
 
+// fused x pass (x transform, Green operator, inverse x transform on `ncomp` components of a tile): ncomp images in LDS
+inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p) {
+  *p = SmoothPlan();
+  if (n < 2) return false;
+  for (int cols : {8, 4}) {
+    if ((size_t)ncomp * n * cols * sizeof(cplx) > kSmoothLdsMax) continue;
+    if (smooth_try(n, cols, 256, 16, p) || smooth_try(n, cols, 256, kSmoothMaxRadix, p) || smooth_try(n, cols, 1024, 16, p)) return true;
+  }
+  return false;
+}
+
 struct SmoothArgs {
   cplx* data;          // component base
   long ls, os;         // line stride / outer stride (complex elements)
@@ -244,6 +256,17 @@ struct SmoothArgs {
   const cplx* w;       // e^{-2 pi i k / n}, k < n
   int nt;
   SmoothPlan plan;
+};
+
+// fused x pass: columns are (ky, kz) pairs, col = jj * nzc + kk of the [x][ny][nzc] spectrum (jj0: first ky of a y-slab)
+struct SmoothXArgs {
+  SmoothArgs base;       // data = component 0
+  long comp_stride;      // complex elements
+  int ncomp;             // 3: elastic Green operator, 1: scalar c10 / |k|^2
+  int nzc, nzf, jj0;
+  double c10, c20;
+  const double* kpm[3];
+  const cplx* kp[3];
 };
 
 struct SmoothZArgs {
@@ -291,6 +314,33 @@ FG_HD void smooth_strided_store(const SmoothArgs& a, int block, int tid, int nth
   for (int idx = tid; idx < a.plan.n * C; idx += nthreads) {
     const int p = idx / C, t = idx % C;
     if (col0 + t < a.ncols) cstore_stream(&a.data[base + (long)p * a.ls + t], cscale(a.scale, img[idx]), a.nt);
+  }
+}
+
+// fused x pass: G0OperatorFourierStaggeredGeneral F:19834-19927 (scalar modes: G0OperatorFourierStaggeredHeat F:19758-19823)
+// on the transformed images [kx][C] of the tile's components, with the 1/N of fftVector (F:18501-18506) folded in
+template <int C, int NC>
+FG_HD void smooth_x_green(const SmoothXArgs& a, int block, int tid, int nthreads, cplx* img) {
+  const int n = a.base.plan.n, col0 = (block % a.base.tiles_per_outer) * C;
+  const long comp = (long)n * C;
+  for (int idx = tid; idx < n * C; idx += nthreads) {
+    const int kx = idx / C, t = idx % C, col = col0 + t;
+    if (col >= a.base.ncols) continue;
+    const int jl = smooth_div(col, 1.0f / (float)a.nzc), kk = col - jl * a.nzc, jj = a.jj0 + jl;
+    if (kk >= a.nzf) continue;   // row padding
+    const bool zero = kx == 0 && jj == 0 && kk == 0;   // zero frequency  F:19924-19926
+    const double kpm0 = a.kpm[0][kx], kpm1 = a.kpm[1][jj], kpm2 = a.kpm[2][kk];
+    if (NC == 3) {
+      const cplx t0 = cscale(a.base.scale, img[idx]), t1 = cscale(a.base.scale, img[comp + idx]), t2 = cscale(a.base.scale, img[2 * comp + idx]);
+      cplx e0 = cmake(0.0, 0.0), e1 = e0, e2 = e0;
+      if (!zero) g0_point_rcp(t0, t1, t2, kpm0, kpm1, kpm2, a.kp[0][kx], a.kp[1][jj], a.kp[2][kk], a.c10, a.c20, &e0, &e1, &e2);
+      img[idx] = e0;
+      img[comp + idx] = e1;
+      img[2 * comp + idx] = e2;
+    } else {
+      const double norm_kp2 = kpm0 * kpm0 + kpm1 * kpm1 + kpm2 * kpm2;
+      img[idx] = zero ? cmake(0.0, 0.0) : cscale(a.base.scale * a.c10 / norm_kp2, img[idx]);
+    }
   }
 }
 

@@ -87,6 +87,13 @@ def test_bench_workload_256_three_passes(mixing):
     _passes_against_cref(256, mixing, 3)
 
 
+@pytest.mark.parametrize("n,mixing", [(200, "voigt"), (200, "laminate"), (300, "voigt")])
+def test_bench_workload_decimal_grids_three_passes(n, mixing):
+    """The decimal grid sizes (200 = 20 x 10, 300 = 20 x 15; nz / 2 = 100, 150): every transform pass runs the Stockham tile
+    kernels of fg_fft_smooth.h, the x pass unfused; the checker transforms with pocketfft.  Same bars as at 256^3."""
+    _passes_against_cref(n, mixing, 3)
+
+
 def test_bench_workload_512_laminate_two_passes():
     psutil = pytest.importorskip("psutil")
     if psutil.virtual_memory().available < 96 * 2 ** 30:

@@ -44,6 +44,8 @@ EXACT = [  # strain-state pipeline: laminate mixing, small / odd / mixed-radix g
     (2, (12, 10, 6), "laminate"),    # generic (non power-of-two) FFT path in every direction, remapped all-to-all layout
     (2, (8, 6, 5), "voigt"),         # odd nz
     (2, (24, 48, 48), "voigt"),      # p * 2^k lengths
+    (2, (20, 30, 36), "voigt"),      # 4*5, 2*3*5, nz/2 = 2*3*3: the Stockham tile kernels (fg_fft_smooth.h) on the slabs
+    (2, (20, 20, 200), "laminate"),  # decimal sizes with rows long enough for the tiled sweep
 ]
 
 
