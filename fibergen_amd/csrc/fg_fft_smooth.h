@@ -237,11 +237,13 @@ inline bool smooth_plan_z(int M, SmoothPlan* p) {
   return false;
 }
 
-// fused x pass (x transform, Green operator, inverse x transform on `ncomp` components of a tile): ncomp images in LDS
+// fused x pass (x transform, Green operator, inverse x transform on `ncomp` components of a tile): ncomp images in LDS.
+// 8-column tiles only: measured against the three separate kernels, 100^3 +9 %, 120^3 +13 %, 300^3 +11 %, 400^3 +14 %, but with
+// the 4-column tiles three components of 480 / 500 points need, 480^3 -1.4 %, 500^3 -2.3 % (half-line segments)
 inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p) {
   *p = SmoothPlan();
   if (n < 2) return false;
-  for (int cols : {8, 4}) {
+  for (int cols : {8}) {
     if ((size_t)ncomp * n * cols * sizeof(cplx) > kSmoothLdsMax) continue;
     if (smooth_try(n, cols, 256, 16, p) || smooth_try(n, cols, 256, kSmoothMaxRadix, p) || smooth_try(n, cols, 1024, 16, p)) return true;
   }
