@@ -90,7 +90,7 @@ int HostStager::host_threads() {
   cpu_set_t set;
   int n = 1;
   if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
-  return std::max(1, std::min(8, n - 1));
+  return std::max(1, std::min(8, n - 1));   // (12 threads measured equal: 16.6-19.2 ms per 805 MB either way)
 }
 
 HostStager& HostStager::of_device(int device) {
