@@ -86,7 +86,8 @@ class Fft3 {
   hipStream_t stream_;
   bool fast_[3];
   int odd_[3];       // odd p <= 25: the axis length (z: nz/2) is that factor times a fast power of two; 0 otherwise
-  fft::SmoothPlan smooth_[3];   // n != 0: the axis (z: nz/2) runs the Stockham tile kernels of fg_fft_smooth.h
+  fft::SmoothPlan smooth_[3];   // n != 0: the axis (z: nz/2, odd nz: nz) runs the Stockham tile kernels of fg_fft_smooth.h
+  bool zodd_ = false;           // odd nz with a plan: the rows are transformed as nz complex points
   int stream_stores_ = 0;  // FFT passes use cache-bypassing stores (fields larger than the Infinity Cache)
   cplx* tw_[3];      // per-axis pass twiddles (fast path) ; z: for M = nz/2
   cplx* half_root_[2];  // e^{-i pi j/n}, j < n/8, of x and y (fused Green-operator pass)

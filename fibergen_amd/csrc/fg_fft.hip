@@ -232,6 +232,15 @@ __global__ __launch_bounds__(THREADS) void k_smooth_z(SmoothZArgs a, long comp_s
   const long row0 = (long)blockIdx.x * a.plan.lines;
   const SmoothMap L = {1, smooth_z_pitch(a.plan.n), a.plan.lines, true};
   constexpr int B = THREADS == 256 ? 16 : 8;
+  if (a.odd) {   // odd nz: the row as nz complex points
+    if (FWD) smooth_zodd_load_real<B>(a, row0, threadIdx.x, THREADS, img);
+    else smooth_zodd_load_half<B>(a, row0, threadIdx.x, THREADS, img);
+    __syncthreads();
+    smooth_dev_passes<FWD ? -1 : +1, RMAX>(img, a.plan, L, a.w, 1);
+    if (FWD) smooth_zodd_store_half(a, row0, threadIdx.x, THREADS, img);
+    else smooth_zodd_store_real(a, row0, threadIdx.x, THREADS, img);
+    return;
+  }
   if (FWD) {
     smooth_z_load_packed<B>(a, row0, threadIdx.x, THREADS, img);
   } else {
@@ -1205,6 +1214,10 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
     } else {
       // p * 2^k: power-of-two kernels on the interleaved sub-lines + a combine sweep; anything else: O(n^2) DFT
       const int m = a == 2 ? (len[a] % 2 == 0 ? len[a] / 2 : 0) : len[a];
+      if (a == 2 && len[a] % 2 == 1 && len[a] > 1) {   // odd nz: no packed-real trick, the rows as nz complex points
+        SmoothPlan so;
+        if (smooth_plan_z(len[a], &so)) smooth_[2] = so, zodd_ = true;
+      }
       odd_[a] = m ? mixed_factor(m) : 0;
       if (odd_[a]) tw_[a] = upload(make_pass_twiddles(m / odd_[a]));
       // lengths with small prime factors that the one-kernel p * 2^k passes (p = 3, 5, 7, 9) do not cover -- 100, 120, 200, 300,
@@ -1626,7 +1639,7 @@ void Fft3::r2c_z(double* data, int ncomp, long comp_stride, const PlaneWindow* w
     return;
   }
   if (smooth_[2].n) {
-    SmoothZArgs a = {data, nrows, g_.nzp, wgen_[2], stream_stores_ ? 3 : 0, smooth_[2]};
+    SmoothZArgs a = {data, nrows, g_.nzp, wgen_[2], stream_stores_ ? 3 : 0, smooth_[2], zodd_ ? 1 : 0};
     launch_smooth_z(a, true, ncomp, comp_stride, stream_);
     return;
   }
@@ -1720,7 +1733,7 @@ void Fft3::c2r_z(double* data, int ncomp, long comp_stride, const PlaneWindow* w
     return;
   }
   if (smooth_[2].n) {
-    SmoothZArgs a = {data, nrows, g_.nzp, wgen_[2], stream_stores_ ? 3 : 0, smooth_[2]};
+    SmoothZArgs a = {data, nrows, g_.nzp, wgen_[2], stream_stores_ ? 3 : 0, smooth_[2], zodd_ ? 1 : 0};
     launch_smooth_z(a, false, ncomp, comp_stride, stream_);
     return;
   }

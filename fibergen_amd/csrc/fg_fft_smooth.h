@@ -277,7 +277,8 @@ struct SmoothZArgs {
   int nzp;
   const cplx* w;       // e^{-2 pi i k / nz}, k < nz  (its even entries are the roots of nz / 2)
   int nt;
-  SmoothPlan plan;     // of M = nz / 2
+  SmoothPlan plan;     // of M = nz / 2 (odd = 0) or of nz (odd = 1)
+  int odd = 0;         // 1: nz is odd -- no packed-real trick: the row as nz complex points with zero imaginary parts
 };
 
 // ---- tile phases (between two workgroup barriers each; thread `tid` of `nthreads`)
@@ -454,6 +455,78 @@ FG_HD void smooth_z_store_packed(const SmoothZArgs& a, long row0, int tid, int n
     const int l = smooth_div(idx, inv), m = idx - l * M;
     const long row = row0 + l;
     if (row < a.nrows) cstore_stream(&reinterpret_cast<cplx*>(a.data + row * a.nzp)[m], img[l * pitch + m], a.nt);
+  }
+}
+
+// ---- odd nz: the real row transformed as nz complex points (twice the arithmetic of the packed form, instead of the O(nz^2)
+// sums such rows took before), image [l][pitch], pitch >= nz + 1
+template <int B>
+FG_HD void smooth_zodd_load_real(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+  const int nz = a.plan.n, pitch = smooth_z_pitch(nz), total = a.plan.lines * nz;
+  const float inv = 1.0f / (float)nz;
+  for (int i0 = tid; i0 < total; i0 += B * nthreads) {
+    double v[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), m = idx - l * nz;
+      const long row = row0 + l;
+      v[i] = idx < total && row < a.nrows ? a.data[row * a.nzp + m] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), m = idx - l * nz;
+      if (idx < total) img[l * pitch + m] = cmake(v[i], 0.0);
+    }
+  }
+}
+
+// r2c: the coefficients k = 0 .. nz / 2 -> memory
+FG_HD void smooth_zodd_store_half(const SmoothZArgs& a, long row0, int tid, int nthreads, const cplx* img) {
+  const int nz = a.plan.n, pitch = smooth_z_pitch(nz), nzf = nz / 2 + 1;
+  const float inv = 1.0f / (float)nzf;
+  for (int idx = tid; idx < a.plan.lines * nzf; idx += nthreads) {
+    const int l = smooth_div(idx, inv), k = idx - l * nzf;
+    const long row = row0 + l;
+    if (row < a.nrows) cstore_stream(&reinterpret_cast<cplx*>(a.data + row * a.nzp)[k], img[l * pitch + k], a.nt);
+  }
+}
+
+// c2r: the coefficients k = 0 .. nz / 2 and their mirror images conj X[k] at nz - k -> image
+template <int B>
+FG_HD void smooth_zodd_load_half(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+  const int nz = a.plan.n, pitch = smooth_z_pitch(nz), nzf = nz / 2 + 1, total = a.plan.lines * nzf;
+  const float inv = 1.0f / (float)nzf;
+  for (int i0 = tid; i0 < total; i0 += B * nthreads) {
+    cplx v[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), k = idx - l * nzf;
+      const long row = row0 + l;
+      v[i] = idx < total && row < a.nrows ? cload_stream(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[k], a.nt) : cmake(0.0, 0.0);
+      if (k == 0) v[i].im = 0.0;   // FFTW's c2r ignores the imaginary part of the DC bin
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int l = smooth_div(idx, inv), k = idx - l * nzf;
+      if (idx >= total) continue;
+      img[l * pitch + k] = v[i];
+      if (k > 0) img[l * pitch + nz - k] = cconj(v[i]);
+    }
+  }
+}
+
+// c2r: the real parts of the inverse transform -> memory
+FG_HD void smooth_zodd_store_real(const SmoothZArgs& a, long row0, int tid, int nthreads, const cplx* img) {
+  const int nz = a.plan.n, pitch = smooth_z_pitch(nz);
+  const float inv = 1.0f / (float)nz;
+  for (int idx = tid; idx < a.plan.lines * nz; idx += nthreads) {
+    const int l = smooth_div(idx, inv), m = idx - l * nz;
+    const long row = row0 + l;
+    if (row < a.nrows) a.data[row * a.nzp + m] = img[l * pitch + m].re;
   }
 }
 

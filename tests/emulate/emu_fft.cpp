@@ -355,8 +355,39 @@ int emu_smooth_strided(int N, int dir, double* data, int ncols, int nouter, doub
 
 int emu_smooth_z(int nz, int fwd, double* data, long nrows, int* plan_out) {
   SmoothZArgs a;
+  if (nz % 2) {   // odd nz: the rows as nz complex points
+    if (!smooth_plan_z(nz, &a.plan)) return 1;
+    a.odd = 1;
+    if (plan_out) {
+      plan_out[0] = a.plan.lines, plan_out[1] = a.plan.threads, plan_out[2] = a.plan.npass;
+      for (int i = 0; i < a.plan.npass; ++i) plan_out[3 + i] = a.plan.fac[i];
+    }
+    std::vector<cplx> w = make_unit_roots(nz, nz);
+    a.data = data;
+    a.nrows = nrows;
+    a.nzp = 2 * (nz / 2 + 1);
+    a.w = w.data();
+    a.nt = 0;
+    const int pitch = smooth_z_pitch(nz), lines = a.plan.lines, T = a.plan.threads;
+    std::vector<cplx> img((size_t)lines * pitch);
+    const SmoothMap L = {1, pitch, lines, true};
+    for (long b = 0; b * lines < nrows; ++b) {
+      for (auto& x : img) x = cmake(NAN, NAN);
+      const long row0 = b * lines;
+      if (fwd) {
+        for (int tid = 0; tid < T; ++tid) smooth_zodd_load_real<16>(a, row0, tid, T, img.data());
+        emu_smooth_passes<-1>(img.data(), a.plan, L, a.w, 1);
+        for (int tid = 0; tid < T; ++tid) smooth_zodd_store_half(a, row0, tid, T, img.data());
+      } else {
+        for (int tid = 0; tid < T; ++tid) smooth_zodd_load_half<16>(a, row0, tid, T, img.data());
+        emu_smooth_passes<+1>(img.data(), a.plan, L, a.w, 1);
+        for (int tid = 0; tid < T; ++tid) smooth_zodd_store_real(a, row0, tid, T, img.data());
+      }
+    }
+    return 0;
+  }
   const int M = nz / 2;
-  if (nz % 2 || !smooth_plan_z(M, &a.plan)) return 1;
+  if (!smooth_plan_z(M, &a.plan)) return 1;
   if (plan_out) {
     plan_out[0] = a.plan.lines, plan_out[1] = a.plan.threads, plan_out[2] = a.plan.npass;
     for (int i = 0; i < a.plan.npass; ++i) plan_out[3 + i] = a.plan.fac[i];

@@ -255,6 +255,25 @@ def test_smooth_r2c_c2r(emu, nz):
     assert np.abs(buf[:, :nz] - ref).max() / np.abs(ref).max() < 2e-14
 
 
+@pytest.mark.parametrize("nz", [3, 5, 9, 15, 25, 27, 35, 45, 75, 77, 99, 105, 125, 143, 175, 225, 243, 375, 625])
+def test_smooth_odd_rows(emu, nz):
+    """odd nz: no packed-real trick -- the rows run through the same passes as nz complex points (before: O(nz^2) sums)"""
+    rng = np.random.default_rng(nz)
+    nrows = 19
+    nzc = nz // 2 + 1
+    x = rng.standard_normal((nrows, nz))
+    buf = np.full((nrows, 2 * nzc), np.nan)
+    buf[:, :nz] = x
+    assert emu.emu_smooth_z(nz, 1, P(buf), ctypes.c_long(nrows), None) == 0
+    ref = np.fft.rfft(x, axis=1)
+    assert np.abs(buf.view(np.complex128) - ref).max() / np.abs(ref).max() < 2e-14
+    X = rng.standard_normal((nrows, nzc)) + 1j * rng.standard_normal((nrows, nzc))   # the imaginary part of the DC bin is ignored
+    buf = X.copy().view(np.float64).copy()
+    assert emu.emu_smooth_z(nz, 0, P(buf), ctypes.c_long(nrows), None) == 0
+    ref = np.fft.irfft(X, n=nz, axis=1) * nz
+    assert np.abs(buf[:, :nz] - ref).max() / np.abs(ref).max() < 2e-14
+
+
 def test_smooth_planner(emu):
     """the decimal sizes in two passes of large radices (one butterfly per thread, 8-column tiles, 256 threads); 1000 in three
     passes of 1024 threads; lengths with a prime factor above 13 have no plan"""

@@ -1,0 +1,3 @@
+mkdir -p gpurun_out/r06
+timeout 1500 python -m pytest tests/test_gpu_parity.py -k "fft_forward or stage or full_run or basic or green" -x -q > gpurun_out/r06/t11.log 2>&1; tail -5 gpurun_out/r06/t11.log
+for n in 75 125 225; do timeout 300 python tools/ab_grid.py --grid $n,$n,$n --steps 5 2>&1 | cut -c1-330; done
