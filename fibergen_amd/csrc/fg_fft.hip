@@ -180,23 +180,28 @@ __global__ void k_scale(double* x, long n, double s) {
 
 // ---------------------------------------------------------------- lengths with factors 2, 3, 5, 7, 11, 13 (fg_fft_smooth.h)
 // one pass of the tile in LDS: read + butterfly, barrier, write, barrier
-template <int R, int DIR>
+template <int R, int DIR, bool MULTI>
 __device__ __forceinline__ void smooth_dev_pass(cplx* img, int N, int Ns, const SmoothMap& L, const cplx* w, int wscale) {
-  cplx v[R];
-  const bool active = smooth_pass_read<R, DIR>(img, N, Ns, L, w, wscale, threadIdx.x, v);
+  constexpr int Q = MULTI ? smooth_rounds(R) : 1;   // butterflies a thread may own (small radices: several)
+  cplx v[Q][R];
+  bool active[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) active[q] = smooth_pass_read<R, DIR>(img, N, Ns, L, w, wscale, threadIdx.x + q * blockDim.x, v[q]);
   __syncthreads();
-  if (active) smooth_pass_write<R>(img, N, Ns, L, threadIdx.x, v);
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    if (active[q]) smooth_pass_write<R>(img, N, Ns, L, threadIdx.x + q * blockDim.x, v[q]);
   __syncthreads();
 }
 
 // RMAX: the largest radix the kernel is built for (32 with 256 threads, 16 with 1024: the butterfly lives in registers)
-template <int DIR, int RMAX>
+template <int DIR, int RMAX, bool MULTI = true>
 __device__ __forceinline__ void smooth_dev_passes(cplx* img, const SmoothPlan& plan, const SmoothMap& L, const cplx* w, int wscale) {
   int Ns = 1;
   for (int f = 0; f < plan.npass; ++f) {
     const int R = plan.fac[f];
     switch (R) {
-#define FG_R(r) case r: if constexpr (r <= RMAX) smooth_dev_pass<r, DIR>(img, plan.n, Ns, L, w, wscale); break;
+#define FG_R(r) case r: if constexpr (r <= RMAX) smooth_dev_pass<r, DIR, MULTI>(img, plan.n, Ns, L, w, wscale); break;
       FG_R(2) FG_R(3) FG_R(4) FG_R(5) FG_R(6) FG_R(7) FG_R(8) FG_R(9) FG_R(10) FG_R(11) FG_R(12) FG_R(13) FG_R(14) FG_R(15)
       FG_R(16) FG_R(18) FG_R(20) FG_R(21) FG_R(22) FG_R(24) FG_R(25) FG_R(26) FG_R(27) FG_R(28) FG_R(30) FG_R(32)
 #undef FG_R
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
   const int C = a.base.plan.lines;
   const long comp = (long)a.base.plan.n * C;
   const SmoothMap L = {C, 1, C, false};
-#pragma unroll
+#pragma nounroll   // (one component's batch of loads in registers at a time)
   for (int c = 0; c < NC; ++c) {
     SmoothArgs ac = a.base;
     ac.data += (long)c * a.comp_stride;
@@ -271,12 +276,14 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
     else smooth_strided_load<4, B>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
   }
   __syncthreads();
-  for (int c = 0; c < NC; ++c) smooth_dev_passes<-1, RMAX>(img + c * comp, a.base.plan, L, a.base.w, 1);
+#pragma nounroll
+  for (int c = 0; c < NC; ++c) smooth_dev_passes<-1, RMAX, false>(img + c * comp, a.base.plan, L, a.base.w, 1);
   if (C == 8) smooth_x_green<8, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else smooth_x_green<4, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
-  for (int c = 0; c < NC; ++c) smooth_dev_passes<+1, RMAX>(img + c * comp, a.base.plan, L, a.base.w, 1);
-#pragma unroll
+#pragma nounroll
+  for (int c = 0; c < NC; ++c) smooth_dev_passes<+1, RMAX, false>(img + c * comp, a.base.plan, L, a.base.w, 1);
+#pragma nounroll
   for (int c = 0; c < NC; ++c) {
     SmoothArgs ac = a.base;
     ac.data += (long)c * a.comp_stride;

@@ -161,11 +161,19 @@ FG_HD void smooth_pass_write(cplx* img, int N, int Ns, const SmoothMap& L, int t
   for (int r = 0; r < R; ++r) dst[(long)r * Ns * L.sp] = v[r];
 }
 
+// A thread may own several butterflies of a SMALL radix in one pass (their values stay in registers across the barrier like
+// one large butterfly's): up to smooth_rounds(R) of them, R * rounds <= 20 values.  That lets lengths such as 200 = 8 x 5 x 5
+// or 500 = 10 x 10 x 5 run with radices <= 16 -- half the registers and twice the resident workgroups of the R <= 32 kernels.
+constexpr int smooth_rounds(int r) { return r > 10 ? 1 : (20 / r > 8 ? 8 : 20 / r); }
+
 // ---- planner: lines per tile, threads per workgroup and the radices of the passes
 // radices of n in [lo, hi], at most kSmoothMaxPasses of them: fewest passes first, then the smallest largest radix; returned
 // largest first (the first pass has no twiddles)
 struct SmoothSearch {
   int lo, hi, best[kSmoothMaxPasses], cur[kSmoothMaxPasses], nbest = 0;
+  long n = 0, lines = 0, threads = 0;   // radix r fits a pass when its n / r butterflies per line need <= smooth_rounds(r) rounds
+  bool multi = true;                    // false: one butterfly per thread and pass only (the fused x pass)
+  bool fits(int r) const { return threads == 0 || (n / r) * lines <= threads * (long)(multi ? smooth_rounds(r) : 1); }
   void go(int rest, int depth, int maxr) {
     if (rest == 1 && depth > 0) {
       bool better = !nbest || depth < nbest;
@@ -178,17 +186,19 @@ struct SmoothSearch {
     }
     if (depth == kSmoothMaxPasses || (nbest && depth + 1 > nbest)) return;
     for (int r = maxr < hi ? maxr : hi; r >= lo && r >= 2; --r) {   // non-increasing: every multiset once
-      if (rest % r || !smooth_radix_ok(r)) continue;
+      if (rest % r || !smooth_radix_ok(r) || !fits(r)) continue;
       cur[depth] = r;
       go(rest / r, depth + 1, r);
     }
   }
 };
 
-inline bool smooth_factor(int n, int lo, int hi, int* fac, int* npass) {
+inline bool smooth_factor(int n, int lines, int threads, int hi, int* fac, int* npass, bool multi = true) {
   SmoothSearch s;
-  s.lo = lo < 2 ? 2 : lo;
+  s.lo = 2;
   s.hi = hi;
+  s.n = n, s.lines = lines, s.threads = threads;
+  s.multi = multi;
   s.go(n, 0, hi);
   if (!s.nbest) return false;
   for (int i = 0; i < s.nbest; ++i) fac[i] = s.best[i];
@@ -198,10 +208,9 @@ inline bool smooth_factor(int n, int lo, int hi, int* fac, int* npass) {
 
 FG_HD int smooth_z_pitch(int M) { return M + 1 + ((M + 1) % 2 == 0 ? 1 : 0); }   // odd: rows start on different banks
 
-inline bool smooth_try(int n, int lines, int threads, int hi, SmoothPlan* p) {
-  const int lo = (n * lines + threads - 1) / threads;
+inline bool smooth_try(int n, int lines, int threads, int hi, SmoothPlan* p, bool multi = true) {
   int fac[kSmoothMaxPasses], np = 0;
-  if (!smooth_factor(n, lo, hi, fac, &np)) return false;
+  if (!smooth_factor(n, lines, threads, hi, fac, &np, multi)) return false;
   p->n = n;
   p->npass = np;
   for (int i = 0; i < np; ++i) p->fac[i] = fac[i];
@@ -245,7 +254,15 @@ inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p) {
   if (n < 2) return false;
   for (int cols : {8}) {
     if ((size_t)ncomp * n * cols * sizeof(cplx) > kSmoothLdsMax) continue;
-    if (smooth_try(n, cols, 256, 16, p) || smooth_try(n, cols, 256, kSmoothMaxRadix, p) || smooth_try(n, cols, 1024, 16, p)) return true;
+    // this kernel holds the forward and the inverse butterflies and takes 256 registers in either class (the pass sets as
+    // non-inlined calls: 200 VGPRs, and 1.7-2 x slower): the plan with the fewest passes wins, not the one with small radices
+    // (and one butterfly per thread and pass: with the several-rounds code for small radices the kernel measured 100^3
+    // 48 -> 68 us, 120^3 58 -> 90 us)
+    SmoothPlan a, b;
+    const bool ha = smooth_try(n, cols, 256, 16, &a, false), hb = smooth_try(n, cols, 256, kSmoothMaxRadix, &b, false);
+    if (ha && (!hb || a.npass <= b.npass)) { *p = a; return true; }
+    if (hb) { *p = b; return true; }
+    if (smooth_try(n, cols, 1024, 16, p, false)) return true;
   }
   return false;
 }

@@ -75,13 +75,15 @@ static void strided_dir(StridedArgs a, long nblocks, int dir) {
 // library's planner makes.  Returns 1 when the length has no plan (a prime factor above 13).
 template <int DIR>
 static void emu_smooth_passes(cplx* img, const SmoothPlan& plan, const SmoothMap& L, const cplx* w, int wscale) {
-  std::vector<cplx> regs((size_t)plan.threads * kSmoothMaxRadix);
-  std::vector<char> active(plan.threads);
+  constexpr int QMAX = 8;   // a thread owns up to smooth_rounds(R) butterflies: virtual threads tid + q * threads
+  std::vector<cplx> regs((size_t)plan.threads * QMAX * kSmoothMaxRadix);
+  std::vector<char> active((size_t)plan.threads * QMAX);
   int Ns = 1;
   for (int f = 0; f < plan.npass; ++f) {
     const int R = plan.fac[f];
+    const int nvirt = plan.threads * smooth_rounds(R);
     for (int half = 0; half < 2; ++half)
-      for (int tid = 0; tid < plan.threads; ++tid) {
+      for (int tid = 0; tid < nvirt; ++tid) {
         cplx* v = &regs[(size_t)tid * kSmoothMaxRadix];
         switch (R) {
 #define FG_R(r)                                                                                              \
