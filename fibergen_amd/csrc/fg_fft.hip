@@ -219,12 +219,16 @@ __global__ __launch_bounds__(THREADS) void k_smooth_strided(SmoothArgs a, long c
   a.data += (long)blockIdx.y * comp_stride;
   constexpr int B = THREADS == 256 ? 16 : 8;
   if (a.plan.lines == 8) smooth_strided_load<8, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else if (a.plan.lines == 16) smooth_strided_load<16, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else if (a.plan.lines == 32) smooth_strided_load<32, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else if (a.plan.lines == 4) smooth_strided_load<4, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else smooth_strided_load<2, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
   const SmoothMap L = {a.plan.lines, 1, a.plan.lines, false};
   smooth_dev_passes<DIR, RMAX>(img, a.plan, L, a.w, 1);
   if (a.plan.lines == 8) smooth_strided_store<8>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else if (a.plan.lines == 16) smooth_strided_store<16>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else if (a.plan.lines == 32) smooth_strided_store<32>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else if (a.plan.lines == 4) smooth_strided_store<4>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else smooth_strided_store<2>(a, blockIdx.x, threadIdx.x, THREADS, img);
 }

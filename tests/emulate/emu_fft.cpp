@@ -341,6 +341,8 @@ int emu_smooth_strided(int N, int dir, double* data, int ncols, int nouter, doub
     for (auto& x : img) x = cmake(NAN, NAN);
     for (int tid = 0; tid < T; ++tid) {   // (the emulation takes the widest variant: more empty slots, the same elements)
       if (C == 8) smooth_strided_load<8, 16>(a, b, tid, T, img.data());
+      else if (C == 16) smooth_strided_load<16, 16>(a, b, tid, T, img.data());
+      else if (C == 32) smooth_strided_load<32, 16>(a, b, tid, T, img.data());
       else if (C == 4) smooth_strided_load<4, 16>(a, b, tid, T, img.data());
       else smooth_strided_load<2, 16>(a, b, tid, T, img.data());
     }
@@ -348,6 +350,8 @@ int emu_smooth_strided(int N, int dir, double* data, int ncols, int nouter, doub
     else emu_smooth_passes<+1>(img.data(), a.plan, L, a.w, 1);
     for (int tid = 0; tid < T; ++tid) {
       if (C == 8) smooth_strided_store<8>(a, b, tid, T, img.data());
+      else if (C == 16) smooth_strided_store<16>(a, b, tid, T, img.data());
+      else if (C == 32) smooth_strided_store<32>(a, b, tid, T, img.data());
       else if (C == 4) smooth_strided_store<4>(a, b, tid, T, img.data());
       else smooth_strided_store<2>(a, b, tid, T, img.data());
     }
