@@ -237,7 +237,7 @@ inline bool smooth_plan_strided(int n, SmoothPlan* p) {
   return false;
 }
 
-// z pass over rows of M = nz / 2 complex points: as many rows per tile (a power of two <= 16) as keep the image at <= 64 KB
+// z pass over rows of M = nz / 2 complex points: as many rows per tile (a power of two <= 64) as keep the image at <= 64 KB
 // (two workgroups per CU), at least one.  Measured: 48 KB -> 64 KB (16 instead of 8 rows of 200 points) 400^3 z passes
 // 1 300 / 1 180 -> 960 / 890 us; 78 KB the same as 64; the point slots padded p + p / 8 against LDS bank conflicts: nothing.
 inline bool smooth_plan_z(int M, SmoothPlan* p) {
@@ -245,7 +245,7 @@ inline bool smooth_plan_z(int M, SmoothPlan* p) {
   if (M < 2) return false;
   const size_t line = (size_t)smooth_z_pitch(M) * sizeof(cplx);
   for (int round = 0; round < 2; ++round)
-    for (int lines : {16, 8, 4, 2, 1}) {
+    for (int lines : {64, 32, 16, 8, 4, 2, 1}) {
       if (line * lines > (round == 0 ? (size_t)64 * 1024 : kSmoothLdsMax)) continue;
       if (smooth_try(M, lines, 256, 16, p) || smooth_try(M, lines, 256, kSmoothMaxRadix, p) || smooth_try(M, lines, 1024, 16, p)) return true;
     }
