@@ -277,12 +277,14 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
     SmoothArgs ac = a.base;
     ac.data += (long)c * a.comp_stride;
     if (C == 8) smooth_strided_load<8, B>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
+    else if (C == 16) smooth_strided_load<16, B>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
     else smooth_strided_load<4, B>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
   }
   __syncthreads();
 #pragma nounroll
   for (int c = 0; c < NC; ++c) smooth_dev_passes<-1, RMAX, false>(img + c * comp, a.base.plan, L, a.base.w, 1);
   if (C == 8) smooth_x_green<8, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  else if (C == 16) smooth_x_green<16, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else smooth_x_green<4, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
 #pragma nounroll
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
     ac.data += (long)c * a.comp_stride;
     ac.scale = 1.0;   // (the 1/N went in with the Green operator)
     if (C == 8) smooth_strided_store<8>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
+    else if (C == 16) smooth_strided_store<16>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
     else smooth_strided_store<4>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
   }
 }

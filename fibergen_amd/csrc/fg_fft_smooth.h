@@ -258,8 +258,8 @@ inline bool smooth_plan_z(int M, SmoothPlan* p) {
 inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p) {
   *p = SmoothPlan();
   if (n < 2) return false;
-  for (int cols : {8}) {
-    if ((size_t)ncomp * n * cols * sizeof(cplx) > kSmoothLdsMax) continue;
+  for (int cols : {16, 8}) {
+    if ((size_t)ncomp * n * cols * sizeof(cplx) > (cols > 8 ? (size_t)80 * 1024 : kSmoothLdsMax)) continue;   // 16 columns: short lines (100^3: fused x pass 46 -> 33 us; 120^3 at 92 KB: 57 -> 61)
     // this kernel holds the forward and the inverse butterflies and takes 256 registers in either class (the pass sets as
     // non-inlined calls: 200 VGPRs, and 1.7-2 x slower): the plan with the fewest passes wins, not the one with small radices
     // (and one butterfly per thread and pass: with the several-rounds code for small radices the kernel measured 100^3
