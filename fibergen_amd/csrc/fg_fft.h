@@ -88,6 +88,7 @@ class Fft3 {
   int odd_[3];       // odd p <= 25: the axis length (z: nz/2) is that factor times a fast power of two; 0 otherwise
   fft::SmoothPlan smooth_[3];   // n != 0: the axis (z: nz/2, odd nz: nz) runs the Stockham tile kernels of fg_fft_smooth.h
   bool zodd_ = false;           // odd nz with a plan: the rows are transformed as nz complex points
+  fft::SmoothPlan xfused_plan_[2];   // fused x pass of the tile kernels: [0] one component, [1] three (n = 0: none)
   int stream_stores_ = 0;  // FFT passes use cache-bypassing stores (fields larger than the Infinity Cache)
   cplx* tw_[3];      // per-axis pass twiddles (fast path) ; z: for M = nz/2
   cplx* half_root_[2];  // e^{-i pi j/n}, j < n/8, of x and y (fused Green-operator pass)

@@ -1244,6 +1244,10 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
       need_scratch = true;
     }
   }
+  if (smooth_[0].n) {   // plans of the tile kernels' fused x pass (one / three components)
+    smooth_plan_xfused(g.nx, 1, &xfused_plan_[0]);
+    smooth_plan_xfused(g.nx, 3, &xfused_plan_[1]);
+  }
   if (fast_[2]) wz_ = upload(make_unit_roots(g.nz, g.nz / 2 + 1));
   if (need_scratch) FG_HIP_CHECK(hipMalloc(&scratch_, g.n * sizeof(double)));
   // three components larger than the 256 MB Infinity Cache: nothing a pass writes is still cached when the next reads it
@@ -1428,10 +1432,8 @@ void Fft3::strided(double* data, int ncomp, long comp_stride, int axis, int dir,
 bool Fft3::can_fuse(int axis, int ncomp) const {
   const int n = axis == 0 ? g_.nx : g_.ny;
   if (fast_[axis]) return n <= 1024;
-  if (axis == 0 && smooth_[0].n && (ncomp == 1 || ncomp == 3)) {   // the tile kernels' fused x pass: ncomp images in LDS
-    SmoothPlan sp;
-    return smooth_plan_xfused(n, ncomp, &sp);
-  }
+  if (axis == 0 && smooth_[0].n && (ncomp == 1 || ncomp == 3))   // the tile kernels' fused x pass: ncomp images in LDS
+    return xfused_plan_[ncomp == 3].n != 0;
   // p * 2^k with p = 3, 5: the three-component form only
   if (ncomp != 3 || (odd_[axis] != 3 && odd_[axis] != 5)) return false;
   XFusedArgs a = {};
@@ -1535,7 +1537,8 @@ void Fft3::fused_g0(double* data, long comp_stride, int axis, double scale, cons
   if (!fast_[axis] && axis == 0 && smooth_[0].n) {
     if (xjump != 0 || xlayout) throw std::runtime_error("fft: the tile kernels' fused x pass takes the plain layout");
     SmoothXArgs x;
-    if (!smooth_plan_xfused(n, ncomp, &x.base.plan)) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
+    x.base.plan = xfused_plan_[ncomp == 3];
+    if (!x.base.plan.n) throw std::runtime_error("fft: fused Green-operator pass not available for this length");
     x.base.data = reinterpret_cast<cplx*>(data);
     x.base.ls = (long)g_.ny * g_.nzc;
     x.base.os = 0;

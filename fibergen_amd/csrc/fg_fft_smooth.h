@@ -308,8 +308,8 @@ struct SmoothZArgs {
 // A thread moves its elements in batches of B: ALL global loads of a batch are issued before the first value is used -- a loop
 // of load -> LDS store -> next load waits for the memory latency once per element (the first form of these kernels: 25 us per
 // 500-point tile, most of it in such loops).  B = 16 with 256 threads (64 KB in flight per workgroup), 8 with 1024.
-// idx / d for 0 <= idx < 2^20 and d < 2^13 without an integer division (exact: the float error is far below 1 / (2 d))
-FG_HD int smooth_div(int idx, float inv_d) { return (int)(((float)idx + 0.5f) * inv_d); }
+// idx / d without an integer division: exact for every 0 <= idx < 2^31 (the double's error is far below 1 / (2 d))
+FG_HD int smooth_div(int idx, double inv_d) { return (int)(((double)idx + 0.5) * inv_d); }
 
 // strided pass: the tile = columns [col0, col0 + C) of outer index o, image [p][C]
 template <int C, int B>
@@ -352,7 +352,7 @@ FG_HD void smooth_x_green(const SmoothXArgs& a, int block, int tid, int nthreads
   for (int idx = tid; idx < n * C; idx += nthreads) {
     const int kx = idx / C, t = idx % C, col = col0 + t;
     if (col >= a.base.ncols) continue;
-    const int jl = smooth_div(col, 1.0f / (float)a.nzc), kk = col - jl * a.nzc, jj = a.jj0 + jl;
+    const int jl = smooth_div(col, 1.0 / (double)a.nzc), kk = col - jl * a.nzc, jj = a.jj0 + jl;
     if (kk >= a.nzf) continue;   // row padding
     const bool zero = kx == 0 && jj == 0 && kk == 0;   // zero frequency  F:19924-19926
     const double kpm0 = a.kpm[0][kx], kpm1 = a.kpm[1][jj], kpm2 = a.kpm[2][kk];
@@ -375,7 +375,7 @@ FG_HD void smooth_x_green(const SmoothXArgs& a, int block, int tid, int nthreads
 template <int B>
 FG_HD void smooth_z_load_packed(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
   const int M = a.plan.n, pitch = smooth_z_pitch(M), total = a.plan.lines * M;
-  const float inv = 1.0f / (float)M;
+  const double inv = 1.0 / (double)M;
   for (int i0 = tid; i0 < total; i0 += B * nthreads) {
     cplx v[B];
 #pragma unroll
@@ -398,7 +398,7 @@ FG_HD void smooth_z_load_packed(const SmoothZArgs& a, long row0, int tid, int nt
 template <int B>
 FG_HD void smooth_z_split_store(const SmoothZArgs& a, long row0, int tid, int nthreads, const cplx* img) {
   const int M = a.plan.n, pitch = smooth_z_pitch(M), total = a.plan.lines * (M + 1);
-  const float inv = 1.0f / (float)(M + 1);
+  const double inv = 1.0 / (double)(M + 1);
   for (int i0 = tid; i0 < total; i0 += B * nthreads) {
     cplx wk[B];
 #pragma unroll
@@ -423,7 +423,7 @@ FG_HD void smooth_z_split_store(const SmoothZArgs& a, long row0, int tid, int nt
 template <int B>
 FG_HD void smooth_z_load_spectrum(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
   const int M = a.plan.n, pitch = smooth_z_pitch(M), total = a.plan.lines * (M + 1);
-  const float inv = 1.0f / (float)(M + 1);
+  const double inv = 1.0 / (double)(M + 1);
   for (int i0 = tid; i0 < total; i0 += B * nthreads) {
     cplx v[B];
 #pragma unroll
@@ -447,7 +447,7 @@ FG_HD void smooth_z_load_spectrum(const SmoothZArgs& a, long row0, int tid, int 
 template <int B>
 FG_HD void smooth_z_merge(const SmoothZArgs& a, int tid, int nthreads, cplx* img) {
   const int M = a.plan.n, pitch = smooth_z_pitch(M), half = M / 2 + 1, total = a.plan.lines * half;
-  const float inv = 1.0f / (float)half;
+  const double inv = 1.0 / (double)half;
   for (int i0 = tid; i0 < total; i0 += (B / 2) * nthreads) {
     cplx w1[B / 2], w2[B / 2];
 #pragma unroll
@@ -473,7 +473,7 @@ FG_HD void smooth_z_merge(const SmoothZArgs& a, int tid, int nthreads, cplx* img
 // c2r: the M complex points of the inverse transform = the nz reals of the row -> memory
 FG_HD void smooth_z_store_packed(const SmoothZArgs& a, long row0, int tid, int nthreads, const cplx* img) {
   const int M = a.plan.n, pitch = smooth_z_pitch(M);
-  const float inv = 1.0f / (float)M;
+  const double inv = 1.0 / (double)M;
   for (int idx = tid; idx < a.plan.lines * M; idx += nthreads) {
     const int l = smooth_div(idx, inv), m = idx - l * M;
     const long row = row0 + l;
@@ -486,7 +486,7 @@ FG_HD void smooth_z_store_packed(const SmoothZArgs& a, long row0, int tid, int n
 template <int B>
 FG_HD void smooth_zodd_load_real(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
   const int nz = a.plan.n, pitch = smooth_z_pitch(nz), total = a.plan.lines * nz;
-  const float inv = 1.0f / (float)nz;
+  const double inv = 1.0 / (double)nz;
   for (int i0 = tid; i0 < total; i0 += B * nthreads) {
     double v[B];
 #pragma unroll
@@ -508,7 +508,7 @@ FG_HD void smooth_zodd_load_real(const SmoothZArgs& a, long row0, int tid, int n
 // r2c: the coefficients k = 0 .. nz / 2 -> memory
 FG_HD void smooth_zodd_store_half(const SmoothZArgs& a, long row0, int tid, int nthreads, const cplx* img) {
   const int nz = a.plan.n, pitch = smooth_z_pitch(nz), nzf = nz / 2 + 1;
-  const float inv = 1.0f / (float)nzf;
+  const double inv = 1.0 / (double)nzf;
   for (int idx = tid; idx < a.plan.lines * nzf; idx += nthreads) {
     const int l = smooth_div(idx, inv), k = idx - l * nzf;
     const long row = row0 + l;
@@ -520,7 +520,7 @@ FG_HD void smooth_zodd_store_half(const SmoothZArgs& a, long row0, int tid, int 
 template <int B>
 FG_HD void smooth_zodd_load_half(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
   const int nz = a.plan.n, pitch = smooth_z_pitch(nz), nzf = nz / 2 + 1, total = a.plan.lines * nzf;
-  const float inv = 1.0f / (float)nzf;
+  const double inv = 1.0 / (double)nzf;
   for (int i0 = tid; i0 < total; i0 += B * nthreads) {
     cplx v[B];
 #pragma unroll
@@ -545,7 +545,7 @@ FG_HD void smooth_zodd_load_half(const SmoothZArgs& a, long row0, int tid, int n
 // c2r: the real parts of the inverse transform -> memory
 FG_HD void smooth_zodd_store_real(const SmoothZArgs& a, long row0, int tid, int nthreads, const cplx* img) {
   const int nz = a.plan.n, pitch = smooth_z_pitch(nz);
-  const float inv = 1.0f / (float)nz;
+  const double inv = 1.0 / (double)nz;
   for (int idx = tid; idx < a.plan.lines * nz; idx += nthreads) {
     const int l = smooth_div(idx, inv), m = idx - l * nz;
     const long row = row0 + l;
