@@ -212,25 +212,31 @@ __device__ __forceinline__ void smooth_dev_passes(cplx* img, const SmoothPlan& p
 }
 
 // THREADS / RMAX classes: (256, 16), (256, 32), (1024, 16) -- registers follow the largest butterfly a kernel is built for
-template <int DIR, int THREADS, int RMAX>
+// CW: the tile width as a compile-time constant (8, 16, 32; 0 = the 4- / 2-column tiles of very long lines, run-time) -- as run-time
+// branches of ONE kernel their load variants raised the allocation of the R <= 16 class from 127 to 147 VGPRs and cost the
+// 8-column passes a resident workgroup (300^3 y passes 367 -> 470 us, old / new library alternating on one box; holding the
+// kernel to 128 VGPRs by attribute made the scheduler serialise the loads instead: 438 us, and the z kernels spill)
+template <int DIR, int THREADS, int RMAX, int CW>
 __global__ __launch_bounds__(THREADS) void k_smooth_strided(SmoothArgs a, long comp_stride) {
   extern __shared__ __align__(16) double lds[];
   cplx* img = reinterpret_cast<cplx*>(lds);
   a.data += (long)blockIdx.y * comp_stride;
   constexpr int B = THREADS == 256 ? 16 : 8;
-  if (a.plan.lines == 8) smooth_strided_load<8, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else if (a.plan.lines == 16) smooth_strided_load<16, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else if (a.plan.lines == 32) smooth_strided_load<32, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else if (a.plan.lines == 4) smooth_strided_load<4, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else smooth_strided_load<2, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  if constexpr (CW != 0) {
+    smooth_strided_load<CW, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  } else {
+    if (a.plan.lines == 4) smooth_strided_load<4, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
+    else smooth_strided_load<2, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  }
   __syncthreads();
   const SmoothMap L = {a.plan.lines, 1, a.plan.lines, false};
   smooth_dev_passes<DIR, RMAX>(img, a.plan, L, a.w, 1);
-  if (a.plan.lines == 8) smooth_strided_store<8>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else if (a.plan.lines == 16) smooth_strided_store<16>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else if (a.plan.lines == 32) smooth_strided_store<32>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else if (a.plan.lines == 4) smooth_strided_store<4>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else smooth_strided_store<2>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  if constexpr (CW != 0) {
+    smooth_strided_store<CW>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  } else {
+    if (a.plan.lines == 4) smooth_strided_store<4>(a, blockIdx.x, threadIdx.x, THREADS, img);
+    else smooth_strided_store<2>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  }
 }
 
 template <bool FWD, int THREADS, int RMAX>
@@ -315,22 +321,47 @@ void launch_smooth_strided(const SmoothArgs& a0, int nouter, int dir, int ncomp,
   const size_t lds = (size_t)a.plan.n * C * sizeof(cplx);
   static PerDeviceOnce configured;
   if (auto once = configured.first_use()) {
-    smooth_configure(&k_smooth_strided<-1, 256, 16>);
-    smooth_configure(&k_smooth_strided<+1, 256, 16>);
-    smooth_configure(&k_smooth_strided<-1, 256, 32>);
-    smooth_configure(&k_smooth_strided<+1, 256, 32>);
-    smooth_configure(&k_smooth_strided<-1, 1024, 16>);
-    smooth_configure(&k_smooth_strided<+1, 1024, 16>);
+    smooth_configure(&k_smooth_strided<-1, 256, 16, 0>);
+    smooth_configure(&k_smooth_strided<+1, 256, 16, 0>);
+    smooth_configure(&k_smooth_strided<-1, 256, 16, 8>);
+    smooth_configure(&k_smooth_strided<+1, 256, 16, 8>);
+    smooth_configure(&k_smooth_strided<-1, 256, 32, 8>);
+    smooth_configure(&k_smooth_strided<+1, 256, 32, 8>);
+    smooth_configure(&k_smooth_strided<-1, 1024, 16, 8>);
+    smooth_configure(&k_smooth_strided<+1, 1024, 16, 8>);
+    smooth_configure(&k_smooth_strided<-1, 256, 16, 16>);
+    smooth_configure(&k_smooth_strided<+1, 256, 16, 16>);
+    smooth_configure(&k_smooth_strided<-1, 256, 16, 32>);
+    smooth_configure(&k_smooth_strided<+1, 256, 16, 32>);
+    smooth_configure(&k_smooth_strided<-1, 256, 32, 0>);
+    smooth_configure(&k_smooth_strided<+1, 256, 32, 0>);
+    smooth_configure(&k_smooth_strided<-1, 1024, 16, 0>);
+    smooth_configure(&k_smooth_strided<+1, 1024, 16, 0>);
   }
   const dim3 grid((unsigned)((long)a.tiles_per_outer * nouter), ncomp);
-  switch (smooth_class(a.plan) * 2 + (dir < 0 ? 0 : 1)) {
-    case 0: hipLaunchKernelGGL((k_smooth_strided<-1, 256, 16>), grid, dim3(256), lds, s, a, cs); break;
-    case 1: hipLaunchKernelGGL((k_smooth_strided<+1, 256, 16>), grid, dim3(256), lds, s, a, cs); break;
-    case 2: hipLaunchKernelGGL((k_smooth_strided<-1, 256, 32>), grid, dim3(256), lds, s, a, cs); break;
-    case 3: hipLaunchKernelGGL((k_smooth_strided<+1, 256, 32>), grid, dim3(256), lds, s, a, cs); break;
-    case 4: hipLaunchKernelGGL((k_smooth_strided<-1, 1024, 16>), grid, dim3(1024), lds, s, a, cs); break;
-    default: hipLaunchKernelGGL((k_smooth_strided<+1, 1024, 16>), grid, dim3(1024), lds, s, a, cs); break;
+  const int cls = smooth_class(a.plan);
+  if (C > 8 && cls != 0) throw std::runtime_error("fft: wide tiles are planned with radices <= 16 and 256 threads");
+#define FG_GO(D, T, R, W) hipLaunchKernelGGL((k_smooth_strided<D, T, R, W>), grid, dim3(T), lds, s, a, cs)
+  if (dir < 0) {
+    if (C == 16) FG_GO(-1, 256, 16, 16);
+    else if (C == 32) FG_GO(-1, 256, 16, 32);
+    else if (C == 8 && cls == 0) FG_GO(-1, 256, 16, 8);
+    else if (C == 8 && cls == 1) FG_GO(-1, 256, 32, 8);
+    else if (C == 8) FG_GO(-1, 1024, 16, 8);
+    else if (cls == 0) FG_GO(-1, 256, 16, 0);
+    else if (cls == 1) FG_GO(-1, 256, 32, 0);
+    else FG_GO(-1, 1024, 16, 0);
+  } else {
+    if (C == 16) FG_GO(+1, 256, 16, 16);
+    else if (C == 32) FG_GO(+1, 256, 16, 32);
+    else if (C == 8 && cls == 0) FG_GO(+1, 256, 16, 8);
+    else if (C == 8 && cls == 1) FG_GO(+1, 256, 32, 8);
+    else if (C == 8) FG_GO(+1, 1024, 16, 8);
+    else if (cls == 0) FG_GO(+1, 256, 16, 0);
+    else if (cls == 1) FG_GO(+1, 256, 32, 0);
+    else FG_GO(+1, 1024, 16, 0);
   }
+#undef FG_GO
   FG_HIP_CHECK(hipGetLastError());
 }
 
