@@ -308,12 +308,17 @@ struct SmoothZArgs {
 // A thread moves its elements in batches of B: ALL global loads of a batch are issued before the first value is used -- a loop
 // of load -> LDS store -> next load waits for the memory latency once per element (the first form of these kernels: 25 us per
 // 500-point tile, most of it in such loops).  B = 16 with 256 threads (64 KB in flight per workgroup), 8 with 1024.
+// the batched loads with the streaming flag decided ONCE per phase (a uniform branch around two straight-line batches), not per
+// load: a flag test in front of every load puts each in a branch of its own (what round 5 found in the fused x pass)
+template <bool NTL>
+FG_HD cplx smooth_cload(const cplx* p) { return cload_stream(p, NTL ? 2 : 0); }
+
 // idx / d without an integer division: exact for every 0 <= idx < 2^31 (the double's error is far below 1 / (2 d))
 FG_HD int smooth_div(int idx, double inv_d) { return (int)(((double)idx + 0.5) * inv_d); }
 
 // strided pass: the tile = columns [col0, col0 + C) of outer index o, image [p][C]
-template <int C, int B>
-FG_HD void smooth_strided_load(const SmoothArgs& a, int block, int tid, int nthreads, cplx* img) {
+template <int C, int B, bool NTL>
+FG_HD void smooth_strided_load_impl(const SmoothArgs& a, int block, int tid, int nthreads, cplx* img) {
   const int o = block / a.tiles_per_outer, col0 = (block % a.tiles_per_outer) * C;
   const long base = (long)o * a.os + col0;
   const int total = a.plan.n * C;
@@ -323,7 +328,7 @@ FG_HD void smooth_strided_load(const SmoothArgs& a, int block, int tid, int nthr
     for (int i = 0; i < B; ++i) {
       const int idx = i0 + i * nthreads;
       const int p = idx / C, t = idx % C;
-      v[i] = idx < total && col0 + t < a.ncols ? cload_stream(&a.data[base + (long)p * a.ls + t], a.nt) : cmake(0.0, 0.0);
+      v[i] = idx < total && col0 + t < a.ncols ? smooth_cload<NTL>(&a.data[base + (long)p * a.ls + t]) : cmake(0.0, 0.0);
     }
 #pragma unroll
     for (int i = 0; i < B; ++i) {
@@ -331,6 +336,12 @@ FG_HD void smooth_strided_load(const SmoothArgs& a, int block, int tid, int nthr
       if (idx < total) img[idx] = v[i];
     }
   }
+}
+
+template <int C, int B>
+FG_HD void smooth_strided_load(const SmoothArgs& a, int block, int tid, int nthreads, cplx* img) {
+  if (a.nt & 2) smooth_strided_load_impl<C, B, true>(a, block, tid, nthreads, img);
+  else smooth_strided_load_impl<C, B, false>(a, block, tid, nthreads, img);
 }
 
 template <int C>
@@ -372,8 +383,8 @@ FG_HD void smooth_x_green(const SmoothXArgs& a, int block, int tid, int nthreads
 
 // z passes: the tile = rows [row0, row0 + lines), image [l][pitch] (pitch >= M + 1)
 // r2c: the packed real row as M complex points -> image
-template <int B>
-FG_HD void smooth_z_load_packed(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+template <int B, bool NTL>
+FG_HD void smooth_z_load_packed_impl(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
   const int M = a.plan.n, pitch = smooth_z_pitch(M), total = a.plan.lines * M;
   const double inv = 1.0 / (double)M;
   for (int i0 = tid; i0 < total; i0 += B * nthreads) {
@@ -383,7 +394,7 @@ FG_HD void smooth_z_load_packed(const SmoothZArgs& a, long row0, int tid, int nt
       const int idx = i0 + i * nthreads;
       const int l = smooth_div(idx, inv), m = idx - l * M;
       const long row = row0 + l;
-      v[i] = idx < total && row < a.nrows ? cload_stream(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[m], a.nt) : cmake(0.0, 0.0);
+      v[i] = idx < total && row < a.nrows ? smooth_cload<NTL>(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[m]) : cmake(0.0, 0.0);
     }
 #pragma unroll
     for (int i = 0; i < B; ++i) {
@@ -392,6 +403,12 @@ FG_HD void smooth_z_load_packed(const SmoothZArgs& a, long row0, int tid, int nt
       if (idx < total) img[l * pitch + m] = v[i];
     }
   }
+}
+
+template <int B>
+FG_HD void smooth_z_load_packed(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+  if (a.nt & 2) smooth_z_load_packed_impl<B, true>(a, row0, tid, nthreads, img);
+  else smooth_z_load_packed_impl<B, false>(a, row0, tid, nthreads, img);
 }
 
 // r2c: the real split X[k], k = 0 .. M, of the transformed image -> memory (FFTW's r2c layout)
@@ -420,8 +437,8 @@ FG_HD void smooth_z_split_store(const SmoothZArgs& a, long row0, int tid, int nt
 }
 
 // c2r: the M + 1 coefficients of a row -> image
-template <int B>
-FG_HD void smooth_z_load_spectrum(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+template <int B, bool NTL>
+FG_HD void smooth_z_load_spectrum_impl(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
   const int M = a.plan.n, pitch = smooth_z_pitch(M), total = a.plan.lines * (M + 1);
   const double inv = 1.0 / (double)(M + 1);
   for (int i0 = tid; i0 < total; i0 += B * nthreads) {
@@ -431,7 +448,7 @@ FG_HD void smooth_z_load_spectrum(const SmoothZArgs& a, long row0, int tid, int 
       const int idx = i0 + i * nthreads;
       const int l = smooth_div(idx, inv), k = idx - l * (M + 1);
       const long row = row0 + l;
-      v[i] = idx < total && row < a.nrows ? cload_stream(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[k], a.nt) : cmake(0.0, 0.0);
+      v[i] = idx < total && row < a.nrows ? smooth_cload<NTL>(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[k]) : cmake(0.0, 0.0);
       if (k == 0 || k == M) v[i].im = 0.0;   // FFTW's c2r ignores the imaginary parts of the DC and Nyquist bins
     }
 #pragma unroll
@@ -441,6 +458,12 @@ FG_HD void smooth_z_load_spectrum(const SmoothZArgs& a, long row0, int tid, int 
       if (idx < total) img[l * pitch + k] = v[i];
     }
   }
+}
+
+template <int B>
+FG_HD void smooth_z_load_spectrum(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+  if (a.nt & 2) smooth_z_load_spectrum_impl<B, true>(a, row0, tid, nthreads, img);
+  else smooth_z_load_spectrum_impl<B, false>(a, row0, tid, nthreads, img);
 }
 
 // c2r: Z'[k] = merge(X[k], X[M - k]), k < M, in place: the merge pairs k and M - k, thread (l, k), k <= M / 2, owns both
@@ -517,8 +540,8 @@ FG_HD void smooth_zodd_store_half(const SmoothZArgs& a, long row0, int tid, int 
 }
 
 // c2r: the coefficients k = 0 .. nz / 2 and their mirror images conj X[k] at nz - k -> image
-template <int B>
-FG_HD void smooth_zodd_load_half(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+template <int B, bool NTL>
+FG_HD void smooth_zodd_load_half_impl(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
   const int nz = a.plan.n, pitch = smooth_z_pitch(nz), nzf = nz / 2 + 1, total = a.plan.lines * nzf;
   const double inv = 1.0 / (double)nzf;
   for (int i0 = tid; i0 < total; i0 += B * nthreads) {
@@ -528,7 +551,7 @@ FG_HD void smooth_zodd_load_half(const SmoothZArgs& a, long row0, int tid, int n
       const int idx = i0 + i * nthreads;
       const int l = smooth_div(idx, inv), k = idx - l * nzf;
       const long row = row0 + l;
-      v[i] = idx < total && row < a.nrows ? cload_stream(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[k], a.nt) : cmake(0.0, 0.0);
+      v[i] = idx < total && row < a.nrows ? smooth_cload<NTL>(&reinterpret_cast<const cplx*>(a.data + row * a.nzp)[k]) : cmake(0.0, 0.0);
       if (k == 0) v[i].im = 0.0;   // FFTW's c2r ignores the imaginary part of the DC bin
     }
 #pragma unroll
@@ -540,6 +563,12 @@ FG_HD void smooth_zodd_load_half(const SmoothZArgs& a, long row0, int tid, int n
       if (k > 0) img[l * pitch + nz - k] = cconj(v[i]);
     }
   }
+}
+
+template <int B>
+FG_HD void smooth_zodd_load_half(const SmoothZArgs& a, long row0, int tid, int nthreads, cplx* img) {
+  if (a.nt & 2) smooth_zodd_load_half_impl<B, true>(a, row0, tid, nthreads, img);
+  else smooth_zodd_load_half_impl<B, false>(a, row0, tid, nthreads, img);
 }
 
 // c2r: the real parts of the inverse transform -> memory
