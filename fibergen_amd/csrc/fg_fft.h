@@ -73,6 +73,10 @@ class Fft3 {
   void fused_g0(double* data, long comp_stride, int axis, double scale, const G0Params& gp, int jj0, int ncomp = 3, int xsplit = 31,
                 long xjump = 0, bool xlayout = false);
 
+  // tile kernels' fused x pass of three components on one joint image (fg_fft_smooth.h SmoothPlan::joint; default) or on one
+  // image per component: the same butterflies in either form
+  void set_joint_x(bool on);
+
   bool fast_x() const { return fast_[0]; }
   bool fast_y() const { return fast_[1]; }
   bool fast_z() const { return fast_[2]; }
@@ -89,6 +93,7 @@ class Fft3 {
   fft::SmoothPlan smooth_[3];   // n != 0: the axis (z: nz/2, odd nz: nz) runs the Stockham tile kernels of fg_fft_smooth.h
   bool zodd_ = false;           // odd nz with a plan: the rows are transformed as nz complex points
   fft::SmoothPlan xfused_plan_[2];   // fused x pass of the tile kernels: [0] one component, [1] three (n = 0: none)
+  bool joint_x_ = true;
   int stream_stores_ = 0;  // FFT passes use cache-bypassing stores (fields larger than the Infinity Cache)
   cplx* tw_[3];      // per-axis pass twiddles (fast path) ; z: for M = nz/2
   cplx* half_root_[2];  // e^{-i pi j/n}, j < n/8, of x and y (fused Green-operator pass)

@@ -180,9 +180,9 @@ __global__ void k_scale(double* x, long n, double s) {
 
 // ---------------------------------------------------------------- lengths with factors 2, 3, 5, 7, 11, 13 (fg_fft_smooth.h)
 // one pass of the tile in LDS: read + butterfly, barrier, write, barrier
-template <int R, int DIR, bool MULTI>
+template <int R, int DIR, int CAP>
 __device__ __forceinline__ void smooth_dev_pass(cplx* img, int N, int Ns, const SmoothMap& L, const cplx* w, int wscale) {
-  constexpr int Q = MULTI ? smooth_rounds(R) : 1;   // butterflies a thread may own (small radices: several)
+  constexpr int Q = CAP ? smooth_rounds(R, CAP) : 1;   // butterflies a thread may own (small radices: several)
   cplx v[Q][R];
   bool active[Q];
 #pragma unroll
@@ -195,13 +195,15 @@ __device__ __forceinline__ void smooth_dev_pass(cplx* img, int N, int Ns, const 
 }
 
 // RMAX: the largest radix the kernel is built for (32 with 256 threads, 16 with 1024: the butterfly lives in registers)
-template <int DIR, int RMAX, bool MULTI = true>
+template <int DIR, int RMAX, int CAP = 20>
 __device__ __forceinline__ void smooth_dev_passes(cplx* img, const SmoothPlan& plan, const SmoothMap& L, const cplx* w, int wscale) {
   int Ns = 1;
   for (int f = 0; f < plan.npass; ++f) {
+    // (the run-time index sends the by-value plan to scratch memory, 104 bytes -- and the radix into a vector register: with
+    // static indices the switch below becomes uniform and the allocation of the (256, R <= 16) kernels goes from 149 to 247 VGPRs)
     const int R = plan.fac[f];
     switch (R) {
-#define FG_R(r) case r: if constexpr (r <= RMAX) smooth_dev_pass<r, DIR, MULTI>(img, plan.n, Ns, L, w, wscale); break;
+#define FG_R(r) case r: if constexpr (r <= RMAX) smooth_dev_pass<r, DIR, CAP>(img, plan.n, Ns, L, w, wscale); break;
       FG_R(2) FG_R(3) FG_R(4) FG_R(5) FG_R(6) FG_R(7) FG_R(8) FG_R(9) FG_R(10) FG_R(11) FG_R(12) FG_R(13) FG_R(14) FG_R(15)
       FG_R(16) FG_R(18) FG_R(20) FG_R(21) FG_R(22) FG_R(24) FG_R(25) FG_R(26) FG_R(27) FG_R(28) FG_R(30) FG_R(32)
 #undef FG_R
@@ -288,13 +290,13 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
   }
   __syncthreads();
 #pragma nounroll
-  for (int c = 0; c < NC; ++c) smooth_dev_passes<-1, RMAX, false>(img + c * comp, a.base.plan, L, a.base.w, 1);
+  for (int c = 0; c < NC; ++c) smooth_dev_passes<-1, RMAX, 0>(img + c * comp, a.base.plan, L, a.base.w, 1);
   if (C == 8) smooth_x_green<8, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else if (C == 16) smooth_x_green<16, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else smooth_x_green<4, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
 #pragma nounroll
-  for (int c = 0; c < NC; ++c) smooth_dev_passes<+1, RMAX, false>(img + c * comp, a.base.plan, L, a.base.w, 1);
+  for (int c = 0; c < NC; ++c) smooth_dev_passes<+1, RMAX, 0>(img + c * comp, a.base.plan, L, a.base.w, 1);
 #pragma nounroll
   for (int c = 0; c < NC; ++c) {
     SmoothArgs ac = a.base;
@@ -306,13 +308,34 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
   }
 }
 
+// The same on the joint image [kx][3][C] of the three components (SmoothPlan::joint): every pass runs once, over three times the
+// butterflies -- the one-image-per-component form has 80 ... 160 of its 256 threads at work in a pass of a 200-point tile and
+// twelve pass phases between its barriers; this one four.  Up to 20 values per thread (32 in the R <= 32 class): several
+// butterflies of a small radix.  The register allocation follows the largest butterfly a kernel is BUILT for, not the plan's:
+// (R <= 16) 228 VGPRs, (R <= 20) 272 -- one wave per SIMD -- held to 256 (30 spilled) for two: 200^3 fused x pass 326 -> 152 us;
+// (R <= 32) 512 + scratch.  512 threads where the image leaves room for one workgroup per CU only (300, 360, 400 points).
+template <int THREADS, int RMAX, int C>
+__global__ __launch_bounds__(THREADS, RMAX <= 20 ? 2 : 1) void k_smooth_xjoint(SmoothXArgs a) {
+  extern __shared__ __align__(16) double lds[];
+  cplx* img = reinterpret_cast<cplx*>(lds);
+  constexpr int CAP = RMAX > 20 ? 32 : 20, W = 3 * C;
+  smooth_joint_load<C, 3, 16>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  __syncthreads();
+  const SmoothMap L = {W, 1, W, false};
+  smooth_dev_passes<-1, RMAX, CAP>(img, a.base.plan, L, a.base.w, 1);
+  smooth_joint_green<C>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  __syncthreads();
+  smooth_dev_passes<+1, RMAX, CAP>(img, a.base.plan, L, a.base.w, 1);
+  smooth_joint_store<C, 3>(a, blockIdx.x, threadIdx.x, THREADS, img);
+}
+
 template <class K>
 void smooth_configure(K kernel) {
   FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmoothLdsMax));
 }
 
 // the kernel class of a plan: 0 = (256 threads, radices <= 16), 1 = (256, <= 32), 2 = (1024, <= 16)
-int smooth_class(const SmoothPlan& p) { return p.threads == 1024 ? 2 : (p.rmax() <= 16 ? 0 : 1); }
+int smooth_class(const SmoothPlan& p) { return p.threads == 1024 ? 2 : (p.rmax() <= 16 && p.cap <= 20 ? 0 : 1); }
 
 void launch_smooth_strided(const SmoothArgs& a0, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
   SmoothArgs a = a0;
@@ -367,7 +390,8 @@ void launch_smooth_strided(const SmoothArgs& a0, int nouter, int dir, int ncomp,
 
 void launch_smooth_xfused(const SmoothXArgs& a0, hipStream_t s) {
   SmoothXArgs a = a0;
-  const int C = a.base.plan.lines;
+  const bool joint = a.base.plan.joint > 1;
+  const int C = joint ? a.base.plan.lines / a.base.plan.joint : a.base.plan.lines;
   a.base.tiles_per_outer = (a.base.ncols + C - 1) / C;
   const size_t lds = (size_t)a.ncomp * a.base.plan.n * C * sizeof(cplx);
   static PerDeviceOnce configured;
@@ -378,9 +402,34 @@ void launch_smooth_xfused(const SmoothXArgs& a0, hipStream_t s) {
     smooth_configure(&k_smooth_xfused<256, 16, 1>);
     smooth_configure(&k_smooth_xfused<256, 32, 1>);
     smooth_configure(&k_smooth_xfused<1024, 16, 1>);
+    smooth_configure(&k_smooth_xjoint<256, 16, 8>);
+    smooth_configure(&k_smooth_xjoint<256, 20, 8>);
+    smooth_configure(&k_smooth_xjoint<512, 20, 8>);
+    smooth_configure(&k_smooth_xjoint<256, 32, 8>);
+    smooth_configure(&k_smooth_xjoint<256, 16, 16>);
+    smooth_configure(&k_smooth_xjoint<256, 20, 16>);
+    smooth_configure(&k_smooth_xjoint<512, 20, 16>);
+    smooth_configure(&k_smooth_xjoint<256, 32, 16>);
   }
   const dim3 grid((unsigned)a.base.tiles_per_outer);
-  switch (smooth_class(a.base.plan) * 2 + (a.ncomp == 3 ? 0 : 1)) {
+  if (joint) {
+    const int rm = a.base.plan.rmax(), cap = a.base.plan.cap, T = a.base.plan.threads;
+    if (a.ncomp != 3 || a.base.plan.joint != 3 || (C != 8 && C != 16) || (T != 256 && T != 512) || (T == 512 && (rm > 20 || cap > 20)))
+      throw std::runtime_error("fft: joint fused x pass: unsupported plan");
+    const int k = T == 512 ? 2 : (rm <= 16 && cap <= 20 ? 0 : (rm <= 20 && cap <= 20 ? 1 : 3));
+#define FG_GO(TT, R) \
+  if (C == 8) hipLaunchKernelGGL((k_smooth_xjoint<TT, R, 8>), grid, dim3(TT), lds, s, a); \
+  else hipLaunchKernelGGL((k_smooth_xjoint<TT, R, 16>), grid, dim3(TT), lds, s, a)
+    if (k == 0) { FG_GO(256, 16); }
+    else if (k == 1) { FG_GO(256, 20); }
+    else if (k == 2) { FG_GO(512, 20); }
+    else { FG_GO(256, 32); }
+#undef FG_GO
+    FG_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  const int cls = smooth_class(a.base.plan);
+  switch (cls * 2 + (a.ncomp == 3 ? 0 : 1)) {
     case 0: hipLaunchKernelGGL((k_smooth_xfused<256, 16, 3>), grid, dim3(256), lds, s, a); break;
     case 1: hipLaunchKernelGGL((k_smooth_xfused<256, 16, 1>), grid, dim3(256), lds, s, a); break;
     case 2: hipLaunchKernelGGL((k_smooth_xfused<256, 32, 3>), grid, dim3(256), lds, s, a); break;
@@ -1283,6 +1332,12 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
   if (need_scratch) FG_HIP_CHECK(hipMalloc(&scratch_, g.n * sizeof(double)));
   // three components larger than the 256 MB Infinity Cache: nothing a pass writes is still cached when the next reads it
   stream_stores_ = 3.0 * (double)g.n * sizeof(double) > 256.0 * 1024 * 1024 ? 1 : 0;
+}
+
+void Fft3::set_joint_x(bool on) {
+  if (on == joint_x_) return;
+  joint_x_ = on;
+  if (smooth_[0].n) smooth_plan_xfused(g_.nx, 3, &xfused_plan_[1], on);
 }
 
 Fft3::~Fft3() {

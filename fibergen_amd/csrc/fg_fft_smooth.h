@@ -30,6 +30,8 @@ struct SmoothPlan {
   int fac[kSmoothMaxPasses] = {};
   int lines = 0;     // lines per tile (strided passes: columns)
   int threads = 0;   // 256 or 1024
+  int cap = 20;      // values a thread holds in a pass (smooth_rounds: several butterflies of a small radix); 0: one butterfly
+  int joint = 0;     // fused x pass: the components whose columns share ONE image [p][joint][columns] (lines = joint * columns); 0: one image each
   int rmax() const { int m = 0; for (int i = 0; i < npass; ++i) m = fac[i] > m ? fac[i] : m; return m; }
 };
 
@@ -164,7 +166,8 @@ FG_HD void smooth_pass_write(cplx* img, int N, int Ns, const SmoothMap& L, int t
 // A thread may own several butterflies of a SMALL radix in one pass (their values stay in registers across the barrier like
 // one large butterfly's): up to smooth_rounds(R) of them, R * rounds <= 20 values.  That lets lengths such as 200 = 8 x 5 x 5
 // or 500 = 10 x 10 x 5 run with radices <= 16 -- half the registers and twice the resident workgroups of the R <= 32 kernels.
-constexpr int smooth_rounds(int r) { return r > 10 ? 1 : (20 / r > 8 ? 8 : 20 / r); }
+// (cap = the values a thread may hold: 20 in the kernels built for radices <= 16, 32 in the joint fused x pass of the R <= 32 class)
+constexpr int smooth_rounds(int r, int cap = 20) { return 2 * r > cap ? 1 : (cap / r > 8 ? 8 : cap / r); }
 
 // ---- planner: lines per tile, threads per workgroup and the radices of the passes
 // radices of n in [lo, hi], at most kSmoothMaxPasses of them: fewest passes first, then the smallest largest radix; returned
@@ -172,8 +175,8 @@ constexpr int smooth_rounds(int r) { return r > 10 ? 1 : (20 / r > 8 ? 8 : 20 / 
 struct SmoothSearch {
   int lo, hi, best[kSmoothMaxPasses], cur[kSmoothMaxPasses], nbest = 0;
   long n = 0, lines = 0, threads = 0;   // radix r fits a pass when its n / r butterflies per line need <= smooth_rounds(r) rounds
-  bool multi = true;                    // false: one butterfly per thread and pass only (the fused x pass)
-  bool fits(int r) const { return threads == 0 || (n / r) * lines <= threads * (long)(multi ? smooth_rounds(r) : 1); }
+  int cap = 20;                         // values per thread (smooth_rounds); 0: one butterfly per thread and pass only
+  bool fits(int r) const { return threads == 0 || (n / r) * lines <= threads * (long)(cap ? smooth_rounds(r, cap) : 1); }
   void go(int rest, int depth, int maxr) {
     if (rest == 1 && depth > 0) {
       bool better = !nbest || depth < nbest;
@@ -193,12 +196,12 @@ struct SmoothSearch {
   }
 };
 
-inline bool smooth_factor(int n, int lines, int threads, int hi, int* fac, int* npass, bool multi = true) {
+inline bool smooth_factor(int n, int lines, int threads, int hi, int* fac, int* npass, int cap = 20) {
   SmoothSearch s;
   s.lo = 2;
   s.hi = hi;
   s.n = n, s.lines = lines, s.threads = threads;
-  s.multi = multi;
+  s.cap = cap;
   s.go(n, 0, hi);
   if (!s.nbest) return false;
   for (int i = 0; i < s.nbest; ++i) fac[i] = s.best[i];
@@ -208,14 +211,15 @@ inline bool smooth_factor(int n, int lines, int threads, int hi, int* fac, int* 
 
 FG_HD int smooth_z_pitch(int M) { return M + 1 + ((M + 1) % 2 == 0 ? 1 : 0); }   // odd: rows start on different banks
 
-inline bool smooth_try(int n, int lines, int threads, int hi, SmoothPlan* p, bool multi = true) {
+inline bool smooth_try(int n, int lines, int threads, int hi, SmoothPlan* p, int cap = 20) {
   int fac[kSmoothMaxPasses], np = 0;
-  if (!smooth_factor(n, lines, threads, hi, fac, &np, multi)) return false;
+  if (!smooth_factor(n, lines, threads, hi, fac, &np, cap)) return false;
   p->n = n;
   p->npass = np;
   for (int i = 0; i < np; ++i) p->fac[i] = fac[i];
   p->lines = lines;
   p->threads = threads;
+  p->cap = cap;
   return true;
 }
 
@@ -255,7 +259,7 @@ inline bool smooth_plan_z(int M, SmoothPlan* p) {
 // fused x pass (x transform, Green operator, inverse x transform on `ncomp` components of a tile): ncomp images in LDS.
 // 8-column tiles only: measured against the three separate kernels, 100^3 +9 %, 120^3 +13 %, 300^3 +11 %, 400^3 +14 %, but with
 // the 4-column tiles three components of 480 / 500 points need, 480^3 -1.4 %, 500^3 -2.3 % (half-line segments)
-inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p) {
+inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p, bool joint = true) {
   *p = SmoothPlan();
   if (n < 2) return false;
   for (int cols : {16, 8}) {
@@ -265,10 +269,26 @@ inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p) {
     // (and one butterfly per thread and pass: with the several-rounds code for small radices the kernel measured 100^3
     // 48 -> 68 us, 120^3 58 -> 90 us)
     SmoothPlan a, b;
-    const bool ha = smooth_try(n, cols, 256, 16, &a, false), hb = smooth_try(n, cols, 256, kSmoothMaxRadix, &b, false);
-    if (ha && (!hb || a.npass <= b.npass)) { *p = a; return true; }
-    if (hb) { *p = b; return true; }
-    if (smooth_try(n, cols, 1024, 16, p, false)) return true;
+    const bool ha = smooth_try(n, cols, 256, 16, &a, 0), hb = smooth_try(n, cols, 256, kSmoothMaxRadix, &b, 0);
+    SmoothPlan best;
+    if (ha && (!hb || a.npass <= b.npass)) best = a;
+    else if (hb) best = b;
+    else smooth_try(n, cols, 1024, 16, &best, 0);
+    // joint image of the ncomp components (every pass runs ONCE, over ncomp x the butterflies: 3 x the threads at work and a
+    // third of the barriers of the one-image-per-component form), where that takes no more passes
+    if (joint && ncomp > 1) {
+      SmoothPlan j, cand;
+      // kernels built for (256 threads, radices <= 16), (256, <= 20), (512, <= 20) with 20 values per thread, (256, <= 32) with 32:
+      // fewest passes, then the first of this list (registers follow the largest radix a kernel is built for)
+      const int jt[4] = {256, 256, 512, 256}, jr[4] = {16, 20, 20, kSmoothMaxRadix}, jc[4] = {20, 20, 20, 32};
+      for (int k = 0; k < 4; ++k)
+        if (smooth_try(n, ncomp * cols, jt[k], jr[k], &cand, jc[k]) && (!j.n || cand.npass < j.npass)) j = cand;
+      if (j.n && (!best.n || j.npass <= best.npass)) {
+        j.joint = ncomp;
+        best = j;
+      }
+    }
+    if (best.n) { *p = best; return true; }
   }
   return false;
 }
@@ -378,6 +398,65 @@ FG_HD void smooth_x_green(const SmoothXArgs& a, int block, int tid, int nthreads
       const double norm_kp2 = kpm0 * kpm0 + kpm1 * kpm1 + kpm2 * kpm2;
       img[idx] = zero ? cmake(0.0, 0.0) : cscale(a.base.scale * a.c10 / norm_kp2, img[idx]);
     }
+  }
+}
+
+// ---- the same phases on the JOINT image [p][NC][C] of the tile's NC components (SmoothPlan::joint): one image of NC * C lines
+template <int C, int NC, int B, bool NTL>
+FG_HD void smooth_joint_load_impl(const SmoothXArgs& a, int block, int tid, int nthreads, cplx* img) {
+  constexpr int W = NC * C;
+  const int col0 = block * C, total = a.base.plan.n * W;
+  for (int i0 = tid; i0 < total; i0 += B * nthreads) {
+    cplx v[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      const int p = idx / W, r = idx % W, c = r / C, t = r % C;
+      v[i] = idx < total && col0 + t < a.base.ncols ? smooth_cload<NTL>(&a.base.data[(long)c * a.comp_stride + col0 + (long)p * a.base.ls + t])
+                                                    : cmake(0.0, 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int idx = i0 + i * nthreads;
+      if (idx < total) img[idx] = v[i];
+    }
+  }
+}
+
+template <int C, int NC, int B>
+FG_HD void smooth_joint_load(const SmoothXArgs& a, int block, int tid, int nthreads, cplx* img) {
+  if (a.base.nt & 2) smooth_joint_load_impl<C, NC, B, true>(a, block, tid, nthreads, img);
+  else smooth_joint_load_impl<C, NC, B, false>(a, block, tid, nthreads, img);
+}
+
+template <int C, int NC>
+FG_HD void smooth_joint_store(const SmoothXArgs& a, int block, int tid, int nthreads, const cplx* img) {
+  constexpr int W = NC * C;
+  const int col0 = block * C, total = a.base.plan.n * W;
+  for (int idx = tid; idx < total; idx += nthreads) {
+    const int p = idx / W, r = idx % W, c = r / C, t = r % C;
+    if (col0 + t < a.base.ncols) cstore_stream(&a.base.data[(long)c * a.comp_stride + col0 + (long)p * a.base.ls + t], img[idx], a.base.nt);
+  }
+}
+
+template <int C>
+FG_HD void smooth_joint_green(const SmoothXArgs& a, int block, int tid, int nthreads, cplx* img) {
+  constexpr int W = 3 * C;
+  const int n = a.base.plan.n, col0 = block * C;
+  for (int idx = tid; idx < n * C; idx += nthreads) {
+    const int kx = idx / C, t = idx % C, col = col0 + t;
+    if (col >= a.base.ncols) continue;
+    const int jl = smooth_div(col, 1.0 / (double)a.nzc), kk = col - jl * a.nzc, jj = a.jj0 + jl;
+    if (kk >= a.nzf) continue;   // row padding
+    const bool zero = kx == 0 && jj == 0 && kk == 0;   // zero frequency  F:19924-19926
+    cplx* q = img + kx * W + t;
+    const cplx t0 = cscale(a.base.scale, q[0]), t1 = cscale(a.base.scale, q[C]), t2 = cscale(a.base.scale, q[2 * C]);
+    cplx e0 = cmake(0.0, 0.0), e1 = e0, e2 = e0;
+    if (!zero)
+      g0_point_rcp(t0, t1, t2, a.kpm[0][kx], a.kpm[1][jj], a.kpm[2][kk], a.kp[0][kx], a.kp[1][jj], a.kp[2][kk], a.c10, a.c20, &e0, &e1, &e2);
+    q[0] = e0;
+    q[C] = e1;
+    q[2 * C] = e2;
   }
 }
 

@@ -85,6 +85,8 @@ struct SolverOptions {
                                 // y^-1(c) -> c2r(c) (hand-over inside the Infinity Cache; measured slower, off by default)
   int staged_copy = -1;         // host <-> device field transfers through the pinned-buffer pipeline (fg_transfer.h): -1 for
                                 // downloads of 8 MB and more, 1 always (both directions), 0 never (one strided copy)
+  int joint_x = 1;              // tile kernels (lengths such as 100, 200, 300): the fused x pass of three components on ONE joint
+                                // image (1) or on one image per component (0); identical butterflies, the default is the faster form
   int stage_chunk_kb = 16384;   // pipeline stage of the staged transfers (<= 16 MB; tests shrink it)
 };
 

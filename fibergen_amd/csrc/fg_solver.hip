@@ -884,6 +884,7 @@ void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* 
     time_begin(5);
     if (fuse_x) {
       // x transform, 1/N, Green operator and inverse x transform in one kernel (spectrum stays in registers)
+      fft_->set_joint_x(opt_.joint_x != 0);
       fft_->fused_g0(buf, g_.n, 0, 1 / (double)nglobal_, gp, 0);
     } else {
       launch_g0(g_, ptrs3(buf), tb, gp.c10, gp.c20, G0Layout{0, 0, 0}, stream_);

@@ -81,7 +81,7 @@ static void emu_smooth_passes(cplx* img, const SmoothPlan& plan, const SmoothMap
   int Ns = 1;
   for (int f = 0; f < plan.npass; ++f) {
     const int R = plan.fac[f];
-    const int nvirt = plan.threads * smooth_rounds(R);
+    const int nvirt = plan.threads * (plan.cap ? smooth_rounds(R, plan.cap) : 1);
     for (int half = 0; half < 2; ++half)
       for (int tid = 0; tid < nvirt; ++tid) {
         cplx* v = &regs[(size_t)tid * kSmoothMaxRadix];
@@ -354,6 +354,89 @@ int emu_smooth_strided(int N, int dir, double* data, int ncols, int nouter, doub
       else if (C == 32) smooth_strided_store<32>(a, b, tid, T, img.data());
       else if (C == 4) smooth_strided_store<4>(a, b, tid, T, img.data());
       else smooth_strided_store<2>(a, b, tid, T, img.data());
+    }
+  }
+  return 0;
+}
+
+// fused x pass of the tile kernels (k_smooth_xfused / k_smooth_xjoint): data[3][N][ncols], columns flattened (ky, kz);
+// joint = 1: the three components on one joint image (what the planner picks where it takes no more passes), 0: one image each
+int emu_smooth_xfused(int N, double* data, int ny, int nzc, int nzf, double scale, double c10, double c20, const double* kpm0,
+                      const double* kp0, const double* kpm1, const double* kp1, const double* kpm2, const double* kp2, int joint,
+                      int* plan_out) {
+  SmoothXArgs a;
+  if (!smooth_plan_xfused(N, 3, &a.base.plan, joint != 0)) return 1;
+  const SmoothPlan& plan = a.base.plan;
+  if (plan_out) {
+    plan_out[0] = plan.lines, plan_out[1] = plan.threads, plan_out[2] = plan.npass, plan_out[3] = plan.joint, plan_out[4] = plan.cap;
+    for (int i = 0; i < plan.npass; ++i) plan_out[5 + i] = plan.fac[i];
+  }
+  std::vector<cplx> w = make_unit_roots(N, N);
+  const bool jn = plan.joint > 1;
+  const int C = jn ? plan.lines / plan.joint : plan.lines, T = plan.threads;
+  a.base.data = reinterpret_cast<cplx*>(data);
+  a.base.ncols = ny * nzc;
+  a.base.ls = a.base.ncols;
+  a.base.os = 0;
+  a.base.tiles_per_outer = (a.base.ncols + C - 1) / C;
+  a.base.scale = scale;
+  a.base.w = w.data();
+  a.base.nt = 0;
+  a.comp_stride = (long)N * a.base.ncols;
+  a.ncomp = 3;
+  a.nzc = nzc, a.nzf = nzf, a.jj0 = 0;
+  a.c10 = c10, a.c20 = c20;
+  a.kpm[0] = kpm0, a.kpm[1] = kpm1, a.kpm[2] = kpm2;
+  a.kp[0] = reinterpret_cast<const cplx*>(kp0), a.kp[1] = reinterpret_cast<const cplx*>(kp1), a.kp[2] = reinterpret_cast<const cplx*>(kp2);
+  std::vector<cplx> img((size_t)3 * N * C);
+  const long comp = (long)N * C;
+  for (int b = 0; b < a.base.tiles_per_outer; ++b) {
+    for (auto& x : img) x = cmake(NAN, NAN);
+    if (jn) {
+      if (C != 8 && C != 16) return 2;
+      const SmoothMap L = {3 * C, 1, 3 * C, false};
+      for (int tid = 0; tid < T; ++tid) {
+        if (C == 8) smooth_joint_load<8, 3, 16>(a, b, tid, T, img.data());
+        else smooth_joint_load<16, 3, 16>(a, b, tid, T, img.data());
+      }
+      emu_smooth_passes<-1>(img.data(), plan, L, a.base.w, 1);
+      for (int tid = 0; tid < T; ++tid) {
+        if (C == 8) smooth_joint_green<8>(a, b, tid, T, img.data());
+        else smooth_joint_green<16>(a, b, tid, T, img.data());
+      }
+      emu_smooth_passes<+1>(img.data(), plan, L, a.base.w, 1);
+      for (int tid = 0; tid < T; ++tid) {
+        if (C == 8) smooth_joint_store<8, 3>(a, b, tid, T, img.data());
+        else smooth_joint_store<16, 3>(a, b, tid, T, img.data());
+      }
+      continue;
+    }
+    const SmoothMap L = {C, 1, C, false};
+    for (int c = 0; c < 3; ++c) {
+      SmoothArgs ac = a.base;
+      ac.data += c * a.comp_stride;
+      for (int tid = 0; tid < T; ++tid) {
+        if (C == 8) smooth_strided_load<8, 16>(ac, b, tid, T, img.data() + c * comp);
+        else if (C == 16) smooth_strided_load<16, 16>(ac, b, tid, T, img.data() + c * comp);
+        else smooth_strided_load<4, 16>(ac, b, tid, T, img.data() + c * comp);
+      }
+    }
+    for (int c = 0; c < 3; ++c) emu_smooth_passes<-1>(img.data() + c * comp, plan, L, a.base.w, 1);
+    for (int tid = 0; tid < T; ++tid) {
+      if (C == 8) smooth_x_green<8, 3>(a, b, tid, T, img.data());
+      else if (C == 16) smooth_x_green<16, 3>(a, b, tid, T, img.data());
+      else smooth_x_green<4, 3>(a, b, tid, T, img.data());
+    }
+    for (int c = 0; c < 3; ++c) emu_smooth_passes<+1>(img.data() + c * comp, plan, L, a.base.w, 1);
+    for (int c = 0; c < 3; ++c) {
+      SmoothArgs ac = a.base;
+      ac.data += c * a.comp_stride;
+      ac.scale = 1.0;
+      for (int tid = 0; tid < T; ++tid) {
+        if (C == 8) smooth_strided_store<8>(ac, b, tid, T, img.data() + c * comp);
+        else if (C == 16) smooth_strided_store<16>(ac, b, tid, T, img.data() + c * comp);
+        else smooth_strided_store<4>(ac, b, tid, T, img.data() + c * comp);
+      }
     }
   }
   return 0;

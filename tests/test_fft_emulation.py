@@ -292,3 +292,73 @@ def test_smooth_planner(emu):
         assert pl["lines"] == (32 if N <= 128 else (16 if N <= 256 else 8)), (N, pl)   # image <= 64 KB for the wide tiles
     x = np.zeros((1, 34, 1), dtype=np.complex128)
     assert emu.emu_smooth_strided(34, -1, P(x.view(np.float64)), 1, 1, ctypes.c_double(1.0), None) == 1   # 34 = 2 * 17
+
+
+@pytest.mark.parametrize("joint", [1, 0])
+@pytest.mark.parametrize("N", [20, 36, 100, 120, 200, 225, 240, 300, 360, 400])
+def test_smooth_fused_x_pass(emu, N, joint):
+    """The tile kernels' fused x pass (x transform, 1/N, Green operator G0OperatorFourierStaggeredGeneral F:19834-19927, inverse x
+    transform) thread by thread on the host, in both forms: one image per component, and the three components on one joint
+    image (every pass once over three times the butterflies, several butterflies of a small radix per thread)."""
+    rng = np.random.default_rng(N + joint)
+    ny, nzc, nzf = 3, 9, 7           # 27 columns: ragged last tile, two padding columns per row
+    ncols = ny * nzc
+    x = rng.standard_normal((3, N, ncols)) + 1j * rng.standard_normal((3, N, ncols))
+    h = [1.0 / (2 * N), 2.0 / (2 * ny), 0.5 / (2 * 12)]
+
+    def tables(n, cnt, hh):
+        half = n // 2 - 1 if n % 2 == 0 else n // 2
+        idx = np.arange(cnt)
+        xi = (np.pi / n) * np.where(idx <= half, idx, idx - n)
+        kpm = np.sin(xi) / hh
+        return kpm, kpm * np.exp(1j * xi)
+    kpm0, kp0 = tables(N, N, h[0])
+    kpm1, kp1 = tables(ny, ny, h[1])
+    kpm2, kp2 = tables(12, nzc, h[2])
+    c10, c20, scale = -1.0 / 0.9, -1.0 / (0.9 * (1 + 0.9 / 1.1)), 1.0 / N
+    y = x.copy()
+    args = [np.ascontiguousarray(a) for a in (kpm0, kp0.view(np.float64), kpm1, kp1.view(np.float64), kpm2, kp2.view(np.float64))]
+    plan = np.zeros(12, dtype=np.int32)
+    assert emu.emu_smooth_xfused(N, P(y.view(np.float64)), ny, nzc, nzf, ctypes.c_double(scale), ctypes.c_double(c10),
+                                 ctypes.c_double(c20), *[P(a) for a in args], joint,
+                                 plan.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == 0
+    lines, threads, npass, pj, cap = (int(v) for v in plan[:5])
+    radices = [int(v) for v in plan[5:5 + npass]]
+    assert int(np.prod(radices)) == N and threads in (256, 512, 1024)
+    if not joint:
+        assert pj == 0 and cap == 0 and threads != 512
+    elif pj:   # the planner's joint form: three components' columns as the lines of one image
+        assert pj == 3 and lines in (24, 48) and threads in (256, 512) and cap in (20, 32)
+        assert threads == 256 or (max(radices) <= 20 and cap == 20)
+    F = np.fft.fft(x, axis=1) * scale
+    jj, kk = np.divmod(np.arange(ncols), nzc)
+    K0, K1, K2 = kp0[:, None], kp1[jj][None, :], kp2[kk][None, :]
+    n2 = (kpm0 ** 2)[:, None] + (kpm1[jj] ** 2)[None, :] + (kpm2[kk] ** 2)[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        c1, c2 = c10 / n2, c20 / (n2 * n2)
+        sdot = F[0] * K0 + F[1] * K1 + F[2] * K2
+        G = np.stack([c1 * F[0] + c2 * sdot * (-np.conj(K0)), c1 * F[1] + c2 * sdot * (-np.conj(K1)),
+                      c1 * F[2] + c2 * sdot * (-np.conj(K2))])
+    G[:, 0, 0] = 0.0                      # zero frequency
+    ref = np.fft.ifft(G, axis=1) * N
+    live = kk < nzf                       # (padding columns of a row carry no data)
+    assert np.abs(y[:, :, live] - ref[:, :, live]).max() / np.abs(ref[:, :, live]).max() < 1e-12
+
+
+def test_smooth_fused_x_plans(emu):
+    """which lengths run the fused x pass on the joint image (no more passes than one image per component), and with what"""
+    got = {}
+    for N in (100, 120, 200, 240, 300, 360, 400):
+        x = np.zeros((3, N, 8), dtype=np.complex128)
+        z = np.zeros(max(N, 8))
+        zc = np.zeros(2 * max(N, 8))
+        plan = np.zeros(12, dtype=np.int32)
+        assert emu.emu_smooth_xfused(N, P(x.view(np.float64)), 1, 8, 8, ctypes.c_double(1.0), ctypes.c_double(1.0),
+                                     ctypes.c_double(1.0), P(z), P(zc), P(z), P(zc), P(z), P(zc), 1,
+                                     plan.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == 0
+        got[N] = (int(plan[0]), int(plan[3]), int(plan[4]), int(plan[1]), [int(v) for v in plan[5:5 + plan[2]]])
+    print(got)
+    assert got[200] == (24, 3, 20, 256, [20, 10])   # (lines, joint components, values per thread, threads, radices)
+    assert got[100] == (48, 3, 20, 256, [10, 10])
+    assert got[300] == (24, 3, 20, 512, [20, 15])   # 7 200 points: 512 threads with <= 20 values each
+    assert got[400] == (24, 3, 20, 512, [20, 20])

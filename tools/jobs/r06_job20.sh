@@ -1,0 +1,7 @@
+#!/bin/bash
+# joint-image fused x pass of the tile kernels: parity, then joint_x = 0 / 1 alternating in one process per grid
+cd "$(dirname "$0")/../.." || exit 1
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fft or random_grids or decimal or basic_scheme" 2>&1 | tail -5
+for n in 100 120 200 240 300; do
+  timeout 300 python tools/ab_grid.py --grid $n,$n,$n --steps 10 --set joint_x=0 --set joint_x=1 --set joint_x=0 --set joint_x=1 2>&1 | cut -c1-330
+done
