@@ -314,19 +314,19 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
 // butterflies of a small radix.  The register allocation follows the largest butterfly a kernel is BUILT for, not the plan's:
 // (R <= 16) 228 VGPRs, (R <= 20) 272 -- one wave per SIMD -- held to 256 (30 spilled) for two: 200^3 fused x pass 326 -> 152 us;
 // (R <= 32) 512 + scratch.  512 threads where the image leaves room for one workgroup per CU only (300, 360, 400 points).
-template <int THREADS, int RMAX, int C>
+template <int THREADS, int RMAX, int C, int NC>
 __global__ __launch_bounds__(THREADS, RMAX <= 20 ? 2 : 1) void k_smooth_xjoint(SmoothXArgs a) {
   extern __shared__ __align__(16) double lds[];
   cplx* img = reinterpret_cast<cplx*>(lds);
-  constexpr int CAP = RMAX > 20 ? 32 : 20, W = 3 * C;
-  smooth_joint_load<C, 3, 16>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  constexpr int CAP = RMAX > 20 ? 32 : 20, W = NC * C;
+  smooth_joint_load<C, NC, 16>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
   const SmoothMap L = {W, 1, W, false};
   smooth_dev_passes<-1, RMAX, CAP>(img, a.base.plan, L, a.base.w, 1);
-  smooth_joint_green<C>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  smooth_joint_green<C, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
   smooth_dev_passes<+1, RMAX, CAP>(img, a.base.plan, L, a.base.w, 1);
-  smooth_joint_store<C, 3>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  smooth_joint_store<C, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
 }
 
 template <class K>
@@ -390,7 +390,7 @@ void launch_smooth_strided(const SmoothArgs& a0, int nouter, int dir, int ncomp,
 
 void launch_smooth_xfused(const SmoothXArgs& a0, hipStream_t s) {
   SmoothXArgs a = a0;
-  const bool joint = a.base.plan.joint > 1;
+  const bool joint = a.base.plan.joint >= 1;
   const int C = joint ? a.base.plan.lines / a.base.plan.joint : a.base.plan.lines;
   a.base.tiles_per_outer = (a.base.ncols + C - 1) / C;
   const size_t lds = (size_t)a.ncomp * a.base.plan.n * C * sizeof(cplx);
@@ -402,29 +402,35 @@ void launch_smooth_xfused(const SmoothXArgs& a0, hipStream_t s) {
     smooth_configure(&k_smooth_xfused<256, 16, 1>);
     smooth_configure(&k_smooth_xfused<256, 32, 1>);
     smooth_configure(&k_smooth_xfused<1024, 16, 1>);
-    smooth_configure(&k_smooth_xjoint<256, 16, 8>);
-    smooth_configure(&k_smooth_xjoint<256, 20, 8>);
-    smooth_configure(&k_smooth_xjoint<512, 20, 8>);
-    smooth_configure(&k_smooth_xjoint<256, 32, 8>);
-    smooth_configure(&k_smooth_xjoint<256, 16, 16>);
-    smooth_configure(&k_smooth_xjoint<256, 20, 16>);
-    smooth_configure(&k_smooth_xjoint<512, 20, 16>);
-    smooth_configure(&k_smooth_xjoint<256, 32, 16>);
+    smooth_configure(&k_smooth_xjoint<512, 20, 4, 3>);
+#define FG_CFG(NC) \
+    smooth_configure(&k_smooth_xjoint<256, 16, 8, NC>); smooth_configure(&k_smooth_xjoint<256, 20, 8, NC>); \
+    smooth_configure(&k_smooth_xjoint<512, 20, 8, NC>); smooth_configure(&k_smooth_xjoint<256, 32, 8, NC>); \
+    smooth_configure(&k_smooth_xjoint<256, 16, 16, NC>); smooth_configure(&k_smooth_xjoint<256, 20, 16, NC>); \
+    smooth_configure(&k_smooth_xjoint<512, 20, 16, NC>); smooth_configure(&k_smooth_xjoint<256, 32, 16, NC>)
+    FG_CFG(3);
+    FG_CFG(1);
+#undef FG_CFG
   }
   const dim3 grid((unsigned)a.base.tiles_per_outer);
   if (joint) {
     const int rm = a.base.plan.rmax(), cap = a.base.plan.cap, T = a.base.plan.threads;
-    if (a.ncomp != 3 || a.base.plan.joint != 3 || (C != 8 && C != 16) || (T != 256 && T != 512) || (T == 512 && (rm > 20 || cap > 20)))
+    if (a.ncomp != a.base.plan.joint || (C != 4 && C != 8 && C != 16) || (T != 256 && T != 512) || (T == 512 && (rm > 20 || cap > 20)) ||
+        (C == 4 && (T != 512 || a.ncomp != 3)))
       throw std::runtime_error("fft: joint fused x pass: unsupported plan");
     const int k = T == 512 ? 2 : (rm <= 16 && cap <= 20 ? 0 : (rm <= 20 && cap <= 20 ? 1 : 3));
+#define FG_GO1(TT, R, CC) \
+  if (a.ncomp == 3) hipLaunchKernelGGL((k_smooth_xjoint<TT, R, CC, 3>), grid, dim3(TT), lds, s, a); \
+  else hipLaunchKernelGGL((k_smooth_xjoint<TT, R, CC, 1>), grid, dim3(TT), lds, s, a)
 #define FG_GO(TT, R) \
-  if (C == 8) hipLaunchKernelGGL((k_smooth_xjoint<TT, R, 8>), grid, dim3(TT), lds, s, a); \
-  else hipLaunchKernelGGL((k_smooth_xjoint<TT, R, 16>), grid, dim3(TT), lds, s, a)
-    if (k == 0) { FG_GO(256, 16); }
-    else if (k == 1) { FG_GO(256, 20); }
-    else if (k == 2) { FG_GO(512, 20); }
-    else { FG_GO(256, 32); }
+  if (C == 8) { FG_GO1(TT, R, 8); } else { FG_GO1(TT, R, 16); }
+    if (C == 4) hipLaunchKernelGGL((k_smooth_xjoint<512, 20, 4, 3>), grid, dim3(512), lds, s, a);
+    else if (k == 0) { FG_GO(256, 16) }
+    else if (k == 1) { FG_GO(256, 20) }
+    else if (k == 2) { FG_GO(512, 20) }
+    else { FG_GO(256, 32) }
 #undef FG_GO
+#undef FG_GO1
     FG_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1337,7 +1343,10 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
 void Fft3::set_joint_x(bool on) {
   if (on == joint_x_) return;
   joint_x_ = on;
-  if (smooth_[0].n) smooth_plan_xfused(g_.nx, 3, &xfused_plan_[1], on);
+  if (smooth_[0].n) {
+    smooth_plan_xfused(g_.nx, 1, &xfused_plan_[0], on);
+    smooth_plan_xfused(g_.nx, 3, &xfused_plan_[1], on);
+  }
 }
 
 Fft3::~Fft3() {

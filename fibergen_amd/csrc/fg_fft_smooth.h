@@ -31,7 +31,8 @@ struct SmoothPlan {
   int lines = 0;     // lines per tile (strided passes: columns)
   int threads = 0;   // 256 or 1024
   int cap = 20;      // values a thread holds in a pass (smooth_rounds: several butterflies of a small radix); 0: one butterfly
-  int joint = 0;     // fused x pass: the components whose columns share ONE image [p][joint][columns] (lines = joint * columns); 0: one image each
+  int joint = 0;     // fused x pass: the components (1 or 3) whose columns share ONE image [p][joint][columns] (lines = joint * columns,
+                     // k_smooth_xjoint); 0: one image and one pass loop per component (k_smooth_xfused)
   int rmax() const { int m = 0; for (int i = 0; i < npass; ++i) m = fac[i] > m ? fac[i] : m; return m; }
 };
 
@@ -276,7 +277,7 @@ inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p, bool joint = tru
     else smooth_try(n, cols, 1024, 16, &best, 0);
     // joint image of the ncomp components (every pass runs ONCE, over ncomp x the butterflies: 3 x the threads at work and a
     // third of the barriers of the one-image-per-component form), where that takes no more passes
-    if (joint && ncomp > 1) {
+    if (joint) {
       SmoothPlan j, cand;
       // kernels built for (256 threads, radices <= 16), (256, <= 20), (512, <= 20) with 20 values per thread, (256, <= 32) with 32:
       // fewest passes, then the first of this list (registers follow the largest radix a kernel is built for)
@@ -289,6 +290,13 @@ inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p, bool joint = tru
       }
     }
     if (best.n) { *p = best; return true; }
+  }
+  // longer lines (420 ... 800 points): a joint image of 4-column tiles (64-byte segments) in the 512-thread kernel.  As one image
+  // per component in the R <= 32 kernels (512 VGPRs, one wave per SIMD) this form lost to three separate kernels (480^3 -1.4 %,
+  // 500^3 -2.3 %); with 8 waves at 256 VGPRs it wins
+  if (joint && ncomp == 3 && (size_t)ncomp * n * 4 * sizeof(cplx) <= kSmoothLdsMax && smooth_try(n, ncomp * 4, 512, 20, p, 20)) {
+    p->joint = ncomp;
+    return true;
   }
   return false;
 }
@@ -439,9 +447,9 @@ FG_HD void smooth_joint_store(const SmoothXArgs& a, int block, int tid, int nthr
   }
 }
 
-template <int C>
+template <int C, int NC>
 FG_HD void smooth_joint_green(const SmoothXArgs& a, int block, int tid, int nthreads, cplx* img) {
-  constexpr int W = 3 * C;
+  constexpr int W = NC * C;
   const int n = a.base.plan.n, col0 = block * C;
   for (int idx = tid; idx < n * C; idx += nthreads) {
     const int kx = idx / C, t = idx % C, col = col0 + t;
@@ -450,13 +458,18 @@ FG_HD void smooth_joint_green(const SmoothXArgs& a, int block, int tid, int nthr
     if (kk >= a.nzf) continue;   // row padding
     const bool zero = kx == 0 && jj == 0 && kk == 0;   // zero frequency  F:19924-19926
     cplx* q = img + kx * W + t;
-    const cplx t0 = cscale(a.base.scale, q[0]), t1 = cscale(a.base.scale, q[C]), t2 = cscale(a.base.scale, q[2 * C]);
-    cplx e0 = cmake(0.0, 0.0), e1 = e0, e2 = e0;
-    if (!zero)
-      g0_point_rcp(t0, t1, t2, a.kpm[0][kx], a.kpm[1][jj], a.kpm[2][kk], a.kp[0][kx], a.kp[1][jj], a.kp[2][kk], a.c10, a.c20, &e0, &e1, &e2);
-    q[0] = e0;
-    q[C] = e1;
-    q[2 * C] = e2;
+    const double kpm0 = a.kpm[0][kx], kpm1 = a.kpm[1][jj], kpm2 = a.kpm[2][kk];
+    if (NC == 3) {
+      const cplx t0 = cscale(a.base.scale, q[0]), t1 = cscale(a.base.scale, q[C]), t2 = cscale(a.base.scale, q[2 * C]);
+      cplx e0 = cmake(0.0, 0.0), e1 = e0, e2 = e0;
+      if (!zero) g0_point_rcp(t0, t1, t2, kpm0, kpm1, kpm2, a.kp[0][kx], a.kp[1][jj], a.kp[2][kk], a.c10, a.c20, &e0, &e1, &e2);
+      q[0] = e0;
+      q[C] = e1;
+      q[2 * C] = e2;
+    } else {   // scalar modes: c10 / |k|^2  (G0OperatorFourierStaggeredHeat F:19758-19823)
+      const double norm_kp2 = kpm0 * kpm0 + kpm1 * kpm1 + kpm2 * kpm2;
+      q[0] = zero ? cmake(0.0, 0.0) : cscale(a.base.scale * a.c10 / norm_kp2, q[0]);
+    }
   }
 }
 

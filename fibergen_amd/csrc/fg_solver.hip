@@ -722,6 +722,7 @@ void Solver::run_pairs(int pc, A first, B second) {
 }
 
 void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* xscratch) {  // alpha = -1: GammaOperator(..., -1)  F:20575
+  fft_->set_joint_x(opt_.joint_x != 0);
   if (opt_.mode == 1) {
     // G0OperatorStaggeredHeat  F:20118-20135 on one component: fftVector(., 1), c1 = c10/|k|^2, fftInvVector
     const double scale = 1 / (double)nglobal_;
@@ -884,7 +885,6 @@ void Solver::fft_g0_chain(double* buf, double alpha, const double* c12, double* 
     time_begin(5);
     if (fuse_x) {
       // x transform, 1/N, Green operator and inverse x transform in one kernel (spectrum stays in registers)
-      fft_->set_joint_x(opt_.joint_x != 0);
       fft_->fused_g0(buf, g_.n, 0, 1 / (double)nglobal_, gp, 0);
     } else {
       launch_g0(g_, ptrs3(buf), tb, gp.c10, gp.c20, G0Layout{0, 0, 0}, stream_);

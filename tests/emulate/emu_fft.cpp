@@ -372,7 +372,7 @@ int emu_smooth_xfused(int N, double* data, int ny, int nzc, int nzf, double scal
     for (int i = 0; i < plan.npass; ++i) plan_out[5 + i] = plan.fac[i];
   }
   std::vector<cplx> w = make_unit_roots(N, N);
-  const bool jn = plan.joint > 1;
+  const bool jn = plan.joint >= 1;
   const int C = jn ? plan.lines / plan.joint : plan.lines, T = plan.threads;
   a.base.data = reinterpret_cast<cplx*>(data);
   a.base.ncols = ny * nzc;
@@ -393,20 +393,23 @@ int emu_smooth_xfused(int N, double* data, int ny, int nzc, int nzf, double scal
   for (int b = 0; b < a.base.tiles_per_outer; ++b) {
     for (auto& x : img) x = cmake(NAN, NAN);
     if (jn) {
-      if (C != 8 && C != 16) return 2;
+      if (C != 4 && C != 8 && C != 16) return 2;
       const SmoothMap L = {3 * C, 1, 3 * C, false};
       for (int tid = 0; tid < T; ++tid) {
-        if (C == 8) smooth_joint_load<8, 3, 16>(a, b, tid, T, img.data());
+        if (C == 4) smooth_joint_load<4, 3, 16>(a, b, tid, T, img.data());
+        else if (C == 8) smooth_joint_load<8, 3, 16>(a, b, tid, T, img.data());
         else smooth_joint_load<16, 3, 16>(a, b, tid, T, img.data());
       }
       emu_smooth_passes<-1>(img.data(), plan, L, a.base.w, 1);
       for (int tid = 0; tid < T; ++tid) {
-        if (C == 8) smooth_joint_green<8>(a, b, tid, T, img.data());
-        else smooth_joint_green<16>(a, b, tid, T, img.data());
+        if (C == 4) smooth_joint_green<4, 3>(a, b, tid, T, img.data());
+        else if (C == 8) smooth_joint_green<8, 3>(a, b, tid, T, img.data());
+        else smooth_joint_green<16, 3>(a, b, tid, T, img.data());
       }
       emu_smooth_passes<+1>(img.data(), plan, L, a.base.w, 1);
       for (int tid = 0; tid < T; ++tid) {
-        if (C == 8) smooth_joint_store<8, 3>(a, b, tid, T, img.data());
+        if (C == 4) smooth_joint_store<4, 3>(a, b, tid, T, img.data());
+        else if (C == 8) smooth_joint_store<8, 3>(a, b, tid, T, img.data());
         else smooth_joint_store<16, 3>(a, b, tid, T, img.data());
       }
       continue;

@@ -926,3 +926,24 @@ def test_counters_report_the_laminate_lists():
     # every interface voxel is affected, and so are its six stencil neighbours at most
     assert mixed <= s.counter("affected_voxels") <= 7 * mixed
     s.close()
+
+
+@pytest.mark.parametrize("mixing", ["voigt", "laminate"])
+@pytest.mark.parametrize("grid", [(20, 12, 14), (36, 10, 22), (100, 6, 18), (120, 4, 10), (200, 3, 12), (240, 2, 10), (300, 3, 8),
+                                  (225, 2, 6), (480, 2, 6), (500, 2, 4)])
+def test_tile_kernels_fused_x_pass_joint_and_per_component(grid, mixing):
+    """joint_x = 1 (default): the fused x pass of the tile kernels on ONE joint image of the three components (k_smooth_xjoint:
+    kernels per largest radix, 256 / 512 threads, 4-column tiles from 420 points on); joint_x = 0: one image per component
+    (lines <= 416 points; longer ones: three separate kernels).  Both against the oracle: same iteration counts, residual
+    histories and strain fields."""
+    E = np.array([1.0, 0, 0, 0.2, 0, 0.5])
+    o = make_oracle(grid, mixing=mixing, tol=1e-8)
+    assert o.run(E) is False
+    for joint in (1, 0):
+        s = make_gpu_solver(grid, mixing=mixing, tol=1e-8, joint_x=joint)
+        assert s.run(E) is False
+        assert s.iterations == o.iterations, (joint, s.iterations, o.iterations)
+        np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-10)
+        assert rel_err(s.get_field("epsilon"), o.eps) < 1e-10
+        assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-11
+        s.close()

@@ -214,3 +214,21 @@ def test_scalar_mixed_boundary_conditions(grid, u_loop):
     with pytest.raises(RuntimeError, match="method=basic"):
         s.run(E, S)
     s.close()
+
+
+@pytest.mark.parametrize("grid", [(20, 12, 14), (100, 6, 18), (120, 4, 10), (200, 3, 12), (300, 3, 8), (225, 2, 6), (500, 2, 4)])
+def test_scalar_modes_on_decimal_grids_fused_x_pass(grid):
+    """the one-component fused x pass of the tile kernels (k_smooth_xjoint<..., 1>: kernels per largest radix; joint_x = 0: the
+    first form, k_smooth_xfused) against the scalar oracle"""
+    phi1 = sphere_phi(grid, 0.3)
+    mus, phis = [1.0, 12.0], [1 - phi1, phi1]
+    E = np.array([1.0, -0.5, 0.25])
+    o = _oracle(grid, mus, phis, tol=1e-9)
+    assert o.run(E) is False
+    for joint in (1, 0):
+        s = _solver(grid, mus, phis, tol=1e-9, joint_x=joint)
+        assert s.run(E) is False
+        assert s.iterations == o.iterations
+        np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-11)
+        assert rel_err(s.get_field("epsilon"), o.eps) < 1e-10
+        s.close()
