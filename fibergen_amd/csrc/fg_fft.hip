@@ -16,6 +16,7 @@
 #include "fg_fft_kernels.h"
 #include "fg_fft_plane.h"
 #include "fg_fft_smooth.h"
+#include "fg_fft_smooth_dev.h"
 #include "fg_fft_tables.h"
 #include "fg_hip_util.h"
 
@@ -178,297 +179,8 @@ __global__ void k_scale(double* x, long n, double s) {
   if (i < n) x[i] *= s;
 }
 
-// ---------------------------------------------------------------- lengths with factors 2, 3, 5, 7, 11, 13 (fg_fft_smooth.h)
-// one pass of the tile in LDS: read + butterfly, barrier, write, barrier
-template <int R, int DIR, int CAP>
-__device__ __forceinline__ void smooth_dev_pass(cplx* img, int N, int Ns, const SmoothMap& L, const cplx* w, int wscale) {
-  constexpr int Q = CAP ? smooth_rounds(R, CAP) : 1;   // butterflies a thread may own (small radices: several)
-  cplx v[Q][R];
-  bool active[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) active[q] = smooth_pass_read<R, DIR>(img, N, Ns, L, w, wscale, threadIdx.x + q * blockDim.x, v[q]);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < Q; ++q)
-    if (active[q]) smooth_pass_write<R>(img, N, Ns, L, threadIdx.x + q * blockDim.x, v[q]);
-  __syncthreads();
-}
-
-// RMAX: the largest radix the kernel is built for (32 with 256 threads, 16 with 1024: the butterfly lives in registers)
-template <int DIR, int RMAX, int CAP = 20>
-__device__ __forceinline__ void smooth_dev_passes(cplx* img, const SmoothPlan& plan, const SmoothMap& L, const cplx* w, int wscale) {
-  int Ns = 1;
-  for (int f = 0; f < plan.npass; ++f) {
-    // (the run-time index sends the by-value plan to scratch memory, 104 bytes -- and the radix into a vector register: with
-    // static indices the switch below becomes uniform and the allocation of the (256, R <= 16) kernels goes from 149 to 247 VGPRs)
-    const int R = plan.fac[f];
-    switch (R) {
-#define FG_R(r) case r: if constexpr (r <= RMAX) smooth_dev_pass<r, DIR, CAP>(img, plan.n, Ns, L, w, wscale); break;
-      FG_R(2) FG_R(3) FG_R(4) FG_R(5) FG_R(6) FG_R(7) FG_R(8) FG_R(9) FG_R(10) FG_R(11) FG_R(12) FG_R(13) FG_R(14) FG_R(15)
-      FG_R(16) FG_R(18) FG_R(20) FG_R(21) FG_R(22) FG_R(24) FG_R(25) FG_R(26) FG_R(27) FG_R(28) FG_R(30) FG_R(32)
-#undef FG_R
-      default: break;
-    }
-    Ns *= R;
-  }
-}
-
-// THREADS / RMAX classes: (256, 16), (256, 32), (1024, 16) -- registers follow the largest butterfly a kernel is built for
-// CW: the tile width as a compile-time constant (8, 16, 32; 0 = the 4- / 2-column tiles of very long lines, run-time) -- as run-time
-// branches of ONE kernel their load variants raised the allocation of the R <= 16 class from 127 to 147 VGPRs and cost the
-// 8-column passes a resident workgroup (300^3 y passes 367 -> 470 us, old / new library alternating on one box; holding the
-// kernel to 128 VGPRs by attribute made the scheduler serialise the loads instead: 438 us, and the z kernels spill)
-template <int DIR, int THREADS, int RMAX, int CW>
-__global__ __launch_bounds__(THREADS) void k_smooth_strided(SmoothArgs a, long comp_stride) {
-  extern __shared__ __align__(16) double lds[];
-  cplx* img = reinterpret_cast<cplx*>(lds);
-  a.data += (long)blockIdx.y * comp_stride;
-  constexpr int B = THREADS == 256 ? 16 : 8;
-  if constexpr (CW != 0) {
-    smooth_strided_load<CW, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  } else {
-    if (a.plan.lines == 4) smooth_strided_load<4, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
-    else smooth_strided_load<2, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  }
-  __syncthreads();
-  const SmoothMap L = {a.plan.lines, 1, a.plan.lines, false};
-  smooth_dev_passes<DIR, RMAX>(img, a.plan, L, a.w, 1);
-  if constexpr (CW != 0) {
-    smooth_strided_store<CW>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  } else {
-    if (a.plan.lines == 4) smooth_strided_store<4>(a, blockIdx.x, threadIdx.x, THREADS, img);
-    else smooth_strided_store<2>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  }
-}
-
-template <bool FWD, int THREADS, int RMAX>
-__global__ __launch_bounds__(THREADS) void k_smooth_z(SmoothZArgs a, long comp_stride) {
-  extern __shared__ __align__(16) double lds[];
-  cplx* img = reinterpret_cast<cplx*>(lds);
-  a.data += (long)blockIdx.y * comp_stride;
-  const long row0 = (long)blockIdx.x * a.plan.lines;
-  const SmoothMap L = {1, smooth_z_pitch(a.plan.n), a.plan.lines, true};
-  constexpr int B = THREADS == 256 ? 16 : 8;
-  if (a.odd) {   // odd nz: the row as nz complex points
-    if (FWD) smooth_zodd_load_real<B>(a, row0, threadIdx.x, THREADS, img);
-    else smooth_zodd_load_half<B>(a, row0, threadIdx.x, THREADS, img);
-    __syncthreads();
-    smooth_dev_passes<FWD ? -1 : +1, RMAX>(img, a.plan, L, a.w, 1);
-    if (FWD) smooth_zodd_store_half(a, row0, threadIdx.x, THREADS, img);
-    else smooth_zodd_store_real(a, row0, threadIdx.x, THREADS, img);
-    return;
-  }
-  if (FWD) {
-    smooth_z_load_packed<B>(a, row0, threadIdx.x, THREADS, img);
-  } else {
-    smooth_z_load_spectrum<B>(a, row0, threadIdx.x, THREADS, img);
-    __syncthreads();
-    smooth_z_merge<B>(a, threadIdx.x, THREADS, img);
-  }
-  __syncthreads();
-  smooth_dev_passes<FWD ? -1 : +1, RMAX>(img, a.plan, L, a.w, 2);
-  if (FWD) smooth_z_split_store<B>(a, row0, threadIdx.x, THREADS, img);
-  else smooth_z_store_packed(a, row0, threadIdx.x, THREADS, img);
-}
-
-// x transform + Green operator + inverse x transform of the tile's NC components (NC images in LDS)
-template <int THREADS, int RMAX, int NC>
-__global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
-  extern __shared__ __align__(16) double lds[];
-  cplx* img = reinterpret_cast<cplx*>(lds);
-  constexpr int B = THREADS == 256 ? 16 : 8;
-  const int C = a.base.plan.lines;
-  const long comp = (long)a.base.plan.n * C;
-  const SmoothMap L = {C, 1, C, false};
-#pragma nounroll   // (one component's batch of loads in registers at a time)
-  for (int c = 0; c < NC; ++c) {
-    SmoothArgs ac = a.base;
-    ac.data += (long)c * a.comp_stride;
-    if (C == 8) smooth_strided_load<8, B>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
-    else if (C == 16) smooth_strided_load<16, B>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
-    else smooth_strided_load<4, B>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
-  }
-  __syncthreads();
-#pragma nounroll
-  for (int c = 0; c < NC; ++c) smooth_dev_passes<-1, RMAX, 0>(img + c * comp, a.base.plan, L, a.base.w, 1);
-  if (C == 8) smooth_x_green<8, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else if (C == 16) smooth_x_green<16, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  else smooth_x_green<4, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  __syncthreads();
-#pragma nounroll
-  for (int c = 0; c < NC; ++c) smooth_dev_passes<+1, RMAX, 0>(img + c * comp, a.base.plan, L, a.base.w, 1);
-#pragma nounroll
-  for (int c = 0; c < NC; ++c) {
-    SmoothArgs ac = a.base;
-    ac.data += (long)c * a.comp_stride;
-    ac.scale = 1.0;   // (the 1/N went in with the Green operator)
-    if (C == 8) smooth_strided_store<8>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
-    else if (C == 16) smooth_strided_store<16>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
-    else smooth_strided_store<4>(ac, blockIdx.x, threadIdx.x, THREADS, img + c * comp);
-  }
-}
-
-// The same on the joint image [kx][3][C] of the three components (SmoothPlan::joint): every pass runs once, over three times the
-// butterflies -- the one-image-per-component form has 80 ... 160 of its 256 threads at work in a pass of a 200-point tile and
-// twelve pass phases between its barriers; this one four.  Up to 20 values per thread (32 in the R <= 32 class): several
-// butterflies of a small radix.  The register allocation follows the largest butterfly a kernel is BUILT for, not the plan's:
-// (R <= 16) 228 VGPRs, (R <= 20) 272 -- one wave per SIMD -- held to 256 (30 spilled) for two: 200^3 fused x pass 326 -> 152 us;
-// (R <= 32) 512 + scratch.  512 threads where the image leaves room for one workgroup per CU only (300, 360, 400 points).
-template <int THREADS, int RMAX, int C, int NC>
-__global__ __launch_bounds__(THREADS, RMAX <= 20 ? 2 : 1) void k_smooth_xjoint(SmoothXArgs a) {
-  extern __shared__ __align__(16) double lds[];
-  cplx* img = reinterpret_cast<cplx*>(lds);
-  constexpr int CAP = RMAX > 20 ? 32 : 20, W = NC * C;
-  smooth_joint_load<C, NC, 16>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  __syncthreads();
-  const SmoothMap L = {W, 1, W, false};
-  smooth_dev_passes<-1, RMAX, CAP>(img, a.base.plan, L, a.base.w, 1);
-  smooth_joint_green<C, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
-  __syncthreads();
-  smooth_dev_passes<+1, RMAX, CAP>(img, a.base.plan, L, a.base.w, 1);
-  smooth_joint_store<C, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
-}
-
-template <class K>
-void smooth_configure(K kernel) {
-  FG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmoothLdsMax));
-}
-
-// the kernel class of a plan: 0 = (256 threads, radices <= 16), 1 = (256, <= 32), 2 = (1024, <= 16)
-int smooth_class(const SmoothPlan& p) { return p.threads == 1024 ? 2 : (p.rmax() <= 16 && p.cap <= 20 ? 0 : 1); }
-
-void launch_smooth_strided(const SmoothArgs& a0, int nouter, int dir, int ncomp, long cs, hipStream_t s) {
-  SmoothArgs a = a0;
-  const int C = a.plan.lines;
-  a.tiles_per_outer = (a.ncols + C - 1) / C;
-  const size_t lds = (size_t)a.plan.n * C * sizeof(cplx);
-  static PerDeviceOnce configured;
-  if (auto once = configured.first_use()) {
-    smooth_configure(&k_smooth_strided<-1, 256, 16, 0>);
-    smooth_configure(&k_smooth_strided<+1, 256, 16, 0>);
-    smooth_configure(&k_smooth_strided<-1, 256, 16, 8>);
-    smooth_configure(&k_smooth_strided<+1, 256, 16, 8>);
-    smooth_configure(&k_smooth_strided<-1, 256, 32, 8>);
-    smooth_configure(&k_smooth_strided<+1, 256, 32, 8>);
-    smooth_configure(&k_smooth_strided<-1, 1024, 16, 8>);
-    smooth_configure(&k_smooth_strided<+1, 1024, 16, 8>);
-    smooth_configure(&k_smooth_strided<-1, 256, 16, 16>);
-    smooth_configure(&k_smooth_strided<+1, 256, 16, 16>);
-    smooth_configure(&k_smooth_strided<-1, 256, 16, 32>);
-    smooth_configure(&k_smooth_strided<+1, 256, 16, 32>);
-    smooth_configure(&k_smooth_strided<-1, 256, 32, 0>);
-    smooth_configure(&k_smooth_strided<+1, 256, 32, 0>);
-    smooth_configure(&k_smooth_strided<-1, 1024, 16, 0>);
-    smooth_configure(&k_smooth_strided<+1, 1024, 16, 0>);
-  }
-  const dim3 grid((unsigned)((long)a.tiles_per_outer * nouter), ncomp);
-  const int cls = smooth_class(a.plan);
-  if (C > 8 && cls != 0) throw std::runtime_error("fft: wide tiles are planned with radices <= 16 and 256 threads");
-#define FG_GO(D, T, R, W) hipLaunchKernelGGL((k_smooth_strided<D, T, R, W>), grid, dim3(T), lds, s, a, cs)
-  if (dir < 0) {
-    if (C == 16) FG_GO(-1, 256, 16, 16);
-    else if (C == 32) FG_GO(-1, 256, 16, 32);
-    else if (C == 8 && cls == 0) FG_GO(-1, 256, 16, 8);
-    else if (C == 8 && cls == 1) FG_GO(-1, 256, 32, 8);
-    else if (C == 8) FG_GO(-1, 1024, 16, 8);
-    else if (cls == 0) FG_GO(-1, 256, 16, 0);
-    else if (cls == 1) FG_GO(-1, 256, 32, 0);
-    else FG_GO(-1, 1024, 16, 0);
-  } else {
-    if (C == 16) FG_GO(+1, 256, 16, 16);
-    else if (C == 32) FG_GO(+1, 256, 16, 32);
-    else if (C == 8 && cls == 0) FG_GO(+1, 256, 16, 8);
-    else if (C == 8 && cls == 1) FG_GO(+1, 256, 32, 8);
-    else if (C == 8) FG_GO(+1, 1024, 16, 8);
-    else if (cls == 0) FG_GO(+1, 256, 16, 0);
-    else if (cls == 1) FG_GO(+1, 256, 32, 0);
-    else FG_GO(+1, 1024, 16, 0);
-  }
-#undef FG_GO
-  FG_HIP_CHECK(hipGetLastError());
-}
-
-void launch_smooth_xfused(const SmoothXArgs& a0, hipStream_t s) {
-  SmoothXArgs a = a0;
-  const bool joint = a.base.plan.joint >= 1;
-  const int C = joint ? a.base.plan.lines / a.base.plan.joint : a.base.plan.lines;
-  a.base.tiles_per_outer = (a.base.ncols + C - 1) / C;
-  const size_t lds = (size_t)a.ncomp * a.base.plan.n * C * sizeof(cplx);
-  static PerDeviceOnce configured;
-  if (auto once = configured.first_use()) {
-    smooth_configure(&k_smooth_xfused<256, 16, 3>);
-    smooth_configure(&k_smooth_xfused<256, 32, 3>);
-    smooth_configure(&k_smooth_xfused<1024, 16, 3>);
-    smooth_configure(&k_smooth_xfused<256, 16, 1>);
-    smooth_configure(&k_smooth_xfused<256, 32, 1>);
-    smooth_configure(&k_smooth_xfused<1024, 16, 1>);
-    smooth_configure(&k_smooth_xjoint<512, 20, 4, 3>);
-#define FG_CFG(NC) \
-    smooth_configure(&k_smooth_xjoint<256, 16, 8, NC>); smooth_configure(&k_smooth_xjoint<256, 20, 8, NC>); \
-    smooth_configure(&k_smooth_xjoint<512, 20, 8, NC>); smooth_configure(&k_smooth_xjoint<256, 32, 8, NC>); \
-    smooth_configure(&k_smooth_xjoint<256, 16, 16, NC>); smooth_configure(&k_smooth_xjoint<256, 20, 16, NC>); \
-    smooth_configure(&k_smooth_xjoint<512, 20, 16, NC>); smooth_configure(&k_smooth_xjoint<256, 32, 16, NC>)
-    FG_CFG(3);
-    FG_CFG(1);
-#undef FG_CFG
-  }
-  const dim3 grid((unsigned)a.base.tiles_per_outer);
-  if (joint) {
-    const int rm = a.base.plan.rmax(), cap = a.base.plan.cap, T = a.base.plan.threads;
-    if (a.ncomp != a.base.plan.joint || (C != 4 && C != 8 && C != 16) || (T != 256 && T != 512) || (T == 512 && (rm > 20 || cap > 20)) ||
-        (C == 4 && (T != 512 || a.ncomp != 3)))
-      throw std::runtime_error("fft: joint fused x pass: unsupported plan");
-    const int k = T == 512 ? 2 : (rm <= 16 && cap <= 20 ? 0 : (rm <= 20 && cap <= 20 ? 1 : 3));
-#define FG_GO1(TT, R, CC) \
-  if (a.ncomp == 3) hipLaunchKernelGGL((k_smooth_xjoint<TT, R, CC, 3>), grid, dim3(TT), lds, s, a); \
-  else hipLaunchKernelGGL((k_smooth_xjoint<TT, R, CC, 1>), grid, dim3(TT), lds, s, a)
-#define FG_GO(TT, R) \
-  if (C == 8) { FG_GO1(TT, R, 8); } else { FG_GO1(TT, R, 16); }
-    if (C == 4) hipLaunchKernelGGL((k_smooth_xjoint<512, 20, 4, 3>), grid, dim3(512), lds, s, a);
-    else if (k == 0) { FG_GO(256, 16) }
-    else if (k == 1) { FG_GO(256, 20) }
-    else if (k == 2) { FG_GO(512, 20) }
-    else { FG_GO(256, 32) }
-#undef FG_GO
-#undef FG_GO1
-    FG_HIP_CHECK(hipGetLastError());
-    return;
-  }
-  const int cls = smooth_class(a.base.plan);
-  switch (cls * 2 + (a.ncomp == 3 ? 0 : 1)) {
-    case 0: hipLaunchKernelGGL((k_smooth_xfused<256, 16, 3>), grid, dim3(256), lds, s, a); break;
-    case 1: hipLaunchKernelGGL((k_smooth_xfused<256, 16, 1>), grid, dim3(256), lds, s, a); break;
-    case 2: hipLaunchKernelGGL((k_smooth_xfused<256, 32, 3>), grid, dim3(256), lds, s, a); break;
-    case 3: hipLaunchKernelGGL((k_smooth_xfused<256, 32, 1>), grid, dim3(256), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((k_smooth_xfused<1024, 16, 3>), grid, dim3(1024), lds, s, a); break;
-    default: hipLaunchKernelGGL((k_smooth_xfused<1024, 16, 1>), grid, dim3(1024), lds, s, a); break;
-  }
-  FG_HIP_CHECK(hipGetLastError());
-}
-
-void launch_smooth_z(const SmoothZArgs& a, bool fwd, int ncomp, long comp_stride, hipStream_t s) {
-  const int lines = a.plan.lines;
-  const size_t lds = (size_t)lines * smooth_z_pitch(a.plan.n) * sizeof(cplx);
-  static PerDeviceOnce configured;
-  if (auto once = configured.first_use()) {
-    smooth_configure(&k_smooth_z<true, 256, 16>);
-    smooth_configure(&k_smooth_z<false, 256, 16>);
-    smooth_configure(&k_smooth_z<true, 256, 32>);
-    smooth_configure(&k_smooth_z<false, 256, 32>);
-    smooth_configure(&k_smooth_z<true, 1024, 16>);
-    smooth_configure(&k_smooth_z<false, 1024, 16>);
-  }
-  const dim3 grid((unsigned)((a.nrows + lines - 1) / lines), ncomp);
-  switch (smooth_class(a.plan) * 2 + (fwd ? 0 : 1)) {
-    case 0: hipLaunchKernelGGL((k_smooth_z<true, 256, 16>), grid, dim3(256), lds, s, a, comp_stride); break;
-    case 1: hipLaunchKernelGGL((k_smooth_z<false, 256, 16>), grid, dim3(256), lds, s, a, comp_stride); break;
-    case 2: hipLaunchKernelGGL((k_smooth_z<true, 256, 32>), grid, dim3(256), lds, s, a, comp_stride); break;
-    case 3: hipLaunchKernelGGL((k_smooth_z<false, 256, 32>), grid, dim3(256), lds, s, a, comp_stride); break;
-    case 4: hipLaunchKernelGGL((k_smooth_z<true, 1024, 16>), grid, dim3(1024), lds, s, a, comp_stride); break;
-    default: hipLaunchKernelGGL((k_smooth_z<false, 1024, 16>), grid, dim3(1024), lds, s, a, comp_stride); break;
-  }
-  FG_HIP_CHECK(hipGetLastError());
-}
+// lengths with factors 2, 3, 5, 7, 11, 13: the Stockham tile kernels live in fg_fft_smooth_yz.hip / fg_fft_smooth_x.hip
+// (translation units of their own: their many instances compile beside this file)
 
 int nt_loads_env() {
   return 15;   // streaming loads in r2c, the strided passes, the fused x pass and the mirrored c2r (bits 1, 2, 4, 8)
