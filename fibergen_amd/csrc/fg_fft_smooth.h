@@ -119,6 +119,12 @@ FG_HD void dft_reg(cplx* v) {
 // Addressing of a tile in LDS: point p of line t sits at p * sp + t * sc.
 //   strided passes: sp = lines, sc = 1 (the columns of a line point are adjacent, as in memory); threads run over t fastest
 //   z passes:       sp = 1, sc = line pitch (a row is contiguous, as in memory);                  threads run over j fastest
+// idx / d without an integer division: exact for every 0 <= idx < 2^31 (the double's error is far below 1 / (2 d))
+FG_HD int smooth_div(int idx, double inv_d) { return (int)(((double)idx + 0.5) * inv_d); }
+// the same in single precision for the small operands of the passes (thread and butterfly numbers): exact while a < 2^21
+// (error of the product <= 3 a / d 2^-24 against a distance of 0.5 / d to the next integer)
+FG_HD int smooth_divf(int a, float inv_d) { return (int)(((float)a + 0.5f) * inv_d); }
+
 struct SmoothMap {
   int sp, sc, lines;
   bool jfast;
@@ -126,21 +132,40 @@ struct SmoothMap {
 
 // First half of a pass for thread `tid`: the R inputs of its butterfly, twiddled and transformed -> v.  Returns whether
 // the thread owns a butterfly.  w: entry k * wscale = e^{-2 pi i k / N}.
-template <int R, int DIR>
+// FDIV: index arithmetic in 32 bits and without integer divisions by run-time values (a single-precision reciprocal is exact
+// here and costs 4 instructions where the division sequence costs ~35 -- seven of them per butterfly and pass; SQ_INSTS_VALU of
+// the 400^3 passes: 2.0-2.4 x the power-of-two kernels' per voxel).  y / z passes 3-8 % faster with it; the fused x pass, which
+// sits at its 256-VGPR cap, 10 % SLOWER (the compiler then keeps all R addresses of a butterfly in registers: 26 -> 107 spilled):
+// it keeps the plain form (its tile width is a compile-time constant, two of the seven divisions fold anyway).
+template <int R, int DIR, bool FDIV = true>
 FG_HD bool smooth_pass_read(const cplx* img, int N, int Ns, const SmoothMap& L, const cplx* w, int wscale, int tid, cplx* v) {
   const int nb = N / R;
   if (tid >= nb * L.lines) return false;
-  const int t = L.jfast ? tid / nb : tid % L.lines;
-  const int j = L.jfast ? tid % nb : tid / L.lines;
-  const cplx* src = img + (long)t * L.sc;
+  int t, j, k = 0;
+  if (FDIV) {
+    const int d = L.jfast ? nb : L.lines;
+    const int q = smooth_divf(tid, 1.0f / (float)d), rem = tid - q * d;
+    t = L.jfast ? q : rem, j = L.jfast ? rem : q;
+    const cplx* src = img + t * L.sc;
 #pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = src[(long)(j + r * nb) * L.sp];
+    for (int r = 0; r < R; ++r) v[r] = src[(j + r * nb) * L.sp];
+    if (Ns > 1) {
+      const float inv_ns = 1.0f / (float)Ns;
+      k = (j - smooth_divf(j, inv_ns) * Ns) * smooth_divf(nb, inv_ns) * wscale;
+    }
+  } else {
+    t = L.jfast ? tid / nb : tid % L.lines;
+    j = L.jfast ? tid % nb : tid / L.lines;
+    const cplx* src = img + (long)t * L.sc;
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = src[(long)(j + r * nb) * L.sp];
+    if (Ns > 1) k = (j % Ns) * (N / (Ns * R)) * wscale;
+  }
   if (Ns > 1) {
     // w^{r m}, m = (j mod Ns) N / (Ns R): the first power from the table, the others as products of two lower ones (error
     // growth ~ log2 R roundings)
-    const int k = j % Ns;
     cplx p[R];
-    p[1] = w[(long)k * (N / (Ns * R)) * wscale];
+    p[1] = w[k];
     if (DIR > 0) p[1] = cconj(p[1]);
     v[1] = cmul(v[1], p[1]);
 #pragma unroll
@@ -154,14 +179,24 @@ FG_HD bool smooth_pass_read(const cplx* img, int N, int Ns, const SmoothMap& L, 
 }
 
 // Second half (behind a barrier: every thread has read its inputs): the outputs to their Stockham positions
-template <int R>
+template <int R, bool FDIV = true>
 FG_HD void smooth_pass_write(cplx* img, int N, int Ns, const SmoothMap& L, int tid, const cplx* v) {
   const int nb = N / R;
-  const int t = L.jfast ? tid / nb : tid % L.lines;
-  const int j = L.jfast ? tid % nb : tid / L.lines;
-  cplx* dst = img + (long)t * L.sc + (long)((j / Ns) * Ns * R + j % Ns) * L.sp;
+  if (FDIV) {
+    const int d = L.jfast ? nb : L.lines;
+    const int q = smooth_divf(tid, 1.0f / (float)d), rem = tid - q * d;
+    const int t = L.jfast ? q : rem, j = L.jfast ? rem : q;
+    const int jh = Ns > 1 ? smooth_divf(j, 1.0f / (float)Ns) : j, jl = j - jh * Ns;
+    cplx* dst = img + t * L.sc + (jh * Ns * R + jl) * L.sp;
 #pragma unroll
-  for (int r = 0; r < R; ++r) dst[(long)r * Ns * L.sp] = v[r];
+    for (int r = 0; r < R; ++r) dst[r * Ns * L.sp] = v[r];
+  } else {
+    const int t = L.jfast ? tid / nb : tid % L.lines;
+    const int j = L.jfast ? tid % nb : tid / L.lines;
+    cplx* dst = img + (long)t * L.sc + (long)((j / Ns) * Ns * R + j % Ns) * L.sp;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dst[(long)r * Ns * L.sp] = v[r];
+  }
 }
 
 // A thread may own several butterflies of a SMALL radix in one pass (their values stay in registers across the barrier like
@@ -341,8 +376,6 @@ struct SmoothZArgs {
 template <bool NTL>
 FG_HD cplx smooth_cload(const cplx* p) { return cload_stream(p, NTL ? 2 : 0); }
 
-// idx / d without an integer division: exact for every 0 <= idx < 2^31 (the double's error is far below 1 / (2 d))
-FG_HD int smooth_div(int idx, double inv_d) { return (int)(((double)idx + 0.5) * inv_d); }
 
 // strided pass: the tile = columns [col0, col0 + C) of outer index o, image [p][C]
 template <int C, int B, bool NTL>

@@ -26,13 +26,13 @@ __global__ __launch_bounds__(THREADS) void k_smooth_xfused(SmoothXArgs a) {
   }
   __syncthreads();
 #pragma nounroll
-  for (int c = 0; c < NC; ++c) smooth_dev_passes<-1, RMAX, 0>(img + c * comp, a.base.plan, L, a.base.w, 1);
+  for (int c = 0; c < NC; ++c) smooth_dev_passes<-1, RMAX, 0, false>(img + c * comp, a.base.plan, L, a.base.w, 1);
   if (C == 8) smooth_x_green<8, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else if (C == 16) smooth_x_green<16, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   else smooth_x_green<4, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
 #pragma nounroll
-  for (int c = 0; c < NC; ++c) smooth_dev_passes<+1, RMAX, 0>(img + c * comp, a.base.plan, L, a.base.w, 1);
+  for (int c = 0; c < NC; ++c) smooth_dev_passes<+1, RMAX, 0, false>(img + c * comp, a.base.plan, L, a.base.w, 1);
 #pragma nounroll
   for (int c = 0; c < NC; ++c) {
     SmoothArgs ac = a.base;
@@ -58,10 +58,10 @@ __global__ __launch_bounds__(THREADS, RMAX <= 20 ? 2 : 1) void k_smooth_xjoint(S
   smooth_joint_load<C, NC, 16>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
   const SmoothMap L = {W, 1, W, false};
-  smooth_dev_passes<-1, RMAX, CAP>(img, a.base.plan, L, a.base.w, 1);
+  smooth_dev_passes<-1, RMAX, CAP, false>(img, a.base.plan, L, a.base.w, 1);
   smooth_joint_green<C, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
-  smooth_dev_passes<+1, RMAX, CAP>(img, a.base.plan, L, a.base.w, 1);
+  smooth_dev_passes<+1, RMAX, CAP, false>(img, a.base.plan, L, a.base.w, 1);
   smooth_joint_store<C, NC>(a, blockIdx.x, threadIdx.x, THREADS, img);
 }
 

@@ -73,7 +73,7 @@ static void strided_dir(StridedArgs a, long nblocks, int dir) {
 // Stockham tile kernels (fg_fft_smooth.h): the phases of k_smooth_strided / k_smooth_z for every thread of every workgroup,
 // in the device's order (load | barrier | per pass: read + butterfly, barrier, write, barrier | store), with the plan the
 // library's planner makes.  Returns 1 when the length has no plan (a prime factor above 13).
-template <int DIR>
+template <int DIR, bool FDIV = true>
 static void emu_smooth_passes(cplx* img, const SmoothPlan& plan, const SmoothMap& L, const cplx* w, int wscale) {
   constexpr int QMAX = 8;   // a thread owns up to smooth_rounds(R) butterflies: virtual threads tid + q * threads
   std::vector<cplx> regs((size_t)plan.threads * QMAX * kSmoothMaxRadix);
@@ -88,8 +88,8 @@ static void emu_smooth_passes(cplx* img, const SmoothPlan& plan, const SmoothMap
         switch (R) {
 #define FG_R(r)                                                                                              \
   case r:                                                                                                    \
-    if (half == 0) active[tid] = smooth_pass_read<r, DIR>(img, plan.n, Ns, L, w, wscale, tid, v);            \
-    else if (active[tid]) smooth_pass_write<r>(img, plan.n, Ns, L, tid, v);                                  \
+    if (half == 0) active[tid] = smooth_pass_read<r, DIR, FDIV>(img, plan.n, Ns, L, w, wscale, tid, v);            \
+    else if (active[tid]) smooth_pass_write<r, FDIV>(img, plan.n, Ns, L, tid, v);                                  \
     break;
           FG_R(2) FG_R(3) FG_R(4) FG_R(5) FG_R(6) FG_R(7) FG_R(8) FG_R(9) FG_R(10) FG_R(11) FG_R(12) FG_R(13) FG_R(14) FG_R(15)
           FG_R(16) FG_R(18) FG_R(20) FG_R(21) FG_R(22) FG_R(24) FG_R(25) FG_R(26) FG_R(27) FG_R(28) FG_R(30) FG_R(32)
@@ -400,13 +400,13 @@ int emu_smooth_xfused(int N, double* data, int ny, int nzc, int nzf, double scal
         else if (C == 8) smooth_joint_load<8, 3, 16>(a, b, tid, T, img.data());
         else smooth_joint_load<16, 3, 16>(a, b, tid, T, img.data());
       }
-      emu_smooth_passes<-1>(img.data(), plan, L, a.base.w, 1);
+      emu_smooth_passes<-1, false>(img.data(), plan, L, a.base.w, 1);
       for (int tid = 0; tid < T; ++tid) {
         if (C == 4) smooth_joint_green<4, 3>(a, b, tid, T, img.data());
         else if (C == 8) smooth_joint_green<8, 3>(a, b, tid, T, img.data());
         else smooth_joint_green<16, 3>(a, b, tid, T, img.data());
       }
-      emu_smooth_passes<+1>(img.data(), plan, L, a.base.w, 1);
+      emu_smooth_passes<+1, false>(img.data(), plan, L, a.base.w, 1);
       for (int tid = 0; tid < T; ++tid) {
         if (C == 4) smooth_joint_store<4, 3>(a, b, tid, T, img.data());
         else if (C == 8) smooth_joint_store<8, 3>(a, b, tid, T, img.data());
@@ -424,13 +424,13 @@ int emu_smooth_xfused(int N, double* data, int ny, int nzc, int nzf, double scal
         else smooth_strided_load<4, 16>(ac, b, tid, T, img.data() + c * comp);
       }
     }
-    for (int c = 0; c < 3; ++c) emu_smooth_passes<-1>(img.data() + c * comp, plan, L, a.base.w, 1);
+    for (int c = 0; c < 3; ++c) emu_smooth_passes<-1, false>(img.data() + c * comp, plan, L, a.base.w, 1);
     for (int tid = 0; tid < T; ++tid) {
       if (C == 8) smooth_x_green<8, 3>(a, b, tid, T, img.data());
       else if (C == 16) smooth_x_green<16, 3>(a, b, tid, T, img.data());
       else smooth_x_green<4, 3>(a, b, tid, T, img.data());
     }
-    for (int c = 0; c < 3; ++c) emu_smooth_passes<+1>(img.data() + c * comp, plan, L, a.base.w, 1);
+    for (int c = 0; c < 3; ++c) emu_smooth_passes<+1, false>(img.data() + c * comp, plan, L, a.base.w, 1);
     for (int c = 0; c < 3; ++c) {
       SmoothArgs ac = a.base;
       ac.data += c * a.comp_stride;
