@@ -246,6 +246,10 @@ inline bool smooth_factor(int n, int lines, int threads, int hi, int* fac, int* 
 }
 
 FG_HD int smooth_z_pitch(int M) { return M + 1 + ((M + 1) % 2 == 0 ? 1 : 0); }   // odd: rows start on different banks
+// thread map of the z passes: lanes across the tile's ROWS (row pitch odd: conflict-free reads and writes in every pass).  With
+// lanes along a row (the first form) the first pass writes its outputs R elements apart -- 8-way bank conflicts for R = 8:
+// SQ_LDS_BANK_CONFLICT 86 M of 199 M LDS cycles in the 400^3 z passes
+FG_HD SmoothMap smooth_z_map(int M, int lines) { return SmoothMap{1, smooth_z_pitch(M), lines, false}; }
 
 inline bool smooth_try(int n, int lines, int threads, int hi, SmoothPlan* p, int cap = 20) {
   int fac[kSmoothMaxPasses], np = 0;

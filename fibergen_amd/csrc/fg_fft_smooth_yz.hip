@@ -40,7 +40,7 @@ __global__ __launch_bounds__(THREADS) void k_smooth_z(SmoothZArgs a, long comp_s
   cplx* img = reinterpret_cast<cplx*>(lds);
   a.data += (long)blockIdx.y * comp_stride;
   const long row0 = (long)blockIdx.x * a.plan.lines;
-  const SmoothMap L = {1, smooth_z_pitch(a.plan.n), a.plan.lines, true};
+  const SmoothMap L = smooth_z_map(a.plan.n, a.plan.lines);
   constexpr int B = THREADS == 256 ? 16 : 8;
   if (a.odd) {   // odd nz: the row as nz complex points
     if (FWD) smooth_zodd_load_real<B>(a, row0, threadIdx.x, THREADS, img);

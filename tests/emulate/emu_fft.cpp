@@ -462,7 +462,7 @@ int emu_smooth_z(int nz, int fwd, double* data, long nrows, int* plan_out) {
     a.nt = 0;
     const int pitch = smooth_z_pitch(nz), lines = a.plan.lines, T = a.plan.threads;
     std::vector<cplx> img((size_t)lines * pitch);
-    const SmoothMap L = {1, pitch, lines, true};
+    const SmoothMap L = smooth_z_map(a.plan.n, lines);
     for (long b = 0; b * lines < nrows; ++b) {
       for (auto& x : img) x = cmake(NAN, NAN);
       const long row0 = b * lines;
@@ -492,7 +492,7 @@ int emu_smooth_z(int nz, int fwd, double* data, long nrows, int* plan_out) {
   a.nt = 0;
   const int pitch = smooth_z_pitch(M), lines = a.plan.lines, T = a.plan.threads;
   std::vector<cplx> img((size_t)lines * pitch);
-  const SmoothMap L = {1, pitch, lines, true};
+  const SmoothMap L = smooth_z_map(a.plan.n, lines);
   for (long b = 0; b * lines < nrows; ++b) {
     for (auto& x : img) x = cmake(NAN, NAN);
     const long row0 = b * lines;
