@@ -11,6 +11,7 @@
 #include "fg_hip_util.h"
 #include "fg_slab.h"
 #include "fg_slab_plan.h"
+#include "fg_fft_smooth_plans.h"
 #include "fg_solver.h"
 
 struct fg_solver {
@@ -257,6 +258,10 @@ int fg_set_option_i(fg_solver* s, const char* key, long value) {
     else if (k == "plane_fft") o.plane_fft = value < 0 ? -1 : (value != 0);
     else if (k == "pair_chunk") o.pair_chunk = value < 0 ? 0 : (int)value;
     else if (k == "joint_x") o.joint_x = value != 0;
+    else if (k == "tile_plans") {
+      o.tile_plans = value != 0;
+      fg::fft::smooth_plan_kernels(value != 0);
+    }
     else if (k == "staged_copy") o.staged_copy = value < 0 ? -1 : (value != 0);
     else if (k == "stage_chunk_kb") {
       if (value < 1 || value > 16384) throw std::runtime_error("stage_chunk_kb must be 1 ... 16384");

@@ -58,6 +58,10 @@ inline int smooth_class(const SmoothPlan& p) { return p.threads == 1024 ? 2 : (p
 void launch_smooth_strided(const SmoothArgs& a0, int nouter, int dir, int ncomp, long cs, hipStream_t s);
 void launch_smooth_z(const SmoothZArgs& a, bool fwd, int ncomp, long comp_stride, hipStream_t s);
 void launch_smooth_xfused(const SmoothXArgs& a0, hipStream_t s);
+// the kernels built for one plan each (fg_fft_smooth_plans.h); false: none for this plan, or switched off
+bool launch_smooth_strided_plan(const SmoothArgs& a, const dim3& grid, size_t lds, int dir, long cs, hipStream_t s);
+bool launch_smooth_z_plan(const SmoothZArgs& a, const dim3& grid, size_t lds, bool fwd, long cs, hipStream_t s);
+bool launch_smooth_x_plan(const SmoothXArgs& a, const dim3& grid, size_t lds, hipStream_t s);
 
 }  // namespace fft
 }  // namespace fg

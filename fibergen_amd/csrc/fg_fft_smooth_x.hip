@@ -92,6 +92,7 @@ void launch_smooth_xfused(const SmoothXArgs& a0, hipStream_t s) {
 #undef FG_CFG
   }
   const dim3 grid((unsigned)a.base.tiles_per_outer);
+  if (joint && launch_smooth_x_plan(a, grid, lds, s)) return;
   if (joint) {
     const int rm = a.base.plan.rmax(), cap = a.base.plan.cap, T = a.base.plan.threads;
     if (a.ncomp != a.base.plan.joint || (C != 4 && C != 8 && C != 16) || (T != 256 && T != 512) || (T == 512 && (rm > 20 || cap > 20)) ||

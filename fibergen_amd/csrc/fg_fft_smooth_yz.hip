@@ -91,6 +91,7 @@ void launch_smooth_strided(const SmoothArgs& a0, int nouter, int dir, int ncomp,
     smooth_configure(&k_smooth_strided<+1, 1024, 16, 0>);
   }
   const dim3 grid((unsigned)((long)a.tiles_per_outer * nouter), ncomp);
+  if (launch_smooth_strided_plan(a, grid, lds, dir, cs, s)) return;
   const int cls = smooth_class(a.plan);
   if (C > 8 && cls != 0) throw std::runtime_error("fft: wide tiles are planned with radices <= 16 and 256 threads");
 #define FG_GO(D, T, R, W) hipLaunchKernelGGL((k_smooth_strided<D, T, R, W>), grid, dim3(T), lds, s, a, cs)
@@ -130,6 +131,7 @@ void launch_smooth_z(const SmoothZArgs& a, bool fwd, int ncomp, long comp_stride
     smooth_configure(&k_smooth_z<false, 1024, 16>);
   }
   const dim3 grid((unsigned)((a.nrows + lines - 1) / lines), ncomp);
+  if (launch_smooth_z_plan(a, grid, lds, fwd, comp_stride, s)) return;
   switch (smooth_class(a.plan) * 2 + (fwd ? 0 : 1)) {
     case 0: hipLaunchKernelGGL((k_smooth_z<true, 256, 16>), grid, dim3(256), lds, s, a, comp_stride); break;
     case 1: hipLaunchKernelGGL((k_smooth_z<false, 256, 16>), grid, dim3(256), lds, s, a, comp_stride); break;

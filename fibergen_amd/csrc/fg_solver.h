@@ -87,6 +87,8 @@ struct SolverOptions {
                                 // downloads of 8 MB and more, 1 always (both directions), 0 never (one strided copy)
   int joint_x = 1;              // tile kernels (lengths such as 100, 200, 300): the fused x pass of three components on ONE joint
                                 // image (1) or on one image per component (0); identical butterflies, the default is the faster form
+  int tile_plans = 1;           // tile kernels (decimal sizes): the kernels built for one plan each where the plan is in their tables
+                                // (fg_fft_smooth_plans.h) (1) or the class kernels for every plan (0); process-wide switch, same butterflies
   int stage_chunk_kb = 16384;   // pipeline stage of the staged transfers (<= 16 MB; tests shrink it)
 };
 

@@ -102,7 +102,7 @@ class LSSolver:
                 if v not in kinds:
                     raise RuntimeError("Unknown error estimator '%s'" % v)
                 self._check(self._lib.fg_set_option_i(self._h, b"error_estimator", kinds[v]))
-            elif k in ("u_loop", "fuse_x", "cg_fused", "fuse_stress_div", "u_tile", "x_layout", "plane_fft", "slab_split", "slab_interleave", "slab_loopback", "laminate_overlap", "phi_sweep", "pair_chunk", "joint_x", "staged_copy", "stage_chunk_kb"):
+            elif k in ("u_loop", "fuse_x", "cg_fused", "fuse_stress_div", "u_tile", "x_layout", "plane_fft", "slab_split", "slab_interleave", "slab_loopback", "laminate_overlap", "phi_sweep", "pair_chunk", "joint_x", "tile_plans", "staged_copy", "stage_chunk_kb"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))
             elif k in ("maxiter", "loadstep_extrapolation_order"):
                 self._check(self._lib.fg_set_option_i(self._h, k.encode(), int(v)))

@@ -9,6 +9,7 @@
 #include "../../fibergen_amd/csrc/fg_fft_kernels.h"
 #include "../../fibergen_amd/csrc/fg_fft_plane.h"
 #include "../../fibergen_amd/csrc/fg_fft_smooth.h"
+#include "../../fibergen_amd/csrc/fg_fft_smooth_plans.h"
 #include "../../fibergen_amd/csrc/fg_fft_tables.h"
 
 using namespace fg;
@@ -443,6 +444,24 @@ int emu_smooth_xfused(int N, double* data, int ny, int nzc, int nzf, double scal
     }
   }
   return 0;
+}
+
+// the plan kernels' tables (fg_fft_smooth_plans.h) against the planner: number of entries whose plan the planner does NOT make
+// (such an entry would never be launched: its grid size runs the class kernels)
+int emu_plan_table_mismatches(int* nentries) {
+  int bad = 0, n = 0;
+  SmoothPlan p;
+#define FG_X(N, C, R0, R1, R2) ++n; if (!smooth_plan_strided(N, &p) || !smooth_plan_is(p, N, C, 256, 20, R0, R1, R2)) ++bad;
+  FG_SMOOTH_STRIDED_PLANS(FG_X)
+#undef FG_X
+#define FG_X(M, LINES, R0, R1, R2) ++n; if (!smooth_plan_z(M, &p) || !smooth_plan_is(p, M, LINES, 256, 20, R0, R1, R2)) ++bad;
+  FG_SMOOTH_Z_PLANS(FG_X)
+#undef FG_X
+#define FG_X(N, C, T, CAP, R0, R1, R2) ++n; if (!smooth_plan_xfused(N, 3, &p) || p.joint != 3 || !smooth_plan_is(p, N, 3 * C, T, CAP, R0, R1, R2)) ++bad;
+  FG_SMOOTH_X_PLANS(FG_X)
+#undef FG_X
+  if (nentries) *nentries = n;
+  return bad;
 }
 
 int emu_smooth_z(int nz, int fwd, double* data, long nrows, int* plan_out) {

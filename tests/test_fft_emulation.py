@@ -367,3 +367,11 @@ def test_smooth_fused_x_plans(emu):
     assert got[300] == (24, 3, 20, 512, [20, 15])   # 7 200 points: 512 threads with <= 20 values each
     assert got[400] == (24, 3, 20, 512, [20, 20])
     assert got[500] == (12, 3, 20, 512, [10, 10, 5])   # 4-column tiles from 420 points on
+
+
+def test_plan_kernel_tables_match_the_planner(emu):
+    """every entry of the plan kernels' tables (fg_fft_smooth_plans.h: kernels built for one plan each) is the plan the
+    planner makes for that length -- an entry that is not would silently fall back to the class kernels"""
+    n = ctypes.c_int(0)
+    assert emu.emu_plan_table_mismatches(ctypes.byref(n)) == 0
+    assert n.value == 36

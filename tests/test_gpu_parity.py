@@ -947,3 +947,40 @@ def test_tile_kernels_fused_x_pass_joint_and_per_component(grid, mixing):
         assert rel_err(s.get_field("epsilon"), o.eps) < 1e-10
         assert rel_err(s.mean_stress(), o.mean_stress()) < 1e-11
         s.close()
+
+
+@pytest.mark.parametrize("grid", [(100, 100, 100), (120, 150, 180), (200, 240, 250), (300, 360, 100), (400, 120, 200), (480, 100, 150),
+                                  (500, 100, 120), (150, 300, 400), (180, 200, 480), (250, 400, 500)])
+def test_tile_kernels_built_for_one_plan_equal_the_class_kernels(grid):
+    """tile_plans = 1 (default): lengths in the tables of fg_fft_smooth_plans.h run kernels built for their plan (line length,
+    tile shape and radices as template parameters); tile_plans = 0: the class kernels, which take any plan.  The same
+    butterflies in the same order: forward and inverse transforms against numpy <= 1e-13 in both forms, the two forms equal to
+    the contraction choices of two compilations, and three passes of the loop (fused x pass) give the same strain field."""
+    rng = np.random.default_rng(grid[0] + grid[1])
+    f = rng.standard_normal((3,) + grid)
+    nzc = grid[2] // 2 + 1
+    spec = rng.standard_normal((3,) + grid[:2] + (nzc,)) + 1j * rng.standard_normal((3,) + grid[:2] + (nzc,))
+    ref_f = np.fft.rfftn(f, axes=(1, 2, 3)) / float(np.prod(grid))
+    ref_i = np.fft.irfftn(spec, s=grid, axes=(1, 2, 3)) * float(np.prod(grid))
+    E = np.array([1.0, 0, 0, 0.3, 0, 0.5])
+    out = {}
+    try:
+        for flag in (1, 0):
+            s = make_gpu_solver(grid, tile_plans=flag)
+            s.set_field("f", f)
+            s.run_stage("fft_forward")
+            fwd = s.get_field("f_hat")
+            assert rel_err(fwd, ref_f) < 1e-13, flag
+            s.set_field("f_hat", spec)
+            s.run_stage("fft_inverse")
+            inv = s.get_field("f")
+            assert rel_err(inv, ref_i) < 1e-13, flag
+            s.calc_ref_material()
+            s.iterate(E, 3)
+            out[flag] = (fwd, inv, s.get_field("epsilon"))
+            s.close()
+    finally:
+        s = make_gpu_solver((8, 8, 8), tile_plans=1)   # (the switch is process-wide)
+        s.close()
+    assert rel_err(out[1][0], out[0][0]) < 1e-14 and rel_err(out[1][1], out[0][1]) < 1e-14
+    assert rel_err(out[1][2], out[0][2]) < 1e-12
