@@ -984,3 +984,50 @@ def test_tile_kernels_built_for_one_plan_equal_the_class_kernels(grid):
         s.close()
     assert rel_err(out[1][0], out[0][0]) < 1e-14 and rel_err(out[1][1], out[0][1]) < 1e-14
     assert rel_err(out[1][2], out[0][2]) < 1e-12
+
+
+def _plan_table(name):
+    """entries of a plan-kernel table of fg_fft_smooth_plans.h (first field = the line length)"""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fibergen_amd", "csrc",
+                            "fg_fft_smooth_plans.h")).read()
+    body = src[src.index("#define " + name + "(X)"):]
+    body = body[:body.index("\n\n")]
+    return sorted({int(m.group(1)) for m in re.finditer(r"X\((\d+),", body)})
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_every_plan_kernel_against_numpy(axis):
+    """every length in the plan kernels' tables, as x (strided pass + fused x pass in the loop), y (strided pass) and z (2 M real
+    points) of a thin grid: forward and inverse transforms against numpy <= 1e-13 and -- for x -- two passes of the loop with the
+    plan kernels on and off"""
+    lengths = _plan_table("FG_SMOOTH_Z_PLANS") if axis == 2 else sorted(set(_plan_table("FG_SMOOTH_STRIDED_PLANS")) |
+                                                                        set(_plan_table("FG_SMOOTH_X_PLANS")))
+    rng = np.random.default_rng(axis)
+    E = np.array([1.0, 0, 0, 0.3, 0, 0.5])
+    for n in lengths:
+        grid = [(n, 3, 10), (5, n, 6), (3, 4, 2 * n)][axis]
+        s = make_gpu_solver(grid)
+        f = rng.standard_normal((3,) + grid)
+        s.set_field("f", f)
+        s.run_stage("fft_forward")
+        assert rel_err(s.get_field("f_hat"), np.fft.rfftn(f, axes=(1, 2, 3)) / float(np.prod(grid))) < 1e-13, grid
+        nzc = grid[2] // 2 + 1
+        spec = rng.standard_normal((3,) + grid[:2] + (nzc,)) + 1j * rng.standard_normal((3,) + grid[:2] + (nzc,))
+        s.set_field("f_hat", spec)
+        s.run_stage("fft_inverse")
+        assert rel_err(s.get_field("f"), np.fft.irfftn(spec, s=grid, axes=(1, 2, 3)) * float(np.prod(grid))) < 1e-13, grid
+        if axis == 0:
+            eps = {}
+            try:
+                for flag in (1, 0):
+                    t = make_gpu_solver(grid, tile_plans=flag)
+                    t.calc_ref_material()
+                    t.iterate(E, 2)
+                    eps[flag] = t.get_field("epsilon")
+                    t.close()
+            finally:
+                s.set_options(tile_plans=1)
+            assert rel_err(eps[1], eps[0]) < 1e-12, grid
+        s.close()
