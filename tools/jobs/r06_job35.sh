@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.." || exit 1
+for rep in 1 2; do for n in 240 300 360 400; do
+  echo -n "8-col "; timeout 300 python tools/ab_grid.py --grid $n,$n,$n --steps 10 2>&1 | cut -c1-300
+  echo -n "4-col "; FG_X_C4=1 timeout 300 python tools/ab_grid.py --grid $n,$n,$n --steps 10 2>&1 | cut -c1-300
+done; done
