@@ -49,6 +49,22 @@
   X(520, 4, 512, 20, 13, 10, 4) X(540, 4, 512, 20, 10, 9, 6) X(560, 4, 512, 20, 10, 8, 7)                              \
   X(600, 4, 512, 20, 10, 10, 6) X(720, 4, 512, 20, 18, 10, 4) X(800, 4, 512, 20, 20, 10, 4)
 
+// the one-component instance (heat / porous modes): the same fields
+#define FG_SMOOTH_X1_PLANS(X) \
+  X(50, 16, 256, 20, 10, 5, 1) X(60, 16, 256, 20, 10, 6, 1) X(70, 16, 256, 20, 10, 7, 1) X(90, 16, 256, 20, 10, 9, 1)  \
+  X(100, 16, 256, 20, 10, 10, 1) X(110, 16, 256, 20, 11, 10, 1) X(120, 16, 256, 20, 12, 10, 1)                         \
+  X(130, 16, 256, 20, 13, 10, 1) X(140, 16, 256, 20, 14, 10, 1) X(150, 16, 256, 20, 15, 10, 1)                         \
+  X(180, 16, 256, 20, 15, 12, 1) X(200, 16, 256, 20, 20, 10, 1) X(210, 16, 256, 20, 15, 14, 1)                         \
+  X(220, 16, 512, 20, 20, 11, 1) X(240, 16, 256, 20, 16, 15, 1) X(250, 16, 256, 32, 25, 10, 1)                         \
+  X(260, 16, 512, 20, 20, 13, 1) X(270, 16, 512, 20, 18, 15, 1) X(280, 16, 512, 20, 20, 14, 1)                         \
+  X(300, 16, 512, 20, 20, 15, 1) X(330, 8, 256, 32, 22, 15, 1) X(350, 8, 256, 32, 25, 14, 1)                           \
+  X(360, 8, 256, 20, 20, 18, 1) X(390, 8, 256, 32, 26, 15, 1) X(400, 8, 256, 20, 20, 20, 1)                            \
+  X(420, 8, 256, 32, 21, 20, 1) X(440, 8, 256, 32, 22, 20, 1) X(450, 8, 256, 32, 25, 18, 1)                            \
+  X(480, 8, 256, 32, 24, 20, 1) X(500, 8, 256, 32, 25, 20, 1) X(520, 8, 256, 32, 26, 20, 1)                            \
+  X(540, 8, 256, 32, 27, 20, 1) X(560, 8, 256, 32, 28, 20, 1) X(600, 8, 256, 32, 25, 24, 1)                            \
+  X(720, 8, 256, 32, 30, 24, 1) X(800, 8, 256, 32, 32, 25, 1) X(900, 8, 256, 32, 30, 30, 1)                            \
+  X(1000, 8, 512, 20, 10, 10, 10)
+
 namespace fg {
 namespace fft {
 

@@ -460,6 +460,9 @@ int emu_plan_table_mismatches(int* nentries) {
 #define FG_X(N, C, T, CAP, R0, R1, R2) ++n; if (!smooth_plan_xfused(N, 3, &p) || p.joint != 3 || !smooth_plan_is(p, N, 3 * C, T, CAP, R0, R1, R2)) ++bad;
   FG_SMOOTH_X_PLANS(FG_X)
 #undef FG_X
+#define FG_X(N, C, T, CAP, R0, R1, R2) ++n; if (!smooth_plan_xfused(N, 1, &p) || p.joint != 1 || !smooth_plan_is(p, N, C, T, CAP, R0, R1, R2)) ++bad;
+  FG_SMOOTH_X1_PLANS(FG_X)
+#undef FG_X
   if (nentries) *nentries = n;
   return bad;
 }

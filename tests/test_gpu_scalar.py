@@ -232,3 +232,31 @@ def test_scalar_modes_on_decimal_grids_fused_x_pass(grid):
         np.testing.assert_allclose(s.residuals, o.residuals, rtol=0, atol=1e-11)
         assert rel_err(s.get_field("epsilon"), o.eps) < 1e-10
         s.close()
+
+
+def test_scalar_fused_x_plan_kernels_equal_the_class_kernels():
+    """every length in the one-component table of fg_fft_smooth_plans.h as the x axis of a thin grid: three passes of the porous
+    loop with the plan kernels (default) and with the class kernels (tile_plans = 0) give the same gradient field"""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fibergen_amd", "csrc",
+                            "fg_fft_smooth_plans.h")).read()
+    body = src[src.index("#define FG_SMOOTH_X1_PLANS(X)"):]
+    lengths = sorted({int(m.group(1)) for m in re.finditer(r"X\((\d+),", body[:body.index("\n\n")])})
+    assert len(lengths) == 38
+    E = np.array([1.0, -0.5, 0.25])
+    try:
+        for n in lengths:
+            grid = (n, 3, 10)
+            phi1 = sphere_phi(grid, 0.3)
+            out = {}
+            for flag in (1, 0):
+                s = _solver(grid, [1.0, 12.0], [1 - phi1, phi1], tile_plans=flag)
+                s.calc_ref_material()
+                s.iterate(E, 3)
+                out[flag] = s.get_field("epsilon")
+                s.close()
+            assert rel_err(out[1], out[0]) < 1e-12, grid
+    finally:
+        s = _solver((8, 8, 8), [1.0, 12.0], [0.5 * np.ones((8, 8, 8))] * 2, tile_plans=1)
+        s.close()
