@@ -1036,7 +1036,7 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
       // 400, 500 ...: the Stockham tile kernels of fg_fft_smooth.h.  (Where a p * 2^k kernel exists it stays: measured in one job
       // with the tile kernels forced on, 96^3 9 160 against 5 510 it/s, 192^3 2 030 / 1 270, 384^3 240 / 174, 448^3 123 / 91.)
       SmoothPlan sp;
-      const bool one_kernel_mixed = (odd_[a] == 3 || odd_[a] == 5 || odd_[a] == 7 || odd_[a] == 9) && m <= 1024;   // (their tile limit)
+      const bool one_kernel_mixed = (odd_[a] == 3 || odd_[a] == 5 || odd_[a] == 7 || odd_[a] == 9) && m <= 1024 && !getenv("FG_SMOOTH_MIXED");   // (their tile limit)  EXPERIMENT
       if (m > 1 && !one_kernel_mixed && (a == 2 ? smooth_plan_z(m, &sp) : smooth_plan_strided(m, &sp))) smooth_[a] = sp;
       wgen_[a] = upload(make_unit_roots(len[a], len[a]));
       need_scratch = true;

@@ -11,6 +11,8 @@
 
 // strided (y / x) passes: X(N, columns per tile, R0, R1, R2)   (R2 = 1: two passes); 256 threads, several butterflies of a radix <= 10 per thread (<= 20 values)
 #define FG_SMOOTH_STRIDED_PLANS(X) \
+  /* p * 2^k lengths (run the tile kernels only where Fft3 prefers them to the sub-line kernels) */ \
+  X(48, 32, 8, 6, 1) X(72, 32, 9, 8, 1) X(80, 32, 10, 8, 1) X(96, 32, 12, 8, 1) X(112, 32, 14, 8, 1) X(144, 16, 12, 12, 1) X(160, 16, 16, 10, 1) X(192, 16, 16, 12, 1) X(224, 16, 16, 14, 1) X(288, 8, 8, 6, 6) X(320, 8, 8, 8, 5) X(384, 8, 8, 8, 6) X(448, 8, 8, 8, 7) X(768, 8, 32, 24, 1) X(896, 8, 32, 28, 1) \
   X(50, 32, 10, 5, 1) X(60, 32, 10, 6, 1) X(70, 32, 10, 7, 1) X(90, 32, 10, 9, 1) X(100, 32, 10, 10, 1)                \
   X(110, 16, 11, 10, 1) X(120, 32, 15, 8, 1) X(130, 16, 13, 10, 1) X(140, 16, 14, 10, 1) X(150, 16, 15, 10, 1)         \
   X(180, 16, 15, 12, 1) X(200, 16, 8, 5, 5) X(210, 16, 15, 14, 1) X(220, 8, 11, 10, 2) X(240, 16, 16, 15, 1)           \
@@ -24,6 +26,8 @@
 
 // z passes (packed real rows of nz = 2 M points): X(M, rows per tile, R0, R1, R2); 256 threads
 #define FG_SMOOTH_Z_PLANS(X) \
+  /* p * 2^k lengths (run the tile kernels only where Fft3 prefers them to the sub-line kernels) */ \
+  X(48, 64, 8, 6, 1) X(72, 32, 9, 8, 1) X(80, 32, 10, 8, 1) X(96, 32, 12, 8, 1) X(112, 32, 14, 8, 1) X(144, 16, 12, 12, 1) X(160, 16, 16, 10, 1) X(192, 16, 16, 12, 1) X(224, 16, 16, 14, 1) X(288, 8, 8, 6, 6) X(320, 8, 8, 8, 5) X(384, 8, 8, 8, 6) X(448, 8, 8, 8, 7) X(576, 4, 9, 8, 8) X(640, 4, 10, 8, 8) X(768, 4, 12, 8, 8) X(896, 4, 14, 8, 8) \
   X(25, 64, 5, 5, 1) X(30, 64, 6, 5, 1) X(35, 64, 7, 5, 1) X(45, 64, 9, 5, 1) X(50, 64, 10, 5, 1) X(60, 64, 10, 6, 1)  \
   X(65, 32, 13, 5, 1) X(70, 32, 10, 7, 1) X(75, 32, 15, 5, 1) X(90, 32, 10, 9, 1) X(100, 32, 10, 10, 1)                \
   X(105, 32, 15, 7, 1) X(110, 32, 22, 5, 1) X(120, 32, 15, 8, 1) X(125, 32, 5, 5, 5) X(130, 16, 13, 10, 1)             \
@@ -37,6 +41,8 @@
 
 // fused x pass on the joint image of three components: X(N, columns per tile, threads, values per thread, R0, R1, R2)
 #define FG_SMOOTH_X_PLANS(X) \
+  /* p * 2^k lengths (run the tile kernels only where Fft3 prefers them to the sub-line kernels) */ \
+  X(48, 16, 256, 20, 8, 6, 1) X(72, 16, 256, 20, 9, 8, 1) X(80, 16, 256, 20, 10, 8, 1) X(96, 16, 512, 20, 12, 8, 1) X(112, 8, 256, 20, 14, 8, 1) X(144, 8, 256, 20, 16, 9, 1) X(160, 8, 256, 20, 16, 10, 1) X(192, 8, 512, 20, 16, 12, 1) X(224, 8, 512, 20, 16, 14, 1) X(288, 8, 512, 20, 18, 16, 1) X(320, 8, 512, 20, 20, 16, 1) X(448, 4, 512, 20, 8, 8, 7) X(576, 4, 512, 20, 9, 8, 8) X(640, 4, 512, 20, 10, 8, 8) \
   X(50, 16, 256, 20, 10, 5, 1) X(60, 16, 256, 20, 10, 6, 1) X(70, 16, 256, 20, 10, 7, 1) X(90, 16, 256, 20, 10, 9, 1)  \
   X(100, 16, 256, 20, 10, 10, 1) X(110, 8, 256, 20, 11, 10, 1) X(120, 8, 256, 20, 12, 10, 1)                           \
   X(130, 8, 256, 20, 13, 10, 1) X(140, 8, 256, 20, 14, 10, 1) X(150, 8, 256, 20, 15, 10, 1)                            \
