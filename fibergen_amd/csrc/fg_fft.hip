@@ -1036,7 +1036,10 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
       // 400, 500 ...: the Stockham tile kernels of fg_fft_smooth.h.  (Where a p * 2^k kernel exists it stays: measured in one job
       // with the tile kernels forced on, 96^3 9 160 against 5 510 it/s, 192^3 2 030 / 1 270, 384^3 240 / 174, 448^3 123 / 91.)
       SmoothPlan sp;
-      const bool one_kernel_mixed = (odd_[a] == 3 || odd_[a] == 5 || odd_[a] == 7 || odd_[a] == 9) && m <= 1024 && !getenv("FG_SMOOTH_MIXED");   // (their tile limit)  EXPERIMENT
+      // ... and, since the tile kernels are built per plan (fg_fft_smooth_plans.h), from 100 points on (z: nz / 2 >= 72): sub-line
+      // kernels / tile kernels in one job 144^3 3 034 / 4 452 it/s, 160^3 3 119 / 3 647, 192^3 2 050 / 2 190, 224^3 965 / 1 237,
+      // 288^3 432 / 657, 320^3 409 / 481, 448^3 121 / 148; 96^3 9 281 / 9 295 (kept on the sub-line kernels)
+      const bool one_kernel_mixed = (odd_[a] == 3 || odd_[a] == 5 || odd_[a] == 7 || odd_[a] == 9) && m <= 1024 && m < (a == 2 ? 72 : 100);
       if (m > 1 && !one_kernel_mixed && (a == 2 ? smooth_plan_z(m, &sp) : smooth_plan_strided(m, &sp))) smooth_[a] = sp;
       wgen_[a] = upload(make_unit_roots(len[a], len[a]));
       need_scratch = true;
@@ -1045,6 +1048,15 @@ Fft3::Fft3(const Grid& g, hipStream_t stream) : g_(g), stream_(stream), wz_(null
   if (smooth_[0].n) {   // plans of the tile kernels' fused x pass (one / three components)
     smooth_plan_xfused(g.nx, 1, &xfused_plan_[0]);
     smooth_plan_xfused(g.nx, 3, &xfused_plan_[1]);
+    // an x length whose three components have no joint image plan (384 = 3 * 2^7: 9 216 points of a tile against 512 threads x 20
+    // values) keeps the sub-line kernels' fused x pass where there is one: 384^3 fused x 1 114 us against 1 732 us in the
+    // R <= 32 class kernel, y and z on the tile kernels either way (238 -> 263 it/s)
+    if (xfused_plan_[1].joint != 3 && (odd_[0] == 3 || odd_[0] == 5)) {
+      XFusedArgs probe = {};
+      const bool mixed_fused = odd_[0] == 3 ? xfused_mixed_p<3>(g.nx / 3, probe, 0, nullptr, stream_, true)
+                                            : xfused_mixed_p<5>(g.nx / 5, probe, 0, nullptr, stream_, true);
+      if (mixed_fused) smooth_[0] = xfused_plan_[0] = xfused_plan_[1] = SmoothPlan();
+    }
   }
   if (fast_[2]) wz_ = upload(make_unit_roots(g.nz, g.nz / 2 + 1));
   if (need_scratch) FG_HIP_CHECK(hipMalloc(&scratch_, g.n * sizeof(double)));

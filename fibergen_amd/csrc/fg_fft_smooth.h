@@ -323,7 +323,9 @@ inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p, bool joint = tru
       const int jt[4] = {256, 256, 512, 256}, jr[4] = {16, 20, 20, kSmoothMaxRadix}, jc[4] = {20, 20, 20, 32};
       for (int k = 0; k < 4; ++k)
         if (smooth_try(n, ncomp * cols, jt[k], jr[k], &cand, jc[k]) && (!j.n || cand.npass < j.npass)) j = cand;
-      if (j.n && (!best.n || j.npass <= best.npass)) {
+      // (one pass more than the per-component plan where that one needs radices > 20: its kernels are built for R <= 32 and take
+      // 512 VGPRs; 384 = 16 x 12 x 2 on the joint image against 24 x 16 per component)
+      if (j.n && (!best.n || j.npass <= best.npass || (best.rmax() > 20 && j.rmax() <= 20 && j.npass <= best.npass + 1))) {
         j.joint = ncomp;
         best = j;
       }

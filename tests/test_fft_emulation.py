@@ -374,4 +374,4 @@ def test_plan_kernel_tables_match_the_planner(emu):
     planner makes for that length -- an entry that is not would silently fall back to the class kernels"""
     n = ctypes.c_int(0)
     assert emu.emu_plan_table_mismatches(ctypes.byref(n)) == 0
-    assert n.value == 211
+    assert n.value == 76 + 80 + 52 + 80

@@ -106,6 +106,8 @@ def test_div_and_eps_stages(grid, dims):
                                        ((100, 200, 300), (1.0, 1.0, 1.0)), ((500, 12, 400), (1.0, 1.0, 1.0)),
                                        ((12, 1000, 20), (1.0, 1.0, 1.0)), ((1001, 10, 1000), (1.0, 1.0, 1.0)),
                                        ((120, 240, 60), (1.0, 1.0, 1.0)), ((6, 10, 2002), (1.0, 1.0, 1.0)),
+                                       # p * 2^k lengths >= 100 on the tile kernels (x = 384: sub-line kernels for x, tile kernels for y / z)
+                                       ((384, 144, 160), (1.0, 1.0, 1.0)), ((192, 384, 224), (1.0, 1.0, 1.0)), ((320, 112, 768), (1.0, 1.0, 1.0)),
                                        # odd nz: the rows as nz complex points through the same passes
                                        ((75, 45, 125), (1.0, 1.0, 1.0)), ((12, 10, 225), (1.0, 1.0, 1.0)), ((9, 6, 1001), (1.0, 1.0, 1.0))])
 def test_fft_forward_inverse(grid, dims):

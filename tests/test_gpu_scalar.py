@@ -243,7 +243,7 @@ def test_scalar_fused_x_plan_kernels_equal_the_class_kernels():
                             "fg_fft_smooth_plans.h")).read()
     body = src[src.index("#define FG_SMOOTH_X1_PLANS(X)"):]
     lengths = sorted({int(m.group(1)) for m in re.finditer(r"X\((\d+),", body[:body.index("\n\n")])})
-    assert len(lengths) == 38
+    assert len(lengths) >= 38
     E = np.array([1.0, -0.5, 0.25])
     try:
         for n in lengths:
