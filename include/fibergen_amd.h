@@ -99,7 +99,13 @@ int fg_set_normals(fg_solver* s, const double* normals /* [3][nx][ny][nz] */);
  * connected to a transport sends its all-to-all blocks and halo planes to itself through that transport),
  * x_layout (-1 = default: on grids whose three components exceed 1 GB the spectrum between the y passes and the fused x pass
  * is stored x-contiguous, [zc/8][y][x][8]; 0 / 1 force it off / on), plane_fft (-1 = default: where the complex z-y plane
- * fits the LDS -- ny * nz <= 128^2, 256 x 64 -- the z and y transforms of a plane run as ONE kernel; 0 = separate passes). */
+ * fits the LDS -- ny * nz <= 128^2, 256 x 64 -- the z and y transforms of a plane run as ONE kernel; 0 = separate passes),
+ * error_estimator (0 epsilon = default, 1 residual, 2 sigma, 3 energy, 4 none: create_error_estimator F:14940-14972),
+ * pair_chunk (0 = default; P: the z and y transform passes in runs of P x planes), staged_copy (-1 = default: field downloads of
+ * 8 MB and more through the pinned-buffer pipeline; 1 both directions, 0 one strided copy), stage_chunk_kb (pipeline stage),
+ * joint_x (tile kernels of the lengths that are not powers of two: 1 = default, fused x pass on one joint LDS image of the three
+ * components; 0 = one image per component), tile_plans (1 = default: tile kernels built for one plan each where the plan is in
+ * the tables of fg_fft_smooth_plans.h; 0 = the class kernels for every plan; a process-wide switch). */
 int fg_set_option_d(fg_solver* s, const char* key, double value);
 int fg_set_option_i(fg_solver* s, const char* key, long value);
 
