@@ -46,8 +46,8 @@ EXACT = [  # strain-state pipeline: laminate mixing, small / odd / mixed-radix g
     (2, (24, 48, 48), "voigt"),      # p * 2^k lengths
     (2, (20, 30, 36), "voigt"),      # 4*5, 2*3*5, nz/2 = 2*3*3: the Stockham tile kernels (fg_fft_smooth.h) on the slabs
     (2, (20, 20, 200), "laminate"),  # decimal sizes with rows long enough for the tiled sweep
-    (2, (192, 112, 144), "voigt"),   # p * 2^k lengths >= 100: the per-plan tile kernels on the slabs (x and y passes, z with nz / 2 = 72)
-    (4, (384, 24, 160), "laminate"), # x = 384 keeps the sub-line kernels' x pass, z on the tile kernels
+    (2, (192, 10, 144), "voigt"),    # p * 2^k lengths >= 100: the per-plan tile kernels on the slabs (x pass, z with nz / 2 = 72)
+    (4, (384, 8, 160), "laminate"),  # x = 384 keeps the sub-line kernels' x pass, z on the tile kernels
 ]
 
 
