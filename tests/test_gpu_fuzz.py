@@ -41,9 +41,22 @@ def smooth_field(rng, shape):
     return np.clip(1.6 * f - 0.3, 0.0, 1.0)
 
 
-def draw(seed):
-    rng = np.random.default_rng(1000 + seed)
+# lengths the Stockham tile kernels take (fg_fft_smooth.h; most of them in the per-plan tables of fg_fft_smooth_plans.h, 108 / 130 /
+# 162 / 250 with the class kernels or odd rows), drawn as ONE long axis of a thin grid
+TILE_LENGTHS = [100, 108, 112, 120, 144, 150, 160, 192, 200, 224, 240, 250, 300, 320, 384, 400]
+TILE_LENGTHS_Z = [100, 130, 144, 162, 200, 225, 250, 288, 320, 400]
+N_TILE = int(os.environ.get("FG_FUZZ_SEEDS", "36"))
+
+
+def draw(seed, tile_lengths=False):
+    rng = np.random.default_rng((9000 if tile_lengths else 1000) + seed)
     while True:
+        if tile_lengths:
+            axis = int(rng.integers(0, 3))
+            shape = [int(rng.choice([2, 4, 5, 6, 8])), int(rng.choice([2, 4, 5, 6, 8])), int(rng.choice([4, 6, 8, 10]))]
+            shape[axis] = int(rng.choice(TILE_LENGTHS_Z if axis == 2 else TILE_LENGTHS))
+            shape = tuple(shape)
+            break
         shape = (int(rng.choice(LENGTHS_XY)), int(rng.choice(LENGTHS_XY)), int(rng.choice(LENGTHS_Z)))
         if 8 <= shape[0] * shape[1] * shape[2] <= 40000:
             break
@@ -86,11 +99,22 @@ def draw(seed):
                 opts=opts, bc=bc, steps=steps, E=E)
 
 
+@pytest.mark.parametrize("seed", range(N_TILE))
+def test_random_combination_on_tile_kernel_lengths_matches_oracle(seed):
+    """the same draw with one axis of a length the Stockham tile kernels transform (decimal and p * 2^k lengths from 100 points
+    on, per-plan and class kernels, fused x pass, odd rows)"""
+    _run_combination(seed, True)
+
+
 @pytest.mark.parametrize("seed", range(N_SINGLE))
 def test_random_combination_matches_oracle(seed):
+    _run_combination(seed, False)
+
+
+def _run_combination(seed, tile_lengths):
     from fibergen_amd import LSSolver
     from oracle.ls_oracle import LSOracle
-    c = draw(seed)
+    c = draw(seed, tile_lengths)
     shape, dims = c["shape"], c["dims"]
     common = dict(tol=1e-7, maxiter=400)
     o = LSOracle(*shape, *dims, mats=c["mats"], phis=c["phis"], normals=c["normals"], mixing_rule=c["mixing"],
