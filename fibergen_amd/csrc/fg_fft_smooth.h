@@ -321,8 +321,10 @@ inline bool smooth_plan_xfused(int n, int ncomp, SmoothPlan* p, bool joint = tru
       // kernels built for (256 threads, radices <= 16), (256, <= 20), (512, <= 20) with 20 values per thread, (256, <= 32) with 32:
       // fewest passes, then the first of this list (registers follow the largest radix a kernel is built for)
       const int jt[4] = {256, 256, 512, 256}, jr[4] = {16, 20, 20, kSmoothMaxRadix}, jc[4] = {20, 20, 20, 32};
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < 4; ++k) {
+        if (k == 3 && j.n && ncomp == 3) break;   // three components: the R <= 32 form (one 256-thread workgroup at 512 VGPRs in its class kernel) only where no other fits
         if (smooth_try(n, ncomp * cols, jt[k], jr[k], &cand, jc[k]) && (!j.n || cand.npass < j.npass)) j = cand;
+      }
       // (one pass more than the per-component plan where that one needs radices > 20: its kernels are built for R <= 32 and take
       // 512 VGPRs; 384 = 16 x 12 x 2 on the joint image against 24 x 16 per component)
       if (j.n && (!best.n || j.npass <= best.npass || (best.rmax() > 20 && j.rmax() <= 20 && j.npass <= best.npass + 1))) {
