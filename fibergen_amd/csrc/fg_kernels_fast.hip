@@ -922,9 +922,13 @@ void launch_u_fast(const Grid& g, double mu_0, double lambda_0, const FieldPtrs<
   FG_HIP_CHECK(hipGetLastError());
 }
 
+// rows of at least 40 pairs: a row shorter than the 62 pairs of a tile is ONE tile whose surplus lanes hold wrapped-around
+// copies (kp0 < 0) -- old / new library in one job: sweep at 80^3 20.9 -> 17.5 us, 96^3 29.1 -> 19.5, 100^3 32.0 -> 22.0,
+// 112^3 41.3 -> 24.2, 120^3 47.0 -> 27.0 (100^3 8 630 -> 9 360 it/s, 120^3 5 990 -> 6 750); at 64^3 (32 pairs) the chunked
+// sweep stays ahead (15.4 against 16.4 us)
 bool u_tile_supported(const Grid& g) {
   const int nzh = g.nz / 2;
-  return g.nz % 2 == 0 && nzh >= 62 && g.ny >= 14 && g.nx >= 4;
+  return g.nz % 2 == 0 && nzh >= 40 && g.ny >= 14 && g.nx >= 4;
 }
 
 // Planes per march of the tiled sweep.  A march of LX planes costs LX + 3 steps (pipeline fill), the workgroups are dealt

@@ -18,6 +18,8 @@ E_LOAD = [1.0, 0, 0, 0, 0, 0.5]
     ((6, 20, 256), "voigt", "residual"),      # a z row is two waves; gamma read back from the device
     ((5, 18, 124), "voigt", "epsilon"),       # tiles with halo lanes, ny not a multiple of the tile height, odd nx
     ((12, 16, 128), "laminate", "residual"),
+    ((9, 16, 100), "voigt", "epsilon"),       # rows shorter than a tile (nz / 2 = 50)
+    ((6, 14, 84), "laminate", "residual"),
 ])
 def test_fused_cg_matches_oracle_and_unfused(grid, mixing, estimator):
     o = make_oracle(grid, (1.0, 2.0, 1.5), mixing, tol=1e-8, error_estimator=estimator)
@@ -56,7 +58,7 @@ def test_fused_cg_with_callback_and_maxiter():
 
 
 @pytest.mark.parametrize("grid,dims,estimator", [((8, 14, 128), (1, 1, 1), "epsilon"), ((6, 16, 256), (2.0, 1.0, 0.5), "epsilon"),
-                                                 ((10, 18, 124), (1, 1, 1), "residual")])
+                                                 ((10, 18, 124), (1, 1, 1), "residual"), ((9, 16, 100), (1, 1, 1), "epsilon")])
 def test_fused_scalar_cg_matches_oracle_and_unfused(grid, dims, estimator):
     """The same in the scalar modes (CG in potential space): no callback, so the fused form runs."""
     from fibergen_amd import LSSolver

@@ -511,7 +511,7 @@ def test_displacement_based_loop_with_laminate_mixing_is_bit_identical(grid):
     assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9
 
 
-@pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (32, 16, 64), (16, 16, 128), (6, 20, 130), (8, 14, 256)])
+@pytest.mark.parametrize("grid", [(16, 16, 16), (12, 10, 6), (32, 16, 64), (16, 16, 128), (6, 20, 130), (8, 14, 256), (10, 16, 100), (7, 14, 80)])
 def test_laminate_mixing_as_correction_of_the_voigt_sweep(grid):
     """u_loop=2 with laminate mixing: f = div tau_voigt (the tiled / fast sweep over all voxels) + div (tau_laminate -
     tau_voigt) gathered at the voxels next to an interface.  Same iterates as the strain-state pipeline up to rounding,
@@ -535,10 +535,12 @@ def test_laminate_mixing_as_correction_of_the_voigt_sweep(grid):
     assert o.iterations == b[0] and rel_err(b[2], o.eps) < 1e-9 and rel_err(b[3], o.get_field("sigma")) < 1e-9
 
 
-@pytest.mark.parametrize("grid", [(16, 16, 128), (8, 16, 124), (32, 32, 256), (5, 14, 128), (6, 20, 130), (40, 30, 128)])
+@pytest.mark.parametrize("grid", [(16, 16, 128), (8, 16, 124), (32, 32, 256), (5, 14, 128), (6, 20, 130), (40, 30, 128),
+                                  # rows shorter than a tile (nz / 2 = 40 ... 61: one tile per row, its surplus lanes wrap around)
+                                  (16, 16, 100), (9, 14, 80), (12, 20, 96), (7, 15, 122), (20, 14, 82)])
 def test_tiled_displacement_sweep(grid):
     """u_tile: the LDS-tiled marching variant of the fast sweep (each strain / polarisation value computed once;
-    halo rows and lanes, overlapping last tiles, periodic wrap in all directions) gives the same iterates."""
+    halo rows and lanes, overlapping last tiles, periodic wrap in all directions; from nz / 2 = 40 on) gives the same iterates."""
     E = np.array([0.2, -0.1, 1.0, 0.3, 0, 0.5])
     res = {}
     for flag in (0, 1):
@@ -556,7 +558,7 @@ def test_tiled_displacement_sweep(grid):
 @pytest.mark.parametrize("grid", [(16, 16, 16), (8, 14, 128)])
 def test_three_phase_voigt_all_loop_variants(grid):
     """Three phases (nested spheres: core, coating, matrix) with Voigt mixing: strain-state pipeline, exact
-    displacement loop and the fast (effective moduli; tiled where nz/2 >= 62) loop against the oracle."""
+    displacement loop and the fast (effective moduli; tiled where nz/2 >= 40) loop against the oracle."""
     from fibergen_amd import LSSolver
     from helpers import sphere_phi
     from oracle.ls_oracle import LSOracle

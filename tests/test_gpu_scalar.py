@@ -59,9 +59,10 @@ def test_scalar_run_matches_oracle(grid, dims, u_loop):
 
 
 @pytest.mark.parametrize("grid,dims", [((16, 16, 128), (1, 1, 1)), ((8, 14, 124), (1.0, 2.0, 0.5)), ((6, 20, 130), (1, 1, 1)),
-                                       ((40, 30, 128), (1, 1, 1)), ((12, 16, 256), (1, 1, 1)), ((5, 14, 256), (2, 1, 1))])
+                                       ((40, 30, 128), (1, 1, 1)), ((12, 16, 256), (1, 1, 1)), ((5, 14, 256), (2, 1, 1)),
+                                       ((16, 16, 100), (1, 1, 1)), ((9, 14, 80), (1.0, 2.0, 0.5)), ((7, 20, 122), (1, 1, 1))])
 def test_tiled_scalar_sweep(grid, dims):
-    """u_loop = 2 on grids the LDS-tiled marching sweep k_sc_tile takes (nz/2 >= 62: halo lanes; nz/2 = 64 / 128: whole
+    """u_loop = 2 on grids the LDS-tiled marching sweep k_sc_tile takes (nz/2 >= 40: halo lanes; nz/2 = 64 / 128: whole
     rows of one / two waves; overlapping last tiles, periodic wrap in all directions): same iterates as the exact-order
     sweep (u_loop = 1) and as the oracle."""
     phi1 = sphere_phi(grid, 0.3)

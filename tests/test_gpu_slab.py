@@ -23,7 +23,7 @@ def make_group(P, grid, dims=(1.0, 1.0, 1.0), mixing="voigt", **kw):
     return g
 
 
-FAST = [   # grids the tiled displacement sweep fits (nz/2 >= 62, ny >= 14, local nx >= 4): the displacement loop
+FAST = [   # grids the tiled displacement sweep fits (nz/2 >= 40, ny >= 14, local nx >= 4): the displacement loop
     (1, (8, 16, 128), "voigt"),
     (2, (8, 16, 128), "voigt"),
     (4, (16, 16, 128), "voigt"),
