@@ -551,9 +551,9 @@ def main():
                     help="cg: `value` is the rate of runCGElasticity iterations (F:23153-23247, the reference's default method; one "
                          "operator application + two inner-product sweeps + two vector updates each) through fg_run_load_case "
                          "with maxiter = steps; the kernel table stays the basic scheme's (the operator is the same kernels)")
-    ap.add_argument("--also", default="128:voigt,512:laminate,200:voigt,256:voigt:porous,256:voigt:viscosity",
+    ap.add_argument("--also", default="128:voigt,512:laminate,200:voigt,400:voigt,256:voigt:porous,256:voigt:viscosity",
                     help="N = 1: further single-GPU workloads n:mixing[:mode] reported under `also` ('' = none): the other "
-                         "BASELINE sizes, a decimal size (200^3: the transform passes of fg_fft_smooth.h) and config 5 "
+                         "BASELINE sizes, two decimal sizes (200^3, 400^3: the transform passes of fg_fft_smooth.h) and config 5 "
                          "(porous / Stokes)")
     ap.add_argument("--u-tile", type=int, default=None, help="override the solver's u_tile option (0 = untiled sweep, 1 = tiled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
