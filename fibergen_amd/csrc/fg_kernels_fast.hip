@@ -957,9 +957,8 @@ void launch_u_tile_t(const Grid& g, double mu_0, double lambda_0, const FieldPtr
   constexpr int TYU = TYR - 2, TZU = ZS ? 64 * ZS : 62;
   const int nzh = g.nz / 2;
   const int nty = (g.ny + TYU - 1) / TYU, ntz = (nzh + TZU - 1) / TZU;
-  static const int lx_env = getenv("FG_TILE_LX") ? atoi(getenv("FG_TILE_LX")) : 0;  // tuning knob (0 = by size)
   const int cus = device_cu_count();
-  int LX = lx_env > 0 ? lx_env : march_length(g.nx, (long)nty * ntz, cus);
+  int LX = march_length(g.nx, (long)nty * ntz, cus);   // (a sweep of fixed lengths 3 ... 10 at 100^3 - 150^3: none beats it)
   if (LX > g.nx) LX = g.nx;
   const int ntx = (g.nx + LX - 1) / LX;
   int nb = nty * ntz * ntx;
