@@ -52,6 +52,8 @@ def test_no_torch_types_and_no_oracle_in_product():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "ls_oracle" not in src, f
+                if f.endswith((".h", ".hip", ".cpp")):
+                    assert "getenv(" not in src, f + ": the library takes its switches through fg_set_option_*, not the environment"
 
 
 def test_fails_loudly_without_gpu(built):
