@@ -492,18 +492,41 @@ template <int C, int NC>
 FG_HD void smooth_joint_green(const SmoothXArgs& a, int block, int tid, int nthreads, cplx* img) {
   constexpr int W = NC * C;
   const int n = a.base.plan.n, col0 = block * C;
+  // a thread's column is the same in every turn of its loop when the stride is a multiple of the tile width: the y and z
+  // factors of that column (four of the six table reads of a point, and the division that splits the column index) once
+  const bool fixed_col = nthreads % C == 0;
+  int jj = 0, kk = 0;
+  bool live = false;
+  double kpm1 = 0.0, kpm2 = 0.0;
+  cplx kp1 = cmake(0.0, 0.0), kp2 = kp1;
+  auto column = [&](int t) {
+    const int col = col0 + t;
+    live = col < a.base.ncols;
+    if (!live) return;
+    const int jl = smooth_div(col, 1.0 / (double)a.nzc);
+    kk = col - jl * a.nzc, jj = a.jj0 + jl;
+    live = kk < a.nzf;   // (row padding)
+    if (!live) return;
+    kpm1 = a.kpm[1][jj], kpm2 = a.kpm[2][kk];
+    if (NC == 3) kp1 = a.kp[1][jj], kp2 = a.kp[2][kk];
+  };
+  if (fixed_col) {
+    column(tid % C);
+    if (!live) return;
+  }
   for (int idx = tid; idx < n * C; idx += nthreads) {
-    const int kx = idx / C, t = idx % C, col = col0 + t;
-    if (col >= a.base.ncols) continue;
-    const int jl = smooth_div(col, 1.0 / (double)a.nzc), kk = col - jl * a.nzc, jj = a.jj0 + jl;
-    if (kk >= a.nzf) continue;   // row padding
+    const int kx = idx / C, t = idx % C;
+    if (!fixed_col) {
+      column(t);
+      if (!live) continue;
+    }
     const bool zero = kx == 0 && jj == 0 && kk == 0;   // zero frequency  F:19924-19926
     cplx* q = img + kx * W + t;
-    const double kpm0 = a.kpm[0][kx], kpm1 = a.kpm[1][jj], kpm2 = a.kpm[2][kk];
+    const double kpm0 = a.kpm[0][kx];
     if (NC == 3) {
       const cplx t0 = cscale(a.base.scale, q[0]), t1 = cscale(a.base.scale, q[C]), t2 = cscale(a.base.scale, q[2 * C]);
       cplx e0 = cmake(0.0, 0.0), e1 = e0, e2 = e0;
-      if (!zero) g0_point_rcp(t0, t1, t2, kpm0, kpm1, kpm2, a.kp[0][kx], a.kp[1][jj], a.kp[2][kk], a.c10, a.c20, &e0, &e1, &e2);
+      if (!zero) g0_point_rcp(t0, t1, t2, kpm0, kpm1, kpm2, a.kp[0][kx], kp1, kp2, a.c10, a.c20, &e0, &e1, &e2);
       q[0] = e0;
       q[C] = e1;
       q[2 * C] = e2;

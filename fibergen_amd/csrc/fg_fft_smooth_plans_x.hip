@@ -13,8 +13,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_smooth_xjoint_plan(SmoothXArgs a
   extern __shared__ __align__(16) double lds[];
   cplx* img = reinterpret_cast<cplx*>(lds);
   constexpr int W = NC * C;
+  // all loads of the tile in ONE batch where a thread has up to 24 of them (18.75 at 200 and 400 points: a second turn of the
+  // batch loop with three loads exposed the memory latency once more)
+  constexpr int PER = (N * W + THREADS - 1) / THREADS, B = PER > 16 && PER <= 24 ? PER : 16;
   a.base.plan.n = N;
-  smooth_joint_load<C, NC, 16>(a, blockIdx.x, threadIdx.x, THREADS, img);
+  smooth_joint_load<C, NC, B>(a, blockIdx.x, threadIdx.x, THREADS, img);
   __syncthreads();
   const SmoothMap L = {W, 1, W, false};
   smooth_dev_pass<R0, -1, CAP, false>(img, N, 1, L, a.base.w, 1);
